@@ -1,0 +1,14 @@
+"""fluidaudio_amd — MI355X-native replacement for FluidAudio's host-side hot path
+(STFT->mel featurizer, argmax + CTC greedy collapse, centroid-linkage AHC, VBx) behind the
+reference's own interfaces.  All arithmetic runs in csrc/libfluidaudio_hip.so (hand-written HIP
+for gfx950) through the C ABI of include/fluidaudio_hip.h; there is no CPU fallback.
+"""
+from ._lib import (AHC_MODE_AUTO, AHC_MODE_EXACT, Context, FluidAudioHipError, build, default_context, lib)  # noqa: F401
+from .ahc import AHCClustering, cut, fastcluster_compute_centroid_linkage, linkage  # noqa: F401
+from .ctc import (LogitsArgmax, ctc_greedy_decode, ctc_greedy_ids_batch, ctc_greedy_ids_dev,  # noqa: F401
+                  decode_ctc_token_ids)
+from .mel import AudioMelSpectrogram, MelPlan  # noqa: F401
+from .sharding import gather_ragged_int32, shard_offsets, shard_range  # noqa: F401
+from .vbx import VBxClustering, VBxOutput  # noqa: F401
+
+__version__ = "0.1.0"

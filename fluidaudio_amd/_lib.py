@@ -1,0 +1,171 @@
+"""ctypes binding of libfluidaudio_hip.so (the C ABI declared in include/fluidaudio_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, the product
+path raises.  (The oracle under oracle/ is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libfluidaudio_hip.so")
+
+SUCCESS, INVALID_ARGUMENT, INDEX_OVERFLOW, OUTPUT_TOO_SMALL, ALLOCATION_FAILURE, RUNTIME_ERROR, UNKNOWN_ERROR = 0, 1, 2, 3, 4, 5, 255
+STATUS_NAMES = {0: "SUCCESS", 1: "INVALID_ARGUMENT", 2: "INDEX_OVERFLOW", 3: "OUTPUT_TOO_SMALL",
+                4: "ALLOCATION_FAILURE", 5: "RUNTIME_ERROR", 255: "UNKNOWN_ERROR"}
+
+MEL_FLOOR_ADDITIVE, MEL_FLOOR_CLAMPED = 0, 1
+MEL_PAD_CENTER, MEL_PAD_PREPADDED, MEL_PAD_LEGACY = 0, 1, 2
+MEL_LAYOUT_MEL_MAJOR, MEL_LAYOUT_FRAME_MAJOR = 0, 1
+DTYPE_F32, DTYPE_F16 = 0, 1
+AHC_MODE_AUTO, AHC_MODE_EXACT = 0, 1
+
+# Every symbol include/fluidaudio_hip.h + include/FastClusterWrapper.h declare (checked by tests/test_abi.py).
+EXPORTED_SYMBOLS = [
+    "fa_version", "fa_ctx_create", "fa_ctx_destroy", "fa_ctx_synchronize", "fa_ctx_stream", "fa_ctx_last_error",
+    "fa_mel_default_config", "fa_mel_num_frames", "fa_mel_padded_frames", "fa_mel_plan_create", "fa_mel_plan_destroy",
+    "fa_mel_plan_utt_stride", "fa_mel_plan_frame_stride", "fa_mel_plan_total_frames", "fa_mel_execute_dev",
+    "fa_mel_batch", "fa_mel_hann_window", "fa_mel_filterbank",
+    "fa_ctc_greedy_batch_dev", "fa_ctc_greedy_batch",
+    "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_cluster", "fa_ahc_cut",
+    "fa_vbx_speaker_count", "fa_vbx_refine",
+]
+
+
+class FluidAudioHipError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: {STATUS_NAMES.get(status, status)}" + (f" ({detail})" if detail else ""))
+
+
+class MelConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("n_mels", C.c_int32), ("n_fft", C.c_int32), ("hop", C.c_int32),
+                ("win", C.c_int32), ("preemph", C.c_float), ("pad_to", C.c_int32), ("log_floor", C.c_float),
+                ("floor_mode", C.c_int32), ("window_periodic", C.c_int32), ("padding_mode", C.c_int32),
+                ("layout", C.c_int32)]
+
+
+class AhcStats(C.Structure):
+    _fields_ = [("merges", C.c_int64), ("rounds", C.c_int64), ("rescans", C.c_int64), ("exact_fallback", C.c_int64),
+                ("init_ms", C.c_double), ("merge_ms", C.c_double), ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into csrc/libfluidaudio_hip.so (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", CSRC, "-j8", "all"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libfluidaudio_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the product path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
+    L.fa_version.restype = C.c_char_p
+    L.fa_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.fa_ctx_destroy.argtypes = [vp]
+    L.fa_ctx_destroy.restype = None
+    L.fa_ctx_synchronize.argtypes = [vp]
+    L.fa_ctx_stream.argtypes = [vp]
+    L.fa_ctx_stream.restype = vp
+    L.fa_ctx_last_error.argtypes = [vp]
+    L.fa_ctx_last_error.restype = C.c_char_p
+    L.fa_mel_default_config.argtypes = [C.POINTER(MelConfig)]
+    L.fa_mel_default_config.restype = None
+    L.fa_mel_num_frames.argtypes = [C.POINTER(MelConfig), i64]
+    L.fa_mel_num_frames.restype = i32
+    L.fa_mel_padded_frames.argtypes = [C.POINTER(MelConfig), i32]
+    L.fa_mel_padded_frames.restype = i32
+    L.fa_mel_plan_create.argtypes = [vp, C.POINTER(MelConfig), vp, i32, vp, i32, C.POINTER(vp)]
+    L.fa_mel_plan_destroy.argtypes = [vp]
+    L.fa_mel_plan_destroy.restype = None
+    L.fa_mel_plan_utt_stride.argtypes = [vp]
+    L.fa_mel_plan_utt_stride.restype = i64
+    L.fa_mel_plan_frame_stride.argtypes = [vp]
+    L.fa_mel_plan_frame_stride.restype = i32
+    L.fa_mel_plan_total_frames.argtypes = [vp]
+    L.fa_mel_plan_total_frames.restype = i64
+    L.fa_mel_execute_dev.argtypes = [vp, vp, vp, vp, vp]
+    L.fa_mel_batch.argtypes = [vp, C.POINTER(MelConfig), vp, vp, i32, vp, vp, i32, vp, vp]
+    L.fa_mel_hann_window.argtypes = [C.POINTER(MelConfig), vp]
+    L.fa_mel_filterbank.argtypes = [C.POINTER(MelConfig), vp]
+    L.fa_ctc_greedy_batch_dev.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, vp, i32, vp, vp, vp]
+    L.fa_ctc_greedy_batch.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, vp, i32, vp, vp, vp]
+    L.fastcluster_compute_centroid_linkage.argtypes = [vp, sz, sz, vp, sz]
+    L.fastcluster_compute_centroid_linkage.restype = C.c_int
+    L.fa_ahc_linkage.argtypes = [vp, vp, sz, sz, vp, sz, i32, i32, C.POINTER(AhcStats)]
+    L.fa_ahc_cluster.argtypes = [vp, vp, sz, sz, f64, i32, vp, C.POINTER(AhcStats)]
+    L.fa_ahc_cut.argtypes = [vp, sz, f64, vp]
+    L.fa_vbx_speaker_count.argtypes = [vp, i64]
+    L.fa_vbx_speaker_count.restype = i32
+    L.fa_vbx_refine.argtypes = [vp, vp, i64, i32, vp, vp, f64, f64, i32, f64, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
+    _lib = L
+    return L
+
+
+class Context:
+    """fa_ctx: one device + one stream + cached workspaces (one per host thread)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p()
+        st = lib().fa_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h))
+        if st != SUCCESS:
+            raise FluidAudioHipError(st, "fa_ctx_create", "no usable MI355X visible" if st == RUNTIME_ERROR else "")
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self) -> int:
+        return lib().fa_ctx_stream(self._h) or 0
+
+    def synchronize(self):
+        self.check(lib().fa_ctx_synchronize(self._h), "fa_ctx_synchronize")
+
+    def last_error(self) -> str:
+        return (lib().fa_ctx_last_error(self._h) or b"").decode()
+
+    def check(self, status: int, where: str):
+        if status != SUCCESS:
+            raise FluidAudioHipError(status, where, self.last_error())
+
+    def close(self):
+        if self._h:
+            lib().fa_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("FLUIDAUDIO_HIP_USE_LOCAL_RANK") else 0
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

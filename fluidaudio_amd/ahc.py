@@ -1,0 +1,74 @@
+"""Host-side mirror of ``AHCClustering`` (reference:
+Sources/FluidAudio/Diarizer/Offline/Clustering/AHCClustering.swift:12-211) and of the
+``fastcluster_compute_centroid_linkage`` FFI it calls
+(Sources/FastClusterWrapper/include/FastClusterWrapper.h:35-41), over the HIP C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def linkage(data, mode: int = L.AHC_MODE_AUTO, ctx: L.Context | None = None, return_stats: bool = False):
+    """Centroid-linkage dendrogram (SciPy format, merge order) of row-major fp64 `data` [N, d].
+
+    Returns (status, Z[(N-1), 4]) like the C ABI: a non-zero status leaves Z unspecified."""
+    ctx = ctx or L.default_context()
+    x = np.ascontiguousarray(data, np.float64)
+    n, d = x.shape
+    z = np.zeros((max(n - 1, 0), 4), np.float64)
+    stats = L.AhcStats()
+    st = L.lib().fa_ahc_linkage(ctx.handle, x.ctypes.data, n, d, z.ctypes.data, z.size, mode, 0, C.byref(stats))
+    return (st, z, stats.as_dict()) if return_stats else (st, z)
+
+
+def fastcluster_compute_centroid_linkage(data) -> tuple[int, np.ndarray]:
+    """The exact reference symbol (no context argument, library-owned default context)."""
+    x = np.ascontiguousarray(data, np.float64)
+    n, d = x.shape
+    z = np.zeros((max(n - 1, 0), 4), np.float64)
+    st = L.lib().fastcluster_compute_centroid_linkage(x.ctypes.data, n, d, z.ctypes.data, z.size)
+    return st, z
+
+
+def cut(z, n: int, threshold: float) -> np.ndarray:
+    """assignmentsFromDendrogram + remapClusterIds (:124-210) with the threshold clamp (:112-121)."""
+    z = np.ascontiguousarray(z, np.float64)
+    labels = np.zeros(max(n, 1), np.int32)
+    st = L.lib().fa_ahc_cut(z.ctypes.data if z.size else None, n, float(threshold), labels.ctypes.data)
+    if st != L.SUCCESS:
+        raise L.FluidAudioHipError(st, "fa_ahc_cut")
+    return labels[:n]
+
+
+class AHCClustering:
+    """struct AHCClustering (:12)."""
+
+    def __init__(self, ctx: L.Context | None = None, mode: int = L.AHC_MODE_AUTO):
+        self._ctx, self.mode = ctx, mode
+        self.last_stats: dict | None = None
+        self.last_status: int = L.SUCCESS
+
+    def cluster(self, embedding_features, threshold: float) -> list[int]:
+        """cluster(embeddingFeatures:threshold:) (:20-67)."""
+        count = len(embedding_features)
+        if count == 0:
+            return []
+        first = embedding_features[0]
+        dim = len(first)
+        if dim == 0:
+            return [0] * count
+        if count == 1:
+            return [0]
+        x = np.ascontiguousarray(embedding_features, np.float64)
+        ctx = self._ctx or L.default_context()
+        labels = np.zeros(count, np.int32)
+        stats = L.AhcStats()
+        st = L.lib().fa_ahc_cluster(ctx.handle, x.ctypes.data, count, dim, float(threshold), self.mode,
+                                    labels.ctypes.data, C.byref(stats))
+        self.last_status, self.last_stats = st, stats.as_dict()
+        # on failure the library has already filled labels with 0..<count (:52-55)
+        return [int(v) for v in labels]

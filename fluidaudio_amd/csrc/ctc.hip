@@ -1,0 +1,239 @@
+// ctc.hip — per-frame argmax + CTC greedy collapse for batches of logit matrices (gfx950).
+//
+// Replaces LogitsArgmax.argmaxPerFrame (reference: Sources/FluidAudio/ASR/Shared/LogitsArgmax.swift:16-55)
+// and the collapse loop of ctcGreedyDecode (Sources/FluidAudio/ASR/Parakeet/SlidingWindow/CTC/CtcDecoder.swift:45-70,
+// Sources/FluidAudio/ASR/SenseVoice/SenseVoiceManager.swift:119-126).
+//
+// One workgroup per matrix.  Each wavefront owns whole rows: 64 lanes stream the row with
+// 16-byte loads, keep a (value, index) pair with the reference's strict '>' rule, and combine
+// across lanes with xor-shuffles (greater value wins, equal values -> lower index, NaN never
+// wins).  Row winners land in LDS; the collapse `id != blank && id != previous id` is a
+// local predicate, so it becomes a block-wide exclusive scan + scatter.  Every logit is read
+// from HBM exactly once: 4*T*V bytes per fp32 matrix.
+#include <climits>
+
+#include <hip/hip_fp16.h>
+
+#include "fa_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kChunk = 2048;  // frames staged in LDS per pass (8 per thread in the scan)
+constexpr int kPerThread = kChunk / kThreads;
+
+struct CtcArgs {
+    const void *logits;
+    const int32_t *valid_frames;
+    int32_t *frame_ids;
+    int32_t *token_ids;
+    int32_t *token_lens;
+    int64_t row_stride, matrix_stride;
+    int32_t frames, vocab, blank_id;
+    int32_t vector_ok;  // rows are 16-byte aligned and vocab is a multiple of the vector width
+};
+
+__device__ __forceinline__ float sanitize(float x) { return x != x ? -INFINITY : x; }  // NaN never wins
+
+__device__ __forceinline__ void take(float x, int idx, float &best, int &bi) {
+    x = sanitize(x);
+    if (x > best) { best = x; bi = idx; }  // strict '>' => lowest index wins ties (CtcDecoder.swift:58-61)
+}
+
+__device__ __forceinline__ void wave_argmax(float &v, int &i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(i, off);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+template <bool F16>
+__device__ __forceinline__ int row_argmax(const void *row_ptr, const int vocab, const bool vector_ok, const int lane) {
+    float best = -INFINITY;
+    int bi = INT_MAX;
+    if (F16) {
+        const __half *row = static_cast<const __half *>(row_ptr);
+        if (vector_ok) {
+            const int nvec = vocab >> 3;
+            const uint4 *r4 = reinterpret_cast<const uint4 *>(row);
+            if (lane < nvec) bi = lane * 8;
+            for (int i = lane; i < nvec; i += 64) {
+                const uint4 q = r4[i];
+                const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    take(__half2float(__ushort_as_half(static_cast<unsigned short>(w[e] & 0xffffu))), 8 * i + 2 * e, best, bi);
+                    take(__half2float(__ushort_as_half(static_cast<unsigned short>(w[e] >> 16))), 8 * i + 2 * e + 1, best, bi);
+                }
+            }
+        } else {
+            if (lane < vocab) bi = lane;
+            for (int i = lane; i < vocab; i += 64) take(__half2float(row[i]), i, best, bi);
+        }
+    } else {
+        const float *row = static_cast<const float *>(row_ptr);
+        if (vector_ok) {
+            const int nvec = vocab >> 2;
+            const float4 *r4 = reinterpret_cast<const float4 *>(row);
+            if (lane < nvec) bi = lane * 4;
+            for (int i = lane; i < nvec; i += 64) {
+                const float4 q = r4[i];
+                take(q.x, 4 * i, best, bi);
+                take(q.y, 4 * i + 1, best, bi);
+                take(q.z, 4 * i + 2, best, bi);
+                take(q.w, 4 * i + 3, best, bi);
+            }
+        } else {
+            if (lane < vocab) bi = lane;
+            for (int i = lane; i < vocab; i += 64) take(row[i], i, best, bi);
+        }
+    }
+    wave_argmax(best, bi);
+    return bi;  // all -inf/NaN row: every lane kept its first index, the minimum is 0
+}
+
+template <bool F16>
+__global__ __launch_bounds__(kThreads) void ctc_greedy_kernel(const CtcArgs a) {
+    __shared__ int32_t ids[kChunk];
+    __shared__ int32_t wave_tot[kWaves];
+    __shared__ int32_t carry_prev, carry_count;
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int T = a.frames;
+    if (a.valid_frames) { const int v = a.valid_frames[b]; T = v < 0 ? 0 : (v < T ? v : T); }
+    const size_t esz = F16 ? 2 : 4;
+    const char *mat = static_cast<const char *>(a.logits) + static_cast<size_t>(b) * a.matrix_stride * esz;
+    int32_t *out = a.token_ids + static_cast<int64_t>(b) * a.frames;
+    int32_t *fids = a.frame_ids ? a.frame_ids + static_cast<int64_t>(b) * a.frames : nullptr;
+
+    if (tid == 0) { carry_prev = -1; carry_count = 0; }
+    __syncthreads();
+
+    for (int c0 = 0; c0 < T; c0 += kChunk) {
+        const int n = T - c0 < kChunk ? T - c0 : kChunk;
+        // phase 1: one row per wavefront
+        for (int r = wave; r < n; r += kWaves) {
+            const char *row = mat + static_cast<size_t>(c0 + r) * a.row_stride * esz;
+            const int bi = row_argmax<F16>(row, a.vocab, a.vector_ok != 0, lane);
+            if (lane == 0) {
+                ids[r] = bi;
+                if (fids) fids[c0 + r] = bi;
+            }
+        }
+        __syncthreads();
+        // phase 2: keep flags -> exclusive scan -> scatter (collapse, CtcDecoder.swift:52-68)
+        const int prev0 = carry_prev, base = carry_count;
+        int32_t mine[kPerThread];
+        int cnt = 0;
+        const int r0 = tid * kPerThread;
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const int r = r0 + j;
+            int keep = 0;
+            int32_t id = 0;
+            if (r < n) {
+                id = ids[r];
+                const int32_t prev = r > 0 ? ids[r - 1] : prev0;
+                keep = (id != a.blank_id) && (id != prev);
+            }
+            mine[j] = keep ? id : -1;
+            cnt += keep;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int wave_base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const int t = wave_tot[w];
+            if (w < wave) wave_base += t;
+            total += t;
+        }
+        int pos = base + wave_base + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j)
+            if (mine[j] >= 0) out[pos++] = mine[j];
+        __syncthreads();
+        if (tid == 0) { carry_prev = ids[n - 1]; carry_count = base + total; }
+        __syncthreads();
+    }
+    if (tid == 0) a.token_lens[b] = carry_count;
+}
+
+fa_status check_args(fa_ctx *ctx, const void *logits, int dtype, int batch, int frames, int vocab, int64_t row_stride,
+                     int64_t matrix_stride, const int32_t *token_ids, const int32_t *token_lens) {
+    if (!ctx || !token_ids || !token_lens) return FA_INVALID_ARGUMENT;
+    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_F16) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc: bad dtype");
+    if (batch < 0 || frames < 0 || vocab < 1 || row_stride < vocab) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc: bad shape");
+    if (batch > 0 && frames > 0 && (!logits || matrix_stride < static_cast<int64_t>(frames - 1) * row_stride + vocab))
+        return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc: bad strides");
+    return FA_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+fa_status fa_ctc_greedy_batch_dev(fa_ctx *ctx, const void *d_logits, int32_t dtype, int32_t batch, int32_t frames,
+                                  int32_t vocab, int64_t row_stride, int64_t matrix_stride,
+                                  const int32_t *d_valid_frames, int32_t blank_id, int32_t *d_frame_ids,
+                                  int32_t *d_token_ids, int32_t *d_token_lens) {
+    FA_TRY(check_args(ctx, d_logits, dtype, batch, frames, vocab, row_stride, matrix_stride, d_token_ids, d_token_lens));
+    if (batch == 0) return FA_SUCCESS;
+    fa::DeviceGuard guard(ctx->device);
+    CtcArgs a;
+    a.logits = d_logits; a.valid_frames = d_valid_frames; a.frame_ids = d_frame_ids; a.token_ids = d_token_ids;
+    a.token_lens = d_token_lens; a.row_stride = row_stride; a.matrix_stride = matrix_stride; a.frames = frames;
+    a.vocab = vocab; a.blank_id = blank_id;
+    const int vw = dtype == FA_DTYPE_F16 ? 8 : 4;
+    a.vector_ok = (vocab % vw == 0) && (row_stride % vw == 0) && (matrix_stride % vw == 0) &&
+                  (reinterpret_cast<uintptr_t>(d_logits) % 16 == 0);
+    if (dtype == FA_DTYPE_F16) hipLaunchKernelGGL(ctc_greedy_kernel<true>, dim3(batch), dim3(kThreads), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(ctc_greedy_kernel<false>, dim3(batch), dim3(kThreads), 0, ctx->stream, a);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+
+fa_status fa_ctc_greedy_batch(fa_ctx *ctx, const void *logits, int32_t dtype, int32_t batch, int32_t frames, int32_t vocab,
+                              int64_t row_stride, int64_t matrix_stride, const int32_t *valid_frames, int32_t blank_id,
+                              int32_t *frame_ids, int32_t *token_ids, int32_t *token_lens) {
+    FA_TRY(check_args(ctx, logits, dtype, batch, frames, vocab, row_stride, matrix_stride, token_ids, token_lens));
+    if (batch == 0) return FA_SUCCESS;
+    fa::DeviceGuard guard(ctx->device);
+    const size_t esz = dtype == FA_DTYPE_F16 ? 2 : 4;
+    const size_t in_bytes = frames > 0 ? (static_cast<size_t>(batch - 1) * matrix_stride + static_cast<size_t>(frames - 1) * row_stride + vocab) * esz : 0;
+    const size_t id_bytes = sizeof(int32_t) * static_cast<size_t>(batch) * (frames > 0 ? frames : 1);
+    fa::DevBuf d_in, d_valid, d_fid, d_tok, d_len;
+    hipError_t e;
+    fa_status st = FA_SUCCESS;
+    do {
+        if ((e = d_in.alloc(in_bytes)) != hipSuccess) break;
+        if ((e = d_tok.alloc(id_bytes)) != hipSuccess) break;
+        if ((e = d_len.alloc(sizeof(int32_t) * batch)) != hipSuccess) break;
+        if (frame_ids && (e = d_fid.alloc(id_bytes)) != hipSuccess) break;
+        if (valid_frames && (e = d_valid.alloc(sizeof(int32_t) * batch)) != hipSuccess) break;
+        if (in_bytes && (e = hipMemcpyAsync(d_in.p, logits, in_bytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        if (valid_frames && (e = hipMemcpyAsync(d_valid.p, valid_frames, sizeof(int32_t) * batch, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        st = fa_ctc_greedy_batch_dev(ctx, d_in.p, dtype, batch, frames, vocab, row_stride, matrix_stride,
+                                     valid_frames ? d_valid.as<int32_t>() : nullptr, blank_id,
+                                     frame_ids ? d_fid.as<int32_t>() : nullptr, d_tok.as<int32_t>(), d_len.as<int32_t>());
+        if (st != FA_SUCCESS) break;
+        if (frames > 0 && (e = hipMemcpyAsync(token_ids, d_tok.p, id_bytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        if (frames > 0 && frame_ids && (e = hipMemcpyAsync(frame_ids, d_fid.p, id_bytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(token_lens, d_len.p, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    if (st != FA_SUCCESS) return st;
+    return fa::hip_status(ctx, e, "fa_ctc_greedy_batch");
+}
+
+}  // extern "C"

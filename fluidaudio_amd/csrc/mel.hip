@@ -1,0 +1,427 @@
+// mel.hip — batched STFT -> power -> Slaney mel -> log featurizer for gfx950.
+//
+// Replaces AudioMelSpectrogram.computeFlat / computeFlatTransposed / compute
+// (reference: Sources/FluidAudio/Shared/AudioMelSpectrogram.swift:132-178,185-292,325-456).
+//
+// One workgroup (256 threads = 16 groups of 16 lanes) walks a contiguous range of 16-frame
+// tiles.  Per tile: stage hop*15+512 pre-emphasised samples into LDS once, each 16-lane
+// group turns one frame into 257 power bins (mel_core.h), then all 256 threads reduce the
+// sparse triangular filterbank, take the log and store either [n_mels, T] or [T, n_mels].
+// HBM traffic per 15 s utterance = 960 000 B read + 768 512 B written; everything else stays
+// in LDS/registers.
+#include <cmath>
+#include <vector>
+
+#include "fa_common.h"
+#include "mel_core.h"
+
+using namespace fa::melcore;
+
+namespace {
+
+constexpr int kTileFrames = 16;
+constexpr int kThreads = 256;
+constexpr int kMaxMels = 256;
+constexpr int kMaxWeights = 2 * kBins + 8;
+
+struct MelArgs {
+    const float *pcm;
+    const int64_t *offsets;   // B+1
+    const int32_t *frames;    // B   (T per utterance)
+    const float *last;        // B or nullptr
+    float *out;
+    int32_t *lengths;         // B or nullptr
+    const float *windowz;     // 512  window zero-extended to n_fft at offset `off`
+    const float2 *tw256;      // 256  exp(-2 pi i k / 256)
+    const float2 *tw512;      // 129  exp(-2 pi i k / 512)
+    const int32_t *mel_tab;   // n_mels packed (lo | cnt<<10 | start<<20)
+    const float *mel_w;       // n_weights
+    int64_t utt_stride;
+    int64_t total_tiles;
+    int32_t tiles_per_utt;
+    int32_t frame_stride;
+    int32_t n_mels, n_weights;
+    int32_t hop, pad, stage_count, stage_alloc;
+    float preemph, log_floor;
+    int32_t floor_clamped;
+};
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kThreads, 3) void mel_kernel(const MelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *samples = smem;
+    float *regions = samples + a.stage_alloc;
+    int32_t *mtab = reinterpret_cast<int32_t *>(regions + kTileFrames * kRegionFloats);
+    float *mw = reinterpret_cast<float *>(mtab + kMaxMels);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kGroup - 1);
+    const int grp = tid >> 4;
+
+    for (int i = tid; i < a.n_mels; i += kThreads) mtab[i] = a.mel_tab[i];
+    for (int i = tid; i < a.n_weights; i += kThreads) mw[i] = a.mel_w[i];
+
+    Tables c;
+    c.windowz = a.windowz;
+    c.tw256 = reinterpret_cast<const float *>(a.tw256);
+    c.tw512 = reinterpret_cast<const float *>(a.tw512);
+    __syncthreads();
+
+    const int64_t per = (a.total_tiles + gridDim.x - 1) / gridDim.x;
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * per;
+    const int64_t stop = first + per < a.total_tiles ? first + per : a.total_tiles;
+
+    for (int64_t tl = first; tl < stop; ++tl) {
+        const int b = static_cast<int>(tl / a.tiles_per_utt);
+        const int t0 = static_cast<int>(tl % a.tiles_per_utt) * kTileFrames;
+        const int T = a.frames[b];
+        const int64_t base = a.offsets[b];
+        const int64_t len = a.offsets[b + 1] - base;
+        if (t0 == 0 && tid == 0 && a.lengths) a.lengths[b] = T;
+
+        if (t0 < T) {  // workgroup-uniform
+            const float *x = a.pcm + base;
+            const float lastv = a.last ? a.last[b] : 0.0f;
+            const int64_t n0 = static_cast<int64_t>(t0) * a.hop - a.pad;
+            for (int i = tid; i < a.stage_count; i += kThreads) {
+                const int64_t n = n0 + i;
+                float y = 0.0f;
+                if (n >= 0 && n < len) {
+                    const float prev = n > 0 ? x[n - 1] : lastv;
+                    y = x[n] - a.preemph * prev;  // :211,:219-225 (y[n] = x[n] - p*x[n-1])
+                }
+                samples[i] = y;
+            }
+            __syncthreads();
+            const bool active = (t0 + grp) < T;
+            // Opaque per-iteration copy of the lane id: stops LICM from hoisting ~40 table
+            // addresses out of the tile loop (they were spilled to scratch when hoisted).
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            float *R = regions + grp * kRegionFloats;
+            const float *fs = samples + grp * a.hop;
+            if (active) phase_a(ln, fs, c, R);
+            __syncthreads();
+            Lane v;
+            if (active) phase_b1(ln, R, v);
+            __syncthreads();
+            if (active) phase_b2(ln, v, R);
+            __syncthreads();
+            Power p;
+            if (active) phase_c1(ln, R, c, p);
+            __syncthreads();
+            if (active) phase_c2(ln, p, R);
+            __syncthreads();
+        }
+
+        float *ob = a.out + static_cast<int64_t>(b) * a.utt_stride;
+        const int work = kTileFrames * a.n_mels;
+        for (int idx = tid; idx < work; idx += kThreads) {
+            int f, m;
+            if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) { f = idx & (kTileFrames - 1); m = idx >> 4; }
+            else { f = idx / a.n_mels; m = idx - f * a.n_mels; }
+            const int t = t0 + f;
+            if (t >= a.frame_stride) continue;
+            float val = 0.0f;  // padValue (:39) for t >= T
+            if (t < T) {
+                const int packed = mtab[m];
+                const int lo = packed & 1023, cnt = (packed >> 10) & 1023, st = packed >> 20;
+                const float *P = regions + f * kRegionFloats + lo;
+                const float *w = mw + st;
+                float acc = 0.0f;
+                for (int j = 0; j < cnt; ++j) acc += w[j] * P[j];  // vDSP_mmul row (:270-283), zeros skipped
+                val = a.floor_clamped ? logf(fmaxf(acc, a.log_floor)) : logf(acc + a.log_floor);  // :542-549
+            }
+            if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) ob[static_cast<int64_t>(m) * a.frame_stride + t] = val;  // :287
+            else ob[static_cast<int64_t>(t) * a.n_mels + m] = val;                                       // :451
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------- host tables
+// createHannWindow (:553-562)
+void make_hann(int win, bool periodic, std::vector<float> &w) {
+    w.resize(win);
+    const float divisor = periodic ? static_cast<float>(win) : static_cast<float>(win - 1);
+    const float pi_f = static_cast<float>(M_PI);
+    for (int i = 0; i < win; ++i) {
+        const float phase = 2.0f * pi_f * static_cast<float>(i) / divisor;
+        w[i] = 0.5f * (1.0f - cosf(phase));
+    }
+}
+
+float hz_to_mel(float hz) {  // :575-586
+    const float f_sp = 200.0f / 3.0f, min_log_hz = 1000.0f;
+    const float min_log_mel = min_log_hz / f_sp, log_step = logf(6.4f) / 27.0f;
+    return hz >= min_log_hz ? min_log_mel + logf(hz / min_log_hz) / log_step : hz / f_sp;
+}
+float mel_to_hz(float mel) {  // :588-599
+    const float f_sp = 200.0f / 3.0f, min_log_hz = 1000.0f;
+    const float min_log_mel = min_log_hz / f_sp, log_step = logf(6.4f) / 27.0f;
+    return mel >= min_log_mel ? min_log_hz * expf(log_step * (mel - min_log_mel)) : f_sp * mel;
+}
+
+// createMelFilterbank (:564-642), dense [n_mels][bins]
+void make_filterbank(int n_fft, int n_mels, int sr, std::vector<float> &fb) {
+    const int bins = n_fft / 2 + 1;
+    fb.assign(static_cast<size_t>(n_mels) * bins, 0.0f);
+    const float mel_min = hz_to_mel(0.0f), mel_max = hz_to_mel(static_cast<float>(sr) / 2.0f);
+    std::vector<float> pts(n_mels + 2), freqs(bins);
+    for (int i = 0; i < n_mels + 2; ++i)
+        pts[i] = mel_to_hz(mel_min + static_cast<float>(i) * (mel_max - mel_min) / static_cast<float>(n_mels + 1));
+    for (int i = 0; i < bins; ++i) freqs[i] = static_cast<float>(i) * static_cast<float>(sr) / static_cast<float>(n_fft);
+    for (int m = 0; m < n_mels; ++m) {
+        const float fl = pts[m], fc = pts[m + 1], fr = pts[m + 2];
+        const float norm = 2.0f / (fr - fl);
+        for (int k = 0; k < bins; ++k) {
+            const float f = freqs[k];
+            if (f >= fl && f < fc) fb[static_cast<size_t>(m) * bins + k] = norm * (f - fl) / (fc - fl);
+            else if (f >= fc && f <= fr) fb[static_cast<size_t>(m) * bins + k] = norm * (fr - f) / (fr - fc);
+        }
+    }
+}
+
+fa_status validate(const fa_mel_config *c) {
+    if (!c) return FA_INVALID_ARGUMENT;
+    if (c->n_fft != kNfft) return FA_INVALID_ARGUMENT;  // device kernel generation: 512 only
+    if (c->win < 2 || c->win > c->n_fft || c->hop < 1 || c->hop > 4096) return FA_INVALID_ARGUMENT;
+    if (c->n_mels < 1 || c->n_mels > kMaxMels || c->sample_rate < 1) return FA_INVALID_ARGUMENT;
+    if (c->padding_mode < 0 || c->padding_mode > 2 || c->layout < 0 || c->layout > 1) return FA_INVALID_ARGUMENT;
+    if (c->floor_mode < 0 || c->floor_mode > 1) return FA_INVALID_ARGUMENT;
+    return FA_SUCCESS;
+}
+
+}  // namespace
+
+struct fa_mel_plan {
+    fa_ctx *ctx = nullptr;
+    fa_mel_config cfg{};
+    int32_t batch = 0;
+    int32_t frame_stride = 0;
+    int64_t utt_stride = 0;
+    int64_t total_frames = 0;
+    int64_t total_samples = 0;
+    void *dev = nullptr;  // one allocation holding every device-side table of the plan
+    MelArgs args{};
+    size_t lds_bytes = 0;
+    int grid = 0;
+};
+
+extern "C" {
+
+void fa_mel_default_config(fa_mel_config *c) {
+    if (!c) return;
+    c->sample_rate = 16000; c->n_mels = 128; c->n_fft = 512; c->hop = 160; c->win = 400;
+    c->preemph = 0.97f; c->pad_to = 0; c->log_floor = ldexpf(1.0f, -24);
+    c->floor_mode = FA_MEL_FLOOR_ADDITIVE; c->window_periodic = 0;
+    c->padding_mode = FA_MEL_PAD_CENTER; c->layout = FA_MEL_LAYOUT_MEL_MAJOR;
+}
+
+int32_t fa_mel_num_frames(const fa_mel_config *c, int64_t n) {
+    if (!c || n <= 0 || c->hop < 1) return 0;
+    int64_t frames;
+    switch (c->padding_mode) {
+        case FA_MEL_PAD_CENTER: frames = 1 + (n + 2 * static_cast<int64_t>(c->n_fft / 2) - c->win) / c->hop; break;  // :195-197
+        case FA_MEL_PAD_PREPADDED: frames = (n - c->n_fft) / c->hop + 1; if (frames < 0) frames = 0; break;          // :345
+        default: frames = 1 + (n - c->win) / c->hop; break;                                                          // :133
+    }
+    if (frames <= 0) return 0;
+    return frames > INT32_MAX ? 0 : static_cast<int32_t>(frames);
+}
+
+int32_t fa_mel_padded_frames(const fa_mel_config *c, int32_t frames) {
+    if (!c) return 0;
+    const int32_t p = c->pad_to > 1 ? c->pad_to : 1;  // :72
+    return ((frames + p - 1) / p) * p;                // :204,:354
+}
+
+fa_status fa_mel_hann_window(const fa_mel_config *c, float *out) {
+    if (!c || !out || c->win < 1) return FA_INVALID_ARGUMENT;
+    std::vector<float> w;
+    make_hann(c->win, c->window_periodic != 0, w);
+    memcpy(out, w.data(), sizeof(float) * w.size());
+    return FA_SUCCESS;
+}
+
+fa_status fa_mel_filterbank(const fa_mel_config *c, float *out) {
+    if (!c || !out || c->n_fft < 2 || c->n_mels < 1) return FA_INVALID_ARGUMENT;
+    std::vector<float> fb;
+    make_filterbank(c->n_fft, c->n_mels, c->sample_rate, fb);
+    memcpy(out, fb.data(), sizeof(float) * fb.size());
+    return FA_SUCCESS;
+}
+
+fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_t *offsets, int32_t batch,
+                             const int32_t *expected_frames, int32_t frame_stride, fa_mel_plan **out) {
+    if (!ctx || !out) return FA_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (validate(cfg) != FA_SUCCESS) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel: unsupported configuration");
+    if (!offsets || batch < 1) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel: empty batch");
+    fa::DeviceGuard guard(ctx->device);
+    try {
+        fa_mel_plan *p = new fa_mel_plan();
+        p->ctx = ctx; p->cfg = *cfg; p->batch = batch;
+        const int bins = kBins;
+        std::vector<int32_t> frames(batch);
+        int32_t max_padded = 1;
+        for (int b = 0; b < batch; ++b) {
+            const int64_t len = offsets[b + 1] - offsets[b];
+            if (len < 0) { delete p; return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel: offsets not monotone"); }
+            int32_t T = fa_mel_num_frames(cfg, len);
+            if (expected_frames && len > 0) T = expected_frames[b] > 0 ? expected_frames[b] : 0;  // :347
+            frames[b] = T;
+            p->total_frames += T;
+            const int32_t tp = T > 0 ? fa_mel_padded_frames(cfg, T) : 1;
+            if (tp > max_padded) max_padded = tp;
+        }
+        p->total_samples = offsets[batch];
+        if (frame_stride <= 0) frame_stride = max_padded;
+        if (frame_stride < max_padded) { delete p; return fa::set_error(ctx, FA_OUTPUT_TOO_SMALL, "mel: frame_stride too small"); }
+        p->frame_stride = frame_stride;
+        p->utt_stride = static_cast<int64_t>(frame_stride) * cfg->n_mels;
+
+        // tables
+        std::vector<float> hann, fb;
+        make_hann(cfg->win, cfg->window_periodic != 0, hann);
+        make_filterbank(cfg->n_fft, cfg->n_mels, cfg->sample_rate, fb);
+        const int off = cfg->padding_mode == FA_MEL_PAD_LEGACY ? 0 : (cfg->n_fft - cfg->win) / 2;  // :234 / :148-153
+        std::vector<float> windowz(kNfft, 0.0f);
+        for (int i = 0; i < cfg->win; ++i) windowz[off + i] = hann[i];
+        std::vector<float2> tw256(256), tw512(129);
+        for (int k = 0; k < 256; ++k) { const double a = -2.0 * M_PI * k / 256.0; tw256[k] = make_float2((float)cos(a), (float)sin(a)); }
+        for (int k = 0; k < 129; ++k) { const double a = -2.0 * M_PI * k / 512.0; tw512[k] = make_float2((float)cos(a), (float)sin(a)); }
+        std::vector<int32_t> tab(cfg->n_mels);
+        std::vector<float> weights;
+        for (int m = 0; m < cfg->n_mels; ++m) {
+            int lo = -1, hi = -1;
+            for (int k = 0; k < bins; ++k)
+                if (fb[static_cast<size_t>(m) * bins + k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
+            const int cnt = lo < 0 ? 0 : hi - lo + 1;
+            if (lo < 0) lo = 0;
+            const int st = static_cast<int>(weights.size());
+            for (int j = 0; j < cnt; ++j) weights.push_back(fb[static_cast<size_t>(m) * bins + lo + j]);
+            tab[m] = lo | (cnt << 10) | (st << 20);
+        }
+        if (weights.size() > static_cast<size_t>(kMaxWeights) * 2) { delete p; return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel: filterbank too dense"); }
+        if (weights.empty()) weights.push_back(0.0f);
+
+        // device blob
+        auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+        size_t o_off = 0, o_fr = align(o_off + sizeof(int64_t) * (batch + 1)), o_wz = align(o_fr + sizeof(int32_t) * batch),
+               o_t256 = align(o_wz + sizeof(float) * kNfft), o_t512 = align(o_t256 + sizeof(float2) * 256),
+               o_tab = align(o_t512 + sizeof(float2) * 129), o_w = align(o_tab + sizeof(int32_t) * cfg->n_mels),
+               total = align(o_w + sizeof(float) * weights.size());
+        std::vector<char> blob(total, 0);
+        memcpy(blob.data() + o_off, offsets, sizeof(int64_t) * (batch + 1));
+        memcpy(blob.data() + o_fr, frames.data(), sizeof(int32_t) * batch);
+        memcpy(blob.data() + o_wz, windowz.data(), sizeof(float) * kNfft);
+        memcpy(blob.data() + o_t256, tw256.data(), sizeof(float2) * 256);
+        memcpy(blob.data() + o_t512, tw512.data(), sizeof(float2) * 129);
+        memcpy(blob.data() + o_tab, tab.data(), sizeof(int32_t) * cfg->n_mels);
+        memcpy(blob.data() + o_w, weights.data(), sizeof(float) * weights.size());
+        hipError_t e = hipMalloc(&p->dev, total);
+        if (e != hipSuccess) { delete p; return fa::hip_status(ctx, e, "mel plan hipMalloc"); }
+        e = hipMemcpy(p->dev, blob.data(), total, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(p->dev); delete p; return fa::hip_status(ctx, e, "mel plan upload"); }
+        char *d = static_cast<char *>(p->dev);
+
+        MelArgs &a = p->args;
+        a.offsets = reinterpret_cast<const int64_t *>(d + o_off);
+        a.frames = reinterpret_cast<const int32_t *>(d + o_fr);
+        a.windowz = reinterpret_cast<const float *>(d + o_wz);
+        a.tw256 = reinterpret_cast<const float2 *>(d + o_t256);
+        a.tw512 = reinterpret_cast<const float2 *>(d + o_t512);
+        a.mel_tab = reinterpret_cast<const int32_t *>(d + o_tab);
+        a.mel_w = reinterpret_cast<const float *>(d + o_w);
+        a.utt_stride = p->utt_stride;
+        a.tiles_per_utt = (frame_stride + kTileFrames - 1) / kTileFrames;
+        a.total_tiles = static_cast<int64_t>(a.tiles_per_utt) * batch;
+        a.frame_stride = frame_stride;
+        a.n_mels = cfg->n_mels;
+        a.n_weights = static_cast<int32_t>(weights.size());
+        a.hop = cfg->hop;
+        a.pad = cfg->padding_mode == FA_MEL_PAD_CENTER ? cfg->n_fft / 2 : 0;
+        a.stage_count = (kTileFrames - 1) * cfg->hop + kNfft;
+        a.stage_alloc = (a.stage_count + 3) & ~3;
+        a.preemph = cfg->padding_mode == FA_MEL_PAD_LEGACY ? 0.0f : cfg->preemph;  // compute() has no pre-emphasis (:146-153)
+        a.log_floor = cfg->log_floor;
+        a.floor_clamped = cfg->floor_mode == FA_MEL_FLOOR_CLAMPED;
+        p->lds_bytes = sizeof(float) * (a.stage_alloc + kTileFrames * kRegionFloats) + sizeof(int32_t) * kMaxMels +
+                       sizeof(float) * (static_cast<size_t>(a.n_weights) + 8);
+        if (p->lds_bytes > 160 * 1024) { (void)hipFree(p->dev); delete p; return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel: hop too large for LDS staging"); }
+        if (p->lds_bytes > 64 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(p->lds_bytes));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(p->lds_bytes));
+        }
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, ctx->device);
+        const int cus = e == hipSuccess ? prop.multiProcessorCount : 256;
+        const int64_t want = static_cast<int64_t>(cus) * 3 * 2;  // 3 resident workgroups per CU, two waves of them
+        p->grid = static_cast<int>(a.total_tiles < want ? a.total_tiles : want);
+        if (p->grid < 1) p->grid = 1;
+        *out = p;
+        return FA_SUCCESS;
+    } catch (const std::bad_alloc &) {
+        return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "mel plan: host allocation failed");
+    } catch (...) {
+        return fa::set_error(ctx, FA_UNKNOWN_ERROR, "mel plan: unexpected failure");
+    }
+}
+
+void fa_mel_plan_destroy(fa_mel_plan *p) {
+    if (!p) return;
+    if (p->dev) { (void)hipSetDevice(p->ctx->device); (void)hipStreamSynchronize(p->ctx->stream); (void)hipFree(p->dev); }
+    delete p;
+}
+
+int64_t fa_mel_plan_utt_stride(const fa_mel_plan *p) { return p ? p->utt_stride : 0; }
+int32_t fa_mel_plan_frame_stride(const fa_mel_plan *p) { return p ? p->frame_stride : 0; }
+int64_t fa_mel_plan_total_frames(const fa_mel_plan *p) { return p ? p->total_frames : 0; }
+
+fa_status fa_mel_execute_dev(fa_mel_plan *p, const float *d_pcm, const float *d_last, float *d_mel, int32_t *d_lengths) {
+    if (!p || !d_mel || (!d_pcm && p->total_samples > 0)) return FA_INVALID_ARGUMENT;
+    fa_ctx *ctx = p->ctx;
+    fa::DeviceGuard guard(ctx->device);
+    MelArgs a = p->args;
+    a.pcm = d_pcm; a.last = d_last; a.out = d_mel; a.lengths = d_lengths;
+    if (p->cfg.layout == FA_MEL_LAYOUT_MEL_MAJOR)
+        hipLaunchKernelGGL(mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR>, dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR>, dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+
+fa_status fa_mel_batch(fa_ctx *ctx, const fa_mel_config *cfg, const float *pcm, const int64_t *offsets, int32_t batch,
+                       const float *last_samples, const int32_t *expected_frames, int32_t frame_stride, float *mel,
+                       int32_t *mel_lengths) {
+    if (!ctx || !mel || !offsets || batch < 1) return FA_INVALID_ARGUMENT;
+    fa::DeviceGuard guard(ctx->device);
+    fa_mel_plan *plan = nullptr;
+    FA_TRY(fa_mel_plan_create(ctx, cfg, offsets, batch, expected_frames, frame_stride, &plan));
+    const int64_t ns = offsets[batch];
+    if (ns > 0 && !pcm) { fa_mel_plan_destroy(plan); return FA_INVALID_ARGUMENT; }
+    const size_t out_floats = static_cast<size_t>(plan->utt_stride) * batch;
+    fa::DevBuf d_pcm, d_last, d_out, d_len;
+    fa_status st = FA_SUCCESS;
+    hipError_t e;
+    do {
+        if ((e = d_pcm.alloc(sizeof(float) * static_cast<size_t>(ns))) != hipSuccess) break;
+        if ((e = d_out.alloc(sizeof(float) * out_floats)) != hipSuccess) break;
+        if ((e = d_len.alloc(sizeof(int32_t) * batch)) != hipSuccess) break;
+        if (last_samples && (e = d_last.alloc(sizeof(float) * batch)) != hipSuccess) break;
+        if (ns > 0 && (e = hipMemcpyAsync(d_pcm.p, pcm, sizeof(float) * ns, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        if (last_samples && (e = hipMemcpyAsync(d_last.p, last_samples, sizeof(float) * batch, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        st = fa_mel_execute_dev(plan, d_pcm.as<float>(), last_samples ? d_last.as<float>() : nullptr, d_out.as<float>(), d_len.as<int32_t>());
+        if (st != FA_SUCCESS) break;
+        if ((e = hipMemcpyAsync(mel, d_out.p, sizeof(float) * out_floats, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        if (mel_lengths && (e = hipMemcpyAsync(mel_lengths, d_len.p, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    fa_mel_plan_destroy(plan);
+    if (st != FA_SUCCESS) return st;
+    return fa::hip_status(ctx, e, "fa_mel_batch");
+}
+
+}  // extern "C"

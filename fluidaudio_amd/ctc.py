@@ -1,0 +1,96 @@
+"""Host-side mirror of ``LogitsArgmax.argmaxPerFrame`` and the greedy half of ``ctcGreedyDecode``
+(reference: Sources/FluidAudio/ASR/Shared/LogitsArgmax.swift:16-55,
+Sources/FluidAudio/ASR/Parakeet/SlidingWindow/CTC/CtcDecoder.swift:15-70,292-297) over the HIP C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+SENTENCEPIECE_WORD_BOUNDARY = "▁"  # ASRConstants.sentencePieceWordBoundary
+
+
+def _as_matrix_batch(logits) -> np.ndarray:
+    x = np.asarray(logits)
+    if x.dtype not in (np.float32, np.float16):
+        x = x.astype(np.float32)
+    if x.ndim == 2:
+        x = x[None]
+    assert x.ndim == 3, "logits must be [T,V] or [B,T,V]"
+    return np.ascontiguousarray(x)
+
+
+def ctc_greedy_ids_batch(logits, blank_id: int, vocab: int | None = None, valid_frames=None, ctx: L.Context | None = None,
+                         return_frame_ids: bool = False):
+    """[B,T,W] host logits -> list of collapsed id arrays (and optionally the [B,T] per-frame argmax)."""
+    ctx = ctx or L.default_context()
+    x = _as_matrix_batch(logits)
+    B, T, W = x.shape
+    V = W if vocab is None else vocab
+    dtype = L.DTYPE_F16 if x.dtype == np.float16 else L.DTYPE_F32
+    tok = np.zeros((B, max(T, 1)), np.int32)
+    lens = np.zeros(B, np.int32)
+    fids = np.zeros((B, max(T, 1)), np.int32) if return_frame_ids else None
+    vf = None if valid_frames is None else np.ascontiguousarray(valid_frames, np.int32)
+    if B > 0:
+        ctx.check(L.lib().fa_ctc_greedy_batch(ctx.handle, x.ctypes.data if x.size else None, dtype, B, T, V, W, T * W,
+                                              None if vf is None else vf.ctypes.data, blank_id,
+                                              None if fids is None else fids.ctypes.data, tok.ctypes.data,
+                                              lens.ctypes.data), "fa_ctc_greedy_batch")
+    out = [tok[b, :lens[b]].copy() for b in range(B)]
+    return (out, fids[:, :T]) if return_frame_ids else out
+
+
+def ctc_greedy_ids_dev(ctx: L.Context, d_logits, blank_id: int, d_token_ids, d_token_lens, d_frame_ids=None,
+                       d_valid_frames=None, vocab: int | None = None):
+    """Device-resident batch: d_logits torch CUDA tensor [B,T,W] (fp32/fp16, contiguous). Enqueues on ctx.stream."""
+    import torch
+    B, T, W = d_logits.shape
+    V = W if vocab is None else vocab
+    dtype = L.DTYPE_F16 if d_logits.dtype == torch.float16 else L.DTYPE_F32
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    ctx.check(L.lib().fa_ctc_greedy_batch_dev(ctx.handle, p(d_logits), dtype, B, T, V, W, T * W, p(d_valid_frames),
+                                              blank_id, p(d_frame_ids), p(d_token_ids), p(d_token_lens)),
+              "fa_ctc_greedy_batch_dev")
+
+
+class LogitsArgmax:
+    """enum LogitsArgmax (LogitsArgmax.swift:13)."""
+
+    @staticmethod
+    def argmax_per_frame(logits, frames: int, vocab: int | None = None, ctx: L.Context | None = None) -> list[int]:
+        """argmaxPerFrame(logits:frames:) (:16-55): logits [1,T,W] (W = row stride >= vocab) or [T,W]."""
+        x = np.asarray(logits)
+        if x.ndim == 3:
+            x = x[0]
+        frames = min(frames, x.shape[0])
+        if frames <= 0:
+            return []
+        _, fids = ctc_greedy_ids_batch(x[:frames], blank_id=-1, vocab=vocab, ctx=ctx, return_frame_ids=True)
+        return [int(v) for v in fids[0]]
+
+
+def decode_ctc_token_ids(ids, vocabulary: dict[int, str]) -> str:
+    """decodeCtcTokenIds (CtcDecoder.swift:292-297)."""
+    text = "".join(vocabulary[int(i)] for i in ids if int(i) in vocabulary)
+    return text.replace(SENTENCEPIECE_WORD_BOUNDARY, " ").strip(" ")
+
+
+def ctc_greedy_decode(log_probs, vocabulary: dict[int, str], blank_id: int = 1024, ctx: L.Context | None = None) -> str:
+    """ctcGreedyDecode(logProbs:vocabulary:blankId:) (:15-36 for [[Float]], :45-70 for [1,T,V])."""
+    if isinstance(log_probs, (list, tuple)):
+        rows = [r for r in log_probs if len(r) > 0]  # `guard !frame.isEmpty else { continue }` (:23)
+        if not rows:
+            return ""
+        x = np.asarray(rows, np.float32)
+    else:
+        x = np.asarray(log_probs)
+        if x.ndim == 3:
+            x = x[0]
+        if x.shape[0] == 0:
+            return ""
+    ids = ctc_greedy_ids_batch(x, blank_id, ctx=ctx)[0]
+    return decode_ctc_token_ids(ids, vocabulary)

@@ -1,0 +1,129 @@
+"""Host-side mirror of ``AudioMelSpectrogram``
+(reference: Sources/FluidAudio/Shared/AudioMelSpectrogram.swift) over the HIP C ABI.
+
+Same constructor parameters (:59-70), same method names and return tuples
+(``computeFlat`` :185-187 -> ``compute_flat`` etc.); the arithmetic runs in
+fluidaudio_amd/csrc/mel.hip.  ``MelPlan`` is the batched, device-resident entry the
+reference does not have (it processes one utterance per call).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class MelPlan:
+    """Fixed batch geometry -> pure kernel launches (fa_mel_plan_*)."""
+
+    def __init__(self, ctx: L.Context, cfg: L.MelConfig, offsets, expected_frames=None, frame_stride: int = 0):
+        self.ctx, self.cfg = ctx, cfg
+        self.offsets = np.ascontiguousarray(offsets, np.int64)
+        self.batch = self.offsets.size - 1
+        exp = None if expected_frames is None else np.ascontiguousarray(expected_frames, np.int32)
+        self._h = C.c_void_p()
+        ctx.check(L.lib().fa_mel_plan_create(ctx.handle, C.byref(cfg), self.offsets.ctypes.data, self.batch,
+                                             None if exp is None else exp.ctypes.data, frame_stride, C.byref(self._h)),
+                  "fa_mel_plan_create")
+        self.utt_stride = L.lib().fa_mel_plan_utt_stride(self._h)
+        self.frame_stride = L.lib().fa_mel_plan_frame_stride(self._h)
+        self.total_frames = L.lib().fa_mel_plan_total_frames(self._h)
+
+    def out_shape(self):
+        if self.cfg.layout == L.MEL_LAYOUT_MEL_MAJOR:
+            return (self.batch, self.cfg.n_mels, self.frame_stride)
+        return (self.batch, self.frame_stride, self.cfg.n_mels)
+
+    def execute(self, d_pcm, d_mel, d_lengths=None, d_last=None):
+        """All arguments are torch CUDA tensors (float32 pcm/mel/last, int32 lengths). Enqueues on ctx.stream."""
+        self.ctx.check(L.lib().fa_mel_execute_dev(self._h, _ptr(d_pcm), _ptr(d_last), _ptr(d_mel), _ptr(d_lengths)),
+                       "fa_mel_execute_dev")
+
+    def close(self):
+        if self._h:
+            L.lib().fa_mel_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class AudioMelSpectrogram:
+    """Drop-in for the reference class of the same name (one instance per thread, like the reference :48-57)."""
+
+    def __init__(self, sample_rate: int = 16000, n_mels: int = 128, n_fft: int = 512, hop_length: int = 160,
+                 win_length: int = 400, preemph: float = 0.97, pad_to: int = 0, log_floor: float = 2.0 ** -24,
+                 log_floor_mode: str = "additive", window_periodic: bool = False, ctx: L.Context | None = None):
+        self.ctx = ctx or L.default_context()
+        self.n_fft, self.n_mels = n_fft, n_mels
+        self._base = dict(sample_rate=sample_rate, n_mels=n_mels, n_fft=n_fft, hop=hop_length, win=win_length,
+                          preemph=preemph, pad_to=pad_to, log_floor=log_floor,
+                          floor_mode=L.MEL_FLOOR_CLAMPED if log_floor_mode == "clamped" else L.MEL_FLOOR_ADDITIVE,
+                          window_periodic=int(window_periodic))
+
+    def config(self, padding_mode=L.MEL_PAD_CENTER, layout=L.MEL_LAYOUT_MEL_MAJOR) -> L.MelConfig:
+        return L.MelConfig(padding_mode=padding_mode, layout=layout, **self._base)
+
+    # -- single-utterance entries with the reference's return tuples ---------------------------
+    def _run(self, audio, last, cfg, expected):
+        a = np.ascontiguousarray(audio, np.float32).reshape(-1)
+        offs = np.array([0, a.size], np.int64)
+        T = L.lib().fa_mel_num_frames(C.byref(cfg), a.size)
+        if expected is not None and a.size > 0:
+            T = max(int(expected), 0)
+        if T <= 0:  # guard (:199-201, :349-351)
+            return np.zeros(self.n_mels, np.float32), 0, 1
+        tpad = L.lib().fa_mel_padded_frames(C.byref(cfg), T)
+        out = np.zeros(self.n_mels * tpad, np.float32)
+        lens = np.zeros(1, np.int32)
+        lastv = np.array([last], np.float32)
+        exp = None if expected is None else np.array([expected], np.int32)
+        self.ctx.check(L.lib().fa_mel_batch(self.ctx.handle, C.byref(cfg), a.ctypes.data, offs.ctypes.data, 1,
+                                            lastv.ctypes.data, None if exp is None else exp.ctypes.data, tpad,
+                                            out.ctypes.data, lens.ctypes.data), "fa_mel_batch")
+        return out, int(lens[0]), tpad
+
+    def compute_flat(self, audio, last_audio_sample: float = 0.0):
+        """computeFlat (:185-292) -> (mel flat [n_mels * numFrames], melLength, numFrames)."""
+        return self._run(audio, last_audio_sample, self.config(L.MEL_PAD_CENTER, L.MEL_LAYOUT_MEL_MAJOR), None)
+
+    def compute_flat_transposed(self, audio, last_audio_sample: float = 0.0, padding_mode: str = "center",
+                                expected_frame_count: int | None = None):
+        """computeFlatTransposed (:325-456) -> (mel flat [numFrames * n_mels], melLength, numFrames)."""
+        pm = L.MEL_PAD_PREPADDED if padding_mode in ("prePadded", "prepadded") else L.MEL_PAD_CENTER
+        return self._run(audio, last_audio_sample, self.config(pm, L.MEL_LAYOUT_FRAME_MAJOR), expected_frame_count)
+
+    def compute(self, audio):
+        """compute (:132-178) -> (mel [1, n_mels, T], melLength)."""
+        mel, ml, nf = self._run(audio, 0.0, self.config(L.MEL_PAD_LEGACY, L.MEL_LAYOUT_MEL_MAJOR), None)
+        if ml == 0:
+            return np.zeros((0, 0, 0), np.float32), 0
+        return mel.reshape(1, self.n_mels, nf)[:, :, :ml].copy(), ml
+
+    def get_filterbank(self) -> np.ndarray:
+        cfg = self.config()
+        out = np.zeros((self.n_mels, self.n_fft // 2 + 1), np.float32)
+        self.ctx.check(L.lib().fa_mel_filterbank(C.byref(cfg), out.ctypes.data), "fa_mel_filterbank")
+        return out
+
+    def get_hann_window(self) -> np.ndarray:
+        cfg = self.config()
+        out = np.zeros(cfg.win, np.float32)
+        self.ctx.check(L.lib().fa_mel_hann_window(C.byref(cfg), out.ctypes.data), "fa_mel_hann_window")
+        return out
+
+    # -- batched, device-resident (no reference counterpart) ------------------------------------
+    def plan(self, offsets, layout="mel_major", padding_mode="center", expected_frames=None, frame_stride=0) -> MelPlan:
+        pm = {"center": L.MEL_PAD_CENTER, "prepadded": L.MEL_PAD_PREPADDED, "prePadded": L.MEL_PAD_PREPADDED,
+              "legacy": L.MEL_PAD_LEGACY}[padding_mode]
+        lay = L.MEL_LAYOUT_MEL_MAJOR if layout == "mel_major" else L.MEL_LAYOUT_FRAME_MAJOR
+        return MelPlan(self.ctx, self.config(pm, lay), offsets, expected_frames, frame_stride)

@@ -1,0 +1,187 @@
+/*
+ * fluidaudio_hip.h — C ABI of libfluidaudio_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the host arithmetic of FluidInference/FluidAudio
+ * (paths below are relative to the reference's Sources/ directory).
+ * Plain pointers and sizes only; no exception crosses this boundary; every entry
+ * returns an fa_status whose numbering equals fastcluster_wrapper_status
+ * (FastClusterWrapper/include/FastClusterWrapper.h:11-19).
+ *
+ * Naming: entries ending in _dev take DEVICE pointers and enqueue work on the
+ * context's stream without synchronising; the un-suffixed entries take HOST
+ * pointers, copy in/out and return when the result is in the caller's buffer
+ * (the calling convention of the Swift seams they replace).
+ */
+#ifndef FLUIDAUDIO_HIP_H
+#define FLUIDAUDIO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    FA_SUCCESS = 0,
+    FA_INVALID_ARGUMENT = 1,
+    FA_INDEX_OVERFLOW = 2,
+    FA_OUTPUT_TOO_SMALL = 3,
+    FA_ALLOCATION_FAILURE = 4,
+    FA_RUNTIME_ERROR = 5, /* HIP errors, NaN distances, unsupported-on-device conditions */
+    FA_UNKNOWN_ERROR = 255
+} fa_status;
+
+/* ------------------------------------------------------------------ context -------- */
+/* One context = one device + one stream + cached workspaces.  A context is NOT
+ * thread-safe; use one per host thread (the reference's AudioMelSpectrogram is likewise
+ * one-instance-per-thread, FluidAudio/Shared/AudioMelSpectrogram.swift:48-57). */
+typedef struct fa_ctx fa_ctx;
+
+/* stream: a hipStream_t to enqueue on, or NULL to let the context create its own. */
+fa_status fa_ctx_create(int device, void *stream, fa_ctx **out);
+void fa_ctx_destroy(fa_ctx *ctx);
+fa_status fa_ctx_synchronize(fa_ctx *ctx);
+/* The hipStream_t every _dev entry of this context enqueues on (for events / stream-ordered callers). */
+void *fa_ctx_stream(const fa_ctx *ctx);
+/* Last error text recorded on this context ("" if none). */
+const char *fa_ctx_last_error(const fa_ctx *ctx);
+/* Library build identification, e.g. "fluidaudio_hip 0.1 gfx950". */
+const char *fa_version(void);
+
+/* ------------------------------------------------------------------ mel ------------- */
+/* Replaces AudioMelSpectrogram (FluidAudio/Shared/AudioMelSpectrogram.swift):
+ *   ctor parameters :59-70, computeFlat :185-292, computeFlatTransposed :325-456,
+ *   compute (legacy) :132-178. */
+enum { FA_MEL_FLOOR_ADDITIVE = 0, FA_MEL_FLOOR_CLAMPED = 1 };              /* LogFloorMode :24-27 */
+enum { FA_MEL_PAD_CENTER = 0, FA_MEL_PAD_PREPADDED = 1, FA_MEL_PAD_LEGACY = 2 }; /* PaddingMode :19-22; LEGACY = compute() */
+enum { FA_MEL_LAYOUT_MEL_MAJOR = 0,   /* [n_mels, frames]  computeFlat  (mel[m*stride + t]) */
+       FA_MEL_LAYOUT_FRAME_MAJOR = 1  /* [frames, n_mels]  computeFlatTransposed (mel[t*n_mels + m]) */ };
+
+typedef struct {
+    int32_t sample_rate;     /* 16000 */
+    int32_t n_mels;          /* 128   (1..256) */
+    int32_t n_fft;           /* 512   (only 512 is implemented on device) */
+    int32_t hop;             /* 160 */
+    int32_t win;             /* 400   (<= n_fft) */
+    float preemph;           /* 0.97 */
+    int32_t pad_to;          /* 0 (treated as 1, :72) */
+    float log_floor;         /* 2^-24 */
+    int32_t floor_mode;      /* FA_MEL_FLOOR_* */
+    int32_t window_periodic; /* 0 symmetric / 1 periodic (:553-562) */
+    int32_t padding_mode;    /* FA_MEL_PAD_* */
+    int32_t layout;          /* FA_MEL_LAYOUT_* */
+} fa_mel_config;
+
+void fa_mel_default_config(fa_mel_config *cfg);
+/* Frame count T the reference would emit for n_samples (:192-197, :335-347, :133); 0 when its guard fires. */
+int32_t fa_mel_num_frames(const fa_mel_config *cfg, int64_t n_samples);
+/* ceil(T / pad_to) * pad_to (:204, :354). */
+int32_t fa_mel_padded_frames(const fa_mel_config *cfg, int32_t frames);
+
+/* A plan fixes the batch geometry (utterance offsets), the tables (Hann window, Slaney
+ * filterbank in sparse form) and the launch grid; executing it is a pure kernel launch. */
+typedef struct fa_mel_plan fa_mel_plan;
+
+/* offsets: HOST array of B+1 sample offsets into the packed pcm buffer (utterance b is
+ *          pcm[offsets[b] .. offsets[b+1])).
+ * expected_frames: HOST array of B frame-count overrides (expectedFrameCount, :329,:347)
+ *          or NULL.
+ * frame_stride: allocated frames per utterance in the output (>= padded frames of every
+ *          utterance); 0 = use the largest padded frame count in the batch.
+ * Output addressing: utterance b starts at mel + b * fa_mel_plan_utt_stride(plan);
+ *   MEL_MAJOR  : mel[b][m][t] at m*frame_stride + t     FRAME_MAJOR: mel[b][t][m] at t*n_mels + m
+ * Frames t >= T(b) inside the allocation are written as 0 (padValue, :39). */
+fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_t *offsets, int32_t batch,
+                             const int32_t *expected_frames, int32_t frame_stride, fa_mel_plan **out);
+void fa_mel_plan_destroy(fa_mel_plan *plan);
+int64_t fa_mel_plan_utt_stride(const fa_mel_plan *plan);   /* floats per utterance in the output */
+int32_t fa_mel_plan_frame_stride(const fa_mel_plan *plan);
+int64_t fa_mel_plan_total_frames(const fa_mel_plan *plan); /* sum of T(b) */
+
+/* d_pcm: device float[offsets[B]]; d_last_samples: device float[B] (lastAudioSample, :186) or NULL = 0;
+ * d_mel: device float[B * utt_stride]; d_mel_lengths: device int32[B] (melLength) or NULL. */
+fa_status fa_mel_execute_dev(fa_mel_plan *plan, const float *d_pcm, const float *d_last_samples,
+                             float *d_mel, int32_t *d_mel_lengths);
+
+/* Host-buffer convenience (the shape of a loop of computeFlat calls): copies pcm in, runs
+ * the plan, copies mel (+lengths) out, synchronises. */
+fa_status fa_mel_batch(fa_ctx *ctx, const fa_mel_config *cfg, const float *pcm, const int64_t *offsets,
+                       int32_t batch, const float *last_samples, const int32_t *expected_frames,
+                       int32_t frame_stride, float *mel, int32_t *mel_lengths);
+
+/* Host copies of the tables (createHannWindow :553-562, createMelFilterbank :564-642). */
+fa_status fa_mel_hann_window(const fa_mel_config *cfg, float *out /* win */);
+fa_status fa_mel_filterbank(const fa_mel_config *cfg, float *out /* n_mels * (n_fft/2+1) */);
+
+/* ------------------------------------------------------------------ argmax / CTC ---- */
+/* Replaces LogitsArgmax.argmaxPerFrame (FluidAudio/ASR/Shared/LogitsArgmax.swift:16-55) and the
+ * greedy collapse of ctcGreedyDecode (FluidAudio/ASR/Parakeet/SlidingWindow/CTC/CtcDecoder.swift:15-36,
+ * 45-70; FluidAudio/ASR/SenseVoice/SenseVoiceManager.swift:119-126). */
+enum { FA_DTYPE_F32 = 0, FA_DTYPE_F16 = 1 };
+
+/* logits: batch matrices, matrix b at element offset b*matrix_stride, row t at t*row_stride,
+ *         `vocab` valid elements per row (padding columns are never read).
+ * valid_frames: int32[batch] (frames to decode per matrix, <= frames) or NULL = all.
+ * frame_ids (optional): int32[batch * frames] per-frame argmax (argmaxPerFrame output).
+ * token_ids: int32[batch * frames] collapsed ids (first token_lens[b] valid per matrix).
+ * Ties -> lowest index; NaN never wins; an all-NaN/-inf row yields 0. */
+fa_status fa_ctc_greedy_batch_dev(fa_ctx *ctx, const void *d_logits, int32_t dtype, int32_t batch, int32_t frames,
+                                  int32_t vocab, int64_t row_stride, int64_t matrix_stride,
+                                  const int32_t *d_valid_frames, int32_t blank_id, int32_t *d_frame_ids,
+                                  int32_t *d_token_ids, int32_t *d_token_lens);
+fa_status fa_ctc_greedy_batch(fa_ctx *ctx, const void *logits, int32_t dtype, int32_t batch, int32_t frames,
+                              int32_t vocab, int64_t row_stride, int64_t matrix_stride,
+                              const int32_t *valid_frames, int32_t blank_id, int32_t *frame_ids,
+                              int32_t *token_ids, int32_t *token_lens);
+
+/* ------------------------------------------------------------------ AHC ------------- */
+/* Exact signature + status contract of the reference FFI
+ * (FastClusterWrapper/include/FastClusterWrapper.h:35-41, FastClusterWrapper.cpp:196-244):
+ * HOST pointers, row-major data, SciPy-format dendrogram rows in merge order.  Declared with
+ * the reference's own names in include/FastClusterWrapper.h (included here):
+ *   fastcluster_wrapper_status fastcluster_compute_centroid_linkage(const double *data,
+ *       size_t pointCount, size_t dimension, double *dendrogramOut, size_t dendrogramLength); */
+#include "FastClusterWrapper.h"
+
+typedef struct {
+    int64_t merges;        /* N-1 */
+    int64_t rounds;        /* select/apply kernel pairs executed */
+    int64_t rescans;       /* lazy row re-scans */
+    int64_t exact_fallback;/* 1 if the Lance-Williams filter hit an ambiguity and the run switched to exact rows */
+    double init_ms, merge_ms, total_ms; /* device time (hipEvent) */
+} fa_ahc_stats;
+
+enum { FA_AHC_MODE_AUTO = 0,   /* Lance-Williams filter + exact re-verification, exact rows on ambiguity */
+       FA_AHC_MODE_EXACT = 1 };/* every matrix entry is the reference's sequential fp64 sum */
+
+/* Same computation with an explicit context; data/dendrogram are HOST pointers unless
+ * device_pointers != 0.  stats may be NULL. */
+fa_status fa_ahc_linkage(fa_ctx *ctx, const double *data, size_t n, size_t d, double *dendrogram,
+                         size_t dendrogram_len, int32_t mode, int32_t device_pointers, fa_ahc_stats *stats);
+
+/* AHCClustering.cluster (FluidAudio/Diarizer/Offline/Clustering/AHCClustering.swift:20-67): L2-normalise
+ * (:70-105), linkage, threshold clamp (:112-121), top-down cut (:124-197), relabel (:200-210).
+ * x: HOST double[n*d]; labels: HOST int32[n].  On linkage failure labels = 0..n-1 (:52-55) and
+ * the failing status is returned. */
+fa_status fa_ahc_cluster(fa_ctx *ctx, const double *x, size_t n, size_t d, double threshold, int32_t mode,
+                         int32_t *labels, fa_ahc_stats *stats);
+/* The cut alone (:124-210) on a host dendrogram. */
+fa_status fa_ahc_cut(const double *dendrogram, size_t n, double threshold, int32_t *labels);
+
+/* ------------------------------------------------------------------ VBx ------------- */
+/* VBxClustering.refine / runVBx (FluidAudio/Diarizer/Offline/Clustering/VBxClustering.swift:41-165,167-664).
+ * HOST pointers.  rho: double[T*D]; initial: int32[T] AHC labels; phi: double[D].
+ * gamma: double[T*S] out, pi: double[S] out, hard: int32[T] out (argmax, first max :144-146),
+ * elbos: double[max_iter] out, n_iters out.  S = number of distinct labels in `initial`
+ * (returned through n_speakers; gamma/pi must be sized for it — query with fa_vbx_speaker_count). */
+int32_t fa_vbx_speaker_count(const int32_t *initial, int64_t T);
+fa_status fa_vbx_refine(fa_ctx *ctx, const double *rho, int64_t T, int32_t D, const int32_t *initial,
+                        const double *phi, double Fa, double Fb, int32_t max_iter, double epsilon,
+                        double *gamma, double *pi, int32_t *hard, double *elbos, int32_t *n_iters,
+                        int32_t *n_speakers);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUIDAUDIO_HIP_H */

@@ -1,0 +1,309 @@
+"""CPU ORACLE bindings (test infrastructure, NOT product code).
+
+ctypes wrappers over ``oracle/libfa_oracle.so`` (C restatement, see fa_oracle.h) and
+``oracle/_ref/libfastcluster_ref.so`` (the reference's own FastClusterWrapper C++ built
+from /root/reference by oracle/Makefile).  Only tests/, ``__graft_entry__.smoke()`` and
+``bench.py``'s cpu_baseline leg may import this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfa_oracle.so")
+_REF_PATH = os.path.join(_HERE, "_ref", "libfastcluster_ref.so")
+
+
+def build(force: bool = False) -> None:
+    """Compile the C restatement and (when /root/reference exists) oracle/_ref."""
+    if force or not os.path.exists(_LIB_PATH) or not os.path.exists(_REF_PATH):
+        subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
+
+
+class _MelCfg(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_int), ("n_mels", C.c_int), ("n_fft", C.c_int), ("hop", C.c_int),
+        ("win", C.c_int), ("preemph", C.c_float), ("pad_to", C.c_int), ("log_floor", C.c_float),
+        ("floor_clamped", C.c_int), ("window_periodic", C.c_int),
+    ]
+
+
+@dataclass
+class MelConfig:
+    sample_rate: int = 16000
+    n_mels: int = 128
+    n_fft: int = 512
+    hop: int = 160
+    win: int = 400
+    preemph: float = 0.97
+    pad_to: int = 0
+    log_floor: float = 2.0 ** -24
+    floor_clamped: bool = False
+    window_periodic: bool = False
+
+    def c(self) -> _MelCfg:
+        return _MelCfg(self.sample_rate, self.n_mels, self.n_fft, self.hop, self.win, self.preemph,
+                       self.pad_to, self.log_floor, int(self.floor_clamped), int(self.window_periodic))
+
+
+_lib = None
+_ref = None
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+LINKAGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        L = _lib
+        L.fa_oracle_hann.argtypes = [C.c_int, C.c_int, _f32p]
+        L.fa_oracle_slaney_filterbank.argtypes = [C.c_int, C.c_int, C.c_int, _f32p]
+        L.fa_oracle_mel_frames_center.argtypes = [C.POINTER(_MelCfg), C.c_long]
+        L.fa_oracle_mel_frames_prepadded.argtypes = [C.POINTER(_MelCfg), C.c_long]
+        L.fa_oracle_mel_padded_frames.argtypes = [C.POINTER(_MelCfg), C.c_int]
+        L.fa_oracle_mel_flat.argtypes = [C.POINTER(_MelCfg), _f32p, C.c_long, C.c_float, _f32p,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.fa_oracle_mel_flat_transposed.argtypes = [C.POINTER(_MelCfg), _f32p, C.c_long, C.c_float, C.c_int,
+                                                    C.c_int, _f32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.fa_oracle_mel_legacy.argtypes = [C.POINTER(_MelCfg), _f32p, C.c_long, _f32p]
+        L.fa_oracle_logmel_generic.argtypes = [_f32p, C.c_long, C.c_int, C.c_int, _f32p, _f32p, C.c_int,
+                                               C.c_int, C.c_float, C.c_int, _f32p]
+        L.fa_oracle_fft_f32.argtypes = [C.c_int, _f32p, _f32p]
+        L.fa_oracle_argmax_rows.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_long, _i32p]
+        L.fa_oracle_ctc_collapse.argtypes = [_i32p, C.c_long, C.c_int32, _i32p]
+        L.fa_oracle_ctc_collapse.restype = C.c_long
+        L.fa_oracle_ctc_greedy.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_long, C.c_int32, _i32p]
+        L.fa_oracle_ctc_greedy.restype = C.c_long
+        L.fa_oracle_ahc_normalize.argtypes = [_f64p, C.c_long, C.c_long, _f64p]
+        L.fa_oracle_ahc_clamp_threshold.argtypes = [C.c_double]
+        L.fa_oracle_ahc_clamp_threshold.restype = C.c_double
+        L.fa_oracle_ahc_cut.argtypes = [_f64p, C.c_long, C.c_double, _i32p]
+        L.fa_oracle_ahc_cluster.argtypes = [C.c_void_p, _f64p, C.c_long, C.c_long, C.c_double, _i32p]
+        L.fa_oracle_linkage_naive.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.fa_oracle_vbx_refine.argtypes = [_f64p, C.c_long, C.c_long, _i32p, _f64p, C.c_int, C.c_double,
+                                           C.c_double, C.c_double, _f64p, _f64p, _i32p, _f64p,
+                                           C.POINTER(C.c_long)]
+        L.fa_oracle_weighted_centroids.argtypes = [_f64p, C.c_long, C.c_long, _f64p, _f64p, C.c_long, _f64p, _i32p]
+        L.fa_oracle_weighted_centroids.restype = C.c_long
+        L.fa_oracle_assign_cosine.argtypes = [_f64p, C.c_long, C.c_long, _f64p, C.c_long, _i32p]
+    return _lib
+
+
+def ref_available() -> bool:
+    return os.path.exists(_REF_PATH)
+
+
+def ref() -> C.CDLL:
+    """The reference's own fastcluster C ABI, built from /root/reference (oracle/_ref)."""
+    global _ref
+    if _ref is None:
+        if not os.path.exists(_REF_PATH):
+            build()
+        _ref = C.CDLL(_REF_PATH)
+        _ref.fastcluster_compute_centroid_linkage.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t,
+                                                              C.c_void_p, C.c_size_t]
+        _ref.fastcluster_compute_centroid_linkage.restype = C.c_int
+    return _ref
+
+
+# ------------------------------------------------------------------ mel
+def hann(win: int, periodic: bool = False) -> np.ndarray:
+    out = np.zeros(win, np.float32)
+    lib().fa_oracle_hann(win, int(periodic), out)
+    return out
+
+
+def slaney_filterbank(n_fft=512, n_mels=128, sample_rate=16000) -> np.ndarray:
+    out = np.zeros((n_mels, n_fft // 2 + 1), np.float32)
+    lib().fa_oracle_slaney_filterbank(n_fft, n_mels, sample_rate, out)
+    return out
+
+
+def mel_frames(cfg: MelConfig, n: int, prepadded: bool = False) -> int:
+    c = cfg.c()
+    f = lib().fa_oracle_mel_frames_prepadded if prepadded else lib().fa_oracle_mel_frames_center
+    return f(C.byref(c), n)
+
+
+def mel_flat(audio, cfg: MelConfig = MelConfig(), last: float = 0.0):
+    """computeFlat -> (mel [n_mels, Tpad], melLength, numFrames)."""
+    a = np.ascontiguousarray(audio, np.float32)
+    c = cfg.c()
+    T = lib().fa_oracle_mel_frames_center(C.byref(c), a.size)
+    tpad = max(1, lib().fa_oracle_mel_padded_frames(C.byref(c), T))
+    out = np.zeros((cfg.n_mels, tpad), np.float32)
+    ml, nf = C.c_int(), C.c_int()
+    rc = lib().fa_oracle_mel_flat(C.byref(c), a if a.size else np.zeros(1, np.float32), a.size, last, out,
+                                  C.byref(ml), C.byref(nf))
+    assert rc == 0
+    return out, ml.value, nf.value
+
+
+def mel_flat_transposed(audio, cfg: MelConfig = MelConfig(), last: float = 0.0, prepadded: bool = False,
+                        expected_frames: int | None = None):
+    """computeFlatTransposed -> (mel [Tpad, n_mels], melLength, numFrames)."""
+    a = np.ascontiguousarray(audio, np.float32)
+    c = cfg.c()
+    T = mel_frames(cfg, a.size, prepadded)
+    if expected_frames is not None and a.size > 0:
+        T = expected_frames
+    tpad = max(1, lib().fa_oracle_mel_padded_frames(C.byref(c), T)) if T > 0 else 1
+    out = np.zeros((tpad, cfg.n_mels), np.float32)
+    ml, nf = C.c_int(), C.c_int()
+    rc = lib().fa_oracle_mel_flat_transposed(C.byref(c), a if a.size else np.zeros(1, np.float32), a.size, last,
+                                             int(prepadded), -1 if expected_frames is None else expected_frames,
+                                             out, C.byref(ml), C.byref(nf))
+    assert rc == 0
+    return out, ml.value, nf.value
+
+
+def mel_legacy(audio, cfg: MelConfig = MelConfig()):
+    a = np.ascontiguousarray(audio, np.float32)
+    T = 1 + int((a.size - cfg.win) / cfg.hop)  # truncating division like Swift
+    if T <= 0:
+        return np.zeros((cfg.n_mels, 0), np.float32), 0
+    out = np.zeros((cfg.n_mels, T), np.float32)
+    c = cfg.c()
+    got = lib().fa_oracle_mel_legacy(C.byref(c), a, a.size, out)
+    assert got == T
+    return out, T
+
+
+def logmel_generic(audio, n_fft, hop, window, fb, power, floor_v, frames):
+    a = np.ascontiguousarray(audio, np.float32)
+    fb = np.ascontiguousarray(fb, np.float32)
+    out = np.zeros((frames, fb.shape[0]), np.float32)
+    lib().fa_oracle_logmel_generic(a, a.size, n_fft, hop, np.ascontiguousarray(window, np.float32), fb,
+                                   fb.shape[0], power, floor_v, frames, out)
+    return out
+
+
+# ------------------------------------------------------------------ argmax / CTC
+def _logits_args(logits: np.ndarray, row_stride):
+    assert logits.dtype in (np.float32, np.float16) and logits.ndim == 2
+    x = np.ascontiguousarray(logits)
+    T, W = x.shape
+    return x, int(x.dtype == np.float16), T, (W if row_stride is None else row_stride)
+
+
+def argmax_rows(logits: np.ndarray, vocab: int | None = None, frames: int | None = None) -> np.ndarray:
+    """logits [T, row_stride]; scans the first `vocab` columns of the first `frames` rows."""
+    x, f16, T, stride = _logits_args(logits, None)
+    V = stride if vocab is None else vocab
+    F = T if frames is None else frames
+    ids = np.zeros(max(F, 1), np.int32)
+    lib().fa_oracle_argmax_rows(x.ctypes.data, f16, F, V, stride, ids)
+    return ids[:F]
+
+
+def ctc_collapse(ids, blank_id: int) -> np.ndarray:
+    ids = np.ascontiguousarray(ids, np.int32)
+    out = np.zeros(max(ids.size, 1), np.int32)
+    n = lib().fa_oracle_ctc_collapse(ids if ids.size else np.zeros(1, np.int32), ids.size, blank_id, out)
+    return out[:n]
+
+
+def ctc_greedy(logits: np.ndarray, blank_id: int, vocab: int | None = None, frames: int | None = None):
+    x, f16, T, stride = _logits_args(logits, None)
+    V = stride if vocab is None else vocab
+    F = T if frames is None else frames
+    out = np.zeros(max(F, 1), np.int32)
+    n = lib().fa_oracle_ctc_greedy(x.ctypes.data, f16, F, V, stride, blank_id, out)
+    return out[:n]
+
+
+# ------------------------------------------------------------------ AHC
+def ahc_normalize(x) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.zeros_like(x)
+    if x.size:
+        lib().fa_oracle_ahc_normalize(x, x.shape[0], x.shape[1], out)
+    return out
+
+
+def ahc_cut(z, n: int, threshold: float) -> np.ndarray:
+    z = np.ascontiguousarray(z, np.float64).reshape(-1)
+    labels = np.zeros(max(n, 1), np.int32)
+    lib().fa_oracle_ahc_cut(z if z.size else np.zeros(4), n, lib().fa_oracle_ahc_clamp_threshold(threshold), labels)
+    return labels[:n]
+
+
+def linkage_ref(x) -> tuple[int, np.ndarray]:
+    """fastcluster_compute_centroid_linkage from the reference's own C++ (oracle/_ref)."""
+    x = np.ascontiguousarray(x, np.float64)
+    n, d = x.shape
+    z = np.zeros((max(n - 1, 0), 4), np.float64)
+    st = ref().fastcluster_compute_centroid_linkage(x.ctypes.data, n, d, z.ctypes.data, z.size)
+    return st, z
+
+
+def linkage_naive(x) -> tuple[int, np.ndarray]:
+    x = np.ascontiguousarray(x, np.float64)
+    n, d = x.shape
+    z = np.zeros((max(n - 1, 0), 4), np.float64)
+    st = lib().fa_oracle_linkage_naive(x.ctypes.data, n, d, z.ctypes.data, z.size)
+    return st, z
+
+
+def ahc_cluster(x, threshold: float, linkage=None) -> np.ndarray:
+    """AHCClustering.cluster; `linkage` = ctypes function with the reference C ABI
+    (default: the reference's own build in oracle/_ref)."""
+    x = np.asarray(x, np.float64)
+    if x.ndim != 2:
+        x = x.reshape(len(x), -1)
+    n, d = x.shape
+    if n == 0:
+        return np.zeros(0, np.int32)
+    fn = linkage if linkage is not None else ref().fastcluster_compute_centroid_linkage
+    labels = np.zeros(n, np.int32)
+    xx = np.ascontiguousarray(x) if d > 0 else np.zeros((n, 1))
+    lib().fa_oracle_ahc_cluster(C.cast(fn, C.c_void_p), xx, n, d, threshold, labels)
+    return labels
+
+
+# ------------------------------------------------------------------ VBx / post-VBx
+def vbx_refine(rho, initial, phi, max_iter=20, epsilon=1e-4, Fa=0.07, Fb=0.8):
+    rho = np.ascontiguousarray(rho, np.float64)
+    T, D = rho.shape
+    initial = np.ascontiguousarray(initial, np.int32)
+    S = len(np.unique(initial))
+    gamma = np.zeros((T, S), np.float64)
+    pi = np.zeros(S, np.float64)
+    hard = np.zeros(T, np.int32)
+    elbos = np.zeros(max(max_iter, 1), np.float64)
+    s_out = C.c_long()
+    it = lib().fa_oracle_vbx_refine(rho, T, D, initial, np.ascontiguousarray(phi, np.float64), max_iter,
+                                    epsilon, Fa, Fb, gamma, pi, hard, elbos, C.byref(s_out))
+    assert s_out.value == S
+    return gamma, pi, hard, elbos[:it]
+
+
+def weighted_centroids(emb, gamma, pi):
+    emb = np.ascontiguousarray(emb, np.float64)
+    gamma = np.ascontiguousarray(gamma, np.float64)
+    pi = np.ascontiguousarray(pi, np.float64)
+    n, d = emb.shape
+    S = pi.size
+    cent = np.zeros((S, d), np.float64)
+    mp = np.zeros(S, np.int32)
+    K = lib().fa_oracle_weighted_centroids(emb, n, d, gamma, pi, S, cent, mp)
+    return cent[:K], mp
+
+
+def assign_cosine(emb, centroids):
+    emb = np.ascontiguousarray(emb, np.float64)
+    centroids = np.ascontiguousarray(centroids, np.float64)
+    out = np.zeros(emb.shape[0], np.int32)
+    lib().fa_oracle_assign_cosine(emb, emb.shape[0], emb.shape[1], centroids if centroids.size else np.zeros((1, 1)),
+                                  centroids.shape[0], out)
+    return out

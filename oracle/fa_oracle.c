@@ -1,0 +1,693 @@
+/*
+ * fa_oracle.c — CPU ORACLE (test infrastructure, NOT product code).  See fa_oracle.h.
+ *
+ * Build with -O2 -ffp-contract=off: the restatement keeps one rounding per
+ * floating-point operation, like the reference's scalar Swift / non-FMA C++ build.
+ */
+#define _GNU_SOURCE
+#include "fa_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ================================ mel ========================================= */
+
+void fa_oracle_mel_default_config(fa_oracle_mel_config *c) {
+    /* AudioMelSpectrogram.swift:59-70 defaults */
+    c->sample_rate = 16000;
+    c->n_mels = 128;
+    c->n_fft = 512;
+    c->hop = 160;
+    c->win = 400;
+    c->preemph = 0.97f;
+    c->pad_to = 0;
+    c->log_floor = ldexpf(1.0f, -24);
+    c->floor_clamped = 0;
+    c->window_periodic = 0;
+}
+
+/* AudioMelSpectrogram.swift:553-562 */
+void fa_oracle_hann(int win, int periodic, float *out) {
+    const float divisor = periodic ? (float)win : (float)(win - 1);
+    const float pi_f = (float)M_PI; /* Float.pi */
+    for (int i = 0; i < win; ++i) {
+        const float phase = 2.0f * pi_f * (float)i / divisor;
+        out[i] = 0.5f * (1.0f - cosf(phase));
+    }
+}
+
+/* AudioMelSpectrogram.swift:575-599 */
+static float hz_to_mel(float hz) {
+    const float f_sp = 200.0f / 3.0f;
+    const float min_log_hz = 1000.0f;
+    const float min_log_mel = min_log_hz / f_sp;
+    const float log_step = logf(6.4f) / 27.0f;
+    if (hz >= min_log_hz) return min_log_mel + logf(hz / min_log_hz) / log_step;
+    return hz / f_sp;
+}
+static float mel_to_hz(float mel) {
+    const float f_sp = 200.0f / 3.0f;
+    const float min_log_hz = 1000.0f;
+    const float min_log_mel = min_log_hz / f_sp;
+    const float log_step = logf(6.4f) / 27.0f;
+    if (mel >= min_log_mel) return min_log_hz * expf(log_step * (mel - min_log_mel));
+    return f_sp * mel;
+}
+
+/* AudioMelSpectrogram.swift:564-642 */
+void fa_oracle_slaney_filterbank(int n_fft, int n_mels, int sample_rate, float *out) {
+    const int bins = n_fft / 2 + 1;
+    const float f_min = 0.0f, f_max = (float)sample_rate / 2.0f;
+    const float mel_min = hz_to_mel(f_min), mel_max = hz_to_mel(f_max);
+    float *pts = (float *)malloc(sizeof(float) * (size_t)(n_mels + 2));
+    float *freqs = (float *)malloc(sizeof(float) * (size_t)bins);
+    for (int i = 0; i < n_mels + 2; ++i) {
+        const float mel = mel_min + (float)i * (mel_max - mel_min) / (float)(n_mels + 1);
+        pts[i] = mel_to_hz(mel);
+    }
+    for (int i = 0; i < bins; ++i) freqs[i] = (float)i * (float)sample_rate / (float)n_fft;
+    memset(out, 0, sizeof(float) * (size_t)n_mels * (size_t)bins);
+    for (int m = 0; m < n_mels; ++m) {
+        const float fl = pts[m], fc = pts[m + 1], fr = pts[m + 2];
+        const float norm = 2.0f / (fr - fl);
+        for (int k = 0; k < bins; ++k) {
+            const float f = freqs[k];
+            if (f >= fl && f < fc) out[(size_t)m * bins + k] = norm * (f - fl) / (fc - fl);
+            else if (f >= fc && f <= fr) out[(size_t)m * bins + k] = norm * (fr - f) / (fr - fc);
+        }
+    }
+    free(pts);
+    free(freqs);
+}
+
+/* fp32 iterative radix-2 DIT FFT, twiddles rounded from double.  Stand-in for
+ * vDSP_DFT_zop (AudioMelSpectrogram.swift:107-111,471) whose internal order is closed. */
+void fa_oracle_fft_f32(int n, float *re, float *im) {
+    int j = 0;
+    for (int i = 1; i < n; ++i) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            float t = re[i]; re[i] = re[j]; re[j] = t;
+            t = im[i]; im[i] = im[j]; im[j] = t;
+        }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        const int half = len >> 1;
+        for (int k = 0; k < half; ++k) {
+            const double ang = -2.0 * M_PI * (double)k / (double)len;
+            const float wr = (float)cos(ang), wi = (float)sin(ang);
+            for (int s = k; s < n; s += len) {
+                const int t = s + half;
+                const float xr = re[t] * wr - im[t] * wi;
+                const float xi = re[t] * wi + im[t] * wr;
+                re[t] = re[s] - xr; im[t] = im[s] - xi;
+                re[s] = re[s] + xr; im[s] = im[s] + xi;
+            }
+        }
+    }
+}
+
+int fa_oracle_mel_frames_center(const fa_oracle_mel_config *c, long n) {
+    /* :195-197, :341-343 */
+    const long padded = n + 2 * (long)(c->n_fft / 2);
+    const long frames = 1 + (padded - c->win) / c->hop;
+    if (frames <= 0 || n <= 0) return 0;
+    return (int)frames;
+}
+int fa_oracle_mel_frames_prepadded(const fa_oracle_mel_config *c, long n) {
+    /* :345 */
+    long frames = (n - c->n_fft) / c->hop + 1;
+    if (frames < 0) frames = 0;
+    if (n <= 0) return 0;
+    return (int)frames;
+}
+int fa_oracle_mel_padded_frames(const fa_oracle_mel_config *c, int frames) {
+    const int pad_to = c->pad_to > 1 ? c->pad_to : 1; /* :72 */
+    return ((frames + pad_to - 1) / pad_to) * pad_to; /* :204 == :354 for frames>0 */
+}
+
+static float log_value(const fa_oracle_mel_config *c, float v) {
+    /* :542-549 */
+    if (c->floor_clamped) return logf(v > c->log_floor ? v : c->log_floor);
+    return logf(v + c->log_floor);
+}
+
+/* shared body of computeFlat / computeFlatTransposed (:185-292, :325-456) */
+static int mel_body(const fa_oracle_mel_config *c, const float *audio, long n, float last,
+                    int prepadded, int frames, int transposed, int special_case_zero_preemph,
+                    float *out, int *mel_length, int *num_frames) {
+    const int nfft = c->n_fft, bins = nfft / 2 + 1, nm = c->n_mels;
+    if (frames <= 0 || n <= 0) {
+        /* guard (:199-201, :349-351): [padValue]*nMels, melLength 0, numFrames 1 */
+        for (int m = 0; m < nm; ++m) out[m] = 0.0f;
+        *mel_length = 0;
+        *num_frames = 1;
+        return 0;
+    }
+    const int tpad = fa_oracle_mel_padded_frames(c, frames);
+    const long pad = prepadded ? 0 : nfft / 2;
+    const long pc = n + 2 * pad;
+    float *padded = (float *)calloc((size_t)pc, sizeof(float));
+    float *hann = (float *)malloc(sizeof(float) * (size_t)c->win);
+    float *fb = (float *)malloc(sizeof(float) * (size_t)nm * (size_t)bins);
+    float *re = (float *)malloc(sizeof(float) * (size_t)nfft);
+    float *im = (float *)malloc(sizeof(float) * (size_t)nfft);
+    float *pw = (float *)malloc(sizeof(float) * (size_t)bins);
+    if (!padded || !hann || !fb || !re || !im || !pw) return -1;
+    fa_oracle_hann(c->win, c->window_periodic, hann);
+    fa_oracle_slaney_filterbank(nfft, nm, c->sample_rate, fb);
+
+    if (special_case_zero_preemph && c->preemph == 0.0f) {
+        memcpy(padded + pad, audio, sizeof(float) * (size_t)n); /* :363-371 */
+    } else {
+        padded[pad] = audio[0] - c->preemph * last; /* :211, :373 */
+        const float neg = -c->preemph;
+        for (long i = 0; i + 1 < n; ++i) padded[pad + 1 + i] = audio[i] * neg + audio[i + 1]; /* vDSP_vsma :219-225 */
+    }
+    memset(out, 0, sizeof(float) * (size_t)nm * (size_t)tpad);
+    const int off = (nfft - c->win) / 2; /* :234 */
+    for (int t = 0; t < frames; ++t) {
+        memset(re, 0, sizeof(float) * (size_t)nfft);
+        memset(im, 0, sizeof(float) * (size_t)nfft);
+        const long a = (long)t * c->hop + off;
+        long avail = pc - a;
+        if (avail > c->win) avail = c->win; /* :248 */
+        for (long i = 0; i < avail; ++i) re[off + i] = padded[a + i] * hann[i];
+        fa_oracle_fft_f32(nfft, re, im);
+        for (int k = 0; k < bins; ++k) {
+            const float r2 = re[k] * re[k], i2 = im[k] * im[k]; /* vsq, vsq, vadd :476-480 */
+            pw[k] = r2 + i2;
+        }
+        for (int m = 0; m < nm; ++m) {
+            float s = 0.0f;
+            const float *row = fb + (size_t)m * bins;
+            for (int k = 0; k < bins; ++k) s += row[k] * pw[k]; /* vDSP_mmul :273-281 */
+            const float v = log_value(c, s);
+            if (transposed) out[(size_t)t * nm + m] = v; /* :451 */
+            else out[(size_t)m * tpad + t] = v;          /* :287 */
+        }
+    }
+    free(padded); free(hann); free(fb); free(re); free(im); free(pw);
+    *mel_length = frames;
+    *num_frames = tpad;
+    return 0;
+}
+
+int fa_oracle_mel_flat(const fa_oracle_mel_config *c, const float *audio, long n, float last,
+                       float *out, int *mel_length, int *num_frames) {
+    /* computeFlat has no preemph==0 special case (:206-227) */
+    return mel_body(c, audio, n, last, 0, fa_oracle_mel_frames_center(c, n), 0, 0, out, mel_length, num_frames);
+}
+
+int fa_oracle_mel_flat_transposed(const fa_oracle_mel_config *c, const float *audio, long n, float last,
+                                  int prepadded, int expected_frames, float *out, int *mel_length,
+                                  int *num_frames) {
+    int frames = prepadded ? fa_oracle_mel_frames_prepadded(c, n) : fa_oracle_mel_frames_center(c, n);
+    if (expected_frames >= 0 && n > 0) frames = expected_frames; /* :347 */
+    return mel_body(c, audio, n, last, prepadded, frames, 1, 1, out, mel_length, num_frames);
+}
+
+int fa_oracle_mel_legacy(const fa_oracle_mel_config *c, const float *audio, long n, float *out) {
+    /* compute (:132-178) */
+    if (n < c->win) {
+        /* Swift Int division truncates toward zero: 1 + (n-win)/hop can still be 1 for
+         * -hop < n-win < 0; the loop then windows what exists (:148-153). */
+    }
+    const long frames = 1 + (n - c->win) / c->hop;
+    if (frames <= 0) return 0;
+    const int nfft = c->n_fft, bins = nfft / 2 + 1, nm = c->n_mels;
+    float *hann = (float *)malloc(sizeof(float) * (size_t)c->win);
+    float *fb = (float *)malloc(sizeof(float) * (size_t)nm * (size_t)bins);
+    float *re = (float *)malloc(sizeof(float) * (size_t)nfft);
+    float *im = (float *)malloc(sizeof(float) * (size_t)nfft);
+    fa_oracle_hann(c->win, c->window_periodic, hann);
+    fa_oracle_slaney_filterbank(nfft, nm, c->sample_rate, fb);
+    for (long t = 0; t < frames; ++t) {
+        memset(re, 0, sizeof(float) * (size_t)nfft);
+        memset(im, 0, sizeof(float) * (size_t)nfft);
+        for (int i = 0; i < c->win; ++i) {
+            const long idx = t * c->hop + i;
+            if (idx >= 0 && idx < n) re[i] = audio[idx] * hann[i];
+        }
+        fa_oracle_fft_f32(nfft, re, im);
+        for (int m = 0; m < nm; ++m) {
+            float s = 0.0f;
+            for (int k = 0; k < bins; ++k) {
+                const float p = re[k] * re[k] + im[k] * im[k]; /* :522 */
+                s += fb[(size_t)m * bins + k] * p;             /* :534 */
+            }
+            out[(size_t)m * frames + t] = log_value(c, s);
+        }
+    }
+    free(hann); free(fb); free(re); free(im);
+    return (int)frames;
+}
+
+int fa_oracle_logmel_generic(const float *audio, long n, int n_fft, int hop, const float *window,
+                             const float *fb, int n_mels, int power, float floor_v, int frames,
+                             float *out) {
+    /* TTS/LuxTts/LuxTtsMelExtractor.swift:52-132 */
+    if (n <= 0 || frames <= 0) return 0;
+    const int pad = n_fft / 2, bins = n_fft / 2 + 1;
+    float *padded = (float *)calloc((size_t)(n + 2 * pad), sizeof(float));
+    float *re = (float *)malloc(sizeof(float) * (size_t)n_fft);
+    float *im = (float *)malloc(sizeof(float) * (size_t)n_fft);
+    float *mag = (float *)malloc(sizeof(float) * (size_t)bins);
+    for (int i = 0; i < pad; ++i) { /* :63-66 */
+        long a = pad - i; if (a > n - 1) a = n - 1;
+        long b = n - 2 - i; if (b < 0) b = 0;
+        padded[i] = audio[a];
+        padded[pad + n + i] = audio[b];
+    }
+    memcpy(padded + pad, audio, sizeof(float) * (size_t)n);
+    const long stft_frames = 1 + n / hop; /* :70 */
+    int produced = 0;
+    for (int t = 0; t < frames && t < stft_frames; ++t) {
+        const long start = (long)t * hop;
+        for (int i = 0; i < n_fft; ++i) { re[i] = padded[start + i] * window[i]; im[i] = 0.0f; }
+        fa_oracle_fft_f32(n_fft, re, im);
+        for (int k = 0; k < bins; ++k) {
+            const float r2 = re[k] * re[k], i2 = im[k] * im[k];
+            const float p = r2 + i2;
+            mag[k] = power == 1 ? sqrtf(p) : p;
+        }
+        for (int m = 0; m < n_mels; ++m) {
+            float s = 0.0f;
+            for (int k = 0; k < bins; ++k) s += fb[(size_t)m * bins + k] * mag[k];
+            out[(size_t)t * n_mels + m] = logf(s > floor_v ? s : floor_v);
+        }
+        produced = t + 1;
+    }
+    for (int t = produced; t < frames && produced > 0; ++t) /* :124-126 replicate last frame */
+        memcpy(out + (size_t)t * n_mels, out + (size_t)(produced - 1) * n_mels, sizeof(float) * (size_t)n_mels);
+    free(padded); free(re); free(im); free(mag);
+    return frames;
+}
+
+/* ============================ argmax + CTC greedy ================================= */
+
+static float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {
+            int e = -1;
+            do { man <<= 1; ++e; } while (!(man & 0x400u));
+            bits = sign | (uint32_t)(127 - 15 - e) << 23 | (man & 0x3ffu) << 13;
+        }
+    } else if (exp == 31) bits = sign | 0x7f800000u | man << 13;
+    else bits = sign | (exp + 127 - 15) << 23 | man << 13;
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+void fa_oracle_argmax_rows(const void *logits, int is_f16, long frames, long vocab, long row_stride,
+                           int32_t *ids) {
+    /* LogitsArgmax.swift:22-28 (+ :33-52 for fp16); tie/NaN rule of CtcDecoder.swift:55-64:
+     * seed -inf at index 0, strict '>' => lowest index wins ties, NaN never wins. */
+    for (long t = 0; t < frames; ++t) {
+        float best = -INFINITY;
+        int32_t bi = 0;
+        for (long v = 0; v < vocab; ++v) {
+            const float x = is_f16 ? half_to_float(((const uint16_t *)logits)[t * row_stride + v])
+                                   : ((const float *)logits)[t * row_stride + v];
+            if (x > best) { best = x; bi = (int32_t)v; }
+        }
+        ids[t] = bi;
+    }
+}
+
+long fa_oracle_ctc_collapse(const int32_t *frame_ids, long frames, int32_t blank_id, int32_t *out) {
+    /* CtcDecoder.swift:52-68 ; SenseVoiceManager.swift:119-126 */
+    long n = 0;
+    int32_t prev = -1;
+    for (long t = 0; t < frames; ++t) {
+        const int32_t b = frame_ids[t];
+        if (b != blank_id && b != prev) out[n++] = b;
+        prev = b;
+    }
+    return n;
+}
+
+long fa_oracle_ctc_greedy(const void *logits, int is_f16, long frames, long vocab, long row_stride,
+                          int32_t blank_id, int32_t *out) {
+    if (frames <= 0) return 0;
+    int32_t *ids = (int32_t *)malloc(sizeof(int32_t) * (size_t)frames);
+    fa_oracle_argmax_rows(logits, is_f16, frames, vocab, row_stride, ids);
+    const long n = fa_oracle_ctc_collapse(ids, frames, blank_id, out);
+    free(ids);
+    return n;
+}
+
+/* ================================ AHC pre/post ==================================== */
+
+void fa_oracle_ahc_normalize(const double *x, long n, long d, double *out) {
+    /* AHCClustering.swift:70-105 */
+    for (long i = 0; i < n; ++i) {
+        double norm = 0.0;
+        for (long k = 0; k < d; ++k) norm += x[i * d + k] * x[i * d + k]; /* vDSP_dotprD */
+        const double scale = norm > 0 ? 1.0 / sqrt(norm) : 0.0;
+        for (long k = 0; k < d; ++k) out[i * d + k] = x[i * d + k] * scale; /* vDSP_vsmulD */
+    }
+}
+
+double fa_oracle_ahc_clamp_threshold(double thr) {
+    /* AHCClustering.swift:112-121 */
+    if (thr != thr) return 0.0;
+    if (thr < 0.0) return 0.0;
+    if (thr > 2.0) return 2.0;
+    return thr;
+}
+
+void fa_oracle_ahc_cut(const double *z, long n, double thr, int32_t *labels) {
+    /* AHCClustering.swift:124-197 then :200-210 */
+    if (n <= 0) return;
+    if (n == 1) { labels[0] = 0; return; }
+    const long total = 2 * n - 1;
+    long *left = (long *)malloc(sizeof(long) * (size_t)total);
+    long *right = (long *)malloc(sizeof(long) * (size_t)total);
+    double *h = (double *)calloc((size_t)total, sizeof(double));
+    long *stack = (long *)malloc(sizeof(long) * (size_t)(2 * total + 2));
+    long *queue = (long *)malloc(sizeof(long) * (size_t)(2 * total + 2));
+    long *assign = (long *)malloc(sizeof(long) * (size_t)n);
+    for (long i = 0; i < total; ++i) left[i] = right[i] = -1;
+    for (long r = 0; r < n - 1; ++r) {
+        left[n + r] = (long)z[4 * r];
+        right[n + r] = (long)z[4 * r + 1];
+        h[n + r] = z[4 * r + 2];
+    }
+    for (long i = 0; i < n; ++i) assign[i] = -1;
+    long sp = 0, next = 0;
+    stack[sp++] = total - 1;
+    while (sp > 0) {
+        const long node = stack[--sp];
+        if (node < 0) continue;
+        if (node < n) {
+            if (assign[node] == -1) assign[node] = next++;
+            continue;
+        }
+        if (h[node] <= thr) {
+            const long label = next++;
+            long qp = 0;
+            queue[qp++] = node;
+            while (qp > 0) {
+                const long cur = queue[--qp];
+                if (cur < n) assign[cur] = label;
+                else {
+                    if (left[cur] >= 0) queue[qp++] = left[cur];
+                    if (right[cur] >= 0) queue[qp++] = right[cur];
+                }
+            }
+        } else {
+            if (left[node] >= 0) stack[sp++] = left[node];
+            if (right[node] >= 0) stack[sp++] = right[node];
+        }
+    }
+    for (long i = 0; i < n; ++i) if (assign[i] == -1) assign[i] = next++;
+    /* remapClusterIds: first-appearance order */
+    long *map = (long *)malloc(sizeof(long) * (size_t)(next + 1));
+    for (long i = 0; i <= next; ++i) map[i] = -1;
+    long nid = 0;
+    for (long i = 0; i < n; ++i) {
+        if (map[assign[i]] < 0) map[assign[i]] = nid++;
+        labels[i] = (int32_t)map[assign[i]];
+    }
+    free(left); free(right); free(h); free(stack); free(queue); free(assign); free(map);
+}
+
+int fa_oracle_ahc_cluster(fa_oracle_linkage_fn linkage, const double *x, long n, long d,
+                          double threshold, int32_t *labels) {
+    /* AHCClustering.swift:20-67 */
+    if (n <= 0) return 0;
+    if (d <= 0) { for (long i = 0; i < n; ++i) labels[i] = 0; return 0; }
+    if (n == 1) { labels[0] = 0; return 0; }
+    double *norm = (double *)malloc(sizeof(double) * (size_t)n * (size_t)d);
+    double *z = (double *)calloc((size_t)(n - 1) * 4, sizeof(double));
+    fa_oracle_ahc_normalize(x, n, d, norm);
+    const int status = linkage(norm, (size_t)n, (size_t)d, z, (size_t)(n - 1) * 4);
+    if (status != 0) {
+        for (long i = 0; i < n; ++i) labels[i] = (int32_t)i; /* :52-55 */
+    } else {
+        fa_oracle_ahc_cut(z, n, fa_oracle_ahc_clamp_threshold(threshold), labels);
+    }
+    free(norm); free(z);
+    return status;
+}
+
+static double sqeuclid(const double *a, const double *b, size_t d) {
+    /* FastClusterWrapper.cpp:45-52,68-75 */
+    double s = 0.0;
+    for (size_t k = 0; k < d; ++k) { const double diff = a[k] - b[k]; s += diff * diff; }
+    return s;
+}
+
+int fa_oracle_linkage_naive(const double *data, size_t n, size_t d, double *z, size_t zlen) {
+    /* status contract: FastClusterWrapper.cpp:203-243 */
+    if (!data || !z) return 1;
+    if (n == 0) return 0;
+    if (d == 0) return 1;
+    if (n > 0x7fffffffu || d > 0x7fffffffu) return 2;
+    if (zlen < (n > 1 ? (n - 1) * 4 : 0)) return 3;
+    if (n == 1) return 0;
+    const size_t total = 2 * n - 1;
+    double *pts = (double *)malloc(sizeof(double) * total * d);
+    double *size = (double *)malloc(sizeof(double) * total);
+    char *active = (char *)calloc(total, 1);
+    if (!pts || !size || !active) { free(pts); free(size); free(active); return 4; }
+    memcpy(pts, data, sizeof(double) * n * d);
+    for (size_t i = 0; i < n; ++i) { active[i] = 1; size[i] = 1.0; }
+    int status = 0;
+    for (size_t step = 0; step + 1 < n && status == 0; ++step) {
+        double best = INFINITY;
+        size_t bi = 0, bj = 0;
+        int found = 0;
+        for (size_t i = 0; i < n + step; ++i) {
+            if (!active[i]) continue;
+            for (size_t j = 0; j < i; ++j) {
+                if (!active[j]) continue;
+                const double v = sqeuclid(pts + i * d, pts + j * d, d);
+                if (v != v) { status = 5; break; }
+                if (!found || v < best) { best = v; bi = i; bj = j; found = 1; }
+            }
+            if (status) break;
+        }
+        if (status) break;
+        const size_t c = n + step;
+        const double mi = size[bi], mj = size[bj], den = mi + mj;
+        for (size_t k = 0; k < d; ++k) /* merge: FastClusterWrapper.cpp:89-100 */
+            pts[c * d + k] = (pts[bi * d + k] * mi + pts[bj * d + k] * mj) / den;
+        size[c] = den;
+        active[bi] = active[bj] = 0;
+        active[c] = 1;
+        z[4 * step + 0] = (double)(bi < bj ? bi : bj); /* LinkageOutput::append :150-160 */
+        z[4 * step + 1] = (double)(bi < bj ? bj : bi);
+        z[4 * step + 2] = sqrt(best);                  /* postprocess :128-130 */
+        z[4 * step + 3] = den;
+    }
+    free(pts); free(size); free(active);
+    return status;
+}
+
+/* ==================================== VBx ========================================= */
+
+int fa_oracle_vbx_run(const double *features, long T, long D, const double *phi,
+                      double *gamma, long S, int max_iter, double epsilon,
+                      double Fa, double Fb, double init_smoothing,
+                      double *pi, double *elbos) {
+    /* VBxClustering.swift:167-664 */
+    double *row = (double *)malloc(sizeof(double) * (size_t)S);
+    if (init_smoothing >= 0.0) { /* :190-219 */
+        for (long t = 0; t < T; ++t) {
+            double *g = gamma + t * S;
+            double mx = -1.7976931348623157e308;
+            for (long s = 0; s < S; ++s) { row[s] = g[s] * init_smoothing; if (row[s] > mx) mx = row[s]; }
+            double sum = 0.0;
+            for (long s = 0; s < S; ++s) { row[s] = exp(row[s] + (-mx)); sum += row[s]; }
+            if (sum <= 0.0 || !isfinite(sum)) for (long s = 0; s < S; ++s) g[s] = 1.0 / (double)S;
+            else { const double inv = 1.0 / sum; for (long s = 0; s < S; ++s) g[s] = row[s] * inv; }
+        }
+    }
+    for (long t = 0; t < T; ++t) { /* :222-237 */
+        double *g = gamma + t * S;
+        double sum = 0.0;
+        for (long s = 0; s < S; ++s) sum += g[s];
+        if (sum <= 0.0 || !isfinite(sum)) for (long s = 0; s < S; ++s) g[s] = 1.0 / (double)S;
+        else { const double inv = 1.0 / sum; for (long s = 0; s < S; ++s) g[s] *= inv; }
+    }
+    for (long s = 0; s < S; ++s) pi[s] = 1.0 / (double)S; /* :239 */
+    double *phic = (double *)malloc(sizeof(double) * (size_t)D);
+    double *rho = (double *)malloc(sizeof(double) * (size_t)T * (size_t)D);
+    double *G = (double *)malloc(sizeof(double) * (size_t)T);
+    double *invL = (double *)malloc(sizeof(double) * (size_t)S * (size_t)D);
+    double *alpha = (double *)malloc(sizeof(double) * (size_t)S * (size_t)D);
+    double *phiT = (double *)malloc(sizeof(double) * (size_t)S);
+    double *gsum = (double *)malloc(sizeof(double) * (size_t)S);
+    double *logP = (double *)malloc(sizeof(double) * (size_t)T * (size_t)S);
+    double *logPi = (double *)malloc(sizeof(double) * (size_t)S);
+    for (long d = 0; d < D; ++d) phic[d] = phi[d] > 1e-12 ? phi[d] : 1e-12; /* :241 */
+    for (long t = 0; t < T; ++t)
+        for (long d = 0; d < D; ++d) rho[t * D + d] = features[t * D + d] * sqrt(phic[d]); /* :242-265 */
+    const double log_const = (double)D * log(2.0 * M_PI);
+    for (long t = 0; t < T; ++t) { /* :267-282 */
+        double ss = 0.0;
+        for (long d = 0; d < D; ++d) ss += features[t * D + d] * features[t * D + d];
+        G[t] = -0.5 * (ss + log_const);
+    }
+    const double ratio = Fa / Fb;
+    double prev = -1.7976931348623157e308;
+    int iters = 0;
+    for (int it = 0; it < max_iter; ++it) {
+        iters = it + 1;
+        for (long s = 0; s < S; ++s) gsum[s] = 0.0; /* dgemv :312-325 */
+        for (long t = 0; t < T; ++t) for (long s = 0; s < S; ++s) gsum[s] += gamma[t * S + s];
+        for (long s = 0; s < S; ++s) { /* :330-337 */
+            const double w = ratio * gsum[s];
+            for (long d = 0; d < D; ++d) {
+                const double den = 1.0 + w * phic[d];
+                invL[s * D + d] = 1.0 / (den > 1e-12 ? den : 1e-12);
+            }
+        }
+        for (long i = 0; i < S * D; ++i) alpha[i] = 0.0; /* dgemm gamma^T rho :342-357 */
+        for (long t = 0; t < T; ++t)
+            for (long s = 0; s < S; ++s) {
+                const double g = gamma[t * S + s];
+                if (g == 0.0) continue;
+                for (long d = 0; d < D; ++d) alpha[s * D + d] += g * rho[t * D + d];
+            }
+        for (long i = 0; i < S * D; ++i) alpha[i] = (alpha[i] * invL[i]) * ratio; /* :370-387 */
+        for (long s = 0; s < S; ++s) { /* :402-432 */
+            double sum = 0.0;
+            for (long d = 0; d < D; ++d) sum += (alpha[s * D + d] * alpha[s * D + d] + invL[s * D + d]) * phic[d];
+            phiT[s] = sum;
+        }
+        for (long t = 0; t < T; ++t) /* dgemm rho alpha^T :441-456, then :485-492 */
+            for (long s = 0; s < S; ++s) {
+                double dot = 0.0;
+                for (long d = 0; d < D; ++d) dot += rho[t * D + d] * alpha[s * D + d];
+                logP[t * S + s] = ((dot + phiT[s] * -0.5) + G[t]) * Fa;
+            }
+        for (long s = 0; s < S; ++s) logPi[s] = log(pi[s] >= 1e-8 ? pi[s] : 1e-8); /* :498-514 */
+        double ll = 0.0;
+        for (long t = 0; t < T; ++t) { /* :516-572 */
+            double mx = -1.7976931348623157e308;
+            for (long s = 0; s < S; ++s) { row[s] = logP[t * S + s] + logPi[s]; if (row[s] > mx) mx = row[s]; }
+            double sum = 0.0;
+            for (long s = 0; s < S; ++s) { row[s] = exp(row[s] + (-mx)); sum += row[s]; }
+            if (sum <= 0.0 || !isfinite(sum)) {
+                for (long s = 0; s < S; ++s) gamma[t * S + s] = 1.0 / (double)S;
+                ll += mx;
+            } else {
+                const double inv = 1.0 / sum;
+                for (long s = 0; s < S; ++s) gamma[t * S + s] = row[s] * inv;
+                ll += mx + log(sum);
+            }
+        }
+        for (long s = 0; s < S; ++s) pi[s] = 0.0; /* :586-621 */
+        for (long t = 0; t < T; ++t) for (long s = 0; s < S; ++s) pi[s] += gamma[t * S + s];
+        double psum = 0.0;
+        for (long s = 0; s < S; ++s) psum += pi[s];
+        if (psum > 0.0 && isfinite(psum)) { const double inv = 1.0 / psum; for (long s = 0; s < S; ++s) pi[s] *= inv; }
+        else for (long s = 0; s < S; ++s) pi[s] = 1.0 / (double)S;
+        double sli = 0.0, si = 0.0, sa = 0.0; /* :623-647 */
+        for (long i = 0; i < S * D; ++i) { sli += log(invL[i]); si += invL[i]; sa += alpha[i] * alpha[i]; }
+        const double elbo = ll + Fb * 0.5 * (sli - si - sa + (double)(S * D));
+        elbos[it] = elbo;
+        if (it > 0 && fabs(elbo - prev) < epsilon) { prev = elbo; break; } /* :653-659 */
+        prev = elbo;
+    }
+    free(row); free(phic); free(rho); free(G); free(invL); free(alpha); free(phiT); free(gsum);
+    free(logP); free(logPi);
+    return iters;
+}
+
+static int cmp_i32(const void *a, const void *b) {
+    const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return (x > y) - (x < y);
+}
+
+int fa_oracle_vbx_refine(const double *rho, long T, long D, const int32_t *initial, const double *phi,
+                         int max_iter, double epsilon, double Fa, double Fb,
+                         double *gamma, double *pi, int32_t *hard, double *elbos, long *S_out) {
+    /* VBxClustering.swift:41-165 */
+    if (T <= 0 || D <= 0) { *S_out = 0; return 0; }
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (size_t)T);
+    memcpy(tmp, initial, sizeof(int32_t) * (size_t)T);
+    qsort(tmp, (size_t)T, sizeof(int32_t), cmp_i32);
+    long S = 1;
+    for (long i = 1; i < T; ++i) if (tmp[i] != tmp[i - 1]) ++S; /* Set(initialClusters).count :78 */
+    free(tmp);
+    memset(gamma, 0, sizeof(double) * (size_t)T * (size_t)S);
+    for (long t = 0; t < T; ++t) { /* :102-107 */
+        long sp = initial[t];
+        if (sp > S - 1) sp = S - 1;
+        if (sp < 0) sp = 0;
+        gamma[t * S + sp] = 1.0;
+    }
+    const int iters = fa_oracle_vbx_run(rho, T, D, phi, gamma, S, max_iter, epsilon, Fa, Fb, 7.0, pi, elbos);
+    for (long t = 0; t < T; ++t) { /* :144-146 first max */
+        long b = 0;
+        for (long s = 1; s < S; ++s) if (gamma[t * S + b] < gamma[t * S + s]) b = s;
+        hard[t] = (int32_t)b;
+    }
+    *S_out = S;
+    return iters;
+}
+
+/* ================================= post-VBx ======================================= */
+
+long fa_oracle_weighted_centroids(const double *emb, long n, long d, const double *gamma, const double *pi,
+                                  long S, double *centroids, int32_t *map) {
+    /* OfflineDiarizerManager.swift:630-684 */
+    long K = 0;
+    for (long s = 0; s < S; ++s) {
+        map[s] = -1;
+        if (!(pi[s] > 1e-7)) continue;
+        double *num = centroids + K * d;
+        for (long k = 0; k < d; ++k) num[k] = 0.0;
+        double den = 0.0;
+        for (long t = 0; t < n; ++t) {
+            const double w = gamma[t * S + s];
+            if (!(w > 0)) continue;
+            den += w;
+            for (long k = 0; k < d; ++k) num[k] += w * emb[t * d + k]; /* cblas_daxpy */
+        }
+        if (den > 0) for (long k = 0; k < d; ++k) num[k] /= den;
+        else for (long k = 0; k < d; ++k) num[k] = 0.0;
+        map[s] = (int32_t)K++;
+    }
+    return K;
+}
+
+static void normalize_vec(const double *v, long d, double *out) {
+    /* OfflineDiarizerManager.swift:824-859: sumSquares <= 0 returns the vector unchanged */
+    double ss = 0.0;
+    for (long k = 0; k < d; ++k) ss += v[k] * v[k];
+    const double scale = ss <= 0 ? 1.0 : 1.0 / sqrt(ss);
+    for (long k = 0; k < d; ++k) out[k] = ss <= 0 ? v[k] : v[k] * scale;
+}
+
+void fa_oracle_assign_cosine(const double *emb, long n, long d, const double *centroids, long K,
+                             int32_t *out) {
+    /* OfflineDiarizerManager.swift:789-822 */
+    if (K <= 0) { for (long i = 0; i < n; ++i) out[i] = 0; return; }
+    double *cn = (double *)malloc(sizeof(double) * (size_t)K * (size_t)d);
+    double *e = (double *)malloc(sizeof(double) * (size_t)d);
+    for (long k = 0; k < K; ++k) normalize_vec(centroids + k * d, d, cn + k * d);
+    for (long i = 0; i < n; ++i) {
+        normalize_vec(emb + i * d, d, e);
+        double best = -INFINITY;
+        int32_t bi = 0;
+        for (long k = 0; k < K; ++k) {
+            double dot = 0.0;
+            for (long j = 0; j < d; ++j) dot += e[j] * cn[k * d + j];
+            if (dot > best) { best = dot; bi = (int32_t)k; }
+        }
+        out[i] = bi;
+    }
+    free(cn); free(e);
+}

@@ -1,0 +1,85 @@
+"""Host-side logic of the library that runs without a GPU: frame arithmetic, tables, dendrogram cut, Python mirrors."""
+import ctypes as C
+
+import numpy as np
+from conftest import same_partition
+
+
+def test_frame_arithmetic_matches_oracle(fa, oracle_mod):
+    L = fa._lib
+    for pm, pre in ((L.MEL_PAD_CENTER, False), (L.MEL_PAD_PREPADDED, True)):
+        cfg = L.MelConfig()
+        fa.lib().fa_mel_default_config(C.byref(cfg))
+        cfg.padding_mode = pm
+        for n in (0, 1, 47, 48, 159, 160, 351, 352, 353, 511, 512, 513, 16000, 240000, 12345):
+            assert fa.lib().fa_mel_num_frames(C.byref(cfg), n) == oracle_mod.mel_frames(oracle_mod.MelConfig(), n, pre), (pm, n)
+    cfg.padding_mode = L.MEL_PAD_LEGACY
+    assert fa.lib().fa_mel_num_frames(C.byref(cfg), 16000) == 98          # AudioMelSpectrogramTests.swift:32-45
+    assert fa.lib().fa_mel_num_frames(C.byref(cfg), 300) == 1            # Swift truncating division: 1 + (-100)/160
+    assert fa.lib().fa_mel_num_frames(C.byref(cfg), 0) == 0
+    cfg.pad_to = 16
+    assert fa.lib().fa_mel_padded_frames(C.byref(cfg), 101) == 112
+
+
+def test_tables_bit_identical_to_oracle(fa, oracle_mod):
+    L = fa._lib
+    for periodic in (0, 1):
+        for n_mels in (128, 80):
+            cfg = L.MelConfig()
+            fa.lib().fa_mel_default_config(C.byref(cfg))
+            cfg.window_periodic, cfg.n_mels = periodic, n_mels
+            w = np.zeros(400, np.float32)
+            fb = np.zeros((n_mels, 257), np.float32)
+            assert fa.lib().fa_mel_hann_window(C.byref(cfg), w.ctypes.data) == 0
+            assert fa.lib().fa_mel_filterbank(C.byref(cfg), fb.ctypes.data) == 0
+            np.testing.assert_array_equal(w, oracle_mod.hann(400, bool(periodic)))
+            np.testing.assert_array_equal(fb, oracle_mod.slaney_filterbank(512, n_mels, 16000))
+
+
+def random_dendrogram(n, rng):
+    """Random merge tree in SciPy format with non-monotone heights (inversions are the norm for centroid linkage)."""
+    alive = list(range(n))
+    z = np.zeros((n - 1, 4))
+    size = {i: 1 for i in range(n)}
+    for r in range(n - 1):
+        i, j = rng.choice(len(alive), 2, replace=False)
+        a, b = alive[i], alive[j]
+        z[r] = (min(a, b), max(a, b), rng.uniform(0, 2), size[a] + size[b])
+        size[n + r] = size[a] + size[b]
+        alive = [v for v in alive if v not in (a, b)] + [n + r]
+    return z
+
+
+def test_cut_matches_oracle_on_random_trees(fa, oracle_mod):
+    rng = np.random.default_rng(4)
+    for n in (2, 3, 7, 64, 500):
+        z = random_dendrogram(n, rng)
+        for thr in (0.0, 0.3, 0.6, 1.0, 1.9, 2.5, -1.0, float("nan")):
+            got = fa.cut(z, n, thr)
+            exp = oracle_mod.ahc_cut(z, n, thr)
+            np.testing.assert_array_equal(got, exp)
+    assert fa.cut(np.zeros((0, 4)), 1, 0.5).tolist() == [0]
+
+
+def test_python_mirror_guards_need_no_gpu(fa):
+    # AHCClustering.cluster guards (:24-31) are decided on the host
+    ahc = fa.AHCClustering.__new__(fa.AHCClustering)
+    ahc._ctx, ahc.mode = None, 0
+    assert ahc.cluster([], 0.7) == []
+    assert ahc.cluster([[], [], []], 0.7) == [0, 0, 0]
+    assert ahc.cluster([[1.0, 0.0, 0.0]], 0.7) == [0]
+    assert fa.decode_ctc_token_ids([0, 1, 2], {0: "he", 1: "llo", 2: "▁world"}) == "hello world"  # CtcDecoderTests.swift:55-59
+    assert fa.ctc_greedy_decode([], {0: "▁hello"}, 1) == ""
+
+
+def test_shard_ranges_cover_and_balance(fa):
+    for n in (0, 1, 7, 8, 1024, 10000):
+        for w in (1, 2, 3, 8):
+            spans = [fa.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    offs = np.array([0, 10, 25, 25, 40, 100])
+    first, local, lo, hi = fa.shard_offsets(offs, 1, 2)
+    assert first == 3 and local.tolist() == [0, 15, 75] and (lo, hi) == (25, 100)

@@ -1,0 +1,135 @@
+"""Pins the mel oracle (oracle/fa_oracle.c) against what the reference's tests hold.
+
+Ported from Tests/FluidAudioTests/ASR/Parakeet/Streaming/AudioMelSpectrogramTests.swift:22-122,
+Diarizer/Sortformer/SortformerStreamingMelTests.swift:84-132, ASR/Parakeet/Streaming/
+EouChunkSizeFrameCountTests.swift:10-60 and the one true golden vector of the repo,
+TTS/LuxTts/LuxTtsMelExtractorTests.swift:18-41.
+"""
+import os
+
+import numpy as np
+import pytest
+from conftest import REFERENCE, synth_audio
+
+LUX = os.path.join(REFERENCE, "Tests/FluidAudioTests/TTS/LuxTts/Resources")
+
+
+def test_frame_counts(oracle_mod):
+    cfg = oracle_mod.MelConfig()
+    # 15 s / 10 s / 1 s -> 1501 / 1001 / 101 ; formula 1 + (n + nFFT - win) / hop
+    for n, t in ((240000, 1501), (160000, 1001), (16000, 101), (1, 1), (0, 0)):
+        assert oracle_mod.mel_frames(cfg, n) == t
+    for n in (159, 160, 2560, 5120, 20480, 12345):
+        assert oracle_mod.mel_frames(cfg, n) == 1 + (n + 512 - 400) // 160
+    # EouChunkSizeFrameCountTests: 160 ms / 320 ms / 1280 ms chunks
+    for ms in (160, 320, 1280):
+        n = ms * 16
+        assert oracle_mod.mel_frames(cfg, n) == 1 + (n + 112) // 160
+    # prePadded: max(0, (n - nFFT)/hop + 1) with truncating division
+    assert oracle_mod.mel_frames(cfg, 512, prepadded=True) == 1
+    assert oracle_mod.mel_frames(cfg, 511, prepadded=True) == 1  # (-1)/160 truncates to 0
+    assert oracle_mod.mel_frames(cfg, 352, prepadded=True) == 0
+    assert oracle_mod.mel_frames(cfg, 1312, prepadded=True) == 6
+
+
+def test_legacy_compute_frame_count(oracle_mod):
+    # AudioMelSpectrogramTests.swift:32-45: 1 s -> 98 frames via compute()
+    mel, T = oracle_mod.mel_legacy(synth_audio(16000))
+    assert T == 98 and mel.shape == (128, 98)
+
+
+def test_flat_size_and_guard(oracle_mod):
+    mel, ml, nf = oracle_mod.mel_flat(synth_audio(16000))
+    assert mel.size == 128 * nf and ml == 101 and nf == 101
+    mel, ml, nf = oracle_mod.mel_flat(np.zeros(0, np.float32))
+    assert ml == 0 and nf == 1 and mel.size == 128 and not mel.any()
+    cfg = oracle_mod.MelConfig(pad_to=16)
+    mel, ml, nf = oracle_mod.mel_flat(synth_audio(16000), cfg)
+    assert ml == 101 and nf == 112 and not mel[:, 101:].any()
+
+
+def test_hann_window_properties(oracle_mod):
+    w = oracle_mod.hann(400)
+    assert w[0] == 0.0 and abs(w[-1]) < 1e-6
+    np.testing.assert_allclose(w, w[::-1], atol=1e-6)
+    assert abs(w.max() - 1.0) < 1e-4
+    wp = oracle_mod.hann(400, periodic=True)
+    assert wp[0] == 0.0 and wp[-1] > 1e-5  # periodic window does not return to zero
+
+
+def test_filterbank_properties(oracle_mod):
+    fb = oracle_mod.slaney_filterbank()
+    assert fb.shape == (128, 257) and (fb >= 0).all()
+    assert (np.count_nonzero(fb, axis=0) <= 2).all()  # every bin feeds at most two triangles
+    for row in fb:  # support of each triangle is one contiguous run (the kernel's sparse form relies on it)
+        nz = np.flatnonzero(row)
+        assert nz.size == 0 or nz[-1] - nz[0] + 1 == nz.size
+
+
+def test_silence_gives_log_floor(oracle_mod):
+    mel, ml, _ = oracle_mod.mel_flat(np.zeros(16000, np.float32))
+    assert (mel[:, :ml] < 0).all()
+    np.testing.assert_allclose(mel[:, :ml], np.log(np.float32(2.0 ** -24)), rtol=1e-6)
+
+
+def test_stream_prepadded_equals_batch_center(oracle_mod):
+    # SortformerStreamingMelTests.swift:100-132: .prePadded frames over a zero-padded copy == .center frames (1e-5)
+    a = synth_audio(16000 * 2, 5)
+    batch, T, _ = oracle_mod.mel_flat_transposed(a)
+    # the padded stream carries the pre-emphasis state across the seam, so emulate with preemph applied once
+    cfg0 = oracle_mod.MelConfig(preemph=0.0)
+    y = np.empty_like(a)
+    y[0] = a[0]
+    y[1:] = a[1:] - np.float32(0.97) * a[:-1]
+    padded = np.concatenate([np.zeros(256, np.float32), y, np.zeros(256, np.float32)])
+    stream, Ts, _ = oracle_mod.mel_flat_transposed(padded, cfg0, prepadded=True)
+    assert Ts == (padded.size - 512) // 160 + 1
+    k = min(T, Ts)
+    np.testing.assert_allclose(stream[:k], batch[:k], atol=1e-5)
+
+
+def test_layouts_agree(oracle_mod):
+    a = synth_audio(8000, 9)
+    f, lf, nf = oracle_mod.mel_flat(a, last=0.1)
+    t, lt, nt = oracle_mod.mel_flat_transposed(a, last=0.1)
+    assert (lf, nf) == (lt, nt)
+    np.testing.assert_array_equal(f[:, :lf], t[:lt].T)
+
+
+def test_fft_restatement_against_float64(oracle_mod):
+    rng = np.random.default_rng(3)
+    for n in (512, 1024):
+        x = rng.standard_normal(n).astype(np.float32)
+        re, im = x.copy(), np.zeros(n, np.float32)
+        oracle_mod.lib().fa_oracle_fft_f32(n, re, im)
+        ref = np.fft.fft(x.astype(np.float64))
+        assert np.abs(re + 1j * im - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LUX, "prompt_mel_f32le.bin")), reason="reference fixtures not present")
+def test_luxtts_golden_fixture(oracle_mod):
+    """The only golden mel in the reference: 103 936 samples -> 406 x 100 log-mel, gate max-abs < 1e-3."""
+    audio = np.fromfile(os.path.join(LUX, "prompt_24k_f32le.bin"), np.float32)
+    gold = np.fromfile(os.path.join(LUX, "prompt_mel_f32le.bin"), np.float32).reshape(-1, 100)
+    assert audio.size == 103936 and gold.shape == (406, 100)
+    n_fft, hop, n_mels, sr = 1024, 256, 100, 24000
+    win = (0.5 * (1 - np.cos(2 * np.float32(np.pi) * np.arange(n_fft, dtype=np.float32) / np.float32(n_fft)))).astype(np.float32)
+    bins, fmax = n_fft // 2 + 1, sr / 2
+    h2m = lambda hz: 2595 * np.log10(1 + hz / 700)  # noqa: E731  (LuxTtsMelExtractor.swift:159-160)
+    m2h = lambda m: 700 * (10 ** (m / 2595) - 1)  # noqa: E731
+    pts = m2h(h2m(0) + np.arange(n_mels + 2) * (h2m(fmax) - h2m(0)) / (n_mels + 1))
+    fr = np.arange(bins) * fmax / (bins - 1)
+    fb = np.stack([np.maximum(0, np.minimum((fr - pts[m]) / (pts[m + 1] - pts[m]), (pts[m + 2] - fr) / (pts[m + 2] - pts[m + 1])))
+                   for m in range(n_mels)]).astype(np.float32)
+    frames = (audio.size + hop // 2) // hop
+    assert frames == 406
+    out = oracle_mod.logmel_generic(audio, n_fft, hop, win, fb, 1, 1e-7, frames)
+    assert np.abs(out * np.float32(0.1) - gold).max() < 1e-3
+
+
+def test_committed_golden_matches_oracle(oracle_mod):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mel_golden.npz"))
+    m1, l1, _ = oracle_mod.mel_flat(g["a1"])
+    np.testing.assert_array_equal(m1, g["flat1"])
+    m2, l2, _ = oracle_mod.mel_flat_transposed(g["a2"], last=0.25)
+    np.testing.assert_array_equal(m2, g["tr2"])
