@@ -1,0 +1,125 @@
+"""GPU parity: centroid-linkage AHC (HIP, through the C ABI incl. the drop-in symbol) vs the reference's own C++
+build (oracle/_ref) and committed golden dendrograms — bit-exact dendrograms on tie-free data, identical partitions
+(and identical height multisets) where exact ties make the reference's merge order a heap artefact."""
+import os
+
+import numpy as np
+import pytest
+from conftest import same_partition, speaker_mixture
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ahc_golden.npz")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_committed_golden_dendrograms(fa, gpu_ctx, mode):
+    g = np.load(GOLD)
+    for x, z, lab, thr in ((g["xm"], g["zm"], g["labels_m"], 0.6), (g["xi"], g["zi"], g["labels_i"], 1.2)):
+        st, got, stats = fa.linkage(x, mode=mode, ctx=gpu_ctx, return_stats=True)
+        assert st == 0
+        np.testing.assert_array_equal(got, z)  # bit-exact: ids, heights, sizes, merge order
+        assert stats["merges"] == x.shape[0] - 1
+        np.testing.assert_array_equal(fa.cut(got, x.shape[0], thr), lab)
+
+
+def test_drop_in_symbol_status_contract(fa, gpu_ctx):
+    f = fa.lib().fastcluster_compute_centroid_linkage
+    x = np.random.default_rng(0).standard_normal((5, 3))
+    z = np.zeros(16)
+    assert f(x.ctypes.data, 5, 3, z.ctypes.data, 16) == 0 and z[3] == 2.0
+    assert f(x.ctypes.data, 5, 3, z.ctypes.data, 15) == 3
+    assert f(None, 5, 3, z.ctypes.data, 16) == 1
+    assert f(x.ctypes.data, 0, 3, z.ctypes.data, 16) == 0
+    assert f(x.ctypes.data, 5, 0, z.ctypes.data, 16) == 1
+    assert f(x.ctypes.data, 1, 3, z.ctypes.data, 0) == 0
+    x[2, 1] = np.nan
+    assert f(x.ctypes.data, 5, 3, z.ctypes.data, 16) == 5  # NaN distance -> RUNTIME_ERROR (FastClusterWrapper.cpp:236-237)
+    st, z2 = fa.fastcluster_compute_centroid_linkage(np.eye(3))
+    assert st == 0 and z2.shape == (2, 4)
+
+
+@pytest.mark.parametrize("n,d,kind", [(2, 4, "iid"), (3, 1, "iid"), (257, 7, "iid"), (1000, 256, "iid"), (1500, 64, "mix"),
+                                      (2000, 256, "mix"), (777, 300, "iid")])
+def test_bit_exact_vs_reference_build(fa, gpu_ctx, oracle_mod, n, d, kind):
+    if kind == "iid":
+        x = oracle_mod.ahc_normalize(np.random.default_rng(n).standard_normal((n, d)))
+    else:
+        x = speaker_mixture(n, d, 16, 0.03, n)
+    sr, zr = oracle_mod.linkage_ref(x)
+    assert sr == 0
+    for mode in (fa.AHC_MODE_AUTO, fa.AHC_MODE_EXACT):
+        st, z, stats = fa.linkage(x, mode=mode, ctx=gpu_ctx, return_stats=True)
+        assert st == 0
+        np.testing.assert_array_equal(z, zr)
+    # unnormalised, shifted data (the ABI does not require unit rows)
+    y = x * 3.0 + 0.5
+    _, zr = oracle_mod.linkage_ref(y)
+    st, z = fa.linkage(y, ctx=gpu_ctx)
+    assert st == 0
+    np.testing.assert_array_equal(z, zr)
+
+
+def test_swift_known_answers_on_device(fa, gpu_ctx):
+    ahc = fa.AHCClustering(ctx=gpu_ctx)                     # AHCClusteringTests.swift:12-145
+    assert ahc.cluster([], 0.7) == []
+    assert ahc.cluster([[1.0, 0.0, 0.0]], 0.7) == [0]
+    assert len(set(ahc.cluster([[1.0, 2.0, 3.0]] * 5, 0.7))) == 1
+    g = [[1, 0, 0], [.9, .1, 0], [.95, .05, 0], [0, 1, 0], [0, .9, .1], [0, .95, .05]]
+    r = ahc.cluster(g, 0.8)
+    assert len(set(r[:3])) == 1 and len(set(r[3:])) == 1 and r[0] != r[3]
+    e4 = [[1, 0, 0], [.9, .1, 0], [0, 1, 0], [0, .9, .1]]
+    assert len(set(ahc.cluster(e4, 0.5))) == 2 and len(set(ahc.cluster(e4, 1.5))) == 1
+    eye = np.eye(3).tolist()
+    assert sorted(set(ahc.cluster(eye, 0.5))) == [0, 1, 2]
+    assert len(set(ahc.cluster(eye, 2.0))) == 1 and len(set(ahc.cluster(eye, 0.0))) == 3
+    assert ahc.cluster([[], [], []], 0.7) == [0, 0, 0]
+    bad = [[1.0, float("nan")], [0.0, 1.0], [1.0, 1.0]]
+    assert ahc.cluster(bad, 0.7) == [0, 1, 2] and ahc.last_status == 5  # degrade to singletons (:52-55)
+
+
+def test_exact_ties_same_heights_and_partitions(fa, gpu_ctx, oracle_mod):
+    """Duplicated / symmetric inputs: the reference's merge ORDER among bit-identical distances is an artefact of
+    its heap; heights (as a multiset) and the partition at every threshold must agree."""
+    rng = np.random.default_rng(3)
+    base = oracle_mod.ahc_normalize(rng.standard_normal((40, 16)))
+    cases = [np.repeat(base, 3, axis=0),                                  # every point three times
+             np.array([[1, 0, 0], [.9, .1, 0], [.95, .05, 0], [0, 1, 0], [0, .9, .1], [0, .95, .05]], float),
+             np.vstack([np.eye(8), np.eye(8)])]
+    for x in cases:
+        xn = oracle_mod.ahc_normalize(x)
+        _, zr = oracle_mod.linkage_ref(xn)
+        for mode in (fa.AHC_MODE_AUTO, fa.AHC_MODE_EXACT):
+            st, z, stats = fa.linkage(xn, mode=mode, ctx=gpu_ctx, return_stats=True)
+            assert st == 0
+            np.testing.assert_allclose(np.sort(z[:, 2]), np.sort(zr[:, 2]), rtol=0, atol=1e-15)
+            for thr in (0.0, 1e-9, 0.3, 0.6, 1.0, 1.3, 1.5, 2.0):
+                assert same_partition(fa.cut(z, len(xn), thr), oracle_mod.ahc_cut(zr, len(xn), thr)), (thr, mode)
+        # the Lance-Williams filter must have detected the ambiguity and handed over to exact rows
+    assert stats is not None
+
+
+def test_cluster_labels_bit_exact_config3_style(fa, gpu_ctx, oracle_mod):
+    """Config-3 distributions at oracle-friendly size: labels equal the reference pipeline at several thresholds."""
+    n = 3000
+    for x in (np.random.default_rng(0).standard_normal((n, 256)), speaker_mixture(n, 256, 64, 0.02, 0) * 1.7):
+        for thr in (0.6, 1.0, 1.05, 1.2):
+            got = fa.AHCClustering(ctx=gpu_ctx).cluster(x, thr)
+            ref = oracle_mod.ahc_cluster(x, thr)
+            np.testing.assert_array_equal(np.asarray(got, np.int32), ref)
+    assert len(set(fa.AHCClustering(ctx=gpu_ctx).cluster(speaker_mixture(n, 256, 64, 0.02, 0), 0.6))) == 64
+
+
+def test_device_pointer_entry_and_reuse(fa, gpu_ctx, oracle_mod):
+    import ctypes as C
+
+    import torch
+    x = speaker_mixture(900, 32, 9, 0.05, 4)
+    _, zr = oracle_mod.linkage_ref(x)
+    d_x = torch.from_numpy(x).cuda()
+    d_z = torch.zeros((899, 4), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(2):  # second call reuses the cached workspace
+        st = fa.lib().fa_ahc_linkage(gpu_ctx.handle, C.c_void_p(d_x.data_ptr()), 900, 32, C.c_void_p(d_z.data_ptr()), 899 * 4,
+                                     fa.AHC_MODE_AUTO, 1, None)
+        assert st == 0
+        np.testing.assert_array_equal(d_z.cpu().numpy(), zr)
