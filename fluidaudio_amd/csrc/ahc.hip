@@ -44,13 +44,18 @@ constexpr int kSelThreads = 1024;
 constexpr int kMaxBlocks = 2048;  // N <= 524 288 (the N^2 matrix limits N far earlier)
 constexpr int kRoundsPerGraph = 512;
 
-enum { OP_NOOP = 0, OP_MERGE = 1, OP_RESCAN = 2 };
+constexpr int kMaxCand = 64;     // candidate rows inside an ambiguity window
+constexpr int kMaxPairs = 1024;  // matrix entries inside an ambiguity window
+
+enum { OP_NOOP = 0, OP_MERGE = 1, OP_RESCAN = 2, OP_WINDOW = 3 };
 
 struct AhcState {
     int32_t step, done, halt, need_exact, error, op, a, b, r, mode;
     double dab, wa, wb, wab, eps;
     unsigned long long dmax_bits;
-    long long rounds, rescans;
+    long long rounds, rescans, windows;
+    double lim;
+    int32_t ncand, npairs;
 };
 
 struct Ws {
@@ -63,6 +68,8 @@ struct Ws {
     double *cvec;    // [d]
     double *Z;       // [(N-1)*4]
     int32_t *rownn, *valid, *active, *node, *pidx;
+    int32_t *cand;   // [kMaxCand]
+    int32_t *pairs;  // [2*kMaxPairs]
     AhcState *state;
     int32_t N, Np, d, nblk;
 };
@@ -214,34 +221,94 @@ __global__ __launch_bounds__(kBlk) void ahc_block_minima(Ws w) {
 }
 
 // ------------------------------------------------------------------------------ round: select
+// Exact squared distances of up to kMaxPairs slot pairs, the reference's summation order
+// (sequential in k, one rounding per operation; FastClusterWrapper.cpp:68-75).  One wavefront per
+// pair: 64 lanes square the differences of a 64-wide slice, lane 0 adds them in index order.
+// Returns the minimum (ties -> lexicographically lowest (a, b)) in every thread.
+__device__ void exact_min_pair(const Ws &w, const int *s_pa, const int *s_pb, const int np, double *s_sq /*[16][64]*/,
+                               double *s_val, int *s_idx, double &best, int &best_a, int &best_b) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Np = w.Np, d = w.d;
+    best = dinf();
+    int best_p = INT_MAX;
+    for (int p0 = 0; p0 < np; p0 += kSelThreads / 64) {
+        const int p = p0 + wave;
+        const bool live = p < np;
+        const int a = live ? s_pa[p] : 0, b = live ? s_pb[p] : 0;
+        double sum = 0.0;
+        for (int k0 = 0; k0 < d; k0 += 64) {
+            const int k = k0 + lane;
+            double sq = 0.0;
+            if (live && k < d) {
+                const double diff = __dsub_rn(w.XT[static_cast<size_t>(k) * Np + a], w.XT[static_cast<size_t>(k) * Np + b]);
+                sq = __dmul_rn(diff, diff);
+            }
+            s_sq[wave * 64 + lane] = sq;
+            __syncthreads();
+            if (lane == 0 && live) {
+                const int n = d - k0 < 64 ? d - k0 : 64;
+                for (int j = 0; j < n; ++j) sum = __dadd_rn(sum, s_sq[wave * 64 + j]);
+            }
+            __syncthreads();
+        }
+        if (lane == 0 && live) {
+            // order pairs by (value, a, b): encode (a, b) through the pair's position after the value compare
+            if (sum != sum) { best = sum; best_p = -1; }  // NaN: remember it, reported by the caller
+            else if (best_p != -1 && (sum < best || (sum == best && (best_p == INT_MAX || a < s_pa[best_p] || (a == s_pa[best_p] && b < s_pb[best_p]))))) {
+                best = sum; best_p = p;
+            }
+        }
+    }
+    // cross-wave reduction (lane 0 of each wave holds its candidate)
+    __syncthreads();
+    if (lane == 0) { s_val[wave] = best; s_idx[wave] = best_p; }
+    __syncthreads();
+    best = dinf(); best_p = INT_MAX;
+    for (int wv = 0; wv < kSelThreads / 64; ++wv) {
+        const double v = s_val[wv];
+        const int p = s_idx[wv];
+        if (p == -1) { best = v; best_p = -1; break; }
+        if (p == INT_MAX) continue;
+        if (best_p == INT_MAX || v < best || (v == best && (s_pa[p] < s_pa[best_p] || (s_pa[p] == s_pa[best_p] && s_pb[p] < s_pb[best_p])))) {
+            best = v; best_p = p;
+        }
+    }
+    __syncthreads();
+    best_a = best_p >= 0 && best_p != INT_MAX ? s_pa[best_p] : -1;
+    best_b = best_p >= 0 && best_p != INT_MAX ? s_pb[best_p] : -1;
+}
+
 __global__ __launch_bounds__(kSelThreads) void ahc_select(Ws w) {
     __shared__ AhcState st;
     __shared__ double s_val[kSelThreads / 64];
     __shared__ int s_idx[kSelThreads / 64];
     __shared__ double s_bm[kMaxBlocks];
     __shared__ double s_sq[kSelThreads];
-    __shared__ int s_stale, s_best, s_cnt;
-    __shared__ double s_dab;
+    __shared__ int s_pa[kMaxPairs], s_pb[kMaxPairs];
+    __shared__ int s_cand[kMaxCand];
+    __shared__ int s_stale, s_best, s_cnt, s_nc;
     const int tid = threadIdx.x;
     AhcState *S = w.state;
     if (tid == 0) st = *S;
     __syncthreads();
     if (st.done || st.halt) { if (tid == 0 && st.op != OP_NOOP) S->op = OP_NOOP; return; }
-    const int Np = w.Np, nblk = w.nblk;
+    const int Np = w.Np, nblk = w.nblk, d = w.d;
+    int np = 0;        // pairs to evaluate exactly
+    double v = dinf();  // approximate (or, in exact mode, exact) value of the selected pair
 
-    // (1) finish the previous round: reduce the per-block partial minima of the row it produced
-    if (st.op == OP_MERGE || st.op == OP_RESCAN) {
+    // (1) finish the previous round
+    if (st.op == OP_MERGE || st.op == OP_RESCAN) {  // reduce the per-block partial minima of the row it produced
         const int row = st.op == OP_MERGE ? st.a : st.r;
-        double v = dinf();
+        double rv = dinf();
         int ix = INT_MAX;
         for (int i = tid; i < nblk; i += kSelThreads) {
             const double pv = w.pval[i];
             const int pi = w.pidx[i];
-            if (pv < v || (pv == v && pi < ix)) { v = pv; ix = pi; }
+            if (pv < rv || (pv == rv && pi < ix)) { rv = pv; ix = pi; }
         }
-        block_argmin<kSelThreads>(v, ix, s_val, s_idx);
+        block_argmin<kSelThreads>(rv, ix, s_val, s_idx);
         if (tid == 0) {
-            w.rowmin[row] = v;
+            w.rowmin[row] = rv;
             w.rownn[row] = ix == INT_MAX ? -1 : ix;
             w.valid[row] = 1;
         }
@@ -253,73 +320,85 @@ __global__ __launch_bounds__(kSelThreads) void ahc_select(Ws w) {
         block_argmin<kSelThreads>(bv, bi, s_val, s_idx);
         if (tid == 0) w.bm[blk] = bv;
         __syncthreads();
+    } else if (st.op == OP_WINDOW) {  // the apply pass listed every pair inside the ambiguity window
+        np = st.npairs;
+        if (np < 1 || np > kMaxPairs) {  // massive ties (duplicated inputs): continue with exact rows
+            if (tid == 0) { S->need_exact = 1; S->halt = 1; S->op = OP_NOOP; }
+            return;
+        }
+        for (int i = tid; i < np; i += kSelThreads) { s_pa[i] = w.pairs[2 * i]; s_pb[i] = w.pairs[2 * i + 1]; }
+        __syncthreads();
     }
     if (st.step >= w.N - 1) {
         if (tid == 0) { S->done = 1; S->op = OP_NOOP; }
         return;
     }
 
-    // (2) global minimum over block minima; candidate rows within 2*eps of it
-    for (int i = tid; i < nblk; i += kSelThreads) s_bm[i] = w.bm[i];
-    if (tid == 0) { s_stale = INT_MAX; s_best = INT_MAX; s_cnt = 0; }
-    __syncthreads();
-    double v = dinf();
-    int vi = INT_MAX;
-    for (int i = tid; i < nblk; i += kSelThreads) if (s_bm[i] < v) { v = s_bm[i]; vi = i; }
-    block_argmin<kSelThreads>(v, vi, s_val, s_idx);
-    const double lim = v + 2.0 * st.eps;
-    for (int blk0 = 0; blk0 < nblk; blk0 += kSelThreads / kBlk) {
-        const int blk = blk0 + tid / kBlk;
-        if (blk < nblk && s_bm[blk] <= lim) {
-            const int x = blk * kBlk + (tid & (kBlk - 1));
-            const double rm = w.rowmin[x];
-            if (w.active[x] && rm <= lim) {
-                if (!w.valid[x]) atomicMin(&s_stale, x);
-                else { atomicAdd(&s_cnt, 1); if (rm == v) atomicMin(&s_best, x); }
+    if (np == 0) {
+        // (2) global minimum over block minima; candidate rows within 2*eps of it
+        for (int i = tid; i < nblk; i += kSelThreads) s_bm[i] = w.bm[i];
+        if (tid == 0) { s_stale = INT_MAX; s_best = INT_MAX; s_cnt = 0; s_nc = 0; }
+        __syncthreads();
+        int vi = INT_MAX;
+        for (int i = tid; i < nblk; i += kSelThreads) if (s_bm[i] < v) { v = s_bm[i]; vi = i; }
+        block_argmin<kSelThreads>(v, vi, s_val, s_idx);
+        const double lim = v + 2.0 * st.eps;
+        for (int blk0 = 0; blk0 < nblk; blk0 += kSelThreads / kBlk) {
+            const int blk = blk0 + tid / kBlk;
+            if (blk < nblk && s_bm[blk] <= lim) {
+                const int x = blk * kBlk + (tid & (kBlk - 1));
+                const double rm = w.rowmin[x];
+                if (w.active[x] && rm <= lim) {
+                    if (!w.valid[x]) atomicMin(&s_stale, x);
+                    else {
+                        atomicAdd(&s_cnt, 1);
+                        if (rm == v) atomicMin(&s_best, x);
+                        const int i = atomicAdd(&s_nc, 1);
+                        if (i < kMaxCand) s_cand[i] = x;
+                    }
+                }
             }
         }
-    }
-    __syncthreads();
-    if (s_stale != INT_MAX) {  // a lower bound reached the minimum: re-scan that row first
-        if (tid == 0) { S->op = OP_RESCAN; S->r = s_stale; S->rescans = st.rescans + 1; S->rounds = st.rounds + 1; }
-        return;
-    }
-    const int r = s_best;
-    if (r == INT_MAX || !(v < dinf())) {  // cannot happen with finite data; stop rather than spin
-        if (tid == 0) { S->error = 2; S->halt = 1; S->op = OP_NOOP; }
-        return;
-    }
-    const int q = w.rownn[r];
-    if (st.mode == FA_AHC_MODE_AUTO) {
-        const bool mutual = s_cnt == 2 && q >= 0 && w.valid[q] && w.rownn[q] == r && w.rowmin[q] <= lim;
-        if (!mutual) {  // two candidates closer than the rounding bound: hand over to exact rows
-            if (tid == 0) { S->need_exact = 1; S->halt = 1; S->op = OP_NOOP; }
+        __syncthreads();
+        if (s_stale != INT_MAX) {  // a lower bound reached the minimum: re-scan that row first
+            if (tid == 0) { S->op = OP_RESCAN; S->r = s_stale; S->rescans = st.rescans + 1; S->rounds = st.rounds + 1; }
             return;
         }
-    }
-    const int a = r < q ? r : q, b = r < q ? q : r;
-    const int d = w.d;
-
-    // (3) the reference's exact distance of the selected pair (sequential sum, one rounding per op)
-    double dab = v;
-    if (st.mode == FA_AHC_MODE_AUTO) {
-        double sum = 0.0;
-        for (int k0 = 0; k0 < d; k0 += kSelThreads) {
-            const int k = k0 + tid;
-            if (k < d) {
-                const double diff = __dsub_rn(w.XT[static_cast<size_t>(k) * Np + a], w.XT[static_cast<size_t>(k) * Np + b]);
-                s_sq[tid] = __dmul_rn(diff, diff);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                const int n = d - k0 < kSelThreads ? d - k0 : kSelThreads;
-                for (int j = 0; j < n; ++j) sum = __dadd_rn(sum, s_sq[j]);
-            }
-            __syncthreads();
+        const int r = s_best;
+        if (r == INT_MAX || !(v < dinf())) {  // cannot happen with finite data; stop rather than spin
+            if (tid == 0) { S->error = 2; S->halt = 1; S->op = OP_NOOP; }
+            return;
         }
-        if (tid == 0) s_dab = sum;
+        const int q = w.rownn[r];
+        if (st.mode == FA_AHC_MODE_AUTO) {
+            const bool mutual = s_cnt == 2 && q >= 0 && w.valid[q] && w.rownn[q] == r && w.rowmin[q] <= lim;
+            if (!mutual) {
+                // Several pairs lie within the rounding bound of the Lance-Williams rows.  Ask the apply pass to list
+                // every matrix entry <= lim in the candidate rows; the next select evaluates them exactly.
+                if (s_nc > kMaxCand) {
+                    if (tid == 0) { S->need_exact = 1; S->halt = 1; S->op = OP_NOOP; }
+                    return;
+                }
+                for (int i = tid; i < s_nc; i += kSelThreads) w.cand[i] = s_cand[i];
+                if (tid == 0) {
+                    S->op = OP_WINDOW; S->ncand = s_nc; S->npairs = 0; S->lim = lim;
+                    S->windows = st.windows + 1; S->rounds = st.rounds + 1;
+                }
+                return;
+            }
+        }
+        if (tid == 0) { s_pa[0] = r < q ? r : q; s_pb[0] = r < q ? q : r; }
+        np = 1;
         __syncthreads();
-        dab = s_dab;
+    }
+
+    // (3) the reference's exact distance of the selected pair(s)
+    double dab = v;
+    int a = s_pa[0], b = s_pb[0];
+    if (st.mode == FA_AHC_MODE_AUTO) exact_min_pair(w, s_pa, s_pb, np, s_sq, s_val, s_idx, dab, a, b);
+    if (a < 0 || dab != dab) {  // NaN distance: nan_error in the reference (status 5)
+        if (tid == 0) { S->error = 1; S->halt = 1; S->op = OP_NOOP; }
+        return;
     }
     // (4) merged centroid (FastClusterWrapper.cpp:89-100) into slot a, plus a contiguous copy
     const double ma = w.size[a], mb = w.size[b], den = ma + mb;
@@ -337,7 +416,6 @@ __global__ __launch_bounds__(kSelThreads) void ahc_select(Ws w) {
         z[1] = na < nb ? nb : na;
         z[2] = dab;                // squared; sqrt applied after the loop (postprocess, :128-130)
         z[3] = den;
-        if (dab != dab) { S->error = 1; S->halt = 1; }
         w.size[a] = den;
         w.node[a] = w.N + st.step;
         w.active[b] = 0;
@@ -364,6 +442,19 @@ __global__ __launch_bounds__(kBlk) void ahc_apply(Ws w) {
         int ix = x;
         block_argmin<kBlk>(v, ix, s_val, s_idx);
         if (tid == 0) { w.pval[blk] = v; w.pidx[blk] = v < dinf() ? ix : INT_MAX; }
+        return;
+    }
+    if (op == OP_WINDOW) {  // list every entry of the candidate rows that lies inside the ambiguity window
+        const int nc = S->ncand;
+        const double lim = S->lim;
+        for (int j = 0; j < nc; ++j) {
+            const int row = w.cand[j];
+            const double val = w.M[static_cast<size_t>(row) * Np + x];
+            if (val <= lim) {
+                const int slot = atomicAdd(&w.state->npairs, 1);
+                if (slot < kMaxPairs) { w.pairs[2 * slot] = row < x ? row : x; w.pairs[2 * slot + 1] = row < x ? x : row; }
+            }
+        }
         return;
     }
     const int a = S->a, b = S->b;
@@ -421,7 +512,7 @@ __global__ void ahc_finish(Ws w) {  // heights: squared -> Euclidean (cluster_re
 
 // ------------------------------------------------------------------------------ host driver
 struct Layout {
-    size_t xt, m, rowmin, size, bm, pval, cvec, z, rownn, valid, active, node, pidx, state, total;
+    size_t xt, m, rowmin, size, bm, pval, cvec, z, rownn, valid, active, node, pidx, cand, pairs, state, total;
 };
 
 Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
@@ -441,6 +532,8 @@ Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
     L.active = take(sizeof(int32_t) * Np);
     L.node = take(sizeof(int32_t) * Np);
     L.pidx = take(sizeof(int32_t) * nblk);
+    L.cand = take(sizeof(int32_t) * kMaxCand);
+    L.pairs = take(sizeof(int32_t) * 2 * kMaxPairs);
     L.m = take(sizeof(double) * Np * Np);
     L.total = o;
     return L;
@@ -483,6 +576,8 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     w.active = reinterpret_cast<int32_t *>(base + L.active);
     w.node = reinterpret_cast<int32_t *>(base + L.node);
     w.pidx = reinterpret_cast<int32_t *>(base + L.pidx);
+    w.cand = reinterpret_cast<int32_t *>(base + L.cand);
+    w.pairs = reinterpret_cast<int32_t *>(base + L.pairs);
     w.N = static_cast<int32_t>(N); w.Np = static_cast<int32_t>(Np); w.d = static_cast<int32_t>(d); w.nblk = static_cast<int32_t>(nblk);
 
     hipEvent_t ev[3];
@@ -504,8 +599,9 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
         double dmax;
         const long long bits = static_cast<long long>(h.dmax_bits);
         memcpy(&dmax, &bits, sizeof(dmax));
-        // rounding bound of the Lance-Williams recurrence: <= ~3 ulp(dmax) per level, depth <= N
-        const double eps = 64.0 * static_cast<double>(N) * 1.1102230246251565e-16 * dmax;
+        // rounding bound of the Lance-Williams recurrence: <= 8 u dmax per merge level (3 products, 2 sums, 3 rounded
+        // weights), errors of the two parents enter with weights wa + wb = 1, tree depth <= N; factor 2 of margin.
+        const double eps = 16.0 * static_cast<double>(N) * 1.1102230246251565e-16 * dmax;
         FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state) + offsetof(AhcState, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
     }
     FA_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
@@ -559,6 +655,7 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
         (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
         (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
         stats->merges = h.step; stats->rounds = h.rounds; stats->rescans = h.rescans; stats->exact_fallback = fallback;
+        stats->windows = h.windows;
         stats->init_ms = t01; stats->merge_ms = t12; stats->total_ms = t01 + t12;
     }
     return FA_SUCCESS;

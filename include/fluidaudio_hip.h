@@ -150,6 +150,7 @@ typedef struct {
     int64_t rescans;       /* lazy row re-scans */
     int64_t exact_fallback;/* 1 if the Lance-Williams filter hit an ambiguity and the run switched to exact rows */
     double init_ms, merge_ms, total_ms; /* device time (hipEvent) */
+    int64_t windows;       /* rounds in which several pairs fell inside the rounding bound and were re-evaluated exactly */
 } fa_ahc_stats;
 
 enum { FA_AHC_MODE_AUTO = 0,   /* Lance-Williams filter + exact re-verification, exact rows on ambiguity */

@@ -24,8 +24,9 @@ static double sqdist_cols(const double *xt, size_t np, size_t d, size_t a, size_
 }
 
 /* mode 0: exact rows (every matrix entry is the reference's sequential fp64 sum)
- * mode 1: Lance-Williams rows + exact verification of the selected pair; returns 100 when an
- *         ambiguity (|S_eps| != mutual pair) is hit (the GPU library then switches to mode 0). */
+ * mode 1: Lance-Williams rows + exact verification of the selected pair; when several pairs lie within
+ *         2*eps of the minimum (|S_eps| != one mutual pair) a WINDOW round re-evaluates every such matrix
+ *         entry exactly.  eps = eps_scale * N * u * dmax (the library uses eps_scale = 16). */
 int ahc_model_linkage(const double *data, size_t n, size_t d, double *z, int mode, double eps_scale,
                       ahc_model_stats *st) {
     memset(st, 0, sizeof(*st));
@@ -78,12 +79,28 @@ int ahc_model_linkage(const double *data, size_t n, size_t d, double *z, int mod
         }
         if (r < 0) return 5;
         long q = rownn[r];
-        if (mode == 1) {
-            if (!(cnt == 2 && rowmin[q] <= lim && rownn[q] == r)) { st->ambiguous++; return 100; }
-        }
-        const size_t a = (size_t)(r < q ? r : q), b = (size_t)(r < q ? q : r);
+        size_t a = (size_t)(r < q ? r : q), b = (size_t)(r < q ? q : r);
         double dab = M[a * np + b];
-        if (mode == 1) { dab = sqdist_cols(xt, np, d, a, b); st->exact_evals++; }
+        if (mode == 1) {
+            if (!(cnt == 2 && rowmin[q] <= lim && rownn[q] == r)) {
+                /* WINDOW round: every matrix entry <= lim in the candidate rows is re-evaluated exactly;
+                 * the exact minimum wins, ties -> lexicographically lowest (a, b). */
+                st->ambiguous++;
+                st->rounds++;
+                double best = INFINITY; long ba = -1, bb = -1;
+                for (size_t i = 0; i < n; ++i) {
+                    if (!active[i] || !valid[i] || !(rowmin[i] <= lim)) continue;
+                    for (size_t j = 0; j < n; ++j) {
+                        if (!(M[i * np + j] <= lim)) continue;
+                        const long pa = (long)(i < j ? i : j), pb = (long)(i < j ? j : i);
+                        const double e = sqdist_cols(xt, np, d, (size_t)pa, (size_t)pb);
+                        st->exact_evals++;
+                        if (e < best || (e == best && (pa < ba || (pa == ba && pb < bb)))) { best = e; ba = pa; bb = pb; }
+                    }
+                }
+                a = (size_t)ba; b = (size_t)bb; dab = best;
+            } else { dab = sqdist_cols(xt, np, d, a, b); st->exact_evals++; }
+        }
         const double ma = size[a], mb = size[b], den = ma + mb;
         z[4 * step + 0] = (double)(node[a] < node[b] ? node[a] : node[b]);
         z[4 * step + 1] = (double)(node[a] < node[b] ? node[b] : node[a]);

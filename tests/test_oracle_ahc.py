@@ -77,13 +77,17 @@ def test_gpu_algorithm_model_equals_reference_build(oracle_mod):
 
     for x in (oracle_mod.ahc_normalize(np.random.default_rng(1).standard_normal((700, 48))), speaker_mixture(800, 64, 16, 0.03, 2)):
         _, zr = oracle_mod.linkage_ref(x)
-        for mode in (0, 1):
+        # (mode, eps_scale): exact rows; Lance-Williams filter with the library's bound; the same with the bound
+        # inflated 1e8x so that almost every step goes through the WINDOW (exact re-evaluation) round
+        for mode, eps_scale in ((0, 0.0), (1, 16.0), (1, 1.6e9)):
             z = np.zeros_like(zr)
             st = St()
             rc = lib.ahc_model_linkage(x.ctypes.data_as(C.c_void_p), C.c_size_t(x.shape[0]), C.c_size_t(x.shape[1]),
-                                       z.ctypes.data_as(C.c_void_p), mode, C.c_double(64.0), C.byref(st))
+                                       z.ctypes.data_as(C.c_void_p), mode, C.c_double(eps_scale), C.byref(st))
             assert rc == 0 and st.merges == x.shape[0] - 1
             np.testing.assert_array_equal(z, zr)
+            if eps_scale > 1e6:
+                assert st.ambiguous > 100
 
 
 def test_cut_is_top_down_not_fcluster(oracle_mod):
