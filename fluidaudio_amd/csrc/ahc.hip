@@ -10,25 +10,35 @@
 // (FastClusterWrapper.cpp:45-52,68-75) and the merged centroid is (m_i x_i + m_j x_j)/(m_i+m_j)
 // (:89-100).  Its heap / nearest-neighbour arrays are bookkeeping for that argmin.
 //
-// How this file computes the same thing:
-//   * vectors live transposed in HBM, XT[k][slot]; a merged cluster keeps the lower slot;
-//   * the full slot x slot distance matrix M (fp64, N^2*8 B: 20 GB at N = 50 000) stays
-//     resident in HBM; dead rows/columns hold +inf so row scans need no mask;
-//   * per row: (rowmin, rownn, valid).  A row whose nearest neighbour was merged away keeps its
-//     old minimum as a LOWER BOUND (valid = 0) and is re-scanned only when that bound reaches
-//     the global minimum — the reference's lazy scheme, applied to full rows;
-//   * one merge = two kernels replayed from a hipGraph: `select` (1 workgroup: finish the
-//     previous round's reduction, global argmin over 256-row block minima, exact re-evaluation
-//     of the winning pair, new centroid, dendrogram row) and `apply` (N/256 workgroups: new
-//     matrix row/column, kill the dead column, maintain row minima and block minima);
-//   * FA_AHC_MODE_AUTO fills the new row with the Lance-Williams centroid update of rows a, b
-//     (O(N) per merge instead of O(N d)) and re-evaluates the selected pair with the
-//     reference's exact sum; if two candidates ever fall within the rounding bound eps of each
-//     other, the run recomputes M exactly and continues with exact rows (FA_AHC_MODE_EXACT),
-//     so the merge sequence never depends on the approximation.
-// Exactly tied distances are merged in (lower slot, higher slot) order, where a cluster's slot
-// is its smallest original point index; the reference's tie order is an artefact of its binary
-// heap layout.  Heights and the partition at any threshold are the same (tests/test_ahc_*.py).
+// How this file computes the same thing.  The N-1 merges are a strictly serial
+// chain, so the design minimises the latency of ONE merge: one kernel per round, replayed from a
+// hipGraph (a dependent kernel boundary costs ~1.7 us on MI355X, a software grid barrier 4-7 us).
+//   * slots: a merged cluster keeps the lower slot; node[slot] = dendrogram node id living there
+//     (0..N-1 points, N+s the cluster made by merge s; DEAD once merged away);
+//   * centroids are stored append-only by node id, C[node][d] (never overwritten, so every
+//     workgroup may read them while one workgroup appends);
+//   * M (slot x slot, fp64, N^2*8 B = 20 GB at N = 50 000) is resident in HBM and ASYMMETRIC:
+//     the distance of slots (x, y) is valid at M[x][y] iff node[x] > node[y] (the row of the more
+//     recently created cluster).  A merge therefore only rewrites ONE row (coalesced); no column is
+//     ever written and dead columns need no clean-up;
+//   * per row x: d1[x] = minimum over all other active slots, nn[x] its slot (lowest on ties) or -1
+//     when the nearest neighbour was merged away — d1 then stays a LOWER BOUND and the row is
+//     re-scanned only when that bound reaches the global minimum (the reference's lazy scheme);
+//   * per 256-row block a record (three smallest d1, rows + neighbours of the first two), double
+//     buffered by round parity.  Every workgroup starts a round by reducing the same records, so
+//     all of them reach the same decision without any inter-workgroup synchronisation inside the
+//     round; the kernel boundary is the only barrier;
+//   * FA_AHC_MODE_AUTO fills the new row with the Lance-Williams centroid update (O(N) per merge);
+//     the pair to merge is taken from those values only when it is the unique mutual-nearest pair
+//     with every other row minimum farther than 2*eps (eps = rounding bound of the recurrence);
+//     otherwise all matrix entries inside the window are re-evaluated with the reference's exact
+//     sum (COLLECT -> PAIRS -> evaluate rounds), and if the window overflows (massive ties,
+//     duplicated inputs) the run switches to FA_AHC_MODE_EXACT rows.  Heights are always
+//     recomputed after the loop from the stored centroids with the reference's sequential sum, so
+//     the merge order never depends on the approximation and the output rows are bit-identical;
+//   * FA_AHC_MODE_EXACT: every new-row entry is the reference's sequential fp64 sum (O(N d) per merge).
+// Exactly tied distances are merged in (value, row, column) order; the reference's tie order is an
+// artefact of its binary heap layout.  Heights and the partition at any threshold are the same.
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -39,65 +49,90 @@
 
 namespace {
 
-constexpr int kBlk = 256;       // rows per block-minimum / threads per apply workgroup
-constexpr int kSelThreads = 1024;
-constexpr int kMaxBlocks = 2048;  // N <= 524 288 (the N^2 matrix limits N far earlier)
-constexpr int kRoundsPerGraph = 512;
+constexpr int kBlk = 256;          // rows per block record == threads per round workgroup
+constexpr int kWaves = kBlk / 64;
+constexpr int kMaxBlocks = 768;    // N <= 196 608 (N^2 * 8 B = 288 GB is reached at N ~ 190 000)
+constexpr int kRoundsPerGraph = 512;  // multiple of 4 (counter rotation) and of 2 (parity)
+constexpr int kMaxCand = 64;       // candidate rows inside an ambiguity window
+constexpr int kMaxPairs = 1024;    // matrix entries inside an ambiguity window
+constexpr int kDead = INT_MAX;     // node id of an empty slot
 
-constexpr int kMaxCand = 64;     // candidate rows inside an ambiguity window
-constexpr int kMaxPairs = 1024;  // matrix entries inside an ambiguity window
+enum { OP_NONE = 0, OP_MERGE = 1, OP_RESCAN = 2, OP_COLLECT = 3, OP_PAIRS = 4 };
 
-enum { OP_NOOP = 0, OP_MERGE = 1, OP_RESCAN = 2, OP_WINDOW = 3 };
-
-struct AhcState {
-    int32_t step, done, halt, need_exact, error, op, a, b, r, mode;
-    double dab, wa, wb, wab, eps;
+struct AhcState {  // double buffered by round parity; written by workgroup 0 only
+    int32_t step, done, halt, need_exact, error, mode;
+    int32_t prev_op;              // what the previous round executed
+    int32_t pend_row, pend_node;  // row whose per-block partial minima the previous round produced (-1: none)
+    int32_t pad0;
+    double eps, lim;              // lim: window limit carried COLLECT -> PAIRS -> evaluation
     unsigned long long dmax_bits;
     long long rounds, rescans, windows;
-    double lim;
+};
+
+struct WinCounters {  // 4 copies rotating with the round index: [t&3] written, [(t-1)&3] read, [(t+1)&3] cleared
+    unsigned long long stale_key;  // (slot << 32 | node) of the lowest stale row inside the window
     int32_t ncand, npairs;
 };
 
 struct Ws {
-    double *XT;      // [d][Np]
     double *M;       // [Np][Np]
-    double *rowmin;  // [Np]
-    double *size;    // [Np]
-    double *bm;      // [nblk]
-    double *pval;    // [nblk]
-    double *cvec;    // [d]
+    double *C;       // [2N][d]  centroids by node id (rows 0..N-1 = input points)
+    double *XT;      // [d][Np]  slot-major transposed coordinates (init; maintained in EXACT mode only)
+    double *d1;      // [Np]
+    double *sizes;   // [2N]     cluster size by node id
     double *Z;       // [(N-1)*4]
-    int32_t *rownn, *valid, *active, *node, *pidx;
-    int32_t *cand;   // [kMaxCand]
-    int32_t *pairs;  // [2*kMaxPairs]
-    AhcState *state;
+    int32_t *nn, *nnnode, *node;  // [Np]
+    // block records, [2][nblk]
+    double *rec_v1, *rec_v2, *rec_v3;
+    int4 *rec_a;     // r1, q1, node(r1), node(q1)
+    int2 *rec_b;     // r2, q2
+    double *pend_v;  // [2][nblk]
+    int2 *pend_i;    // slot, node
+    int2 *cand;      // [kMaxCand]  slot, node
+    int4 *pairs;     // [kMaxPairs] a, b, node a, node b
+    WinCounters *cnt;  // [4]
+    int32_t *flags;    // [0]: a NaN distance was seen (nan_error, FastClusterWrapper.cpp:60-62)
+    AhcState *state;   // [2]
     int32_t N, Np, d, nblk;
 };
 
 __device__ __forceinline__ double dinf() { return __longlong_as_double(0x7ff0000000000000LL); }
+__device__ __forceinline__ bool lt2(double v, int i, double ov, int oi) { return v < ov || (v == ov && i < oi); }
 
-// (value, index) minimum, lower index on ties.  Result valid in every thread.
-template <int THREADS>
-__device__ __forceinline__ void block_argmin(double &v, int &ix, double *s_val, int *s_idx) {
-    constexpr int W = THREADS / 64;
+// ------------------------------------------------------------------------------ wave helpers
+// (value, index) minimum over the 64 lanes, lower index on ties; result in every lane.
+__device__ __forceinline__ void wave_argmin(double &v, int &ix) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const double ov = __shfl_xor(v, off);
         const int oi = __shfl_xor(ix, off);
-        if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+        if (lt2(ov, oi, v, ix)) { v = ov; ix = oi; }
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) { s_val[wave] = v; s_idx[wave] = ix; }
-    __syncthreads();
-    v = s_val[0]; ix = s_idx[0];
+}
+
+struct Top3 {  // three smallest (value, index) keys seen, third as a value only
+    double v1, v2, v3;
+    int i1, i2;
+};
+__device__ __forceinline__ void top3_init(Top3 &t) { t.v1 = t.v2 = t.v3 = dinf(); t.i1 = t.i2 = INT_MAX; }
+__device__ __forceinline__ void top3_push(Top3 &t, double v, int i) {
+    if (lt2(v, i, t.v1, t.i1)) { t.v3 = t.v2; t.v2 = t.v1; t.i2 = t.i1; t.v1 = v; t.i1 = i; }
+    else if (lt2(v, i, t.v2, t.i2)) { t.v3 = t.v2; t.v2 = v; t.i2 = i; }
+    else if (v < t.v3) t.v3 = v;
+}
+__device__ __forceinline__ void top3_merge(Top3 &t, const Top3 &o) {
+    top3_push(t, o.v1, o.i1);
+    top3_push(t, o.v2, o.i2);
+    if (o.v3 < t.v3) t.v3 = o.v3;
+}
+__device__ __forceinline__ void wave_top3(Top3 &t) {
 #pragma unroll
-    for (int w = 1; w < W; ++w) {
-        const double ov = s_val[w];
-        const int oi = s_idx[w];
-        if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+    for (int off = 32; off > 0; off >>= 1) {
+        Top3 o;
+        o.v1 = __shfl_xor(t.v1, off); o.v2 = __shfl_xor(t.v2, off); o.v3 = __shfl_xor(t.v3, off);
+        o.i1 = __shfl_xor(t.i1, off); o.i2 = __shfl_xor(t.i2, off);
+        top3_merge(t, o);
     }
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------ init kernels
@@ -116,18 +151,27 @@ __global__ void ahc_transpose(const double *__restrict__ data, double *__restric
     }
 }
 
-__global__ void ahc_init_rows(Ws w) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= w.Np) return;
-    w.active[i] = i < w.N;
-    w.node[i] = i;
-    w.size[i] = 1.0;
-    w.valid[i] = 1;
-    w.rownn[i] = -1;
-    w.rowmin[i] = dinf();
+// slot-major coordinates of the clusters currently alive (switch to EXACT rows mid-run)
+__global__ void ahc_gather_xt(Ws w) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= w.Np) return;
+    const int nx = w.node[x];
+    for (int k = 0; k < w.d; ++k)
+        w.XT[static_cast<size_t>(k) * w.Np + x] = nx != kDead ? w.C[static_cast<size_t>(nx) * w.d + k] : 0.0;
 }
 
-// Exact pairwise squared distances, the reference's summation order (FastClusterWrapper.cpp:45-52).
+__global__ void ahc_init_rows(Ws w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * w.N) w.sizes[i] = 1.0;
+    if (i >= w.Np) return;
+    w.node[i] = i < w.N ? i : kDead;
+    w.nn[i] = -1;
+    w.nnnode[i] = -1;
+    w.d1[i] = dinf();
+}
+
+// Exact pairwise squared distances of the live slots, the reference's summation order
+// (FastClusterWrapper.cpp:45-52).  Both triangles are written; dead slots and the diagonal get +inf.
 constexpr int PT = 64, PK = 16;
 __global__ __launch_bounds__(256) void ahc_pairwise(Ws w) {
     __shared__ double sa[PK][PT];
@@ -167,12 +211,12 @@ __global__ __launch_bounds__(256) void ahc_pairwise(Ws w) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = i0 + ty * 4 + r;
-        const bool ai = i < w.N && w.active[i];
+        const bool ai = w.node[i] != kDead;
         double out[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int j = j0 + tx * 4 + c;
-            const bool ok = ai && j < w.N && i != j && w.active[j];
+            const bool ok = ai && i != j && w.node[j] != kDead;
             const double v = acc[r][c];
             if (ok) { if (v != v) bad = true; else if (v > lmax) lmax = v; }
             out[c] = ok ? v : dinf();
@@ -181,369 +225,472 @@ __global__ __launch_bounds__(256) void ahc_pairwise(Ws w) {
         reinterpret_cast<double2 *>(dst)[0] = make_double2(out[0], out[1]);
         reinterpret_cast<double2 *>(dst)[1] = make_double2(out[2], out[3]);
     }
-    if (bad) w.state->error = 1;  // nan_error (fastcluster_internal.hpp / FastClusterWrapper.cpp:60-62)
+    if (bad) w.flags[0] = 1;  // nan_error (FastClusterWrapper.cpp:60-62)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(lmax, off); if (o > lmax) lmax = o; }
     if ((tid & 63) == 0 && lmax > 0.0)
-        atomicMax(&w.state->dmax_bits, static_cast<unsigned long long>(__double_as_longlong(lmax)));
+        atomicMax(&w.state[0].dmax_bits, static_cast<unsigned long long>(__double_as_longlong(lmax)));
 }
 
-// Row minimum + lowest-index argmin of every active row (one workgroup per row).
+// Row minimum + lowest-index argmin of every live row of a freshly rebuilt (symmetric) matrix.
 __global__ __launch_bounds__(kBlk) void ahc_row_minima(Ws w) {
-    __shared__ double s_val[kBlk / 64];
-    __shared__ int s_idx[kBlk / 64];
+    __shared__ double s_val[kWaves];
+    __shared__ int s_idx[kWaves];
     const int i = blockIdx.x;
     double v = dinf();
     int ix = INT_MAX;
-    if (w.active[i]) {
+    if (w.node[i] != kDead) {
         const double *row = w.M + static_cast<size_t>(i) * w.Np;
         for (int x = threadIdx.x; x < w.Np; x += kBlk) {
             const double m = row[x];
             if (m < v) { v = m; ix = x; }  // x ascending per thread => lowest index kept
         }
     }
-    block_argmin<kBlk>(v, ix, s_val, s_idx);
+    wave_argmin(v, ix);
+    if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = v; s_idx[threadIdx.x >> 6] = ix; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        w.rowmin[i] = v;
-        w.rownn[i] = ix == INT_MAX ? -1 : ix;
-        w.valid[i] = 1;
+        for (int wv = 1; wv < kWaves; ++wv) if (lt2(s_val[wv], s_idx[wv], v, ix)) { v = s_val[wv]; ix = s_idx[wv]; }
+        w.d1[i] = v;
+        w.nn[i] = ix == INT_MAX ? -1 : ix;
+        w.nnnode[i] = ix == INT_MAX ? -1 : w.node[ix];
     }
 }
 
-__global__ __launch_bounds__(kBlk) void ahc_block_minima(Ws w) {
-    __shared__ double s_val[kBlk / 64];
-    __shared__ int s_idx[kBlk / 64];
-    const int x = blockIdx.x * kBlk + threadIdx.x;
-    double v = w.active[x] ? w.rowmin[x] : dinf();
-    int ix = x;
-    block_argmin<kBlk>(v, ix, s_val, s_idx);
-    if (threadIdx.x == 0) w.bm[blockIdx.x] = v;
+// ------------------------------------------------------------------------------ block record
+// Three smallest row minima of this workgroup's 256 rows (+ optionally the block-partial minimum of a row being
+// produced) -> the records of the NEXT round.  One __syncthreads.
+struct BlockOut {
+    Top3 rows;
+    double pv;
+    int pi;
+};
+__device__ __forceinline__ BlockOut block_reduce(double key, int x, double pkey, int px, Top3 *s_top, double *s_pv, int *s_pi) {
+    Top3 t;
+    top3_init(t);
+    top3_push(t, key, x);
+    wave_top3(t);
+    wave_argmin(pkey, px);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_top[wave] = t; s_pv[wave] = pkey; s_pi[wave] = px; }
+    __syncthreads();
+    BlockOut o;
+    o.rows = s_top[0]; o.pv = s_pv[0]; o.pi = s_pi[0];
+#pragma unroll
+    for (int wv = 1; wv < kWaves; ++wv) {
+        top3_merge(o.rows, s_top[wv]);
+        if (lt2(s_pv[wv], s_pi[wv], o.pv, o.pi)) { o.pv = s_pv[wv]; o.pi = s_pi[wv]; }
+    }
+    return o;
 }
 
-// ------------------------------------------------------------------------------ round: select
-// Exact squared distances of up to kMaxPairs slot pairs, the reference's summation order
-// (sequential in k, one rounding per operation; FastClusterWrapper.cpp:68-75).  One wavefront per
-// pair: 64 lanes square the differences of a 64-wide slice, lane 0 adds them in index order.
-// Returns the minimum (ties -> lexicographically lowest (a, b)) in every thread.
-__device__ void exact_min_pair(const Ws &w, const int *s_pa, const int *s_pb, const int np, double *s_sq /*[16][64]*/,
-                               double *s_val, int *s_idx, double &best, int &best_a, int &best_b) {
+__device__ __forceinline__ void write_record(const Ws &w, int par, int blk, const Top3 &t, int tid, int x, int nnx, int nx, int nnnodex) {
+    const size_t o = static_cast<size_t>(par) * w.nblk + blk;
+    if (tid == 0) { w.rec_v1[o] = t.v1; w.rec_v2[o] = t.v2; w.rec_v3[o] = t.v3; }
+    if (x == t.i1) w.rec_a[o] = make_int4(x, nnx, nx, nnnodex);
+    if (x == t.i2) w.rec_b[o] = make_int2(x, nnx);
+    if (tid == 0 && t.i1 == INT_MAX) w.rec_a[o] = make_int4(-1, -1, -1, -1);
+    if (tid == 0 && t.i2 == INT_MAX) w.rec_b[o] = make_int2(-1, -1);
+}
+
+__global__ __launch_bounds__(kBlk) void ahc_records(Ws w) {  // records of parity 0 from the row arrays
+    __shared__ Top3 s_top[kWaves];
+    __shared__ double s_pv[kWaves];
+    __shared__ int s_pi[kWaves];
+    const int tid = threadIdx.x, blk = blockIdx.x, x = blk * kBlk + tid;
+    const int nx = w.node[x];
+    const double key = nx != kDead ? w.d1[x] : dinf();
+    const BlockOut o = block_reduce(key, x, dinf(), INT_MAX, s_top, s_pv, s_pi);
+    write_record(w, 0, blk, o.rows, tid, x, w.nn[x], nx, w.nnnode[x]);
+    if (tid == 0) { w.pend_v[blk] = dinf(); w.pend_i[blk] = make_int2(-1, -1); }
+}
+
+// ------------------------------------------------------------------------------ the round kernel
+struct Decision {
+    int op;
+    int a, b, na, nb;  // MERGE: slots (a < b) and their node ids; RESCAN: a = row, na = its node
+    double dab;        // exact distance when known (window evaluation), else < 0
+    double lim;
+    int halt, need_exact, error, done;
+};
+
+// Exact squared distances of the listed pairs, the reference's summation order (sequential in k, one rounding per
+// operation; FastClusterWrapper.cpp:68-75).  One wavefront per pair: 64 lanes square the differences of a 64-wide
+// slice, lane 0 adds them in index order.  Minimum by (value, a, b); returned in every thread.
+__device__ void exact_min_pair(const Ws &w, const int np, double *s_sq /*[kWaves*64]*/, double *s_val, int *s_idx,
+                               double &best, int &best_p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Np = w.Np, d = w.d;
+    const int d = w.d;
     best = dinf();
-    int best_p = INT_MAX;
-    for (int p0 = 0; p0 < np; p0 += kSelThreads / 64) {
+    best_p = INT_MAX;
+    bool nan_seen = false;
+    for (int p0 = 0; p0 < np; p0 += kWaves) {
         const int p = p0 + wave;
         const bool live = p < np;
-        const int a = live ? s_pa[p] : 0, b = live ? s_pb[p] : 0;
+        const int4 pr = live ? w.pairs[p] : make_int4(0, 0, 0, 0);
+        const double *ca = w.C + static_cast<size_t>(pr.z) * d, *cb = w.C + static_cast<size_t>(pr.w) * d;
         double sum = 0.0;
         for (int k0 = 0; k0 < d; k0 += 64) {
             const int k = k0 + lane;
             double sq = 0.0;
-            if (live && k < d) {
-                const double diff = __dsub_rn(w.XT[static_cast<size_t>(k) * Np + a], w.XT[static_cast<size_t>(k) * Np + b]);
-                sq = __dmul_rn(diff, diff);
-            }
+            if (live && k < d) { const double diff = __dsub_rn(ca[k], cb[k]); sq = __dmul_rn(diff, diff); }
             s_sq[wave * 64 + lane] = sq;
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (lane == 0 && live) {
                 const int n = d - k0 < 64 ? d - k0 : 64;
                 for (int j = 0; j < n; ++j) sum = __dadd_rn(sum, s_sq[wave * 64 + j]);
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         if (lane == 0 && live) {
-            // order pairs by (value, a, b): encode (a, b) through the pair's position after the value compare
-            if (sum != sum) { best = sum; best_p = -1; }  // NaN: remember it, reported by the caller
-            else if (best_p != -1 && (sum < best || (sum == best && (best_p == INT_MAX || a < s_pa[best_p] || (a == s_pa[best_p] && b < s_pb[best_p]))))) {
-                best = sum; best_p = p;
+            if (sum != sum) nan_seen = true;
+            else if (best_p == INT_MAX || sum < best) { best = sum; best_p = p; }
+            else if (sum == best) {
+                const int4 bp = w.pairs[best_p];
+                if (pr.x < bp.x || (pr.x == bp.x && pr.y < bp.y)) best_p = p;
             }
         }
     }
-    // cross-wave reduction (lane 0 of each wave holds its candidate)
-    __syncthreads();
-    if (lane == 0) { s_val[wave] = best; s_idx[wave] = best_p; }
+    if (lane == 0) { s_val[wave] = nan_seen ? -1.0 : best; s_idx[wave] = best_p; }
     __syncthreads();
     best = dinf(); best_p = INT_MAX;
-    for (int wv = 0; wv < kSelThreads / 64; ++wv) {
+    bool bad = false;
+    for (int wv = 0; wv < kWaves; ++wv) {
         const double v = s_val[wv];
         const int p = s_idx[wv];
-        if (p == -1) { best = v; best_p = -1; break; }
+        if (v < 0.0) bad = true;
         if (p == INT_MAX) continue;
-        if (best_p == INT_MAX || v < best || (v == best && (s_pa[p] < s_pa[best_p] || (s_pa[p] == s_pa[best_p] && s_pb[p] < s_pb[best_p])))) {
-            best = v; best_p = p;
+        bool take = best_p == INT_MAX || v < best;
+        if (!take && v == best) {
+            const int4 q = w.pairs[p], bq = w.pairs[best_p];
+            take = q.x < bq.x || (q.x == bq.x && q.y < bq.y);
+        }
+        if (take) { best = v; best_p = p; }
+    }
+    __syncthreads();
+    if (bad) best_p = -1;  // NaN distance -> nan_error in the reference
+}
+
+__global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round index & 3 */) {
+    extern __shared__ double s_cvec[];  // [d] merged centroid (EXACT rows)
+    __shared__ double s_v1[kMaxBlocks], s_v2[kMaxBlocks], s_v3[kMaxBlocks], s_pv_in[kMaxBlocks];
+    __shared__ int4 s_ra[kMaxBlocks];
+    __shared__ int2 s_rb[kMaxBlocks], s_pi_in[kMaxBlocks];
+    __shared__ Top3 s_top[kWaves];
+    __shared__ double s_pv[kWaves];
+    __shared__ int s_pi[kWaves];
+    __shared__ double s_red[kWaves];
+    __shared__ double s_sq[kBlk];
+    __shared__ double s_val[kWaves];
+    __shared__ int s_idx[kWaves];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x, x = blk * kBlk + tid;
+    const int par = ph & 1, npar = par ^ 1;
+    const int Np = w.Np, nblk = w.nblk, d = w.d, N = w.N;
+    const AhcState st = w.state[par];
+    AhcState *const nst = w.state + npar;
+    if (blk == 0 && tid == 0) {  // clear the counters of the next round
+        WinCounters *z = w.cnt + ((ph + 1) & 3);
+        z->stale_key = ~0ULL; z->ncand = 0; z->npairs = 0;
+    }
+    if (st.done || st.halt) {
+        if (blk == 0 && tid == 0) { *nst = st; nst->prev_op = OP_NONE; nst->pend_row = -1; }
+        return;
+    }
+
+    // own row state (prefetch; independent of the decision)
+    int nx = w.node[x];
+    double d1x = w.d1[x];
+    int nnx = w.nn[x], nnnodex = w.nnnode[x];
+
+    // ---- phase 1: every workgroup reduces the same records -> the same decision --------------------------------
+    {
+        const size_t ro = static_cast<size_t>(par) * nblk;
+        for (int i = tid; i < nblk; i += kBlk) {
+            s_v1[i] = w.rec_v1[ro + i]; s_v2[i] = w.rec_v2[ro + i]; s_v3[i] = w.rec_v3[ro + i];
+            s_pv_in[i] = w.pend_v[ro + i];
+            s_ra[i] = w.rec_a[ro + i]; s_rb[i] = w.rec_b[ro + i]; s_pi_in[i] = w.pend_i[ro + i];
         }
     }
     __syncthreads();
-    best_a = best_p >= 0 && best_p != INT_MAX ? s_pa[best_p] : -1;
-    best_b = best_p >= 0 && best_p != INT_MAX ? s_pb[best_p] : -1;
-}
-
-__global__ __launch_bounds__(kSelThreads) void ahc_select(Ws w) {
-    __shared__ AhcState st;
-    __shared__ double s_val[kSelThreads / 64];
-    __shared__ int s_idx[kSelThreads / 64];
-    __shared__ double s_bm[kMaxBlocks];
-    __shared__ double s_sq[kSelThreads];
-    __shared__ int s_pa[kMaxPairs], s_pb[kMaxPairs];
-    __shared__ int s_cand[kMaxCand];
-    __shared__ int s_stale, s_best, s_cnt, s_nc;
-    const int tid = threadIdx.x;
-    AhcState *S = w.state;
-    if (tid == 0) st = *S;
-    __syncthreads();
-    if (st.done || st.halt) { if (tid == 0 && st.op != OP_NOOP) S->op = OP_NOOP; return; }
-    const int Np = w.Np, nblk = w.nblk, d = w.d;
-    int np = 0;        // pairs to evaluate exactly
-    double v = dinf();  // approximate (or, in exact mode, exact) value of the selected pair
-
-    // (1) finish the previous round
-    if (st.op == OP_MERGE || st.op == OP_RESCAN) {  // reduce the per-block partial minima of the row it produced
-        const int row = st.op == OP_MERGE ? st.a : st.r;
-        double rv = dinf();
-        int ix = INT_MAX;
-        for (int i = tid; i < nblk; i += kSelThreads) {
-            const double pv = w.pval[i];
-            const int pi = w.pidx[i];
-            if (pv < rv || (pv == rv && pi < ix)) { rv = pv; ix = pi; }
-        }
-        block_argmin<kSelThreads>(rv, ix, s_val, s_idx);
-        if (tid == 0) {
-            w.rowmin[row] = rv;
-            w.rownn[row] = ix == INT_MAX ? -1 : ix;
-            w.valid[row] = 1;
-        }
-        __syncthreads();
-        const int blk = row / kBlk;
-        double bv = dinf();
+    // (a) finish the row produced by the previous round
+    double pd1 = dinf();
+    int pnn = -1, pnnnode = -1;
+    const int P = st.pend_row;
+    if (P >= 0) {
+        double v = dinf();
         int bi = INT_MAX;
-        if (tid < kBlk) { const int x = blk * kBlk + tid; if (w.active[x]) { bv = w.rowmin[x]; bi = x; } }
-        block_argmin<kSelThreads>(bv, bi, s_val, s_idx);
-        if (tid == 0) w.bm[blk] = bv;
-        __syncthreads();
-    } else if (st.op == OP_WINDOW) {  // the apply pass listed every pair inside the ambiguity window
-        np = st.npairs;
-        if (np < 1 || np > kMaxPairs) {  // massive ties (duplicated inputs): continue with exact rows
-            if (tid == 0) { S->need_exact = 1; S->halt = 1; S->op = OP_NOOP; }
-            return;
-        }
-        for (int i = tid; i < np; i += kSelThreads) { s_pa[i] = w.pairs[2 * i]; s_pb[i] = w.pairs[2 * i + 1]; }
-        __syncthreads();
+        for (int i = lane; i < nblk; i += 64) if (s_pv_in[i] < v) { v = s_pv_in[i]; bi = i; }  // blocks ascending => lowest slot on ties
+        wave_argmin(v, bi);
+        pd1 = v;
+        if (bi != INT_MAX) { const int2 e = s_pi_in[bi]; pnn = e.x; pnnnode = e.y; }
+        if (x == P) { d1x = pd1; nnx = pnn; nnnodex = pnnnode; }
     }
-    if (st.step >= w.N - 1) {
-        if (tid == 0) { S->done = 1; S->op = OP_NOOP; }
-        return;
+    // (b) three smallest row minima over all blocks (+ the pending row)
+    Top3 g;
+    top3_init(g);
+    for (int i = lane; i < nblk; i += 64) {
+        top3_push(g, s_v1[i], 2 * i);
+        top3_push(g, s_v2[i], 2 * i + 1);
+        if (s_v3[i] < g.v3) g.v3 = s_v3[i];
     }
-
-    if (np == 0) {
-        // (2) global minimum over block minima; candidate rows within 2*eps of it
-        for (int i = tid; i < nblk; i += kSelThreads) s_bm[i] = w.bm[i];
-        if (tid == 0) { s_stale = INT_MAX; s_best = INT_MAX; s_cnt = 0; s_nc = 0; }
-        __syncthreads();
-        int vi = INT_MAX;
-        for (int i = tid; i < nblk; i += kSelThreads) if (s_bm[i] < v) { v = s_bm[i]; vi = i; }
-        block_argmin<kSelThreads>(v, vi, s_val, s_idx);
-        const double lim = v + 2.0 * st.eps;
-        for (int blk0 = 0; blk0 < nblk; blk0 += kSelThreads / kBlk) {
-            const int blk = blk0 + tid / kBlk;
-            if (blk < nblk && s_bm[blk] <= lim) {
-                const int x = blk * kBlk + (tid & (kBlk - 1));
-                const double rm = w.rowmin[x];
-                if (w.active[x] && rm <= lim) {
-                    if (!w.valid[x]) atomicMin(&s_stale, x);
-                    else {
-                        atomicAdd(&s_cnt, 1);
-                        if (rm == v) atomicMin(&s_best, x);
-                        const int i = atomicAdd(&s_nc, 1);
-                        if (i < kMaxCand) s_cand[i] = x;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (s_stale != INT_MAX) {  // a lower bound reached the minimum: re-scan that row first
-            if (tid == 0) { S->op = OP_RESCAN; S->r = s_stale; S->rescans = st.rescans + 1; S->rounds = st.rounds + 1; }
-            return;
-        }
-        const int r = s_best;
-        if (r == INT_MAX || !(v < dinf())) {  // cannot happen with finite data; stop rather than spin
-            if (tid == 0) { S->error = 2; S->halt = 1; S->op = OP_NOOP; }
-            return;
-        }
-        const int q = w.rownn[r];
-        if (st.mode == FA_AHC_MODE_AUTO) {
-            const bool mutual = s_cnt == 2 && q >= 0 && w.valid[q] && w.rownn[q] == r && w.rowmin[q] <= lim;
-            if (!mutual) {
-                // Several pairs lie within the rounding bound of the Lance-Williams rows.  Ask the apply pass to list
-                // every matrix entry <= lim in the candidate rows; the next select evaluates them exactly.
-                if (s_nc > kMaxCand) {
-                    if (tid == 0) { S->need_exact = 1; S->halt = 1; S->op = OP_NOOP; }
-                    return;
-                }
-                for (int i = tid; i < s_nc; i += kSelThreads) w.cand[i] = s_cand[i];
-                if (tid == 0) {
-                    S->op = OP_WINDOW; S->ncand = s_nc; S->npairs = 0; S->lim = lim;
-                    S->windows = st.windows + 1; S->rounds = st.rounds + 1;
-                }
-                return;
-            }
-        }
-        if (tid == 0) { s_pa[0] = r < q ? r : q; s_pb[0] = r < q ? q : r; }
-        np = 1;
-        __syncthreads();
+    wave_top3(g);
+    // candidate rows: (value, row, neighbour, nodes)
+    double g1 = g.v1, g2 = g.v2, g3 = g.v3;
+    int R1 = -1, Q1 = -1, NR1 = -1, NQ1 = -1, R2 = -1, Q2 = -1;
+    if (g.i1 != INT_MAX) {
+        const int o = g.i1 >> 1;
+        if (g.i1 & 1) { const int2 e = s_rb[o]; R1 = e.x; Q1 = e.y; }
+        else { const int4 e = s_ra[o]; R1 = e.x; Q1 = e.y; NR1 = e.z; NQ1 = e.w; }
+    }
+    if (g.i2 != INT_MAX) {
+        const int o = g.i2 >> 1;
+        if (g.i2 & 1) { const int2 e = s_rb[o]; R2 = e.x; Q2 = e.y; }
+        else { const int4 e = s_ra[o]; R2 = e.x; Q2 = e.y; }
+    }
+    // (g.i1 odd cannot happen: a block's second never precedes its first.)
+    if (P >= 0) {  // merge the pending row into the ordering
+        if (lt2(pd1, P, g1, R1 < 0 ? INT_MAX : R1)) {
+            g3 = g2; g2 = g1; R2 = R1; Q2 = Q1;
+            g1 = pd1; R1 = P; Q1 = pnn; NR1 = st.pend_node; NQ1 = pnnnode;
+        } else if (lt2(pd1, P, g2, R2 < 0 ? INT_MAX : R2)) {
+            g3 = g2; g2 = pd1; R2 = P; Q2 = pnn;
+        } else if (pd1 < g3) g3 = pd1;
     }
 
-    // (3) the reference's exact distance of the selected pair(s)
-    double dab = v;
-    int a = s_pa[0], b = s_pb[0];
-    if (st.mode == FA_AHC_MODE_AUTO) exact_min_pair(w, s_pa, s_pb, np, s_sq, s_val, s_idx, dab, a, b);
-    if (a < 0 || dab != dab) {  // NaN distance: nan_error in the reference (status 5)
-        if (tid == 0) { S->error = 1; S->halt = 1; S->op = OP_NOOP; }
-        return;
-    }
-    // (4) merged centroid (FastClusterWrapper.cpp:89-100) into slot a, plus a contiguous copy
-    const double ma = w.size[a], mb = w.size[b], den = ma + mb;
-    __syncthreads();
-    for (int k = tid; k < d; k += kSelThreads) {
-        const double xa = w.XT[static_cast<size_t>(k) * Np + a], xb = w.XT[static_cast<size_t>(k) * Np + b];
-        const double c = __ddiv_rn(__dadd_rn(__dmul_rn(xa, ma), __dmul_rn(xb, mb)), den);
-        w.XT[static_cast<size_t>(k) * Np + a] = c;
-        w.cvec[k] = c;
-    }
-    if (tid == 0) {
-        const int na = w.node[a], nb = w.node[b];
-        double *z = w.Z + static_cast<size_t>(st.step) * 4;
-        z[0] = na < nb ? na : nb;  // LinkageOutput::append (FastClusterWrapper.cpp:150-160)
-        z[1] = na < nb ? nb : na;
-        z[2] = dab;                // squared; sqrt applied after the loop (postprocess, :128-130)
-        z[3] = den;
-        w.size[a] = den;
-        w.node[a] = w.N + st.step;
-        w.active[b] = 0;
-        w.rowmin[b] = dinf();
-        w.valid[b] = 1;
-        S->op = OP_MERGE; S->a = a; S->b = b; S->dab = dab;
-        S->wa = ma / den; S->wb = mb / den; S->wab = (ma * mb) / (den * den);
-        S->step = st.step + 1;
-        S->rounds = st.rounds + 1;
-    }
-}
-
-// ------------------------------------------------------------------------------ round: apply
-__global__ __launch_bounds__(kBlk) void ahc_apply(Ws w) {
-    __shared__ double s_val[kBlk / 64];
-    __shared__ int s_idx[kBlk / 64];
-    const AhcState *S = w.state;
-    const int op = S->op;
-    if (op == OP_NOOP) return;
-    const int tid = threadIdx.x, blk = blockIdx.x, x = blk * kBlk + tid;
-    const int Np = w.Np;
-    if (op == OP_RESCAN) {
-        double v = w.M[static_cast<size_t>(S->r) * Np + x];
-        int ix = x;
-        block_argmin<kBlk>(v, ix, s_val, s_idx);
-        if (tid == 0) { w.pval[blk] = v; w.pidx[blk] = v < dinf() ? ix : INT_MAX; }
-        return;
-    }
-    if (op == OP_WINDOW) {  // list every entry of the candidate rows that lies inside the ambiguity window
-        const int nc = S->ncand;
-        const double lim = S->lim;
-        for (int j = 0; j < nc; ++j) {
-            const int row = w.cand[j];
-            const double val = w.M[static_cast<size_t>(row) * Np + x];
-            if (val <= lim) {
-                const int slot = atomicAdd(&w.state->npairs, 1);
-                if (slot < kMaxPairs) { w.pairs[2 * slot] = row < x ? row : x; w.pairs[2 * slot + 1] = row < x ? x : row; }
-            }
+    Decision D;
+    D.op = OP_NONE; D.a = D.b = D.na = D.nb = -1; D.dab = -1.0; D.lim = st.lim; D.halt = D.need_exact = D.error = D.done = 0;
+    const WinCounters *cr = w.cnt + ((ph + 3) & 3);
+    if (w.flags[0]) {
+        D.halt = 1; D.error = 1;  // NaN distance in an earlier round
+    } else if (st.step >= N - 1) {
+        D.done = 1;
+    } else if (st.prev_op == OP_COLLECT) {
+        const unsigned long long sk = cr->stale_key;
+        const int nc = cr->ncand;
+        if (sk != ~0ULL) { D.op = OP_RESCAN; D.a = static_cast<int>(sk >> 32); D.na = static_cast<int>(sk & 0xffffffffULL); }
+        else if (nc > kMaxCand || nc < 1) { D.halt = 1; D.need_exact = 1; }
+        else D.op = OP_PAIRS;
+    } else if (st.prev_op == OP_PAIRS) {
+        const int np = cr->npairs;
+        if (np > kMaxPairs || np < 1) { D.halt = 1; D.need_exact = 1; }
+        else {
+            double best; int bp;
+            exact_min_pair(w, np, s_sq, s_val, s_idx, best, bp);
+            if (bp < 0 || bp == INT_MAX) { D.halt = 1; D.error = 1; }
+            else { const int4 e = w.pairs[bp]; D.op = OP_MERGE; D.a = e.x; D.b = e.y; D.na = e.z; D.nb = e.w; D.dab = best; }
         }
-        return;
-    }
-    const int a = S->a, b = S->b;
-    const bool act = w.active[x] != 0 && x != a;
-    double dc = dinf();
-    if (S->mode == FA_AHC_MODE_AUTO) {
-        const double da = w.M[static_cast<size_t>(a) * Np + x];
-        const double db = w.M[static_cast<size_t>(b) * Np + x];
-        if (act) {  // Lance-Williams centroid update; only a filter, the winner is re-evaluated exactly
-            dc = S->wa * da + S->wb * db - S->wab * S->dab;
-            if (dc < 0.0) dc = 0.0;
-        }
+    } else if (R1 < 0 || !(g1 < dinf())) {
+        D.halt = 1; D.error = 2;  // cannot happen with finite data; stop rather than spin
+    } else if (Q1 < 0) {
+        D.op = OP_RESCAN; D.a = R1; D.na = NR1;  // a lower bound reached the minimum: re-scan that row first
+    } else if (st.mode == FA_AHC_MODE_EXACT) {
+        D.op = OP_MERGE;
     } else {
-        const int d = w.d;
-        const double *col = w.XT + x;
-        double sum = 0.0;
+        const double lim = g1 + 2.0 * st.eps;
+        // unique mutual-nearest pair, every other row minimum (bounds of stale rows included) beyond the window
+        if (g2 <= lim && !(g3 <= lim) && R2 == Q1 && Q2 == R1) D.op = OP_MERGE;
+        else { D.op = OP_COLLECT; D.lim = lim; }
+    }
+    if (D.op == OP_MERGE && D.a < 0) {
+        const bool lo = R1 < Q1;
+        D.a = lo ? R1 : Q1; D.b = lo ? Q1 : R1; D.na = lo ? NR1 : NQ1; D.nb = lo ? NQ1 : NR1;
+    }
+
+    // ---- phase 2 ------------------------------------------------------------------------------------------------
+    if (D.done || D.halt) {
+        if (blk == 0 && tid == 0) {
+            *nst = st;
+            nst->done = D.done; nst->halt = D.halt; nst->need_exact = D.need_exact; nst->error = D.error;
+            nst->prev_op = OP_NONE; nst->pend_row = -1;
+        }
+        if (x == P) { w.d1[x] = d1x; w.nn[x] = nnx; w.nnnode[x] = nnnodex; }
+        return;
+    }
+
+    double key = nx != kDead ? d1x : dinf();  // this row's entry in the next record
+    double pkey = dinf();                     // this column's entry of the row being produced
+    int new_pend = -1, new_pend_node = -1;
+    bool dirty = x == P;
+
+    if (D.op == OP_MERGE) {
+        const int a = D.a, b = D.b, na = D.na, nb = D.nb, nnew = N + st.step;
+        const double ma = w.sizes[na], mb = w.sizes[nb], den = ma + mb;
+        const double *ca = w.C + static_cast<size_t>(na) * d, *cb = w.C + static_cast<size_t>(nb) * d;
+        const bool act = nx != kDead && x != a && x != b;
+        double da = 0.0, db = 0.0;
+        if (act && st.mode == FA_AHC_MODE_AUTO) {  // valid copy of a pair lives in the row of the younger node
+            da = na > nx ? w.M[static_cast<size_t>(a) * Np + x] : w.M[static_cast<size_t>(x) * Np + a];
+            db = nb > nx ? w.M[static_cast<size_t>(b) * Np + x] : w.M[static_cast<size_t>(x) * Np + b];
+        }
+        // merged centroid (FastClusterWrapper.cpp:89-100) and a tree-summed |ca - cb|^2 (error <= ~9 ulp, independent of depth)
+        double part = 0.0;
+        for (int k = tid; k < d; k += kBlk) {
+            const double xa = ca[k], xb = cb[k];
+            const double c = __ddiv_rn(__dadd_rn(__dmul_rn(xa, ma), __dmul_rn(xb, mb)), den);
+            s_cvec[k] = c;
+            if (blk == 0) w.C[static_cast<size_t>(nnew) * d + k] = c;
+            const double diff = xa - xb;
+            part += diff * diff;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0) s_red[wave] = part;
+        __syncthreads();
+        double dab = D.dab;
+        if (dab < 0.0) dab = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        double dc = dinf();
+        if (st.mode == FA_AHC_MODE_AUTO) {
+            if (act) {  // Lance-Williams centroid update: a filter only, ties/near-ties are re-evaluated exactly
+                const double wa = ma / den, wb = mb / den, wab = (ma * mb) / (den * den);
+                dc = wa * da + wb * db - wab * dab;
+                if (dc < 0.0) dc = 0.0;
+            }
+        } else {
+            const double *col = w.XT + x;
+            double sum = 0.0;
 #pragma unroll 8
-        for (int k = 0; k < d; ++k) {
-            const double diff = __dsub_rn(w.cvec[k], col[static_cast<size_t>(k) * Np]);
-            sum = __dadd_rn(sum, __dmul_rn(diff, diff));  // sqeuclidean_extended (FastClusterWrapper.cpp:68-75)
+            for (int k = 0; k < d; ++k) {
+                const double diff = __dsub_rn(s_cvec[k], col[static_cast<size_t>(k) * Np]);
+                sum = __dadd_rn(sum, __dmul_rn(diff, diff));  // sqeuclidean_extended (FastClusterWrapper.cpp:68-75)
+            }
+            if (act) { dc = sum; if (sum != sum) w.flags[0] = 1; }
+            __syncthreads();
+            if (a / kBlk == blk)
+                for (int k = tid; k < d; k += kBlk) w.XT[static_cast<size_t>(k) * Np + a] = s_cvec[k];
         }
-        if (act) { dc = sum; if (sum != sum) w.state->error = 1; }
-    }
-    w.M[static_cast<size_t>(a) * Np + x] = dc;
-    double rm = dinf();
-    if (act) {
-        w.M[static_cast<size_t>(x) * Np + a] = dc;
-        w.M[static_cast<size_t>(x) * Np + b] = dinf();
-        rm = w.rowmin[x];
-        const int nn = w.rownn[x];
-        const int vld = w.valid[x];
-        if (dc < rm || (vld && dc == rm && a <= nn)) {
-            rm = dc;
-            w.rowmin[x] = dc; w.rownn[x] = a; w.valid[x] = 1;
-        } else if (vld && (nn == a || nn == b)) {
-            w.valid[x] = 0;  // minimum lost: rm stays as a lower bound
+        if (act) {
+            w.M[static_cast<size_t>(a) * Np + x] = dc;
+            const bool vld = nnx >= 0;
+            if (dc < d1x || (vld && dc == d1x && a <= nnx)) { d1x = dc; nnx = a; nnnodex = nnew; dirty = true; }
+            else if (vld && (nnx == a || nnx == b)) { nnx = -1; dirty = true; }  // minimum lost: d1 stays as a lower bound
+            key = d1x;
+            pkey = dc;
+        } else if (x == a) {
+            nx = nnew; d1x = dinf(); nnx = -1; nnnodex = -1; key = dinf(); dirty = true;
+            w.sizes[nnew] = den;
+        } else if (x == b) {
+            nx = kDead; d1x = dinf(); nnx = -1; nnnodex = -1; key = dinf(); dirty = true;
+        }
+        new_pend = a; new_pend_node = nnew;
+        if (blk == 0 && tid == 0) {
+            double *z = w.Z + static_cast<size_t>(st.step) * 4;
+            z[0] = na < nb ? na : nb;  // LinkageOutput::append (FastClusterWrapper.cpp:150-160)
+            z[1] = na < nb ? nb : na;
+            z[2] = 0.0;                // exact height filled by ahc_heights after the loop
+            z[3] = den;
+        }
+    } else if (D.op == OP_RESCAN) {
+        const int R = D.a, nR = D.na;
+        if (nx != kDead && x != R)
+            pkey = nR > nx ? w.M[static_cast<size_t>(R) * Np + x] : w.M[static_cast<size_t>(x) * Np + R];
+        if (x == R) { d1x = dinf(); nnx = -1; nnnodex = -1; key = dinf(); dirty = true; }  // pending until the next round
+        new_pend = R; new_pend_node = nR;
+    } else if (D.op == OP_COLLECT) {
+        WinCounters *cw = w.cnt + (ph & 3);
+        if (nx != kDead && d1x <= D.lim) {
+            if (nnx < 0) atomicMin(&cw->stale_key, (static_cast<unsigned long long>(x) << 32) | static_cast<unsigned>(nx));
+            else { const int i = atomicAdd(&cw->ncand, 1); if (i < kMaxCand) w.cand[i] = make_int2(x, nx); }
+        }
+    } else if (D.op == OP_PAIRS) {
+        WinCounters *cw = w.cnt + (ph & 3);
+        const int nc = cr->ncand;
+        for (int j = 0; j < nc; ++j) {
+            const int2 c = w.cand[j];
+            if (nx == kDead || x == c.x) continue;
+            const double val = c.y > nx ? w.M[static_cast<size_t>(c.x) * Np + x] : w.M[static_cast<size_t>(x) * Np + c.x];
+            if (val <= D.lim) {
+                const int slot = atomicAdd(&cw->npairs, 1);
+                if (slot < kMaxPairs) w.pairs[slot] = c.x < x ? make_int4(c.x, x, c.y, nx) : make_int4(x, c.x, nx, c.y);
+            }
         }
     }
-    // block minimum of row minima (row a is finished by the next select)
-    double bv = rm;
-    int bi = x;
-    block_argmin<kBlk>(bv, bi, s_val, s_idx);
-    if (tid == 0) w.bm[blk] = bv;
-    // partial minimum of the new row
-    double pv = dc;
-    int pi = x;
-    block_argmin<kBlk>(pv, pi, s_val, s_idx);
-    if (tid == 0) { w.pval[blk] = pv; w.pidx[blk] = pv < dinf() ? pi : INT_MAX; }
+
+    // own row state back to HBM (only when it changed), then the records of the next round
+    if (dirty) {
+        w.d1[x] = d1x; w.nn[x] = nnx; w.nnnode[x] = nnnodex;
+        if (D.op == OP_MERGE && (x == D.a || x == D.b)) w.node[x] = nx;
+    }
+    const BlockOut o = block_reduce(key, x, pkey, x, s_top, s_pv, s_pi);
+    write_record(w, npar, blk, o.rows, tid, x, nnx, nx, nnnodex);
+    if (tid == 0) {
+        const size_t po = static_cast<size_t>(npar) * nblk + blk;
+        w.pend_v[po] = o.pv;
+        if (!(o.pv < dinf())) w.pend_i[po] = make_int2(-1, -1);
+    }
+    if (o.pv < dinf() && x == o.pi) w.pend_i[static_cast<size_t>(npar) * nblk + blk] = make_int2(x, nx);
+    if (blk == 0 && tid == 0) {
+        AhcState n = st;
+        n.prev_op = D.op;
+        n.pend_row = new_pend; n.pend_node = new_pend_node;
+        n.lim = D.lim;
+        n.rounds = st.rounds + 1;
+        if (D.op == OP_MERGE) n.step = st.step + 1;
+        if (D.op == OP_RESCAN) n.rescans = st.rescans + 1;
+        if (D.op == OP_COLLECT) n.windows = st.windows + 1;
+        *nst = n;
+    }
 }
 
-__global__ void ahc_finish(Ws w) {  // heights: squared -> Euclidean (cluster_result::sqrt, FastClusterWrapper.cpp:128-130)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < w.N - 1) w.Z[static_cast<size_t>(i) * 4 + 2] = __dsqrt_rn(w.Z[static_cast<size_t>(i) * 4 + 2]);
+// Exact heights from the stored centroids, the reference's summation order, then sqrt
+// (cluster_result::sqrt, FastClusterWrapper.cpp:128-130).
+__global__ void ahc_heights(Ws w) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= w.N - 1) return;
+    double *z = w.Z + static_cast<size_t>(s) * 4;
+    const double *ca = w.C + static_cast<size_t>(z[0]) * w.d, *cb = w.C + static_cast<size_t>(z[1]) * w.d;
+    double sum = 0.0;
+    for (int k = 0; k < w.d; ++k) {
+        const double diff = __dsub_rn(ca[k], cb[k]);
+        sum = __dadd_rn(sum, __dmul_rn(diff, diff));
+    }
+    if (sum != sum) w.flags[0] = 1;
+    z[2] = __dsqrt_rn(sum);
 }
 
 // ------------------------------------------------------------------------------ host driver
 struct Layout {
-    size_t xt, m, rowmin, size, bm, pval, cvec, z, rownn, valid, active, node, pidx, cand, pairs, state, total;
+    size_t state, cnt, flags, c, xt, d1, sizes, z, nn, nnnode, node, rv1, rv2, rv3, ra, rb, pv, pi, cand, pairs, m, total;
 };
 
 Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
     Layout L{};
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~static_cast<size_t>(255); return at; };
-    L.state = take(sizeof(AhcState));
+    L.state = take(sizeof(AhcState) * 2);
+    L.cnt = take(sizeof(WinCounters) * 4);
+    L.flags = take(sizeof(int32_t) * 4);
+    L.c = take(sizeof(double) * d * 2 * N);
     L.xt = take(sizeof(double) * d * Np);
-    L.rowmin = take(sizeof(double) * Np);
-    L.size = take(sizeof(double) * Np);
-    L.bm = take(sizeof(double) * nblk);
-    L.pval = take(sizeof(double) * nblk);
-    L.cvec = take(sizeof(double) * d);
+    L.d1 = take(sizeof(double) * Np);
+    L.sizes = take(sizeof(double) * 2 * N);
     L.z = take(sizeof(double) * 4 * (N > 1 ? N - 1 : 1));
-    L.rownn = take(sizeof(int32_t) * Np);
-    L.valid = take(sizeof(int32_t) * Np);
-    L.active = take(sizeof(int32_t) * Np);
+    L.nn = take(sizeof(int32_t) * Np);
+    L.nnnode = take(sizeof(int32_t) * Np);
     L.node = take(sizeof(int32_t) * Np);
-    L.pidx = take(sizeof(int32_t) * nblk);
-    L.cand = take(sizeof(int32_t) * kMaxCand);
-    L.pairs = take(sizeof(int32_t) * 2 * kMaxPairs);
+    L.rv1 = take(sizeof(double) * 2 * nblk);
+    L.rv2 = take(sizeof(double) * 2 * nblk);
+    L.rv3 = take(sizeof(double) * 2 * nblk);
+    L.ra = take(sizeof(int4) * 2 * nblk);
+    L.rb = take(sizeof(int2) * 2 * nblk);
+    L.pv = take(sizeof(double) * 2 * nblk);
+    L.pi = take(sizeof(int2) * 2 * nblk);
+    L.cand = take(sizeof(int2) * kMaxCand);
+    L.pairs = take(sizeof(int4) * kMaxPairs);
     L.m = take(sizeof(double) * Np * Np);
     L.total = o;
     return L;
 }
 
+// exact matrix, row minima and parity-0 records of the clusters currently alive (XT must hold their coordinates)
 fa_status exact_rebuild(fa_ctx *ctx, const Ws &w) {
     const int tiles = w.Np / PT;
     hipLaunchKernelGGL(ahc_pairwise, dim3(tiles, tiles), dim3(256), 0, ctx->stream, w);
     hipLaunchKernelGGL(ahc_row_minima, dim3(w.Np), dim3(kBlk), 0, ctx->stream, w);
-    hipLaunchKernelGGL(ahc_block_minima, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);
+    hipLaunchKernelGGL(ahc_records, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }
@@ -553,6 +700,7 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     const size_t Np = (N + kBlk - 1) / kBlk * kBlk;
     const size_t nblk = Np / kBlk;
     if (nblk > kMaxBlocks) return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: N too large for the resident distance matrix");
+    if (d * sizeof(double) > 60 * 1024) return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: dimension too large for the LDS centroid buffer");
     const Layout L = make_layout(N, Np, d, nblk);
     if (ctx->ahc_ws_bytes < L.total) {
         if (ctx->ahc_ws) { FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ahc_ws); ctx->ahc_ws = nullptr; ctx->ahc_ws_bytes = 0; }
@@ -563,58 +711,73 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     char *base = static_cast<char *>(ctx->ahc_ws);
     Ws w{};
     w.state = reinterpret_cast<AhcState *>(base + L.state);
+    w.cnt = reinterpret_cast<WinCounters *>(base + L.cnt);
+    w.flags = reinterpret_cast<int32_t *>(base + L.flags);
+    w.C = reinterpret_cast<double *>(base + L.c);
     w.XT = reinterpret_cast<double *>(base + L.xt);
     w.M = reinterpret_cast<double *>(base + L.m);
-    w.rowmin = reinterpret_cast<double *>(base + L.rowmin);
-    w.size = reinterpret_cast<double *>(base + L.size);
-    w.bm = reinterpret_cast<double *>(base + L.bm);
-    w.pval = reinterpret_cast<double *>(base + L.pval);
-    w.cvec = reinterpret_cast<double *>(base + L.cvec);
+    w.d1 = reinterpret_cast<double *>(base + L.d1);
+    w.sizes = reinterpret_cast<double *>(base + L.sizes);
     w.Z = reinterpret_cast<double *>(base + L.z);
-    w.rownn = reinterpret_cast<int32_t *>(base + L.rownn);
-    w.valid = reinterpret_cast<int32_t *>(base + L.valid);
-    w.active = reinterpret_cast<int32_t *>(base + L.active);
+    w.nn = reinterpret_cast<int32_t *>(base + L.nn);
+    w.nnnode = reinterpret_cast<int32_t *>(base + L.nnnode);
     w.node = reinterpret_cast<int32_t *>(base + L.node);
-    w.pidx = reinterpret_cast<int32_t *>(base + L.pidx);
-    w.cand = reinterpret_cast<int32_t *>(base + L.cand);
-    w.pairs = reinterpret_cast<int32_t *>(base + L.pairs);
+    w.rec_v1 = reinterpret_cast<double *>(base + L.rv1);
+    w.rec_v2 = reinterpret_cast<double *>(base + L.rv2);
+    w.rec_v3 = reinterpret_cast<double *>(base + L.rv3);
+    w.rec_a = reinterpret_cast<int4 *>(base + L.ra);
+    w.rec_b = reinterpret_cast<int2 *>(base + L.rb);
+    w.pend_v = reinterpret_cast<double *>(base + L.pv);
+    w.pend_i = reinterpret_cast<int2 *>(base + L.pi);
+    w.cand = reinterpret_cast<int2 *>(base + L.cand);
+    w.pairs = reinterpret_cast<int4 *>(base + L.pairs);
     w.N = static_cast<int32_t>(N); w.Np = static_cast<int32_t>(Np); w.d = static_cast<int32_t>(d); w.nblk = static_cast<int32_t>(nblk);
+    const size_t lds = sizeof(double) * d;
 
     hipEvent_t ev[3];
     for (auto &e : ev) FA_HIP_TRY(ctx, hipEventCreate(&e));
     struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
 
-    AhcState init{};
-    init.mode = mode == FA_AHC_MODE_EXACT ? FA_AHC_MODE_EXACT : FA_AHC_MODE_AUTO;
+    AhcState init[2]{};
+    init[0].mode = mode == FA_AHC_MODE_EXACT ? FA_AHC_MODE_EXACT : FA_AHC_MODE_AUTO;
+    init[0].pend_row = -1; init[0].pend_node = -1; init[0].prev_op = OP_NONE;
+    init[1] = init[0];
+    WinCounters cinit[4];
+    for (auto &c : cinit) { c.stale_key = ~0ULL; c.ncand = 0; c.npairs = 0; }
     FA_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
-    FA_HIP_TRY(ctx, hipMemcpyAsync(w.state, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(ahc_init_rows, dim3((Np + 255) / 256), dim3(256), 0, ctx->stream, w);
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.state, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.cnt, cinit, sizeof(cinit), hipMemcpyHostToDevice, ctx->stream));
+    FA_HIP_TRY(ctx, hipMemsetAsync(w.flags, 0, sizeof(int32_t) * 4, ctx->stream));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(ahc_init_rows, dim3((std::max(Np, 2 * N) + 255) / 256), dim3(256), 0, ctx->stream, w);
     hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, ctx->stream, d_data, w.XT, w.N, w.Np, w.d);
     FA_TRY(exact_rebuild(ctx, w));
     AhcState h{};
+    int32_t hflag = 0;
     FA_HIP_TRY(ctx, hipMemcpyAsync(&h, w.state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(&hflag, w.flags, sizeof(hflag), hipMemcpyDeviceToHost, ctx->stream));
     FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (h.error) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
-    if (init.mode == FA_AHC_MODE_AUTO) {
+    if (hflag) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
+    if (init[0].mode == FA_AHC_MODE_AUTO) {
         double dmax;
         const long long bits = static_cast<long long>(h.dmax_bits);
         memcpy(&dmax, &bits, sizeof(dmax));
         // rounding bound of the Lance-Williams recurrence: <= 8 u dmax per merge level (3 products, 2 sums, 3 rounded
-        // weights), errors of the two parents enter with weights wa + wb = 1, tree depth <= N; factor 2 of margin.
+        // weights, the tree-summed d(a,b)), errors of the two parents enter with weights wa + wb = 1, tree depth <= N;
+        // factor 2 of margin.
         const double eps = 16.0 * static_cast<double>(N) * 1.1102230246251565e-16 * dmax;
         FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state) + offsetof(AhcState, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
     }
     FA_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
 
-    // one graph = kRoundsPerGraph (select, apply) pairs; replayed until the device reports done
+    // one graph = kRoundsPerGraph rounds; replayed until the device reports done
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool use_graph = true;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        for (int i = 0; i < kRoundsPerGraph; ++i) {
-            hipLaunchKernelGGL(ahc_select, dim3(1), dim3(kSelThreads), 0, ctx->stream, w);
-            hipLaunchKernelGGL(ahc_apply, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);
-        }
+        for (int i = 0; i < kRoundsPerGraph; ++i)
+            hipLaunchKernelGGL(ahc_round, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, w, i & 3);
         if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || !graph) use_graph = false;
         else if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) use_graph = false;
     } else use_graph = false;
@@ -622,34 +785,39 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     struct GraphGuard { hipGraph_t &g; hipGraphExec_t &e; ~GraphGuard() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); } } gg{graph, exec};
 
     long long fallback = 0;
-    const long long max_batches = 64 + 8 * static_cast<long long>(N) / kRoundsPerGraph;  // bound on rounds (merges + rescans)
+    const long long max_batches = 64 + 8 * static_cast<long long>(N) / kRoundsPerGraph;  // bound on rounds (merges + rescans + windows)
     fa_status st = FA_SUCCESS;
     for (long long it = 0; it < max_batches; ++it) {
         if (use_graph) FA_HIP_TRY(ctx, hipGraphLaunch(exec, ctx->stream));
         else
-            for (int i = 0; i < kRoundsPerGraph; ++i) {
-                hipLaunchKernelGGL(ahc_select, dim3(1), dim3(kSelThreads), 0, ctx->stream, w);
-                hipLaunchKernelGGL(ahc_apply, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);
-            }
+            for (int i = 0; i < kRoundsPerGraph; ++i)
+                hipLaunchKernelGGL(ahc_round, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, w, i & 3);
         FA_HIP_TRY(ctx, hipMemcpyAsync(&h, w.state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (h.error == 1) { st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance"); break; }
         if (h.error) { st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: internal selection failure (%d)", h.error); break; }
         if (h.done) break;
-        if (h.halt && h.need_exact) {  // ambiguity under the Lance-Williams filter: exact rows from here on
+        if (h.halt && h.need_exact) {  // ambiguity window overflow under the Lance-Williams filter: exact rows from here on
             ++fallback;
-            AhcState patch = h;
-            patch.halt = 0; patch.need_exact = 0; patch.mode = FA_AHC_MODE_EXACT; patch.eps = 0.0; patch.op = OP_NOOP;
-            FA_HIP_TRY(ctx, hipMemcpyAsync(w.state, &patch, sizeof(patch), hipMemcpyHostToDevice, ctx->stream));
+            AhcState patch[2];
+            patch[0] = h;
+            patch[0].halt = 0; patch[0].need_exact = 0; patch[0].mode = FA_AHC_MODE_EXACT; patch[0].eps = 0.0;
+            patch[0].prev_op = OP_NONE; patch[0].pend_row = -1; patch[0].pend_node = -1;
+            patch[1] = patch[0];
+            FA_HIP_TRY(ctx, hipMemcpyAsync(w.state, patch, sizeof(patch), hipMemcpyHostToDevice, ctx->stream));
+            FA_HIP_TRY(ctx, hipMemcpyAsync(w.cnt, cinit, sizeof(cinit), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(ahc_gather_xt, dim3((Np + 255) / 256), dim3(256), 0, ctx->stream, w);
             FA_TRY(exact_rebuild(ctx, w));
-        }
+        } else if (h.halt) { st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: halted without a reason"); break; }
     }
     if (st == FA_SUCCESS && !h.done) st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: round budget exhausted at step %d", h.step);
     if (st != FA_SUCCESS) return st;
-    hipLaunchKernelGGL(ahc_finish, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, w);
+    hipLaunchKernelGGL(ahc_heights, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, w);
     FA_HIP_TRY(ctx, hipMemcpyAsync(d_Z, w.Z, sizeof(double) * 4 * (N - 1), hipMemcpyDeviceToDevice, ctx->stream));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(&hflag, w.flags, sizeof(hflag), hipMemcpyDeviceToHost, ctx->stream));
     FA_HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
     FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (hflag) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
     if (stats) {
         float t01 = 0, t12 = 0;
         (void)hipEventElapsedTime(&t01, ev[0], ev[1]);

@@ -2,8 +2,8 @@
  * ahc_model.c — CPU MODEL of the GPU merge-round algorithm (test infrastructure only).
  *
  * Mirrors, step for step, the round structure of fluidaudio_amd/csrc/ahc.hip
- * (slot matrix M, per-row minima with lazy rescans, optional Lance-Williams filter with
- * exact re-verification) so that the algorithm itself can be checked against the
+ * (asymmetric slot matrix M, per-row minima with lazy rescans, Lance-Williams filter with
+ * mutual-nearest certification and exact window re-evaluation, exact heights after the loop) so that the algorithm itself can be checked against the
  * reference build (oracle/_ref) on the CPU, and so that round counts can be measured
  * before any GPU time is spent.  It is not an oracle (it restates nothing from the
  * reference) and nothing in the product path uses it.
@@ -17,35 +17,47 @@ typedef struct {
     long merges, rescans, rounds, ambiguous, exact_evals;
 } ahc_model_stats;
 
-static double sqdist_cols(const double *xt, size_t np, size_t d, size_t a, size_t b) {
+static double sqdist_rows(const double *c, size_t d, long a, long b) { /* the reference's sequential sum */
     double s = 0.0;
-    for (size_t k = 0; k < d; ++k) { const double diff = xt[k * np + a] - xt[k * np + b]; s += diff * diff; }
+    for (size_t k = 0; k < d; ++k) { const double diff = c[(size_t)a * d + k] - c[(size_t)b * d + k]; s += diff * diff; }
     return s;
 }
+static double treesum_rows(const double *c, size_t d, long a, long b) { /* pairwise-tree sum (what the device uses inside Lance-Williams) */
+    double part[256];
+    for (int t = 0; t < 256; ++t) part[t] = 0.0;
+    for (size_t k = 0; k < d; ++k) { const double diff = c[(size_t)a * d + k] - c[(size_t)b * d + k]; part[k & 255] += diff * diff; }
+    for (int w = 128; w > 0; w >>= 1) for (int t = 0; t < w; ++t) part[t] += part[t + w];
+    return part[0];
+}
 
-/* mode 0: exact rows (every matrix entry is the reference's sequential fp64 sum)
- * mode 1: Lance-Williams rows + exact verification of the selected pair; when several pairs lie within
- *         2*eps of the minimum (|S_eps| != one mutual pair) a WINDOW round re-evaluates every such matrix
- *         entry exactly.  eps = eps_scale * N * u * dmax (the library uses eps_scale = 16). */
+#define DEAD 0x7fffffffL
+/* valid copy of the pair (x, y): the row of the slot holding the younger node */
+#define VAL(x, y) (node[x] > node[y] ? M[(size_t)(x) * np + (y)] : M[(size_t)(y) * np + (x)])
+
+/* mode 0: exact rows (every new-row entry is the reference's sequential fp64 sum)
+ * mode 1: Lance-Williams rows; the pair is taken from them only when it is the unique mutual-nearest pair with
+ *         every other row minimum beyond 2*eps; otherwise every matrix entry inside the window is re-evaluated
+ *         exactly.  eps = eps_scale * N * u * dmax (the library uses eps_scale = 16).
+ * Storage is asymmetric like the device's: a merge writes ONE row; VAL() picks the valid copy.
+ * Heights are recomputed exactly after the loop from the stored centroids. */
 int ahc_model_linkage(const double *data, size_t n, size_t d, double *z, int mode, double eps_scale,
                       ahc_model_stats *st) {
     memset(st, 0, sizeof(*st));
     if (n < 2) return 0;
     const size_t np = n;
-    double *xt = (double *)malloc(sizeof(double) * d * np);
+    double *C = (double *)malloc(sizeof(double) * d * 2 * n);
     double *M = (double *)malloc(sizeof(double) * np * np);
-    double *rowmin = (double *)malloc(sizeof(double) * np);
-    long *rownn = (long *)malloc(sizeof(long) * np);
-    char *valid = (char *)malloc(np), *active = (char *)malloc(np);
-    double *size = (double *)malloc(sizeof(double) * np);
+    double *d1 = (double *)malloc(sizeof(double) * np);
+    long *nn = (long *)malloc(sizeof(long) * np);
     long *node = (long *)malloc(sizeof(long) * np);
-    if (!xt || !M || !rowmin || !rownn || !valid || !active || !size || !node) return 4;
-    for (size_t i = 0; i < n; ++i)
-        for (size_t k = 0; k < d; ++k) xt[k * np + i] = data[i * d + k];
+    double *size = (double *)malloc(sizeof(double) * 2 * n);
+    if (!C || !M || !d1 || !nn || !node || !size) return 4;
+    memcpy(C, data, sizeof(double) * n * d);
     double dmax = 0.0;
     for (size_t i = 0; i < n; ++i) {
+        node[i] = (long)i; size[i] = 1.0;
         for (size_t j = 0; j < n; ++j) {
-            double v = i == j ? INFINITY : sqdist_cols(xt, np, d, i, j);
+            double v = i == j ? INFINITY : sqdist_rows(C, d, (long)i, (long)j);
             M[i * np + j] = v;
             if (i != j && v > dmax) dmax = v;
         }
@@ -53,84 +65,95 @@ int ahc_model_linkage(const double *data, size_t n, size_t d, double *z, int mod
     for (size_t i = 0; i < n; ++i) {
         double mv = INFINITY; long mi = -1;
         for (size_t j = 0; j < n; ++j) if (M[i * np + j] < mv) { mv = M[i * np + j]; mi = (long)j; }
-        rowmin[i] = mv; rownn[i] = mi; valid[i] = 1; active[i] = 1; size[i] = 1.0; node[i] = (long)i;
+        d1[i] = mv; nn[i] = mi;
     }
     const double eps = mode == 1 ? eps_scale * (double)n * 1.1102230246251565e-16 * dmax : 0.0;
     size_t step = 0;
     while (step + 1 < n) {
         st->rounds++;
-        /* K1: global min over row minima (stale rows contribute their lower bound) */
-        double v = INFINITY;
-        for (size_t i = 0; i < n; ++i) if (active[i] && rowmin[i] < v) v = rowmin[i];
-        const double lim = v + 2.0 * eps;
-        long stale = -1, cnt = 0, r = -1;
+        /* three smallest row minima (value, row) */
+        double g1 = INFINITY, g2 = INFINITY, g3 = INFINITY; long R1 = -1, R2 = -1;
         for (size_t i = 0; i < n; ++i) {
-            if (!active[i] || !(rowmin[i] <= lim)) continue;
-            if (!valid[i]) { if (stale < 0) stale = (long)i; continue; }
-            ++cnt;
-            if (r < 0 && rowmin[i] == v) r = (long)i;
+            if (node[i] == DEAD) continue;
+            const double v = d1[i];
+            if (v < g1) { g3 = g2; g2 = g1; R2 = R1; g1 = v; R1 = (long)i; }
+            else if (v < g2) { g3 = g2; g2 = v; R2 = (long)i; }
+            else if (v < g3) g3 = v;
         }
-        if (stale >= 0) { /* RESCAN round */
+        if (R1 < 0) return 5;
+        long rescan = -1, a = -1, b = -1; double dab_exact = -1.0;
+        if (nn[R1] < 0) rescan = R1;
+        else if (mode == 0) { a = R1 < nn[R1] ? R1 : nn[R1]; b = R1 < nn[R1] ? nn[R1] : R1; }
+        else {
+            const double lim = g1 + 2.0 * eps;
+            if (g2 <= lim && !(g3 <= lim) && R2 == nn[R1] && nn[R2] == R1) { a = R1 < R2 ? R1 : R2; b = R1 < R2 ? R2 : R1; }
+            else {
+                /* COLLECT: stale rows inside the window are re-scanned first */
+                st->ambiguous++; st->rounds++;
+                for (size_t i = 0; i < n && rescan < 0; ++i) if (node[i] != DEAD && d1[i] <= lim && nn[i] < 0) rescan = (long)i;
+                if (rescan < 0) {
+                    st->rounds++;
+                    double best = INFINITY; long ba = -1, bb = -1;
+                    for (size_t i = 0; i < n; ++i) {
+                        if (node[i] == DEAD || !(d1[i] <= lim)) continue;
+                        for (size_t j = 0; j < n; ++j) {
+                            if (j == i || node[j] == DEAD || !(VAL(i, j) <= lim)) continue;
+                            const long pa = (long)(i < j ? i : j), pb = (long)(i < j ? j : i);
+                            const double e = sqdist_rows(C, d, node[pa], node[pb]);
+                            st->exact_evals++;
+                            if (e < best || (e == best && (pa < ba || (pa == ba && pb < bb)))) { best = e; ba = pa; bb = pb; }
+                        }
+                    }
+                    a = ba; b = bb; dab_exact = best;
+                }
+            }
+        }
+        if (rescan >= 0) {
             double mv = INFINITY; long mi = -1;
-            for (size_t j = 0; j < n; ++j) if (M[(size_t)stale * np + j] < mv) { mv = M[(size_t)stale * np + j]; mi = (long)j; }
-            rowmin[stale] = mv; rownn[stale] = mi; valid[stale] = 1;
+            for (size_t j = 0; j < n; ++j) {
+                if ((long)j == rescan || node[j] == DEAD) continue;
+                const double v = VAL(rescan, j);
+                if (v < mv) { mv = v; mi = (long)j; }
+            }
+            d1[rescan] = mv; nn[rescan] = mi;
             st->rescans++;
             continue;
         }
-        if (r < 0) return 5;
-        long q = rownn[r];
-        size_t a = (size_t)(r < q ? r : q), b = (size_t)(r < q ? q : r);
-        double dab = M[a * np + b];
-        if (mode == 1) {
-            if (!(cnt == 2 && rowmin[q] <= lim && rownn[q] == r)) {
-                /* WINDOW round: every matrix entry <= lim in the candidate rows is re-evaluated exactly;
-                 * the exact minimum wins, ties -> lexicographically lowest (a, b). */
-                st->ambiguous++;
-                st->rounds++;
-                double best = INFINITY; long ba = -1, bb = -1;
-                for (size_t i = 0; i < n; ++i) {
-                    if (!active[i] || !valid[i] || !(rowmin[i] <= lim)) continue;
-                    for (size_t j = 0; j < n; ++j) {
-                        if (!(M[i * np + j] <= lim)) continue;
-                        const long pa = (long)(i < j ? i : j), pb = (long)(i < j ? j : i);
-                        const double e = sqdist_cols(xt, np, d, (size_t)pa, (size_t)pb);
-                        st->exact_evals++;
-                        if (e < best || (e == best && (pa < ba || (pa == ba && pb < bb)))) { best = e; ba = pa; bb = pb; }
-                    }
-                }
-                a = (size_t)ba; b = (size_t)bb; dab = best;
-            } else { dab = sqdist_cols(xt, np, d, a, b); st->exact_evals++; }
-        }
-        const double ma = size[a], mb = size[b], den = ma + mb;
-        z[4 * step + 0] = (double)(node[a] < node[b] ? node[a] : node[b]);
-        z[4 * step + 1] = (double)(node[a] < node[b] ? node[b] : node[a]);
-        z[4 * step + 2] = sqrt(dab);
+        const long na = node[a], nb = node[b], nnew = (long)(n + step);
+        const double ma = size[na], mb = size[nb], den = ma + mb;
+        z[4 * step + 0] = (double)(na < nb ? na : nb);
+        z[4 * step + 1] = (double)(na < nb ? nb : na);
+        z[4 * step + 2] = 0.0;
         z[4 * step + 3] = den;
         for (size_t k = 0; k < d; ++k)
-            xt[k * np + a] = (xt[k * np + a] * ma + xt[k * np + b] * mb) / den;
-        size[a] = den; node[a] = (long)(n + step); active[b] = 0; rowmin[b] = INFINITY;
-        ++step; st->merges++;
-        /* K2: new row/column a, kill row/column b, maintain row minima */
+            C[(size_t)nnew * d + k] = (C[(size_t)na * d + k] * ma + C[(size_t)nb * d + k] * mb) / den;
+        const double dab = dab_exact >= 0.0 ? dab_exact : treesum_rows(C, d, na, nb);
         const double wa = ma / den, wb = mb / den, wab = (ma * mb) / (den * den);
         double nmv = INFINITY; long nmi = -1;
+        /* new row a (old node ids still in place while VAL() is evaluated) */
+        double *newrow = (double *)malloc(sizeof(double) * n);
         for (size_t x = 0; x < n; ++x) {
+            if (node[x] == DEAD || (long)x == a || (long)x == b) { newrow[x] = INFINITY; continue; }
             double dc;
-            if (!active[x] || x == a) dc = INFINITY;
-            else if (mode == 0) dc = sqdist_cols(xt, np, d, a, x);
-            else dc = wa * M[a * np + x] + wb * M[b * np + x] - wab * dab;
-            if (mode == 1 && dc < 0 && dc != INFINITY) dc = 0.0;
-            M[a * np + x] = dc; M[x * np + a] = dc;
-            M[b * np + x] = INFINITY; M[x * np + b] = INFINITY;
-            if (!active[x] || x == a) continue;
-            if (dc < nmv) { nmv = dc; nmi = (long)x; }
-            if (dc < rowmin[x] || (valid[x] && dc == rowmin[x] && (long)a <= rownn[x])) {
-                rowmin[x] = dc; rownn[x] = (long)a; valid[x] = 1;
-            } else if (valid[x] && (rownn[x] == (long)a || rownn[x] == (long)b)) {
-                valid[x] = 0;
-            }
+            if (mode == 0) dc = sqdist_rows(C, d, nnew, node[x]);
+            else { dc = wa * VAL(a, x) + wb * VAL(b, x) - wab * dab; if (dc < 0) dc = 0.0; }
+            newrow[x] = dc;
         }
-        rowmin[a] = nmv; rownn[a] = nmi; valid[a] = 1;
+        size[nnew] = den; node[a] = nnew; node[b] = DEAD; d1[b] = INFINITY; nn[b] = -1;
+        for (size_t x = 0; x < n; ++x) {
+            if (node[x] == DEAD || (long)x == a) continue;
+            const double dc = newrow[x];
+            M[(size_t)a * np + x] = dc;  /* the only matrix write of the merge */
+            if (dc < nmv) { nmv = dc; nmi = (long)x; }
+            const int vld = nn[x] >= 0;
+            if (dc < d1[x] || (vld && dc == d1[x] && a <= nn[x])) { d1[x] = dc; nn[x] = a; }
+            else if (vld && (nn[x] == a || nn[x] == b)) nn[x] = -1;
+        }
+        free(newrow);
+        d1[a] = nmv; nn[a] = nmi;
+        ++step; st->merges++;
     }
-    free(xt); free(M); free(rowmin); free(rownn); free(valid); free(active); free(size); free(node);
+    for (size_t s = 0; s + 1 < n; ++s) z[4 * s + 2] = sqrt(sqdist_rows(C, d, (long)z[4 * s], (long)z[4 * s + 1]));
+    free(C); free(M); free(d1); free(nn); free(node); free(size);
     return 0;
 }
