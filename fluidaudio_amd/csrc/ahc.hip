@@ -74,24 +74,32 @@ struct WinCounters {  // 4 copies rotating with the round index: [t&3] written, 
     int32_t ncand, npairs;
 };
 
+struct __attribute__((aligned(16))) Rec {  // per 256-row block, double buffered by round parity (64 B)
+    double v1, v2, v3;       // three smallest row minima of the block (bounds of stale rows included)
+    double pv;               // block-partial minimum of the row produced this round (+inf: none)
+    int r1, q1, nr1, nq1;    // row holding v1, its neighbour slot (-1: stale), their node ids
+    int pslot, pnode, pad0, pad1;  // column holding pv and its node id
+};
+
+struct __attribute__((aligned(16))) RowSt {  // per slot, owned by thread (slot & 255) of workgroup (slot >> 8)
+    double d1;               // minimum over all other live slots (lower bound while nn < 0)
+    int nn, nnnode;          // nearest neighbour slot (lowest on ties; -1: merged away) and its node id
+};
+
 struct Ws {
     double *M;       // [Np][Np]
     double *C;       // [2N][d]  centroids by node id (rows 0..N-1 = input points)
     double *XT;      // [d][Np]  slot-major transposed coordinates (init; maintained in EXACT mode only)
-    double *d1;      // [Np]
+    RowSt *row;      // [Np]
+    int32_t *node;   // [Np]
     double *sizes;   // [2N]     cluster size by node id
     double *Z;       // [(N-1)*4]
-    int32_t *nn, *nnnode, *node;  // [Np]
-    // block records, [2][nblk]
-    double *rec_v1, *rec_v2, *rec_v3;
-    int4 *rec_a;     // r1, q1, node(r1), node(q1)
-    int2 *rec_b;     // r2, q2
-    double *pend_v;  // [2][nblk]
-    int2 *pend_i;    // slot, node
+    Rec *rec;        // [2][nblk]
     int2 *cand;      // [kMaxCand]  slot, node
     int4 *pairs;     // [kMaxPairs] a, b, node a, node b
     WinCounters *cnt;  // [4]
     int32_t *flags;    // [0]: a NaN distance was seen (nan_error, FastClusterWrapper.cpp:60-62)
+    unsigned long long *prof;  // [16] cycle counters (FA_AHC_PROFILE builds only)
     AhcState *state;   // [2]
     int32_t N, Np, d, nblk;
 };
@@ -99,41 +107,44 @@ struct Ws {
 __device__ __forceinline__ double dinf() { return __longlong_as_double(0x7ff0000000000000LL); }
 __device__ __forceinline__ bool lt2(double v, int i, double ov, int oi) { return v < ov || (v == ov && i < oi); }
 
-// ------------------------------------------------------------------------------ wave helpers
-// (value, index) minimum over the 64 lanes, lower index on ties; result in every lane.
-__device__ __forceinline__ void wave_argmin(double &v, int &ix) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off);
-        const int oi = __shfl_xor(ix, off);
-        if (lt2(ov, oi, v, ix)) { v = ov; ix = oi; }
-    }
+// ------------------------------------------------------------------------------ wave helpers (DPP)
+// A 64-lane reduction through __shfl_xor costs ~6 dependent ds_bpermute round trips per 32-bit word (measured
+// ~1000 cycles per step for the 8-word payloads this kernel needs); DPP row shifts + row broadcasts stay in the
+// VALU.  Values are non-negative doubles (or +inf), never NaN.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(const double old, const double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
-
-struct Top3 {  // three smallest (value, index) keys seen, third as a value only
-    double v1, v2, v3;
-    int i1, i2;
-};
-__device__ __forceinline__ void top3_init(Top3 &t) { t.v1 = t.v2 = t.v3 = dinf(); t.i1 = t.i2 = INT_MAX; }
-__device__ __forceinline__ void top3_push(Top3 &t, double v, int i) {
-    if (lt2(v, i, t.v1, t.i1)) { t.v3 = t.v2; t.v2 = t.v1; t.i2 = t.i1; t.v1 = v; t.i1 = i; }
-    else if (lt2(v, i, t.v2, t.i2)) { t.v3 = t.v2; t.v2 = v; t.i2 = i; }
-    else if (v < t.v3) t.v3 = v;
+__device__ __forceinline__ double bcast_lane63(const double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
-__device__ __forceinline__ void top3_merge(Top3 &t, const Top3 &o) {
-    top3_push(t, o.v1, o.i1);
-    top3_push(t, o.v2, o.i2);
-    if (o.v3 < t.v3) t.v3 = o.v3;
+__device__ __forceinline__ double wave_min(double v) {  // result uniform
+    const double id = dinf();
+    v = fmin(v, dpp_f64<0x111, 0xf>(id, v));  // row_shr:1
+    v = fmin(v, dpp_f64<0x112, 0xf>(id, v));  // row_shr:2
+    v = fmin(v, dpp_f64<0x114, 0xf>(id, v));  // row_shr:4
+    v = fmin(v, dpp_f64<0x118, 0xf>(id, v));  // row_shr:8   -> lane 15 of each row holds the row minimum
+    v = fmin(v, dpp_f64<0x142, 0xa>(id, v));  // row_bcast:15 into rows 1, 3
+    v = fmin(v, dpp_f64<0x143, 0xc>(id, v));  // row_bcast:31 into rows 2, 3 -> lane 63 holds the minimum
+    return bcast_lane63(v);
 }
-__device__ __forceinline__ void wave_top3(Top3 &t) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        Top3 o;
-        o.v1 = __shfl_xor(t.v1, off); o.v2 = __shfl_xor(t.v2, off); o.v3 = __shfl_xor(t.v3, off);
-        o.i1 = __shfl_xor(t.i1, off); o.i2 = __shfl_xor(t.i2, off);
-        top3_merge(t, o);
-    }
+__device__ __forceinline__ double wave_sum(double v) {  // fixed association order; result uniform
+    v += dpp_f64<0x111, 0xf>(0.0, v);
+    v += dpp_f64<0x112, 0xf>(0.0, v);
+    v += dpp_f64<0x114, 0xf>(0.0, v);
+    v += dpp_f64<0x118, 0xf>(0.0, v);
+    v += dpp_f64<0x142, 0xa>(0.0, v);
+    v += dpp_f64<0x143, 0xc>(0.0, v);
+    return bcast_lane63(v);
 }
+// lowest lane whose value equals the (uniform) minimum
+__device__ __forceinline__ int first_lane_eq(const double v, const double m) {
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(v == m);
+    return __builtin_amdgcn_readfirstlane(mask ? __ffsll(static_cast<long long>(mask)) - 1 : 0);
+}
+__device__ __forceinline__ int lane_value(const int v, const int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
 // ------------------------------------------------------------------------------ init kernels
 __global__ void ahc_transpose(const double *__restrict__ data, double *__restrict__ XT, int N, int Np, int d) {
@@ -165,9 +176,8 @@ __global__ void ahc_init_rows(Ws w) {
     if (i < 2 * w.N) w.sizes[i] = 1.0;
     if (i >= w.Np) return;
     w.node[i] = i < w.N ? i : kDead;
-    w.nn[i] = -1;
-    w.nnnode[i] = -1;
-    w.d1[i] = dinf();
+    RowSt r; r.d1 = dinf(); r.nn = -1; r.nnnode = -1;
+    w.row[i] = r;
 }
 
 // Exact pairwise squared distances of the live slots, the reference's summation order
@@ -246,63 +256,86 @@ __global__ __launch_bounds__(kBlk) void ahc_row_minima(Ws w) {
             if (m < v) { v = m; ix = x; }  // x ascending per thread => lowest index kept
         }
     }
-    wave_argmin(v, ix);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(ix, off);
+        if (lt2(ov, oi, v, ix)) { v = ov; ix = oi; }
+    }
     if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = v; s_idx[threadIdx.x >> 6] = ix; }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int wv = 1; wv < kWaves; ++wv) if (lt2(s_val[wv], s_idx[wv], v, ix)) { v = s_val[wv]; ix = s_idx[wv]; }
-        w.d1[i] = v;
-        w.nn[i] = ix == INT_MAX ? -1 : ix;
-        w.nnnode[i] = ix == INT_MAX ? -1 : w.node[ix];
+        RowSt r; r.d1 = v; r.nn = ix == INT_MAX ? -1 : ix; r.nnnode = ix == INT_MAX ? -1 : w.node[ix];
+        w.row[i] = r;
     }
 }
 
 // ------------------------------------------------------------------------------ block record
-// Three smallest row minima of this workgroup's 256 rows (+ optionally the block-partial minimum of a row being
-// produced) -> the records of the NEXT round.  One __syncthreads.
-struct BlockOut {
-    Top3 rows;
-    double pv;
-    int pi;
-};
-__device__ __forceinline__ BlockOut block_reduce(double key, int x, double pkey, int px, Top3 *s_top, double *s_pv, int *s_pi) {
-    Top3 t;
-    top3_init(t);
-    top3_push(t, key, x);
-    wave_top3(t);
-    wave_argmin(pkey, px);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { s_top[wave] = t; s_pv[wave] = pkey; s_pi[wave] = px; }
-    __syncthreads();
-    BlockOut o;
-    o.rows = s_top[0]; o.pv = s_pv[0]; o.pi = s_pi[0];
-#pragma unroll
-    for (int wv = 1; wv < kWaves; ++wv) {
-        top3_merge(o.rows, s_top[wv]);
-        if (lt2(s_pv[wv], s_pi[wv], o.pv, o.pi)) { o.pv = s_pv[wv]; o.pi = s_pi[wv]; }
-    }
-    return o;
-}
+// Three smallest row minima of this workgroup's 256 rows, the row holding the smallest, and the block-partial
+// minimum of the row being produced -> record of the NEXT round.  Per wave: four DPP min-reductions (the winner
+// lane found by ballot, then masked out); across the four waves: LDS + ONE __syncthreads.
+struct WaveOut { double v1, v2, v3, pv; int i1, pi; };
 
-__device__ __forceinline__ void write_record(const Ws &w, int par, int blk, const Top3 &t, int tid, int x, int nnx, int nx, int nnnodex) {
-    const size_t o = static_cast<size_t>(par) * w.nblk + blk;
-    if (tid == 0) { w.rec_v1[o] = t.v1; w.rec_v2[o] = t.v2; w.rec_v3[o] = t.v3; }
-    if (x == t.i1) w.rec_a[o] = make_int4(x, nnx, nx, nnnodex);
-    if (x == t.i2) w.rec_b[o] = make_int2(x, nnx);
-    if (tid == 0 && t.i1 == INT_MAX) w.rec_a[o] = make_int4(-1, -1, -1, -1);
-    if (tid == 0 && t.i2 == INT_MAX) w.rec_b[o] = make_int2(-1, -1);
+__device__ __forceinline__ void block_record(const Ws &w, const int par, const int blk, const double key, const double pkey,
+                                             const int x, const int nx, const int nnx, const int nnnodex, WaveOut *s_out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    WaveOut o;
+    double k = key;
+    o.v1 = wave_min(k);
+    const int l1 = first_lane_eq(k, o.v1);  // lowest lane == lowest row of the wave
+    o.i1 = (wave << 6) + l1;
+    if (lane == l1) k = dinf();
+    o.v2 = wave_min(k);
+    const int l2 = first_lane_eq(k, o.v2);
+    if (lane == l2) k = dinf();
+    o.v3 = wave_min(k);
+    o.pv = wave_min(pkey);
+    o.pi = (wave << 6) + first_lane_eq(pkey, o.pv);
+    if (lane == 0) s_out[wave] = o;
+    __syncthreads();
+    // 4-way merge of the sorted triples (ties -> lowest wave == lowest rows); uniform arithmetic in every thread
+    double a[kWaves][3];
+    int head[kWaves];
+#pragma unroll
+    for (int wv = 0; wv < kWaves; ++wv) { a[wv][0] = s_out[wv].v1; a[wv][1] = s_out[wv].v2; a[wv][2] = s_out[wv].v3; head[wv] = 0; }
+    double m[3];
+    int first_wave = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double best = dinf();
+        int bw = -1;
+#pragma unroll
+        for (int wv = 0; wv < kWaves; ++wv) {
+            const double c = head[wv] == 0 ? a[wv][0] : head[wv] == 1 ? a[wv][1] : head[wv] == 2 ? a[wv][2] : dinf();
+            if (c < best) { best = c; bw = wv; }
+        }
+        m[r] = best;
+        if (r == 0) first_wave = bw;
+#pragma unroll
+        for (int wv = 0; wv < kWaves; ++wv) if (wv == bw) ++head[wv];
+    }
+    double pv = s_out[0].pv;
+    int pi = s_out[0].pi;
+#pragma unroll
+    for (int wv = 1; wv < kWaves; ++wv) if (s_out[wv].pv < pv) { pv = s_out[wv].pv; pi = s_out[wv].pi; }
+    const int i1 = first_wave >= 0 && m[0] < dinf() ? s_out[first_wave].i1 : -1;
+    Rec *rec = w.rec + static_cast<size_t>(par) * w.nblk + blk;
+    if (tid == 0) {
+        rec->v1 = m[0]; rec->v2 = m[1]; rec->v3 = m[2]; rec->pv = pv;
+        if (i1 < 0) { rec->r1 = -1; rec->q1 = -1; rec->nr1 = -1; rec->nq1 = -1; }
+        if (!(pv < dinf())) { rec->pslot = -1; rec->pnode = -1; }
+    }
+    if (tid == i1) { rec->r1 = x; rec->q1 = nnx; rec->nr1 = nx; rec->nq1 = nnnodex; }
+    if (pv < dinf() && tid == pi) { rec->pslot = x; rec->pnode = nx; }
 }
 
 __global__ __launch_bounds__(kBlk) void ahc_records(Ws w) {  // records of parity 0 from the row arrays
-    __shared__ Top3 s_top[kWaves];
-    __shared__ double s_pv[kWaves];
-    __shared__ int s_pi[kWaves];
+    __shared__ WaveOut s_out[kWaves];
     const int tid = threadIdx.x, blk = blockIdx.x, x = blk * kBlk + tid;
     const int nx = w.node[x];
-    const double key = nx != kDead ? w.d1[x] : dinf();
-    const BlockOut o = block_reduce(key, x, dinf(), INT_MAX, s_top, s_pv, s_pi);
-    write_record(w, 0, blk, o.rows, tid, x, w.nn[x], nx, w.nnnode[x]);
-    if (tid == 0) { w.pend_v[blk] = dinf(); w.pend_i[blk] = make_int2(-1, -1); }
+    const RowSt r = w.row[x];
+    block_record(w, 0, blk, nx != kDead ? r.d1 : dinf(), dinf(), x, nx, r.nn, r.nnnode, s_out);
 }
 
 // ------------------------------------------------------------------------------ the round kernel
@@ -374,15 +407,21 @@ __device__ void exact_min_pair(const Ws &w, const int np, double *s_sq /*[kWaves
     if (bad) best_p = -1;  // NaN distance -> nan_error in the reference
 }
 
+#ifdef FA_AHC_PROFILE
+#define AHC_STAMP(i)                                                                  \
+    do {                                                                              \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                   \
+        const unsigned long long t_now = clock64();                                   \
+        if (blk == prof_blk && tid == 0) atomicAdd(&w.prof[i], t_now - t_prev);       \
+        t_prev = t_now;                                                               \
+    } while (0)
+#else
+#define AHC_STAMP(i) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round index & 3 */) {
     extern __shared__ double s_cvec[];  // [d] merged centroid (EXACT rows)
-    __shared__ double s_v1[kMaxBlocks], s_v2[kMaxBlocks], s_v3[kMaxBlocks], s_pv_in[kMaxBlocks];
-    __shared__ int4 s_ra[kMaxBlocks];
-    __shared__ int2 s_rb[kMaxBlocks], s_pi_in[kMaxBlocks];
-    __shared__ Top3 s_top[kWaves];
-    __shared__ double s_pv[kWaves];
-    __shared__ int s_pi[kWaves];
-    __shared__ double s_red[kWaves];
+    __shared__ WaveOut s_out[kWaves];
     __shared__ double s_sq[kBlk];
     __shared__ double s_val[kWaves];
     __shared__ int s_idx[kWaves];
@@ -390,6 +429,10 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x, x = blk * kBlk + tid;
     const int par = ph & 1, npar = par ^ 1;
     const int Np = w.Np, nblk = w.nblk, d = w.d, N = w.N;
+#ifdef FA_AHC_PROFILE
+    const int prof_blk = gridDim.x / 2;
+    unsigned long long t_prev = clock64();
+#endif
     const AhcState st = w.state[par];
     AhcState *const nst = w.state + npar;
     if (blk == 0 && tid == 0) {  // clear the counters of the next round
@@ -401,70 +444,70 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
         return;
     }
 
-    // own row state (prefetch; independent of the decision)
+    // own row state (independent of the decision)
     int nx = w.node[x];
-    double d1x = w.d1[x];
-    int nnx = w.nn[x], nnnodex = w.nnnode[x];
+    RowSt rs = w.row[x];
+    const int nanflag = w.flags[0];
 
-    // ---- phase 1: every workgroup reduces the same records -> the same decision --------------------------------
+    // ---- phase 1: every WAVE of every workgroup reduces the same records -> the same decision (no barrier) ----------
+    // lane l owns the contiguous blocks [l*per, (l+1)*per): lane order == row order, so ballot+ffs breaks ties low.
+    const int per = (nblk + 63) >> 6;
+    double l1 = dinf(), l2 = dinf(), l3 = dinf(), lp = dinf();
+    int lr = -1, lq = -1, lnr = -1, lnq = -1, lps = -1, lpn = -1;
     {
-        const size_t ro = static_cast<size_t>(par) * nblk;
-        for (int i = tid; i < nblk; i += kBlk) {
-            s_v1[i] = w.rec_v1[ro + i]; s_v2[i] = w.rec_v2[ro + i]; s_v3[i] = w.rec_v3[ro + i];
-            s_pv_in[i] = w.pend_v[ro + i];
-            s_ra[i] = w.rec_a[ro + i]; s_rb[i] = w.rec_b[ro + i]; s_pi_in[i] = w.pend_i[ro + i];
+        const Rec *recs = w.rec + static_cast<size_t>(par) * nblk;
+        for (int j = 0; j < per; ++j) {
+            const int i = lane * per + j;
+            if (i >= nblk) break;
+            const int4 *p = reinterpret_cast<const int4 *>(recs + i);
+            const int4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            const double v1 = __hiloint2double(q0.y, q0.x), v2 = __hiloint2double(q0.w, q0.z);
+            const double v3 = __hiloint2double(q1.y, q1.x), pv = __hiloint2double(q1.w, q1.z);
+            if (v1 < l1) { l3 = l2; l2 = l1; l1 = v1; lr = q2.x; lq = q2.y; lnr = q2.z; lnq = q2.w; }
+            else if (v1 < l2) { l3 = l2; l2 = v1; }
+            else if (v1 < l3) l3 = v1;
+            if (v2 < l2) { l3 = l2; l2 = v2; } else if (v2 < l3) l3 = v2;
+            if (v3 < l3) l3 = v3;
+            if (pv < lp) { lp = pv; lps = q3.x; lpn = q3.y; }
         }
     }
-    __syncthreads();
+    AHC_STAMP(0);
     // (a) finish the row produced by the previous round
     double pd1 = dinf();
     int pnn = -1, pnnnode = -1;
     const int P = st.pend_row;
     if (P >= 0) {
-        double v = dinf();
-        int bi = INT_MAX;
-        for (int i = lane; i < nblk; i += 64) if (s_pv_in[i] < v) { v = s_pv_in[i]; bi = i; }  // blocks ascending => lowest slot on ties
-        wave_argmin(v, bi);
-        pd1 = v;
-        if (bi != INT_MAX) { const int2 e = s_pi_in[bi]; pnn = e.x; pnnnode = e.y; }
-        if (x == P) { d1x = pd1; nnx = pnn; nnnodex = pnnnode; }
+        pd1 = wave_min(lp);
+        if (pd1 < dinf()) { const int L = first_lane_eq(lp, pd1); pnn = lane_value(lps, L); pnnnode = lane_value(lpn, L); }
+        if (x == P) { rs.d1 = pd1; rs.nn = pnn; rs.nnnode = pnnnode; }
     }
-    // (b) three smallest row minima over all blocks (+ the pending row)
-    Top3 g;
-    top3_init(g);
-    for (int i = lane; i < nblk; i += 64) {
-        top3_push(g, s_v1[i], 2 * i);
-        top3_push(g, s_v2[i], 2 * i + 1);
-        if (s_v3[i] < g.v3) g.v3 = s_v3[i];
+    // (b) smallest row minimum (with its row) and the two next values over all blocks, then the pending row
+    double g1 = wave_min(l1);
+    int R1 = -1, Q1 = -1, NR1 = -1, NQ1 = -1;
+    {
+        const int L = first_lane_eq(l1, g1);
+        R1 = lane_value(lr, L); Q1 = lane_value(lq, L); NR1 = lane_value(lnr, L); NQ1 = lane_value(lnq, L);
+        if (lane == L) { l1 = l2; l2 = l3; l3 = dinf(); }
     }
-    wave_top3(g);
-    // candidate rows: (value, row, neighbour, nodes)
-    double g1 = g.v1, g2 = g.v2, g3 = g.v3;
-    int R1 = -1, Q1 = -1, NR1 = -1, NQ1 = -1, R2 = -1, Q2 = -1;
-    if (g.i1 != INT_MAX) {
-        const int o = g.i1 >> 1;
-        if (g.i1 & 1) { const int2 e = s_rb[o]; R1 = e.x; Q1 = e.y; }
-        else { const int4 e = s_ra[o]; R1 = e.x; Q1 = e.y; NR1 = e.z; NQ1 = e.w; }
+    double g2 = wave_min(l1);
+    {
+        const int L = first_lane_eq(l1, g2);
+        if (lane == L) { l1 = l2; l2 = l3; l3 = dinf(); }
     }
-    if (g.i2 != INT_MAX) {
-        const int o = g.i2 >> 1;
-        if (g.i2 & 1) { const int2 e = s_rb[o]; R2 = e.x; Q2 = e.y; }
-        else { const int4 e = s_ra[o]; R2 = e.x; Q2 = e.y; }
-    }
-    // (g.i1 odd cannot happen: a block's second never precedes its first.)
-    if (P >= 0) {  // merge the pending row into the ordering
+    double g3 = wave_min(l1);
+    if (!(g1 < dinf())) R1 = -1;
+    if (P >= 0) {
         if (lt2(pd1, P, g1, R1 < 0 ? INT_MAX : R1)) {
-            g3 = g2; g2 = g1; R2 = R1; Q2 = Q1;
+            g3 = g2; g2 = g1;
             g1 = pd1; R1 = P; Q1 = pnn; NR1 = st.pend_node; NQ1 = pnnnode;
-        } else if (lt2(pd1, P, g2, R2 < 0 ? INT_MAX : R2)) {
-            g3 = g2; g2 = pd1; R2 = P; Q2 = pnn;
-        } else if (pd1 < g3) g3 = pd1;
+        } else if (pd1 < g2) { g3 = g2; g2 = pd1; }
+        else if (pd1 < g3) g3 = pd1;
     }
 
     Decision D;
     D.op = OP_NONE; D.a = D.b = D.na = D.nb = -1; D.dab = -1.0; D.lim = st.lim; D.halt = D.need_exact = D.error = D.done = 0;
     const WinCounters *cr = w.cnt + ((ph + 3) & 3);
-    if (w.flags[0]) {
+    if (nanflag) {
         D.halt = 1; D.error = 1;  // NaN distance in an earlier round
     } else if (st.step >= N - 1) {
         D.done = 1;
@@ -483,22 +526,25 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
             if (bp < 0 || bp == INT_MAX) { D.halt = 1; D.error = 1; }
             else { const int4 e = w.pairs[bp]; D.op = OP_MERGE; D.a = e.x; D.b = e.y; D.na = e.z; D.nb = e.w; D.dab = best; }
         }
-    } else if (R1 < 0 || !(g1 < dinf())) {
+    } else if (R1 < 0) {
         D.halt = 1; D.error = 2;  // cannot happen with finite data; stop rather than spin
     } else if (Q1 < 0) {
         D.op = OP_RESCAN; D.a = R1; D.na = NR1;  // a lower bound reached the minimum: re-scan that row first
     } else if (st.mode == FA_AHC_MODE_EXACT) {
         D.op = OP_MERGE;
     } else {
+        // The pair (R1, Q1) is stored once, so row Q1 carries the same value: exactly two row minima inside the
+        // window [g1, g1 + 2 eps] means {R1, Q1} is the unique candidate pair (any other entry <= lim of either row
+        // would put a third row inside the window; bounds of stale rows count as row minima).
         const double lim = g1 + 2.0 * st.eps;
-        // unique mutual-nearest pair, every other row minimum (bounds of stale rows included) beyond the window
-        if (g2 <= lim && !(g3 <= lim) && R2 == Q1 && Q2 == R1) D.op = OP_MERGE;
+        if (g2 <= lim && !(g3 <= lim)) D.op = OP_MERGE;
         else { D.op = OP_COLLECT; D.lim = lim; }
     }
     if (D.op == OP_MERGE && D.a < 0) {
         const bool lo = R1 < Q1;
         D.a = lo ? R1 : Q1; D.b = lo ? Q1 : R1; D.na = lo ? NR1 : NQ1; D.nb = lo ? NQ1 : NR1;
     }
+    AHC_STAMP(1);
 
     // ---- phase 2 ------------------------------------------------------------------------------------------------
     if (D.done || D.halt) {
@@ -507,12 +553,12 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
             nst->done = D.done; nst->halt = D.halt; nst->need_exact = D.need_exact; nst->error = D.error;
             nst->prev_op = OP_NONE; nst->pend_row = -1;
         }
-        if (x == P) { w.d1[x] = d1x; w.nn[x] = nnx; w.nnnode[x] = nnnodex; }
+        if (x == P) w.row[x] = rs;
         return;
     }
 
-    double key = nx != kDead ? d1x : dinf();  // this row's entry in the next record
-    double pkey = dinf();                     // this column's entry of the row being produced
+    double key = nx != kDead ? rs.d1 : dinf();  // this row's entry in the next record
+    double pkey = dinf();                        // this column's entry of the row being produced
     int new_pend = -1, new_pend_node = -1;
     bool dirty = x == P;
 
@@ -526,22 +572,22 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
             da = na > nx ? w.M[static_cast<size_t>(a) * Np + x] : w.M[static_cast<size_t>(x) * Np + a];
             db = nb > nx ? w.M[static_cast<size_t>(b) * Np + x] : w.M[static_cast<size_t>(x) * Np + b];
         }
-        // merged centroid (FastClusterWrapper.cpp:89-100) and a tree-summed |ca - cb|^2 (error <= ~9 ulp, independent of depth)
+        // merged centroid (FastClusterWrapper.cpp:89-100), and |ca - cb|^2 summed as a tree (error <= ~10 ulp,
+        // independent of the merge depth).  Every wave evaluates the whole sum: no workgroup barrier.
         double part = 0.0;
-        for (int k = tid; k < d; k += kBlk) {
+        for (int k = lane; k < d; k += 64) {
             const double xa = ca[k], xb = cb[k];
             const double c = __ddiv_rn(__dadd_rn(__dmul_rn(xa, ma), __dmul_rn(xb, mb)), den);
-            s_cvec[k] = c;
-            if (blk == 0) w.C[static_cast<size_t>(nnew) * d + k] = c;
+            if (wave == 0) {
+                if (st.mode == FA_AHC_MODE_EXACT) s_cvec[k] = c;
+                if (blk == 0) w.C[static_cast<size_t>(nnew) * d + k] = c;
+            }
             const double diff = xa - xb;
             part += diff * diff;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-        if (lane == 0) s_red[wave] = part;
-        __syncthreads();
-        double dab = D.dab;
-        if (dab < 0.0) dab = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        double dab = wave_sum(part);
+        if (D.dab >= 0.0) dab = D.dab;
+        AHC_STAMP(2);
         double dc = dinf();
         if (st.mode == FA_AHC_MODE_AUTO) {
             if (act) {  // Lance-Williams centroid update: a filter only, ties/near-ties are re-evaluated exactly
@@ -550,6 +596,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
                 if (dc < 0.0) dc = 0.0;
             }
         } else {
+            __syncthreads();
             const double *col = w.XT + x;
             double sum = 0.0;
 #pragma unroll 8
@@ -564,16 +611,16 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
         }
         if (act) {
             w.M[static_cast<size_t>(a) * Np + x] = dc;
-            const bool vld = nnx >= 0;
-            if (dc < d1x || (vld && dc == d1x && a <= nnx)) { d1x = dc; nnx = a; nnnodex = nnew; dirty = true; }
-            else if (vld && (nnx == a || nnx == b)) { nnx = -1; dirty = true; }  // minimum lost: d1 stays as a lower bound
-            key = d1x;
+            const bool vld = rs.nn >= 0;
+            if (dc < rs.d1 || (vld && dc == rs.d1 && a <= rs.nn)) { rs.d1 = dc; rs.nn = a; rs.nnnode = nnew; dirty = true; }
+            else if (vld && (rs.nn == a || rs.nn == b)) { rs.nn = -1; dirty = true; }  // minimum lost: d1 stays as a lower bound
+            key = rs.d1;
             pkey = dc;
         } else if (x == a) {
-            nx = nnew; d1x = dinf(); nnx = -1; nnnodex = -1; key = dinf(); dirty = true;
+            nx = nnew; rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; key = dinf(); dirty = true;
             w.sizes[nnew] = den;
         } else if (x == b) {
-            nx = kDead; d1x = dinf(); nnx = -1; nnnodex = -1; key = dinf(); dirty = true;
+            nx = kDead; rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; key = dinf(); dirty = true;
         }
         new_pend = a; new_pend_node = nnew;
         if (blk == 0 && tid == 0) {
@@ -587,12 +634,12 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
         const int R = D.a, nR = D.na;
         if (nx != kDead && x != R)
             pkey = nR > nx ? w.M[static_cast<size_t>(R) * Np + x] : w.M[static_cast<size_t>(x) * Np + R];
-        if (x == R) { d1x = dinf(); nnx = -1; nnnodex = -1; key = dinf(); dirty = true; }  // pending until the next round
+        if (x == R) { rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; key = dinf(); dirty = true; }  // pending until the next round
         new_pend = R; new_pend_node = nR;
     } else if (D.op == OP_COLLECT) {
         WinCounters *cw = w.cnt + (ph & 3);
-        if (nx != kDead && d1x <= D.lim) {
-            if (nnx < 0) atomicMin(&cw->stale_key, (static_cast<unsigned long long>(x) << 32) | static_cast<unsigned>(nx));
+        if (nx != kDead && rs.d1 <= D.lim) {
+            if (rs.nn < 0) atomicMin(&cw->stale_key, (static_cast<unsigned long long>(x) << 32) | static_cast<unsigned>(nx));
             else { const int i = atomicAdd(&cw->ncand, 1); if (i < kMaxCand) w.cand[i] = make_int2(x, nx); }
         }
     } else if (D.op == OP_PAIRS) {
@@ -608,20 +655,15 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
             }
         }
     }
+    AHC_STAMP(3);
 
-    // own row state back to HBM (only when it changed), then the records of the next round
+    // own row state back to HBM (only when it changed), then the record of the next round
     if (dirty) {
-        w.d1[x] = d1x; w.nn[x] = nnx; w.nnnode[x] = nnnodex;
+        w.row[x] = rs;
         if (D.op == OP_MERGE && (x == D.a || x == D.b)) w.node[x] = nx;
     }
-    const BlockOut o = block_reduce(key, x, pkey, x, s_top, s_pv, s_pi);
-    write_record(w, npar, blk, o.rows, tid, x, nnx, nx, nnnodex);
-    if (tid == 0) {
-        const size_t po = static_cast<size_t>(npar) * nblk + blk;
-        w.pend_v[po] = o.pv;
-        if (!(o.pv < dinf())) w.pend_i[po] = make_int2(-1, -1);
-    }
-    if (o.pv < dinf() && x == o.pi) w.pend_i[static_cast<size_t>(npar) * nblk + blk] = make_int2(x, nx);
+    block_record(w, npar, blk, key, pkey, x, nx, rs.nn, rs.nnnode, s_out);
+    AHC_STAMP(4);
     if (blk == 0 && tid == 0) {
         AhcState n = st;
         n.prev_op = D.op;
@@ -633,6 +675,10 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
         if (D.op == OP_COLLECT) n.windows = st.windows + 1;
         *nst = n;
     }
+    AHC_STAMP(5);
+#ifdef FA_AHC_PROFILE
+    if (blk == prof_blk && tid == 0) atomicAdd(&w.prof[15], 1ULL);
+#endif
 }
 
 // Exact heights from the stored centroids, the reference's summation order, then sqrt
@@ -653,7 +699,7 @@ __global__ void ahc_heights(Ws w) {
 
 // ------------------------------------------------------------------------------ host driver
 struct Layout {
-    size_t state, cnt, flags, c, xt, d1, sizes, z, nn, nnnode, node, rv1, rv2, rv3, ra, rb, pv, pi, cand, pairs, m, total;
+    size_t state, cnt, flags, prof, c, xt, row, node, sizes, z, rec, cand, pairs, m, total;
 };
 
 Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
@@ -663,23 +709,16 @@ Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
     L.state = take(sizeof(AhcState) * 2);
     L.cnt = take(sizeof(WinCounters) * 4);
     L.flags = take(sizeof(int32_t) * 4);
-    L.c = take(sizeof(double) * d * 2 * N);
-    L.xt = take(sizeof(double) * d * Np);
-    L.d1 = take(sizeof(double) * Np);
+    L.prof = take(sizeof(unsigned long long) * 16);
+    L.rec = take(sizeof(Rec) * 2 * nblk);
+    L.row = take(sizeof(RowSt) * Np);
+    L.node = take(sizeof(int32_t) * Np);
     L.sizes = take(sizeof(double) * 2 * N);
     L.z = take(sizeof(double) * 4 * (N > 1 ? N - 1 : 1));
-    L.nn = take(sizeof(int32_t) * Np);
-    L.nnnode = take(sizeof(int32_t) * Np);
-    L.node = take(sizeof(int32_t) * Np);
-    L.rv1 = take(sizeof(double) * 2 * nblk);
-    L.rv2 = take(sizeof(double) * 2 * nblk);
-    L.rv3 = take(sizeof(double) * 2 * nblk);
-    L.ra = take(sizeof(int4) * 2 * nblk);
-    L.rb = take(sizeof(int2) * 2 * nblk);
-    L.pv = take(sizeof(double) * 2 * nblk);
-    L.pi = take(sizeof(int2) * 2 * nblk);
     L.cand = take(sizeof(int2) * kMaxCand);
     L.pairs = take(sizeof(int4) * kMaxPairs);
+    L.c = take(sizeof(double) * d * 2 * N);
+    L.xt = take(sizeof(double) * d * Np);
     L.m = take(sizeof(double) * Np * Np);
     L.total = o;
     return L;
@@ -713,24 +752,17 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     w.state = reinterpret_cast<AhcState *>(base + L.state);
     w.cnt = reinterpret_cast<WinCounters *>(base + L.cnt);
     w.flags = reinterpret_cast<int32_t *>(base + L.flags);
+    w.prof = reinterpret_cast<unsigned long long *>(base + L.prof);
+    w.rec = reinterpret_cast<Rec *>(base + L.rec);
+    w.row = reinterpret_cast<RowSt *>(base + L.row);
+    w.node = reinterpret_cast<int32_t *>(base + L.node);
+    w.sizes = reinterpret_cast<double *>(base + L.sizes);
+    w.Z = reinterpret_cast<double *>(base + L.z);
+    w.cand = reinterpret_cast<int2 *>(base + L.cand);
+    w.pairs = reinterpret_cast<int4 *>(base + L.pairs);
     w.C = reinterpret_cast<double *>(base + L.c);
     w.XT = reinterpret_cast<double *>(base + L.xt);
     w.M = reinterpret_cast<double *>(base + L.m);
-    w.d1 = reinterpret_cast<double *>(base + L.d1);
-    w.sizes = reinterpret_cast<double *>(base + L.sizes);
-    w.Z = reinterpret_cast<double *>(base + L.z);
-    w.nn = reinterpret_cast<int32_t *>(base + L.nn);
-    w.nnnode = reinterpret_cast<int32_t *>(base + L.nnnode);
-    w.node = reinterpret_cast<int32_t *>(base + L.node);
-    w.rec_v1 = reinterpret_cast<double *>(base + L.rv1);
-    w.rec_v2 = reinterpret_cast<double *>(base + L.rv2);
-    w.rec_v3 = reinterpret_cast<double *>(base + L.rv3);
-    w.rec_a = reinterpret_cast<int4 *>(base + L.ra);
-    w.rec_b = reinterpret_cast<int2 *>(base + L.rb);
-    w.pend_v = reinterpret_cast<double *>(base + L.pv);
-    w.pend_i = reinterpret_cast<int2 *>(base + L.pi);
-    w.cand = reinterpret_cast<int2 *>(base + L.cand);
-    w.pairs = reinterpret_cast<int4 *>(base + L.pairs);
     w.N = static_cast<int32_t>(N); w.Np = static_cast<int32_t>(Np); w.d = static_cast<int32_t>(d); w.nblk = static_cast<int32_t>(nblk);
     const size_t lds = sizeof(double) * d;
 
@@ -748,6 +780,7 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     FA_HIP_TRY(ctx, hipMemcpyAsync(w.state, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
     FA_HIP_TRY(ctx, hipMemcpyAsync(w.cnt, cinit, sizeof(cinit), hipMemcpyHostToDevice, ctx->stream));
     FA_HIP_TRY(ctx, hipMemsetAsync(w.flags, 0, sizeof(int32_t) * 4, ctx->stream));
+    FA_HIP_TRY(ctx, hipMemsetAsync(w.prof, 0, sizeof(unsigned long long) * 16, ctx->stream));
     FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(ahc_init_rows, dim3((std::max(Np, 2 * N) + 255) / 256), dim3(256), 0, ctx->stream, w);
     hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, ctx->stream, d_data, w.XT, w.N, w.Np, w.d);
@@ -818,6 +851,15 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     FA_HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
     FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (hflag) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
+#ifdef FA_AHC_PROFILE
+    {
+        unsigned long long hp[16];
+        (void)hipMemcpy(hp, w.prof, sizeof(hp), hipMemcpyDeviceToHost);
+        const double n = hp[15] ? static_cast<double>(hp[15]) : 1.0;
+        fprintf(stderr, "ahc profile (cycles/round, block %d of %d, %llu rounds): load+sync %.0f | decide %.0f | merge loads+dab %.0f | row update %.0f | block reduce %.0f | tail %.0f\n",
+                w.nblk / 2, w.nblk, hp[15], hp[0] / n, hp[1] / n, hp[2] / n, hp[3] / n, hp[4] / n, hp[5] / n);
+    }
+#endif
     if (stats) {
         float t01 = 0, t12 = 0;
         (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
