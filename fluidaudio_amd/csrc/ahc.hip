@@ -120,15 +120,27 @@ __device__ __forceinline__ double dpp_f64(const double old, const double v) {
 __device__ __forceinline__ double bcast_lane63(const double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
-__device__ __forceinline__ double wave_min(double v) {  // result uniform
-    const double id = dinf();
-    v = fmin(v, dpp_f64<0x111, 0xf>(id, v));  // row_shr:1
-    v = fmin(v, dpp_f64<0x112, 0xf>(id, v));  // row_shr:2
-    v = fmin(v, dpp_f64<0x114, 0xf>(id, v));  // row_shr:4
-    v = fmin(v, dpp_f64<0x118, 0xf>(id, v));  // row_shr:8   -> lane 15 of each row holds the row minimum
-    v = fmin(v, dpp_f64<0x142, 0xa>(id, v));  // row_bcast:15 into rows 1, 3
-    v = fmin(v, dpp_f64<0x143, 0xc>(id, v));  // row_bcast:31 into rows 2, 3 -> lane 63 holds the minimum
-    return bcast_lane63(v);
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_umin(const unsigned v) {
+    const unsigned o = static_cast<unsigned>(__builtin_amdgcn_update_dpp(-1, static_cast<int>(v), CTRL, ROWMASK, 0xf, false));
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_umin(unsigned v) {  // result uniform
+    v = dpp_umin<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_umin<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_umin<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_umin<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row minimum
+    v = dpp_umin<0x142, 0xa>(v);  // row_bcast:15 into rows 1, 3
+    v = dpp_umin<0x143, 0xc>(v);  // row_bcast:31 into rows 2, 3 -> lane 63 holds the minimum
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+// Minimum of non-negative doubles (+0 .. +inf: the IEEE bit pattern is monotone) as two 32-bit DPP reductions;
+// v_min_u32 takes the DPP operand directly, v_min_f64 would need two v_mov_dpp per step.
+__device__ __forceinline__ double wave_min(const double v) {  // result uniform
+    const unsigned hi = static_cast<unsigned>(__double2hiint(v)), lo = static_cast<unsigned>(__double2loint(v));
+    const unsigned mhi = wave_umin(hi);
+    const unsigned mlo = wave_umin(hi == mhi ? lo : 0xffffffffu);
+    return __hiloint2double(static_cast<int>(mhi), static_cast<int>(mlo));
 }
 __device__ __forceinline__ double wave_sum(double v) {  // fixed association order; result uniform
     v += dpp_f64<0x111, 0xf>(0.0, v);
@@ -412,7 +424,7 @@ __device__ void exact_min_pair(const Ws &w, const int np, double *s_sq /*[kWaves
     do {                                                                              \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                   \
         const unsigned long long t_now = clock64();                                   \
-        if (blk == prof_blk && tid == 0) atomicAdd(&w.prof[i], t_now - t_prev);       \
+        t_seg[i] = t_now - t_prev;                                                    \
         t_prev = t_now;                                                               \
     } while (0)
 #else
@@ -431,20 +443,13 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
     const int Np = w.Np, nblk = w.nblk, d = w.d, N = w.N;
 #ifdef FA_AHC_PROFILE
     const int prof_blk = gridDim.x / 2;
+    unsigned long long t_seg[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = clock64();
 #endif
+    // Every load of the round's first memory round trip is issued before anything is branched on: state, own row
+    // state and the block records all have addresses that depend on kernel arguments only.
     const AhcState st = w.state[par];
     AhcState *const nst = w.state + npar;
-    if (blk == 0 && tid == 0) {  // clear the counters of the next round
-        WinCounters *z = w.cnt + ((ph + 1) & 3);
-        z->stale_key = ~0ULL; z->ncand = 0; z->npairs = 0;
-    }
-    if (st.done || st.halt) {
-        if (blk == 0 && tid == 0) { *nst = st; nst->prev_op = OP_NONE; nst->pend_row = -1; }
-        return;
-    }
-
-    // own row state (independent of the decision)
     int nx = w.node[x];
     RowSt rs = w.row[x];
     const int nanflag = w.flags[0];
@@ -456,20 +461,32 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
     int lr = -1, lq = -1, lnr = -1, lnq = -1, lps = -1, lpn = -1;
     {
         const Rec *recs = w.rec + static_cast<size_t>(par) * nblk;
-        for (int j = 0; j < per; ++j) {
-            const int i = lane * per + j;
-            if (i >= nblk) break;
-            const int4 *p = reinterpret_cast<const int4 *>(recs + i);
-            const int4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-            const double v1 = __hiloint2double(q0.y, q0.x), v2 = __hiloint2double(q0.w, q0.z);
-            const double v3 = __hiloint2double(q1.y, q1.x), pv = __hiloint2double(q1.w, q1.z);
-            if (v1 < l1) { l3 = l2; l2 = l1; l1 = v1; lr = q2.x; lq = q2.y; lnr = q2.z; lnq = q2.w; }
-            else if (v1 < l2) { l3 = l2; l2 = v1; }
-            else if (v1 < l3) l3 = v1;
-            if (v2 < l2) { l3 = l2; l2 = v2; } else if (v2 < l3) l3 = v2;
-            if (v3 < l3) l3 = v3;
-            if (pv < lp) { lp = pv; lps = q3.x; lpn = q3.y; }
-        }
+        constexpr int kBatch = 4;  // records in flight per lane: all loads of a batch are issued before any is used
+        auto batch = [&](const int j0) {
+            int4 q[kBatch][4];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int i = lane * per + j0 + j;
+                const int4 *p = reinterpret_cast<const int4 *>(recs + (i < nblk && j0 + j < per ? i : 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[j][e] = p[e];
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int i = lane * per + j0 + j;
+                if (i >= nblk || j0 + j >= per) continue;
+                const double v1 = __hiloint2double(q[j][0].y, q[j][0].x), v2 = __hiloint2double(q[j][0].w, q[j][0].z);
+                const double v3 = __hiloint2double(q[j][1].y, q[j][1].x), pv = __hiloint2double(q[j][1].w, q[j][1].z);
+                if (v1 < l1) { l3 = l2; l2 = l1; l1 = v1; lr = q[j][2].x; lq = q[j][2].y; lnr = q[j][2].z; lnq = q[j][2].w; }
+                else if (v1 < l2) { l3 = l2; l2 = v1; }
+                else if (v1 < l3) l3 = v1;
+                if (v2 < l2) { l3 = l2; l2 = v2; } else if (v2 < l3) l3 = v2;
+                if (v3 < l3) l3 = v3;
+                if (pv < lp) { lp = pv; lps = q[j][3].x; lpn = q[j][3].y; }
+            }
+        };
+        batch(0);  // N <= 65 536: the only batch, straight-line
+        for (int j0 = kBatch; j0 < per; j0 += kBatch) batch(j0);
     }
     AHC_STAMP(0);
     // (a) finish the row produced by the previous round
@@ -502,6 +519,15 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
             g1 = pd1; R1 = P; Q1 = pnn; NR1 = st.pend_node; NQ1 = pnnnode;
         } else if (pd1 < g2) { g3 = g2; g2 = pd1; }
         else if (pd1 < g3) g3 = pd1;
+    }
+
+    if (st.done || st.halt) {  // finished or waiting for the host: carry the state forward
+        if (blk == 0 && tid == 0) { *nst = st; nst->prev_op = OP_NONE; nst->pend_row = -1; }
+        return;
+    }
+    if (blk == 0 && tid == 0) {  // clear the window counters of the next round
+        WinCounters *z = w.cnt + ((ph + 1) & 3);
+        z->stale_key = ~0ULL; z->ncand = 0; z->npairs = 0;
     }
 
     Decision D;
@@ -593,7 +619,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
             if (act) {  // Lance-Williams centroid update: a filter only, ties/near-ties are re-evaluated exactly
                 const double wa = ma / den, wb = mb / den, wab = (ma * mb) / (den * den);
                 dc = wa * da + wb * db - wab * dab;
-                if (dc < 0.0) dc = 0.0;
+                if (!(dc > 0.0)) dc = 0.0;  // also keeps -0.0 out of the bit-pattern reductions
             }
         } else {
             __syncthreads();
@@ -677,7 +703,10 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
     }
     AHC_STAMP(5);
 #ifdef FA_AHC_PROFILE
-    if (blk == prof_blk && tid == 0) atomicAdd(&w.prof[15], 1ULL);
+    if (blk == prof_blk && tid == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&w.prof[i], t_seg[i]);
+        atomicAdd(&w.prof[15], 1ULL);
+    }
 #endif
 }
 

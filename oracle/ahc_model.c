@@ -30,6 +30,9 @@ static double treesum_rows(const double *c, size_t d, long a, long b) { /* pairw
     return part[0];
 }
 
+static int g_piggy = 0;  /* piggy-back re-scans per merge round (0 = the lazy scheme only) */
+void ahc_model_set_piggyback(int k) { g_piggy = k; }
+
 #define DEAD 0x7fffffffL
 /* valid copy of the pair (x, y): the row of the slot holding the younger node */
 #define VAL(x, y) (node[x] > node[y] ? M[(size_t)(x) * np + (y)] : M[(size_t)(y) * np + (x)])
@@ -152,6 +155,19 @@ int ahc_model_linkage(const double *data, size_t n, size_t d, double *z, int mod
         free(newrow);
         d1[a] = nmv; nn[a] = nmi;
         ++step; st->merges++;
+        /* piggy-back: the same round also re-scans the stale row(s) with the smallest lower bound */
+        for (int pg = 0; pg < g_piggy; ++pg) {
+            long srow = -1; double sv = INFINITY;
+            for (size_t i = 0; i < n; ++i) if (node[i] != DEAD && nn[i] < 0 && d1[i] < sv) { sv = d1[i]; srow = (long)i; }
+            if (srow < 0) break;
+            double mv = INFINITY; long mi = -1;
+            for (size_t j = 0; j < n; ++j) {
+                if ((long)j == srow || node[j] == DEAD) continue;
+                const double v = VAL(srow, j);
+                if (v < mv) { mv = v; mi = (long)j; }
+            }
+            d1[srow] = mv; nn[srow] = mi;
+        }
     }
     for (size_t s = 0; s + 1 < n; ++s) z[4 * s + 2] = sqrt(sqdist_rows(C, d, (long)z[4 * s], (long)z[4 * s + 1]));
     free(C); free(M); free(d1); free(nn); free(node); free(size);
