@@ -59,14 +59,17 @@ constexpr int kDead = INT_MAX;     // node id of an empty slot
 
 enum { OP_NONE = 0, OP_MERGE = 1, OP_RESCAN = 2, OP_COLLECT = 3, OP_PAIRS = 4 };
 
+constexpr int kPiggy = 3;          // stale rows re-scanned on top of every merge / forced re-scan round
+constexpr int kPend = 1 + kPiggy;  // rows whose per-block partial minima one round can produce
+
 struct AhcState {  // double buffered by round parity; written by workgroup 0 only
     int32_t step, done, halt, need_exact, error, mode;
     int32_t prev_op;              // what the previous round executed
-    int32_t pend_row, pend_node;  // row whose per-block partial minima the previous round produced (-1: none)
     int32_t pad0;
+    int32_t pend_row[kPend], pend_node[kPend];  // rows whose block-partial minima the previous round produced (-1: none)
     double eps, lim;              // lim: window limit carried COLLECT -> PAIRS -> evaluation
     unsigned long long dmax_bits;
-    long long rounds, rescans, windows;
+    long long rounds, rescans, windows, piggy;
 };
 
 struct WinCounters {  // 4 copies rotating with the round index: [t&3] written, [(t-1)&3] read, [(t+1)&3] cleared
@@ -74,12 +77,13 @@ struct WinCounters {  // 4 copies rotating with the round index: [t&3] written, 
     int32_t ncand, npairs;
 };
 
-struct __attribute__((aligned(16))) Rec {  // per 256-row block, double buffered by round parity (64 B)
-    double v1, v2, v3;       // three smallest row minima of the block (bounds of stale rows included)
-    double pv;               // block-partial minimum of the row produced this round (+inf: none)
-    int r1, q1, nr1, nq1;    // row holding v1, its neighbour slot (-1: stale), their node ids
-    int pslot, pnode, pad0, pad1;  // column holding pv and its node id
-};
+// Block records, double buffered by round parity and stored field-by-field ([2][nblk] arrays of 16-byte elements) so
+// that lane i of a wave reads element i: every record load is one fully coalesced dwordx4.
+struct __attribute__((aligned(16))) RecA { double v1; int cnt, pad; };        // smallest row minimum of the block (bounds of
+                                                                              // stale rows included); rows within 2 eps of it
+struct __attribute__((aligned(16))) RecS { double sv; int srow, snode; };     // smallest bound among the block's stale rows
+struct __attribute__((aligned(16))) RecP { double pv; int slot, node; };      // block-partial minimum of a row being produced
+// recI: int4 {r1, q1, node(r1), node(q1)}: the row holding v1, its neighbour slot (-1: stale), their node ids
 
 struct __attribute__((aligned(16))) RowSt {  // per slot, owned by thread (slot & 255) of workgroup (slot >> 8)
     double d1;               // minimum over all other live slots (lower bound while nn < 0)
@@ -94,7 +98,10 @@ struct Ws {
     int32_t *node;   // [Np]
     double *sizes;   // [2N]     cluster size by node id
     double *Z;       // [(N-1)*4]
-    Rec *rec;        // [2][nblk]
+    RecA *recA;      // [2][nblk]
+    int4 *recI;      // [2][nblk]
+    RecS *recS;      // [2][nblk]
+    RecP *recP;      // [2][kPend][nblk]
     int2 *cand;      // [kMaxCand]  slot, node
     int4 *pairs;     // [kMaxPairs] a, b, node a, node b
     WinCounters *cnt;  // [4]
@@ -142,6 +149,37 @@ __device__ __forceinline__ double wave_min(const double v) {  // result uniform
     const unsigned mlo = wave_umin(hi == mhi ? lo : 0xffffffffu);
     return __hiloint2double(static_cast<int>(mhi), static_cast<int>(mlo));
 }
+// NQ independent minimum reductions advanced in lock step: the DPP chains interleave, so no wait states are spent
+// between dependent steps (a single chain needs 2 idle slots after every VALU write that a DPP read consumes).
+template <int NQ>
+__device__ __forceinline__ void wave_umin_multi(unsigned (&v)[NQ]) {
+#define FA_AHC_STEP(CTRL, MASK) _Pragma("unroll") for (int q = 0; q < NQ; ++q) v[q] = dpp_umin<CTRL, MASK>(v[q]);
+    FA_AHC_STEP(0x111, 0xf) FA_AHC_STEP(0x112, 0xf) FA_AHC_STEP(0x114, 0xf) FA_AHC_STEP(0x118, 0xf)
+    FA_AHC_STEP(0x142, 0xa) FA_AHC_STEP(0x143, 0xc)
+#undef FA_AHC_STEP
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v[q]), 63));
+}
+// minima m[q] of NQ non-negative doubles per lane and the lowest lane L[q] holding each (uniform results)
+template <int NQ>
+__device__ __forceinline__ void wave_min_multi(const double (&key)[NQ], double (&m)[NQ], int (&L)[NQ]) {
+    unsigned hi[NQ], lo[NQ], mh[NQ], ml[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { hi[q] = static_cast<unsigned>(__double2hiint(key[q])); lo[q] = static_cast<unsigned>(__double2loint(key[q])); mh[q] = hi[q]; }
+    wave_umin_multi<NQ>(mh);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) ml[q] = hi[q] == mh[q] ? lo[q] : 0xffffffffu;
+    wave_umin_multi<NQ>(ml);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        m[q] = __hiloint2double(static_cast<int>(mh[q]), static_cast<int>(ml[q]));
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hi[q] == mh[q] && lo[q] == ml[q]);
+        L[q] = __builtin_amdgcn_readfirstlane(mask ? __ffsll(static_cast<long long>(mask)) - 1 : 0);
+    }
+}
+// number of lanes whose predicate holds (uniform)
+__device__ __forceinline__ int wave_count(const bool p) { return __popcll(__builtin_amdgcn_ballot_w64(p)); }
+
 __device__ __forceinline__ double wave_sum(double v) {  // fixed association order; result uniform
     v += dpp_f64<0x111, 0xf>(0.0, v);
     v += dpp_f64<0x112, 0xf>(0.0, v);
@@ -284,62 +322,64 @@ __global__ __launch_bounds__(kBlk) void ahc_row_minima(Ws w) {
 }
 
 // ------------------------------------------------------------------------------ block record
-// Three smallest row minima of this workgroup's 256 rows, the row holding the smallest, and the block-partial
-// minimum of the row being produced -> record of the NEXT round.  Per wave: four DPP min-reductions (the winner
-// lane found by ballot, then masked out); across the four waves: LDS + ONE __syncthreads.
-struct WaveOut { double v1, v2, v3, pv; int i1, pi; };
+// Per workgroup, for the NEXT round: the smallest row minimum (+ its row), how many rows lie within 2 eps of it, the
+// smallest stale bound, and the block-partial minima of the rows being produced.  Per wave: 2 + kPend interleaved
+// DPP min-reductions (winner lanes by ballot); across the four waves: LDS + ONE __syncthreads; thread 0 writes.
+constexpr int kNQ = 2 + kPend;
+struct WaveOut {
+    double v1, sv;
+    double pv[kPend];
+    int cnt, r1, q1, nr1, nq1, srow, snode, pad;
+    int ps[kPend], pn[kPend];
+};
 
-__device__ __forceinline__ void block_record(const Ws &w, const int par, const int blk, const double key, const double pkey,
-                                             const int x, const int nx, const int nnx, const int nnnodex, WaveOut *s_out) {
+__device__ __forceinline__ void block_record(const Ws &w, const int par, const int blk, const double eps, const double key,
+                                             const double skey, const double (&pkey)[kPend], const int (&pslot)[kPend],
+                                             const int (&pnode)[kPend], const int x, const int nx, const int nnx,
+                                             const int nnnodex, WaveOut *s_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double keys[kNQ], m[kNQ];
+    int L[kNQ];
+    keys[0] = key; keys[1] = skey;
+#pragma unroll
+    for (int p = 0; p < kPend; ++p) keys[2 + p] = pkey[p];
+    wave_min_multi<kNQ>(keys, m, L);
     WaveOut o;
-    double k = key;
-    o.v1 = wave_min(k);
-    const int l1 = first_lane_eq(k, o.v1);  // lowest lane == lowest row of the wave
-    o.i1 = (wave << 6) + l1;
-    if (lane == l1) k = dinf();
-    o.v2 = wave_min(k);
-    const int l2 = first_lane_eq(k, o.v2);
-    if (lane == l2) k = dinf();
-    o.v3 = wave_min(k);
-    o.pv = wave_min(pkey);
-    o.pi = (wave << 6) + first_lane_eq(pkey, o.pv);
+    o.v1 = m[0];
+    o.cnt = wave_count(key <= m[0] + 2.0 * eps && key < dinf());
+    o.r1 = lane_value(x, L[0]); o.q1 = lane_value(nnx, L[0]); o.nr1 = lane_value(nx, L[0]); o.nq1 = lane_value(nnnodex, L[0]);
+    o.sv = m[1]; o.srow = lane_value(x, L[1]); o.snode = lane_value(nx, L[1]); o.pad = 0;
+#pragma unroll
+    for (int p = 0; p < kPend; ++p) { o.pv[p] = m[2 + p]; o.ps[p] = lane_value(pslot[p], L[2 + p]); o.pn[p] = lane_value(pnode[p], L[2 + p]); }
     if (lane == 0) s_out[wave] = o;
     __syncthreads();
-    // 4-way merge of the sorted triples (ties -> lowest wave == lowest rows); uniform arithmetic in every thread
-    double a[kWaves][3];
-    int head[kWaves];
+    if (tid != 0) return;
+    // merge of the four waves' results in registers (one batch of LDS reads; ties -> lowest wave == lowest rows)
+    WaveOut wo[kWaves];
 #pragma unroll
-    for (int wv = 0; wv < kWaves; ++wv) { a[wv][0] = s_out[wv].v1; a[wv][1] = s_out[wv].v2; a[wv][2] = s_out[wv].v3; head[wv] = 0; }
-    double m[3];
-    int first_wave = 0;
+    for (int wv = 0; wv < kWaves; ++wv) wo[wv] = s_out[wv];
+    RecA ra; ra.v1 = dinf(); ra.cnt = 0; ra.pad = 0;
+    int4 ri = make_int4(-1, -1, -1, -1);
+    RecS rsv; rsv.sv = dinf(); rsv.srow = -1; rsv.snode = -1;
+    RecP rp[kPend];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        double best = dinf();
-        int bw = -1;
+    for (int p = 0; p < kPend; ++p) { rp[p].pv = dinf(); rp[p].slot = -1; rp[p].node = -1; }
 #pragma unroll
-        for (int wv = 0; wv < kWaves; ++wv) {
-            const double c = head[wv] == 0 ? a[wv][0] : head[wv] == 1 ? a[wv][1] : head[wv] == 2 ? a[wv][2] : dinf();
-            if (c < best) { best = c; bw = wv; }
-        }
-        m[r] = best;
-        if (r == 0) first_wave = bw;
+    for (int wv = 0; wv < kWaves; ++wv) {
+        const WaveOut &f = wo[wv];
+        if (f.v1 < ra.v1) { ra.v1 = f.v1; ri = make_int4(f.r1, f.q1, f.nr1, f.nq1); }
+        if (f.sv < rsv.sv) { rsv.sv = f.sv; rsv.srow = f.srow; rsv.snode = f.snode; }
 #pragma unroll
-        for (int wv = 0; wv < kWaves; ++wv) if (wv == bw) ++head[wv];
+        for (int p = 0; p < kPend; ++p)
+            if (f.pv[p] < rp[p].pv) { rp[p].pv = f.pv[p]; rp[p].slot = f.ps[p]; rp[p].node = f.pn[p]; }
     }
-    double pv = s_out[0].pv;
-    int pi = s_out[0].pi;
+    // rows within 2 eps of the block minimum, counted conservatively (a wave's rows were counted against ITS minimum)
 #pragma unroll
-    for (int wv = 1; wv < kWaves; ++wv) if (s_out[wv].pv < pv) { pv = s_out[wv].pv; pi = s_out[wv].pi; }
-    const int i1 = first_wave >= 0 && m[0] < dinf() ? s_out[first_wave].i1 : -1;
-    Rec *rec = w.rec + static_cast<size_t>(par) * w.nblk + blk;
-    if (tid == 0) {
-        rec->v1 = m[0]; rec->v2 = m[1]; rec->v3 = m[2]; rec->pv = pv;
-        if (i1 < 0) { rec->r1 = -1; rec->q1 = -1; rec->nr1 = -1; rec->nq1 = -1; }
-        if (!(pv < dinf())) { rec->pslot = -1; rec->pnode = -1; }
-    }
-    if (tid == i1) { rec->r1 = x; rec->q1 = nnx; rec->nr1 = nx; rec->nq1 = nnnodex; }
-    if (pv < dinf() && tid == pi) { rec->pslot = x; rec->pnode = nx; }
+    for (int wv = 0; wv < kWaves; ++wv) if (wo[wv].v1 <= ra.v1 + 2.0 * eps) ra.cnt += wo[wv].cnt;
+    const size_t o1 = static_cast<size_t>(par) * w.nblk + blk;
+    w.recA[o1] = ra; w.recI[o1] = ri; w.recS[o1] = rsv;
+#pragma unroll
+    for (int p = 0; p < kPend; ++p) w.recP[(static_cast<size_t>(par) * kPend + p) * w.nblk + blk] = rp[p];
 }
 
 __global__ __launch_bounds__(kBlk) void ahc_records(Ws w) {  // records of parity 0 from the row arrays
@@ -347,7 +387,13 @@ __global__ __launch_bounds__(kBlk) void ahc_records(Ws w) {  // records of parit
     const int tid = threadIdx.x, blk = blockIdx.x, x = blk * kBlk + tid;
     const int nx = w.node[x];
     const RowSt r = w.row[x];
-    block_record(w, 0, blk, nx != kDead ? r.d1 : dinf(), dinf(), x, nx, r.nn, r.nnnode, s_out);
+    double pkey[kPend];
+    int pslot[kPend], pnode[kPend];
+#pragma unroll
+    for (int p = 0; p < kPend; ++p) { pkey[p] = dinf(); pslot[p] = -1; pnode[p] = -1; }
+    const bool live = nx != kDead;
+    block_record(w, 0, blk, w.state[0].eps, live ? r.d1 : dinf(), live && r.nn < 0 ? r.d1 : dinf(), pkey, pslot, pnode, x, nx, r.nn,
+                 r.nnnode, s_out);
 }
 
 // ------------------------------------------------------------------------------ the round kernel
@@ -431,9 +477,19 @@ __device__ void exact_min_pair(const Ws &w, const int np, double *s_sq /*[kWaves
 #define AHC_STAMP(i) do {} while (0)
 #endif
 
+// what one wave extracts from its share of the block records (phase 1), merged across the four waves through LDS
+constexpr int kMaxC = (kMaxBlocks + 4 * 64 - 1) / (4 * 64);  // block records per lane
+struct WaveDec {
+    double v1, sv;
+    double pd[kPend];
+    int cnt, r1, q1, nr1, nq1, srow, snode, pad;
+    int ps[kPend], pn[kPend];
+};
+
 __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round index & 3 */) {
     extern __shared__ double s_cvec[];  // [d] merged centroid (EXACT rows)
     __shared__ WaveOut s_out[kWaves];
+    __shared__ WaveDec s_dec[kWaves];
     __shared__ double s_sq[kBlk];
     __shared__ double s_val[kWaves];
     __shared__ int s_idx[kWaves];
@@ -454,75 +510,101 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
     RowSt rs = w.row[x];
     const int nanflag = w.flags[0];
 
-    // ---- phase 1: every WAVE of every workgroup reduces the same records -> the same decision (no barrier) ----------
-    // lane l owns the contiguous blocks [l*per, (l+1)*per): lane order == row order, so ballot+ffs breaks ties low.
-    const int per = (nblk + 63) >> 6;
-    double l1 = dinf(), l2 = dinf(), l3 = dinf(), lp = dinf();
-    int lr = -1, lq = -1, lnr = -1, lnq = -1, lps = -1, lpn = -1;
+    // ---- phase 1: every workgroup reduces the same records -> the same decision ------------------------------------
+    // wave v owns the blocks [v*perw, (v+1)*perw), lane l of it the contiguous run [.. + l*c, .. + (l+1)*c): lane and
+    // wave order == row order, so ballot+ffs and "lowest wave first" break ties towards the lowest row.
+    const int perw = (nblk + kWaves - 1) / kWaves, c = (perw + 63) >> 6;
+    double va[kMaxC];
+    int ca[kMaxC];
+    double keys[kNQ];
+    int4 ids = make_int4(-1, -1, -1, -1);
+    int ssrow = -1, ssnode = -1, lps[kPend], lpn[kPend];
+#pragma unroll
+    for (int q = 0; q < kNQ; ++q) keys[q] = dinf();
+#pragma unroll
+    for (int k = 0; k < kPend; ++k) { lps[k] = -1; lpn[k] = -1; }
     {
-        const Rec *recs = w.rec + static_cast<size_t>(par) * nblk;
-        constexpr int kBatch = 4;  // records in flight per lane: all loads of a batch are issued before any is used
-        auto batch = [&](const int j0) {
-            int4 q[kBatch][4];
+        const size_t ro = static_cast<size_t>(par) * nblk;
 #pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                const int i = lane * per + j0 + j;
-                const int4 *p = reinterpret_cast<const int4 *>(recs + (i < nblk && j0 + j < per ? i : 0));
+        for (int j = 0; j < kMaxC; ++j) {
+            const int i = wave * perw + lane * c + j;
+            const bool ok = j < c && lane * c + j < perw && i < nblk;
+            va[j] = dinf(); ca[j] = 0;
+            if (j > 0 && !(j < c)) continue;  // N <= 65 536: one record per lane, straight-line
+            const int ii = ok ? i : 0;
+            const RecA ra = w.recA[ro + ii];
+            const int4 ri = w.recI[ro + ii];
+            const RecS rv = w.recS[ro + ii];
+            RecP rp[kPend];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) q[j][e] = p[e];
-            }
+            for (int k = 0; k < kPend; ++k) rp[k] = w.recP[(static_cast<size_t>(par) * kPend + k) * nblk + ii];
+            if (!ok) continue;
+            va[j] = ra.v1; ca[j] = ra.cnt;
+            if (ra.v1 < keys[0]) { keys[0] = ra.v1; ids = ri; }
+            if (rv.sv < keys[1]) { keys[1] = rv.sv; ssrow = rv.srow; ssnode = rv.snode; }
 #pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                const int i = lane * per + j0 + j;
-                if (i >= nblk || j0 + j >= per) continue;
-                const double v1 = __hiloint2double(q[j][0].y, q[j][0].x), v2 = __hiloint2double(q[j][0].w, q[j][0].z);
-                const double v3 = __hiloint2double(q[j][1].y, q[j][1].x), pv = __hiloint2double(q[j][1].w, q[j][1].z);
-                if (v1 < l1) { l3 = l2; l2 = l1; l1 = v1; lr = q[j][2].x; lq = q[j][2].y; lnr = q[j][2].z; lnq = q[j][2].w; }
-                else if (v1 < l2) { l3 = l2; l2 = v1; }
-                else if (v1 < l3) l3 = v1;
-                if (v2 < l2) { l3 = l2; l2 = v2; } else if (v2 < l3) l3 = v2;
-                if (v3 < l3) l3 = v3;
-                if (pv < lp) { lp = pv; lps = q[j][3].x; lpn = q[j][3].y; }
-            }
-        };
-        batch(0);  // N <= 65 536: the only batch, straight-line
-        for (int j0 = kBatch; j0 < per; j0 += kBatch) batch(j0);
+            for (int k = 0; k < kPend; ++k)
+                if (rp[k].pv < keys[2 + k]) { keys[2 + k] = rp[k].pv; lps[k] = rp[k].slot; lpn[k] = rp[k].node; }
+        }
     }
     AHC_STAMP(0);
-    // (a) finish the row produced by the previous round
-    double pd1 = dinf();
-    int pnn = -1, pnnnode = -1;
-    const int P = st.pend_row;
-    if (P >= 0) {
-        pd1 = wave_min(lp);
-        if (pd1 < dinf()) { const int L = first_lane_eq(lp, pd1); pnn = lane_value(lps, L); pnnnode = lane_value(lpn, L); }
-        if (x == P) { rs.d1 = pd1; rs.nn = pnn; rs.nnnode = pnnnode; }
+    {   // wave level: 2 + kPend interleaved minimum reductions
+        double m[kNQ];
+        int L[kNQ];
+        wave_min_multi<kNQ>(keys, m, L);
+        WaveDec o;
+        o.v1 = m[0];
+        int cl = 0;
+        const double wl = m[0] + 2.0 * st.eps;
+#pragma unroll
+        for (int j = 0; j < kMaxC; ++j) if (va[j] <= wl && va[j] < dinf()) cl += ca[j];
+        o.cnt = wave_count(cl >= 1) + wave_count(cl >= 2) + wave_count(cl >= 3);  // exact up to 3 per lane; only "== 2" matters
+        o.r1 = lane_value(ids.x, L[0]); o.q1 = lane_value(ids.y, L[0]); o.nr1 = lane_value(ids.z, L[0]); o.nq1 = lane_value(ids.w, L[0]);
+        o.sv = m[1]; o.srow = lane_value(ssrow, L[1]); o.snode = lane_value(ssnode, L[1]); o.pad = 0;
+#pragma unroll
+        for (int k = 0; k < kPend; ++k) { o.pd[k] = m[2 + k]; o.ps[k] = lane_value(lps[k], L[2 + k]); o.pn[k] = lane_value(lpn[k], L[2 + k]); }
+        if (lane == 0) s_dec[wave] = o;
     }
-    // (b) smallest row minimum (with its row) and the two next values over all blocks, then the pending row
-    double g1 = wave_min(l1);
+    __syncthreads();
+    WaveDec dw[kWaves];  // one batch of LDS reads, everything below is register arithmetic on uniform values
+#pragma unroll
+    for (int wv = 0; wv < kWaves; ++wv) dw[wv] = s_dec[wv];
+    // (a) finish the rows produced by the previous round
+    double pd1[kPend];
+    int pnn[kPend], pnnnode[kPend];
+#pragma unroll
+    for (int k = 0; k < kPend; ++k) {
+        pd1[k] = dinf(); pnn[k] = -1; pnnnode[k] = -1;
+#pragma unroll
+        for (int wv = 0; wv < kWaves; ++wv)
+            if (dw[wv].pd[k] < pd1[k]) { pd1[k] = dw[wv].pd[k]; pnn[k] = dw[wv].ps[k]; pnnnode[k] = dw[wv].pn[k]; }
+        if (st.pend_row[k] < 0) { pd1[k] = dinf(); pnn[k] = -1; pnnnode[k] = -1; }
+        else if (x == st.pend_row[k]) { rs.d1 = pd1[k]; rs.nn = pnn[k]; rs.nnnode = pnnnode[k]; }
+    }
+    // (b) smallest row minimum (with its row) over all blocks and the finished rows; rows within 2 eps of it
+    double g1 = dinf();
     int R1 = -1, Q1 = -1, NR1 = -1, NQ1 = -1;
-    {
-        const int L = first_lane_eq(l1, g1);
-        R1 = lane_value(lr, L); Q1 = lane_value(lq, L); NR1 = lane_value(lnr, L); NQ1 = lane_value(lnq, L);
-        if (lane == L) { l1 = l2; l2 = l3; l3 = dinf(); }
+#pragma unroll
+    for (int wv = 0; wv < kWaves; ++wv)  // ties -> lowest wave == lowest rows
+        if (dw[wv].v1 < g1) { g1 = dw[wv].v1; R1 = dw[wv].r1; Q1 = dw[wv].q1; NR1 = dw[wv].nr1; NQ1 = dw[wv].nq1; }
+#pragma unroll
+    for (int k = 0; k < kPend; ++k) {
+        const int P = st.pend_row[k];
+        if (P >= 0 && lt2(pd1[k], P, g1, R1 < 0 ? INT_MAX : R1)) { g1 = pd1[k]; R1 = P; Q1 = pnn[k]; NR1 = st.pend_node[k]; NQ1 = pnnnode[k]; }
     }
-    double g2 = wave_min(l1);
-    {
-        const int L = first_lane_eq(l1, g2);
-        if (lane == L) { l1 = l2; l2 = l3; l3 = dinf(); }
-    }
-    double g3 = wave_min(l1);
     if (!(g1 < dinf())) R1 = -1;
-    if (P >= 0) {
-        if (lt2(pd1, P, g1, R1 < 0 ? INT_MAX : R1)) {
-            g3 = g2; g2 = g1;
-            g1 = pd1; R1 = P; Q1 = pnn; NR1 = st.pend_node; NQ1 = pnnnode;
-        } else if (pd1 < g2) { g3 = g2; g2 = pd1; }
-        else if (pd1 < g3) g3 = pd1;
-    }
+    const double glim = g1 + 2.0 * st.eps;
+    int nwin = 0;  // conservative (never too small): nested counts were taken against local minima
+#pragma unroll
+    for (int wv = 0; wv < kWaves; ++wv) if (dw[wv].v1 <= glim) nwin += dw[wv].cnt;
+#pragma unroll
+    for (int k = 0; k < kPend; ++k) if (st.pend_row[k] >= 0 && pd1[k] <= glim) nwin += 1;
 
     if (st.done || st.halt) {  // finished or waiting for the host: carry the state forward
-        if (blk == 0 && tid == 0) { *nst = st; nst->prev_op = OP_NONE; nst->pend_row = -1; }
+        if (blk == 0 && tid == 0) {
+            *nst = st; nst->prev_op = OP_NONE;
+            for (int k = 0; k < kPend; ++k) nst->pend_row[k] = -1;
+        }
         return;
     }
     if (blk == 0 && tid == 0) {  // clear the window counters of the next round
@@ -562,31 +644,59 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
         // The pair (R1, Q1) is stored once, so row Q1 carries the same value: exactly two row minima inside the
         // window [g1, g1 + 2 eps] means {R1, Q1} is the unique candidate pair (any other entry <= lim of either row
         // would put a third row inside the window; bounds of stale rows count as row minima).
-        const double lim = g1 + 2.0 * st.eps;
-        if (g2 <= lim && !(g3 <= lim)) D.op = OP_MERGE;
-        else { D.op = OP_COLLECT; D.lim = lim; }
+        if (nwin == 2) D.op = OP_MERGE;
+        else { D.op = OP_COLLECT; D.lim = glim; }
     }
     if (D.op == OP_MERGE && D.a < 0) {
         const bool lo = R1 < Q1;
         D.a = lo ? R1 : Q1; D.b = lo ? Q1 : R1; D.na = lo ? NR1 : NQ1; D.nb = lo ? NQ1 : NR1;
     }
+    // rows produced this round: [0] the merged row / the forced re-scan, [1..] piggy-backed re-scans of the stale rows
+    // with the smallest bounds (one candidate per wave's share of the blocks; a heuristic, any choice is correct)
+    int prow[kPend], pnode_[kPend];
+#pragma unroll
+    for (int k = 0; k < kPend; ++k) { prow[k] = -1; pnode_[k] = -1; }
+    if (D.op == OP_MERGE || D.op == OP_RESCAN) {
+        prow[0] = D.a; pnode_[0] = D.op == OP_MERGE ? N + st.step : D.na;
+        bool used[kWaves];
+#pragma unroll
+        for (int wv = 0; wv < kWaves; ++wv) {
+            const int sr = dw[wv].srow;
+            used[wv] = !(dw[wv].sv < dinf()) || sr < 0 || sr == D.a || (D.op == OP_MERGE && sr == D.b);
+        }
+#pragma unroll
+        for (int k = 1; k < kPend; ++k) {
+            int bw = -1;
+            double bv = dinf();
+#pragma unroll
+            for (int wv = 0; wv < kWaves; ++wv) if (!used[wv] && dw[wv].sv < bv) { bv = dw[wv].sv; bw = wv; }
+#pragma unroll
+            for (int wv = 0; wv < kWaves; ++wv) if (wv == bw) { used[wv] = true; prow[k] = dw[wv].srow; pnode_[k] = dw[wv].snode; }
+        }
+    }
     AHC_STAMP(1);
 
     // ---- phase 2 ------------------------------------------------------------------------------------------------
+    bool was_pending = false;
+#pragma unroll
+    for (int k = 0; k < kPend; ++k) was_pending = was_pending || x == st.pend_row[k];
     if (D.done || D.halt) {
         if (blk == 0 && tid == 0) {
             *nst = st;
             nst->done = D.done; nst->halt = D.halt; nst->need_exact = D.need_exact; nst->error = D.error;
-            nst->prev_op = OP_NONE; nst->pend_row = -1;
+            nst->prev_op = OP_NONE;
+            for (int k = 0; k < kPend; ++k) nst->pend_row[k] = -1;
         }
-        if (x == P) w.row[x] = rs;
+        if (was_pending) w.row[x] = rs;
         return;
     }
 
-    double key = nx != kDead ? rs.d1 : dinf();  // this row's entry in the next record
-    double pkey = dinf();                        // this column's entry of the row being produced
-    int new_pend = -1, new_pend_node = -1;
-    bool dirty = x == P;
+    double pkey[kPend];  // this column's entry of each row being produced
+    int pslot[kPend], pnd[kPend];
+#pragma unroll
+    for (int k = 0; k < kPend; ++k) { pkey[k] = dinf(); pslot[k] = x; pnd[k] = nx; }
+    bool dirty = was_pending;
+    bool in_flight = false;  // this row is being (re)produced: it leaves the record until the next round finishes it
 
     if (D.op == OP_MERGE) {
         const int a = D.a, b = D.b, na = D.na, nb = D.nb, nnew = N + st.step;
@@ -598,15 +708,21 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
             da = na > nx ? w.M[static_cast<size_t>(a) * Np + x] : w.M[static_cast<size_t>(x) * Np + a];
             db = nb > nx ? w.M[static_cast<size_t>(b) * Np + x] : w.M[static_cast<size_t>(x) * Np + b];
         }
+#pragma unroll
+        for (int k = 1; k < kPend; ++k) {  // piggy-backed re-scans: pairs not touched by this merge
+            const int S = prow[k];
+            if (S >= 0 && act && x != S)
+                pkey[k] = pnode_[k] > nx ? w.M[static_cast<size_t>(S) * Np + x] : w.M[static_cast<size_t>(x) * Np + S];
+        }
         // merged centroid (FastClusterWrapper.cpp:89-100), and |ca - cb|^2 summed as a tree (error <= ~10 ulp,
         // independent of the merge depth).  Every wave evaluates the whole sum: no workgroup barrier.
         double part = 0.0;
         for (int k = lane; k < d; k += 64) {
             const double xa = ca[k], xb = cb[k];
-            const double c = __ddiv_rn(__dadd_rn(__dmul_rn(xa, ma), __dmul_rn(xb, mb)), den);
+            const double cc = __ddiv_rn(__dadd_rn(__dmul_rn(xa, ma), __dmul_rn(xb, mb)), den);
             if (wave == 0) {
-                if (st.mode == FA_AHC_MODE_EXACT) s_cvec[k] = c;
-                if (blk == 0) w.C[static_cast<size_t>(nnew) * d + k] = c;
+                if (st.mode == FA_AHC_MODE_EXACT) s_cvec[k] = cc;
+                if (blk == 0) w.C[static_cast<size_t>(nnew) * d + k] = cc;
             }
             const double diff = xa - xb;
             part += diff * diff;
@@ -640,15 +756,16 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
             const bool vld = rs.nn >= 0;
             if (dc < rs.d1 || (vld && dc == rs.d1 && a <= rs.nn)) { rs.d1 = dc; rs.nn = a; rs.nnnode = nnew; dirty = true; }
             else if (vld && (rs.nn == a || rs.nn == b)) { rs.nn = -1; dirty = true; }  // minimum lost: d1 stays as a lower bound
-            key = rs.d1;
-            pkey = dc;
+            pkey[0] = dc;
+#pragma unroll
+            for (int k = 1; k < kPend; ++k)
+                if (x == prow[k]) { pkey[k] = dc; pslot[k] = a; pnd[k] = nnew; in_flight = true; }  // its entry for the new cluster
         } else if (x == a) {
-            nx = nnew; rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; key = dinf(); dirty = true;
+            nx = nnew; rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; dirty = true; in_flight = true;
             w.sizes[nnew] = den;
         } else if (x == b) {
-            nx = kDead; rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; key = dinf(); dirty = true;
+            nx = kDead; rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; dirty = true;
         }
-        new_pend = a; new_pend_node = nnew;
         if (blk == 0 && tid == 0) {
             double *z = w.Z + static_cast<size_t>(st.step) * 4;
             z[0] = na < nb ? na : nb;  // LinkageOutput::append (FastClusterWrapper.cpp:150-160)
@@ -657,11 +774,14 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
             z[3] = den;
         }
     } else if (D.op == OP_RESCAN) {
-        const int R = D.a, nR = D.na;
-        if (nx != kDead && x != R)
-            pkey = nR > nx ? w.M[static_cast<size_t>(R) * Np + x] : w.M[static_cast<size_t>(x) * Np + R];
-        if (x == R) { rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; key = dinf(); dirty = true; }  // pending until the next round
-        new_pend = R; new_pend_node = nR;
+#pragma unroll
+        for (int k = 0; k < kPend; ++k) {
+            const int S = prow[k];
+            if (S < 0) continue;
+            if (nx != kDead && x != S)
+                pkey[k] = pnode_[k] > nx ? w.M[static_cast<size_t>(S) * Np + x] : w.M[static_cast<size_t>(x) * Np + S];
+            if (x == S) in_flight = true;
+        }
     } else if (D.op == OP_COLLECT) {
         WinCounters *cw = w.cnt + (ph & 3);
         if (nx != kDead && rs.d1 <= D.lim) {
@@ -672,12 +792,12 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
         WinCounters *cw = w.cnt + (ph & 3);
         const int nc = cr->ncand;
         for (int j = 0; j < nc; ++j) {
-            const int2 c = w.cand[j];
-            if (nx == kDead || x == c.x) continue;
-            const double val = c.y > nx ? w.M[static_cast<size_t>(c.x) * Np + x] : w.M[static_cast<size_t>(x) * Np + c.x];
+            const int2 cj = w.cand[j];
+            if (nx == kDead || x == cj.x) continue;
+            const double val = cj.y > nx ? w.M[static_cast<size_t>(cj.x) * Np + x] : w.M[static_cast<size_t>(x) * Np + cj.x];
             if (val <= D.lim) {
                 const int slot = atomicAdd(&cw->npairs, 1);
-                if (slot < kMaxPairs) w.pairs[slot] = c.x < x ? make_int4(c.x, x, c.y, nx) : make_int4(x, c.x, nx, c.y);
+                if (slot < kMaxPairs) w.pairs[slot] = cj.x < x ? make_int4(cj.x, x, cj.y, nx) : make_int4(x, cj.x, nx, cj.y);
             }
         }
     }
@@ -688,12 +808,13 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
         w.row[x] = rs;
         if (D.op == OP_MERGE && (x == D.a || x == D.b)) w.node[x] = nx;
     }
-    block_record(w, npar, blk, key, pkey, x, nx, rs.nn, rs.nnnode, s_out);
+    const bool live = nx != kDead && !in_flight;
+    block_record(w, npar, blk, st.eps, live ? rs.d1 : dinf(), live && rs.nn < 0 ? rs.d1 : dinf(), pkey, pslot, pnd, x, nx, rs.nn, rs.nnnode, s_out);
     AHC_STAMP(4);
     if (blk == 0 && tid == 0) {
         AhcState n = st;
         n.prev_op = D.op;
-        n.pend_row = new_pend; n.pend_node = new_pend_node;
+        for (int k = 0; k < kPend; ++k) { n.pend_row[k] = prow[k]; n.pend_node[k] = pnode_[k]; if (k > 0 && prow[k] >= 0) n.piggy = n.piggy + 1; }
         n.lim = D.lim;
         n.rounds = st.rounds + 1;
         if (D.op == OP_MERGE) n.step = st.step + 1;
@@ -728,7 +849,7 @@ __global__ void ahc_heights(Ws w) {
 
 // ------------------------------------------------------------------------------ host driver
 struct Layout {
-    size_t state, cnt, flags, prof, c, xt, row, node, sizes, z, rec, cand, pairs, m, total;
+    size_t state, cnt, flags, prof, c, xt, row, node, sizes, z, reca, reci, recs, recp, cand, pairs, m, total;
 };
 
 Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
@@ -739,7 +860,10 @@ Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
     L.cnt = take(sizeof(WinCounters) * 4);
     L.flags = take(sizeof(int32_t) * 4);
     L.prof = take(sizeof(unsigned long long) * 16);
-    L.rec = take(sizeof(Rec) * 2 * nblk);
+    L.reca = take(sizeof(RecA) * 2 * nblk);
+    L.reci = take(sizeof(int4) * 2 * nblk);
+    L.recs = take(sizeof(RecS) * 2 * nblk);
+    L.recp = take(sizeof(RecP) * 2 * kPend * nblk);
     L.row = take(sizeof(RowSt) * Np);
     L.node = take(sizeof(int32_t) * Np);
     L.sizes = take(sizeof(double) * 2 * N);
@@ -782,7 +906,10 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     w.cnt = reinterpret_cast<WinCounters *>(base + L.cnt);
     w.flags = reinterpret_cast<int32_t *>(base + L.flags);
     w.prof = reinterpret_cast<unsigned long long *>(base + L.prof);
-    w.rec = reinterpret_cast<Rec *>(base + L.rec);
+    w.recA = reinterpret_cast<RecA *>(base + L.reca);
+    w.recI = reinterpret_cast<int4 *>(base + L.reci);
+    w.recS = reinterpret_cast<RecS *>(base + L.recs);
+    w.recP = reinterpret_cast<RecP *>(base + L.recp);
     w.row = reinterpret_cast<RowSt *>(base + L.row);
     w.node = reinterpret_cast<int32_t *>(base + L.node);
     w.sizes = reinterpret_cast<double *>(base + L.sizes);
@@ -801,7 +928,8 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
 
     AhcState init[2]{};
     init[0].mode = mode == FA_AHC_MODE_EXACT ? FA_AHC_MODE_EXACT : FA_AHC_MODE_AUTO;
-    init[0].pend_row = -1; init[0].pend_node = -1; init[0].prev_op = OP_NONE;
+    for (int k = 0; k < kPend; ++k) { init[0].pend_row[k] = -1; init[0].pend_node[k] = -1; }
+    init[0].prev_op = OP_NONE;
     init[1] = init[0];
     WinCounters cinit[4];
     for (auto &c : cinit) { c.stale_key = ~0ULL; c.ncand = 0; c.npairs = 0; }
@@ -829,6 +957,8 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
         // factor 2 of margin.
         const double eps = 16.0 * static_cast<double>(N) * 1.1102230246251565e-16 * dmax;
         FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state) + offsetof(AhcState, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state + 1) + offsetof(AhcState, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(ahc_records, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);  // window counts need eps
     }
     FA_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
 
@@ -864,7 +994,8 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
             AhcState patch[2];
             patch[0] = h;
             patch[0].halt = 0; patch[0].need_exact = 0; patch[0].mode = FA_AHC_MODE_EXACT; patch[0].eps = 0.0;
-            patch[0].prev_op = OP_NONE; patch[0].pend_row = -1; patch[0].pend_node = -1;
+            patch[0].prev_op = OP_NONE;
+            for (int k = 0; k < kPend; ++k) { patch[0].pend_row[k] = -1; patch[0].pend_node[k] = -1; }
             patch[1] = patch[0];
             FA_HIP_TRY(ctx, hipMemcpyAsync(w.state, patch, sizeof(patch), hipMemcpyHostToDevice, ctx->stream));
             FA_HIP_TRY(ctx, hipMemcpyAsync(w.cnt, cinit, sizeof(cinit), hipMemcpyHostToDevice, ctx->stream));
