@@ -3,12 +3,14 @@
 // Replaces AudioMelSpectrogram.computeFlat / computeFlatTransposed / compute
 // (reference: Sources/FluidAudio/Shared/AudioMelSpectrogram.swift:132-178,185-292,325-456).
 //
-// One workgroup (256 threads = 16 groups of 16 lanes) walks a contiguous range of 16-frame
-// tiles.  Per tile: stage hop*15+512 pre-emphasised samples into LDS once, each 16-lane
-// group turns one frame into 257 power bins (mel_core.h), then all 256 threads reduce the
-// sparse triangular filterbank, take the log and store either [n_mels, T] or [T, n_mels].
-// HBM traffic per 15 s utterance = 960 000 B read + 768 512 B written; everything else stays
-// in LDS/registers.
+// One workgroup (256 threads = 4 wavefronts) walks a contiguous range of 32-frame tiles.  Per tile the
+// hop*31+512 pre-emphasised samples are staged in LDS once; then every wavefront runs its own 8 frames
+// (two passes of 4 frames x 16 lanes) with NO workgroup barrier: window and twiddles sit in registers,
+// the only LDS traffic of the FFT is one radix-16 transpose, the Z[k] <-> Z[256-k] exchange of the
+// real-FFT recombination is a DPP lane permutation, and the 257 power bins go back to the wavefront's
+// LDS region only to be gathered by the sparse triangular filterbank.  Log-mel values are staged in LDS
+// and stored by the whole workgroup as full rows ([n_mels, T]: 128-byte runs; [T, n_mels]: contiguous).
+// HBM traffic per 15 s utterance = 960 000 B read + 768 512 B written.
 #include <cmath>
 #include <vector>
 
@@ -19,10 +21,14 @@ using namespace fa::melcore;
 
 namespace {
 
-constexpr int kTileFrames = 16;
+constexpr int kTileFrames = 32;
 constexpr int kThreads = 256;
+constexpr int kWaveFrames = 4;                 // frames in flight per wavefront (16 lanes each)
+constexpr int kRegions = kThreads / kGroup;    // 16 LDS regions (4 waves x 4 frames)
+constexpr int kPasses = kTileFrames / kRegions;  // 2
 constexpr int kMaxMels = 256;
-constexpr int kMaxWeights = 2 * kBins + 8;
+constexpr int kMelPad = 33;                    // [n_mels][33] staging: conflict-free writes and reads
+constexpr int kFramePad = 8;                   // [32][n_mels + 8] staging
 
 struct MelArgs {
     const float *pcm;
@@ -41,101 +47,243 @@ struct MelArgs {
     int32_t tiles_per_utt;
     int32_t frame_stride;
     int32_t n_mels, n_weights;
-    int32_t hop, pad, stage_count, stage_alloc;
+    int32_t hop, pad, stage_count, stage_alloc, out_alloc;
     float preemph, log_floor;
     int32_t floor_clamped;
 };
 
-template <int LAYOUT>
-__global__ __launch_bounds__(kThreads, 3) void mel_kernel(const MelArgs a) {
+// lane l <- lane (16 - l) & 15 inside every row of 16 lanes: row_mirror (l <- 15 - l), then row_ror:1 (l <- l - 1)
+__device__ __forceinline__ float dpp_partner(const float x) {
+    int v = __float_as_int(x);
+    v = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
+    v = __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, true);
+    return __int_as_float(v);
+}
+
+// Compile-time slot profile of the sparse filterbank fast path: group i holds the mels 16 i .. 16 i + 15 (one per lane)
+// and each of them has at most kSlots[i] non-zero weights (default NeMo bank: 2 2 2 3 4 6 9 13).  Banks that do not fit
+// (other n_fft / sample rates / > 128 mels) take the generic loop.
+constexpr int kFastGroups = 8;
+__host__ __device__ constexpr int fast_slots(int i) { return i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 2 : i == 3 ? 3 : i == 4 ? 4 : i == 5 ? 6 : i == 6 ? 9 : 13; }
+__host__ __device__ constexpr int fast_slot_base(int i) { int o = 0; for (int k = 0; k < i; ++k) o += fast_slots(k); return o; }
+constexpr int kFastSlots = fast_slot_base(kFastGroups);  // 41
+
+constexpr int kStageVec = 6;  // float4 loads per thread and tile held in registers while the previous tile is computed
+
+struct TileInfo {
+    const float *x;  // utterance samples
+    float *ob;       // utterance output
+    int64_t len, n0;
+    float lastv;
+    int t0, T;
+    bool stage;      // tile has frames to compute
+};
+
+template <int LAYOUT, bool FAST>
+__global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *samples = smem;
     float *regions = samples + a.stage_alloc;
-    int32_t *mtab = reinterpret_cast<int32_t *>(regions + kTileFrames * kRegionFloats);
+    float *outs = regions + kRegions * kRegionFloats;
+    int32_t *mtab = reinterpret_cast<int32_t *>(outs + a.out_alloc);
     float *mw = reinterpret_cast<float *>(mtab + kMaxMels);
 
     const int tid = threadIdx.x;
-    const int lane = tid & (kGroup - 1);
-    const int grp = tid >> 4;
+    const int l = tid & (kGroup - 1);   // lane inside the 16-lane frame group
+    const int grp = tid >> 4;           // 0..15: LDS region == (wave, frame of the pass)
 
     for (int i = tid; i < a.n_mels; i += kThreads) mtab[i] = a.mel_tab[i];
     for (int i = tid; i < a.n_weights; i += kThreads) mw[i] = a.mel_w[i];
 
-    Tables c;
-    c.windowz = a.windowz;
-    c.tw256 = reinterpret_cast<const float *>(a.tw256);
-    c.tw512 = reinterpret_cast<const float *>(a.tw512);
+    LaneConst kc;
+    {
+        Tables c;
+        c.windowz = a.windowz;
+        c.tw256 = reinterpret_cast<const float *>(a.tw256);
+        c.tw512 = reinterpret_cast<const float *>(a.tw512);
+        lane_const_init(l, c, kc);
+    }
+    int mlo[(kFastGroups + 2) / 3];  // first power bin of the lane's mel in every group, 3 x 10 bits per register (fast path)
+#pragma unroll
+    for (int i = 0; i < (kFastGroups + 2) / 3; ++i) mlo[i] = 0;
+#pragma unroll
+    for (int i = 0; i < kFastGroups; ++i)
+        if (FAST && l + 16 * i < a.n_mels) mlo[i / 3] |= (a.mel_tab[l + 16 * i] & 1023) << (10 * (i % 3));
     __syncthreads();
 
     const int64_t per = (a.total_tiles + gridDim.x - 1) / gridDim.x;
     const int64_t first = static_cast<int64_t>(blockIdx.x) * per;
     const int64_t stop = first + per < a.total_tiles ? first + per : a.total_tiles;
+    const int n_mels = a.n_mels;
+    const bool hop_even = (a.hop & 1) == 0;
+    const bool vec_stage = a.stage_alloc <= kStageVec * kThreads * 4;
+
+    auto tile_info = [&](const int64_t tl) {
+        TileInfo ti;
+        const int b = static_cast<int>(tl / a.tiles_per_utt);
+        ti.t0 = static_cast<int>(tl % a.tiles_per_utt) * kTileFrames;
+        ti.T = a.frames[b];
+        const int64_t base = a.offsets[b];
+        ti.len = a.offsets[b + 1] - base;
+        ti.x = a.pcm + base;
+        ti.ob = a.out + static_cast<int64_t>(b) * a.utt_stride;
+        ti.lastv = a.last ? a.last[b] : 0.0f;
+        ti.n0 = static_cast<int64_t>(ti.t0) * a.hop - a.pad;
+        ti.stage = ti.t0 < ti.T;
+        if (ti.t0 == 0 && tid == 0 && a.lengths) a.lengths[b] = ti.T;
+        return ti;
+    };
+    // raw samples of a tile: thread t owns the float4 groups t, t + 256, ... of the staged span, plus the sample before each
+    float4 raw[kStageVec];
+    float rprev[kStageVec];
+    auto fetch = [&](const TileInfo &ti) {
+#pragma unroll
+        for (int r = 0; r < kStageVec; ++r) {
+            const int e = 4 * (tid + kThreads * r);
+            const int64_t n = ti.n0 + e;
+            raw[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rprev[r] = 0.f;
+            if (e >= a.stage_alloc) continue;
+            if (n >= 1 && n + 3 < ti.len) {  // interior: one 16-byte load + the preceding sample
+                raw[r] = *reinterpret_cast<const float4 *>(ti.x + n);
+                rprev[r] = ti.x[n - 1];
+            } else {                          // utterance edges: guarded scalar loads
+                float t[5];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const int64_t m = n - 1 + c;
+                    t[c] = m >= 0 && m < ti.len ? ti.x[m] : (m == -1 ? ti.lastv : 0.f);
+                }
+                rprev[r] = t[0];
+                raw[r] = make_float4(t[1], t[2], t[3], t[4]);
+            }
+        }
+    };
+    auto stage = [&](const TileInfo &ti) {  // pre-emphasis (:211,:219-225: y[n] = x[n] - p x[n-1]); zero outside [0, len)
+#pragma unroll
+        for (int r = 0; r < kStageVec; ++r) {
+            const int e = 4 * (tid + kThreads * r);
+            if (e >= a.stage_alloc) continue;
+            const int64_t n = ti.n0 + e;
+            float4 y;
+            y.x = raw[r].x - a.preemph * rprev[r];
+            y.y = raw[r].y - a.preemph * raw[r].x;
+            y.z = raw[r].z - a.preemph * raw[r].y;
+            y.w = raw[r].w - a.preemph * raw[r].z;
+            if (!(n >= 0 && n + 3 < ti.len)) {
+                if (n < 0 || n >= ti.len) y.x = 0.f;
+                if (n + 1 < 0 || n + 1 >= ti.len) y.y = 0.f;
+                if (n + 2 < 0 || n + 2 >= ti.len) y.z = 0.f;
+                if (n + 3 < 0 || n + 3 >= ti.len) y.w = 0.f;
+            }
+            *reinterpret_cast<float4 *>(samples + e) = y;
+        }
+    };
+
+    TileInfo cur = first < stop ? tile_info(first) : TileInfo{};
+    if (first < stop && cur.stage && vec_stage) fetch(cur);
 
     for (int64_t tl = first; tl < stop; ++tl) {
-        const int b = static_cast<int>(tl / a.tiles_per_utt);
-        const int t0 = static_cast<int>(tl % a.tiles_per_utt) * kTileFrames;
-        const int T = a.frames[b];
-        const int64_t base = a.offsets[b];
-        const int64_t len = a.offsets[b + 1] - base;
-        if (t0 == 0 && tid == 0 && a.lengths) a.lengths[b] = T;
-
-        if (t0 < T) {  // workgroup-uniform
-            const float *x = a.pcm + base;
-            const float lastv = a.last ? a.last[b] : 0.0f;
-            const int64_t n0 = static_cast<int64_t>(t0) * a.hop - a.pad;
-            for (int i = tid; i < a.stage_count; i += kThreads) {
-                const int64_t n = n0 + i;
-                float y = 0.0f;
-                if (n >= 0 && n < len) {
-                    const float prev = n > 0 ? x[n - 1] : lastv;
-                    y = x[n] - a.preemph * prev;  // :211,:219-225 (y[n] = x[n] - p*x[n-1])
+        if (cur.stage) {
+            if (vec_stage) stage(cur);
+            else
+                for (int i = tid; i < a.stage_count; i += kThreads) {  // large hops: plain staging loop
+                    const int64_t n = cur.n0 + i;
+                    float y = 0.0f;
+                    if (n >= 0 && n < cur.len) y = cur.x[n] - a.preemph * (n > 0 ? cur.x[n - 1] : cur.lastv);
+                    samples[i] = y;
                 }
-                samples[i] = y;
-            }
-            __syncthreads();
-            const bool active = (t0 + grp) < T;
-            // Opaque per-iteration copy of the lane id: stops LICM from hoisting ~40 table
-            // addresses out of the tile loop (they were spilled to scratch when hoisted).
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            float *R = regions + grp * kRegionFloats;
-            const float *fs = samples + grp * a.hop;
-            if (active) phase_a(ln, fs, c, R);
-            __syncthreads();
-            Lane v;
-            if (active) phase_b1(ln, R, v);
-            __syncthreads();
-            if (active) phase_b2(ln, v, R);
-            __syncthreads();
-            Power p;
-            if (active) phase_c1(ln, R, c, p);
-            __syncthreads();
-            if (active) phase_c2(ln, p, R);
-            __syncthreads();
-        }
-
-        float *ob = a.out + static_cast<int64_t>(b) * a.utt_stride;
-        const int work = kTileFrames * a.n_mels;
-        for (int idx = tid; idx < work; idx += kThreads) {
-            int f, m;
-            if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) { f = idx & (kTileFrames - 1); m = idx >> 4; }
-            else { f = idx / a.n_mels; m = idx - f * a.n_mels; }
-            const int t = t0 + f;
-            if (t >= a.frame_stride) continue;
-            float val = 0.0f;  // padValue (:39) for t >= T
-            if (t < T) {
-                const int packed = mtab[m];
-                const int lo = packed & 1023, cnt = (packed >> 10) & 1023, st = packed >> 20;
-                const float *P = regions + f * kRegionFloats + lo;
-                const float *w = mw + st;
-                float acc = 0.0f;
-                for (int j = 0; j < cnt; ++j) acc += w[j] * P[j];  // vDSP_mmul row (:270-283), zeros skipped
-                val = a.floor_clamped ? logf(fmaxf(acc, a.log_floor)) : logf(acc + a.log_floor);  // :542-549
-            }
-            if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) ob[static_cast<int64_t>(m) * a.frame_stride + t] = val;  // :287
-            else ob[static_cast<int64_t>(t) * a.n_mels + m] = val;                                       // :451
         }
         __syncthreads();
+        // the next tile's samples travel from HBM while this tile is computed
+        TileInfo nxt{};
+        nxt.stage = false;
+        if (tl + 1 < stop) { nxt = tile_info(tl + 1); if (nxt.stage && vec_stage) fetch(nxt); }
+
+        if (cur.stage) {  // workgroup-uniform
+            float *R = regions + grp * kRegionFloats;
+#pragma unroll 1
+            for (int pass = 0; pass < kPasses; ++pass) {
+                // frame of this 16-lane group inside the tile: wave w owns frames [8w, 8w + 8)
+                const int f = (grp >> 2) * (kWaveFrames * kPasses) + pass * kWaveFrames + (grp & 3);
+                const float *fs = samples + f * a.hop;
+                Lane v;
+                if (hop_even) {
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) {
+                        const float2 s2 = *reinterpret_cast<const float2 *>(fs + 32 * n1 + 2 * l);
+                        v.re[n1] = s2.x; v.im[n1] = s2.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) { v.re[n1] = fs[32 * n1 + 2 * l]; v.im[n1] = fs[32 * n1 + 2 * l + 1]; }
+                }
+                // Everything below exchanges data only between the 16 lanes of one frame group, i.e. inside one
+                // wavefront: LDS operations of a wavefront complete in program order, no barrier is needed.
+                phase_a2(l, v, kc, R);
+                phase_b1(l, R, v);
+                float qr[8], qi[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {  // Z[256 - (l + 16 j)]: lane (16 - l) & 15, register 15 - j (lane 0: own (16 - j) & 15)
+                    const float pr = dpp_partner(v.re[15 - j]), pi = dpp_partner(v.im[15 - j]);
+                    qr[j] = l == 0 ? v.re[(16 - j) & 15] : pr;
+                    qi[j] = l == 0 ? v.im[(16 - j) & 15] : pi;
+                }
+                Power p;
+                phase_c1v2(l, v, qr, qi, kc, p);
+                phase_c2(l, p, R);
+                // sparse triangular filterbank + log for this group's frame: lane l owns mels l, l + 16, ...
+                if (FAST) {
+                    // weights zero-padded to the slot profile, [slot][16 lanes]: every read below is independent
+                    float acc[kFastGroups];
+#pragma unroll
+                    for (int i = 0; i < kFastGroups; ++i) {
+                        acc[i] = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < fast_slots(i); ++j)
+                            acc[i] += mw[(fast_slot_base(i) + j) * kGroup + l] * R[((mlo[i / 3] >> (10 * (i % 3))) & 1023) + j];  // vDSP_mmul row (:270-283), zeros skipped
+                    }
+#pragma unroll
+                    for (int i = 0; i < kFastGroups; ++i) {
+                        const int m = l + 16 * i;
+                        const float val = a.floor_clamped ? logf(fmaxf(acc[i], a.log_floor)) : logf(acc[i] + a.log_floor);  // :542-549
+                        if (m < n_mels) {
+                            if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) outs[m * kMelPad + f] = val;
+                            else outs[f * (n_mels + kFramePad) + m] = val;
+                        }
+                    }
+                } else {
+                    for (int m = l; m < n_mels; m += kGroup) {
+                        const int packed = mtab[m];
+                        const int lo = packed & 1023, cnt = (packed >> 10) & 1023, st = packed >> 20;
+                        const float *P = R + lo;
+                        const float *wgt = mw + st;
+                        float acc = 0.0f;
+                        for (int j = 0; j < cnt; ++j) acc += wgt[j] * P[j];
+                        const float val = a.floor_clamped ? logf(fmaxf(acc, a.log_floor)) : logf(acc + a.log_floor);
+                        if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) outs[m * kMelPad + f] = val;
+                        else outs[f * (n_mels + kFramePad) + m] = val;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        const int work = kTileFrames * n_mels;
+        for (int idx = tid; idx < work; idx += kThreads) {
+            int f, m;
+            if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) { f = idx & (kTileFrames - 1); m = idx >> 5; }
+            else { f = idx / n_mels; m = idx - f * n_mels; }
+            const int t = cur.t0 + f;
+            if (t >= a.frame_stride) continue;
+            float val = 0.0f;  // padValue (:39) for t >= T
+            if (t < cur.T) val = LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR ? outs[m * kMelPad + f] : outs[f * (n_mels + kFramePad) + m];
+            if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) cur.ob[static_cast<int64_t>(m) * a.frame_stride + t] = val;  // :287
+            else cur.ob[static_cast<int64_t>(t) * n_mels + m] = val;                                       // :451
+        }
+        // the next tile's staging writes `samples` (no reader left) and its barrier orders the `outs` reads above
+        // before the next writes
+        cur = nxt;
     }
 }
 
@@ -206,6 +354,7 @@ struct fa_mel_plan {
     MelArgs args{};
     size_t lds_bytes = 0;
     int grid = 0;
+    bool fast = false;  // filterbank fits the compile-time slot profile
 };
 
 extern "C" {
@@ -293,17 +442,33 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         for (int k = 0; k < 129; ++k) { const double a = -2.0 * M_PI * k / 512.0; tw512[k] = make_float2((float)cos(a), (float)sin(a)); }
         std::vector<int32_t> tab(cfg->n_mels);
         std::vector<float> weights;
+        bool fast = cfg->n_mels <= kFastGroups * kGroup;
+        std::vector<int> lo_of(cfg->n_mels, 0), cnt_of(cfg->n_mels, 0);
         for (int m = 0; m < cfg->n_mels; ++m) {
             int lo = -1, hi = -1;
             for (int k = 0; k < bins; ++k)
                 if (fb[static_cast<size_t>(m) * bins + k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
             const int cnt = lo < 0 ? 0 : hi - lo + 1;
             if (lo < 0) lo = 0;
-            const int st = static_cast<int>(weights.size());
-            for (int j = 0; j < cnt; ++j) weights.push_back(fb[static_cast<size_t>(m) * bins + lo + j]);
-            tab[m] = lo | (cnt << 10) | (st << 20);
+            lo_of[m] = lo; cnt_of[m] = cnt;
+            if (cnt > fast_slots(m / kGroup < kFastGroups ? m / kGroup : kFastGroups - 1)) fast = false;
         }
-        if (weights.size() > static_cast<size_t>(kMaxWeights) * 2) { delete p; return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel: filterbank too dense"); }
+        if (fast) {  // [slot][lane] zero-padded weights; mel_tab keeps (lo, cnt) and a dummy start
+            weights.assign(static_cast<size_t>(kFastSlots) * kGroup, 0.0f);
+            for (int m = 0; m < cfg->n_mels; ++m) {
+                const int i = m / kGroup, l = m % kGroup;
+                for (int j = 0; j < cnt_of[m]; ++j)
+                    weights[static_cast<size_t>(fast_slot_base(i) + j) * kGroup + l] = fb[static_cast<size_t>(m) * bins + lo_of[m] + j];
+                tab[m] = lo_of[m] | (cnt_of[m] << 10);
+            }
+        } else {
+            for (int m = 0; m < cfg->n_mels; ++m) {
+                const int st = static_cast<int>(weights.size());
+                for (int j = 0; j < cnt_of[m]; ++j) weights.push_back(fb[static_cast<size_t>(m) * bins + lo_of[m] + j]);
+                tab[m] = lo_of[m] | (cnt_of[m] << 10) | (st << 20);
+            }
+        }
+        p->fast = fast;
         if (weights.empty()) weights.push_back(0.0f);
 
         // device blob
@@ -344,20 +509,27 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         a.pad = cfg->padding_mode == FA_MEL_PAD_CENTER ? cfg->n_fft / 2 : 0;
         a.stage_count = (kTileFrames - 1) * cfg->hop + kNfft;
         a.stage_alloc = (a.stage_count + 3) & ~3;
+        {
+            const int mm = cfg->n_mels * kMelPad, fm = kTileFrames * (cfg->n_mels + kFramePad);
+            a.out_alloc = ((mm > fm ? mm : fm) + 3) & ~3;
+        }
         a.preemph = cfg->padding_mode == FA_MEL_PAD_LEGACY ? 0.0f : cfg->preemph;  // compute() has no pre-emphasis (:146-153)
         a.log_floor = cfg->log_floor;
         a.floor_clamped = cfg->floor_mode == FA_MEL_FLOOR_CLAMPED;
-        p->lds_bytes = sizeof(float) * (a.stage_alloc + kTileFrames * kRegionFloats) + sizeof(int32_t) * kMaxMels +
+        p->lds_bytes = sizeof(float) * (a.stage_alloc + kRegions * kRegionFloats + a.out_alloc) + sizeof(int32_t) * kMaxMels +
                        sizeof(float) * (static_cast<size_t>(a.n_weights) + 8);
         if (p->lds_bytes > 160 * 1024) { (void)hipFree(p->dev); delete p; return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel: hop too large for LDS staging"); }
         if (p->lds_bytes > 64 * 1024) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(p->lds_bytes));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(p->lds_bytes));
+            const int lb = static_cast<int>(p->lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
         }
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, ctx->device);
         const int cus = e == hipSuccess ? prop.multiProcessorCount : 256;
-        const int64_t want = static_cast<int64_t>(cus) * 3 * 2;  // 3 resident workgroups per CU, two waves of them
+        const int64_t want = static_cast<int64_t>(cus) * 2 * 4;  // 2 resident workgroups per CU, four rounds of them
         p->grid = static_cast<int>(a.total_tiles < want ? a.total_tiles : want);
         if (p->grid < 1) p->grid = 1;
         *out = p;
@@ -385,10 +557,11 @@ fa_status fa_mel_execute_dev(fa_mel_plan *p, const float *d_pcm, const float *d_
     fa::DeviceGuard guard(ctx->device);
     MelArgs a = p->args;
     a.pcm = d_pcm; a.last = d_last; a.out = d_mel; a.lengths = d_lengths;
-    if (p->cfg.layout == FA_MEL_LAYOUT_MEL_MAJOR)
-        hipLaunchKernelGGL(mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR>, dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
-    else
-        hipLaunchKernelGGL(mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR>, dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
+    const bool mm = p->cfg.layout == FA_MEL_LAYOUT_MEL_MAJOR;
+    if (mm && p->fast) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, true>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
+    else if (mm) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, false>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
+    else if (p->fast) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, true>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
+    else hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, false>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }

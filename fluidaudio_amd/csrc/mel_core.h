@@ -4,9 +4,13 @@
 // vDSP_DFT_zop) is evaluated by a 16-lane group as a 256-point complex FFT of
 // z[n] = x[2n] + i*x[2n+1] (two radix-16 passes held in registers, one transpose through
 // the group's LDS region) followed by the even/odd recombination that yields the 257
-// power bins.  Every function here is written against (lane, LDS region, registers) so the
-// same code runs inside the kernel and inside tests/cpu/mel_core_emul.cpp, which replays
-// the 16 lanes sequentially on the host to check the index algebra without a GPU.
+// power bins.  The recombination pairs Z[k] with Z[256-k]; with k = lane + 16*j the partner
+// lives in lane (16 - lane) & 15, so that exchange is a lane permutation (DPP row_mirror +
+// row_ror:1 on the device) and never touches LDS.  Window and twiddle factors a lane needs
+// depend only on (lane & 15): they are loaded once into registers (LaneConst).
+// Every function here is written against (lane, LDS region, registers) so the same code
+// runs inside the kernel and inside tests/cpu/mel_core_emul.cpp, which replays the 16 lanes
+// sequentially on the host to check the index algebra without a GPU.
 #pragma once
 
 #if defined(__HIPCC__)
@@ -194,6 +198,81 @@ FA_HD void phase_c2(const int lane, const Power &p, float *region) {
         region[kHalf - k] = p.hi[j];
     }
     if (lane == 0) region[128] = p.mid;
+}
+
+// =============================================================================== v2 dataflow
+// Per-lane constants (lane = index inside the 16-lane frame group).
+struct LaneConst {
+    float wz[32];          // windowz[32*n1 + 2*lane], windowz[32*n1 + 2*lane + 1]  (n1 = 0..15)
+    float t1r[15], t1i[15];  // exp(-2*pi*i*lane*k1/256), k1 = 1..15 at index k1 - 1
+    float t2r[8], t2i[8];    // exp(-2*pi*i*(lane + 16*j)/512), j = 0..7
+};
+
+FA_HD void lane_const_init(const int lane, const Tables &c, LaneConst &k) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int n1 = 0; n1 < 16; ++n1) {
+        k.wz[2 * n1] = c.windowz[32 * n1 + 2 * lane];
+        k.wz[2 * n1 + 1] = c.windowz[32 * n1 + 2 * lane + 1];
+    }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k1 = 1; k1 < 16; ++k1) {
+        const int tk = (lane * k1) & (kHalf - 1);
+        k.t1r[k1 - 1] = c.tw256[2 * tk];
+        k.t1i[k1 - 1] = c.tw256[2 * tk + 1];
+    }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 8; ++j) {
+        k.t2r[j] = c.tw512[2 * (lane + 16 * j)];
+        k.t2i[j] = c.tw512[2 * (lane + 16 * j) + 1];
+    }
+}
+
+// ---- phase A: window (registers), first radix-16 pass, inter-pass twiddle, scatter into the transpose buffer.
+// v.re[n1] / v.im[n1] hold the frame samples 32*n1 + 2*lane, + 1 on entry.
+FA_HD void phase_a2(const int lane, Lane &v, const LaneConst &k, float *region) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int n1 = 0; n1 < 16; ++n1) { v.re[n1] *= k.wz[2 * n1]; v.im[n1] *= k.wz[2 * n1 + 1]; }
+    fft16(v);  // v[k1] = sum_n1 z[16*n1 + lane] W16^(n1*k1)
+    region[2 * lane] = v.re[0];
+    region[2 * lane + 1] = v.im[0];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k1 = 1; k1 < 16; ++k1) {
+        cmul(v.re[k1], v.im[k1], k.t1r[k1 - 1], k.t1i[k1 - 1]);
+        region[2 * (k1 * kEStride + lane)] = v.re[k1];
+        region[2 * (k1 * kEStride + lane) + 1] = v.im[k1];
+    }
+}
+
+// ---- phase C (v2): v = Z[lane + 16*k2] of this lane (after phase_b1); (qr, qi)[j] = Z[256 - (lane + 16*j)],
+// fetched from the partner lane by the caller (device: DPP, host: array).  Power bins stay in registers.
+FA_HD void phase_c1v2(const int lane, const Lane &v, const float (&qr)[8], const float (&qi)[8], const LaneConst &k, Power &p) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 8; ++j)
+        pair_power(v.re[j], v.im[j], qr[j], qi[j], k.t2r[j], k.t2i[j], p.lo[j], p.hi[j]);
+    p.mid = 0.0f;
+    if (lane == 0) {
+        float dummy;
+        pair_power(v.re[8], v.im[8], v.re[8], v.im[8], 0.0f, -1.0f, p.mid, dummy);  // k = 128: w = exp(-i*pi/2)
+    }
+}
+
+// Which register of which lane holds Z[256 - (lane + 16*j)]: lane (16 - lane) & 15, register 15 - j; lane 0 pairs
+// with itself, register (16 - j) & 15.  (Used by the host replay; the device hard-wires the same mapping in DPP.)
+FA_HD void partner_of(const int lane, const int j, int &plane, int &preg) {
+    plane = (16 - lane) & 15;
+    preg = lane == 0 ? ((16 - j) & 15) : 15 - j;
 }
 
 }  // namespace melcore

@@ -10,12 +10,17 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_lane_dataflow_matches_float64_dft(oracle_mod):
+import pytest
+
+
+@pytest.mark.parametrize("entry", ["mel_core_emul_power", "mel_core_emul_power_v2"])
+def test_lane_dataflow_matches_float64_dft(oracle_mod, entry):
     so = os.path.join(HERE, "cpu", "libmel_core_emul.so")
     subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(HERE, "cpu", "mel_core_emul.cpp")], check=True)
     lib = C.CDLL(so)
     f32 = np.ctypeslib.ndpointer(np.float32)
-    lib.mel_core_emul_power.argtypes = [f32, f32, f32]
+    fn = getattr(lib, entry)
+    fn.argtypes = [f32, f32, f32]
     rng = np.random.default_rng(1)
     for off, win in ((56, 400), (0, 400), (0, 512)):
         wz = np.zeros(512, np.float32)
@@ -23,7 +28,7 @@ def test_lane_dataflow_matches_float64_dft(oracle_mod):
         for _ in range(4):
             x = (rng.standard_normal(512) * 0.1).astype(np.float32)
             p = np.zeros(257, np.float32)
-            lib.mel_core_emul_power(x, wz, p)
+            fn(x, wz, p)
             ref = np.abs(np.fft.rfft(x.astype(np.float64) * wz.astype(np.float64))) ** 2
             assert np.max(np.abs(p - ref)) < 1e-6 * ref.max()
     # impulse at every position exercises each lane/index path exactly
@@ -32,5 +37,5 @@ def test_lane_dataflow_matches_float64_dft(oracle_mod):
         x = np.zeros(512, np.float32)
         x[pos] = 1.0
         p = np.zeros(257, np.float32)
-        lib.mel_core_emul_power(x, wz, p)
+        fn(x, wz, p)
         np.testing.assert_allclose(p, 1.0, atol=2e-6)
