@@ -27,7 +27,7 @@ constexpr int kWaveFrames = 4;                 // frames in flight per wavefront
 constexpr int kRegions = kThreads / kGroup;    // 16 LDS regions (4 waves x 4 frames)
 constexpr int kPasses = kTileFrames / kRegions;  // 2
 constexpr int kMaxMels = 256;
-constexpr int kMelPad = 33;                    // [n_mels][33] staging: conflict-free writes and reads
+constexpr int kMelPad = 36;                    // [n_mels][36] staging: rows 16-byte aligned for float4 reads
 constexpr int kFramePad = 8;                   // [32][n_mels + 8] staging
 
 struct MelArgs {
@@ -231,7 +231,10 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
                 }
                 Power p;
                 phase_c1v2(l, v, qr, qi, kc, p);
-                phase_c2(l, p, R);
+                // power bins at R + {0,14,28,10}[frame]: regions are 578 = 2 (mod 32) floats apart, so this puts the two frames
+                // of a 32-lane LDS service group 16 banks apart and the gathers below stop colliding
+                float *PR = R + ((0x0a1c0e00u >> (8 * (grp & 3))) & 0xff);
+                phase_c2(l, p, PR);
                 // sparse triangular filterbank + log for this group's frame: lane l owns mels l, l + 16, ...
                 if (FAST) {
                     // weights zero-padded to the slot profile, [slot][16 lanes]: every read below is independent
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
                         acc[i] = 0.0f;
 #pragma unroll
                         for (int j = 0; j < fast_slots(i); ++j)
-                            acc[i] += mw[(fast_slot_base(i) + j) * kGroup + l] * R[((mlo[i / 3] >> (10 * (i % 3))) & 1023) + j];  // vDSP_mmul row (:270-283), zeros skipped
+                            acc[i] += mw[(fast_slot_base(i) + j) * kGroup + l] * PR[((mlo[i / 3] >> (10 * (i % 3))) & 1023) + j];  // vDSP_mmul row (:270-283), zeros skipped
                     }
 #pragma unroll
                     for (int i = 0; i < kFastGroups; ++i) {
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
                     for (int m = l; m < n_mels; m += kGroup) {
                         const int packed = mtab[m];
                         const int lo = packed & 1023, cnt = (packed >> 10) & 1023, st = packed >> 20;
-                        const float *P = R + lo;
+                        const float *P = PR + lo;
                         const float *wgt = mw + st;
                         float acc = 0.0f;
                         for (int j = 0; j < cnt; ++j) acc += wgt[j] * P[j];
@@ -269,17 +272,27 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
         }
         __syncthreads();
 
-        const int work = kTileFrames * n_mels;
-        for (int idx = tid; idx < work; idx += kThreads) {
-            int f, m;
-            if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) { f = idx & (kTileFrames - 1); m = idx >> 5; }
-            else { f = idx / n_mels; m = idx - f * n_mels; }
-            const int t = cur.t0 + f;
-            if (t >= a.frame_stride) continue;
-            float val = 0.0f;  // padValue (:39) for t >= T
-            if (t < cur.T) val = LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR ? outs[m * kMelPad + f] : outs[f * (n_mels + kFramePad) + m];
-            if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) cur.ob[static_cast<int64_t>(m) * a.frame_stride + t] = val;  // :287
-            else cur.ob[static_cast<int64_t>(t) * n_mels + m] = val;                                       // :451
+        if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) {
+            // 8 threads per mel row, 4 consecutive frames each: 16-byte LDS reads, 16-byte global stores (:287)
+            for (int idx = tid; idx < n_mels * (kTileFrames / 4); idx += kThreads) {
+                const int m = idx >> 3, f = (idx & 7) * 4, t = cur.t0 + f;
+                if (t >= a.frame_stride) continue;
+                float4 v4 = *reinterpret_cast<const float4 *>(outs + m * kMelPad + f);
+                float *dst = cur.ob + static_cast<int64_t>(m) * a.frame_stride + t;
+                if (t + 3 < cur.T && t + 3 < a.frame_stride) { *reinterpret_cast<float4 *>(dst) = v4; continue; }
+                const float e[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (t + c < a.frame_stride) dst[c] = t + c < cur.T ? e[c] : 0.0f;  // padValue (:39) for t >= T
+            }
+        } else {
+            const int work = kTileFrames * n_mels;
+            for (int idx = tid; idx < work; idx += kThreads) {
+                const int f = idx / n_mels, m = idx - f * n_mels;
+                const int t = cur.t0 + f;
+                if (t >= a.frame_stride) continue;
+                cur.ob[static_cast<int64_t>(t) * n_mels + m] = t < cur.T ? outs[f * (n_mels + kFramePad) + m] : 0.0f;  // :451
+            }
         }
         // the next tile's staging writes `samples` (no reader left) and its barrier orders the `outs` reads above
         // before the next writes
