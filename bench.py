@@ -42,6 +42,21 @@ def synth_pcm(torch, n_chunks, seed):
     return x
 
 
+def measured_traffic():
+    """HBM bytes per launch of the mel kernel from the committed rocprofv3 PMC passes (profiles/*_mel_pmc.json, written by
+    scripts/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction of MI355X_MICROARCH.md); None if absent.
+    PMC collection needs its own rocprofv3 runs, so bench.py reports the value measured for the committed kernel."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mel_pmc.json"))):
+        try:
+            with open(f) as fh:
+                best = json.load(fh).get("hbm_traffic_bytes_per_launch", best)
+        except Exception:  # noqa: BLE001
+            pass
+    return best
+
+
 def cpu_mel_baseline(budget_s=12.0):
     """Time the CPU oracle (1 thread) on a bounded sample of the same workload."""
     import oracle
@@ -207,7 +222,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: batched STFT->mel, 1024 x 15 s 16 kHz chunks per GPU, NeMo config "
                                "(n_fft 512, hop 160, win 400, 128 mels, preemph 0.97), output [B,128,1501] fp32, inputs resident in HBM",
                    "chunks_per_gpu": B, "realtime_factor": value * 3600.0, "parallelism": f"dp{world} (independent utterance shards, no collective)"},
-        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(),
                      "kernel": "mel_kernel<MEL_MAJOR>", "kernel_ms_avg": kernel_ms_avg, "kernel_ms_min": float(np.min(kernel_ms)),
                      "algorithmic_bytes_per_launch": B * MEL_BYTES_PER_CHUNK},
     }
