@@ -32,6 +32,8 @@ EXPORTED_SYMBOLS = [
     "fa_ctc_greedy_batch_dev", "fa_ctc_greedy_batch",
     "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_cluster", "fa_ahc_cut",
     "fa_vbx_speaker_count", "fa_vbx_refine",
+    "fa_vbx_weighted_centroids", "fa_assign_cosine",
+    "fa_resample_linear_frames", "fa_resample_linear", "fa_resample_poly_frames", "fa_resample_poly_taps", "fa_resample_poly",
 ]
 
 
@@ -116,6 +118,15 @@ def lib() -> C.CDLL:
     L.fa_vbx_speaker_count.argtypes = [vp, i64]
     L.fa_vbx_speaker_count.restype = i32
     L.fa_vbx_refine.argtypes = [vp, vp, i64, i32, vp, vp, f64, f64, i32, f64, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
+    L.fa_vbx_weighted_centroids.argtypes = [vp, vp, i64, i32, vp, vp, i32, vp, vp, C.POINTER(i32)]
+    L.fa_assign_cosine.argtypes = [vp, vp, i64, i32, vp, i32, vp]
+    L.fa_resample_linear_frames.argtypes = [i64, f64, f64]
+    L.fa_resample_linear_frames.restype = i64
+    L.fa_resample_linear.argtypes = [vp, vp, i32, i64, f64, f64, vp, i64, C.POINTER(i64)]
+    L.fa_resample_poly_frames.argtypes = [i64, i32, i32]
+    L.fa_resample_poly_frames.restype = i64
+    L.fa_resample_poly_taps.argtypes = [i32, i32, vp, i64, C.POINTER(i64), C.POINTER(i64)]
+    L.fa_resample_poly.argtypes = [vp, vp, i64, i32, i32, vp, i64, C.POINTER(i64)]
     _lib = L
     return L
 

@@ -1,0 +1,188 @@
+// resample.hip — sample-rate conversion to the 16 kHz mono fp32 the featurizer consumes (gfx950).
+//
+// (1) fa_resample_linear replaces AudioConverter.linearResample
+//     (reference: Sources/FluidAudio/Shared/AudioConverter.swift:388-442): mix N planar channels down to mono with
+//     weight 1/N (:399-408), then linear interpolation at sourceIndex = i * (inRate / outRate) in double precision
+//     (:419-434).  This is the only resampling arithmetic that exists in the reference tree; it is pinned by
+//     AudioConverterTests.swift:546-761 and reproduced bit-for-bit (fp32 mix and blend with one rounding per operation).
+// (2) fa_resample_poly is an EXTENSION with its own specification (PARITY UNPINNED): the reference's default path hands
+//     the job to Apple's closed-source AVAudioConverter (AudioConverter.swift:299-370), whose arithmetic cannot be
+//     restated.  The kernel is a rational-ratio polyphase FIR (Kaiser beta = 5 windowed sinc, half length
+//     10 * max(up, down), unit DC gain, the output alignment of scipy.signal.resample_poly) so that an independent
+//     second opinion exists on the CPU.  One thread per output sample walks the ~2*10*max(up,down)/up taps of its
+//     phase; consecutive threads read consecutive input samples and taps `up` apart.
+#include <cmath>
+#include <vector>
+
+#include "fa_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__global__ void mixdown_kernel(const float *__restrict__ planar, float *__restrict__ mono, int channels, int64_t frames) {
+    const int64_t f = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (f >= frames) return;
+    float sum = 0.0f;
+    for (int c = 0; c < channels; ++c) sum = __fadd_rn(sum, planar[static_cast<int64_t>(c) * frames + f]);  // :403-407
+    mono[f] = __fmul_rn(sum, 1.0f / static_cast<float>(channels));
+}
+
+__global__ void linear_kernel(const float *__restrict__ mono, float *__restrict__ out, int64_t frames, int64_t out_frames, double ratio) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= out_frames) return;
+    const double src = static_cast<double>(i) * ratio;       // :424
+    const int64_t idx = static_cast<int64_t>(src);            // Int(sourceIndex): truncation
+    const float frac = static_cast<float>(src - static_cast<double>(idx));
+    float v = 0.0f;
+    if (idx < frames - 1) v = __fadd_rn(__fmul_rn(mono[idx], __fsub_rn(1.0f, frac)), __fmul_rn(mono[idx + 1], frac));  // :428-430
+    else if (idx < frames) v = mono[idx];                     // :431-432
+    out[i] = v;
+}
+
+__global__ void poly_kernel(const float *__restrict__ x, const float *__restrict__ h, float *__restrict__ y, int64_t n_in, int64_t n_out,
+                            int64_t h_len, int up, int down, int64_t pre_remove) {
+    const int64_t m = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (m >= n_out) return;
+    const int64_t p = (m + pre_remove) * down;  // position in the zero-stuffed stream
+    int64_t k_hi = p / up;                      // largest k with p - k*up >= 0
+    int64_t k_lo = (p - (h_len - 1) + up - 1) / up;  // smallest k with p - k*up <= h_len - 1
+    if (p - (h_len - 1) < 0) k_lo = 0;
+    if (k_hi > n_in - 1) k_hi = n_in - 1;
+    float acc = 0.0f;
+    for (int64_t k = k_lo; k <= k_hi; ++k) acc = fmaf(h[p - k * up], x[k], acc);
+    y[m] = acc;
+}
+
+double bessel_i0(double x) {  // power series, converges fast for the beta used here
+    double sum = 1.0, term = 1.0;
+    const double q = x * x / 4.0;
+    for (int k = 1; k < 200; ++k) { term *= q / (static_cast<double>(k) * k); sum += term; if (term < 1e-18 * sum) break; }
+    return sum;
+}
+
+int64_t gcd64(int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t fa_resample_linear_frames(int64_t frames, double in_rate, double out_rate) {
+    if (frames < 0 || !(in_rate > 0) || !(out_rate > 0)) return 0;
+    if (in_rate == out_rate) return frames;  // :414-416
+    return static_cast<int64_t>(static_cast<double>(frames) / (in_rate / out_rate));  // :420
+}
+
+fa_status fa_resample_linear(fa_ctx *ctx, const float *planar, int32_t channels, int64_t frames, double in_rate, double out_rate,
+                             float *out, int64_t out_capacity, int64_t *out_frames) {
+    if (!ctx || !out_frames) return FA_INVALID_ARGUMENT;
+    *out_frames = 0;
+    if (channels < 1 || frames < 0 || !(in_rate > 0) || !(out_rate > 0)) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "resample: bad arguments");
+    const int64_t n_out = fa_resample_linear_frames(frames, in_rate, out_rate);
+    if (n_out > out_capacity) return fa::set_error(ctx, FA_OUTPUT_TOO_SMALL, "resample: output buffer too small");
+    *out_frames = n_out;
+    if (frames == 0 || n_out == 0) return FA_SUCCESS;
+    if (!planar || !out) return FA_INVALID_ARGUMENT;
+    fa::DeviceGuard guard(ctx->device);
+    fa::DevBuf d_in, d_mono, d_out;
+    hipError_t e;
+    do {
+        if ((e = d_in.alloc(sizeof(float) * frames * channels)) != hipSuccess) break;
+        if ((e = d_mono.alloc(sizeof(float) * frames)) != hipSuccess) break;
+        if ((e = d_out.alloc(sizeof(float) * n_out)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d_in.p, planar, sizeof(float) * frames * channels, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        hipLaunchKernelGGL(mixdown_kernel, dim3(static_cast<unsigned>((frames + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
+                           d_in.as<float>(), d_mono.as<float>(), channels, frames);
+        const float *src = d_mono.as<float>();
+        if (in_rate != out_rate) {
+            hipLaunchKernelGGL(linear_kernel, dim3(static_cast<unsigned>((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
+                               d_mono.as<float>(), d_out.as<float>(), frames, n_out, in_rate / out_rate);
+            src = d_out.as<float>();
+        }
+        if ((e = hipGetLastError()) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(out, src, sizeof(float) * n_out, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    return fa::hip_status(ctx, e, "fa_resample_linear");
+}
+
+int64_t fa_resample_poly_frames(int64_t frames, int32_t up, int32_t down) {
+    if (frames < 0 || up < 1 || down < 1) return 0;
+    const int64_t g = gcd64(up, down);
+    const int64_t u = up / g, dn = down / g;
+    return (frames * u + dn - 1) / dn;  // ceil(n * up / down)
+}
+
+fa_status fa_resample_poly_taps(int32_t up, int32_t down, float *taps, int64_t capacity, int64_t *n_taps, int64_t *pre_remove) {
+    if (up < 1 || down < 1 || !n_taps || !pre_remove) return FA_INVALID_ARGUMENT;
+    const int64_t g = gcd64(up, down);
+    const int64_t u = up / g, dn = down / g, mx = u > dn ? u : dn;
+    const int64_t half = 10 * mx, len = 2 * half + 1;
+    const int64_t pre_pad = dn - half % dn;
+    *n_taps = len + pre_pad;
+    *pre_remove = (half + pre_pad) / dn;
+    if (!taps) return FA_SUCCESS;
+    if (capacity < *n_taps) return FA_OUTPUT_TOO_SMALL;
+    try {
+        // firwin(len, 1/mx, window=('kaiser', 5.0)) * up : windowed sinc, cut-off 1/mx of Nyquist, unit DC gain
+        std::vector<double> h(len);
+        const double fc = 1.0 / static_cast<double>(mx), alpha = 0.5 * (len - 1), beta = 5.0, i0b = bessel_i0(beta);
+        double sum = 0.0;
+        for (int64_t n = 0; n < len; ++n) {
+            const double m = static_cast<double>(n) - alpha;
+            const double a = M_PI * fc * m;
+            const double sinc = m == 0.0 ? 1.0 : sin(a) / a;
+            const double r = 2.0 * n / static_cast<double>(len - 1) - 1.0;
+            const double w = bessel_i0(beta * sqrt(1.0 - r * r > 0 ? 1.0 - r * r : 0.0)) / i0b;
+            h[n] = fc * sinc * w;
+            sum += h[n];
+        }
+        for (int64_t n = 0; n < pre_pad; ++n) taps[n] = 0.0f;
+        for (int64_t n = 0; n < len; ++n) taps[pre_pad + n] = static_cast<float>(h[n] / sum * static_cast<double>(u));
+        return FA_SUCCESS;
+    } catch (const std::bad_alloc &) {
+        return FA_ALLOCATION_FAILURE;
+    }
+}
+
+fa_status fa_resample_poly(fa_ctx *ctx, const float *x, int64_t frames, int32_t up, int32_t down, float *out, int64_t out_capacity,
+                           int64_t *out_frames) {
+    if (!ctx || !out_frames) return FA_INVALID_ARGUMENT;
+    *out_frames = 0;
+    if (frames < 0 || up < 1 || down < 1) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "resample_poly: bad arguments");
+    const int64_t g = gcd64(up, down);
+    const int u = static_cast<int>(up / g), dn = static_cast<int>(down / g);
+    const int64_t n_out = fa_resample_poly_frames(frames, up, down);
+    if (n_out > out_capacity) return fa::set_error(ctx, FA_OUTPUT_TOO_SMALL, "resample_poly: output buffer too small");
+    *out_frames = n_out;
+    if (frames == 0) return FA_SUCCESS;
+    if (!x || !out) return FA_INVALID_ARGUMENT;
+    try {
+        int64_t n_taps = 0, pre_remove = 0;
+        FA_TRY(fa_resample_poly_taps(u, dn, nullptr, 0, &n_taps, &pre_remove));
+        std::vector<float> taps(n_taps);
+        FA_TRY(fa_resample_poly_taps(u, dn, taps.data(), n_taps, &n_taps, &pre_remove));
+        fa::DeviceGuard guard(ctx->device);
+        fa::DevBuf d_x, d_h, d_y;
+        hipError_t e;
+        do {
+            if ((e = d_x.alloc(sizeof(float) * frames)) != hipSuccess) break;
+            if ((e = d_h.alloc(sizeof(float) * n_taps)) != hipSuccess) break;
+            if ((e = d_y.alloc(sizeof(float) * n_out)) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(d_x.p, x, sizeof(float) * frames, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(d_h.p, taps.data(), sizeof(float) * n_taps, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+            hipLaunchKernelGGL(poly_kernel, dim3(static_cast<unsigned>((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
+                               d_x.as<float>(), d_h.as<float>(), d_y.as<float>(), frames, n_out, n_taps, u, dn, pre_remove);
+            if ((e = hipGetLastError()) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(out, d_y.p, sizeof(float) * n_out, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+            e = hipStreamSynchronize(ctx->stream);
+        } while (0);
+        return fa::hip_status(ctx, e, "fa_resample_poly");
+    } catch (const std::bad_alloc &) {
+        return FA_ALLOCATION_FAILURE;
+    } catch (...) {
+        return FA_UNKNOWN_ERROR;
+    }
+}
+
+}  // extern "C"

@@ -182,6 +182,31 @@ fa_status fa_vbx_refine(fa_ctx *ctx, const double *rho, int64_t T, int32_t D, co
                         double *gamma, double *pi, int32_t *hard, double *elbos, int32_t *n_iters,
                         int32_t *n_speakers);
 
+/* ------------------------------------------------------------------ post-VBx -------- */
+/* OfflineDiarizerManager.computeCentroids (FluidAudio/Diarizer/Offline/Core/OfflineDiarizerManager.swift:613-691) and
+ * assignEmbeddings (:789-822).  HOST pointers, fp64.
+ * emb: double[n*d]; gamma: double[n*S]; pi: double[S].  Speakers with pi > 1e-7 are kept: map[s] = row of `centroids`
+ * (or -1), *n_centroids = number kept; centroids must hold S*d doubles.  Summation order = the reference's. */
+fa_status fa_vbx_weighted_centroids(fa_ctx *ctx, const double *emb, int64_t n, int32_t d, const double *gamma,
+                                    const double *pi, int32_t S, double *centroids, int32_t *map, int32_t *n_centroids);
+/* out[i] = argmax_k cosine(emb_i, centroid_k), first maximum; K == 0 -> all 0 (:795-797). */
+fa_status fa_assign_cosine(fa_ctx *ctx, const double *emb, int64_t n, int32_t d, const double *centroids, int32_t K,
+                           int32_t *out);
+
+/* ------------------------------------------------------------------ resampling ------ */
+/* AudioConverter.linearResample (FluidAudio/Shared/AudioConverter.swift:388-442): planar float[channels][frames] ->
+ * mono mix (weight 1/channels) -> linear interpolation to out_rate.  HOST pointers.  Bit-exact restatement. */
+int64_t fa_resample_linear_frames(int64_t frames, double in_rate, double out_rate);
+fa_status fa_resample_linear(fa_ctx *ctx, const float *planar, int32_t channels, int64_t frames, double in_rate,
+                             double out_rate, float *out, int64_t out_capacity, int64_t *out_frames);
+/* EXTENSION (parity unpinned: the reference delegates to Apple's closed-source AVAudioConverter, :299-370):
+ * rational polyphase FIR resampler, Kaiser(5.0) windowed sinc, half length 10*max(up,down), output length
+ * ceil(frames*up/down) — the specification of scipy.signal.resample_poly.  up/down are reduced by their gcd. */
+int64_t fa_resample_poly_frames(int64_t frames, int32_t up, int32_t down);
+fa_status fa_resample_poly_taps(int32_t up, int32_t down, float *taps, int64_t capacity, int64_t *n_taps, int64_t *pre_remove);
+fa_status fa_resample_poly(fa_ctx *ctx, const float *x, int64_t frames, int32_t up, int32_t down, float *out,
+                           int64_t out_capacity, int64_t *out_frames);
+
 #ifdef __cplusplus
 }
 #endif

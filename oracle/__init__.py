@@ -21,7 +21,9 @@ _REF_PATH = os.path.join(_HERE, "_ref", "libfastcluster_ref.so")
 
 def build(force: bool = False) -> None:
     """Compile the C restatement and (when /root/reference exists) oracle/_ref."""
-    if force or not os.path.exists(_LIB_PATH) or not os.path.exists(_REF_PATH):
+    stale = os.path.exists(_LIB_PATH) and os.path.getmtime(_LIB_PATH) < max(
+        os.path.getmtime(os.path.join(_HERE, f)) for f in ("fa_oracle.c", "fa_oracle.h"))
+    if force or stale or not os.path.exists(_LIB_PATH) or not os.path.exists(_REF_PATH):
         subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
 
 
@@ -96,6 +98,10 @@ def lib() -> C.CDLL:
         L.fa_oracle_weighted_centroids.argtypes = [_f64p, C.c_long, C.c_long, _f64p, _f64p, C.c_long, _f64p, _i32p]
         L.fa_oracle_weighted_centroids.restype = C.c_long
         L.fa_oracle_assign_cosine.argtypes = [_f64p, C.c_long, C.c_long, _f64p, C.c_long, _i32p]
+        L.fa_oracle_resample_linear_frames.argtypes = [C.c_long, C.c_double, C.c_double]
+        L.fa_oracle_resample_linear_frames.restype = C.c_long
+        L.fa_oracle_resample_linear.argtypes = [_f32p, C.c_int, C.c_long, C.c_double, C.c_double, _f32p]
+        L.fa_oracle_resample_linear.restype = C.c_long
     return _lib
 
 
@@ -307,3 +313,15 @@ def assign_cosine(emb, centroids):
     lib().fa_oracle_assign_cosine(emb, emb.shape[0], emb.shape[1], centroids if centroids.size else np.zeros((1, 1)),
                                   centroids.shape[0], out)
     return out
+
+
+def resample_linear(channel_data, sample_rate: float, target_rate: float = 16000.0) -> np.ndarray:
+    """AudioConverter.linearResample (AudioConverter.swift:388-442) on planar [channels, frames] float32."""
+    x = np.ascontiguousarray(channel_data, np.float32)
+    if x.ndim == 1:
+        x = x[None, :]
+    ch, frames = x.shape
+    n = lib().fa_oracle_resample_linear_frames(frames, float(sample_rate), float(target_rate))
+    out = np.zeros(max(n, 1), np.float32)
+    got = lib().fa_oracle_resample_linear(x, ch, frames, float(sample_rate), float(target_rate), out)
+    return out[:got]

@@ -691,3 +691,40 @@ void fa_oracle_assign_cosine(const double *emb, long n, long d, const double *ce
     }
     free(cn); free(e);
 }
+
+/* ================================ resampling ================================== */
+
+/* AudioConverter.swift:420 */
+long fa_oracle_resample_linear_frames(long frames, double in_rate, double out_rate) {
+    if (in_rate == out_rate) return frames;
+    return (long)((double)frames / (in_rate / out_rate));
+}
+
+/* AudioConverter.linearResample (AudioConverter.swift:388-442): planar [channels][frames] -> mono -> linear interpolation */
+long fa_oracle_resample_linear(const float *planar, int channels, long frames, double in_rate, double out_rate, float *out) {
+    float *mono = (float *)malloc(sizeof(float) * (size_t)(frames > 0 ? frames : 1));
+    const float weight = 1.0f / (float)channels;                       /* :400 */
+    for (long f = 0; f < frames; ++f) {
+        float sum = 0.0f;
+        for (int c = 0; c < channels; ++c) sum += planar[(size_t)c * frames + f];
+        mono[f] = sum * weight;                                         /* :402-408 */
+    }
+    if (in_rate == out_rate) {                                          /* :414-416 */
+        memcpy(out, mono, sizeof(float) * (size_t)frames);
+        free(mono);
+        return frames;
+    }
+    const double ratio = in_rate / out_rate;                            /* :419 */
+    const long n_out = (long)((double)frames / ratio);                  /* :420 */
+    for (long i = 0; i < n_out; ++i) {
+        const double src = (double)i * ratio;
+        const long idx = (long)src;
+        const float frac = (float)(src - (double)idx);
+        float v = 0.0f;
+        if (idx < frames - 1) v = mono[idx] * (1.0f - frac) + mono[idx + 1] * frac;   /* :428-430 */
+        else if (idx < frames) v = mono[idx];                                           /* :431-432 */
+        out[i] = v;
+    }
+    free(mono);
+    return n_out;
+}

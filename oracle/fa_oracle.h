@@ -144,6 +144,10 @@ long fa_oracle_weighted_centroids(const double *emb, long n, long d, const doubl
 void fa_oracle_assign_cosine(const double *emb, long n, long d, const double *centroids, long K,
                              int32_t *out);
 
+/* AudioConverter.linearResample (FluidAudio/Shared/AudioConverter.swift:388-442) */
+long fa_oracle_resample_linear_frames(long frames, double in_rate, double out_rate);
+long fa_oracle_resample_linear(const float *planar, int channels, long frames, double in_rate, double out_rate, float *out);
+
 #ifdef __cplusplus
 }
 #endif

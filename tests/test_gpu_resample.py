@@ -1,0 +1,36 @@
+"""Resampling kernels: AudioConverter.linearResample bit-exact vs the oracle; polyphase extension vs scipy."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ch,frames,rate", [(3, 24000, 48000), (4, 4000, 16000), (5, 800, 8000), (6, 8820, 44100),
+                                            (8, 48000, 48000), (3, 1, 48000), (32, 1600, 16000), (3, 40, 4000), (1, 12345, 22050)])
+def test_linear_bit_exact(fa, gpu_ctx, oracle_mod, ch, frames, rate):
+    x = np.random.default_rng(frames + ch).uniform(-1, 1, (ch, frames)).astype(np.float32)
+    ref = oracle_mod.resample_linear(x, rate)
+    got = fa.linear_resample(x, rate, ctx=gpu_ctx)
+    assert got.size == ref.size
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_linear_reference_known_answers(fa, gpu_ctx):   # AudioConverterTests.swift:571-597, :731-761
+    x = np.empty((4, 4000), np.float32)
+    x[0], x[1], x[2], x[3] = 0.4, 0.8, -0.4, -0.8
+    y = fa.linear_resample(x, 16000, ctx=gpu_ctx)
+    assert y.size == 4000 and np.all(np.abs(y) <= 0.001)
+    y = fa.linear_resample(np.tile(np.arange(40, dtype=np.float32), (3, 1)), 4000, ctx=gpu_ctx)
+    np.testing.assert_array_equal(y[:157], (np.arange(157) * 0.25).astype(np.float32))
+
+
+@pytest.mark.parametrize("up,down,n", [(1, 3, 48000), (160, 441, 44100), (2, 1, 8000), (1, 1, 1000), (3, 2, 777)])
+def test_polyphase_extension_vs_scipy(fa, gpu_ctx, up, down, n):
+    from scipy import signal
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / 16000.0
+    x = (0.5 * np.sin(2 * np.pi * 300 * t) + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    ref = signal.resample_poly(x.astype(np.float64), up, down, window=("kaiser", 5.0))
+    got = fa.resample_poly(x, up, down, ctx=gpu_ctx)
+    assert got.size == ref.size
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
