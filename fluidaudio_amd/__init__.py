@@ -7,8 +7,9 @@ from ._lib import (AHC_MODE_AUTO, AHC_MODE_EXACT, Context, FluidAudioHipError, b
 from .ahc import AHCClustering, cut, fastcluster_compute_centroid_linkage, linkage  # noqa: F401
 from .ctc import (LogitsArgmax, ctc_greedy_decode, ctc_greedy_ids_batch, ctc_greedy_ids_dev,  # noqa: F401
                   decode_ctc_token_ids)
-from .mel import AudioMelSpectrogram, MelPlan  # noqa: F401
-from .post import assign_embeddings, compute_centroids  # noqa: F401
+from .mel import AudioMelSpectrogram, MelPlan, UnifiedMelExtractor  # noqa: F401
+from .post import (ConstrainedClusterAssignment, HungarianAssignment, assign_embeddings, centroid_scores,  # noqa: F401
+                   compute_centroids)
 from .resample import linear_resample, poly_taps, resample_poly  # noqa: F401
 from .sharding import gather_ragged_int32, shard_offsets, shard_range  # noqa: F401
 from .vbx import VBxClustering, VBxOutput  # noqa: F401

@@ -28,11 +28,11 @@ EXPORTED_SYMBOLS = [
     "fa_version", "fa_ctx_create", "fa_ctx_destroy", "fa_ctx_synchronize", "fa_ctx_stream", "fa_ctx_last_error",
     "fa_mel_default_config", "fa_mel_num_frames", "fa_mel_padded_frames", "fa_mel_plan_create", "fa_mel_plan_destroy",
     "fa_mel_plan_utt_stride", "fa_mel_plan_frame_stride", "fa_mel_plan_total_frames", "fa_mel_execute_dev",
-    "fa_mel_batch", "fa_mel_hann_window", "fa_mel_filterbank",
+    "fa_mel_batch", "fa_mel_hann_window", "fa_mel_filterbank", "fa_mel_normalize_per_feature_dev",
     "fa_ctc_greedy_batch_dev", "fa_ctc_greedy_batch",
     "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_cluster", "fa_ahc_cut",
     "fa_vbx_speaker_count", "fa_vbx_refine",
-    "fa_vbx_weighted_centroids", "fa_assign_cosine",
+    "fa_vbx_weighted_centroids", "fa_assign_cosine", "fa_centroid_scores", "fa_constrained_assign",
     "fa_resample_linear_frames", "fa_resample_linear", "fa_resample_poly_frames", "fa_resample_poly_taps", "fa_resample_poly",
 ]
 
@@ -107,6 +107,7 @@ def lib() -> C.CDLL:
     L.fa_mel_execute_dev.argtypes = [vp, vp, vp, vp, vp]
     L.fa_mel_batch.argtypes = [vp, C.POINTER(MelConfig), vp, vp, i32, vp, vp, i32, vp, vp]
     L.fa_mel_hann_window.argtypes = [C.POINTER(MelConfig), vp]
+    L.fa_mel_normalize_per_feature_dev.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.fa_mel_filterbank.argtypes = [C.POINTER(MelConfig), vp]
     L.fa_ctc_greedy_batch_dev.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, vp, i32, vp, vp, vp]
     L.fa_ctc_greedy_batch.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, vp, i32, vp, vp, vp]
@@ -120,6 +121,8 @@ def lib() -> C.CDLL:
     L.fa_vbx_refine.argtypes = [vp, vp, i64, i32, vp, vp, f64, f64, i32, f64, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.fa_vbx_weighted_centroids.argtypes = [vp, vp, i64, i32, vp, vp, i32, vp, vp, C.POINTER(i32)]
     L.fa_assign_cosine.argtypes = [vp, vp, i64, i32, vp, i32, vp]
+    L.fa_centroid_scores.argtypes = [vp, vp, i64, i32, vp, i32, vp]
+    L.fa_constrained_assign.argtypes = [vp, vp, i64, i32, vp, vp]
     L.fa_resample_linear_frames.argtypes = [i64, f64, f64]
     L.fa_resample_linear_frames.restype = i64
     L.fa_resample_linear.argtypes = [vp, vp, i32, i64, f64, f64, vp, i64, C.POINTER(i64)]

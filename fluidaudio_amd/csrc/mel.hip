@@ -300,6 +300,36 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
     }
 }
 
+// NeMo per_feature normalisation as done by UnifiedMelExtractor.normalizePerFeature
+// (reference: Sources/FluidAudio/ASR/Parakeet/Unified/UnifiedMelExtractor.swift:91-113): for every mel bin subtract the
+// mean and divide by the unbiased std (+1e-5) over the valid frames; frames >= valid become 0; valid == 0 zeroes the row.
+// One wavefront per (utterance, mel) row of a [B][n_mels][frame_stride] tensor; the row (<= a few KB) stays in L2.
+__global__ __launch_bounds__(256) void mel_norm_kernel(float *__restrict__ mel, const int32_t *__restrict__ valid_frames, int64_t rows,
+                                                         int32_t n_mels, int32_t frame_stride, int32_t frames) {
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int b = static_cast<int>(row / n_mels);
+    int valid = valid_frames[b];
+    valid = valid < 0 ? 0 : (valid > frames ? frames : valid);
+    float *x = mel + row * frame_stride;
+    float mean = 0.0f, inv_std = 0.0f;
+    if (valid > 0) {
+        float sum = 0.0f;
+        for (int t = lane; t < valid; t += 64) sum += x[t];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        mean = sum / static_cast<float>(valid);
+        float var = 0.0f;
+        for (int t = lane; t < valid; t += 64) { const float dlt = x[t] - mean; var += dlt * dlt; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off);
+        const float denom = static_cast<float>(valid > 1 ? valid - 1 : 1);
+        inv_std = 1.0f / (sqrtf(var / denom) + 1e-5f);
+    }
+    for (int t = lane; t < frames; t += 64) x[t] = t < valid ? (x[t] - mean) * inv_std : 0.0f;
+}
+
 // ----------------------------------------------------------------------------- host tables
 // createHannWindow (:553-562)
 void make_hann(int win, bool periodic, std::vector<float> &w) {
@@ -575,6 +605,19 @@ fa_status fa_mel_execute_dev(fa_mel_plan *p, const float *d_pcm, const float *d_
     else if (mm) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, false>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
     else if (p->fast) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, true>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
     else hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, false>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+
+fa_status fa_mel_normalize_per_feature_dev(fa_ctx *ctx, float *d_mel, int32_t batch, int32_t n_mels, int32_t frame_stride,
+                                           int32_t frames, const int32_t *d_valid_frames) {
+    if (!ctx || !d_mel || !d_valid_frames) return FA_INVALID_ARGUMENT;
+    if (batch < 0 || n_mels < 1 || frames < 0 || frame_stride < frames) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel normalise: bad shape");
+    if (batch == 0 || frames == 0) return FA_SUCCESS;
+    fa::DeviceGuard guard(ctx->device);
+    const int64_t rows = static_cast<int64_t>(batch) * n_mels;
+    hipLaunchKernelGGL(mel_norm_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, ctx->stream, d_mel, d_valid_frames, rows,
+                       n_mels, frame_stride, frames);
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }

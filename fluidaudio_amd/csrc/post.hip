@@ -7,6 +7,8 @@
 // (sequential in t for the centroid sums, sequential in the dimension for norms and dot products) and are therefore
 // bit-identical to the CPU restatement, not just close: one thread owns one output element and walks the reduction
 // axis; the loads of different iterations are independent, so they pipeline.
+#include <algorithm>
+#include <climits>
 #include <cmath>
 #include <vector>
 
@@ -66,6 +68,124 @@ __global__ void assign_kernel(const double *__restrict__ emb, const double *__re
         if (dot > best) { best = dot; bi = c; }
     }
     out[i] = bi;
+}
+
+// centroidScores (:789-798): scores[i][k] = <normalised e_i, normalised c_k>, same arithmetic as assign_kernel
+__global__ void scores_kernel(const double *__restrict__ emb, const double *__restrict__ cn, double *__restrict__ scores, int64_t n, int d,
+                              int K) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *x = emb + i * d;
+    double ss = 0.0;
+    for (int k = 0; k < d; ++k) ss = __dadd_rn(ss, __dmul_rn(x[k], x[k]));
+    const double scale = ss <= 0 ? 1.0 : __ddiv_rn(1.0, __dsqrt_rn(ss));
+    const bool keep = ss <= 0;
+    for (int c = 0; c < K; ++c) {
+        const double *cv = cn + static_cast<int64_t>(c) * d;
+        double dot = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double e = keep ? x[k] : __dmul_rn(x[k], scale);
+            dot = __dadd_rn(dot, __dmul_rn(e, cv[k]));
+        }
+        scores[i * K + c] = dot;
+    }
+}
+
+// ConstrainedClusterAssignment.assign (reference: Sources/FluidAudio/Diarizer/Offline/Clustering/ConstrainedClusterAssignment.swift:20-42)
+// = per segmentation chunk, HungarianAssignment.maxScoreAssignment (Sources/FluidAudio/Diarizer/HungarianAssignment.swift:67-97)
+// over the chunk's rows, solved by Kuhn-Munkres with potentials on integer costs (:8-62).  One wavefront per chunk; the
+// potentials / matching / slack arrays (n + 1 <= 257 entries) live in the wavefront's LDS slice and the inner loops over
+// columns j run across the lanes.  Every comparison is on the reference's integers, so assignments are identical.
+constexpr int kHungMaxN = 256;
+constexpr long long kHungInf = 0x7fffffffffffffffLL / 4;  // Int.max / 4 (:14)
+
+struct HungLds {
+    long long u[kHungMaxN + 1], v[kHungMaxN + 1], minv[kHungMaxN + 1];
+    int p[kHungMaxN + 1], way[kHungMaxN + 1];
+    unsigned char used[kHungMaxN + 1];
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void hungarian_kernel(const double *__restrict__ scores, const int32_t *__restrict__ chunk_start,
+                                                          const int32_t *__restrict__ row_ids, int32_t *__restrict__ out, int n_chunks, int K) {
+    __shared__ HungLds lds[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.x * 4 + wave;
+    if (chunk >= n_chunks) return;
+    HungLds &h = lds[wave];
+    const int r0 = chunk_start[chunk], R = chunk_start[chunk + 1] - r0;
+    const int32_t *rows = row_ids + r0;
+    if (K <= 0) { for (int r = lane; r < R; r += 64) out[rows[r]] = -2; return; }  // no columns: every row unassigned (:71)
+    const int n = R > K ? R : K;
+    // finite range of the chunk's scores (:73-76)
+    double mx = -INFINITY, mn = INFINITY;
+    for (int e = lane; e < R * K; e += 64) {
+        const double sc = scores[static_cast<int64_t>(rows[e / K]) * K + e % K];
+        if (isfinite(sc)) { mx = sc > mx ? sc : mx; mn = sc < mn ? sc : mn; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double omx = __shfl_xor(mx, off), omn = __shfl_xor(mn, off);
+        mx = omx > mx ? omx : mx; mn = omn < mn ? omn : mn;
+    }
+    const double max_score = mx == -INFINITY ? 0.0 : mx, min_score = mn == INFINITY ? 0.0 : mn;
+    const double sentinel = min_score - 1.0;
+    auto cost = [&](const int r, const int c) -> long long {  // (:84-90) padding cells cost 0
+        if (r >= R || c >= K) return 0;
+        double sc = scores[static_cast<int64_t>(rows[r]) * K + c];
+        if (!isfinite(sc)) sc = sentinel;
+        return static_cast<long long>(round((max_score - sc) * 1e6));
+    };
+    for (int j = lane; j <= n; j += 64) { h.u[j] = 0; h.v[j] = 0; h.p[j] = 0; h.way[j] = 0; }
+    wave_sync();
+    for (int i = 1; i <= n; ++i) {
+        for (int j = lane; j <= n; j += 64) { h.minv[j] = kHungInf; h.used[j] = 0; }
+        if (lane == 0) h.p[0] = i;
+        wave_sync();
+        int j0 = 0;
+        do {
+            if (lane == 0) h.used[j0] = 1;
+            wave_sync();
+            const int i0 = h.p[j0];
+            const long long ui0 = h.u[i0];
+            long long delta = kHungInf;
+            int j1 = 0x7fffffff;
+            for (int j = 1 + lane; j <= n; j += 64) {
+                if (h.used[j]) continue;
+                const long long cur = cost(i0 - 1, j - 1) - ui0 - h.v[j];
+                if (cur < h.minv[j]) { h.minv[j] = cur; h.way[j] = j0; }
+                const long long mv = h.minv[j];
+                if (mv < delta) { delta = mv; j1 = j; }  // ascending j per lane: first minimum kept (:36-39)
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const long long od = __shfl_xor(delta, off);
+                const int oj = __shfl_xor(j1, off);
+                if (od < delta || (od == delta && oj < j1)) { delta = od; j1 = oj; }
+            }
+            if (j1 == 0x7fffffff) j1 = 0;  // cannot happen for n >= 1 (some column is always unused here)
+            wave_sync();
+            for (int j = lane; j <= n; j += 64) {
+                if (h.used[j]) { h.u[h.p[j]] += delta; h.v[j] -= delta; }  // p is injective on the used columns
+                else h.minv[j] -= delta;
+            }
+            wave_sync();
+            j0 = j1;
+        } while (h.p[j0] != 0);
+        if (lane == 0) {
+            do { const int j1 = h.way[j0]; h.p[j0] = h.p[j1]; j0 = j1; } while (j0 != 0);
+        }
+        wave_sync();
+    }
+    for (int j = 1 + lane; j <= n; j += 64) {
+        const int r = h.p[j] - 1;
+        if (r >= 0 && r < R) out[rows[r]] = j - 1 < K ? j - 1 : -2;  // dropped slot (:93-96, ConstrainedClusterAssignment.swift:37)
+    }
 }
 
 }  // namespace
@@ -136,6 +256,74 @@ fa_status fa_assign_cosine(fa_ctx *ctx, const double *emb, int64_t n, int32_t d,
         e = hipStreamSynchronize(ctx->stream);
     } while (0);
     return fa::hip_status(ctx, e, "fa_assign_cosine");
+}
+
+fa_status fa_centroid_scores(fa_ctx *ctx, const double *emb, int64_t n, int32_t d, const double *centroids, int32_t K, double *scores) {
+    if (!ctx) return FA_INVALID_ARGUMENT;
+    if (n == 0 || K == 0) return FA_SUCCESS;
+    if (n < 0 || d < 1 || K < 0 || !emb || !centroids || !scores) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "scores: bad arguments");
+    fa::DeviceGuard guard(ctx->device);
+    fa::DevBuf d_emb, d_c, d_cn, d_s;
+    hipError_t e;
+    do {
+        if ((e = d_emb.alloc(sizeof(double) * n * d)) != hipSuccess) break;
+        if ((e = d_c.alloc(sizeof(double) * K * d)) != hipSuccess) break;
+        if ((e = d_cn.alloc(sizeof(double) * K * d)) != hipSuccess) break;
+        if ((e = d_s.alloc(sizeof(double) * n * K)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d_emb.p, emb, sizeof(double) * n * d, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d_c.p, centroids, sizeof(double) * K * d, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        hipLaunchKernelGGL(normalize_rows, dim3((K + 63) / 64), dim3(64), 0, ctx->stream, d_c.as<double>(), d_cn.as<double>(), static_cast<int64_t>(K), d);
+        hipLaunchKernelGGL(scores_kernel, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
+                           d_emb.as<double>(), d_cn.as<double>(), d_s.as<double>(), n, d, K);
+        if ((e = hipGetLastError()) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(scores, d_s.p, sizeof(double) * n * K, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    return fa::hip_status(ctx, e, "fa_centroid_scores");
+}
+
+fa_status fa_constrained_assign(fa_ctx *ctx, const double *scores, int64_t n, int32_t K, const int32_t *chunk_indices, int32_t *out) {
+    if (!ctx) return FA_INVALID_ARGUMENT;
+    if (n == 0) return FA_SUCCESS;
+    if (n < 0 || n > INT32_MAX || K < 0 || !chunk_indices || !out || (K > 0 && !scores)) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "constrained assign: bad arguments");
+    try {
+        // rows grouped by chunk, ascending row order inside a chunk (rowsByChunk[chunk].append(row), :27-30)
+        std::vector<int32_t> order(static_cast<size_t>(n));
+        for (int64_t i = 0; i < n; ++i) order[i] = static_cast<int32_t>(i);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return chunk_indices[a] < chunk_indices[b]; });
+        std::vector<int32_t> starts;
+        int max_rows = 0;
+        for (int64_t i = 0; i < n; ++i)
+            if (i == 0 || chunk_indices[order[i]] != chunk_indices[order[i - 1]]) starts.push_back(static_cast<int32_t>(i));
+        starts.push_back(static_cast<int32_t>(n));
+        const int n_chunks = static_cast<int>(starts.size()) - 1;
+        for (int c = 0; c < n_chunks; ++c) max_rows = std::max(max_rows, starts[c + 1] - starts[c]);
+        if (std::max(max_rows, static_cast<int>(K)) > kHungMaxN)
+            return fa::set_error(ctx, FA_RUNTIME_ERROR, "constrained assign: more than %d rows per chunk or clusters", kHungMaxN);
+        fa::DeviceGuard guard(ctx->device);
+        fa::DevBuf d_s, d_start, d_rows, d_out;
+        hipError_t e;
+        do {
+            if ((e = d_s.alloc(sizeof(double) * n * (K > 0 ? K : 1))) != hipSuccess) break;
+            if ((e = d_start.alloc(sizeof(int32_t) * starts.size())) != hipSuccess) break;
+            if ((e = d_rows.alloc(sizeof(int32_t) * n)) != hipSuccess) break;
+            if ((e = d_out.alloc(sizeof(int32_t) * n)) != hipSuccess) break;
+            if (K > 0 && (e = hipMemcpyAsync(d_s.p, scores, sizeof(double) * n * K, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(d_start.p, starts.data(), sizeof(int32_t) * starts.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(d_rows.p, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+            if ((e = hipMemsetAsync(d_out.p, 0xfe, sizeof(int32_t) * n, ctx->stream)) != hipSuccess) break;  // placeholder, every row is written
+            hipLaunchKernelGGL(hungarian_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, ctx->stream, d_s.as<double>(), d_start.as<int32_t>(),
+                               d_rows.as<int32_t>(), d_out.as<int32_t>(), n_chunks, K);
+            if ((e = hipGetLastError()) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(out, d_out.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+            e = hipStreamSynchronize(ctx->stream);
+        } while (0);
+        return fa::hip_status(ctx, e, "fa_constrained_assign");
+    } catch (const std::bad_alloc &) {
+        return FA_ALLOCATION_FAILURE;
+    } catch (...) {
+        return FA_UNKNOWN_ERROR;
+    }
 }
 
 }  // extern "C"

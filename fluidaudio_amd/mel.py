@@ -127,3 +127,46 @@ class AudioMelSpectrogram:
               "legacy": L.MEL_PAD_LEGACY}[padding_mode]
         lay = L.MEL_LAYOUT_MEL_MAJOR if layout == "mel_major" else L.MEL_LAYOUT_FRAME_MAJOR
         return MelPlan(self.ctx, self.config(pm, lay), offsets, expected_frames, frame_stride)
+
+
+class UnifiedMelExtractor:
+    """Mirror of ``UnifiedMelExtractor`` (reference: Sources/FluidAudio/ASR/Parakeet/Unified/UnifiedMelExtractor.swift:26-113):
+    NeMo-config log-mel of one zero-padded encoder window + per-feature normalisation over the valid frames, returned
+    as ``[1, n_mels, totalFrames]`` + the valid frame count.  ``features_batch`` is the device-resident batched form
+    (B windows of equal length in one launch pair) the reference does not have."""
+
+    hop_length = 160
+
+    def __init__(self, window_samples: int, n_mels: int = 128, ctx: L.Context | None = None):
+        self.window_samples, self.n_mels = window_samples, n_mels
+        self.total_frames = window_samples // self.hop_length + 1          # :29
+        self.mel = AudioMelSpectrogram(sample_rate=16000, n_mels=n_mels, n_fft=512, hop_length=160, win_length=400,
+                                       preemph=0.97, pad_to=0, window_periodic=False, ctx=ctx)
+
+    def features_batch(self, d_windows, valid_counts):
+        """d_windows: torch CUDA float32 [B, window_samples]; valid_counts: int sequence.  Returns (mel CUDA tensor
+        [B, n_mels, totalFrames], valid frames int32 numpy [B])."""
+        import torch
+        B = d_windows.shape[0]
+        offs = np.arange(B + 1, dtype=np.int64) * self.window_samples
+        plan = self.mel.plan(offs, layout="mel_major", expected_frames=np.full(B, self.total_frames, np.int32),
+                             frame_stride=self.total_frames)
+        d_mel = torch.empty((B, self.n_mels, self.total_frames), dtype=torch.float32, device=d_windows.device)
+        d_len = torch.empty(B, dtype=torch.int32, device=d_windows.device)
+        plan.execute(d_windows.contiguous().view(-1), d_mel, d_len)
+        valid = np.minimum(np.asarray(valid_counts, np.int64) // self.hop_length, self.total_frames).astype(np.int32)   # :66
+        d_valid = torch.from_numpy(valid).to(d_windows.device)
+        ctx = self.mel.ctx
+        ctx.check(L.lib().fa_mel_normalize_per_feature_dev(ctx.handle, _ptr(d_mel), B, self.n_mels, self.total_frames,
+                                                           self.total_frames, _ptr(d_valid)), "fa_mel_normalize_per_feature_dev")
+        ctx.synchronize()
+        plan.close()
+        return d_mel, valid
+
+    def features(self, window, valid_count: int):
+        """features(window:validCount:) (:52-90) -> (mel [1, n_mels, totalFrames] float32 numpy, valid frames)."""
+        import torch
+        w = np.ascontiguousarray(window, np.float32).reshape(1, -1)
+        assert w.shape[1] == self.window_samples
+        d_mel, valid = self.features_batch(torch.from_numpy(w).cuda(self.mel.ctx.device), [valid_count])
+        return d_mel.cpu().numpy(), int(valid[0])

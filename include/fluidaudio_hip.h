@@ -110,6 +110,14 @@ fa_status fa_mel_batch(fa_ctx *ctx, const fa_mel_config *cfg, const float *pcm, 
                        int32_t batch, const float *last_samples, const int32_t *expected_frames,
                        int32_t frame_stride, float *mel, int32_t *mel_lengths);
 
+/* NeMo per_feature normalisation as applied by UnifiedMelExtractor.normalizePerFeature
+ * (FluidAudio/ASR/Parakeet/Unified/UnifiedMelExtractor.swift:91-113), in place on a MEL_MAJOR tensor
+ * d_mel[batch][n_mels][frame_stride]: per (utterance, mel) row, over the first valid_frames[b] frames, subtract the mean
+ * and divide by (unbiased std + 1e-5); frames valid..frames-1 become 0.  valid_frames[b] = min(validCount / hop, T) is
+ * the caller's (:66). */
+fa_status fa_mel_normalize_per_feature_dev(fa_ctx *ctx, float *d_mel, int32_t batch, int32_t n_mels, int32_t frame_stride,
+                                           int32_t frames, const int32_t *d_valid_frames);
+
 /* Host copies of the tables (createHannWindow :553-562, createMelFilterbank :564-642). */
 fa_status fa_mel_hann_window(const fa_mel_config *cfg, float *out /* win */);
 fa_status fa_mel_filterbank(const fa_mel_config *cfg, float *out /* n_mels * (n_fft/2+1) */);
@@ -192,6 +200,15 @@ fa_status fa_vbx_weighted_centroids(fa_ctx *ctx, const double *emb, int64_t n, i
 /* out[i] = argmax_k cosine(emb_i, centroid_k), first maximum; K == 0 -> all 0 (:795-797). */
 fa_status fa_assign_cosine(fa_ctx *ctx, const double *emb, int64_t n, int32_t d, const double *centroids, int32_t K,
                            int32_t *out);
+/* centroidScores (:789-798): scores[i*K + k] = cosine(emb_i, centroid_k). */
+fa_status fa_centroid_scores(fa_ctx *ctx, const double *emb, int64_t n, int32_t d, const double *centroids, int32_t K,
+                             double *scores);
+/* ConstrainedClusterAssignment.assign (FluidAudio/Diarizer/Offline/Clustering/ConstrainedClusterAssignment.swift:20-42):
+ * per chunk, HungarianAssignment.maxScoreAssignment (FluidAudio/Diarizer/HungarianAssignment.swift:67-97) — distinct
+ * local speakers of a chunk get distinct clusters, maximising the total score; -2 = slot dropped (more speakers than
+ * clusters).  scores: double[n*K]; chunk_indices: int32[n]; out: int32[n].  At most 256 rows per chunk / clusters. */
+fa_status fa_constrained_assign(fa_ctx *ctx, const double *scores, int64_t n, int32_t K, const int32_t *chunk_indices,
+                                int32_t *out);
 
 /* ------------------------------------------------------------------ resampling ------ */
 /* AudioConverter.linearResample (FluidAudio/Shared/AudioConverter.swift:388-442): planar float[channels][frames] ->

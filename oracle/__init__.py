@@ -98,6 +98,16 @@ def lib() -> C.CDLL:
         L.fa_oracle_weighted_centroids.argtypes = [_f64p, C.c_long, C.c_long, _f64p, _f64p, C.c_long, _f64p, _i32p]
         L.fa_oracle_weighted_centroids.restype = C.c_long
         L.fa_oracle_assign_cosine.argtypes = [_f64p, C.c_long, C.c_long, _f64p, C.c_long, _i32p]
+        L.fa_oracle_hungarian_solve.argtypes = [np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS"), C.c_int, _i32p]
+        L.fa_oracle_hungarian_solve.restype = None
+        L.fa_oracle_max_score_assignment.argtypes = [_f64p, C.c_int, C.c_int, _i32p]
+        L.fa_oracle_max_score_assignment.restype = None
+        L.fa_oracle_constrained_assign.argtypes = [_f64p, C.c_long, C.c_int, _i32p, _i32p]
+        L.fa_oracle_constrained_assign.restype = None
+        L.fa_oracle_centroid_scores.argtypes = [_f64p, C.c_long, C.c_long, _f64p, C.c_long, _f64p]
+        L.fa_oracle_centroid_scores.restype = None
+        L.fa_oracle_normalize_per_feature.argtypes = [_f32p, C.c_int, C.c_int, C.c_int]
+        L.fa_oracle_normalize_per_feature.restype = None
         L.fa_oracle_resample_linear_frames.argtypes = [C.c_long, C.c_double, C.c_double]
         L.fa_oracle_resample_linear_frames.restype = C.c_long
         L.fa_oracle_resample_linear.argtypes = [_f32p, C.c_int, C.c_long, C.c_double, C.c_double, _f32p]
@@ -325,3 +335,51 @@ def resample_linear(channel_data, sample_rate: float, target_rate: float = 16000
     out = np.zeros(max(n, 1), np.float32)
     got = lib().fa_oracle_resample_linear(x, ch, frames, float(sample_rate), float(target_rate), out)
     return out[:got]
+
+
+def unified_mel_features(window, valid_count: int, n_mels: int = 128):
+    """UnifiedMelExtractor.features (UnifiedMelExtractor.swift:52-90): (mel [n_mels, totalFrames], valid frames)."""
+    window = np.ascontiguousarray(window, np.float32)
+    total = window.size // 160 + 1
+    cfg = MelConfig(n_mels=n_mels)
+    flat, _, _ = mel_flat_transposed(window, cfg, 0.0, expected_frames=total)
+    flat = np.ascontiguousarray(flat.reshape(total, n_mels), np.float32)
+    valid = min(valid_count // 160, total)
+    lib().fa_oracle_normalize_per_feature(flat, n_mels, total, valid)
+    return np.ascontiguousarray(flat.T), valid
+
+
+def hungarian_solve(cost, n: int) -> np.ndarray:
+    out = np.zeros(max(n, 1), np.int32)
+    if n:
+        lib().fa_oracle_hungarian_solve(np.ascontiguousarray(cost, np.int64).reshape(-1), n, out)
+    return out[:n]
+
+
+def max_score_assignment(scores) -> np.ndarray:
+    rows = len(scores)
+    cols = len(scores[0]) if rows else 0
+    out = np.zeros(max(rows, 1), np.int32)
+    if rows:
+        sc = np.ascontiguousarray(scores, np.float64).reshape(rows, cols) if cols else np.zeros((rows, 1))
+        lib().fa_oracle_max_score_assignment(sc, rows, cols, out)
+    return out[:rows]
+
+
+def constrained_assign(scores, chunk_indices) -> np.ndarray:
+    sc = np.ascontiguousarray(scores, np.float64)
+    n = len(chunk_indices)
+    K = sc.shape[1] if sc.ndim == 2 else 0
+    out = np.zeros(max(n, 1), np.int32)
+    if n:
+        lib().fa_oracle_constrained_assign(sc if sc.size else np.zeros((1, 1)), n, K, np.ascontiguousarray(chunk_indices, np.int32), out)
+    return out[:n]
+
+
+def centroid_scores(emb, centroids) -> np.ndarray:
+    emb = np.ascontiguousarray(emb, np.float64)
+    cen = np.ascontiguousarray(centroids, np.float64)
+    out = np.zeros((emb.shape[0], cen.shape[0]), np.float64)
+    if out.size:
+        lib().fa_oracle_centroid_scores(emb, emb.shape[0], emb.shape[1], cen, cen.shape[0], out)
+    return out

@@ -728,3 +728,113 @@ long fa_oracle_resample_linear(const float *planar, int channels, long frames, d
     free(mono);
     return n_out;
 }
+
+/* UnifiedMelExtractor.normalizePerFeature (ASR/Parakeet/Unified/UnifiedMelExtractor.swift:91-113) on a time-major
+ * [frames][n_mels] buffer, in place */
+void fa_oracle_normalize_per_feature(float *x, int n_mels, int frames, int valid_frames) {
+    if (valid_frames <= 0) { for (long i = 0; i < (long)frames * n_mels; ++i) x[i] = 0.0f; return; }
+    const float denom = (float)(valid_frames > 1 ? valid_frames - 1 : 1);
+    for (int m = 0; m < n_mels; ++m) {
+        float mean = 0.0f;
+        for (int t = 0; t < valid_frames; ++t) mean += x[(long)t * n_mels + m];
+        mean /= (float)valid_frames;
+        float var_sum = 0.0f;
+        for (int t = 0; t < valid_frames; ++t) { const float d = x[(long)t * n_mels + m] - mean; var_sum += d * d; }
+        const float std = sqrtf(var_sum / denom) + 1e-5f;
+        for (int t = 0; t < frames; ++t) x[(long)t * n_mels + m] = t < valid_frames ? (x[(long)t * n_mels + m] - mean) / std : 0.0f;
+    }
+}
+
+/* ================================ constrained assignment ====================== */
+
+/* HungarianAssignment.solve (Diarizer/HungarianAssignment.swift:8-62): Kuhn-Munkres with potentials, 1-based arrays */
+void fa_oracle_hungarian_solve(const long long *cost, int n, int *assign) {
+    if (n == 0) return;
+    const long long INF = 0x7fffffffffffffffLL / 4;
+    long long *u = (long long *)calloc((size_t)n + 1, sizeof(long long)), *v = (long long *)calloc((size_t)n + 1, sizeof(long long));
+    long long *minv = (long long *)malloc(sizeof(long long) * ((size_t)n + 1));
+    int *p = (int *)calloc((size_t)n + 1, sizeof(int)), *way = (int *)calloc((size_t)n + 1, sizeof(int));
+    char *used = (char *)malloc((size_t)n + 1);
+    for (int i = 1; i <= n; ++i) {
+        p[0] = i;
+        int j0 = 0;
+        for (int j = 0; j <= n; ++j) { minv[j] = INF; used[j] = 0; }
+        do {
+            used[j0] = 1;
+            const int i0 = p[j0];
+            long long delta = INF;
+            int j1 = 0;
+            for (int j = 1; j <= n; ++j) {
+                if (used[j]) continue;
+                const long long cur = cost[(size_t)(i0 - 1) * n + (j - 1)] - u[i0] - v[j];
+                if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+                if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+            }
+            for (int j = 0; j <= n; ++j) {
+                if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+                else minv[j] -= delta;
+            }
+            j0 = j1;
+        } while (p[j0] != 0);
+        do { const int j1 = way[j0]; p[j0] = p[j1]; j0 = j1; } while (j0 != 0);
+    }
+    for (int r = 0; r < n; ++r) assign[r] = -1;
+    for (int j = 1; j <= n; ++j) if (p[j] != 0) assign[p[j] - 1] = j - 1;
+    free(u); free(v); free(minv); free(p); free(way); free(used);
+}
+
+/* HungarianAssignment.maxScoreAssignment (:67-97) on row-major scores[rows][cols] */
+void fa_oracle_max_score_assignment(const double *scores, int rows, int cols, int *assign) {
+    if (rows <= 0) return;
+    if (cols <= 0) { for (int r = 0; r < rows; ++r) assign[r] = -1; return; }
+    double mx = -INFINITY, mn = INFINITY;
+    for (long i = 0; i < (long)rows * cols; ++i) if (isfinite(scores[i])) { if (scores[i] > mx) mx = scores[i]; if (scores[i] < mn) mn = scores[i]; }
+    const double max_score = mx == -INFINITY ? 0.0 : mx, min_score = mn == INFINITY ? 0.0 : mn;
+    const double sentinel = min_score - 1.0;
+    const int n = rows > cols ? rows : cols;
+    long long *cost = (long long *)calloc((size_t)n * n, sizeof(long long));
+    int *full = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            const double sc = isfinite(scores[(long)r * cols + c]) ? scores[(long)r * cols + c] : sentinel;
+            cost[(size_t)r * n + c] = (long long)round((max_score - sc) * 1e6);
+        }
+    fa_oracle_hungarian_solve(cost, n, full);
+    for (int r = 0; r < rows; ++r) assign[r] = full[r] < cols ? full[r] : -1;
+    free(cost); free(full);
+}
+
+/* ConstrainedClusterAssignment.assign (Diarizer/Offline/Clustering/ConstrainedClusterAssignment.swift:20-42) */
+void fa_oracle_constrained_assign(const double *scores, long n, int K, const int32_t *chunk, int32_t *out) {
+    for (long i = 0; i < n; ++i) out[i] = -2;
+    char *done = (char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    long *rows = (long *)malloc(sizeof(long) * (size_t)(n > 0 ? n : 1));
+    for (long i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        long cnt = 0;
+        for (long j = i; j < n; ++j) if (!done[j] && chunk[j] == chunk[i]) { rows[cnt++] = j; done[j] = 1; }
+        double *cs = (double *)malloc(sizeof(double) * (size_t)cnt * (size_t)(K > 0 ? K : 1));
+        int *as = (int *)malloc(sizeof(int) * (size_t)cnt);
+        for (long r = 0; r < cnt; ++r) for (int c = 0; c < K; ++c) cs[r * K + c] = scores[rows[r] * K + c];
+        fa_oracle_max_score_assignment(cs, (int)cnt, K, as);
+        for (long r = 0; r < cnt; ++r) out[rows[r]] = as[r] >= 0 ? as[r] : -2;
+        free(cs); free(as);
+    }
+    free(done); free(rows);
+}
+
+/* centroidScores (OfflineDiarizerManager.swift:789-798) */
+void fa_oracle_centroid_scores(const double *emb, long n, long d, const double *centroids, long K, double *scores) {
+    double *cn = (double *)malloc(sizeof(double) * (size_t)(K > 0 ? K : 1) * (size_t)d);
+    double *e = (double *)malloc(sizeof(double) * (size_t)d);
+    for (long k = 0; k < K; ++k) normalize_vec(centroids + k * d, d, cn + k * d);
+    for (long i = 0; i < n; ++i) {
+        normalize_vec(emb + i * d, d, e);
+        for (long k = 0; k < K; ++k) {
+            double dot = 0.0;
+            for (long j = 0; j < d; ++j) dot += e[j] * cn[k * d + j];
+            scores[i * K + k] = dot;
+        }
+    }
+    free(cn); free(e);
+}

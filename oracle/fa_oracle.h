@@ -148,6 +148,17 @@ void fa_oracle_assign_cosine(const double *emb, long n, long d, const double *ce
 long fa_oracle_resample_linear_frames(long frames, double in_rate, double out_rate);
 long fa_oracle_resample_linear(const float *planar, int channels, long frames, double in_rate, double out_rate, float *out);
 
+/* UnifiedMelExtractor.normalizePerFeature (FluidAudio/ASR/Parakeet/Unified/UnifiedMelExtractor.swift:91-113) */
+void fa_oracle_normalize_per_feature(float *x_time_major, int n_mels, int frames, int valid_frames);
+
+/* HungarianAssignment (FluidAudio/Diarizer/HungarianAssignment.swift:8-97), ConstrainedClusterAssignment
+ * (FluidAudio/Diarizer/Offline/Clustering/ConstrainedClusterAssignment.swift:20-42), centroidScores
+ * (FluidAudio/Diarizer/Offline/Core/OfflineDiarizerManager.swift:789-798) */
+void fa_oracle_hungarian_solve(const long long *cost, int n, int *assign);
+void fa_oracle_max_score_assignment(const double *scores, int rows, int cols, int *assign);
+void fa_oracle_constrained_assign(const double *scores, long n, int K, const int32_t *chunk, int32_t *out);
+void fa_oracle_centroid_scores(const double *emb, long n, long d, const double *centroids, long K, double *scores);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,3 +174,30 @@ def test_full_size_config2_properties(fa, gpu_ctx, oracle_mod):
     strong = ref > -8.0  # bins where the 2^-24 floor is negligible
     np.testing.assert_allclose(shift[strong], 2 * np.log(2.0), atol=2e-3)
     plan.close()
+
+
+def test_unified_extractor_per_feature_normalisation(fa, gpu_ctx, oracle_mod):
+    """UnifiedMelExtractor.features (UnifiedMelExtractor.swift:52-113): NeMo per_feature normalisation over the valid
+    frames, pad frames zero, [1, n_mels, T] layout; batched form against per-window oracle results."""
+    import torch
+    ws = 16000 * 2
+    ex = fa.UnifiedMelExtractor(ws, ctx=gpu_ctx)
+    assert ex.total_frames == ws // 160 + 1
+    wins, valids = [], [ws, 12345, 160, 100, 0]
+    for i, v in enumerate(valids):
+        w = np.zeros(ws, np.float32)
+        w[:v] = synth_audio(v, 40 + i) if v else 0
+        wins.append(w)
+    d_mel, vf = ex.features_batch(torch.from_numpy(np.stack(wins)).cuda(), valids)
+    got = d_mel.cpu().numpy()
+    for i, v in enumerate(valids):
+        ref, rv = oracle_mod.unified_mel_features(wins[i], v)
+        assert vf[i] == rv == min(v // 160, ex.total_frames)
+        assert np.all(got[i][:, rv:] == 0)
+        # normalised values are O(1); the oracle sums sequentially in fp32, the kernel as a tree
+        np.testing.assert_allclose(got[i], ref, rtol=0, atol=2e-3 if rv > 1 else 1e-6)
+        if rv > 8:
+            assert np.abs(got[i][:, :rv].mean(1)).max() < 1e-4
+    one, v1 = ex.features(wins[1], valids[1])
+    assert one.shape == (1, 128, ex.total_frames) and v1 == vf[1]
+    np.testing.assert_array_equal(one[0], got[1])

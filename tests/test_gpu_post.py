@@ -30,3 +30,32 @@ def test_guards(fa, gpu_ctx):
     assert c.shape == (0, 4) and m.tolist() == [-1, -1]
     # zero vectors are left unnormalised (:824-859) and score 0 against everything: first centroid wins
     assert fa.assign_embeddings(np.zeros((2, 4)), np.eye(4)[:2], ctx=gpu_ctx) == [0, 0]
+
+
+def test_constrained_assignment_known_answers(fa, gpu_ctx):
+    from test_oracle_assign import CONSTRAINED, HUNGARIAN
+    for scores, want in HUNGARIAN:
+        assert fa.HungarianAssignment.max_score_assignment(scores, ctx=gpu_ctx) == want
+    assert fa.HungarianAssignment.max_score_assignment([[], []], ctx=gpu_ctx) == [-1, -1]
+    for scores, chunks, want in CONSTRAINED:
+        assert fa.ConstrainedClusterAssignment.assign(scores, chunks, ctx=gpu_ctx) == want
+    assert fa.ConstrainedClusterAssignment.assign([], [], ctx=gpu_ctx) == []
+
+
+@pytest.mark.parametrize("n,K,seed", [(3000, 7, 0), (5000, 40, 1), (600, 2, 2), (900, 130, 3)])
+def test_scores_and_constrained_assignment_match_oracle(fa, gpu_ctx, oracle_mod, n, K, seed):
+    rng = np.random.default_rng(seed)
+    d = 64
+    emb = rng.standard_normal((n, d))
+    cen = rng.standard_normal((K, d))
+    sr = oracle_mod.centroid_scores(emb, cen)
+    sg = fa.centroid_scores(emb, cen, ctx=gpu_ctx)
+    np.testing.assert_array_equal(sg, sr)
+    chunks = np.repeat(np.arange((n + 2) // 3), 3)[:n]          # 3 local speakers per chunk (OfflineDiarizerTypes.swift:46-55)
+    chunks = chunks[rng.permutation(n)]                          # rows of a chunk are not adjacent
+    sg[rng.random(sg.shape) < 0.01] = np.nan                     # non-finite scores rank below all finite ones (:78-80)
+    want = oracle_mod.constrained_assign(sg, chunks).tolist()
+    got = fa.ConstrainedClusterAssignment.assign(sg, chunks, ctx=gpu_ctx)
+    assert got == want
+    if K >= 3:
+        assert min(got) >= 0
