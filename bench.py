@@ -12,6 +12,7 @@ no data-path collective).  Rank 0 prints ONE JSON line which also carries
   cpu_baseline  — the CPU oracle (a restatement of the Swift/Accelerate path, NOT Apple's vDSP) timed on this box
   ahc_50k       — wall-clock of centroid-linkage AHC on 50 000 x 256 embeddings (the metric's second half; rank 0)
   ctc           — greedy CTC decode rate on [T=1500, V=1024] matrices (BASELINE configs[3]; rank 0)
+  e2e_8h        — BASELINE configs[4] on one GPU: 8 h audio -> mel -> precomputed embeddings -> AHC + VBx + assignment (rank 0)
 """
 import argparse
 import json
@@ -138,6 +139,46 @@ def ctc_leg(fa, ctx, torch, batch, steps=3):
             "mean_tokens_per_matrix": float(lens.float().mean())}
 
 
+def e2e_leg(fa, ctx, torch, hours=8.0, speakers=12):
+    """BASELINE configs[4] on ONE GPU: `hours` of synthetic 16 kHz audio -> mel (15 s chunks) -> precomputed embeddings
+    (3 local speaker slots per 2 s step, OfflineDiarizerTypes.swift:46-55) -> AHC + VBx + centroids + constrained
+    assignment.  Embeddings/PLDA features are synthetic (the reference computes them with CoreML nets, out of scope)."""
+    n_chunks15 = int(hours * 3600 / 15)
+    d_pcm = synth_pcm(torch, n_chunks15, 99)
+    mel = fa.AudioMelSpectrogram(ctx=ctx)
+    plan = mel.plan(np.arange(n_chunks15 + 1, dtype=np.int64) * CHUNK_SAMPLES, layout="mel_major")
+    d_out = torch.empty(plan.out_shape(), dtype=torch.float32, device="cuda")
+    d_len = torch.empty(n_chunks15, dtype=torch.int32, device="cuda")
+    plan.execute(d_pcm, d_out, d_len)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    plan.execute(d_pcm, d_out, d_len)
+    ctx.synchronize()
+    t_mel = time.perf_counter() - t0
+    del d_out, d_pcm
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(5)
+    n_win = int(hours * 3600 / 2)
+    n = 3 * n_win
+    centers = rng.standard_normal((speakers, 256))
+    centers /= np.linalg.norm(centers, axis=1, keepdims=True)
+    spk = np.stack([rng.permutation(speakers)[:3] for _ in range(n_win)]).reshape(-1)
+    emb = (centers[spk] + 0.03 * rng.standard_normal((n, 256))).astype(np.float32)
+    phi = np.linspace(2.0, 1.0, 128)
+    rho = (rng.standard_normal((speakers, 128)) * np.sqrt(phi))[spk] + rng.standard_normal((n, 128))
+    chunks = np.repeat(np.arange(n_win), 3)
+    fa.cluster_embeddings(emb[:3000], rho[:3000], chunks[:3000], phi, ctx=ctx)   # warm-up (workspace, code objects)
+    t0 = time.perf_counter()
+    res = fa.cluster_embeddings(emb, rho, chunks, phi, ctx=ctx)
+    t_cl = time.perf_counter() - t0
+    lab = np.asarray(res.assignments)
+    pure = len(set(zip(spk.tolist(), lab.tolist()))) == speakers
+    return {"audio_hours": hours, "mel_chunks": n_chunks15, "mel_s": t_mel, "embeddings": n, "cluster_s": t_cl,
+            "stages_s": res.timings, "speakers_true": speakers, "clusters_found": int(res.centroids.shape[0]),
+            "labels_match_speakers": bool(pure), "audio_hours_per_s": hours / (t_mel + t_cl),
+            "note": "host-pointer clustering entries (PCIe copies included); mel inputs resident in HBM"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +188,7 @@ def main():
     ap.add_argument("--skip-ahc", action="store_true")
     ap.add_argument("--skip-ctc", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-e2e", action="store_true")
     ap.add_argument("--ctc-matrices", type=int, default=10000)
     args = ap.parse_args()
 
@@ -242,6 +284,12 @@ def main():
             line["ahc_50k"] = ahc_leg(fa, ctx, torch)
         except Exception as e:  # noqa: BLE001
             line["ahc_50k"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    if solo and not args.skip_e2e:
+        try:
+            line["e2e_8h"] = e2e_leg(fa, ctx, torch)
+        except Exception as e:  # noqa: BLE001
+            line["e2e_8h"] = {"error": repr(e)}
     print(json.dumps(line))
     if dist is not None:
         dist.barrier()

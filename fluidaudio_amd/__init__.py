@@ -8,6 +8,7 @@ from .ahc import AHCClustering, cut, fastcluster_compute_centroid_linkage, linka
 from .ctc import (LogitsArgmax, ctc_greedy_decode, ctc_greedy_ids_batch, ctc_greedy_ids_dev,  # noqa: F401
                   decode_ctc_token_ids)
 from .mel import AudioMelSpectrogram, MelPlan, UnifiedMelExtractor  # noqa: F401
+from .pipeline import ClusteringResult, OfflineClusteringConfig, cluster_embeddings, select_training_embeddings  # noqa: F401
 from .post import (ConstrainedClusterAssignment, HungarianAssignment, assign_embeddings, centroid_scores,  # noqa: F401
                    compute_centroids)
 from .resample import linear_resample, poly_taps, resample_poly  # noqa: F401

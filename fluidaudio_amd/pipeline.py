@@ -1,0 +1,90 @@
+"""The arithmetic of ``OfflineDiarizerManager.cluster`` (reference:
+Sources/FluidAudio/Diarizer/Offline/Core/OfflineDiarizerManager.swift:270-375) on precomputed embeddings, composed from
+the library's device stages — the "embeddings in -> final per-embedding cluster ids out" path of BASELINE config 5:
+
+    select finite embeddings (:591-611) -> AHC (AHCClustering.cluster, threshold 0.6) -> VBx refine (Fa 0.07, Fb 0.8,
+    <= 20 iterations) -> gamma-weighted centroids of the active speakers (:613-691) -> cosine scores (:789-798) ->
+    constrained per-chunk assignment (ConstrainedClusterAssignment, default) or plain argmax (:800-822).
+
+Segmentation, embedding extraction and PLDA are CoreML models in the reference (out of scope); speaker-count
+constraints with the K-Means fallback (VBxClustering.swift:685-733) are a "next" row and not wired here."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib as L
+from .ahc import AHCClustering
+from .post import ConstrainedClusterAssignment, assign_embeddings, centroid_scores, compute_centroids
+from .vbx import VBxClustering, VBxOutput
+
+
+@dataclass
+class OfflineClusteringConfig:  # OfflineDiarizerTypes.swift:155-163,189-192
+    clustering_threshold: float = 0.6
+    warm_start_fa: float = 0.07
+    warm_start_fb: float = 0.8
+    max_vbx_iterations: int = 20
+    convergence_tolerance: float = 1e-4
+    constrained_assignment: bool = True
+
+
+@dataclass
+class ClusteringResult:
+    assignments: list
+    centroids: np.ndarray
+    initial_clusters: list
+    vbx: VBxOutput
+    training_indices: list = field(default_factory=list)
+    timings: dict = field(default_factory=dict)
+
+
+def select_training_embeddings(embedding256) -> list:
+    """selectTrainingEmbeddings (:591-611): indices of the rows without NaN/Inf; all rows if none qualifies."""
+    e = np.asarray(embedding256)
+    ok = np.isfinite(e).all(axis=1) if e.ndim == 2 and e.size else np.zeros(len(e), bool)
+    sel = np.nonzero(ok)[0].tolist()
+    return sel if sel else list(range(len(e)))
+
+
+def cluster_embeddings(embedding256, rho128, chunk_indices, phi, config: OfflineClusteringConfig | None = None,
+                       ctx: L.Context | None = None) -> ClusteringResult:
+    import time
+    cfg = config or OfflineClusteringConfig()
+    ctx = ctx or L.default_context()
+    t = {}
+    emb = np.asarray(embedding256, np.float32).astype(np.float64)          # Float -> Double widening (:286)
+    rho = np.ascontiguousarray(rho128, np.float64)
+    if emb.shape[0] == 0:
+        raise ValueError("noSpeechDetected")                                 # :281-283
+    train = select_training_embeddings(embedding256)
+    temb, trho = emb[train], rho[train]
+    t0 = time.perf_counter()
+    if len(train) >= 2:
+        initial = AHCClustering(ctx=ctx).cluster(temb, cfg.clustering_threshold)   # :301-306
+    else:
+        initial = [0] * len(train)
+    t["ahc_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    if trho.size and initial:
+        vbx = VBxClustering(phi, cfg.max_vbx_iterations, cfg.convergence_tolerance, cfg.warm_start_fa, cfg.warm_start_fb,
+                            ctx=ctx).refine(trho, initial)                   # :328-333 (no speaker-count constraints)
+    else:
+        vbx = VBxOutput(np.zeros((0, 0)), np.zeros(0), [list(initial)], [], (max(initial) + 1) if initial else 0, [])
+    t["vbx_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    centroids = np.zeros((0, emb.shape[1]))
+    if vbx.gamma.size and vbx.pi.size:
+        centroids, _ = compute_centroids(temb, vbx.gamma, vbx.pi, ctx=ctx)  # :613-684
+    if centroids.shape[0] == 0:                                              # computeCentroidsFromClusters (:686-) fallback
+        labs = np.asarray(initial)
+        centroids = np.stack([temb[labs == k].mean(0) for k in sorted(set(initial))]) if len(initial) else centroids
+    use_constrained = cfg.constrained_assignment and centroids.shape[0] > 1  # :355-358
+    if use_constrained:
+        scores = centroid_scores(emb, centroids, ctx=ctx)
+        assignments = ConstrainedClusterAssignment.assign(scores, chunk_indices, ctx=ctx)
+    else:
+        assignments = assign_embeddings(emb, centroids, ctx=ctx)
+    t["assign_s"] = time.perf_counter() - t0
+    return ClusteringResult(assignments, centroids, list(initial), vbx, train, t)

@@ -383,3 +383,21 @@ def centroid_scores(emb, centroids) -> np.ndarray:
     if out.size:
         lib().fa_oracle_centroid_scores(emb, emb.shape[0], emb.shape[1], cen, cen.shape[0], out)
     return out
+
+
+def cluster_embeddings(embedding256, rho128, chunk_indices, phi, threshold=0.6, Fa=0.07, Fb=0.8, max_iter=20, tol=1e-4,
+                       constrained=True):
+    """CPU restatement of OfflineDiarizerManager.cluster (:270-375) on precomputed embeddings (no speaker-count constraints)."""
+    e32 = np.asarray(embedding256, np.float32)
+    emb = e32.astype(np.float64)
+    ok = np.isfinite(e32).all(axis=1)
+    train = np.nonzero(ok)[0] if ok.any() else np.arange(len(e32))
+    temb, trho = emb[train], np.ascontiguousarray(rho128, np.float64)[train]
+    initial = ahc_cluster(temb, threshold) if len(train) >= 2 else np.zeros(len(train), np.int32)
+    gamma, pi, hard, elbos = vbx_refine(trho, initial, phi, max_iter, tol, Fa, Fb)
+    cent, _ = weighted_centroids(temb, gamma, pi)
+    if cent.shape[0] > 1 and constrained:
+        assign = constrained_assign(centroid_scores(emb, cent), chunk_indices)
+    else:
+        assign = assign_cosine(emb, cent)
+    return dict(assignments=assign, centroids=cent, initial=np.asarray(initial), gamma=gamma, pi=pi)

@@ -11,7 +11,7 @@ tail -12 gpurun_out/pytest_gpu.log
 tail -4 gpurun_out/bench.log | cut -c1-3000
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_mel gpurun_out/prof_ahc gpurun_out/pmc
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_mel" -o mel -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --skip-ahc --skip-ctc --skip-cpu ) > gpurun_out/rocprof_mel.log 2>&1; echo "rocprof mel rc=$?"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_mel" -o mel -- python "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 3 --skip-ahc --skip-ctc --skip-cpu --skip-e2e ) > gpurun_out/rocprof_mel.log 2>&1; echo "rocprof mel rc=$?"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_ahc" -o ahc -- python "$GRAFT_REPO_ROOT/scripts/ahc_probe.py" 50000 --kinds iid --modes 0 --check 0 ) > gpurun_out/rocprof_ahc.log 2>&1; echo "rocprof ahc rc=$?"
 timeout 300 python scripts/ahc_probe.py 2000,10000,20000,50000 --modes 0 2>&1 | grep -v amdgpu.ids > gpurun_out/ahc_scaling.log
 bash scripts/gpu_mel_pmc.sh > gpurun_out/pmc.log 2>&1; echo "pmc rc=$?"
