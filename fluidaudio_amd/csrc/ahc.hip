@@ -68,7 +68,7 @@ struct AhcState {  // double buffered by round parity; written by workgroup 0 on
     int32_t pad0;
     int32_t pend_row[kPend], pend_node[kPend];  // rows whose block-partial minima the previous round produced (-1: none)
     double eps, lim;              // lim: window limit carried COLLECT -> PAIRS -> evaluation
-    unsigned long long dmax_bits;
+    unsigned long long dmax_bits, nmax_bits;  // largest matrix entry / largest squared norm seen by the start-up kernels
     long long rounds, rescans, windows, piggy;
 };
 
@@ -289,6 +289,103 @@ __global__ __launch_bounds__(256) void ahc_pairwise(Ws w) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(lmax, off); if (o > lmax) lmax = o; }
     if ((tid & 63) == 0 && lmax > 0.0)
+        atomicMax(&w.state[0].dmax_bits, static_cast<unsigned long long>(__double_as_longlong(lmax)));
+}
+
+// ---- FA_AHC_MODE_AUTO start: the N x d . d x N contraction on the fp64 matrix cores ---------------------------------
+// In AUTO mode every matrix entry is only a filter (decisions inside 2 eps are re-evaluated exactly), so the initial
+// matrix may be the Gram form |x|^2 + |y|^2 - 2 x.y: 2 N^2 d = 1.28 TFLOP at N = 50 000, d = 256 on
+// v_mfma_f64_16x16x4_f64 instead of 1.9 T dependent fp64 VALU operations.  Its rounding error (<= ~(d + 2) u (|x| + |y|)^2)
+// is added to eps by the host.  Workgroup = 128 x 128 tile, wavefront = 64 x 64 (4 x 4 MFMA tiles, 64 accumulator
+// doubles per lane); operands staged k-major in LDS with a 144-double row stride (two k rows of a 32-lane ds_read_b64
+// service group land 32 banks apart).
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int GT = 128, GK = 16, GS = 144;
+
+__global__ void ahc_sqnorms(Ws w, double *__restrict__ norms) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= w.Np) return;
+    double s = 0.0;
+    for (int k = 0; k < w.d; ++k) { const double v = w.XT[static_cast<size_t>(k) * w.Np + x]; s += v * v; }
+    norms[x] = s;
+    if (s > 0.0) atomicMax(&w.state[0].nmax_bits, static_cast<unsigned long long>(__double_as_longlong(s)));
+}
+
+__global__ __launch_bounds__(256, 1) void ahc_gram_mfma(Ws w, const double *__restrict__ norms) {
+    __shared__ double sA[GK][GS];
+    __shared__ double sB[GK][GS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int Np = w.Np, d = w.d;
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = v4f64{0.0, 0.0, 0.0, 0.0};
+    // [GK][128] doubles of both operand tiles per k chunk: thread -> (k row, 16-byte column pair); the next chunk travels
+    // from L2/HBM into registers while the matrix cores work on the current one
+    constexpr int kVec = (GK * GT / 2) / 256;  // 4
+    double2 ra[kVec], rb[kVec];
+    auto fetch = [&](const int k0) {
+#pragma unroll
+        for (int e = 0; e < kVec; ++e) {
+            const int q = tid + 256 * e, k = k0 + q / (GT / 2), c2 = (q % (GT / 2)) * 2;
+            ra[e] = rb[e] = make_double2(0.0, 0.0);
+            if (k < d) {
+                ra[e] = *reinterpret_cast<const double2 *>(w.XT + static_cast<size_t>(k) * Np + i0 + c2);
+                rb[e] = *reinterpret_cast<const double2 *>(w.XT + static_cast<size_t>(k) * Np + j0 + c2);
+            }
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < d; k0 += GK) {
+#pragma unroll
+        for (int e = 0; e < kVec; ++e) {
+            const int q = tid + 256 * e, kk = q / (GT / 2), c2 = (q % (GT / 2)) * 2;
+            *reinterpret_cast<double2 *>(&sA[kk][c2]) = ra[e];
+            *reinterpret_cast<double2 *>(&sB[kk][c2]) = rb[e];
+        }
+        __syncthreads();
+        if (k0 + GK < d) fetch(k0 + GK);
+#pragma unroll
+        for (int ks = 0; ks < GK / 4; ++ks) {
+            const int kr = 4 * ks + (lane >> 4);
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { a[t] = sA[kr][wr + 16 * t + (lane & 15)]; b[t] = sB[kr][wc + 16 * t + (lane & 15)]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[c], acc[r][c], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    double lmax = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int j = j0 + wc + 16 * c + (lane & 15);
+        const bool lj = w.node[j] != kDead;
+        const double nj = norms[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + wr + 16 * r + (lane >> 4) + 4 * e;
+                const bool ok = lj && i != j && w.node[i] != kDead;
+                double v = norms[i] + nj - 2.0 * acc[r][c][e];
+                if (ok) { if (v != v) bad = true; }
+                if (!(v > 0.0)) v = 0.0;  // duplicates can come out slightly negative; keeps -0.0 out of the bit-pattern reductions
+                if (ok && v > lmax) lmax = v;
+                w.M[static_cast<size_t>(i) * Np + j] = ok ? v : dinf();
+            }
+    }
+    if (bad) w.flags[0] = 1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(lmax, off); if (o > lmax) lmax = o; }
+    if (lane == 0 && lmax > 0.0)
         atomicMax(&w.state[0].dmax_bits, static_cast<unsigned long long>(__double_as_longlong(lmax)));
 }
 
@@ -849,7 +946,7 @@ __global__ void ahc_heights(Ws w) {
 
 // ------------------------------------------------------------------------------ host driver
 struct Layout {
-    size_t state, cnt, flags, prof, c, xt, row, node, sizes, z, reca, reci, recs, recp, cand, pairs, m, total;
+    size_t state, cnt, flags, prof, c, xt, row, node, sizes, z, reca, reci, recs, recp, cand, pairs, norms, m, total;
 };
 
 Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
@@ -870,6 +967,7 @@ Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
     L.z = take(sizeof(double) * 4 * (N > 1 ? N - 1 : 1));
     L.cand = take(sizeof(int2) * kMaxCand);
     L.pairs = take(sizeof(int4) * kMaxPairs);
+    L.norms = take(sizeof(double) * Np);
     L.c = take(sizeof(double) * d * 2 * N);
     L.xt = take(sizeof(double) * d * Np);
     L.m = take(sizeof(double) * Np * Np);
@@ -878,9 +976,14 @@ Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
 }
 
 // exact matrix, row minima and parity-0 records of the clusters currently alive (XT must hold their coordinates)
-fa_status exact_rebuild(fa_ctx *ctx, const Ws &w) {
-    const int tiles = w.Np / PT;
-    hipLaunchKernelGGL(ahc_pairwise, dim3(tiles, tiles), dim3(256), 0, ctx->stream, w);
+fa_status exact_rebuild(fa_ctx *ctx, const Ws &w, double *gram_norms = nullptr) {
+    if (gram_norms) {  // AUTO start: Gram form on the fp64 matrix cores (approximate entries, see ahc_gram_mfma)
+        hipLaunchKernelGGL(ahc_sqnorms, dim3((w.Np + 255) / 256), dim3(256), 0, ctx->stream, w, gram_norms);
+        hipLaunchKernelGGL(ahc_gram_mfma, dim3(w.Np / GT, w.Np / GT), dim3(256), 0, ctx->stream, w, gram_norms);
+    } else {
+        const int tiles = w.Np / PT;
+        hipLaunchKernelGGL(ahc_pairwise, dim3(tiles, tiles), dim3(256), 0, ctx->stream, w);
+    }
     hipLaunchKernelGGL(ahc_row_minima, dim3(w.Np), dim3(kBlk), 0, ctx->stream, w);
     hipLaunchKernelGGL(ahc_records, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);
     FA_HIP_TRY(ctx, hipGetLastError());
@@ -941,7 +1044,8 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(ahc_init_rows, dim3((std::max(Np, 2 * N) + 255) / 256), dim3(256), 0, ctx->stream, w);
     hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, ctx->stream, d_data, w.XT, w.N, w.Np, w.d);
-    FA_TRY(exact_rebuild(ctx, w));
+    double *d_norms = reinterpret_cast<double *>(base + L.norms);
+    FA_TRY(exact_rebuild(ctx, w, init[0].mode == FA_AHC_MODE_AUTO ? d_norms : nullptr));
     AhcState h{};
     int32_t hflag = 0;
     FA_HIP_TRY(ctx, hipMemcpyAsync(&h, w.state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -955,7 +1059,12 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
         // rounding bound of the Lance-Williams recurrence: <= 8 u dmax per merge level (3 products, 2 sums, 3 rounded
         // weights, the tree-summed d(a,b)), errors of the two parents enter with weights wa + wb = 1, tree depth <= N;
         // factor 2 of margin.
-        const double eps = 16.0 * static_cast<double>(N) * 1.1102230246251565e-16 * dmax;
+        // Start-up matrix in Gram form: |x|^2 + |y|^2 - 2 x.y carries <= (d + 2) u (|x|^2 + |y|^2 + 2 |x||y|) <= 4 (d + 2) u nmax.
+        double nmax;
+        const long long nbits = static_cast<long long>(h.nmax_bits);
+        memcpy(&nmax, &nbits, sizeof(nmax));
+        const double u = 1.1102230246251565e-16;
+        const double eps = 16.0 * static_cast<double>(N) * u * dmax + 8.0 * (static_cast<double>(d) + 2.0) * u * nmax;
         FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state) + offsetof(AhcState, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
         FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state + 1) + offsetof(AhcState, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(ahc_records, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);  // window counts need eps
