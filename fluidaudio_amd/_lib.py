@@ -30,6 +30,8 @@ EXPORTED_SYMBOLS = [
     "fa_mel_plan_utt_stride", "fa_mel_plan_frame_stride", "fa_mel_plan_total_frames", "fa_mel_execute_dev",
     "fa_mel_batch", "fa_mel_hann_window", "fa_mel_filterbank", "fa_mel_normalize_per_feature_dev",
     "fa_ctc_greedy_batch_dev", "fa_ctc_greedy_batch",
+    "fa_tdt_default_config", "fa_tdt_initial_time_index", "fa_tdt_navigation_state", "fa_tdt_final_time_jump",
+    "fa_tdt_map_duration_bin", "fa_tdt_clamp_probability", "fa_tdt_greedy_tables_dev",
     "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_cluster", "fa_ahc_cut",
     "fa_vbx_speaker_count", "fa_vbx_refine",
     "fa_vbx_weighted_centroids", "fa_assign_cosine", "fa_centroid_scores", "fa_constrained_assign",
@@ -48,6 +50,11 @@ class MelConfig(C.Structure):
                 ("win", C.c_int32), ("preemph", C.c_float), ("pad_to", C.c_int32), ("log_floor", C.c_float),
                 ("floor_mode", C.c_int32), ("window_periodic", C.c_int32), ("padding_mode", C.c_int32),
                 ("layout", C.c_int32)]
+
+
+class TdtConfig(C.Structure):
+    _fields_ = [("blank_id", C.c_int32), ("max_symbols_per_step", C.c_int32), ("max_tokens_per_chunk", C.c_int32),
+                ("consecutive_blank_limit", C.c_int32), ("n_duration_bins", C.c_int32), ("duration_bins", C.c_int32 * 8)]
 
 
 class AhcStats(C.Structure):
@@ -111,6 +118,18 @@ def lib() -> C.CDLL:
     L.fa_mel_filterbank.argtypes = [C.POINTER(MelConfig), vp]
     L.fa_ctc_greedy_batch_dev.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, vp, i32, vp, vp, vp]
     L.fa_ctc_greedy_batch.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, vp, i32, vp, vp, vp]
+    L.fa_tdt_default_config.argtypes = [C.POINTER(TdtConfig)]
+    L.fa_tdt_default_config.restype = None
+    L.fa_tdt_initial_time_index.argtypes = [i32, i32, i32]
+    L.fa_tdt_initial_time_index.restype = i32
+    L.fa_tdt_navigation_state.argtypes = [i32, i32, i32] + [C.POINTER(i32)] * 4
+    L.fa_tdt_navigation_state.restype = None
+    L.fa_tdt_final_time_jump.argtypes = [i32, i32, i32, C.POINTER(i32)]
+    L.fa_tdt_final_time_jump.restype = i32
+    L.fa_tdt_map_duration_bin.argtypes = [C.POINTER(TdtConfig), i32, C.POINTER(i32)]
+    L.fa_tdt_clamp_probability.argtypes = [f32]
+    L.fa_tdt_clamp_probability.restype = f32
+    L.fa_tdt_greedy_tables_dev.argtypes = [vp, C.POINTER(TdtConfig), vp, vp, vp, i32, i32, i32] + [vp] * 6 + [i32] + [vp] * 8
     L.fastcluster_compute_centroid_linkage.argtypes = [vp, sz, sz, vp, sz]
     L.fastcluster_compute_centroid_linkage.restype = C.c_int
     L.fa_ahc_linkage.argtypes = [vp, vp, sz, sz, vp, sz, i32, i32, C.POINTER(AhcStats)]

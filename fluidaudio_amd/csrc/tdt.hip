@@ -1,0 +1,196 @@
+// tdt.hip — Parakeet-TDT greedy decoding: frame navigation + the token/duration control loop (gfx950).
+//
+// Restates the control flow of TdtDecoderV3.decodeWithTimings (reference:
+// Sources/FluidAudio/ASR/Parakeet/SlidingWindow/TDT/Decoder/TdtDecoderV3.swift:103-607) and its helpers
+// (TdtFrameNavigation.swift:20-105, TdtDurationMapping.swift:17-31, TdtConfig.swift:13-26).
+//
+// In the reference every step of that loop crosses into CoreML: the decoder LSTM (one call per emitted token) and the
+// joint network, which already returns the ARG-MAXED (token id, token probability, duration bin)
+// (TdtModelInference.swift:107-138).  Those networks are not part of the reference tree, so what can be reproduced is
+// the integer control flow.  The device entry therefore consumes the joint's decisions as tables indexed by
+// (u = decoder steps taken so far in this chunk, t = encoder frame) — exactly the values the reference would see along
+// its greedy path — and replays the loop for a whole batch of chunks, one thread per chunk (the loop is a serial walk of
+// <= T + maxTokens table look-ups; the batch is the parallel axis).  PARITY of token outputs against the real models is
+// UNPINNED (models absent); the navigation helpers are pinned by TdtRefactoredComponentsTests.swift:12-195.
+#include "fa_common.h"
+
+namespace {
+
+constexpr int kStandardOverlapFrames = 25;  // ASRConstants.standardOverlapFrames (Shared/ASRConstants.swift:49)
+
+struct TdtArgs {
+    const int32_t *tok, *bin;  // [B][U][T]
+    const float *prob;         // [B][U][T]
+    const int32_t *enc_len, *audio_frames, *t0, *is_last, *global_offset, *emit_after;  // [B]; emit_after < 0: emit all
+    int32_t *out_tok, *out_time, *out_dur;  // [B][max_out]
+    float *out_conf;                        // [B][max_out]
+    int32_t *out_count, *final_time, *final_u, *status;  // [B]
+    int32_t B, U, T, max_out;
+    fa_tdt_config cfg;
+};
+
+__host__ __device__ inline float clamp_probability(const float v) {  // TdtDurationMapping.swift:28-31
+    if (!(v - v == 0.0f)) return 0.0f;  // NaN / +-inf
+    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+}
+
+__global__ void tdt_kernel(const TdtArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const fa_tdt_config &c = a.cfg;
+    const int64_t tb = static_cast<int64_t>(b) * a.U * a.T;
+    int32_t *otok = a.out_tok + static_cast<int64_t>(b) * a.max_out, *otime = a.out_time + static_cast<int64_t>(b) * a.max_out;
+    int32_t *odur = a.out_dur + static_cast<int64_t>(b) * a.max_out;
+    float *oconf = a.out_conf + static_cast<int64_t>(b) * a.max_out;
+    int count = 0, st = FA_SUCCESS, u = 0;
+    const int enc_len = a.enc_len[b];
+    const int goff = a.global_offset ? a.global_offset[b] : 0;
+    const int emit_after = a.emit_after ? a.emit_after[b] : -1;
+    int t = a.t0 ? a.t0[b] : 0;
+    a.final_time[b] = INT32_MIN;  // "timeJump not updated" (early returns, :110-112,:150-152)
+    auto finish = [&]() { a.out_count[b] = count; a.final_u[b] = u; a.status[b] = st; };
+    if (enc_len <= 1) { finish(); return; }                        // :110-112
+    const int Teff = min(enc_len, a.audio_frames ? a.audio_frames[b] : enc_len);  // TdtFrameNavigation.swift:59-78
+    if (t >= Teff) { finish(); return; }                           // :150-152
+    const int last = Teff - 1;
+    int safe = min(t, last);
+    bool active = t < Teff;
+    int last_emit_t = -1, n_at_t = 0, processed = 0, tok = c.blank_id, dur = 0;
+    float score = 0.0f;
+    auto joint = [&](const int frame) -> bool {  // one joint decision; false on a table / duration-bin error
+        if (u >= a.U || frame < 0 || frame >= a.T) { st = FA_OUTPUT_TOO_SMALL; return false; }
+        const int64_t i = tb + static_cast<int64_t>(u) * a.T + frame;
+        tok = a.tok[i];
+        score = clamp_probability(a.prob[i]);
+        const int bi = a.bin[i];
+        if (bi < 0 || bi >= c.n_duration_bins) { st = FA_RUNTIME_ERROR; return false; }  // mapDurationBin throws (:17-22)
+        dur = c.duration_bins[bi];
+        return true;
+    };
+    auto emit = [&](const int ts) {
+        if (emit_after >= 0 && ts < emit_after) return;  // shouldEmitToken (:600-606)
+        if (count < a.max_out) { otok[count] = tok; otime[count] = ts; odur[count] = dur; oconf[count] = score; }
+        else st = FA_OUTPUT_TOO_SMALL;
+        ++count;
+    };
+    while (active) {  // :230-467
+        if (!joint(safe)) { finish(); return; }
+        bool blank = tok == c.blank_id;
+        if (!blank && dur == 0 && t == last_emit_t && n_at_t >= 1) dur = 1;  // :318-323
+        if (blank && dur == 0) dur = 1;                                       // :327-329
+        int t_label = t;
+        t += dur;
+        safe = min(t, last);
+        active = t < Teff;
+        bool advance = active && blank;
+        while (advance) {  // :348-405: same predictor state, blanks only move the frame pointer
+            t_label = t;
+            if (!joint(safe)) { finish(); return; }
+            blank = tok == c.blank_id;
+            if (blank && dur == 0) dur = 1;
+            t += dur;
+            safe = min(t, last);
+            active = t < Teff;
+            advance = active && blank;
+        }
+        if (active && tok != c.blank_id) {  // :409-463
+            if (++processed > c.max_tokens_per_chunk) break;
+            emit(t_label + goff);
+            ++u;  // decoder LSTM step on the emitted token (:433-444)
+            if (t_label == last_emit_t) ++n_at_t; else { last_emit_t = t_label; n_at_t = 1; }
+            if (n_at_t >= c.max_symbols_per_step) {  // force-advance (:453-462)
+                t = min(t + 1, last);
+                safe = min(t, last);
+                n_at_t = 0;
+                last_emit_t = -1;
+            }
+        }
+        active = t < Teff;
+    }
+    if (a.is_last && a.is_last[b]) {  // last-chunk flush (:472-571)
+        int steps = 0, blanks = 0, fp = t;
+        while (steps < c.max_symbols_per_step && blanks < c.consecutive_blank_limit) {
+            const int var3[3] = {min(fp, enc_len - 1), min(Teff - 1, enc_len - 1), min(max(0, Teff - 2), enc_len - 1)};
+            if (!joint(var3[steps % 3])) { finish(); return; }
+            if (tok == c.blank_id) ++blanks;
+            else {
+                blanks = 0;
+                emit(min(fp, Teff - 1) + goff);
+                ++u;
+            }
+            fp = min(fp + max(1, dur), Teff);
+            ++steps;
+        }
+    }
+    a.final_time[b] = t;
+    finish();
+}
+
+}  // namespace
+
+extern "C" {
+
+void fa_tdt_default_config(fa_tdt_config *c) {  // TdtConfig.swift:13-26
+    if (!c) return;
+    c->blank_id = 8192; c->max_symbols_per_step = 10; c->max_tokens_per_chunk = 150; c->consecutive_blank_limit = 5;
+    c->n_duration_bins = 5;
+    for (int i = 0; i < 8; ++i) c->duration_bins[i] = i < 5 ? i : 0;
+}
+
+int32_t fa_tdt_initial_time_index(int32_t has_time_jump, int32_t time_jump, int32_t context_frame_adjustment) {
+    // TdtFrameNavigation.calculateInitialTimeIndices (TdtFrameNavigation.swift:20-49)
+    if (!has_time_jump) return context_frame_adjustment;
+    if (time_jump == 0 && context_frame_adjustment == 0) return kStandardOverlapFrames;
+    const int32_t v = time_jump + context_frame_adjustment;
+    return v > 0 ? v : 0;
+}
+
+void fa_tdt_navigation_state(int32_t time_indices, int32_t encoder_sequence_length, int32_t actual_audio_frames,
+                             int32_t *effective_length, int32_t *safe_time_indices, int32_t *last_timestep, int32_t *active) {
+    // TdtFrameNavigation.initializeNavigationState (:59-78)
+    const int32_t eff = encoder_sequence_length < actual_audio_frames ? encoder_sequence_length : actual_audio_frames;
+    if (effective_length) *effective_length = eff;
+    if (safe_time_indices) *safe_time_indices = time_indices < eff - 1 ? time_indices : eff - 1;
+    if (last_timestep) *last_timestep = eff - 1;
+    if (active) *active = time_indices < eff;
+}
+
+int32_t fa_tdt_final_time_jump(int32_t current_time_indices, int32_t effective_length, int32_t is_last_chunk, int32_t *has_value) {
+    // TdtFrameNavigation.calculateFinalTimeJump (:91-105): nil for the last chunk
+    if (has_value) *has_value = !is_last_chunk;
+    return is_last_chunk ? 0 : current_time_indices - effective_length;
+}
+
+fa_status fa_tdt_map_duration_bin(const fa_tdt_config *cfg, int32_t bin_index, int32_t *duration) {
+    if (!cfg || !duration) return FA_INVALID_ARGUMENT;
+    if (bin_index < 0 || bin_index >= cfg->n_duration_bins) return FA_RUNTIME_ERROR;  // "Duration bin index out of range" (:19-21)
+    *duration = cfg->duration_bins[bin_index];
+    return FA_SUCCESS;
+}
+
+float fa_tdt_clamp_probability(float v) { return clamp_probability(v); }
+
+fa_status fa_tdt_greedy_tables_dev(fa_ctx *ctx, const fa_tdt_config *cfg, const int32_t *d_tok, const int32_t *d_bin, const float *d_prob,
+                                   int32_t batch, int32_t U, int32_t T, const int32_t *d_enc_len, const int32_t *d_audio_frames,
+                                   const int32_t *d_t0, const int32_t *d_is_last, const int32_t *d_global_offset,
+                                   const int32_t *d_emit_after, int32_t max_out, int32_t *d_out_tok, int32_t *d_out_time,
+                                   int32_t *d_out_dur, float *d_out_conf, int32_t *d_out_count, int32_t *d_final_time,
+                                   int32_t *d_final_u, int32_t *d_status) {
+    if (!ctx || !cfg) return FA_INVALID_ARGUMENT;
+    if (batch == 0) return FA_SUCCESS;
+    if (batch < 0 || U < 1 || T < 1 || max_out < 0 || cfg->n_duration_bins < 1 || cfg->n_duration_bins > 8 || !d_tok || !d_bin || !d_prob ||
+        !d_enc_len || !d_out_count || !d_final_time || !d_final_u || !d_status || (max_out > 0 && (!d_out_tok || !d_out_time || !d_out_dur || !d_out_conf)))
+        return fa::set_error(ctx, FA_INVALID_ARGUMENT, "tdt: bad arguments");
+    fa::DeviceGuard guard(ctx->device);
+    TdtArgs a;
+    a.tok = d_tok; a.bin = d_bin; a.prob = d_prob; a.enc_len = d_enc_len; a.audio_frames = d_audio_frames; a.t0 = d_t0;
+    a.is_last = d_is_last; a.global_offset = d_global_offset; a.emit_after = d_emit_after;
+    a.out_tok = d_out_tok; a.out_time = d_out_time; a.out_dur = d_out_dur; a.out_conf = d_out_conf; a.out_count = d_out_count;
+    a.final_time = d_final_time; a.final_u = d_final_u; a.status = d_status;
+    a.B = batch; a.U = U; a.T = T; a.max_out = max_out; a.cfg = *cfg;
+    hipLaunchKernelGGL(tdt_kernel, dim3((batch + 63) / 64), dim3(64), 0, ctx->stream, a);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+
+}  // extern "C"

@@ -143,6 +143,44 @@ fa_status fa_ctc_greedy_batch(fa_ctx *ctx, const void *logits, int32_t dtype, in
                               const int32_t *valid_frames, int32_t blank_id, int32_t *frame_ids,
                               int32_t *token_ids, int32_t *token_lens);
 
+/* ------------------------------------------------------------------ TDT ------------- */
+/* Control flow of TdtDecoderV3.decodeWithTimings (FluidAudio/ASR/Parakeet/SlidingWindow/TDT/Decoder/TdtDecoderV3.swift:103-607)
+ * and its helpers (TdtFrameNavigation.swift:20-105, TdtDurationMapping.swift:17-31, TdtConfig.swift:13-26).  The decoder
+ * LSTM and joint network are CoreML models outside the reference tree: token parity is UNPINNED; the device entry
+ * replays the loop over tables of the joint's decisions indexed by (decoder steps taken u, encoder frame t). */
+typedef struct {
+    int32_t blank_id;                /* 8192 */
+    int32_t max_symbols_per_step;    /* 10 */
+    int32_t max_tokens_per_chunk;    /* 150 */
+    int32_t consecutive_blank_limit; /* 5 */
+    int32_t n_duration_bins;         /* 5 (<= 8) */
+    int32_t duration_bins[8];        /* 0 1 2 3 4 */
+} fa_tdt_config;
+void fa_tdt_default_config(fa_tdt_config *cfg);
+/* calculateInitialTimeIndices (TdtFrameNavigation.swift:20-49); has_time_jump == 0 <=> timeJump == nil */
+int32_t fa_tdt_initial_time_index(int32_t has_time_jump, int32_t time_jump, int32_t context_frame_adjustment);
+/* initializeNavigationState (:59-78) */
+void fa_tdt_navigation_state(int32_t time_indices, int32_t encoder_sequence_length, int32_t actual_audio_frames,
+                             int32_t *effective_length, int32_t *safe_time_indices, int32_t *last_timestep, int32_t *active);
+/* calculateFinalTimeJump (:91-105); *has_value == 0 <=> nil (last chunk) */
+int32_t fa_tdt_final_time_jump(int32_t current_time_indices, int32_t effective_length, int32_t is_last_chunk, int32_t *has_value);
+/* mapDurationBin (TdtDurationMapping.swift:17-22): RUNTIME_ERROR when out of range */
+fa_status fa_tdt_map_duration_bin(const fa_tdt_config *cfg, int32_t bin_index, int32_t *duration);
+/* clampProbability (:28-31) */
+float fa_tdt_clamp_probability(float value);
+/* Batched greedy walk, one chunk per table set.  DEVICE pointers.  d_tok/d_bin/d_prob: [batch][U][T] joint decisions;
+ * per chunk: d_enc_len (encoderSequenceLength), d_audio_frames (NULL = enc_len), d_t0 (initial time index, NULL = 0),
+ * d_is_last (NULL = 0), d_global_offset (NULL = 0), d_emit_after (emitTokensAfterGlobalFrame, NULL or < 0 = nil).
+ * Outputs per chunk: up to max_out (token, global timestamp, duration, confidence), their count, the final time index
+ * (INT32_MIN when the reference returns before touching timeJump), decoder steps taken, and a status (RUNTIME_ERROR for
+ * a duration bin out of range, OUTPUT_TOO_SMALL when U or max_out is exhausted). */
+fa_status fa_tdt_greedy_tables_dev(fa_ctx *ctx, const fa_tdt_config *cfg, const int32_t *d_tok, const int32_t *d_bin,
+                                   const float *d_prob, int32_t batch, int32_t U, int32_t T, const int32_t *d_enc_len,
+                                   const int32_t *d_audio_frames, const int32_t *d_t0, const int32_t *d_is_last,
+                                   const int32_t *d_global_offset, const int32_t *d_emit_after, int32_t max_out,
+                                   int32_t *d_out_tok, int32_t *d_out_time, int32_t *d_out_dur, float *d_out_conf,
+                                   int32_t *d_out_count, int32_t *d_final_time, int32_t *d_final_u, int32_t *d_status);
+
 /* ------------------------------------------------------------------ AHC ------------- */
 /* Exact signature + status contract of the reference FFI
  * (FastClusterWrapper/include/FastClusterWrapper.h:35-41, FastClusterWrapper.cpp:196-244):

@@ -98,6 +98,11 @@ def lib() -> C.CDLL:
         L.fa_oracle_weighted_centroids.argtypes = [_f64p, C.c_long, C.c_long, _f64p, _f64p, C.c_long, _f64p, _i32p]
         L.fa_oracle_weighted_centroids.restype = C.c_long
         L.fa_oracle_assign_cosine.argtypes = [_f64p, C.c_long, C.c_long, _f64p, C.c_long, _i32p]
+        L.fa_oracle_tdt_initial_time_index.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.fa_oracle_tdt_clamp_probability.argtypes = [C.c_float]
+        L.fa_oracle_tdt_clamp_probability.restype = C.c_float
+        L.fa_oracle_tdt_greedy.argtypes = [_i32p, _i32p, _f32p] + [C.c_int] * 12 + [_i32p, C.c_int, C.c_int, _i32p, _i32p, _i32p, _f32p,
+                                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.fa_oracle_hungarian_solve.argtypes = [np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS"), C.c_int, _i32p]
         L.fa_oracle_hungarian_solve.restype = None
         L.fa_oracle_max_score_assignment.argtypes = [_f64p, C.c_int, C.c_int, _i32p]
@@ -401,3 +406,32 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, threshold=0.6, 
     else:
         assign = assign_cosine(emb, cent)
     return dict(assignments=assign, centroids=cent, initial=np.asarray(initial), gamma=gamma, pi=pi)
+
+
+def tdt_initial_time_index(time_jump, context_frame_adjustment: int) -> int:
+    return lib().fa_oracle_tdt_initial_time_index(0 if time_jump is None else 1, 0 if time_jump is None else int(time_jump),
+                                                  int(context_frame_adjustment))
+
+
+def tdt_clamp_probability(v: float) -> float:
+    return float(lib().fa_oracle_tdt_clamp_probability(float(v)))
+
+
+def tdt_greedy(tok, dur_bin, prob, enc_len, audio_frames=None, t0=0, is_last=False, global_offset=0, emit_after=None,
+               blank_id=8192, max_symbols=10, max_tokens=150, blank_limit=5, bins=(0, 1, 2, 3, 4), max_out=512):
+    """One chunk of TdtDecoderV3.decodeWithTimings over [U, T] joint-decision tables -> dict."""
+    tok = np.ascontiguousarray(tok, np.int32)
+    dur_bin = np.ascontiguousarray(dur_bin, np.int32)
+    prob = np.ascontiguousarray(prob, np.float32)
+    U, T = tok.shape
+    ot, oti, od = (np.zeros(max(max_out, 1), np.int32) for _ in range(3))
+    oc = np.zeros(max(max_out, 1), np.float32)
+    cnt, ft, fu = C.c_int(), C.c_int(), C.c_int()
+    b = np.ascontiguousarray(bins, np.int32)
+    st = lib().fa_oracle_tdt_greedy(tok, dur_bin, prob, U, T, int(enc_len), int(enc_len if audio_frames is None else audio_frames),
+                                    int(t0), int(bool(is_last)), int(global_offset), -1 if emit_after is None else int(emit_after),
+                                    blank_id, max_symbols, max_tokens, blank_limit, b, b.size, max_out,
+                                    ot, oti, od, oc, C.byref(cnt), C.byref(ft), C.byref(fu))
+    n = min(cnt.value, max_out)
+    return dict(status=st, tokens=ot[:n].copy(), timestamps=oti[:n].copy(), durations=od[:n].copy(), confidences=oc[:n].copy(),
+                count=cnt.value, final_time=None if ft.value == -2 ** 31 else ft.value, final_u=fu.value)

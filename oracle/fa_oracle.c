@@ -838,3 +838,129 @@ void fa_oracle_centroid_scores(const double *emb, long n, long d, const double *
     }
     free(cn); free(e);
 }
+
+/* ================================ TDT control loop ============================ */
+
+int fa_oracle_tdt_initial_time_index(int has_time_jump, int time_jump, int context_frame_adjustment) {
+    /* TdtFrameNavigation.swift:20-49 */
+    if (!has_time_jump) return context_frame_adjustment;
+    if (time_jump == 0 && context_frame_adjustment == 0) return 25; /* ASRConstants.standardOverlapFrames */
+    return time_jump + context_frame_adjustment > 0 ? time_jump + context_frame_adjustment : 0;
+}
+
+float fa_oracle_tdt_clamp_probability(float v) {
+    /* TdtDurationMapping.swift:28-31 */
+    if (!isfinite(v)) return 0.0f;
+    return fmaxf(0.0f, fminf(1.0f, v));
+}
+
+typedef struct {
+    const int32_t *tok, *bin; const float *prob; int U, T, u;
+    const int *bins; int nbins;
+    int token, duration, err; float score;
+} tdt_joint;
+
+static int tdt_run_joint(tdt_joint *j, int frame) { /* TdtModelInference.runJointPrepared, served from the decision tables */
+    if (j->u >= j->U || frame < 0 || frame >= j->T) { j->err = 3; return 0; }
+    const long i = (long)j->u * j->T + frame;
+    j->token = j->tok[i];
+    j->score = fa_oracle_tdt_clamp_probability(j->prob[i]);
+    if (j->bin[i] < 0 || j->bin[i] >= j->nbins) { j->err = 5; return 0; } /* mapDurationBin throws (TdtDurationMapping.swift:17-22) */
+    j->duration = j->bins[j->bin[i]];
+    return 1;
+}
+
+/* TdtDecoderV3.decodeWithTimings (TdtDecoderV3.swift:103-607) for ONE chunk with language == nil; the joint decisions come
+ * from tables [U][T] indexed by (decoder steps taken, encoder frame).  Returns the status (0 ok, 5 duration bin out of
+ * range, 3 table/output exhausted); *final_time == INT32_MIN when the reference returns before updating timeJump. */
+int fa_oracle_tdt_greedy(const int32_t *tok, const int32_t *bin, const float *prob, int U, int T, int enc_len, int audio_frames,
+                         int t0, int is_last, int global_offset, int emit_after, int blank_id, int max_symbols, int max_tokens,
+                         int blank_limit, const int *bins, int nbins, int max_out, int32_t *out_tok, int32_t *out_time,
+                         int32_t *out_dur, float *out_conf, int *out_count, int *final_time, int *final_u) {
+    tdt_joint j = {tok, bin, prob, U, T, 0, bins, nbins, blank_id, 0, 0, 0.0f};
+    int count = 0, status = 0;
+    *out_count = 0; *final_u = 0; *final_time = INT32_MIN;
+    if (enc_len <= 1) return 0;                                         /* :110-112 */
+    int time_indices = t0;
+    const int effective = enc_len < audio_frames ? enc_len : audio_frames;
+    int safe = time_indices < effective - 1 ? time_indices : effective - 1;
+    const int last_timestep = effective - 1;
+    int active = time_indices < effective;
+    int time_indices_current_labels = time_indices;
+    if (time_indices >= effective) return 0;                            /* :150-152 */
+    int last_emission_timestamp = -1, emissions_at_this_timestamp = 0, tokens_processed = 0;
+    int label = blank_id, duration = 0; float score = 0.0f;
+#define TDT_EMIT(ts)                                                                                         \
+    do {                                                                                                     \
+        if (emit_after < 0 || (ts) >= emit_after) {                                                          \
+            if (count < max_out) { out_tok[count] = label; out_time[count] = (ts); out_dur[count] = duration; out_conf[count] = score; } \
+            else status = 3;                                                                                 \
+            ++count;                                                                                         \
+        }                                                                                                    \
+    } while (0)
+    while (active) {                                                    /* :230 */
+        if (!tdt_run_joint(&j, safe)) { status = j.err; goto done; }
+        label = j.token; score = j.score; duration = j.duration;
+        int blank_mask = label == blank_id;
+        const int current_time_index = time_indices;
+        if (!blank_mask && duration == 0 && current_time_index == last_emission_timestamp && emissions_at_this_timestamp >= 1) duration = 1;
+        if (blank_mask && duration == 0) duration = 1;
+        time_indices_current_labels = time_indices;
+        time_indices += duration;
+        safe = time_indices < last_timestep ? time_indices : last_timestep;
+        active = time_indices < effective;
+        int advance = active && blank_mask;
+        while (advance) {                                               /* :348-405 */
+            time_indices_current_labels = time_indices;
+            if (!tdt_run_joint(&j, safe)) { status = j.err; goto done; }
+            label = j.token; score = j.score; duration = j.duration;
+            blank_mask = label == blank_id;
+            if (blank_mask && duration == 0) duration = 1;
+            time_indices += duration;
+            safe = time_indices < last_timestep ? time_indices : last_timestep;
+            active = time_indices < effective;
+            advance = active && blank_mask;
+        }
+        if (active && label != blank_id) {                              /* :409 */
+            tokens_processed += 1;
+            if (tokens_processed > max_tokens) break;
+            TDT_EMIT(time_indices_current_labels + global_offset);
+            j.u += 1;                                                   /* runDecoder(token) (:433-444) */
+            if (time_indices_current_labels == last_emission_timestamp) emissions_at_this_timestamp += 1;
+            else { last_emission_timestamp = time_indices_current_labels; emissions_at_this_timestamp = 1; }
+            if (emissions_at_this_timestamp >= max_symbols) {
+                time_indices = time_indices + 1 < last_timestep ? time_indices + 1 : last_timestep;
+                safe = time_indices < last_timestep ? time_indices : last_timestep;
+                emissions_at_this_timestamp = 0;
+                last_emission_timestamp = -1;
+            }
+        }
+        active = time_indices < effective;
+    }
+    if (is_last) {                                                      /* :472-571 */
+        int additional = 0, consecutive_blanks = 0, fp = time_indices;
+        while (additional < max_symbols && consecutive_blanks < blank_limit) {
+            int var[3];
+            var[0] = fp < enc_len - 1 ? fp : enc_len - 1;
+            var[1] = effective - 1 < enc_len - 1 ? effective - 1 : enc_len - 1;
+            var[2] = (effective - 2 > 0 ? effective - 2 : 0) < enc_len - 1 ? (effective - 2 > 0 ? effective - 2 : 0) : enc_len - 1;
+            if (!tdt_run_joint(&j, var[additional % 3])) { status = j.err; goto done; }
+            label = j.token; score = j.score; duration = j.duration;
+            if (label == blank_id) consecutive_blanks += 1;
+            else {
+                consecutive_blanks = 0;
+                const int final_ts = (fp < effective - 1 ? fp : effective - 1) + global_offset;
+                TDT_EMIT(final_ts);
+                j.u += 1;
+            }
+            const int adv = duration > 1 ? duration : 1;
+            fp = fp + adv < effective ? fp + adv : effective;
+            additional += 1;
+        }
+    }
+    *final_time = time_indices;
+done:
+    *out_count = count; *final_u = j.u;
+    return status;
+#undef TDT_EMIT
+}

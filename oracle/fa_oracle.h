@@ -159,6 +159,15 @@ void fa_oracle_max_score_assignment(const double *scores, int rows, int cols, in
 void fa_oracle_constrained_assign(const double *scores, long n, int K, const int32_t *chunk, int32_t *out);
 void fa_oracle_centroid_scores(const double *emb, long n, long d, const double *centroids, long K, double *scores);
 
+/* TDT greedy control flow (FluidAudio/ASR/Parakeet/SlidingWindow/TDT/Decoder/TdtDecoderV3.swift:103-607,
+ * TdtFrameNavigation.swift:20-105, TdtDurationMapping.swift:17-31); joint decisions served from [U][T] tables */
+int fa_oracle_tdt_initial_time_index(int has_time_jump, int time_jump, int context_frame_adjustment);
+float fa_oracle_tdt_clamp_probability(float v);
+int fa_oracle_tdt_greedy(const int32_t *tok, const int32_t *bin, const float *prob, int U, int T, int enc_len, int audio_frames,
+                         int t0, int is_last, int global_offset, int emit_after, int blank_id, int max_symbols, int max_tokens,
+                         int blank_limit, const int *bins, int nbins, int max_out, int32_t *out_tok, int32_t *out_time,
+                         int32_t *out_dur, float *out_conf, int *out_count, int *final_time, int *final_u);
+
 #ifdef __cplusplus
 }
 #endif
