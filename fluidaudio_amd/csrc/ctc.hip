@@ -169,6 +169,78 @@ __global__ __launch_bounds__(kThreads) void ctc_greedy_kernel(const CtcArgs a) {
     if (tid == 0) a.token_lens[b] = carry_count;
 }
 
+// Per-frame log-softmax with temperature and blank bias as CtcKeywordSpotter.makeLogProbs / logSoftmax do it
+// (reference: Sources/FluidAudio/ASR/Parakeet/SlidingWindow/CustomVocabulary/WordSpotting/CtcKeywordSpotter+Inference.swift:350-431):
+// x / temperature (only when temperature != 1), max, sum of expf(x - max), (x - max) - logf(sum); then blankBias is
+// subtracted from the blank column.  One wavefront per row; the row is read ONCE from HBM and lives in registers
+// (up to 64 lanes x 32 values), so the kernel moves 2 x 4 T V bytes per matrix.
+constexpr int kLsmRegs = 32;  // values per lane held in registers: V <= 2048 single pass
+
+struct LsmArgs {
+    const void *logits;
+    float *out;
+    int64_t row_stride, matrix_stride, out_row_stride, out_matrix_stride, rows_total;
+    int32_t frames, vocab, blank_id;
+    float inv_temp_unused, temperature, blank_bias;
+};
+
+template <bool F16>
+__device__ __forceinline__ float lsm_load(const void *row, const int i) {
+    return F16 ? __half2float(static_cast<const __half *>(row)[i]) : static_cast<const float *>(row)[i];
+}
+
+template <bool F16>
+__global__ __launch_bounds__(kThreads) void ctc_log_softmax_kernel(const LsmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kWaves + (threadIdx.x >> 6);
+    if (r >= a.rows_total) return;
+    const int64_t b = r / a.frames, t = r % a.frames;
+    const size_t esz = F16 ? 2 : 4;
+    const char *row = static_cast<const char *>(a.logits) + (static_cast<size_t>(b) * a.matrix_stride + static_cast<size_t>(t) * a.row_stride) * esz;
+    float *orow = a.out + b * a.out_matrix_stride + t * a.out_row_stride;
+    const int V = a.vocab;
+    const bool scale = a.temperature != 1.0f;
+    float x[kLsmRegs];
+    float mx = -INFINITY;
+    const bool in_regs = V <= 64 * kLsmRegs;
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < kLsmRegs; ++j) {
+            const int i = lane + 64 * j;
+            float v = -INFINITY;
+            if (i < V) { v = lsm_load<F16>(row, i); if (scale) v = v / a.temperature; }
+            x[j] = v;
+            mx = fmaxf(mx, v);
+        }
+    } else {
+        for (int i = lane; i < V; i += 64) { float v = lsm_load<F16>(row, i); if (scale) v = v / a.temperature; mx = fmaxf(mx, v); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.0f;
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < kLsmRegs; ++j) if (lane + 64 * j < V) sum += expf(x[j] - mx);
+    } else {
+        for (int i = lane; i < V; i += 64) { float v = lsm_load<F16>(row, i); if (scale) v = v / a.temperature; sum += expf(v - mx); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float lse = logf(sum);
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < kLsmRegs; ++j) {
+            const int i = lane + 64 * j;
+            if (i < V) { float o = (x[j] - mx) - lse; if (i == a.blank_id && a.blank_bias != 0.0f) o -= a.blank_bias; orow[i] = o; }
+        }
+    } else {
+        for (int i = lane; i < V; i += 64) {
+            float v = lsm_load<F16>(row, i); if (scale) v = v / a.temperature;
+            float o = (v - mx) - lse; if (i == a.blank_id && a.blank_bias != 0.0f) o -= a.blank_bias; orow[i] = o;
+        }
+    }
+}
+
 fa_status check_args(fa_ctx *ctx, const void *logits, int dtype, int batch, int frames, int vocab, int64_t row_stride,
                      int64_t matrix_stride, const int32_t *token_ids, const int32_t *token_lens) {
     if (!ctx || !token_ids || !token_lens) return FA_INVALID_ARGUMENT;
@@ -234,6 +306,27 @@ fa_status fa_ctc_greedy_batch(fa_ctx *ctx, const void *logits, int32_t dtype, in
     } while (0);
     if (st != FA_SUCCESS) return st;
     return fa::hip_status(ctx, e, "fa_ctc_greedy_batch");
+}
+
+fa_status fa_ctc_log_softmax_batch_dev(fa_ctx *ctx, const void *d_logits, int32_t dtype, int32_t batch, int32_t frames, int32_t vocab,
+                                       int64_t row_stride, int64_t matrix_stride, float temperature, float blank_bias, int32_t blank_id,
+                                       float *d_log_probs) {
+    if (!ctx || !d_log_probs) return FA_INVALID_ARGUMENT;
+    if (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_F16) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "log_softmax: bad dtype");
+    if (batch < 0 || frames < 0 || vocab < 1 || row_stride < vocab || !(temperature > 0.0f)) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "log_softmax: bad shape");
+    if (batch == 0 || frames == 0) return FA_SUCCESS;
+    if (!d_logits || matrix_stride < static_cast<int64_t>(frames - 1) * row_stride + vocab) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "log_softmax: bad strides");
+    fa::DeviceGuard guard(ctx->device);
+    LsmArgs a{};
+    a.logits = d_logits; a.out = d_log_probs; a.row_stride = row_stride; a.matrix_stride = matrix_stride;
+    a.out_row_stride = vocab; a.out_matrix_stride = static_cast<int64_t>(frames) * vocab;
+    a.rows_total = static_cast<int64_t>(batch) * frames; a.frames = frames; a.vocab = vocab; a.blank_id = blank_id;
+    a.temperature = temperature; a.blank_bias = blank_bias;
+    const unsigned grid = static_cast<unsigned>((a.rows_total + kWaves - 1) / kWaves);
+    if (dtype == FA_DTYPE_F16) hipLaunchKernelGGL(ctc_log_softmax_kernel<true>, dim3(grid), dim3(kThreads), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(ctc_log_softmax_kernel<false>, dim3(grid), dim3(kThreads), 0, ctx->stream, a);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
 }
 
 }  // extern "C"

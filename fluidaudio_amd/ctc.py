@@ -94,3 +94,18 @@ def ctc_greedy_decode(log_probs, vocabulary: dict[int, str], blank_id: int = 102
             return ""
     ids = ctc_greedy_ids_batch(x, blank_id, ctx=ctx)[0]
     return decode_ctc_token_ids(ids, vocabulary)
+
+
+def ctc_log_probs_dev(ctx, d_logits, temperature: float = 1.0, blank_bias: float = 0.0, blank_id: int = -1, d_out=None):
+    """makeLogProbs (CtcKeywordSpotter+Inference.swift:350-405) for a batch: d_logits torch CUDA [B, T, V] fp32/fp16
+    (last dim contiguous) -> float32 CUDA tensor [B, T, V].  Enqueues on ctx.stream."""
+    import torch
+    B, T, V = d_logits.shape
+    assert d_logits.stride(2) == 1
+    if d_out is None:
+        d_out = torch.empty((B, T, V), dtype=torch.float32, device=d_logits.device)
+    dt = L.DTYPE_F16 if d_logits.dtype == torch.float16 else L.DTYPE_F32
+    ctx.check(L.lib().fa_ctc_log_softmax_batch_dev(ctx.handle, C.c_void_p(d_logits.data_ptr()), dt, B, T, V, d_logits.stride(1),
+                                                   d_logits.stride(0), float(temperature), float(blank_bias), int(blank_id),
+                                                   C.c_void_p(d_out.data_ptr())), "fa_ctc_log_softmax_batch_dev")
+    return d_out

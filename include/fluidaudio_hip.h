@@ -143,6 +143,14 @@ fa_status fa_ctc_greedy_batch(fa_ctx *ctx, const void *logits, int32_t dtype, in
                               const int32_t *valid_frames, int32_t blank_id, int32_t *frame_ids,
                               int32_t *token_ids, int32_t *token_lens);
 
+/* Per-frame log-softmax with temperature and blank bias: CtcKeywordSpotter.makeLogProbs / logSoftmax
+ * (FluidAudio/ASR/Parakeet/SlidingWindow/CustomVocabulary/WordSpotting/CtcKeywordSpotter+Inference.swift:350-431).
+ * DEVICE pointers; logits addressed like fa_ctc_greedy_batch_dev; d_log_probs: float[batch][frames][vocab] contiguous.
+ * blank_bias is subtracted from column blank_id when != 0 (:397-399); temperature divides the logits when != 1 (:412). */
+fa_status fa_ctc_log_softmax_batch_dev(fa_ctx *ctx, const void *d_logits, int32_t dtype, int32_t batch, int32_t frames,
+                                       int32_t vocab, int64_t row_stride, int64_t matrix_stride, float temperature,
+                                       float blank_bias, int32_t blank_id, float *d_log_probs);
+
 /* ------------------------------------------------------------------ TDT ------------- */
 /* Control flow of TdtDecoderV3.decodeWithTimings (FluidAudio/ASR/Parakeet/SlidingWindow/TDT/Decoder/TdtDecoderV3.swift:103-607)
  * and its helpers (TdtFrameNavigation.swift:20-105, TdtDurationMapping.swift:17-31, TdtConfig.swift:13-26).  The decoder

@@ -98,6 +98,8 @@ def lib() -> C.CDLL:
         L.fa_oracle_weighted_centroids.argtypes = [_f64p, C.c_long, C.c_long, _f64p, _f64p, C.c_long, _f64p, _i32p]
         L.fa_oracle_weighted_centroids.restype = C.c_long
         L.fa_oracle_assign_cosine.argtypes = [_f64p, C.c_long, C.c_long, _f64p, C.c_long, _i32p]
+        L.fa_oracle_log_softmax_row.argtypes = [_f32p, C.c_int, C.c_float, C.c_float, C.c_int, _f32p]
+        L.fa_oracle_log_softmax_row.restype = None
         L.fa_oracle_tdt_initial_time_index.argtypes = [C.c_int, C.c_int, C.c_int]
         L.fa_oracle_tdt_clamp_probability.argtypes = [C.c_float]
         L.fa_oracle_tdt_clamp_probability.restype = C.c_float
@@ -435,3 +437,12 @@ def tdt_greedy(tok, dur_bin, prob, enc_len, audio_frames=None, t0=0, is_last=Fal
     n = min(cnt.value, max_out)
     return dict(status=st, tokens=ot[:n].copy(), timestamps=oti[:n].copy(), durations=od[:n].copy(), confidences=oc[:n].copy(),
                 count=cnt.value, final_time=None if ft.value == -2 ** 31 else ft.value, final_u=fu.value)
+
+
+def ctc_log_probs(logits, temperature: float = 1.0, blank_bias: float = 0.0, blank_id: int = -1) -> np.ndarray:
+    """CtcKeywordSpotter.makeLogProbs (:350-405) on a [T, V] float32 matrix."""
+    x = np.ascontiguousarray(logits, np.float32)
+    out = np.zeros_like(x)
+    for t in range(x.shape[0]):
+        lib().fa_oracle_log_softmax_row(x[t], x.shape[1], temperature, blank_bias, blank_id, out[t])
+    return out

@@ -964,3 +964,15 @@ done:
     return status;
 #undef TDT_EMIT
 }
+
+/* CtcKeywordSpotter.logSoftmax + blank bias (CtcKeywordSpotter+Inference.swift:397-431), one row */
+void fa_oracle_log_softmax_row(const float *logits, int V, float temperature, float blank_bias, int blank_id, float *out) {
+    if (V <= 0) return;
+    float mx = -INFINITY;
+    for (int i = 0; i < V; ++i) { const float v = temperature != 1.0f ? logits[i] / temperature : logits[i]; out[i] = v; if (v > mx) mx = v; }
+    float sum = 0.0f;
+    for (int i = 0; i < V; ++i) sum += expf(out[i] - mx);
+    const float lse = logf(sum);
+    for (int i = 0; i < V; ++i) out[i] = (out[i] - mx) - lse;
+    if (blank_bias != 0.0f && blank_id >= 0 && blank_id < V) out[blank_id] -= blank_bias;
+}

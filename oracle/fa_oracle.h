@@ -168,6 +168,9 @@ int fa_oracle_tdt_greedy(const int32_t *tok, const int32_t *bin, const float *pr
                          int blank_limit, const int *bins, int nbins, int max_out, int32_t *out_tok, int32_t *out_time,
                          int32_t *out_dur, float *out_conf, int *out_count, int *final_time, int *final_u);
 
+/* CtcKeywordSpotter.logSoftmax + blank bias (CtcKeywordSpotter+Inference.swift:397-431) */
+void fa_oracle_log_softmax_row(const float *logits, int V, float temperature, float blank_bias, int blank_id, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,3 +95,22 @@ def test_full_size_config4_slice_properties(fa, gpu_ctx, oracle_mod):
     assert torch.equal(lens, lens2)
     m = torch.arange(T, device="cuda")[None, :] < lens[:, None]
     assert torch.equal(tok[m], tok2[m])
+
+
+@pytest.mark.parametrize("T,V,dtype,temp,bias", [(50, 1025, "float32", 1.0, 0.0), (37, 1024, "float32", 1.7, 2.5),
+                                                  (20, 257, "float16", 0.5, 1.0), (9, 5000, "float32", 1.3, 0.5), (5, 1, "float32", 1.0, 0.0)])
+def test_log_softmax_with_temperature_and_blank_bias(fa, gpu_ctx, oracle_mod, T, V, dtype, temp, bias):
+    """makeLogProbs / logSoftmax (CtcKeywordSpotter+Inference.swift:350-431); fp32 sums in a different order: 2e-6 abs."""
+    import torch
+    rng = np.random.default_rng(T * V)
+    x = (rng.standard_normal((3, T, V)) * 3).astype(dtype)
+    blank = V - 1
+    d = fa.ctc_log_probs_dev(gpu_ctx, torch.from_numpy(x).cuda(), temp, bias, blank)
+    gpu_ctx.synchronize()
+    got = d.cpu().numpy()
+    for b in range(3):
+        ref = oracle_mod.ctc_log_probs(x[b].astype(np.float32), temp, bias, blank)
+        np.testing.assert_allclose(got[b], ref, rtol=0, atol=4e-6 * max(1.0, float(np.abs(ref).max()) / 10))
+    p = np.exp(got.astype(np.float64))
+    p[:, :, blank] *= np.exp(bias)
+    np.testing.assert_allclose(p.sum(-1), 1.0, atol=2e-5)
