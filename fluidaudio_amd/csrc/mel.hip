@@ -50,6 +50,7 @@ struct MelArgs {
     int32_t hop, pad, stage_count, stage_alloc, out_alloc;
     float preemph, log_floor;
     int32_t floor_clamped;
+    unsigned long long *prof;  // FA_MEL_PROF env (diagnostics): per-phase cycle sums of one workgroup's wave 0
 };
 
 // lane l <- lane (16 - l) & 15 inside every row of 16 lanes: row_mirror (l <- 15 - l), then row_ror:1 (l <- l - 1)
@@ -77,6 +78,7 @@ struct TileInfo {
     float lastv;
     int t0, T;
     bool stage;      // tile has frames to compute
+    bool interior;   // the whole staged span (and the sample before it) lies inside the utterance
 };
 
 template <int LAYOUT, bool FAST>
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
         ti.lastv = a.last ? a.last[b] : 0.0f;
         ti.n0 = static_cast<int64_t>(ti.t0) * a.hop - a.pad;
         ti.stage = ti.t0 < ti.T;
+        ti.interior = ti.n0 >= 1 && ti.n0 + kStageVec * kThreads * 4 <= ti.len;
         if (ti.t0 == 0 && tid == 0 && a.lengths) a.lengths[b] = ti.T;
         return ti;
     };
@@ -137,26 +140,27 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
     float4 raw[kStageVec];
     float rprev[kStageVec];
     auto fetch = [&](const TileInfo &ti) {
+        if (ti.interior) {  // workgroup-uniform: straight-line independent loads, one memory round trip for the whole tile
 #pragma unroll
-        for (int r = 0; r < kStageVec; ++r) {
+            for (int r = 0; r < kStageVec; ++r) {
+                const float *src = ti.x + ti.n0 + 4 * (tid + kThreads * r);
+                raw[r] = *reinterpret_cast<const float4 *>(src);
+                rprev[r] = src[-1];
+            }
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < kStageVec; ++r) {  // utterance edges (first / last tiles): guarded scalar loads
             const int e = 4 * (tid + kThreads * r);
             const int64_t n = ti.n0 + e;
-            raw[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rprev[r] = 0.f;
-            if (e >= a.stage_alloc) continue;
-            if (n >= 1 && n + 3 < ti.len) {  // interior: one 16-byte load + the preceding sample
-                raw[r] = *reinterpret_cast<const float4 *>(ti.x + n);
-                rprev[r] = ti.x[n - 1];
-            } else {                          // utterance edges: guarded scalar loads
-                float t[5];
+            float t[5];
 #pragma unroll
-                for (int c = 0; c < 5; ++c) {
-                    const int64_t m = n - 1 + c;
-                    t[c] = m >= 0 && m < ti.len ? ti.x[m] : (m == -1 ? ti.lastv : 0.f);
-                }
-                rprev[r] = t[0];
-                raw[r] = make_float4(t[1], t[2], t[3], t[4]);
+            for (int c = 0; c < 5; ++c) {
+                const int64_t m = n - 1 + c;
+                t[c] = e < a.stage_alloc && m >= 0 && m < ti.len ? ti.x[m] : (m == -1 ? ti.lastv : 0.f);
             }
+            rprev[r] = t[0];
+            raw[r] = make_float4(t[1], t[2], t[3], t[4]);
         }
     };
     auto stage = [&](const TileInfo &ti) {  // pre-emphasis (:211,:219-225: y[n] = x[n] - p x[n-1]); zero outside [0, len)
@@ -164,13 +168,13 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
         for (int r = 0; r < kStageVec; ++r) {
             const int e = 4 * (tid + kThreads * r);
             if (e >= a.stage_alloc) continue;
-            const int64_t n = ti.n0 + e;
             float4 y;
             y.x = raw[r].x - a.preemph * rprev[r];
             y.y = raw[r].y - a.preemph * raw[r].x;
             y.z = raw[r].z - a.preemph * raw[r].y;
             y.w = raw[r].w - a.preemph * raw[r].z;
-            if (!(n >= 0 && n + 3 < ti.len)) {
+            if (!ti.interior) {
+                const int64_t n = ti.n0 + e;
                 if (n < 0 || n >= ti.len) y.x = 0.f;
                 if (n + 1 < 0 || n + 1 >= ti.len) y.y = 0.f;
                 if (n + 2 < 0 || n + 2 >= ti.len) y.z = 0.f;
@@ -180,6 +184,14 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
         }
     };
 
+    unsigned long long t_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = clock64();
+#define MEL_STAMP(i) do { if (a.prof) { const unsigned long long t_now = clock64(); t_seg[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+    // All table / constant loads are complete from here on (vmcnt(0), expcnt/lgkmcnt untouched).  Without this explicit
+    // instruction the wait-count pass keeps them "possibly pending" around the tile loop and guards the first LDS reads of
+    // every pass with s_waitcnt vmcnt(<=3), which also drains the next tile's prefetch loads (vmcnt retires in order) and
+    // exposes a full HBM round trip per tile.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     TileInfo cur = first < stop ? tile_info(first) : TileInfo{};
     if (first < stop && cur.stage && vec_stage) fetch(cur);
 
@@ -194,19 +206,22 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
                     samples[i] = y;
                 }
         }
+        MEL_STAMP(0);
         __syncthreads();
+        MEL_STAMP(1);
         // the next tile's samples travel from HBM while this tile is computed
         TileInfo nxt{};
         nxt.stage = false;
         if (tl + 1 < stop) { nxt = tile_info(tl + 1); if (nxt.stage && vec_stage) fetch(nxt); }
 
+        MEL_STAMP(2);
         if (cur.stage) {  // workgroup-uniform
-            float *R = regions + grp * kRegionFloats;
+            float *R = static_cast<float *>(__builtin_assume_aligned(regions + grp * kRegionFloats, 8));
 #pragma unroll 1
             for (int pass = 0; pass < kPasses; ++pass) {
                 // frame of this 16-lane group inside the tile: wave w owns frames [8w, 8w + 8)
                 const int f = (grp >> 2) * (kWaveFrames * kPasses) + pass * kWaveFrames + (grp & 3);
-                const float *fs = samples + f * a.hop;
+                const float *fs = hop_even ? static_cast<const float *>(__builtin_assume_aligned(samples + f * a.hop, 8)) : samples + f * a.hop;
                 Lane v;
                 if (hop_even) {
 #pragma unroll
@@ -270,7 +285,9 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
                 }
             }
         }
+        MEL_STAMP(3);
         __syncthreads();
+        MEL_STAMP(4);
 
         if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) {
             // 8 threads per mel row, 4 consecutive frames each: 16-byte LDS reads, 16-byte global stores (:287)
@@ -296,8 +313,14 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
         }
         // the next tile's staging writes `samples` (no reader left) and its barrier orders the `outs` reads above
         // before the next writes
+        MEL_STAMP(5);
         cur = nxt;
     }
+    if (a.prof && blockIdx.x == gridDim.x / 2 && tid == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&a.prof[i], t_seg[i]);
+        atomicAdd(&a.prof[7], static_cast<unsigned long long>(stop - first));
+    }
+#undef MEL_STAMP
 }
 
 // NeMo per_feature normalisation as done by UnifiedMelExtractor.normalizePerFeature
@@ -600,6 +623,19 @@ fa_status fa_mel_execute_dev(fa_mel_plan *p, const float *d_pcm, const float *d_
     fa::DeviceGuard guard(ctx->device);
     MelArgs a = p->args;
     a.pcm = d_pcm; a.last = d_last; a.out = d_mel; a.lengths = d_lengths;
+    static unsigned long long *s_prof = nullptr;
+    static int s_prof_calls = 0;
+    if (getenv("FA_MEL_PROF")) {  // diagnostics only: per-phase cycles of one workgroup, printed every 10 launches
+        if (!s_prof) { (void)hipMalloc(&s_prof, 64); (void)hipMemset(s_prof, 0, 64); }
+        a.prof = s_prof;
+        if (++s_prof_calls % 10 == 0) {
+            unsigned long long h[8];
+            (void)hipMemcpy(h, s_prof, 64, hipMemcpyDeviceToHost);
+            const double n = h[7] ? static_cast<double>(h[7]) : 1.0;
+            fprintf(stderr, "mel profile (cycles per tile, wave 0 of one workgroup, %llu tiles): stage-write %.0f | barrier1 %.0f | prefetch issue %.0f | passes %.0f | barrier2 %.0f | store %.0f\n",
+                    h[7], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n);
+        }
+    } else a.prof = nullptr;
     const bool mm = p->cfg.layout == FA_MEL_LAYOUT_MEL_MAJOR;
     if (mm && p->fast) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, true>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
     else if (mm) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, false>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
