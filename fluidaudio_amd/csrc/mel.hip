@@ -11,6 +11,7 @@
 // LDS region only to be gathered by the sparse triangular filterbank.  Log-mel values are staged in LDS
 // and stored by the whole workgroup as full rows ([n_mels, T]: 128-byte runs; [T, n_mels]: contiguous).
 // HBM traffic per 15 s utterance = 960 000 B read + 768 512 B written.
+#include <climits>
 #include <cmath>
 #include <vector>
 
@@ -122,8 +123,10 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
 
     auto tile_info = [&](const int64_t tl) {
         TileInfo ti;
-        const int b = static_cast<int>(tl / a.tiles_per_utt);
-        ti.t0 = static_cast<int>(tl % a.tiles_per_utt) * kTileFrames;
+        // workgroup-uniform values, forced into SGPRs: the metadata loads below become scalar loads
+        const int tli = __builtin_amdgcn_readfirstlane(static_cast<int>(tl));
+        const int b = tli / a.tiles_per_utt;
+        ti.t0 = (tli - b * a.tiles_per_utt) * kTileFrames;
         ti.T = a.frames[b];
         const int64_t base = a.offsets[b];
         ti.len = a.offsets[b + 1] - base;
@@ -289,8 +292,18 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
         __syncthreads();
         MEL_STAMP(4);
 
-        if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) {
-            // 8 threads per mel row, 4 consecutive frames each: 16-byte LDS reads, 16-byte global stores (:287)
+        const bool full_tile = cur.t0 + kTileFrames <= cur.T && cur.t0 + kTileFrames <= a.frame_stride;
+        if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR && FAST && full_tile) {
+            // 8 threads per mel row, 4 consecutive frames each: 16-byte LDS reads, 16-byte global stores (:287); a fixed number
+            // of stores per thread keeps the wait count for the next tile's prefetch exact (vmcnt(4) instead of vmcnt(0))
+#pragma unroll
+            for (int it = 0; it < kFastGroups * kGroup * (kTileFrames / 4) / kThreads; ++it) {
+                const int idx = tid + kThreads * it, m = idx >> 3, f = (idx & 7) * 4;
+                if (m < n_mels)
+                    *reinterpret_cast<float4 *>(cur.ob + static_cast<int64_t>(m) * a.frame_stride + cur.t0 + f) =
+                        *reinterpret_cast<const float4 *>(outs + m * kMelPad + f);
+            }
+        } else if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) {
             for (int idx = tid; idx < n_mels * (kTileFrames / 4); idx += kThreads) {
                 const int m = idx >> 3, f = (idx & 7) * 4, t = cur.t0 + f;
                 if (t >= a.frame_stride) continue;
@@ -568,6 +581,7 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         a.utt_stride = p->utt_stride;
         a.tiles_per_utt = (frame_stride + kTileFrames - 1) / kTileFrames;
         a.total_tiles = static_cast<int64_t>(a.tiles_per_utt) * batch;
+        if (a.total_tiles > INT32_MAX) { (void)hipFree(p->dev); delete p; return fa::set_error(ctx, FA_INDEX_OVERFLOW, "mel: too many tiles in one plan"); }
         a.frame_stride = frame_stride;
         a.n_mels = cfg->n_mels;
         a.n_weights = static_cast<int32_t>(weights.size());
