@@ -173,7 +173,14 @@ def e2e_leg(fa, ctx, torch, hours=8.0, speakers=12):
     t_cl = time.perf_counter() - t0
     lab = np.asarray(res.assignments)
     pure = len(set(zip(spk.tolist(), lab.tolist()))) == speakers
-    return {"audio_hours": hours, "mel_chunks": n_chunks15, "mel_s": t_mel, "embeddings": n, "cluster_s": t_cl,
+    # the speaker-count fallback on the same embeddings: best-of-10 K-Means to speakers - 2 (VBxClustering.swift:716-722)
+    emb64 = emb.astype(np.float64)
+    fa.KMeansClustering.cluster_with_centroids_n_init(emb64[:3000], speakers - 2, 100, 10, 0, ctx=ctx)
+    t0 = time.perf_counter()
+    det = {}
+    km, _ = fa.KMeansClustering.cluster_with_centroids_n_init(emb64, speakers - 2, 100, 10, 0, ctx=ctx, details=det)
+    t_km = time.perf_counter() - t0
+    return {"audio_hours": hours, "kmeans_fallback_s": t_km, "kmeans_clusters": len(set(km)), "mel_chunks": n_chunks15, "mel_s": t_mel, "embeddings": n, "cluster_s": t_cl,
             "stages_s": res.timings, "speakers_true": speakers, "clusters_found": int(res.centroids.shape[0]),
             "labels_match_speakers": bool(pure), "audio_hours_per_s": hours / (t_mel + t_cl),
             "note": "host-pointer clustering entries (PCIe copies included); mel inputs resident in HBM"}

@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_cluster", "fa_ahc_cut",
     "fa_vbx_speaker_count", "fa_vbx_refine",
     "fa_vbx_weighted_centroids", "fa_assign_cosine", "fa_centroid_scores", "fa_constrained_assign",
+    "fa_seeded_rng_next", "fa_seeded_rng_below", "fa_kmeans_cluster", "fa_kmeans_cluster_ninit", "fa_speaker_constraints_resolve",
     "fa_resample_linear_frames", "fa_resample_linear", "fa_resample_poly_frames", "fa_resample_poly_taps", "fa_resample_poly",
 ]
 
@@ -143,6 +144,15 @@ def lib() -> C.CDLL:
     L.fa_assign_cosine.argtypes = [vp, vp, i64, i32, vp, i32, vp]
     L.fa_centroid_scores.argtypes = [vp, vp, i64, i32, vp, i32, vp]
     L.fa_constrained_assign.argtypes = [vp, vp, i64, i32, vp, vp]
+    u64 = C.c_uint64
+    L.fa_seeded_rng_next.argtypes = [C.POINTER(u64)]
+    L.fa_seeded_rng_next.restype = u64
+    L.fa_seeded_rng_below.argtypes = [C.POINTER(u64), u64]
+    L.fa_seeded_rng_below.restype = u64
+    L.fa_kmeans_cluster.argtypes = [vp, vp, i64, i32, i32, i32, u64, vp, vp, C.POINTER(i32), C.POINTER(i32)]
+    L.fa_kmeans_cluster_ninit.argtypes = [vp, vp, i64, i32, i32, i32, i32, u64, vp, vp, C.POINTER(i32), C.POINTER(i32), vp]
+    L.fa_speaker_constraints_resolve.argtypes = [i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64 * 3)]
+    L.fa_speaker_constraints_resolve.restype = None
     L.fa_resample_linear_frames.argtypes = [i64, f64, f64]
     L.fa_resample_linear_frames.restype = i64
     L.fa_resample_linear.argtypes = [vp, vp, i32, i64, f64, f64, vp, i64, C.POINTER(i64)]

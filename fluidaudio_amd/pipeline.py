@@ -6,8 +6,10 @@ the library's device stages — the "embeddings in -> final per-embedding cluste
     <= 20 iterations) -> gamma-weighted centroids of the active speakers (:613-691) -> cosine scores (:789-798) ->
     constrained per-chunk assignment (ConstrainedClusterAssignment, default) or plain argmax (:800-822).
 
-Segmentation, embedding extraction and PLDA are CoreML models in the reference (out of scope); speaker-count
-constraints with the K-Means fallback (VBxClustering.swift:685-733) are a "next" row and not wired here."""
+Speaker-count constraints (numSpeakers / minSpeakers / maxSpeakers, :308-326) route through
+``VBxClustering.refine_with_constraints`` and the batched K-Means fallback; as in the reference (:355-358) the constrained
+assignment is skipped when the count was forced.  Segmentation, embedding extraction and PLDA are CoreML models in the
+reference (out of scope)."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -16,6 +18,7 @@ import numpy as np
 
 from . import _lib as L
 from .ahc import AHCClustering
+from .kmeans import SpeakerCountConstraints
 from .post import ConstrainedClusterAssignment, assign_embeddings, centroid_scores, compute_centroids
 from .vbx import VBxClustering, VBxOutput
 
@@ -28,6 +31,9 @@ class OfflineClusteringConfig:  # OfflineDiarizerTypes.swift:155-163,189-192
     max_vbx_iterations: int = 20
     convergence_tolerance: float = 1e-4
     constrained_assignment: bool = True
+    num_speakers: int | None = None      # OfflineDiarizerTypes.swift clustering.numSpeakers / minSpeakers / maxSpeakers
+    min_speakers: int | None = None
+    max_speakers: int | None = None
 
 
 @dataclass
@@ -68,19 +74,23 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, config: Offline
     t["ahc_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     if trho.size and initial:
+        has = cfg.num_speakers is not None or cfg.min_speakers is not None or cfg.max_speakers is not None   # :309-312
+        cons = SpeakerCountConstraints.resolve(len(train), cfg.num_speakers, cfg.min_speakers, cfg.max_speakers) if has else None
         vbx = VBxClustering(phi, cfg.max_vbx_iterations, cfg.convergence_tolerance, cfg.warm_start_fa, cfg.warm_start_fb,
-                            ctx=ctx).refine(trho, initial)                   # :328-333 (no speaker-count constraints)
+                            ctx=ctx).refine_with_constraints(trho, temb, initial, cons)    # :328-333
     else:
         vbx = VBxOutput(np.zeros((0, 0)), np.zeros(0), [list(initial)], [], (max(initial) + 1) if initial else 0, [])
     t["vbx_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     centroids = np.zeros((0, emb.shape[1]))
-    if vbx.gamma.size and vbx.pi.size:
+    if vbx.was_adjusted and len(vbx.centroids):                              # K-Means centroids as they are (:622-629)
+        centroids = np.asarray(vbx.centroids, np.float64)
+    elif vbx.gamma.size and vbx.pi.size:
         centroids, _ = compute_centroids(temb, vbx.gamma, vbx.pi, ctx=ctx)  # :613-684
     if centroids.shape[0] == 0:                                              # computeCentroidsFromClusters (:686-) fallback
         labs = np.asarray(initial)
         centroids = np.stack([temb[labs == k].mean(0) for k in sorted(set(initial))]) if len(initial) else centroids
-    use_constrained = cfg.constrained_assignment and centroids.shape[0] > 1  # :355-358
+    use_constrained = cfg.constrained_assignment and not vbx.was_adjusted and centroids.shape[0] > 1  # :355-358
     if use_constrained:
         scores = centroid_scores(emb, centroids, ctx=ctx)
         assignments = ConstrainedClusterAssignment.assign(scores, chunk_indices, ctx=ctx)

@@ -20,10 +20,22 @@ class VBxOutput:
     centroids: list = field(default_factory=list)
     num_clusters: int = 0
     elbos: list = field(default_factory=list)
+    was_adjusted: bool = False                 # OfflineDiarizerTypes.swift VBxOutput.wasAdjusted
+    original_cluster_count: int | None = None
+
+    ACTIVE_CLUSTER_EPSILON = 1e-7
 
     @property
-    def assigned_cluster_count(self) -> int:
-        return len(set(self.hard_clusters[0])) if self.hard_clusters and len(self.hard_clusters[0]) else 0
+    def active_cluster_count(self) -> int:     # OfflineDiarizerTypes.swift:675-678
+        pi = np.asarray(self.pi)
+        return self.num_clusters if pi.size == 0 else int((pi > self.ACTIVE_CLUSTER_EPSILON).sum())
+
+    @property
+    def assigned_cluster_count(self) -> int:   # OfflineDiarizerTypes.swift:687-702: clusters that win some row's first-max argmax
+        g = np.asarray(self.gamma)
+        if g.size == 0:
+            return self.active_cluster_count
+        return len(set(np.argmax(g, axis=1).tolist()))
 
 
 class VBxClustering:
@@ -52,3 +64,18 @@ class VBxClustering:
                                         self.fb, self.max_iterations, self.tol, gamma.ctypes.data, pi.ctypes.data,
                                         hard.ctypes.data, elbos.ctypes.data, C.byref(it), C.byref(ns)), "fa_vbx_refine")
         return VBxOutput(gamma, pi, [[int(v) for v in hard]], [], S, [float(v) for v in elbos[:it.value]])
+
+    def refine_with_constraints(self, rho_features, training_embeddings, initial_clusters, constraints) -> VBxOutput:
+        """refineWithConstraints (:685-733): when the clusters the posteriors actually use fall outside [min, max] speakers,
+        re-cluster the training embeddings with best-of-10 K-Means (<= 100 iterations, seeds 0..9) to the nearest bound."""
+        from .kmeans import KMeansClustering
+        out = self.refine(rho_features, initial_clusters)
+        if constraints is None:
+            return out
+        detected = out.assigned_cluster_count
+        if not constraints.needs_adjustment(detected):
+            return out
+        target = constraints.target_count(detected)
+        clusters, centroids = KMeansClustering.cluster_with_centroids_n_init(training_embeddings, target, 100, 10, 0,
+                                                                             ctx=self._ctx)
+        return VBxOutput(out.gamma, out.pi, [clusters], centroids, target, out.elbos, True, detected)

@@ -256,6 +256,28 @@ fa_status fa_centroid_scores(fa_ctx *ctx, const double *emb, int64_t n, int32_t 
 fa_status fa_constrained_assign(fa_ctx *ctx, const double *scores, int64_t n, int32_t K, const int32_t *chunk_indices,
                                 int32_t *out);
 
+/* ------------------------------------------------ speaker-count constraints + K-Means fallback ------ */
+/* KMeansClustering.SeededRNG.next (FluidAudio/Diarizer/Offline/Clustering/KMeansClustering.swift:212-223) and the Swift
+ * standard library's RandomNumberGenerator.next(upperBound:) over it (Lemire's method; the draw behind shuffle(using:) and
+ * randomElement(using:)).  Pure host functions. */
+uint64_t fa_seeded_rng_next(uint64_t *state);
+uint64_t fa_seeded_rng_below(uint64_t *state, uint64_t upper_bound);
+/* KMeansClustering.clusterWithCentroids (:39-91): unit-normalise, centroids = first k of a seeded shuffle, Lloyd iterations
+ * until the assignment repeats or max_iterations; empty clusters re-seeded from a random embedding.  HOST pointers:
+ * emb double[n*d] -> labels int32[n], centroids double[min(k,n)*d] (nullable), *out_k = centroid rows written (0 for the
+ * degenerate returns: d == 0 or num_clusters <= 0 -> all labels 0; n <= k -> labels 0..n-1 and the raw embeddings). */
+fa_status fa_kmeans_cluster(fa_ctx *ctx, const double *emb, int64_t n, int32_t d, int32_t num_clusters, int32_t max_iterations,
+                            uint64_t seed, int32_t *labels, double *centroids, int32_t *out_k, int32_t *out_iterations);
+/* KMeansClustering.clusterWithCentroidsNInit (:99-129): seeds base_seed + 0..n_init-1, lowest inertia wins (first on ties).
+ * All runs advance together on the device.  best_run / inertias[n_init] nullable. */
+fa_status fa_kmeans_cluster_ninit(fa_ctx *ctx, const double *emb, int64_t n, int32_t d, int32_t num_clusters, int32_t max_iterations,
+                                  int32_t n_init, uint64_t base_seed, int32_t *labels, double *centroids, int32_t *out_k,
+                                  int32_t *best_run, double *inertias);
+/* SpeakerCountConstraints.resolve (FluidAudio/Diarizer/Offline/Clustering/SpeakerCountConstraints.swift:25-62).  A null
+ * pointer is Swift's nil.  out = { numSpeakers or -1 for nil, minSpeakers, maxSpeakers }. */
+void fa_speaker_constraints_resolve(int64_t num_embeddings, const int64_t *num_speakers, const int64_t *min_speakers,
+                                    const int64_t *max_speakers, int64_t out[3]);
+
 /* ------------------------------------------------------------------ resampling ------ */
 /* AudioConverter.linearResample (FluidAudio/Shared/AudioConverter.swift:388-442): planar float[channels][frames] ->
  * mono mix (weight 1/channels) -> linear interpolation to out_rate.  HOST pointers.  Bit-exact restatement. */

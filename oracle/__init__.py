@@ -99,6 +99,19 @@ def lib() -> C.CDLL:
         L.fa_oracle_weighted_centroids.restype = C.c_long
         L.fa_oracle_assign_cosine.argtypes = [_f64p, C.c_long, C.c_long, _f64p, C.c_long, _i32p]
         L.fa_oracle_log_softmax_row.argtypes = [_f32p, C.c_int, C.c_float, C.c_float, C.c_int, _f32p]
+        L.fa_oracle_seeded_rng_next.argtypes = [C.POINTER(C.c_uint64)]
+        L.fa_oracle_seeded_rng_next.restype = C.c_uint64
+        L.fa_oracle_rng_upper_bound.argtypes = [C.POINTER(C.c_uint64), C.c_uint64]
+        L.fa_oracle_rng_upper_bound.restype = C.c_uint64
+        L.fa_oracle_shuffle_indices.argtypes = [C.POINTER(C.c_uint64), C.c_long, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
+        L.fa_oracle_shuffle_indices.restype = None
+        L.fa_oracle_kmeans.argtypes = [_f64p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_uint64, _i32p, _f64p,
+                                       C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.fa_oracle_kmeans_ninit.argtypes = [_f64p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_long, C.c_uint64, _i32p, _f64p,
+                                             C.POINTER(C.c_long), C.POINTER(C.c_long), _f64p]
+        L.fa_oracle_speaker_constraints.argtypes = [C.c_long, C.c_int, C.c_long, C.c_int, C.c_long, C.c_int, C.c_long,
+                                                    C.POINTER(C.c_long * 3)]
+        L.fa_oracle_speaker_constraints.restype = None
         L.fa_oracle_log_softmax_row.restype = None
         L.fa_oracle_tdt_initial_time_index.argtypes = [C.c_int, C.c_int, C.c_int]
         L.fa_oracle_tdt_clamp_probability.argtypes = [C.c_float]
@@ -393,8 +406,9 @@ def centroid_scores(emb, centroids) -> np.ndarray:
 
 
 def cluster_embeddings(embedding256, rho128, chunk_indices, phi, threshold=0.6, Fa=0.07, Fb=0.8, max_iter=20, tol=1e-4,
-                       constrained=True):
-    """CPU restatement of OfflineDiarizerManager.cluster (:270-375) on precomputed embeddings (no speaker-count constraints)."""
+                       constrained=True, num_speakers=None, min_speakers=None, max_speakers=None):
+    """CPU restatement of OfflineDiarizerManager.cluster (:270-375) on precomputed embeddings, including the speaker-count
+    constraints of VBxClustering.refineWithConstraints (VBxClustering.swift:685-733)."""
     e32 = np.asarray(embedding256, np.float32)
     emb = e32.astype(np.float64)
     ok = np.isfinite(e32).all(axis=1)
@@ -402,12 +416,82 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, threshold=0.6, 
     temb, trho = emb[train], np.ascontiguousarray(rho128, np.float64)[train]
     initial = ahc_cluster(temb, threshold) if len(train) >= 2 else np.zeros(len(train), np.int32)
     gamma, pi, hard, elbos = vbx_refine(trho, initial, phi, max_iter, tol, Fa, Fb)
-    cent, _ = weighted_centroids(temb, gamma, pi)
-    if cent.shape[0] > 1 and constrained:
+    out = dict(initial=np.asarray(initial), gamma=gamma, pi=pi, was_adjusted=False)
+    if num_speakers is not None or min_speakers is not None or max_speakers is not None:
+        _, lo, hi = speaker_constraints(len(train), num_speakers, min_speakers, max_speakers)
+        detected = len(set(np.argmax(gamma, axis=1).tolist())) if gamma.size else int((np.asarray(pi) > 1e-7).sum())
+        if detected < lo or detected > hi:
+            target = min(max(detected, lo), hi)
+            km, cent, _, _ = kmeans_ninit(temb, target, 100, 10, 0)
+            out.update(was_adjusted=True, detected=detected, kmeans_clusters=km)
+    if not out["was_adjusted"]:
+        cent, _ = weighted_centroids(temb, gamma, pi)
+    if cent.shape[0] > 1 and constrained and not out["was_adjusted"]:
         assign = constrained_assign(centroid_scores(emb, cent), chunk_indices)
     else:
         assign = assign_cosine(emb, cent)
-    return dict(assignments=assign, centroids=cent, initial=np.asarray(initial), gamma=gamma, pi=pi)
+    out.update(assignments=assign, centroids=cent)
+    return out
+
+
+class SeededRNG:
+    """KMeansClustering.SeededRNG (:212-223) + the Swift-stdlib draws built on it (restated, see fa_oracle.c)."""
+
+    def __init__(self, seed: int):
+        self._s = C.c_uint64(seed & (2 ** 64 - 1))
+
+    def next(self) -> int:
+        return int(lib().fa_oracle_seeded_rng_next(C.byref(self._s)))
+
+    def next_upper_bound(self, bound: int) -> int:
+        return int(lib().fa_oracle_rng_upper_bound(C.byref(self._s), bound))
+
+    def shuffled_indices(self, n: int) -> np.ndarray:
+        idx = np.zeros(max(n, 1), np.int64)
+        lib().fa_oracle_shuffle_indices(C.byref(self._s), n, idx)
+        return idx[:n]
+
+    def random_double(self, lo: float, hi: float) -> float:
+        """Double.random(in: lo...hi, using:) of the Swift stdlib (FloatingPointRandom.swift, closed range): 53 random bits + 1
+        extra value for the closed upper end: rand = next(upperBound: 2^53 + 1); unit = rand == 2^53 ? 1 : rand * 2^-53."""
+        r = self.next_upper_bound((1 << 53) + 1)
+        unit = 1.0 if r == (1 << 53) else r * (2.0 ** -53)
+        return lo + (hi - lo) * unit
+
+
+def kmeans(emb, num_clusters: int, max_iter: int = 300, seed: int = 0):
+    """KMeansClustering.clusterWithCentroids -> (labels int32[n], centroids [k, d], iterations)."""
+    x = np.ascontiguousarray(emb, np.float64)
+    n, d = (x.shape[0], x.shape[1]) if x.ndim == 2 else (len(x), 0)
+    lab = np.zeros(max(n, 1), np.int32)
+    cen = np.zeros((max(min(num_clusters, n), 1), max(d, 1)), np.float64)
+    k, it = C.c_long(), C.c_long()
+    st = lib().fa_oracle_kmeans(x if x.size else np.zeros((1, 1)), n, d, num_clusters, max_iter, seed & (2 ** 64 - 1), lab, cen,
+                                C.byref(k), C.byref(it))
+    assert st == 0
+    return lab[:n], cen[:k.value, :d].copy(), it.value
+
+
+def kmeans_ninit(emb, num_clusters: int, max_iter: int = 300, n_init: int = 10, base_seed: int = 0):
+    """KMeansClustering.clusterWithCentroidsNInit -> (labels, centroids, best run, inertias)."""
+    x = np.ascontiguousarray(emb, np.float64)
+    n, d = (x.shape[0], x.shape[1]) if x.ndim == 2 else (len(x), 0)
+    lab = np.zeros(max(n, 1), np.int32)
+    cen = np.zeros((max(min(num_clusters, n), 1), max(d, 1)), np.float64)
+    k, best = C.c_long(), C.c_long()
+    inert = np.full(max(n_init, 1), np.nan)
+    st = lib().fa_oracle_kmeans_ninit(x if x.size else np.zeros((1, 1)), n, d, num_clusters, max_iter, n_init,
+                                      base_seed & (2 ** 64 - 1), lab, cen, C.byref(k), C.byref(best), inert)
+    assert st == 0
+    return lab[:n], cen[:k.value, :d].copy(), best.value, inert
+
+
+def speaker_constraints(num_embeddings: int, num_speakers=None, min_speakers=None, max_speakers=None):
+    """SpeakerCountConstraints.resolve -> (numSpeakers or None, minSpeakers, maxSpeakers)."""
+    out = (C.c_long * 3)()
+    lib().fa_oracle_speaker_constraints(num_embeddings, num_speakers is not None, num_speakers or 0, min_speakers is not None,
+                                        min_speakers or 0, max_speakers is not None, max_speakers or 0, C.byref(out))
+    return (None if out[0] < 0 else int(out[0])), int(out[1]), int(out[2])
 
 
 def tdt_initial_time_index(time_jump, context_frame_adjustment: int) -> int:

@@ -7,6 +7,7 @@
 #define _GNU_SOURCE
 #include "fa_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -975,4 +976,168 @@ void fa_oracle_log_softmax_row(const float *logits, int V, float temperature, fl
     const float lse = logf(sum);
     for (int i = 0; i < V; ++i) out[i] = (out[i] - mx) - lse;
     if (blank_bias != 0.0f && blank_id >= 0 && blank_id < V) out[blank_id] -= blank_bias;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * K-Means fallback for speaker-count constraints (KMeansClustering.swift:39-224) + SpeakerCountConstraints.
+ *
+ * The random draws come from two places: the reference's own LCG (SeededRNG.next, KMeansClustering.swift:212-223) and the
+ * SWIFT STANDARD LIBRARY (third party, not under /root/reference, toolchain version unpinned by Package.swift):
+ *   - RandomNumberGenerator.next(upperBound:)  — Lemire's "nearly divisionless" method on the full-width product
+ *     (stdlib/public/core/Random.swift, Swift >= 5.0): m = next() * bound (128 bit); if low64(m) < bound:
+ *     t = (0 - bound) % bound; while low64(m) < t: redraw; return high64(m).
+ *   - MutableCollection.shuffle(using:) (CollectionAlgorithms.swift): for amount = count, count-1, ..., 2:
+ *     swapAt(cur, cur + Int.random(in: 0..<amount)); cur += 1.
+ *   - Collection.randomElement(using:): self[Int.random(in: 0..<count)].
+ * The reference tests pin only structural outcomes for fixed seeds (KMeansClusteringTests.swift:10-131), which the
+ * restatement reproduces (tests/test_oracle_kmeans.py); draw-level parity with a real Swift toolchain is UNPINNED.
+ * vDSP_svesqD's internal summation order is not documented; sums here are sequential in the dimension.
+ * ------------------------------------------------------------------------------------------------------------------- */
+uint64_t fa_oracle_seeded_rng_next(uint64_t *state) {                    /* KMeansClustering.swift:219-222 */
+    *state = *state * 6364136223846793005ULL + 1442695040888963407ULL;
+    return *state;
+}
+
+uint64_t fa_oracle_rng_upper_bound(uint64_t *state, uint64_t bound) {    /* Swift stdlib next(upperBound:) */
+    uint64_t r = fa_oracle_seeded_rng_next(state);
+    unsigned __int128 m = (unsigned __int128)r * bound;
+    if ((uint64_t)m < bound) {
+        const uint64_t t = (0 - bound) % bound;
+        while ((uint64_t)m < t) {
+            r = fa_oracle_seeded_rng_next(state);
+            m = (unsigned __int128)r * bound;
+        }
+    }
+    return (uint64_t)(m >> 64);
+}
+
+void fa_oracle_shuffle_indices(uint64_t *state, long n, int64_t *idx) {  /* Swift stdlib shuffle(using:) */
+    for (long i = 0; i < n; ++i) idx[i] = i;
+    long amount = n, cur = 0;
+    while (amount > 1) {
+        const long r = (long)fa_oracle_rng_upper_bound(state, (uint64_t)amount);
+        amount -= 1;
+        const int64_t tmp = idx[cur]; idx[cur] = idx[cur + r]; idx[cur + r] = tmp;
+        cur += 1;
+    }
+}
+
+static double km_dist2(const double *a, const double *b, long d) {       /* euclideanDistanceSquared :170-177 */
+    double s = 0.0;
+    for (long k = 0; k < d; ++k) { const double df = a[k] - b[k]; s += df * df; }
+    return s;
+}
+
+void fa_oracle_kmeans_normalize(const double *x, long n, long d, double *out) {   /* normalizeEmbeddings :131-142 */
+    for (long i = 0; i < n; ++i) {
+        double ss = 0.0;
+        for (long k = 0; k < d; ++k) ss += x[i * d + k] * x[i * d + k];
+        const double norm = sqrt(ss);
+        if (!(norm > 1e-10)) { memcpy(out + i * d, x + i * d, (size_t)d * sizeof(double)); continue; }
+        const double inv = 1.0 / norm;
+        for (long k = 0; k < d; ++k) out[i * d + k] = x[i * d + k] * inv;
+    }
+}
+
+/* clusterWithCentroids (:39-91).  labels[n]; centroids[min(k,n)*d] (may be NULL); *out_k = number of centroid rows
+ * written (0 for the degenerate returns that carry no centroids); *out_iters = assignment passes executed. */
+int fa_oracle_kmeans(const double *emb, long n, long d, long num_clusters, long max_iter, uint64_t seed,
+                     int32_t *labels, double *centroids, long *out_k, long *out_iters) {
+    if (out_k) *out_k = 0;
+    if (out_iters) *out_iters = 0;
+    if (n <= 0) return 0;                                                /* :46-48 */
+    if (d <= 0) { for (long i = 0; i < n; ++i) labels[i] = 0; return 0; }   /* :49-51 */
+    const long k = num_clusters < n ? num_clusters : n;
+    if (k <= 0) { for (long i = 0; i < n; ++i) labels[i] = 0; return 0; }   /* :54-56 */
+    if (n <= k) {                                                        /* :57-59: identity labels, raw embeddings */
+        for (long i = 0; i < n; ++i) labels[i] = (int32_t)i;
+        if (centroids) memcpy(centroids, emb, (size_t)(n * d) * sizeof(double));
+        if (out_k) *out_k = n;
+        return 0;
+    }
+    uint64_t rng = seed;
+    double *xn = malloc((size_t)(n * d) * sizeof(double));
+    double *cen = malloc((size_t)(k * d) * sizeof(double));
+    double *sums = malloc((size_t)(k * d) * sizeof(double));
+    int64_t *idx = malloc((size_t)n * sizeof(int64_t));
+    long *cnt = malloc((size_t)k * sizeof(long));
+    int32_t *cur = calloc((size_t)n, sizeof(int32_t)), *nxt = malloc((size_t)n * sizeof(int32_t));
+    if (!xn || !cen || !sums || !idx || !cnt || !cur || !nxt) { free(xn); free(cen); free(sums); free(idx); free(cnt); free(cur); free(nxt); return 4; }
+    fa_oracle_kmeans_normalize(emb, n, d, xn);
+    fa_oracle_shuffle_indices(&rng, n, idx);                             /* initializeCentroids :144-152 */
+    for (long c = 0; c < k; ++c) memcpy(cen + c * d, xn + idx[c] * d, (size_t)d * sizeof(double));
+    long it = 0;
+    for (; it < max_iter; ++it) {
+        int same = 1;
+        for (long i = 0; i < n; ++i) {                                   /* assignToCentroids :154-168 */
+            int best = 0; double bd = DBL_MAX;
+            for (long c = 0; c < k; ++c) { const double ds = km_dist2(xn + i * d, cen + c * d, d); if (ds < bd) { bd = ds; best = (int)c; } }
+            nxt[i] = best; if (best != cur[i]) same = 0;
+        }
+        if (same) { it += 1; break; }                                    /* :70-73 */
+        memcpy(cur, nxt, (size_t)n * sizeof(int32_t));
+        memset(sums, 0, (size_t)(k * d) * sizeof(double));               /* updateCentroids :179-207 */
+        memset(cnt, 0, (size_t)k * sizeof(long));
+        for (long i = 0; i < n; ++i) { const long c = cur[i]; cnt[c] += 1; for (long q = 0; q < d; ++q) sums[c * d + q] += xn[i * d + q]; }
+        for (long c = 0; c < k; ++c) {
+            if (cnt[c] == 0) {                                           /* empty cluster: random data point (:196-199) */
+                const long r = (long)fa_oracle_rng_upper_bound(&rng, (uint64_t)n);
+                memcpy(cen + c * d, xn + r * d, (size_t)d * sizeof(double));
+            } else {
+                const double inv = 1.0 / (double)cnt[c];
+                for (long q = 0; q < d; ++q) cen[c * d + q] = sums[c * d + q] * inv;
+            }
+        }
+    }
+    memcpy(labels, cur, (size_t)n * sizeof(int32_t));
+    if (centroids) memcpy(centroids, cen, (size_t)(k * d) * sizeof(double));
+    if (out_k) *out_k = k;
+    if (out_iters) *out_iters = it;
+    free(xn); free(cen); free(sums); free(idx); free(cnt); free(cur); free(nxt);
+    return 0;
+}
+
+/* clusterWithCentroidsNInit (:99-129): seeds base, base+1, ...; lowest inertia, first on ties. */
+int fa_oracle_kmeans_ninit(const double *emb, long n, long d, long num_clusters, long max_iter, long n_init, uint64_t base_seed,
+                           int32_t *labels, double *centroids, long *out_k, long *best_run, double *inertias) {
+    if (best_run) *best_run = 0;
+    if (!(n > num_clusters && n_init > 1))                               /* :106-110 */
+        return fa_oracle_kmeans(emb, n, d, num_clusters, max_iter, base_seed, labels, centroids, out_k, NULL);
+    const long kmax = num_clusters < n ? (num_clusters > 0 ? num_clusters : 0) : n;
+    double *xn = malloc((size_t)(n * (d > 0 ? d : 1)) * sizeof(double));
+    double *cen = malloc((size_t)((kmax > 0 ? kmax : 1) * (d > 0 ? d : 1)) * sizeof(double));
+    int32_t *lab = malloc((size_t)n * sizeof(int32_t));
+    if (!xn || !cen || !lab) { free(xn); free(cen); free(lab); return 4; }
+    if (d > 0) fa_oracle_kmeans_normalize(emb, n, d, xn);
+    double best = DBL_MAX; int have = 0;
+    for (long r = 0; r < n_init; ++r) {
+        long kk = 0;
+        const int st = fa_oracle_kmeans(emb, n, d, num_clusters, max_iter, base_seed + (uint64_t)r, lab, cen, &kk, NULL);
+        if (st) { free(xn); free(cen); free(lab); return st; }
+        double inertia = 0.0;                                            /* :118-121 */
+        for (long i = 0; i < n; ++i) if (lab[i] >= 0 && lab[i] < kk) inertia += km_dist2(xn + i * d, cen + lab[i] * d, d);
+        if (inertias) inertias[r] = inertia;
+        if (inertia < best) {
+            best = inertia; have = 1;
+            memcpy(labels, lab, (size_t)n * sizeof(int32_t));
+            if (centroids && kk > 0) memcpy(centroids, cen, (size_t)(kk * d) * sizeof(double));
+            if (out_k) *out_k = kk;
+            if (best_run) *best_run = r;
+        }
+    }
+    free(xn); free(cen); free(lab);
+    if (!have) return fa_oracle_kmeans(emb, n, d, num_clusters, max_iter, base_seed, labels, centroids, out_k, NULL);   /* :126-128 */
+    return 0;
+}
+
+/* SpeakerCountConstraints.resolve (SpeakerCountConstraints.swift:25-62).  has_* = 0 encodes nil.
+ * out = {numSpeakers or -1 for nil, minSpeakers, maxSpeakers}. */
+void fa_oracle_speaker_constraints(long num_embeddings, int has_num, long num, int has_min, long mn, int has_max, long mx, long out[3]) {
+    long rmin = has_num ? num : (has_min ? mn : 1);
+    rmin = rmin < num_embeddings ? rmin : num_embeddings; rmin = rmin > 1 ? rmin : 1;
+    long rmax = has_num ? num : (has_max ? mx : num_embeddings);
+    rmax = rmax < num_embeddings ? rmax : num_embeddings; rmax = rmax > 1 ? rmax : 1;
+    if (rmin > rmax) rmin = rmax;
+    out[0] = rmin == rmax ? rmin : (has_num ? num : -1);
+    out[1] = rmin; out[2] = rmax;
 }

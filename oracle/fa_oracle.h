@@ -171,6 +171,17 @@ int fa_oracle_tdt_greedy(const int32_t *tok, const int32_t *bin, const float *pr
 /* CtcKeywordSpotter.logSoftmax + blank bias (CtcKeywordSpotter+Inference.swift:397-431) */
 void fa_oracle_log_softmax_row(const float *logits, int V, float temperature, float blank_bias, int blank_id, float *out);
 
+/* K-Means fallback (KMeansClustering.swift:39-224) with the Swift-stdlib draws restated; SpeakerCountConstraints.resolve */
+uint64_t fa_oracle_seeded_rng_next(uint64_t *state);
+uint64_t fa_oracle_rng_upper_bound(uint64_t *state, uint64_t bound);
+void fa_oracle_shuffle_indices(uint64_t *state, long n, int64_t *idx);
+void fa_oracle_kmeans_normalize(const double *x, long n, long d, double *out);
+int fa_oracle_kmeans(const double *emb, long n, long d, long num_clusters, long max_iter, uint64_t seed,
+                     int32_t *labels, double *centroids, long *out_k, long *out_iters);
+int fa_oracle_kmeans_ninit(const double *emb, long n, long d, long num_clusters, long max_iter, long n_init, uint64_t base_seed,
+                           int32_t *labels, double *centroids, long *out_k, long *best_run, double *inertias);
+void fa_oracle_speaker_constraints(long num_embeddings, int has_num, long num, int has_min, long mn, int has_max, long mx, long out[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,3 +83,35 @@ def test_shard_ranges_cover_and_balance(fa):
     offs = np.array([0, 10, 25, 25, 40, 100])
     first, local, lo, hi = fa.shard_offsets(offs, 1, 2)
     assert first == 3 and local.tolist() == [0, 15, 75] and (lo, hi) == (25, 100)
+
+
+def test_speaker_constraints_and_rng_host_functions(fa, oracle_mod):
+    """SpeakerCountConstraints.resolve and the seeded draws are pure host functions of the library (no GPU)."""
+    from test_oracle_kmeans import test_speaker_constraints_resolve
+    cases = test_speaker_constraints_resolve.pytestmark[0].args[1]
+    for args, expect in cases:
+        c = fa.SpeakerCountConstraints.resolve(*args)
+        assert (c.num_speakers, c.min_speakers, c.max_speakers) == expect
+    c = fa.SpeakerCountConstraints.resolve(100, None, 5, 10)       # SpeakerCountConstraintsTests.swift:104-136
+    assert c.needs_adjustment(3) and c.target_count(3) == 5
+    c = fa.SpeakerCountConstraints.resolve(100, None, 2, 5)
+    assert c.needs_adjustment(8) and c.target_count(8) == 5 and not c.needs_adjustment(3) and c.target_count(3) == 3
+    a, b = fa.SeededRNG(1234), oracle_mod.SeededRNG(1234)
+    for bound in (1, 2, 3, 10, 43200, 2 ** 31 + 11, 2 ** 63 + 5, 2 ** 64 - 1):
+        for _ in range(50):
+            assert a.next_below(bound) == b.next_upper_bound(bound)
+    assert a.next() == b.next()
+
+
+def test_vbx_output_cluster_counts(fa):
+    """VBxConstraintTests.swift:53-160: pi census vs clusters that actually win an argmax."""
+    V = fa.VBxOutput
+    out = V(np.zeros((0, 0)), np.array([0.5, 0.3, 0.2, 1e-9, 1e-10]), [], [], 5, [])
+    assert out.active_cluster_count == 3
+    assert V(np.zeros((0, 0)), np.zeros(0), [], [], 4, []).active_cluster_count == 4
+    g = np.array([[0.7, 0.1, 0.1, 0.05, 0.05], [0.1, 0.7, 0.1, 0.05, 0.05], [0.1, 0.1, 0.7, 0.05, 0.05],
+                  [0.6, 0.2, 0.1, 0.05, 0.05], [0.2, 0.6, 0.1, 0.05, 0.05], [0.1, 0.2, 0.6, 0.05, 0.05]])
+    out = V(g, np.array([0.4, 0.3, 0.28, 0.01, 0.01]), [], [], 5, [])
+    cons = fa.SpeakerCountConstraints.resolve(6, 5)
+    assert out.active_cluster_count == 5 and out.assigned_cluster_count == 3
+    assert not cons.needs_adjustment(out.active_cluster_count) and cons.needs_adjustment(out.assigned_cluster_count)
