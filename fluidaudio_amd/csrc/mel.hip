@@ -17,8 +17,10 @@
 
 #include "fa_common.h"
 #include "mel_core.h"
+#include "mel_pk.h"
 
 using namespace fa::melcore;
+using fa::melpk::f2;
 
 namespace {
 
@@ -70,6 +72,9 @@ __host__ __device__ constexpr int fast_slots(int i) { return i == 0 ? 2 : i == 1
 __host__ __device__ constexpr int fast_slot_base(int i) { int o = 0; for (int k = 0; k < i; ++k) o += fast_slots(k); return o; }
 constexpr int kFastSlots = fast_slot_base(kFastGroups);  // 41
 
+constexpr int kRegionFloatsPk = 2 * 16 * kEStride;  // packed kernel: 16 x 17 frame pairs, 64-bit accesses only (one 16-lane group per LDS cycle)
+constexpr int kPkHop = 160;  // hop of the frame-pair packed kernel (compile-time: the two frames of a lane are read by one ds_read2_b32)
+
 constexpr int kStageVec = 6;  // float4 loads per thread and tile held in registers while the previous tile is computed
 
 struct TileInfo {
@@ -82,24 +87,61 @@ struct TileInfo {
     bool interior;   // the whole staged span (and the sample before it) lies inside the utterance
 };
 
-template <int LAYOUT, bool FAST>
+// global filterbank slot s -> (mel group i, slot j inside the group), resolved at compile time inside unrolled loops
+template <class F>
+__device__ __forceinline__ void constexpr_for_slot(const int s, F &&fn) {
+#pragma unroll
+    for (int i = 0; i < kFastGroups; ++i)
+        if (s >= fast_slot_base(i) && s < fast_slot_base(i) + fast_slots(i)) fn(i, s - fast_slot_base(i));
+}
+
+// Both frames of a 16-lane group straight from the staged samples: v.re[n1] = (x[32 n1], x[32 n1 + hop]) and v.im[n1] the same
+// one sample later, x = the lane's pointer (frame start + 2 lane).  One ds_read2_b32 per register pair.  Written in assembly
+// because the load combiner pairs LDS reads by ascending offset — (x[32 n1], x[32 n1 + 32]) — which costs four register moves
+// per pair to re-pair by frame; the wait for the 32 reads is part of the block (the compiler does not track them).
+__device__ __forceinline__ void load_frame_pair(const float *x, fa::melpk::LanePk &v) {
+    static_assert(kPkHop == 160, "offsets below are written for hop 160");
+    const unsigned a0 = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const float *)x));
+#define FA_RD(i, b, o0, o1) "ds_read2_b32 %" #i ", %" #b " offset0:" #o0 " offset1:" #o1 "\n"
+#define FA_RD4(i0, i1, i2, i3, b) FA_RD(i0, b, 0, 160) FA_RD(i1, b, 1, 161) FA_RD(i2, b, 32, 192) FA_RD(i3, b, 33, 193)
+    asm volatile(FA_RD4(0, 1, 2, 3, 32) FA_RD4(4, 5, 6, 7, 33) FA_RD4(8, 9, 10, 11, 34) FA_RD4(12, 13, 14, 15, 35)
+                 FA_RD4(16, 17, 18, 19, 36) FA_RD4(20, 21, 22, 23, 37) FA_RD4(24, 25, 26, 27, 38) FA_RD4(28, 29, 30, 31, 39)
+                 "s_waitcnt lgkmcnt(0)\n"
+                 : "=&v"(v.re[0]), "=&v"(v.im[0]), "=&v"(v.re[1]), "=&v"(v.im[1]), "=&v"(v.re[2]), "=&v"(v.im[2]), "=&v"(v.re[3]), "=&v"(v.im[3]),
+                   "=&v"(v.re[4]), "=&v"(v.im[4]), "=&v"(v.re[5]), "=&v"(v.im[5]), "=&v"(v.re[6]), "=&v"(v.im[6]), "=&v"(v.re[7]), "=&v"(v.im[7]),
+                   "=&v"(v.re[8]), "=&v"(v.im[8]), "=&v"(v.re[9]), "=&v"(v.im[9]), "=&v"(v.re[10]), "=&v"(v.im[10]), "=&v"(v.re[11]), "=&v"(v.im[11]),
+                   "=&v"(v.re[12]), "=&v"(v.im[12]), "=&v"(v.re[13]), "=&v"(v.im[13]), "=&v"(v.re[14]), "=&v"(v.im[14]), "=&v"(v.re[15]), "=&v"(v.im[15])
+                 : "v"(a0), "v"(a0 + 256), "v"(a0 + 512), "v"(a0 + 768), "v"(a0 + 1024), "v"(a0 + 1280), "v"(a0 + 1536), "v"(a0 + 1792)
+                 : "memory");
+#undef FA_RD4
+#undef FA_RD
+}
+
+// PK: frame-pair packed arithmetic (mel_pk.h): one pass of 2 frames per 16-lane group instead of two passes of one; needs
+// FAST and hop == kPkHop.
+template <int LAYOUT, bool FAST, bool PK>
 __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *samples = smem;
     float *regions = samples + a.stage_alloc;
-    float *outs = regions + kRegions * kRegionFloats;
+    float *outs = regions + kRegions * (PK ? kRegionFloatsPk : kRegionFloats);
     int32_t *mtab = reinterpret_cast<int32_t *>(outs + a.out_alloc);
     float *mw = reinterpret_cast<float *>(mtab + kMaxMels);
+    float *wtab = mw + ((a.n_weights + 24 + 3) & ~3);   // packed kernel: per-lane window rows (mel_pk.h)
 
     const int tid = threadIdx.x;
     const int l = tid & (kGroup - 1);   // lane inside the 16-lane frame group
     const int grp = tid >> 4;           // 0..15: LDS region == (wave, frame of the pass)
 
     for (int i = tid; i < a.n_mels; i += kThreads) mtab[i] = a.mel_tab[i];
-    for (int i = tid; i < a.n_weights; i += kThreads) mw[i] = a.mel_w[i];
+    for (int i = tid; i < a.n_weights; i += kThreads) mw[i] = PK ? 0.25f * a.mel_w[i] : a.mel_w[i];  // PK power bins carry an exact factor 4
 
     LaneConst kc;
-    {
+    fa::melpk::LaneConstPk kp;
+    if (PK) {
+        fa::melpk::lane_const_init(l, a.tw256, a.tw512, kp);
+        fa::melpk::window_table_fill(tid, kThreads, a.windowz, wtab);
+    } else {
         Tables c;
         c.windowz = a.windowz;
         c.tw256 = reinterpret_cast<const float *>(a.tw256);
@@ -127,12 +169,18 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
         const int tli = __builtin_amdgcn_readfirstlane(static_cast<int>(tl));
         const int b = tli / a.tiles_per_utt;
         ti.t0 = (tli - b * a.tiles_per_utt) * kTileFrames;
-        ti.T = a.frames[b];
-        const int64_t base = a.offsets[b];
-        ti.len = a.offsets[b + 1] - base;
+        // The plan's tables are read-only for the kernel: read them through the constant address space so that they become
+        // scalar loads (lgkmcnt).  As plain global loads they are vector loads, and the s_waitcnt vmcnt(0) in front of their
+        // first use also sits out every output store and prefetch load still in flight — about 2 k cycles per tile.
+        typedef const int32_t __attribute__((address_space(4))) *c_i32;
+        typedef const int64_t __attribute__((address_space(4))) *c_i64;
+        typedef const float __attribute__((address_space(4))) *c_f32;
+        ti.T = ((c_i32)a.frames)[b];
+        const int64_t base = ((c_i64)a.offsets)[b];
+        ti.len = ((c_i64)a.offsets)[b + 1] - base;
         ti.x = a.pcm + base;
         ti.ob = a.out + static_cast<int64_t>(b) * a.utt_stride;
-        ti.lastv = a.last ? a.last[b] : 0.0f;
+        ti.lastv = a.last ? ((c_f32)a.last)[b] : 0.0f;
         ti.n0 = static_cast<int64_t>(ti.t0) * a.hop - a.pad;
         ti.stage = ti.t0 < ti.T;
         ti.interior = ti.n0 >= 1 && ti.n0 + kStageVec * kThreads * 4 <= ti.len;
@@ -148,29 +196,45 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
             for (int r = 0; r < kStageVec; ++r) {
                 const float *src = ti.x + ti.n0 + 4 * (tid + kThreads * r);
                 raw[r] = *reinterpret_cast<const float4 *>(src);
-                rprev[r] = src[-1];
+                // the sample before the group through an opaque index: seen together, the two loads are re-cut into
+                // (x[-1..2], x[3]) and the pieces copied into place right behind the loads, i.e. behind an s_waitcnt vmcnt
+                int before = -1;
+                asm volatile("" : "+v"(before));
+                rprev[r] = src[before];
             }
             return;
         }
 #pragma unroll
-        for (int r = 0; r < kStageVec; ++r) {  // utterance edges (first / last tiles): guarded scalar loads
-            const int e = 4 * (tid + kThreads * r);
-            const int64_t n = ti.n0 + e;
+        for (int r = 0; r < kStageVec; ++r) {  // utterance edges (first / last tiles): unconditional loads from clamped indices
+            const int64_t n = ti.n0 + 4 * (tid + kThreads * r);
             float t[5];
 #pragma unroll
-            for (int c = 0; c < 5; ++c) {
+            for (int c = 0; c < 5; ++c) {  // values outside [0, len) are replaced in stage(): no select (= no wait) behind the loads here
                 const int64_t m = n - 1 + c;
-                t[c] = e < a.stage_alloc && m >= 0 && m < ti.len ? ti.x[m] : (m == -1 ? ti.lastv : 0.f);
+                t[c] = ti.x[m < 0 ? 0 : (m < ti.len ? m : ti.len - 1)];
             }
             rprev[r] = t[0];
             raw[r] = make_float4(t[1], t[2], t[3], t[4]);
         }
     };
     auto stage = [&](const TileInfo &ti) {  // pre-emphasis (:211,:219-225: y[n] = x[n] - p x[n-1]); zero outside [0, len)
+        int ts = tid;
+        asm volatile("" : "+v"(ts));  // distinct from fetch()'s index arithmetic: shared, it would stay live (and spill) across the pass
+        // Pin the prefetched values to this point.  The pre-emphasis below is vectorised into packed fma's whose operand pairs
+        // (x[n - 1], x[n]) are assembled by register copies; without the pin those copies are scheduled right behind the loads
+        // in fetch() — a whole pass earlier — together with the s_waitcnt vmcnt that makes the loads synchronous.
+#pragma unroll
+        for (int r = 0; r < kStageVec; ++r) asm volatile("" : "+v"(raw[r].x), "+v"(raw[r].y), "+v"(raw[r].z), "+v"(raw[r].w), "+v"(rprev[r]));
 #pragma unroll
         for (int r = 0; r < kStageVec; ++r) {
-            const int e = 4 * (tid + kThreads * r);
+            const int e = 4 * (ts + kThreads * r);
             if (e >= a.stage_alloc) continue;
+            if (!ti.interior) {  // x[-1] = the carried last sample (:211), x = 0 elsewhere outside the utterance
+                const int64_t n = ti.n0 + e;
+                auto fix = [&](const float v, const int64_t m) { return m >= 0 && m < ti.len ? v : (m == -1 ? ti.lastv : 0.0f); };
+                rprev[r] = fix(rprev[r], n - 1);
+                raw[r].x = fix(raw[r].x, n); raw[r].y = fix(raw[r].y, n + 1); raw[r].z = fix(raw[r].z, n + 2); raw[r].w = fix(raw[r].w, n + 3);
+            }
             float4 y;
             y.x = raw[r].x - a.preemph * rprev[r];
             y.y = raw[r].y - a.preemph * raw[r].x;
@@ -187,38 +251,130 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
         }
     };
 
-    unsigned long long t_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = clock64();
 #define MEL_STAMP(i) do { if (a.prof) { const unsigned long long t_now = clock64(); t_seg[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+#ifdef FA_MEL_PROF_FINE   // diagnostics build: split the packed pass (slots 8..11; slot 3 keeps the remainder)
+#define MEL_STAMP_FINE(i) MEL_STAMP(i)
+#else
+#define MEL_STAMP_FINE(i) do { } while (0)
+#endif
     // All table / constant loads are complete from here on (vmcnt(0), expcnt/lgkmcnt untouched).  Without this explicit
     // instruction the wait-count pass keeps them "possibly pending" around the tile loop and guards the first LDS reads of
     // every pass with s_waitcnt vmcnt(<=3), which also drains the next tile's prefetch loads (vmcnt retires in order) and
     // exposes a full HBM round trip per tile.
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    auto stage_tile = [&](const TileInfo &ti) {
+        if (!ti.stage) return;
+        if (vec_stage) stage(ti);
+        else
+            for (int i = tid; i < a.stage_count; i += kThreads) {  // large hops: plain staging loop
+                const int64_t n = ti.n0 + i;
+                float y = 0.0f;
+                if (n >= 0 && n < ti.len) y = ti.x[n] - a.preemph * (n > 0 ? ti.x[n - 1] : ti.lastv);
+                samples[i] = y;
+            }
+    };
     TileInfo cur = first < stop ? tile_info(first) : TileInfo{};
     if (first < stop && cur.stage && vec_stage) fetch(cur);
+    stage_tile(cur);
 
+    // Per tile: barrier | issue the next tile's loads | compute | barrier | stage the next tile | store this tile.  Staging
+    // BEFORE the stores matters: the wait in front of the staging is vmcnt(0) (the wait-count pass cannot bound it across the
+    // loop), and with the four output stores issued first it would sit out their write acknowledgements (~1.5 k cycles per
+    // tile); in this order the only VMEM operations in flight are the loads issued a whole pass earlier.
     for (int64_t tl = first; tl < stop; ++tl) {
-        if (cur.stage) {
-            if (vec_stage) stage(cur);
-            else
-                for (int i = tid; i < a.stage_count; i += kThreads) {  // large hops: plain staging loop
-                    const int64_t n = cur.n0 + i;
-                    float y = 0.0f;
-                    if (n >= 0 && n < cur.len) y = cur.x[n] - a.preemph * (n > 0 ? cur.x[n - 1] : cur.lastv);
-                    samples[i] = y;
-                }
-        }
-        MEL_STAMP(0);
         __syncthreads();
         MEL_STAMP(1);
         // the next tile's samples travel from HBM while this tile is computed
         TileInfo nxt{};
         nxt.stage = false;
-        if (tl + 1 < stop) { nxt = tile_info(tl + 1); if (nxt.stage && vec_stage) fetch(nxt); }
+        if (tl + 1 < stop) { nxt = tile_info(tl + 1); MEL_STAMP_FINE(6); if (nxt.stage && vec_stage) fetch(nxt); }
 
         MEL_STAMP(2);
-        if (cur.stage) {  // workgroup-uniform
+        if (PK && cur.stage) {  // workgroup-uniform; group g computes the frames 2 g and 2 g + 1 of the tile in one pass
+            using namespace fa::melpk;
+            const int f = 2 * grp;
+            LanePk v;
+            float4 w4[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w4[q] = reinterpret_cast<const float4 *>(wtab)[q * kGroup + l];
+            load_frame_pair(samples + f * kPkHop + 2 * l, v);
+            MEL_STAMP_FINE(8);
+            f2 *P2 = reinterpret_cast<f2 *>(__builtin_assume_aligned(regions + grp * kRegionFloatsPk, 8));
+            fft256(l, v, w4, kp, P2);
+            MEL_STAMP_FINE(9);
+            // power bins of both frames, pair k at P2[k], over the transpose buffer (its last reads are already issued)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // Z[256 - (l + 16 j)]: lane (16 - l) & 15, register 15 - j (lane 0: own (16 - j) & 15)
+                const f2 pr = partner(v.re[15 - j]), pi = partner(v.im[15 - j]);
+                const f2 qr = l == 0 ? v.re[(16 - j) & 15] : pr;
+                const f2 qi = l == 0 ? v.im[(16 - j) & 15] : pi;
+                f2 plo, phi;
+                pair_power4(v.re[j], v.im[j], qr, qi, kp.t2[j], plo, phi);
+                P2[l + 16 * j] = plo;
+                P2[kHalf - (l + 16 * j)] = phi;
+            }
+            if (l == 0) P2[128] = 4.0f * (v.re[8] * v.re[8] + v.im[8] * v.im[8]);  // k = 128: X = conj(Z[128])
+            MEL_STAMP_FINE(10);
+            // sparse triangular filterbank (vDSP_mmul row, :270-283, zeros skipped): lane l owns the mels l + 16 i; weights are
+            // fetched two global slots (2 p, 2 p + 1) per register pair, so a pair may straddle two mel groups
+            f2 acc[kFastGroups];
+            const f2 *P[kFastGroups];
+#pragma unroll
+            for (int i = 0; i < kFastGroups; ++i) {
+                acc[i] = f2{0.0f, 0.0f};
+                P[i] = P2 + ((mlo[i / 3] >> (10 * (i % 3))) & 1023);
+            }
+            // All LDS reads of a half are issued before its first fma (sched_barrier keeps the scheduler from re-serialising
+            // them into load -> wait -> fma chains, which exposes one LDS round trip per slot): weights first, then the bins.
+            constexpr int kSplit = fast_slot_base(6) & ~1;   // slots [0, kSplit): groups 0..5 (even, so weight pairs do not straddle the halves)
+            {
+                f2 w[kSplit / 2], pb[kSplit];
+#pragma unroll
+                for (int sp = 0; sp < kSplit / 2; ++sp) w[sp] = f2{mw[(2 * sp) * kGroup + l], mw[(2 * sp + 1) * kGroup + l]};
+#pragma unroll
+                for (int s = 0; s < kSplit; ++s) constexpr_for_slot(s, [&](const int i, const int j) { pb[s] = P[i][j]; });
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < kSplit; ++s)
+                    constexpr_for_slot(s, [&](const int i, const int) { acc[i] = (s & 1) ? fma_hi(pb[s], w[s / 2], acc[i]) : fma_lo(pb[s], w[s / 2], acc[i]); });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                constexpr int kRest = kFastSlots - kSplit;
+                f2 w[(kRest + 1) / 2], pb[kRest];
+#pragma unroll
+                for (int sp = 0; sp < (kRest + 1) / 2; ++sp) w[sp] = f2{mw[(kSplit + 2 * sp) * kGroup + l], mw[(kSplit + 2 * sp + 1) * kGroup + l]};
+#pragma unroll
+                for (int s = kSplit; s < kFastSlots; ++s) constexpr_for_slot(s, [&](const int i, const int j) { pb[s - kSplit] = P[i][j]; });
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = kSplit; s < kFastSlots; ++s)
+                    constexpr_for_slot(s, [&](const int i, const int) {
+                        acc[i] = (s & 1) ? fma_hi(pb[s - kSplit], w[(s - kSplit) / 2], acc[i]) : fma_lo(pb[s - kSplit], w[(s - kSplit) / 2], acc[i]);
+                    });
+            }
+            // :542-549: log(acc + floor) or log(max(acc, floor)) as log(max(acc + add, clamp)) with wave-uniform add / clamp.
+            // The argument is >= floor > 0 and far from the denormal range, so the hardware log2 (1 ulp) times ln 2 replaces
+            // logf's denormal pre-scaling and two-term ln 2 product: 2 instructions instead of 11.
+            MEL_STAMP_FINE(11);
+            const float add_floor = a.floor_clamped ? 0.0f : a.log_floor, clamp_floor = a.floor_clamped ? a.log_floor : 0.0f;
+#pragma unroll
+            for (int i = 0; i < kFastGroups; ++i) {
+                const int m = l + 16 * i;
+                constexpr float kLn2 = 0.693147180559945309f;
+                const f2 x = acc[i] + add_floor;
+                f2 val;
+                val.x = kLn2 * __builtin_amdgcn_logf(fmaxf(x.x, clamp_floor));
+                val.y = kLn2 * __builtin_amdgcn_logf(fmaxf(x.y, clamp_floor));
+                if (m < n_mels) {
+                    if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) *reinterpret_cast<f2 *>(outs + m * kMelPad + f) = val;
+                    else { outs[f * (n_mels + kFramePad) + m] = val.x; outs[(f + 1) * (n_mels + kFramePad) + m] = val.y; }
+                }
+            }
+        }
+        if (!PK && cur.stage) {  // workgroup-uniform
             float *R = static_cast<float *>(__builtin_assume_aligned(regions + grp * kRegionFloats, 8));
 #pragma unroll 1
             for (int pass = 0; pass < kPasses; ++pass) {
@@ -291,17 +447,20 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
         MEL_STAMP(3);
         __syncthreads();
         MEL_STAMP(4);
+        stage_tile(nxt);   // `samples` has no reader left after the barrier
+        MEL_STAMP(0);
 
         const bool full_tile = cur.t0 + kTileFrames <= cur.T && cur.t0 + kTileFrames <= a.frame_stride;
-        if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR && FAST && full_tile) {
+        if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR && FAST && full_tile && n_mels == kFastGroups * kGroup) {
             // 8 threads per mel row, 4 consecutive frames each: 16-byte LDS reads, 16-byte global stores (:287); a fixed number
             // of stores per thread keeps the wait count for the next tile's prefetch exact (vmcnt(4) instead of vmcnt(0))
+            int st = tid;
+            asm volatile("" : "+v"(st));   // keep the store addresses loop-variant: hoisted, they sit in 12 registers across the whole tile loop
 #pragma unroll
             for (int it = 0; it < kFastGroups * kGroup * (kTileFrames / 4) / kThreads; ++it) {
-                const int idx = tid + kThreads * it, m = idx >> 3, f = (idx & 7) * 4;
-                if (m < n_mels)
-                    *reinterpret_cast<float4 *>(cur.ob + static_cast<int64_t>(m) * a.frame_stride + cur.t0 + f) =
-                        *reinterpret_cast<const float4 *>(outs + m * kMelPad + f);
+                const int idx = st + kThreads * it, m = idx >> 3, f = (idx & 7) * 4;   // every thread stores: no exec masking, exact vmcnt
+                *reinterpret_cast<float4 *>(cur.ob + static_cast<int64_t>(m) * a.frame_stride + cur.t0 + f) =
+                    *reinterpret_cast<const float4 *>(outs + m * kMelPad + f);
             }
         } else if (LAYOUT == FA_MEL_LAYOUT_MEL_MAJOR) {
             for (int idx = tid; idx < n_mels * (kTileFrames / 4); idx += kThreads) {
@@ -324,13 +483,12 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
                 cur.ob[static_cast<int64_t>(t) * n_mels + m] = t < cur.T ? outs[f * (n_mels + kFramePad) + m] : 0.0f;  // :451
             }
         }
-        // the next tile's staging writes `samples` (no reader left) and its barrier orders the `outs` reads above
-        // before the next writes
+        // the barrier at the top of the next iteration orders these `outs` reads before the next tile's writes
         MEL_STAMP(5);
         cur = nxt;
     }
     if (a.prof && blockIdx.x == gridDim.x / 2 && tid == 0) {
-        for (int i = 0; i < 6; ++i) atomicAdd(&a.prof[i], t_seg[i]);
+        for (int i = 0; i < 12; ++i) if (i != 7) atomicAdd(&a.prof[i], t_seg[i]);
         atomicAdd(&a.prof[7], static_cast<unsigned long long>(stop - first));
     }
 #undef MEL_STAMP
@@ -434,6 +592,7 @@ struct fa_mel_plan {
     size_t lds_bytes = 0;
     int grid = 0;
     bool fast = false;  // filterbank fits the compile-time slot profile
+    bool pk = false;    // frame-pair packed kernel (fast bank, hop == kPkHop)
 };
 
 extern "C" {
@@ -596,20 +755,25 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         a.preemph = cfg->padding_mode == FA_MEL_PAD_LEGACY ? 0.0f : cfg->preemph;  // compute() has no pre-emphasis (:146-153)
         a.log_floor = cfg->log_floor;
         a.floor_clamped = cfg->floor_mode == FA_MEL_FLOOR_CLAMPED;
-        p->lds_bytes = sizeof(float) * (a.stage_alloc + kRegions * kRegionFloats + a.out_alloc) + sizeof(int32_t) * kMaxMels +
-                       sizeof(float) * (static_cast<size_t>(a.n_weights) + 8);
+        p->pk = fast && cfg->hop == kPkHop && getenv("FA_MEL_SCALAR") == nullptr;   // FA_MEL_SCALAR: diagnostics, one frame per lane
+        p->lds_bytes = sizeof(float) * (a.stage_alloc + kRegions * (p->pk ? kRegionFloatsPk : kRegionFloats) + a.out_alloc) + sizeof(int32_t) * kMaxMels +
+                       sizeof(float) * (static_cast<size_t>(a.n_weights) + 24 + 4 + (p->pk ? fa::melpk::kWindowTableFloats : 0));   // the paired weight reads of the packed kernel touch one slot row past the table
         if (p->lds_bytes > 160 * 1024) { (void)hipFree(p->dev); delete p; return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel: hop too large for LDS staging"); }
         if (p->lds_bytes > 64 * 1024) {
             const int lb = static_cast<int>(p->lds_bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
         }
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, ctx->device);
         const int cus = e == hipSuccess ? prop.multiProcessorCount : 256;
-        const int64_t want = static_cast<int64_t>(cus) * 2 * 4;  // 2 resident workgroups per CU, four rounds of them
+        const char *rounds_env = getenv("FA_MEL_ROUNDS");  // diagnostics
+        const int rounds = rounds_env && atoi(rounds_env) > 0 ? atoi(rounds_env) : 4;
+        const int64_t want = static_cast<int64_t>(cus) * 2 * rounds;  // 2 resident workgroups per CU, `rounds` rounds of them
         p->grid = static_cast<int>(a.total_tiles < want ? a.total_tiles : want);
         if (p->grid < 1) p->grid = 1;
         *out = p;
@@ -640,21 +804,28 @@ fa_status fa_mel_execute_dev(fa_mel_plan *p, const float *d_pcm, const float *d_
     static unsigned long long *s_prof = nullptr;
     static int s_prof_calls = 0;
     if (getenv("FA_MEL_PROF")) {  // diagnostics only: per-phase cycles of one workgroup, printed every 10 launches
-        if (!s_prof) { (void)hipMalloc(&s_prof, 64); (void)hipMemset(s_prof, 0, 64); }
+        if (!s_prof) { (void)hipMalloc(&s_prof, 128); (void)hipMemset(s_prof, 0, 128); }
         a.prof = s_prof;
         if (++s_prof_calls % 10 == 0) {
-            unsigned long long h[8];
-            (void)hipMemcpy(h, s_prof, 64, hipMemcpyDeviceToHost);
+            unsigned long long h[16];
+            (void)hipMemcpy(h, s_prof, 128, hipMemcpyDeviceToHost);
             const double n = h[7] ? static_cast<double>(h[7]) : 1.0;
             fprintf(stderr, "mel profile (cycles per tile, wave 0 of one workgroup, %llu tiles): stage-write %.0f | barrier1 %.0f | prefetch issue %.0f | passes %.0f | barrier2 %.0f | store %.0f\n",
-                    h[7], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n);
+                    h[7], h[0] / n, h[1] / n, (h[2] + h[6]) / n, (h[3] + h[8] + h[9] + h[10] + h[11]) / n, h[4] / n, h[5] / n);
+            if (h[6]) fprintf(stderr, "mel profile, prefetch: tile_info %.0f | load issue %.0f\n", h[6] / n, h[2] / n);
+            if (h[8]) fprintf(stderr, "mel profile, packed pass: sample reads %.0f | fft256 %.0f | partner + power %.0f | filterbank %.0f | log + stage %.0f\n",
+                              h[8] / n, h[9] / n, h[10] / n, h[11] / n, h[3] / n);
         }
     } else a.prof = nullptr;
     const bool mm = p->cfg.layout == FA_MEL_LAYOUT_MEL_MAJOR;
-    if (mm && p->fast) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, true>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
-    else if (mm) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, false>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
-    else if (p->fast) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, true>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
-    else hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, false>), dim3(p->grid), dim3(kThreads), p->lds_bytes, ctx->stream, a);
+    const bool pk = p->pk;
+    const dim3 grid(p->grid), block(kThreads);
+    if (mm && pk) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, true, true>), grid, block, p->lds_bytes, ctx->stream, a);
+    else if (pk) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, true, true>), grid, block, p->lds_bytes, ctx->stream, a);
+    else if (mm && p->fast) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, true, false>), grid, block, p->lds_bytes, ctx->stream, a);
+    else if (mm) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, false, false>), grid, block, p->lds_bytes, ctx->stream, a);
+    else if (p->fast) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, true, false>), grid, block, p->lds_bytes, ctx->stream, a);
+    else hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, false, false>), grid, block, p->lds_bytes, ctx->stream, a);
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }
