@@ -7,6 +7,7 @@ from ._lib import (AHC_MODE_AUTO, AHC_MODE_EXACT, Context, FluidAudioHipError, b
 from .ahc import AHCClustering, cut, fastcluster_compute_centroid_linkage, linkage  # noqa: F401
 from .ctc import (LogitsArgmax, ctc_greedy_decode, ctc_greedy_ids_batch, ctc_greedy_ids_dev, ctc_log_probs_dev,  # noqa: F401
                   decode_ctc_token_ids)
+from .formats import AudioWAV, RTTMParser, RTTMParserError, TimedSpeakerSegment, export_embeddings_json  # noqa: F401
 from .kmeans import KMeansClustering, SeededRNG, SpeakerCountConstraints  # noqa: F401
 from .mel import AudioMelSpectrogram, MelPlan, UnifiedMelExtractor  # noqa: F401
 from .pipeline import ClusteringResult, OfflineClusteringConfig, cluster_embeddings, select_training_embeddings  # noqa: F401

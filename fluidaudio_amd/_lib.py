@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_cluster", "fa_ahc_cut",
     "fa_vbx_speaker_count", "fa_vbx_refine",
     "fa_vbx_weighted_centroids", "fa_assign_cosine", "fa_centroid_scores", "fa_constrained_assign",
+    "fa_wav_pcm16_size", "fa_wav_encode_pcm16", "fa_wav_decode", "fa_rttm_parse", "fa_rttm_format", "fa_export_embeddings_json",
     "fa_seeded_rng_next", "fa_seeded_rng_below", "fa_kmeans_cluster", "fa_kmeans_cluster_ninit", "fa_speaker_constraints_resolve",
     "fa_resample_linear_frames", "fa_resample_linear", "fa_resample_poly_frames", "fa_resample_poly_taps", "fa_resample_poly",
 ]
@@ -145,6 +146,15 @@ def lib() -> C.CDLL:
     L.fa_centroid_scores.argtypes = [vp, vp, i64, i32, vp, i32, vp]
     L.fa_constrained_assign.argtypes = [vp, vp, i64, i32, vp, vp]
     u64 = C.c_uint64
+    L.fa_wav_pcm16_size.argtypes = [i64]
+    L.fa_wav_pcm16_size.restype = i64
+    L.fa_wav_encode_pcm16.argtypes = [vp, vp, i64, f64, i32, vp, i64, C.POINTER(i64)]
+    L.fa_wav_decode.argtypes = [vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
+    L.fa_rttm_parse.argtypes = [C.c_char_p, i64, i32, vp, i64, C.POINTER(i64), C.c_char_p, i64]
+    L.fa_rttm_format.argtypes = [vp, i64, C.c_char_p, C.c_char_p, i64]
+    L.fa_rttm_format.restype = i64
+    L.fa_export_embeddings_json.argtypes = [vp, i64, vp, i32, vp, i32, vp, i64, C.c_char_p, i64]
+    L.fa_export_embeddings_json.restype = i64
     L.fa_seeded_rng_next.argtypes = [C.POINTER(u64)]
     L.fa_seeded_rng_next.restype = u64
     L.fa_seeded_rng_below.argtypes = [C.POINTER(u64), u64]

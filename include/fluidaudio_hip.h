@@ -278,6 +278,43 @@ fa_status fa_kmeans_cluster_ninit(fa_ctx *ctx, const double *emb, int64_t n, int
 void fa_speaker_constraints_resolve(int64_t num_embeddings, const int64_t *num_speakers, const int64_t *min_speakers,
                                     const int64_t *max_speakers, int64_t out[3]);
 
+/* ------------------------------------------------------------------ wire formats ------ */
+/* AudioWAV.data (FluidAudio/Shared/AudioConverter.swift:474-532): float samples -> peak normalisation (normalize != 0 and
+ * max |x| > 0) -> clamp to [-1, 1] -> Int16(x * 32767) -> 16-bit PCM mono RIFF/WAVE (44-byte header + 2 n bytes).  HOST
+ * pointers; the sample pass runs on the device and is bit-identical to the reference's Float arithmetic. */
+int64_t fa_wav_pcm16_size(int64_t n_samples);
+fa_status fa_wav_encode_pcm16(fa_ctx *ctx, const float *samples, int64_t n, double sample_rate, int32_t normalize, uint8_t *out,
+                              int64_t out_capacity, int64_t *out_len);
+/* Extension (the reference reads audio through AVFoundation): RIFF/WAVE reader for 16-bit PCM and 32-bit float data,
+ * interleaved float output; out may be NULL to query frames / channels / sample_rate.  Pure host function. */
+fa_status fa_wav_decode(const uint8_t *data, int64_t len, float *out, int64_t out_capacity, int64_t *frames, int32_t *channels,
+                        int32_t *sample_rate);
+
+typedef struct fa_rttm_segment {   /* TimedSpeakerSegment as the RTTM loaders fill it */
+    float start_seconds, end_seconds, quality;
+    char speaker_id[64];
+} fa_rttm_segment;
+/* RTTMParser.loadSegments (FluidAudioCLI/Utils/RTTMParser.swift:22-63; strict = 1: blank and '#' lines skipped, any other
+ * malformed line is an error reported in bad_line, result sorted by start time) or the benchmark loader
+ * (FluidAudioCLI/Commands/SortformerBenchmark.swift:681-731; strict = 0: malformed lines skipped, file order kept).
+ * Pure host function; *count receives the number of segments even when out is NULL / too small. */
+fa_status fa_rttm_parse(const char *text, int64_t len, int32_t strict, fa_rttm_segment *out, int64_t out_capacity, int64_t *count,
+                        char *bad_line, int64_t bad_line_capacity);
+/* Extension: one "SPEAKER <file> 1 <start> <duration> <NA> <NA> <speaker> <NA> <NA>" line per segment; returns the text
+ * length and writes it (NUL-terminated) when out_capacity is larger. */
+int64_t fa_rttm_format(const fa_rttm_segment *segs, int64_t n, const char *file_id, char *out, int64_t out_capacity);
+
+typedef struct fa_export_embedding {   /* TimedEmbedding fields of the export payload */
+    int32_t chunk_index, speaker_index, start_frame, end_frame;
+    double start_time, end_time;
+} fa_export_embedding;
+/* OfflineDiarizerManager.exportEmbeddings (FluidAudio/Diarizer/Offline/Core/OfflineDiarizerManager.swift:913-955): JSON
+ * array of {chunkIndex, speakerIndex, startFrame, endFrame, startTime, endTime, embedding256, rho128, cluster}; cluster = -1
+ * past the end of assignments.  Numbers are printed in their shortest round-trip form.  Returns the text length. */
+int64_t fa_export_embeddings_json(const fa_export_embedding *items, int64_t n, const float *embedding256, int32_t emb_dim,
+                                  const double *rho128, int32_t rho_dim, const int32_t *assignments, int64_t n_assignments,
+                                  char *out, int64_t out_capacity);
+
 /* ------------------------------------------------------------------ resampling ------ */
 /* AudioConverter.linearResample (FluidAudio/Shared/AudioConverter.swift:388-442): planar float[channels][frames] ->
  * mono mix (weight 1/channels) -> linear interpolation to out_rate.  HOST pointers.  Bit-exact restatement. */

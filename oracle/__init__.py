@@ -530,3 +530,43 @@ def ctc_log_probs(logits, temperature: float = 1.0, blank_bias: float = 0.0, bla
     for t in range(x.shape[0]):
         lib().fa_oracle_log_softmax_row(x[t], x.shape[1], temperature, blank_bias, blank_id, out[t])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# wire formats (pure Python / numpy restatements; small inputs only)
+def wav_pcm16(samples, sample_rate: float, normalize: bool = True) -> bytes:
+    """AudioWAV.data (Sources/FluidAudio/Shared/AudioConverter.swift:474-532) in float32 arithmetic."""
+    import struct
+    x = np.asarray(samples, np.float32)
+    mx = np.float32(np.abs(x).max()) if x.size else np.float32(1.0)                  # :486
+    norm = (x / mx).astype(np.float32) if (normalize and mx > 0) else x             # :487
+    clipped = np.maximum(np.float32(-1.0), np.minimum(np.float32(1.0), norm))       # :493
+    pcm = np.trunc((clipped * np.float32(32767)).astype(np.float32)).astype("<i2")  # Int16(Float): toward zero (:494)
+    hdr = b"RIFF" + struct.pack("<I", 36 + 2 * pcm.size) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, int(sample_rate),
+                                                                                             int(sample_rate * 2), 2, 16)
+    return hdr + b"data" + struct.pack("<I", 2 * pcm.size) + pcm.tobytes()
+
+
+def rttm_parse(text: str, strict: bool = True):
+    """RTTMParser.loadSegments (RTTMParser.swift:22-63) / SortformerBenchmark.loadRTTMGroundTruth (:681-731) -> list of
+    (speaker, start float32, end float32); raises ValueError(line) in strict mode."""
+    out = []
+    for raw in text.split("\n"):
+        line = raw.strip(" \t\r\f\v")
+        if not line or (strict and line.startswith("#")):
+            continue
+        f = line.split()
+        ok = len(f) >= 8 and f[0] == "SPEAKER"
+        if ok:
+            try:
+                start, dur = np.float32(f[3]), np.float32(f[4])
+            except ValueError:
+                ok = False
+        if not ok:
+            if strict:
+                raise ValueError(line)
+            continue
+        out.append((f[7], float(start), float(np.float32(start + dur))))
+    if strict:
+        out.sort(key=lambda s: s[1])      # Python's sort is stable, like the reference's (:62)
+    return out
