@@ -35,6 +35,8 @@ EXPORTED_SYMBOLS = [
     "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_cluster", "fa_ahc_cut",
     "fa_vbx_speaker_count", "fa_vbx_refine",
     "fa_vbx_weighted_centroids", "fa_assign_cosine", "fa_centroid_scores", "fa_constrained_assign",
+    "fa_arpa_parse", "fa_arpa_destroy", "fa_arpa_unigram_count", "fa_arpa_bigram_context_count", "fa_arpa_score",
+    "fa_ctc_vocab_create", "fa_ctc_vocab_destroy", "fa_ctc_beam_search_batch_dev", "fa_ctc_beam_search_batch",
     "fa_wav_pcm16_size", "fa_wav_encode_pcm16", "fa_wav_decode", "fa_rttm_parse", "fa_rttm_format", "fa_export_embeddings_json",
     "fa_seeded_rng_next", "fa_seeded_rng_below", "fa_kmeans_cluster", "fa_kmeans_cluster_ninit", "fa_speaker_constraints_resolve",
     "fa_resample_linear_frames", "fa_resample_linear", "fa_resample_poly_frames", "fa_resample_poly_taps", "fa_resample_poly",
@@ -146,6 +148,19 @@ def lib() -> C.CDLL:
     L.fa_centroid_scores.argtypes = [vp, vp, i64, i32, vp, i32, vp]
     L.fa_constrained_assign.argtypes = [vp, vp, i64, i32, vp, vp]
     u64 = C.c_uint64
+    L.fa_arpa_parse.argtypes = [vp, C.c_char_p, i64, C.POINTER(vp)]
+    L.fa_arpa_destroy.argtypes = [vp]
+    L.fa_arpa_destroy.restype = None
+    L.fa_arpa_unigram_count.argtypes = [vp]
+    L.fa_arpa_unigram_count.restype = i64
+    L.fa_arpa_bigram_context_count.argtypes = [vp]
+    L.fa_arpa_bigram_context_count.restype = i64
+    L.fa_arpa_score.argtypes = [vp, C.c_char_p, C.c_char_p, C.POINTER(f32)]
+    L.fa_ctc_vocab_create.argtypes = [vp, vp, vp, i32, i32, C.POINTER(vp)]
+    L.fa_ctc_vocab_destroy.argtypes = [vp]
+    L.fa_ctc_vocab_destroy.restype = None
+    L.fa_ctc_beam_search_batch_dev.argtypes = [vp, vp, i32, i32, i32, i64, i64, vp, vp, vp, i32, f32, f32, i32, i32, vp, vp, vp]
+    L.fa_ctc_beam_search_batch.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, f32, f32, i32, i32, vp, vp, vp]
     L.fa_wav_pcm16_size.argtypes = [i64]
     L.fa_wav_pcm16_size.restype = i64
     L.fa_wav_encode_pcm16.argtypes = [vp, vp, i64, f64, i32, vp, i64, C.POINTER(i64)]

@@ -1,0 +1,614 @@
+// beam.hip — CTC prefix beam search with word-level ARPA language model rescoring, batched on gfx950.
+//
+// Replaces ctcBeamSearch (reference: Sources/FluidAudio/ASR/Parakeet/SlidingWindow/CTC/CtcDecoder.swift:118-241) and
+// ARPALanguageModel (…/CTC/ARPALanguageModel.swift:16-104).  One workgroup per utterance walks the frames; inside a frame
+// everything is data-parallel over the <= beamWidth x (tokenCandidates + 1) candidate hypotheses:
+//
+//   1. top-K tokens of the frame: most-significant-digit radix select on (log-prob descending, index ascending) keys;
+//   2. candidate totals.  The reference merges hypotheses through a dictionary keyed by the whole token prefix; here a prefix
+//      is a node of a trie kept in HBM — an open-addressing hash table over (parent node, token), so that a prefix which is
+//      pruned and later re-created gets the SAME node — and two observations replace the dictionary: an extension
+//      (beam i, token v) can only collide with the ONE live beam whose (parent node, last token) is (node i, v), and never
+//      with another extension.  Two 256-slot LDS hash maps (node -> beam, (parent, token) -> beam) answer both questions;
+//   3. pruning to the beam width: the same radix select on (total descending, candidate order ascending) keys, then a
+//      bitonic sort of the <= 128 survivors;
+//   4. survivors become the new beams; new prefixes get trie nodes, and — when a language model is attached — their
+//      running word (a polynomial hash of its bytes, built from per-token (multiplier, addend) pairs) is scored once
+//      against the unigram / bigram hash tables in HBM, so a frame costs at most beamWidth table probes.
+//
+// Order-dependent details of the reference (it iterates Swift dictionaries) are resolved as in the CPU restatement
+// (oracle.ctc_beam_search): candidates are ordered beam-major / token-minor, a merged hypothesis takes the earlier position,
+// ties keep that order.  logAddExp is evaluated in double and rounded to float (within 1 ulp of the reference's Float libm).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "fa_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBeam = 128;
+constexpr int kMaxTop = 64;
+constexpr int kMaxCand = kMaxBeam * (kMaxTop + 1);
+constexpr int kMapSlots = 256;
+constexpr uint64_t kHashBase = 0x100000001b3ull;   // odd: multiplication by it is a bijection mod 2^64
+constexpr float kUnkLogProb = -23.026f;            // ARPALanguageModel.unkLogProb (:33)
+
+struct UniEntry { uint64_t h; int32_t len; float logp, backoff; int32_t used; };
+struct BiEntry { uint64_t hp, hw; int32_t lp, lw; float logp; int32_t used; };
+struct TokInfo { uint64_t mult, add; int32_t len, boundary; };   // stripped piece: h' = h * mult + add, len' = len + this len
+
+struct LmView {
+    const UniEntry *uni; const BiEntry *bi;
+    uint32_t uni_mask, bi_mask;   // capacity - 1
+};
+
+__host__ __device__ inline uint64_t mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
+
+__host__ __device__ inline bool uni_find(const LmView &lm, uint64_t h, int32_t len, float &logp, float &backoff) {
+    if (!lm.uni) return false;
+    for (uint32_t s = static_cast<uint32_t>(mix64(h + static_cast<uint64_t>(len))) & lm.uni_mask;; s = (s + 1) & lm.uni_mask) {
+        const UniEntry e = lm.uni[s];
+        if (!e.used) return false;
+        if (e.h == h && e.len == len) { logp = e.logp; backoff = e.backoff; return true; }
+    }
+}
+
+__host__ __device__ inline bool bi_find(const LmView &lm, uint64_t hp, int32_t lp, uint64_t hw, int32_t lw, float &logp) {
+    if (!lm.bi) return false;
+    for (uint32_t s = static_cast<uint32_t>(mix64(mix64(hp + static_cast<uint64_t>(lp)) ^ (hw + static_cast<uint64_t>(lw) * 0x9e3779b97f4a7c15ull))) & lm.bi_mask;;
+         s = (s + 1) & lm.bi_mask) {
+        const BiEntry e = lm.bi[s];
+        if (!e.used) return false;
+        if (e.hp == hp && e.hw == hw && e.lp == lp && e.lw == lw) { logp = e.logp; return true; }
+    }
+}
+
+// ARPALanguageModel.score (:98-103); plen < 0 encodes prev == nil
+__host__ __device__ inline float lm_score(const LmView &lm, uint64_t hw, int32_t lw, uint64_t hp, int32_t plen) {
+    float logp, bo;
+    if (plen >= 0 && bi_find(lm, hp, plen, hw, lw, logp)) return logp;
+    float backoff = 0.0f;
+    if (plen >= 0 && uni_find(lm, hp, plen, logp, bo)) backoff = bo;
+    const float uni = uni_find(lm, hw, lw, logp, bo) ? logp : kUnkLogProb;
+    return backoff + uni;
+}
+
+inline void hash_bytes(const char *s, size_t n, uint64_t &h, uint64_t &mult) {
+    h = 0; mult = 1;
+    for (size_t i = 0; i < n; ++i) { h = h * kHashBase + static_cast<unsigned char>(s[i]); mult *= kHashBase; }
+}
+
+// monotone float -> uint map (larger float, larger uint); NaN sorts below everything
+__device__ __forceinline__ uint32_t ord_f32(float f) {
+    if (f != f) return 0u;
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ uint64_t desc_key(float value, uint32_t order) { return (static_cast<uint64_t>(~ord_f32(value)) << 32) | order; }
+
+__device__ __forceinline__ float log_add_exp(float a, float b) {   // CtcDecoder.swift:279-284
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    const float m = fmaxf(a, b);
+    const double s = exp(static_cast<double>(a - m)) + exp(static_cast<double>(b - m));
+    return static_cast<float>(static_cast<double>(m) + log(s));
+}
+
+struct Beams {   // structure of arrays in LDS
+    int32_t node[kMaxBeam], parent[kMaxBeam], last[kMaxBeam], wlen[kMaxBeam], plen[kMaxBeam];
+    float pb[kMaxBeam], pnb[kMaxBeam], lm[kMaxBeam], wscore[kMaxBeam];
+    uint64_t wh[kMaxBeam], ph[kMaxBeam];
+};
+
+struct BeamArgs {
+    const float *logp; const int32_t *valid; const TokInfo *tok; LmView lm;
+    unsigned long long *arena;   // [B][arena_stride] trie = hash table of (parent node << 32 | token), node id = slot; -1 = empty prefix
+    int32_t *tokens, *lens; float *scores;
+    int64_t row_stride, matrix_stride, arena_stride;
+    int32_t frames, vocab, blank, beam_width, top_k, use_lm, first;
+    float lm_weight, word_bonus;
+};
+
+struct Shared {
+    Beams b[2];
+    float cand_tot[kMaxCand];
+    int32_t stay_ord[kMaxBeam]; float stay_pb[kMaxBeam], stay_pnb[kMaxBeam], tot[kMaxBeam];
+    int32_t top_tok[kMaxTop]; float top_lp[kMaxTop];
+    unsigned long long sel_key[kMaxBeam];
+    int32_t hist[256];
+    int32_t map_node[kMapSlots], map_node_val[kMapSlots];
+    int32_t map_pl_parent[kMapSlots], map_pl_tok[kMapSlots], map_pl_val[kMapSlots];
+    unsigned long long thr;
+    int32_t sel_count, bin, remaining, done, n_beams;
+};
+
+// K smallest of `n` distinct 64-bit keys: returns (through s.thr) the K-th smallest key.  key(i) may be ~0ull for "absent".
+template <class KeyFn>
+__device__ void radix_select(Shared &s, const int n, int k, KeyFn key) {
+    const int tid = threadIdx.x;
+    unsigned long long prefix = 0;
+    if (k <= 0) {   // nothing to select: no key is <= 0
+        if (tid == 0) s.thr = 0;
+        __syncthreads();
+        return;
+    }
+    if (tid == 0) { s.done = 0; s.remaining = k; }
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        s.hist[tid] = 0;
+        __syncthreads();
+        if (s.done) break;
+        for (int i = tid; i < n; i += kThreads) {
+            const unsigned long long kk = key(i);
+            if (pass == 0 || (kk >> (shift + 8)) == prefix) atomicAdd(&s.hist[(kk >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {   // wave 0: bin where the running count reaches `remaining`
+            const int h0 = s.hist[4 * tid], h1 = s.hist[4 * tid + 1], h2 = s.hist[4 * tid + 2], h3 = s.hist[4 * tid + 3];
+            const int mine = h0 + h1 + h2 + h3;
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (tid >= off) incl += o; }
+            const int excl = incl - mine, need = s.remaining;
+            if (excl < need && need <= incl) {
+                int c = excl, b = 4 * tid;
+                if (c + h0 >= need) { } else { c += h0; b += 1; if (c + h1 >= need) { } else { c += h1; b += 1; if (c + h2 >= need) { } else { c += h2; b += 1; } } }
+                const int hb = s.hist[b];
+                s.bin = b;
+                s.remaining = need - c;
+                if (hb == need - c || pass == 7) s.done = 1;   // the whole bin belongs to the selection
+            }
+            if (tid == 63 && incl < need) { s.bin = 255; s.done = 2; }   // fewer than k keys present: take everything
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | static_cast<unsigned>(s.bin);
+        if (s.done) {
+            const unsigned long long low = shift ? ((1ull << shift) - 1) : 0ull;
+            if (tid == 0) s.thr = s.done == 2 ? ~0ull - 1 : ((prefix << shift) | low);
+        }
+    }
+    __syncthreads();
+}
+
+// ascending bitonic sort of s.sel_key[0 .. 128) (padded with ~0ull) by the first 128 threads
+__device__ void sort_selected(Shared &s) {
+    const int tid = threadIdx.x;
+    for (int k = 2; k <= kMaxBeam; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (tid < kMaxBeam) {
+                const int p = tid ^ j;
+                if (p > tid) {
+                    const unsigned long long a = s.sel_key[tid], b = s.sel_key[p];
+                    const bool up = (tid & k) == 0;
+                    if ((a > b) == up) { s.sel_key[tid] = b; s.sel_key[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__device__ __forceinline__ uint32_t slot_of(uint32_t a, uint32_t b) { return static_cast<uint32_t>(mix64((static_cast<uint64_t>(a) << 32) | b)) & (kMapSlots - 1); }
+
+__global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Shared &s = *reinterpret_cast<Shared *>(smem_raw);
+    const int tid = threadIdx.x;
+    const int u = a.first + blockIdx.x;
+    int T = a.frames;
+    if (a.valid) { const int v = a.valid[u]; T = v < 0 ? 0 : (v < T ? v : T); }
+    const float *mat = a.logp + static_cast<int64_t>(u) * a.matrix_stride;
+    unsigned long long *arena = a.arena + static_cast<int64_t>(blockIdx.x) * a.arena_stride;
+    const uint32_t arena_mask = static_cast<uint32_t>(a.arena_stride - 1);
+    const int W = a.beam_width, K = a.top_k, V = a.vocab;
+
+    if (tid == 0) {
+        Beams &b = s.b[0];
+        b.node[0] = -1; b.parent[0] = -3; b.last[0] = -1; b.wlen[0] = 0; b.plen[0] = -1;
+        b.pb[0] = 0.0f; b.pnb[0] = -INFINITY; b.lm[0] = 0.0f; b.wscore[0] = 0.0f; b.wh[0] = 0; b.ph[0] = 0;
+        s.n_beams = 1;
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int t = 0; t < T; ++t) {
+        const float *frame = mat + static_cast<int64_t>(t) * a.row_stride;
+        Beams &b = s.b[cur];
+        Beams &nb = s.b[cur ^ 1];
+        const int n = s.n_beams;
+        const float blank_lp = a.blank >= 0 && a.blank < V ? frame[a.blank] : -INFINITY;
+
+        // ---- 1. top-K tokens, best first (sorted { frame[$0] > frame[$1] }, stable: ties by index) ----
+        auto tok_key = [&](const int i) -> unsigned long long { return i == a.blank ? ~0ull : desc_key(frame[i], static_cast<uint32_t>(i)); };
+        radix_select(s, V, K, tok_key);
+        if (tid < kMaxBeam) s.sel_key[tid] = ~0ull;
+        if (tid == 0) s.sel_count = 0;
+        __syncthreads();
+        for (int i = tid; i < V; i += kThreads) {
+            const unsigned long long kk = tok_key(i);
+            if (kk <= s.thr && kk != ~0ull) { const int p = atomicAdd(&s.sel_count, 1); if (p < kMaxBeam) s.sel_key[p] = kk; }
+        }
+        __syncthreads();
+        sort_selected(s);
+        const int ntop = min(s.sel_count, K);
+        if (tid < ntop) { const int v = static_cast<int>(s.sel_key[tid] & 0xffffffffu); s.top_tok[tid] = v; s.top_lp[tid] = frame[v]; }
+        // ---- 2. maps over the live beams ----
+        s.map_node[tid] = -2;
+        s.map_pl_parent[tid] = -4;
+        if (tid < n) s.tot[tid] = log_add_exp(b.pb[tid], b.pnb[tid]);   // totalAcoustic (:83)
+        __syncthreads();
+        if (tid < n) {
+            for (uint32_t q = slot_of(static_cast<uint32_t>(b.node[tid]), 0x51u);; q = (q + 1) & (kMapSlots - 1))
+                if (atomicCAS(&s.map_node[q], -2, b.node[tid]) == -2) { s.map_node_val[q] = tid; break; }
+            for (uint32_t q = slot_of(static_cast<uint32_t>(b.parent[tid]), static_cast<uint32_t>(b.last[tid]));; q = (q + 1) & (kMapSlots - 1))
+                if (atomicCAS(&s.map_pl_parent[q], -4, b.parent[tid]) == -4) { s.map_pl_tok[q] = b.last[tid]; s.map_pl_val[q] = tid; break; }
+        }
+        __syncthreads();
+        auto find_node = [&](const int node) {
+            for (uint32_t q = slot_of(static_cast<uint32_t>(node), 0x51u);; q = (q + 1) & (kMapSlots - 1)) {
+                const int k = s.map_node[q];
+                if (k == -2) return -1;
+                if (k == node) return s.map_node_val[q];
+            }
+        };
+        auto find_child = [&](const int parent, const int tok) {   // live beam whose prefix is (parent prefix) + tok
+            for (uint32_t q = slot_of(static_cast<uint32_t>(parent), static_cast<uint32_t>(tok));; q = (q + 1) & (kMapSlots - 1)) {
+                const int k = s.map_pl_parent[q];
+                if (k == -4) return -1;
+                if (k == parent && s.map_pl_tok[q] == tok) return s.map_pl_val[q];
+            }
+        };
+        // ---- 3. candidate totals; candidate c = i (K + 1) + slot, slot 0 = the beam itself, slot 1 + r = beam + top token r ----
+        const int stride = ntop + 1, ncand = n * stride;
+        for (int c = tid; c < ncand; c += kThreads) {
+            const int i = c / stride, slot = c - i * stride;
+            const float tot_i = s.tot[i];
+            if (slot == 0) {
+                float pnb = -INFINITY;
+                int ord = c, r = -1;
+                const int last = b.last[i];
+                for (int q = 0; q < ntop; ++q) if (s.top_tok[q] == last) r = q;
+                if (r >= 0) {
+                    pnb = b.pnb[i] + s.top_lp[r];                                        // same prefix, repeated token (:190-194)
+                    const int p = b.parent[i] != -3 ? find_node(b.parent[i]) : -1;       // the beam one token shorter extends into this one
+                    if (p >= 0) {
+                        const float from_parent = (b.last[p] == last ? b.pb[p] : s.tot[p]) + s.top_lp[r];
+                        pnb = log_add_exp(pnb, from_parent);
+                        ord = min(ord, p * stride + 1 + r);
+                    }
+                }
+                const float pb = tot_i + blank_lp;                                      // blank extension (:172-176)
+                s.stay_pb[i] = pb; s.stay_pnb[i] = pnb; s.stay_ord[i] = ord;
+                s.cand_tot[c] = log_add_exp(pb, pnb) + b.lm[i];
+            } else {
+                const int r = slot - 1, v = s.top_tok[r];
+                if (find_child(b.node[i], v) >= 0) { s.cand_tot[c] = NAN; continue; }   // merged into that beam's slot 0
+                const float pnb = (v == b.last[i] ? b.pb[i] : tot_i) + s.top_lp[r];     // (:196-214)
+                float lm = b.lm[i];
+                if (a.use_lm && a.tok[v].boundary && b.wlen[i] > 0) lm = lm + b.wscore[i];   // a word is completed (:185-189)
+                s.cand_tot[c] = pnb + lm;
+            }
+        }
+        __syncthreads();
+        // ---- 4. prune: W best totals, earlier candidate first on ties ----
+        auto cand_key = [&](const int c) -> unsigned long long {
+            const float v = s.cand_tot[c];
+            if (v != v) return ~0ull;
+            const int i = c / stride;
+            return desc_key(v, static_cast<uint32_t>(c == i * stride ? s.stay_ord[i] : c));
+        };
+        radix_select(s, ncand, W, cand_key);
+        if (tid < kMaxBeam) s.sel_key[tid] = ~0ull;
+        if (tid == 0) s.sel_count = 0;
+        __syncthreads();
+        for (int c = tid; c < ncand; c += kThreads) {
+            const unsigned long long kk = cand_key(c);
+            if (kk <= s.thr && kk != ~0ull) {
+                const int p = atomicAdd(&s.sel_count, 1);
+                // keep the candidate index next to the key: low 32 bits of the key are the ORDER, which for a merged beam is not c
+                if (p < kMaxBeam) { s.sel_key[p] = kk; }
+            }
+        }
+        __syncthreads();
+        sort_selected(s);
+        const int nsel = min(s.sel_count, W);
+        // ---- 5. survivors -> new beams (rank = sorted position) ----
+        if (tid < nsel) {
+            const unsigned ord = static_cast<unsigned>(s.sel_key[tid] & 0xffffffffu);
+            // recover the candidate: order values of extensions are their own index; a beam's slot 0 may carry a parent-extension order
+            int c = static_cast<int>(ord);
+            int i = c / stride, slot = c - i * stride;
+            if (slot != 0) {
+                const int j = find_child(b.node[i], s.top_tok[slot - 1]);
+                if (j >= 0) { i = j; slot = 0; }                                         // it was the merged position of beam j
+            }
+            if (slot == 0) {
+                nb.node[tid] = b.node[i]; nb.parent[tid] = b.parent[i]; nb.last[tid] = b.last[i];
+                nb.pb[tid] = s.stay_pb[i]; nb.pnb[tid] = s.stay_pnb[i]; nb.lm[tid] = b.lm[i];
+                nb.wlen[tid] = b.wlen[i]; nb.plen[tid] = b.plen[i]; nb.wh[tid] = b.wh[i]; nb.ph[tid] = b.ph[i]; nb.wscore[tid] = b.wscore[i];
+            } else {
+                const int r = slot - 1, v = s.top_tok[r];
+                // canonical trie node of (prefix of beam i) + v: find or insert; at most frames x beam_width nodes, table twice that
+                const unsigned long long nk = (static_cast<unsigned long long>(static_cast<uint32_t>(b.node[i])) << 32) | static_cast<uint32_t>(v);
+                int node;
+                for (uint32_t q = static_cast<uint32_t>(mix64(nk)) & arena_mask;; q = (q + 1) & arena_mask) {
+                    const unsigned long long seen = atomicCAS(&arena[q], ~0ull, nk);
+                    if (seen == ~0ull || seen == nk) { node = static_cast<int>(q); break; }
+                }
+                const float tot_i = s.tot[i];
+                nb.node[tid] = node; nb.parent[tid] = b.node[i]; nb.last[tid] = v;
+                nb.pb[tid] = -INFINITY;
+                nb.pnb[tid] = (v == b.last[i] ? b.pb[i] : tot_i) + s.top_lp[r];
+                float lm = b.lm[i], ws = 0.0f;
+                uint64_t wh = b.wh[i], ph = b.ph[i];
+                int wlen = b.wlen[i], plen = b.plen[i];
+                if (a.use_lm) {
+                    const TokInfo ti = a.tok[v];
+                    if (ti.boundary) {                                                   // (:183-194)
+                        if (wlen > 0) { lm = lm + b.wscore[i]; ph = wh; plen = wlen; }
+                        wh = ti.add; wlen = ti.len;
+                    } else { wh = wh * ti.mult + ti.add; wlen += ti.len; }               // wordPieces.append(piece) (:195-197)
+                    if (wlen > 0) ws = a.lm_weight * lm_score(a.lm, wh, wlen, ph, plen) + a.word_bonus;
+                }
+                nb.lm[tid] = lm; nb.wscore[tid] = ws; nb.wh[tid] = wh; nb.ph[tid] = ph; nb.wlen[tid] = wlen; nb.plen[tid] = plen;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s.n_beams = nsel;
+        cur ^= 1;
+        __syncthreads();
+    }
+
+    // ---- finalize: trailing partial word (:222-229), first maximum in rank order, read the prefix back from the trie ----
+    if (tid == 0) {
+        const Beams &b = s.b[cur];
+        int best = -1;
+        float best_total = 0.0f;
+        for (int i = 0; i < s.n_beams; ++i) {
+            float lm = b.lm[i];
+            if (a.use_lm && b.wlen[i] > 0) lm = lm + b.wscore[i];
+            const float total = log_add_exp(b.pb[i], b.pnb[i]) + lm;
+            if (best < 0 || total > best_total) { best = i; best_total = total; }
+        }
+        int32_t *out = a.tokens + static_cast<int64_t>(u) * a.frames;
+        int len = 0;
+        if (best >= 0 && T > 0) {
+            for (int node = b.node[best]; node >= 0; node = static_cast<int>(arena[node] >> 32)) ++len;
+            int pos = len;
+            for (int node = b.node[best]; node >= 0; node = static_cast<int>(arena[node] >> 32)) out[--pos] = static_cast<int32_t>(arena[node] & 0xffffffffu);
+        }
+        a.lens[u] = len;
+        if (a.scores) a.scores[u] = T > 0 && best >= 0 ? best_total : 0.0f;
+    }
+}
+
+inline uint32_t pow2_at_least(size_t n) { uint32_t c = 16; while (c < n) c <<= 1; return c; }
+
+bool parse_float_full(const std::string &s, float &out) {   // Swift's Float(String)
+    if (s.empty()) return false;
+    char *end = nullptr;
+    const float v = strtof(s.c_str(), &end);
+    if (end != s.c_str() + s.size() || s[0] == ' ') return false;
+    out = v;
+    return true;
+}
+
+}  // namespace
+
+struct fa_arpa_lm {
+    fa_ctx *ctx = nullptr;
+    std::vector<UniEntry> uni;
+    std::vector<BiEntry> bi;
+    int64_t n_uni = 0, n_bi_ctx = 0, n_bi = 0;
+    void *d_uni = nullptr, *d_bi = nullptr;
+    LmView host_view() const { return LmView{uni.empty() ? nullptr : uni.data(), bi.empty() ? nullptr : bi.data(), static_cast<uint32_t>(uni.size() - 1), static_cast<uint32_t>(bi.size() - 1)}; }
+    LmView dev_view() const { return LmView{static_cast<const UniEntry *>(d_uni), static_cast<const BiEntry *>(d_bi), static_cast<uint32_t>(uni.size() - 1), static_cast<uint32_t>(bi.size() - 1)}; }
+};
+
+struct fa_ctc_vocab {
+    fa_ctx *ctx = nullptr;
+    int32_t vocab_size = 0;
+    void *d_tok = nullptr;
+};
+
+extern "C" {
+
+fa_status fa_arpa_parse(fa_ctx *ctx, const char *text, int64_t len, fa_arpa_lm **out) {
+    if (!out || (!text && len > 0) || len < 0) return FA_INVALID_ARGUMENT;   // ctx may be NULL: parsing and scoring are host code
+    *out = nullptr;
+    try {
+        const float log10_to_nat = static_cast<float>(std::log(10.0));           // ARPALanguageModel.log10ToNat (:30)
+        struct U { std::string w; float p, b; };
+        struct B2 { std::string c, w; float p; };
+        std::unordered_map<std::string, size_t> uidx;
+        std::unordered_map<std::string, size_t> bidx;
+        std::vector<U> us;
+        std::vector<B2> bs;
+        std::unordered_map<std::string, int> contexts;
+        std::string section;
+        const std::string ws = " \t\r\n\f\v";
+        for (int64_t pos = 0; pos <= len;) {
+            int64_t e = pos;
+            while (e < len && text[e] != '\n') ++e;
+            std::string line(text + pos, text + e);
+            pos = e + 1;
+            const size_t a0 = line.find_first_not_of(ws), a1 = line.find_last_not_of(ws);
+            line = a0 == std::string::npos ? std::string() : line.substr(a0, a1 - a0 + 1);   // trimmingCharacters (:131)
+            if (line.empty() || line.rfind("\\data\\", 0) == 0) continue;                       // :54
+            if (line == "\\end\\") break;                                                       // :55
+            if (line[0] == '\\') { section = line; continue; }                                  // :56-59
+            if (line.rfind("ngram ", 0) == 0) continue;                                         // :61
+            std::vector<std::string> parts;
+            for (size_t i = 0;;) { const size_t j = line.find('\t', i); parts.emplace_back(line.substr(i, j == std::string::npos ? j : j - i)); if (j == std::string::npos) break; i = j + 1; }
+            float l10;
+            if (!parse_float_full(parts[0], l10)) continue;                                     // malformed line skipped (:64-67)
+            const float prob = l10 * log10_to_nat;
+            auto backoff = [&](size_t i) { float v; return parts.size() > i ? (parse_float_full(parts[i], v) ? v : 0.0f) * log10_to_nat : 0.0f; };
+            if (section == "\\1-grams:" && parts.size() >= 2) {
+                const float bo = backoff(2);
+                auto it = uidx.find(parts[1]);
+                if (it == uidx.end()) { uidx[parts[1]] = us.size(); us.push_back({parts[1], prob, bo}); } else { us[it->second].p = prob; us[it->second].b = bo; }
+            } else if (section == "\\2-grams:" && parts.size() >= 3) {
+                const std::string key = parts[1] + '\t' + parts[2];
+                auto it = bidx.find(key);
+                if (it == bidx.end()) { bidx[key] = bs.size(); bs.push_back({parts[1], parts[2], prob}); } else bs[it->second].p = prob;
+                contexts[parts[1]] = 1;
+            }
+        }
+        fa_arpa_lm *lm = new fa_arpa_lm();
+        lm->ctx = ctx; lm->n_uni = static_cast<int64_t>(us.size()); lm->n_bi = static_cast<int64_t>(bs.size()); lm->n_bi_ctx = static_cast<int64_t>(contexts.size());
+        lm->uni.assign(pow2_at_least(2 * us.size() + 1), UniEntry{0, 0, 0.f, 0.f, 0});
+        lm->bi.assign(pow2_at_least(2 * bs.size() + 1), BiEntry{0, 0, 0, 0, 0.f, 0});
+        const uint32_t um = static_cast<uint32_t>(lm->uni.size() - 1), bm = static_cast<uint32_t>(lm->bi.size() - 1);
+        for (const U &x : us) {
+            uint64_t h, m; hash_bytes(x.w.data(), x.w.size(), h, m);
+            const int32_t l = static_cast<int32_t>(x.w.size());
+            uint32_t s = static_cast<uint32_t>(mix64(h + static_cast<uint64_t>(l))) & um;
+            while (lm->uni[s].used) s = (s + 1) & um;
+            lm->uni[s] = UniEntry{h, l, x.p, x.b, 1};
+        }
+        for (const B2 &x : bs) {
+            uint64_t hp, hw, m; hash_bytes(x.c.data(), x.c.size(), hp, m); hash_bytes(x.w.data(), x.w.size(), hw, m);
+            const int32_t lp = static_cast<int32_t>(x.c.size()), lw = static_cast<int32_t>(x.w.size());
+            uint32_t s = static_cast<uint32_t>(mix64(mix64(hp + static_cast<uint64_t>(lp)) ^ (hw + static_cast<uint64_t>(lw) * 0x9e3779b97f4a7c15ull))) & bm;
+            while (lm->bi[s].used) s = (s + 1) & bm;
+            lm->bi[s] = BiEntry{hp, hw, lp, lw, x.p, 1};
+        }
+        *out = lm;
+        return FA_SUCCESS;
+    } catch (const std::bad_alloc &) {
+        return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "arpa: host allocation failed");
+    } catch (...) {
+        return fa::set_error(ctx, FA_UNKNOWN_ERROR, "arpa: unexpected failure");
+    }
+}
+
+void fa_arpa_destroy(fa_arpa_lm *lm) {
+    if (!lm) return;
+    if ((lm->d_uni || lm->d_bi) && lm->ctx) { (void)hipSetDevice(lm->ctx->device); (void)hipFree(lm->d_uni); (void)hipFree(lm->d_bi); }
+    delete lm;
+}
+
+int64_t fa_arpa_unigram_count(const fa_arpa_lm *lm) { return lm ? lm->n_uni : 0; }
+int64_t fa_arpa_bigram_context_count(const fa_arpa_lm *lm) { return lm ? lm->n_bi_ctx : 0; }
+
+fa_status fa_arpa_score(const fa_arpa_lm *lm, const char *word, const char *prev, float *out) {
+    if (!lm || !word || !out) return FA_INVALID_ARGUMENT;
+    uint64_t hw, hp = 0, m;
+    hash_bytes(word, strlen(word), hw, m);
+    if (prev) hash_bytes(prev, strlen(prev), hp, m);
+    *out = lm_score(lm->host_view(), hw, static_cast<int32_t>(strlen(word)), hp, prev ? static_cast<int32_t>(strlen(prev)) : -1);
+    return FA_SUCCESS;
+}
+
+fa_status fa_ctc_vocab_create(fa_ctx *ctx, const int32_t *ids, const char *const *pieces, int32_t n, int32_t vocab_size, fa_ctc_vocab **out) {
+    if (!ctx || !out || n < 0 || vocab_size < 1 || (n > 0 && (!ids || !pieces))) return FA_INVALID_ARGUMENT;
+    *out = nullptr;
+    std::vector<TokInfo> tok(vocab_size, TokInfo{1, 0, 0, 0});                        // missing id: vocabulary[v] ?? "" (:181)
+    static const char kBoundary[] = "\xe2\x96\x81";                                   // U+2581, ASRConstants.sentencePieceWordBoundary
+    for (int32_t i = 0; i < n; ++i) {
+        if (ids[i] < 0 || ids[i] >= vocab_size || !pieces[i]) continue;
+        const char *p = pieces[i];
+        size_t len = strlen(p);
+        TokInfo t{1, 0, 0, 0};
+        if (len >= 3 && memcmp(p, kBoundary, 3) == 0) { t.boundary = 1; p += 3; len -= 3; }   // hasPrefix + dropFirst (:184,:192)
+        hash_bytes(p, len, t.add, t.mult);
+        t.len = static_cast<int32_t>(len);
+        tok[ids[i]] = t;
+    }
+    fa::DeviceGuard guard(ctx->device);
+    fa_ctc_vocab *v = new (std::nothrow) fa_ctc_vocab();
+    if (!v) return FA_ALLOCATION_FAILURE;
+    v->ctx = ctx; v->vocab_size = vocab_size;
+    hipError_t e = hipMalloc(&v->d_tok, sizeof(TokInfo) * vocab_size);
+    if (e == hipSuccess) e = hipMemcpy(v->d_tok, tok.data(), sizeof(TokInfo) * vocab_size, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(v->d_tok); delete v; return fa::hip_status(ctx, e, "ctc vocab upload"); }
+    *out = v;
+    return FA_SUCCESS;
+}
+
+void fa_ctc_vocab_destroy(fa_ctc_vocab *v) {
+    if (!v) return;
+    if (v->d_tok) { (void)hipSetDevice(v->ctx->device); (void)hipFree(v->d_tok); }
+    delete v;
+}
+
+fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, int32_t batch, int32_t frames, int32_t vocab, int64_t row_stride,
+                                       int64_t matrix_stride, const int32_t *d_valid_frames, const fa_ctc_vocab *vocabulary, fa_arpa_lm *lm,
+                                       int32_t beam_width, float lm_weight, float word_bonus, int32_t blank_id, int32_t token_candidates,
+                                       int32_t *d_tokens, int32_t *d_lens, float *d_scores) {
+    if (!ctx) return FA_INVALID_ARGUMENT;
+    if (batch == 0) return FA_SUCCESS;
+    if (batch < 0 || frames < 0 || vocab < 1 || !d_tokens || !d_lens || (frames > 0 && !d_log_probs))
+        return fa::set_error(ctx, FA_INVALID_ARGUMENT, "beam search: bad arguments");
+    if (beam_width < 1 || beam_width > kMaxBeam || token_candidates < 0 || token_candidates > kMaxTop)
+        return fa::set_error(ctx, FA_INVALID_ARGUMENT, "beam search: beam width 1..%d, token candidates 0..%d", kMaxBeam, kMaxTop);
+    if (lm && (!vocabulary || vocabulary->vocab_size < vocab)) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "beam search: the language model needs a vocabulary covering all tokens");
+    if (row_stride < vocab) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "beam search: row stride < vocab");
+    fa::DeviceGuard guard(ctx->device);
+    if (lm && !lm->d_uni) {   // first use: upload the tables to this context's device
+        lm->ctx = ctx;
+        FA_HIP_TRY(ctx, hipMalloc(&lm->d_uni, sizeof(UniEntry) * lm->uni.size()));
+        FA_HIP_TRY(ctx, hipMalloc(&lm->d_bi, sizeof(BiEntry) * lm->bi.size()));
+        FA_HIP_TRY(ctx, hipMemcpy(lm->d_uni, lm->uni.data(), sizeof(UniEntry) * lm->uni.size(), hipMemcpyHostToDevice));
+        FA_HIP_TRY(ctx, hipMemcpy(lm->d_bi, lm->bi.data(), sizeof(BiEntry) * lm->bi.size(), hipMemcpyHostToDevice));
+    }
+    BeamArgs a{};
+    a.logp = d_log_probs; a.valid = d_valid_frames; a.tok = vocabulary ? static_cast<const TokInfo *>(vocabulary->d_tok) : nullptr;
+    if (lm) a.lm = lm->dev_view();
+    a.tokens = d_tokens; a.lens = d_lens; a.scores = d_scores;
+    a.row_stride = row_stride; a.matrix_stride = matrix_stride;
+    a.frames = frames; a.vocab = vocab; a.blank = blank_id; a.beam_width = beam_width; a.top_k = token_candidates;
+    a.use_lm = lm != nullptr; a.lm_weight = lm_weight; a.word_bonus = word_bonus;
+    a.arena_stride = pow2_at_least(static_cast<size_t>(2) * frames * beam_width + 2);
+    // trie tables: one per utterance in flight, at most ~2 GiB at a time
+    const int64_t per = a.arena_stride * static_cast<int64_t>(sizeof(unsigned long long));
+    const int chunk = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(batch, (int64_t(2) << 30) / std::max<int64_t>(per, 1))));
+    fa::DevBuf d_arena;
+    FA_HIP_TRY(ctx, d_arena.alloc(static_cast<size_t>(per) * chunk));
+    a.arena = d_arena.as<unsigned long long>();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_beam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(Shared)));
+    for (int first = 0; first < batch; first += chunk) {
+        a.first = first;
+        FA_HIP_TRY(ctx, hipMemsetAsync(d_arena.p, 0xff, static_cast<size_t>(per) * std::min(chunk, batch - first), ctx->stream));
+        hipLaunchKernelGGL(ctc_beam_kernel, dim3(std::min(chunk, batch - first)), dim3(kThreads), sizeof(Shared), ctx->stream, a);
+        FA_HIP_TRY(ctx, hipGetLastError());
+    }
+    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the arena is freed on return
+    return FA_SUCCESS;
+}
+
+fa_status fa_ctc_beam_search_batch(fa_ctx *ctx, const float *log_probs, int32_t batch, int32_t frames, int32_t vocab, const int32_t *valid_frames,
+                                   const fa_ctc_vocab *vocabulary, fa_arpa_lm *lm, int32_t beam_width, float lm_weight, float word_bonus,
+                                   int32_t blank_id, int32_t token_candidates, int32_t *tokens, int32_t *lens, float *scores) {
+    if (!ctx) return FA_INVALID_ARGUMENT;
+    if (batch == 0) return FA_SUCCESS;
+    if (batch < 0 || frames < 0 || vocab < 1 || !tokens || !lens || (frames > 0 && !log_probs)) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "beam search: bad arguments");
+    fa::DeviceGuard guard(ctx->device);
+    const size_t n = static_cast<size_t>(batch) * frames * vocab;
+    fa::DevBuf d_lp, d_valid, d_tok, d_len, d_sc;
+    FA_HIP_TRY(ctx, d_lp.alloc(sizeof(float) * n));
+    FA_HIP_TRY(ctx, d_tok.alloc(sizeof(int32_t) * static_cast<size_t>(batch) * std::max(frames, 1)));
+    FA_HIP_TRY(ctx, d_len.alloc(sizeof(int32_t) * batch));
+    FA_HIP_TRY(ctx, d_sc.alloc(sizeof(float) * batch));
+    if (n) FA_HIP_TRY(ctx, hipMemcpyAsync(d_lp.p, log_probs, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
+    if (valid_frames) {
+        FA_HIP_TRY(ctx, d_valid.alloc(sizeof(int32_t) * batch));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(d_valid.p, valid_frames, sizeof(int32_t) * batch, hipMemcpyHostToDevice, ctx->stream));
+    }
+    FA_TRY(fa_ctc_beam_search_batch_dev(ctx, d_lp.as<float>(), batch, frames, vocab, vocab, static_cast<int64_t>(frames) * vocab,
+                                        valid_frames ? d_valid.as<int32_t>() : nullptr, vocabulary, lm, beam_width, lm_weight, word_bonus, blank_id,
+                                        token_candidates, d_tok.as<int32_t>(), d_len.as<int32_t>(), d_sc.as<float>()));
+    if (frames > 0) FA_HIP_TRY(ctx, hipMemcpyAsync(tokens, d_tok.p, sizeof(int32_t) * static_cast<size_t>(batch) * frames, hipMemcpyDeviceToHost, ctx->stream));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(lens, d_len.p, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, ctx->stream));
+    if (scores) FA_HIP_TRY(ctx, hipMemcpyAsync(scores, d_sc.p, sizeof(float) * batch, hipMemcpyDeviceToHost, ctx->stream));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FA_SUCCESS;
+}
+
+}  // extern "C"

@@ -278,6 +278,41 @@ fa_status fa_kmeans_cluster_ninit(fa_ctx *ctx, const double *emb, int64_t n, int
 void fa_speaker_constraints_resolve(int64_t num_embeddings, const int64_t *num_speakers, const int64_t *min_speakers,
                                     const int64_t *max_speakers, int64_t out[3]);
 
+/* ------------------------------------------------------------------ CTC beam search + ARPA LM ------ */
+/* ARPALanguageModel (FluidAudio/ASR/Parakeet/SlidingWindow/CTC/ARPALanguageModel.swift:16-104): unigrams and bigrams of a
+ * plain-text ARPA file (tab-separated fields, log10 -> natural log in float); higher orders ignored, malformed lines
+ * skipped.  Words are keyed by a 64-bit polynomial hash of their bytes plus their length.  Parsing and fa_arpa_score are
+ * host code (ctx may be NULL); the tables move to the device on the first search. */
+typedef struct fa_arpa_lm fa_arpa_lm;
+fa_status fa_arpa_parse(fa_ctx *ctx, const char *text, int64_t len, fa_arpa_lm **out);
+void fa_arpa_destroy(fa_arpa_lm *lm);
+int64_t fa_arpa_unigram_count(const fa_arpa_lm *lm);          /* lm.unigrams.count */
+int64_t fa_arpa_bigram_context_count(const fa_arpa_lm *lm);   /* lm.bigrams.count (context words) */
+/* ARPALanguageModel.score(word:prev:) (:98-103); prev may be NULL (nil).  Pure host function on the same tables. */
+fa_status fa_arpa_score(const fa_arpa_lm *lm, const char *word, const char *prev, float *out);
+
+/* The token vocabulary ([Int: String]) as the device needs it for word tracking: SentencePiece word-boundary flag and the
+ * hash pair of the piece.  ids[i] -> pieces[i] (UTF-8); ids not listed decode to "". */
+typedef struct fa_ctc_vocab fa_ctc_vocab;
+fa_status fa_ctc_vocab_create(fa_ctx *ctx, const int32_t *ids, const char *const *pieces, int32_t n, int32_t vocab_size,
+                              fa_ctc_vocab **out);
+void fa_ctc_vocab_destroy(fa_ctc_vocab *vocab);
+
+/* ctcBeamSearch (FluidAudio/ASR/Parakeet/SlidingWindow/CTC/CtcDecoder.swift:118-241) for a batch of [frames, vocab] float
+ * log-probability matrices: one workgroup per utterance.  lm / vocabulary may be NULL (no rescoring).  beam_width <= 128,
+ * token_candidates <= 64.  tokens: int32[batch][frames] (best prefix, lens[b] entries used), scores: total of the winner
+ * (nullable).  The string form is decodeCtcTokenIds over tokens.  DEVICE pointers, synchronous. */
+fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, int32_t batch, int32_t frames, int32_t vocab,
+                                       int64_t row_stride, int64_t matrix_stride, const int32_t *d_valid_frames,
+                                       const fa_ctc_vocab *vocabulary, fa_arpa_lm *lm, int32_t beam_width, float lm_weight,
+                                       float word_bonus, int32_t blank_id, int32_t token_candidates, int32_t *d_tokens,
+                                       int32_t *d_lens, float *d_scores);
+/* Same with HOST pointers and contiguous matrices. */
+fa_status fa_ctc_beam_search_batch(fa_ctx *ctx, const float *log_probs, int32_t batch, int32_t frames, int32_t vocab,
+                                   const int32_t *valid_frames, const fa_ctc_vocab *vocabulary, fa_arpa_lm *lm,
+                                   int32_t beam_width, float lm_weight, float word_bonus, int32_t blank_id,
+                                   int32_t token_candidates, int32_t *tokens, int32_t *lens, float *scores);
+
 /* ------------------------------------------------------------------ wire formats ------ */
 /* AudioWAV.data (FluidAudio/Shared/AudioConverter.swift:474-532): float samples -> peak normalisation (normalize != 0 and
  * max |x| > 0) -> clamp to [-1, 1] -> Int16(x * 32767) -> 16-bit PCM mono RIFF/WAVE (44-byte header + 2 n bytes).  HOST

@@ -570,3 +570,142 @@ def rttm_parse(text: str, strict: bool = True):
     if strict:
         out.sort(key=lambda s: s[1])      # Python's sort is stable, like the reference's (:62)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CTC prefix beam search with ARPA language model (pure Python restatement; small cases only)
+WORD_BOUNDARY = "▁"          # ASRConstants.sentencePieceWordBoundary
+
+
+def _swift_float(s: str):
+    """Float(String) of the Swift standard library: the whole string must be a number, no surrounding whitespace."""
+    if not s or s != s.strip() or "_" in s:
+        raise ValueError(s)
+    return np.float32(s)
+
+
+class ARPALanguageModel:
+    """ARPALanguageModel (Sources/FluidAudio/ASR/Parakeet/SlidingWindow/CTC/ARPALanguageModel.swift:16-104): unigrams and
+    bigrams of a plain-text ARPA file, log10 -> natural log in float32."""
+    LOG10_TO_NAT = np.float32(np.log(10.0))
+    UNK_LOG_PROB = np.float32(-23.026)
+
+    def __init__(self):
+        self.unigrams, self.bigrams = {}, {}
+
+    @classmethod
+    def parse(cls, text: str):
+        lm, section = cls(), ""
+        for raw in text.split("\n"):
+            line = raw.strip()
+            if not line or line.startswith("\\data\\"):
+                continue
+            if line == "\\end\\":
+                break
+            if line.startswith("\\"):
+                section = line
+                continue
+            if line.startswith("ngram "):
+                continue
+            parts = line.split("\t")
+            try:
+                prob = np.float32(_swift_float(parts[0]) * cls.LOG10_TO_NAT)
+            except ValueError:
+                continue                                                             # malformed line skipped (:64-67)
+
+            def backoff(i):
+                try:
+                    return np.float32(_swift_float(parts[i]) * cls.LOG10_TO_NAT) if len(parts) > i else np.float32(0.0)
+                except ValueError:
+                    return np.float32(0.0) * cls.LOG10_TO_NAT
+            if section == "\\1-grams:" and len(parts) >= 2:
+                lm.unigrams[parts[1]] = (prob, backoff(2))
+            elif section == "\\2-grams:" and len(parts) >= 3:
+                lm.bigrams.setdefault(parts[1], {})[parts[2]] = (prob, backoff(3))
+        return lm
+
+    def score(self, word: str, prev):                                                # :98-103
+        if prev is not None and word in self.bigrams.get(prev, {}):
+            return self.bigrams[prev][word][0]
+        bo = self.unigrams[prev][1] if (prev is not None and prev in self.unigrams) else np.float32(0.0)
+        return np.float32(bo + (self.unigrams[word][0] if word in self.unigrams else self.UNK_LOG_PROB))
+
+
+def log_add_exp(a, b):                                                               # CtcDecoder.swift:279-284
+    a, b = np.float32(a), np.float32(b)
+    if a == -np.inf:
+        return b
+    if b == -np.inf:
+        return a
+    m = max(a, b)
+    # evaluated in double and rounded once: within 1 ulp of the reference's Float exp/log (Darwin libm, not reproducible
+    # bit for bit anyway) and identical between this restatement and the device
+    return np.float32(np.float64(m) + np.log(np.exp(np.float64(np.float32(a - m))) + np.exp(np.float64(np.float32(b - m)))))
+
+
+def ctc_beam_search(log_probs, vocabulary: dict, lm=None, beam_width=100, lm_weight=0.3, word_bonus=0.0, blank_id=1024,
+                    token_candidates=40):
+    """ctcBeamSearch (CtcDecoder.swift:118-241) -> (token ids of the best prefix, its total score).  The reference iterates
+    Swift dictionaries (arbitrary order); every quantity is order-independent except ties, which are resolved HERE as:
+    top tokens by (log-prob desc, index asc); beams in rank order, each followed by its extensions in token order; stable
+    sort by total for the pruning; first maximum at the end."""
+    lp = np.asarray(log_probs, np.float32)
+    if lp.size == 0 or lp.shape[1] == 0:
+        return [], None
+    V = lp.shape[1]
+    lm_weight, word_bonus = np.float32(lm_weight), np.float32(word_bonus)
+    NEG = np.float32(-np.inf)
+    beams = {(): dict(prefix=(), pb=np.float32(0.0), pnb=NEG, lm=np.float32(0.0), pieces=(), prev=None)}
+    total_ac = lambda b: log_add_exp(b["pb"], b["pnb"])
+    total = lambda b: np.float32(total_ac(b) + b["lm"])
+    for frame in lp:
+        blank_lp = frame[blank_id] if 0 <= blank_id < V else NEG
+        top = sorted((v for v in range(V) if v != blank_id), key=lambda v: (-frame[v], v))[:token_candidates]
+        new = {}
+
+        def merge(b):
+            e = new.get(b["prefix"])
+            if e is not None:
+                e["pb"], e["pnb"] = log_add_exp(e["pb"], b["pb"]), log_add_exp(e["pnb"], b["pnb"])
+            else:
+                new[b["prefix"]] = b
+        for beam in list(beams.values()):
+            prev_total = total_ac(beam)
+            merge(dict(beam, pb=np.float32(prev_total + blank_lp), pnb=NEG))
+            for v in top:
+                tlp = frame[v]
+                last = beam["prefix"][-1] if beam["prefix"] else None
+                piece = vocabulary.get(v, "")
+                pieces, prev, delta = beam["pieces"], beam["prev"], np.float32(0.0)
+                if lm is not None and piece.startswith(WORD_BOUNDARY):
+                    done = "".join(pieces)
+                    if done:
+                        delta = np.float32(np.float32(lm_weight * lm.score(done, prev)) + word_bonus)
+                        prev = done
+                    stripped = piece[1:]
+                    pieces = (stripped,) if stripped else ()
+                elif lm is not None:
+                    pieces = pieces + (piece,)
+                ext = dict(prefix=beam["prefix"] + (v,), pb=NEG, lm=np.float32(beam["lm"] + delta), pieces=pieces, prev=prev)
+                if last == v:
+                    merge(dict(beam, pb=NEG, pnb=np.float32(beam["pnb"] + tlp)))
+                    merge(dict(ext, pnb=np.float32(beam["pb"] + tlp)))
+                else:
+                    merge(dict(ext, pnb=np.float32(prev_total + tlp)))
+        # deterministic candidate order: existing prefixes keep their beam's position, new ones follow their parent
+        order = sorted(new.values(), key=lambda b: -total(b))                        # Python's sort is stable
+        beams = {b["prefix"]: b for b in order[:beam_width]}
+    best, best_total = None, None
+    for b in beams.values():
+        t = total(b)
+        if lm is not None:
+            word = "".join(b["pieces"])
+            if word:
+                t = np.float32(total_ac(b) + np.float32(b["lm"] + np.float32(np.float32(lm_weight * lm.score(word, b["prev"])) + word_bonus)))
+        if best is None or t > best_total:
+            best, best_total = b, t
+    return list(best["prefix"]), float(best_total)
+
+
+def decode_ctc_token_ids(ids, vocabulary: dict) -> str:                             # CtcDecoder.swift:289-294
+    return "".join(vocabulary[i] for i in ids if i in vocabulary).replace(WORD_BOUNDARY, " ").strip(" \t")

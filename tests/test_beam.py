@@ -1,0 +1,119 @@
+"""CTC prefix beam search + ARPA language model: the CPU restatement against the reference's own test answers
+(CtcDecoderTests.swift:145-260, ARPALanguageModelTests.swift:39-176), the library's host-side LM against the restatement
+(no GPU), and the device search against the restatement (gpu)."""
+import numpy as np
+import pytest
+
+W = "\u2581"
+SAMPLE_ARPA = ("\\data\\\nngram 1=4\nngram 2=2\n\n\\1-grams:\n-1.0\tthe\t-0.5\n-1.2\tcat\t-0.3\n-1.5\tsat\t0.0\n-2.0\t<unk>\t0.0\n\n"
+               "\\2-grams:\n-0.5\tthe\tcat\n-0.8\tcat\tsat\n\n\\end\\\n")
+LOG10 = float(np.float32(np.log(10.0)))
+
+
+def test_oracle_beam_known_answers(oracle_mod):
+    o = oracle_mod
+    v = {0: W + "hello", 1: W + "world"}
+    lp = [[0.0, -100.0, -100.0], [-100.0, -100.0, 0.0], [-100.0, 0.0, -100.0]]
+    ids, _ = o.ctc_beam_search(lp, v, None, 5, 0.0, 0.0, 2)
+    assert o.decode_ctc_token_ids(ids, v) == "hello world"                            # == greedy (:145-158)
+    assert o.ctc_beam_search([[-100.0, 0.0]] * 3, {0: W + "hello"}, None, 5, 0.0, 0.0, 1)[0] == []      # all blanks (:160-172)
+    assert o.ctc_beam_search([], {0: W + "hello"}, None, 5, 0.0, 0.0, 1)[0] == []                       # empty (:174-181)
+    assert o.ctc_beam_search([[0.0, -100.0]], {0: W + "hello"}, None, 5, 0.0, 0.0, 1)[0] == [0]         # single token (:183-194)
+    lm = o.ARPALanguageModel.parse(SAMPLE_ARPA)
+    v = {0: W + "the", 1: W + "cat", 2: W + "dog"}
+    lp = [[0.0, -100.0, -100.0, -100.0], [-100.0, -1.0, -0.9, -100.0]]
+    assert o.decode_ctc_token_ids(o.ctc_beam_search(lp, v, None, 10, 0.0, 0.0, 3)[0], v) == "the dog"   # :148-165
+    assert o.decode_ctc_token_ids(o.ctc_beam_search(lp, v, lm, 10, 5.0, 0.0, 3)[0], v) == "the cat"     # :167-175
+
+
+def check_lm(lm, count_uni, count_ctx):
+    assert count_uni == 4 and count_ctx == 2                                          # :41-47
+    assert lm.score("cat", "the") == pytest.approx(-0.5 * LOG10, abs=1e-3)            # bigram (:101-108)
+    assert lm.score("sat", "the") == pytest.approx(-0.5 * LOG10 - 1.5 * LOG10, abs=1e-3)   # backoff + unigram (:110-120)
+    assert lm.score("cat", None) == pytest.approx(-1.2 * LOG10, abs=1e-3)             # :122-129
+    assert lm.score("xyzzy", None) == pytest.approx(-23.026, abs=1e-3)                # :131-137
+    assert lm.score("xyzzy", "the") == pytest.approx(-0.5 * LOG10 - 23.026, abs=1e-3)   # :139-148
+
+
+def test_arpa_oracle_and_library_agree(fa, oracle_mod):
+    ref = oracle_mod.ARPALanguageModel.parse(SAMPLE_ARPA)
+    check_lm(ref, len(ref.unigrams), len(ref.bigrams))
+    lm = fa.ARPALanguageModel(SAMPLE_ARPA)                                            # parsing and scoring are host code
+    check_lm(lm, lm.unigram_count, lm.bigram_context_count)
+    words = ["the", "cat", "sat", "<unk>", "dog", ""]
+    for w in words:
+        for p in words + [None]:
+            assert lm.score(w, p) == float(ref.score(w, p)), (w, p)                   # bit-identical float arithmetic
+    empty = fa.ARPALanguageModel("\\data\\\nngram 1=0\n\n\\1-grams:\n\n\\end\\\n")    # :83-97
+    assert empty.unigram_count == 0 and empty.bigram_context_count == 0
+    with pytest.raises(fa.ARPAError):                                                 # :77-80
+        fa.ARPALanguageModel.load("/nonexistent/path/to/model.arpa")
+    # malformed lines are skipped, later sections ignored, duplicate entries overwrite (:52-85)
+    odd = ("\\data\\\nngram 1=2\n\\1-grams:\nnot_a_number\tw\n-1.0\ta\n-2.0\ta\t-0.25\n-1.0 \tb\n\\2-grams:\n-0.1\ta\tb\textra\n-0.3\ta\n"
+           "\\3-grams:\n-0.1\ta\tb\tc\n\\end\\\n-9.0\tz\n")
+    r2, l2 = oracle_mod.ARPALanguageModel.parse(odd), fa.ARPALanguageModel(odd)
+    assert l2.unigram_count == len(r2.unigrams) and l2.bigram_context_count == len(r2.bigrams)
+    for w in ["a", "b", "z", "c"]:
+        for p in ["a", "b", None]:
+            assert l2.score(w, p) == float(r2.score(w, p)), (w, p)
+
+
+def random_case(rng, T, V, peaky):
+    x = rng.standard_normal((T, V)).astype(np.float32) * peaky
+    x = x - np.log(np.exp(x.astype(np.float64)).sum(1, keepdims=True)).astype(np.float32)
+    return x.astype(np.float32)
+
+
+def make_vocab(rng, V, blank):
+    words = ["the", "cat", "sat", "dog", "on", "mat", "a"]
+    voc = {}
+    for v in range(V):
+        if v == blank:
+            continue
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            voc[v] = W + words[rng.integers(0, len(words))]
+        elif kind == 1:
+            voc[v] = W + "c"
+        elif kind == 2:
+            voc[v] = ["at", "s", "og", "t", "he"][rng.integers(0, 5)]
+        # kind 3: id missing from the vocabulary -> "" piece
+    voc[(blank + 1) % V] = W                                                          # bare boundary piece: empty word start
+    return voc
+
+
+@pytest.mark.gpu
+def test_reference_cases_on_device(fa, gpu_ctx):
+    v = {0: W + "hello", 1: W + "world"}
+    lp = [[0.0, -100.0, -100.0], [-100.0, -100.0, 0.0], [-100.0, 0.0, -100.0]]
+    assert fa.ctc_beam_search(lp, v, None, 5, 0.0, 0.0, 2, ctx=gpu_ctx) == fa.ctc_greedy_decode(lp, v, blank_id=2) == "hello world"
+    assert fa.ctc_beam_search([[-100.0, 0.0]] * 3, {0: W + "hello"}, None, 5, 0.0, 0.0, 1, ctx=gpu_ctx) == ""
+    assert fa.ctc_beam_search([], {0: W + "hello"}, None, 5, 0.0, 0.0, 1, ctx=gpu_ctx) == ""
+    assert fa.ctc_beam_search([[0.0, -100.0]], {0: W + "hello"}, None, 5, 0.0, 0.0, 1, ctx=gpu_ctx) == "hello"
+    lm = fa.ARPALanguageModel(SAMPLE_ARPA, ctx=gpu_ctx)
+    v = {0: W + "the", 1: W + "cat", 2: W + "dog"}
+    lp = [[0.0, -100.0, -100.0, -100.0], [-100.0, -1.0, -0.9, -100.0]]
+    assert fa.ctc_beam_search(lp, v, None, 10, 0.0, 0.0, 3, ctx=gpu_ctx) == "the dog"
+    assert fa.ctc_beam_search(lp, v, lm, 10, 5.0, 0.0, 3, ctx=gpu_ctx) == "the cat"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,V,W_,K,peaky,use_lm,seed", [(40, 12, 4, 3, 2.0, False, 0), (60, 33, 8, 6, 3.0, True, 1), (25, 9, 16, 8, 1.0, True, 2),
+                                                       (120, 70, 10, 40, 4.0, True, 3), (80, 40, 100, 40, 2.5, False, 4), (30, 300, 5, 64, 3.0, True, 5),
+                                                       (50, 17, 128, 16, 0.5, True, 6), (90, 6, 3, 5, 0.7, True, 7), (200, 8, 6, 4, 1.0, True, 8),
+                                                       (150, 5, 12, 4, 0.3, False, 9), (64, 1025, 100, 40, 5.0, True, 10)])
+def test_device_matches_restatement(fa, gpu_ctx, oracle_mod, T, V, W_, K, peaky, use_lm, seed):
+    rng = np.random.default_rng(seed)
+    blank = V - 1 if seed % 2 == 0 else 0
+    B = 3
+    batch = np.stack([random_case(rng, T, V, peaky) for _ in range(B)])
+    voc = make_vocab(rng, V, blank)
+    lm_ref = oracle_mod.ARPALanguageModel.parse(SAMPLE_ARPA) if use_lm else None
+    lm_dev = fa.ARPALanguageModel(SAMPLE_ARPA, ctx=gpu_ctx) if use_lm else None
+    valid = [T, T // 2, 0]
+    ids, scores = fa.ctc_beam_search_ids_batch(batch, voc, lm_dev, W_, 0.7, 0.25, blank, K, valid_frames=valid, ctx=gpu_ctx)
+    for b in range(B):
+        want, total = oracle_mod.ctc_beam_search(batch[b, :valid[b]], voc, lm_ref, W_, 0.7, 0.25, blank, K)
+        assert ids[b] == want, (b, ids[b], want)
+        if total is not None:
+            assert scores[b] == pytest.approx(total, rel=2e-6, abs=2e-5)
