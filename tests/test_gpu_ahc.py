@@ -123,3 +123,41 @@ def test_device_pointer_entry_and_reuse(fa, gpu_ctx, oracle_mod):
                                      fa.AHC_MODE_AUTO, 1, None)
         assert st == 0
         np.testing.assert_array_equal(d_z.cpu().numpy(), zr)
+
+
+def test_full_size_config3_known_prefix_and_structure(fa, gpu_ctx):
+    """BASELINE config 3 size (50 000 x 256), checked through size-independent properties: half of the dendrogram has a
+    closed-form answer (25 000 planted pairs whose members differ in ONE coordinate, so the centroid-linkage height is
+    exactly |delta| and the greedy order is the order of the deltas), the other half must be a structurally valid
+    dendrogram, and a second run must reproduce the first bit for bit."""
+    n, d = 50000, 256
+    rng = np.random.default_rng(11)
+    base = rng.standard_normal((n // 2, d))
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    pos = rng.permutation(n).reshape(-1, 2)                       # the two rows of pair i
+    x = np.empty((n, d))
+    x[pos[:, 0]] = base
+    x[pos[:, 1]] = base
+    coord = rng.integers(0, d, n // 2)
+    delta = np.linspace(1e-4, 0.2, n // 2)[rng.permutation(n // 2)]
+    x[pos[:, 1], coord] += delta
+    height = np.abs(x[pos[:, 1], coord] - x[pos[:, 0], coord])    # sqrt of a single square is exact
+    assert len(np.unique(height)) == n // 2
+    st, z, stats = fa.linkage(x, ctx=gpu_ctx, return_stats=True)
+    assert st == 0
+    order = np.argsort(height)
+    want = np.stack([pos[order].min(1), pos[order].max(1), height[order], np.full(n // 2, 2.0)], axis=1)
+    np.testing.assert_array_equal(z[: n // 2], want)
+    # structure of the whole dendrogram (FastClusterWrapper.cpp:169-192): every node is merged exactly once, children precede
+    # their parent, sizes add up
+    a, b = z[:, 0].astype(np.int64), z[:, 1].astype(np.int64)
+    assert (a < b).all() and (b < n + np.arange(n - 1)).all() and (a >= 0).all()
+    assert np.array_equal(np.sort(np.concatenate([a, b])), np.arange(2 * n - 2))
+    size = np.concatenate([np.ones(n), z[:, 3]])
+    np.testing.assert_array_equal(z[:, 3], size[a] + size[b])
+    assert z[-1, 3] == n and np.isfinite(z[:, 2]).all() and (z[:, 2] >= 0).all()
+    assert (z[n // 2:, 2] > 0.5).all()                            # pair centroids are ~sqrt(2) apart; centroid linkage may invert but not collapse
+    st2, z2 = fa.linkage(x, ctx=gpu_ctx)
+    assert st2 == 0 and np.array_equal(z, z2)
+    labels = fa.cut(z, n, 0.25)
+    assert len(set(labels.tolist())) == n // 2 and (labels[pos[:, 0]] == labels[pos[:, 1]]).all()
