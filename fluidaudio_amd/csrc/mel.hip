@@ -275,23 +275,23 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
                 samples[i] = y;
             }
     };
-    TileInfo cur = first < stop ? tile_info(first) : TileInfo{};
-    if (first < stop && cur.stage && vec_stage) fetch(cur);
+    auto info_and_fetch = [&](const int64_t tl) {   // metadata + the 12 loads of tile tl (a no-op tile past the range)
+        TileInfo ti{};
+        ti.stage = false;
+        if (tl < stop) { ti = tile_info(tl); if (ti.stage && vec_stage) fetch(ti); }
+        return ti;
+    };
+    TileInfo cur = info_and_fetch(first);
     stage_tile(cur);
+    TileInfo nxt = info_and_fetch(first + 1);   // always one tile ahead: its samples sit in registers during the pass
 
-    // Per tile: barrier | issue the next tile's loads | compute | barrier | stage the next tile | store this tile.  Staging
+    // Per tile: barrier | compute | barrier | stage the next tile | store this tile | issue the loads of the tile after.  Staging
     // BEFORE the stores matters: the wait in front of the staging is vmcnt(0) (the wait-count pass cannot bound it across the
     // loop), and with the four output stores issued first it would sit out their write acknowledgements (~1.5 k cycles per
     // tile); in this order the only VMEM operations in flight are the loads issued a whole pass earlier.
     for (int64_t tl = first; tl < stop; ++tl) {
         __syncthreads();
         MEL_STAMP(1);
-        // the next tile's samples travel from HBM while this tile is computed
-        TileInfo nxt{};
-        nxt.stage = false;
-        if (tl + 1 < stop) { nxt = tile_info(tl + 1); MEL_STAMP_FINE(6); if (nxt.stage && vec_stage) fetch(nxt); }
-
-        MEL_STAMP(2);
         if (PK && cur.stage) {  // workgroup-uniform; group g computes the frames 2 g and 2 g + 1 of the tile in one pass
             using namespace fa::melpk;
             const int f = 2 * grp;
@@ -486,6 +486,9 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
         // the barrier at the top of the next iteration orders these `outs` reads before the next tile's writes
         MEL_STAMP(5);
         cur = nxt;
+        // the loads of the tile after the next travel from HBM during the barrier wait and the whole next pass
+        nxt = info_and_fetch(tl + 2);
+        MEL_STAMP(2);
     }
     if (a.prof && blockIdx.x == gridDim.x / 2 && tid == 0) {
         for (int i = 0; i < 12; ++i) if (i != 7) atomicAdd(&a.prof[i], t_seg[i]);
@@ -812,7 +815,6 @@ fa_status fa_mel_execute_dev(fa_mel_plan *p, const float *d_pcm, const float *d_
             const double n = h[7] ? static_cast<double>(h[7]) : 1.0;
             fprintf(stderr, "mel profile (cycles per tile, wave 0 of one workgroup, %llu tiles): stage-write %.0f | barrier1 %.0f | prefetch issue %.0f | passes %.0f | barrier2 %.0f | store %.0f\n",
                     h[7], h[0] / n, h[1] / n, (h[2] + h[6]) / n, (h[3] + h[8] + h[9] + h[10] + h[11]) / n, h[4] / n, h[5] / n);
-            if (h[6]) fprintf(stderr, "mel profile, prefetch: tile_info %.0f | load issue %.0f\n", h[6] / n, h[2] / n);
             if (h[8]) fprintf(stderr, "mel profile, packed pass: sample reads %.0f | fft256 %.0f | partner + power %.0f | filterbank %.0f | log + stage %.0f\n",
                               h[8] / n, h[9] / n, h[10] / n, h[11] / n, h[3] / n);
         }
