@@ -1,0 +1,32 @@
+/* A plain C host of the drop-in symbol: compiled with gcc against include/FastClusterWrapper.h and include/fluidaudio_hip.h
+ * and linked to libfluidaudio_hip.so the way the reference's SwiftPM target links its FastClusterWrapper.
+ * Mode "args": only the argument contract (FastClusterWrapper.cpp:203-226), needs no GPU.
+ * Mode "run": a tie-free variant of the 6-point orthogonal-groups case probed on the reference build in SURVEY.md §8(c); prints the dendrogram. */
+#include <stdio.h>
+#include <string.h>
+
+#include "FastClusterWrapper.h"
+#include "fluidaudio_hip.h"
+
+int main(int argc, char **argv) {
+    double z[20] = {0};
+    if (argc > 1 && strcmp(argv[1], "args") == 0) {
+        double x[6] = {1, 0, 0, 1, 1, 1};
+        int bad = 0;
+        bad += fastcluster_compute_centroid_linkage(NULL, 3, 2, z, 8) != FASTCLUSTER_WRAPPER_INVALID_ARGUMENT;
+        bad += fastcluster_compute_centroid_linkage(x, 3, 2, NULL, 8) != FASTCLUSTER_WRAPPER_INVALID_ARGUMENT;
+        bad += fastcluster_compute_centroid_linkage(x, 0, 2, z, 8) != FASTCLUSTER_WRAPPER_SUCCESS;
+        bad += fastcluster_compute_centroid_linkage(x, 3, 0, z, 8) != FASTCLUSTER_WRAPPER_INVALID_ARGUMENT;
+        bad += fastcluster_compute_centroid_linkage(x, 3, 2, z, 7) != FASTCLUSTER_WRAPPER_OUTPUT_TOO_SMALL;
+        bad += fastcluster_compute_centroid_linkage(x, 1, 2, z, 0) != FASTCLUSTER_WRAPPER_SUCCESS;
+        printf("version %s; argument contract violations: %d\n", fa_version(), bad);
+        return bad;
+    }
+    /* two orthogonal groups: (0, 2) and (3, 5) nearly parallel, 1 and 4 a little further; all distances distinct */
+    const double x[6 * 3] = {1.00, 0.00, 0.0,   0.99, 0.00, 0.141067,   0.998614, 0.052631, 0.0,
+                             0.00, 1.00, 0.0,   0.00, 0.985, 0.172,      0.061, 0.998138, 0.0};
+    const fastcluster_wrapper_status st = fastcluster_compute_centroid_linkage(x, 6, 3, z, 20);
+    printf("status %d\n", (int)st);
+    for (int r = 0; r < 5; ++r) printf("%.0f %.0f %.17g %.0f\n", z[4 * r], z[4 * r + 1], z[4 * r + 2], z[4 * r + 3]);
+    return st;
+}

@@ -1,0 +1,42 @@
+"""The drop-in boundary without Python in the loop: a C program built with gcc against include/*.h and linked to
+libfluidaudio_hip.so (the way the reference's SwiftPM target links FastClusterWrapper) — argument contract on the CPU tier,
+a real dendrogram against the reference build on the GPU tier."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "fluidaudio_amd", "csrc")
+EXE = os.path.join(ROOT, "tests", "cabi", "dropin")
+
+
+def build(fa):
+    fa.lib()                                                    # makes sure the library is built
+    src = os.path.join(ROOT, "tests", "cabi", "dropin.c")
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(LIBDIR, "libfluidaudio_hip.so"))):
+        subprocess.run(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", EXE, "-L", LIBDIR, "-lfluidaudio_hip",
+                        "-Wl,-rpath," + LIBDIR], check=True)
+    return EXE
+
+
+def test_c_host_links_and_keeps_the_argument_contract(fa):
+    r = subprocess.run([build(fa), "args"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "gfx950" in r.stdout and "violations: 0" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_host_dendrogram_equals_reference_build(fa, oracle_mod):
+    r = subprocess.run([build(fa), "run"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "status 0"
+    got = np.array([[float(v) for v in ln.split()] for ln in lines[1:6]])
+    x = np.array([[1.00, 0.00, 0.0], [0.99, 0.00, 0.141067], [0.998614, 0.052631, 0.0],
+                  [0.00, 1.00, 0.0], [0.00, 0.985, 0.172], [0.061, 0.998138, 0.0]])
+    st, want = oracle_mod.linkage_ref(x)
+    assert st == 0
+    np.testing.assert_array_equal(got, want)                    # %.17g round-trips doubles
+    assert [tuple(int(v) for v in row[[0, 1, 3]]) for row in got] == [(0, 2, 2), (3, 5, 2), (1, 6, 3), (4, 7, 3), (8, 9, 6)]   # tie-free variant of the SURVEY §8(c) probe
