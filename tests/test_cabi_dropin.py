@@ -40,3 +40,30 @@ def test_c_host_dendrogram_equals_reference_build(fa, oracle_mod):
     assert st == 0
     np.testing.assert_array_equal(got, want)                    # %.17g round-trips doubles
     assert [tuple(int(v) for v in row[[0, 1, 3]]) for row in got] == [(0, 2, 2), (3, 5, 2), (1, 6, 3), (4, 7, 3), (8, 9, 6)]   # tie-free variant of the SURVEY §8(c) probe
+
+
+HOST = os.path.join(ROOT, "tests", "cabi", "host")
+
+
+def build_cpp_host(fa):
+    fa.lib()
+    src = os.path.join(ROOT, "tests", "cabi", "host.cpp")
+    deps = [src, os.path.join(ROOT, "include", "fluidaudio.hpp"), os.path.join(ROOT, "include", "fluidaudio_hip.h"), os.path.join(LIBDIR, "libfluidaudio_hip.so")]
+    if not os.path.exists(HOST) or os.path.getmtime(HOST) < max(os.path.getmtime(p) for p in deps):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", HOST, "-L", LIBDIR,
+                        "-lfluidaudio_hip", "-Wl,-rpath," + LIBDIR], check=True)
+    return HOST
+
+
+def test_cpp_host_mirror_compiles_and_links(fa):
+    """include/fluidaudio.hpp (the C++ mirror of the reference's Swift types) builds warning-free; its host-only pieces work."""
+    r = subprocess.run([build_cpp_host(fa), "link"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "FAIL" not in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_runs_the_reference_test_cases(fa):
+    """tests/cabi/host.cpp: the reference's own XCTest cases restated in C++ against include/fluidaudio.hpp."""
+    r = subprocess.run([build_cpp_host(fa)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FAIL" not in r.stdout and "0 failed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("PASS") >= 50
