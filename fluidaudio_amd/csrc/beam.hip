@@ -113,13 +113,15 @@ struct BeamArgs {
     int64_t row_stride, matrix_stride, arena_stride;
     int32_t frames, vocab, blank, beam_width, top_k, use_lm, first;
     float lm_weight, word_bonus;
+    unsigned long long *prof;   // FA_BEAM_PROF (diagnostics): cycles per step of workgroup 0, thread 0
 };
 
 struct Shared {
     Beams b[2];
     float cand_tot[kMaxCand];
+    unsigned short cand_ord[kMaxCand];   // tie-break order of a candidate (its index, or the merged position for a beam's own slot)
     int32_t stay_ord[kMaxBeam]; float stay_pb[kMaxBeam], stay_pnb[kMaxBeam], tot[kMaxBeam];
-    int32_t top_tok[kMaxTop]; float top_lp[kMaxTop];
+    int32_t top_tok[kMaxTop], top_boundary[kMaxTop]; float top_lp[kMaxTop];
     unsigned long long sel_key[kMaxBeam];
     int32_t hist[256];
     int32_t map_node[kMapSlots], map_node_val[kMapSlots];
@@ -144,7 +146,7 @@ __device__ void radix_select(Shared &s, const int n, int k, KeyFn key) {
         s.hist[tid] = 0;
         __syncthreads();
         if (s.done) break;
-        for (int i = tid; i < n; i += kThreads) {
+        for (int i = tid; i < n; i += kThreads) {   // plain LDS atomics: wave-aggregating the increments was measured slower
             const unsigned long long kk = key(i);
             if (pass == 0 || (kk >> (shift + 8)) == prefix) atomicAdd(&s.hist[(kk >> shift) & 255], 1);
         }
@@ -215,6 +217,8 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
     }
     __syncthreads();
 
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = clock64();
+#define BEAM_STAMP(i) do { if (a.prof) { const unsigned long long t_now = clock64(); t_acc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
     int cur = 0;
     for (int t = 0; t < T; ++t) {
         const float *frame = mat + static_cast<int64_t>(t) * a.row_stride;
@@ -225,7 +229,9 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
 
         // ---- 1. top-K tokens, best first (sorted { frame[$0] > frame[$1] }, stable: ties by index) ----
         auto tok_key = [&](const int i) -> unsigned long long { return i == a.blank ? ~0ull : desc_key(frame[i], static_cast<uint32_t>(i)); };
+        BEAM_STAMP(7);
         radix_select(s, V, K, tok_key);
+        BEAM_STAMP(0);
         if (tid < kMaxBeam) s.sel_key[tid] = ~0ull;
         if (tid == 0) s.sel_count = 0;
         __syncthreads();
@@ -236,7 +242,12 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
         __syncthreads();
         sort_selected(s);
         const int ntop = min(s.sel_count, K);
-        if (tid < ntop) { const int v = static_cast<int>(s.sel_key[tid] & 0xffffffffu); s.top_tok[tid] = v; s.top_lp[tid] = frame[v]; }
+        if (tid < ntop) {
+            const int v = static_cast<int>(s.sel_key[tid] & 0xffffffffu);
+            s.top_tok[tid] = v; s.top_lp[tid] = frame[v];
+            s.top_boundary[tid] = a.use_lm ? a.tok[v].boundary : 0;   // one table read per token and frame, not per candidate
+        }
+        BEAM_STAMP(1);
         // ---- 2. maps over the live beams ----
         s.map_node[tid] = -2;
         s.map_pl_parent[tid] = -4;
@@ -264,45 +275,48 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
             }
         };
         // ---- 3. candidate totals; candidate c = i (K + 1) + slot, slot 0 = the beam itself, slot 1 + r = beam + top token r ----
+        BEAM_STAMP(2);
         const int stride = ntop + 1, ncand = n * stride;
-        for (int c = tid; c < ncand; c += kThreads) {
-            const int i = c / stride, slot = c - i * stride;
-            const float tot_i = s.tot[i];
-            if (slot == 0) {
-                float pnb = -INFINITY;
-                int ord = c, r = -1;
-                const int last = b.last[i];
-                for (int q = 0; q < ntop; ++q) if (s.top_tok[q] == last) r = q;
-                if (r >= 0) {
-                    pnb = b.pnb[i] + s.top_lp[r];                                        // same prefix, repeated token (:190-194)
-                    const int p = b.parent[i] != -3 ? find_node(b.parent[i]) : -1;       // the beam one token shorter extends into this one
-                    if (p >= 0) {
-                        const float from_parent = (b.last[p] == last ? b.pb[p] : s.tot[p]) + s.top_lp[r];
-                        pnb = log_add_exp(pnb, from_parent);
-                        ord = min(ord, p * stride + 1 + r);
-                    }
+        // slot 0 of every beam first, one thread per beam: this path evaluates logAddExp in double and would otherwise run
+        // with one or two active lanes in every wavefront of the candidate loop
+        if (tid < n) {
+            const int i = tid, c = i * stride;
+            float pnb = -INFINITY;
+            int ord = c, r = -1;
+            const int last = b.last[i];
+            for (int q = 0; q < ntop; ++q) if (s.top_tok[q] == last) r = q;
+            if (r >= 0) {
+                pnb = b.pnb[i] + s.top_lp[r];                                        // same prefix, repeated token (:190-194)
+                const int p = b.parent[i] != -3 ? find_node(b.parent[i]) : -1;       // the beam one token shorter extends into this one
+                if (p >= 0) {
+                    const float from_parent = (b.last[p] == last ? b.pb[p] : s.tot[p]) + s.top_lp[r];
+                    pnb = log_add_exp(pnb, from_parent);
+                    ord = min(ord, p * stride + 1 + r);
                 }
-                const float pb = tot_i + blank_lp;                                      // blank extension (:172-176)
-                s.stay_pb[i] = pb; s.stay_pnb[i] = pnb; s.stay_ord[i] = ord;
-                s.cand_tot[c] = log_add_exp(pb, pnb) + b.lm[i];
-            } else {
-                const int r = slot - 1, v = s.top_tok[r];
-                if (find_child(b.node[i], v) >= 0) { s.cand_tot[c] = NAN; continue; }   // merged into that beam's slot 0
-                const float pnb = (v == b.last[i] ? b.pb[i] : tot_i) + s.top_lp[r];     // (:196-214)
-                float lm = b.lm[i];
-                if (a.use_lm && a.tok[v].boundary && b.wlen[i] > 0) lm = lm + b.wscore[i];   // a word is completed (:185-189)
-                s.cand_tot[c] = pnb + lm;
             }
+            const float pb = s.tot[i] + blank_lp;                                    // blank extension (:172-176)
+            s.stay_pb[i] = pb; s.stay_pnb[i] = pnb; s.stay_ord[i] = ord;
+            s.cand_tot[c] = log_add_exp(pb, pnb) + b.lm[i];
+            s.cand_ord[c] = static_cast<unsigned short>(ord);
+        }
+        for (int e = tid; e < n * ntop; e += kThreads) {
+            const int i = e / ntop, r = e - i * ntop, c = i * stride + 1 + r, v = s.top_tok[r];
+            s.cand_ord[c] = static_cast<unsigned short>(c);
+            if (find_child(b.node[i], v) >= 0) { s.cand_tot[c] = NAN; continue; }       // merged into that beam's slot 0
+            const float pnb = (v == b.last[i] ? b.pb[i] : s.tot[i]) + s.top_lp[r];      // (:196-214)
+            float lm = b.lm[i];
+            if (s.top_boundary[r] && b.wlen[i] > 0) lm = lm + b.wscore[i];               // a word is completed (:185-189)
+            s.cand_tot[c] = pnb + lm;
         }
         __syncthreads();
         // ---- 4. prune: W best totals, earlier candidate first on ties ----
         auto cand_key = [&](const int c) -> unsigned long long {
             const float v = s.cand_tot[c];
-            if (v != v) return ~0ull;
-            const int i = c / stride;
-            return desc_key(v, static_cast<uint32_t>(c == i * stride ? s.stay_ord[i] : c));
+            return v != v ? ~0ull : desc_key(v, s.cand_ord[c]);
         };
+        BEAM_STAMP(3);
         radix_select(s, ncand, W, cand_key);
+        BEAM_STAMP(4);
         if (tid < kMaxBeam) s.sel_key[tid] = ~0ull;
         if (tid == 0) s.sel_count = 0;
         __syncthreads();
@@ -317,6 +331,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
         __syncthreads();
         sort_selected(s);
         const int nsel = min(s.sel_count, W);
+        BEAM_STAMP(5);
         // ---- 5. survivors -> new beams (rank = sorted position) ----
         if (tid < nsel) {
             const unsigned ord = static_cast<unsigned>(s.sel_key[tid] & 0xffffffffu);
@@ -362,7 +377,10 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
         if (tid == 0) s.n_beams = nsel;
         cur ^= 1;
         __syncthreads();
+        BEAM_STAMP(6);
     }
+    if (a.prof && blockIdx.x == 0 && tid == 0 && a.first == 0) for (int i = 0; i < 8; ++i) a.prof[i] = t_acc[i];
+#undef BEAM_STAMP
 
     // ---- finalize: trailing partial word (:222-229), first maximum in rank order, read the prefix back from the trie ----
     if (tid == 0) {
@@ -573,6 +591,8 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
     FA_HIP_TRY(ctx, d_arena.alloc(static_cast<size_t>(per) * chunk));
     a.arena = d_arena.as<unsigned long long>();
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_beam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(Shared)));
+    fa::DevBuf d_prof;
+    if (getenv("FA_BEAM_PROF")) { FA_HIP_TRY(ctx, d_prof.alloc(64)); FA_HIP_TRY(ctx, hipMemsetAsync(d_prof.p, 0, 64, ctx->stream)); a.prof = d_prof.as<unsigned long long>(); }
     for (int first = 0; first < batch; first += chunk) {
         a.first = first;
         FA_HIP_TRY(ctx, hipMemsetAsync(d_arena.p, 0xff, static_cast<size_t>(per) * std::min(chunk, batch - first), ctx->stream));
@@ -580,6 +600,13 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
         FA_HIP_TRY(ctx, hipGetLastError());
     }
     FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the arena is freed on return
+    if (a.prof) {
+        unsigned long long h[8];
+        FA_HIP_TRY(ctx, hipMemcpy(h, d_prof.p, 64, hipMemcpyDeviceToHost));
+        const double f = frames > 0 ? frames : 1;
+        fprintf(stderr, "beam profile (cycles per frame, workgroup 0): token select %.0f | token gather+sort %.0f | maps %.0f | candidates %.0f | prune select %.0f | "
+                        "prune gather+sort %.0f | new beams %.0f | loop head %.0f\n", h[0] / f, h[1] / f, h[2] / f, h[3] / f, h[4] / f, h[5] / f, h[6] / f, h[7] / f);
+    }
     return FA_SUCCESS;
 }
 
