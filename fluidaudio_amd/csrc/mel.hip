@@ -54,6 +54,7 @@ struct MelArgs {
     float preemph, log_floor;
     int32_t floor_clamped;
     unsigned long long *prof;  // FA_MEL_PROF env (diagnostics): per-phase cycle sums of one workgroup's wave 0
+    int32_t prio_lo, prio_hi, prio_pw, prio_rd;  // wave priorities: FFT / filterbank..store / power / sample reads (FA_MEL_PRIO=a,b,c,d)
 };
 
 // lane l <- lane (16 - l) & 15 inside every row of 16 lanes: row_mirror (l <- 15 - l), then row_ror:1 (l <- l - 1)
@@ -115,6 +116,13 @@ __device__ __forceinline__ void load_frame_pair(const float *x, fa::melpk::LaneP
                  : "memory");
 #undef FA_RD4
 #undef FA_RD
+}
+
+__device__ __forceinline__ void set_prio(const int p) {   // s_setprio takes an immediate
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
 }
 
 // PK: frame-pair packed arithmetic (mel_pk.h): one pass of 2 frames per 16-lane group instead of two passes of one; needs
@@ -297,13 +305,16 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
             const int f = 2 * grp;
             LanePk v;
             float4 w4[8];
+            set_prio(a.prio_rd);
 #pragma unroll
             for (int q = 0; q < 8; ++q) w4[q] = reinterpret_cast<const float4 *>(wtab)[q * kGroup + l];
             load_frame_pair(samples + f * kPkHop + 2 * l, v);
             MEL_STAMP_FINE(8);
             f2 *P2 = reinterpret_cast<f2 *>(__builtin_assume_aligned(regions + grp * kRegionFloatsPk, 8));
+            set_prio(a.prio_lo);   // VALU-bound stretch: yield issue slots to the co-resident wave's short latency-bound bursts
             fft256(l, v, w4, kp, P2);
             MEL_STAMP_FINE(9);
+            set_prio(a.prio_pw);
             // power bins of both frames, pair k at P2[k], over the transpose buffer (its last reads are already issued)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {  // Z[256 - (l + 16 j)]: lane (16 - l) & 15, register 15 - j (lane 0: own (16 - j) & 15)
@@ -317,6 +328,7 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
             }
             if (l == 0) P2[128] = 4.0f * (v.re[8] * v.re[8] + v.im[8] * v.im[8]);  // k = 128: X = conj(Z[128])
             MEL_STAMP_FINE(10);
+            set_prio(a.prio_hi);   // LDS-latency-bound from here to the next pass: issue as soon as data arrives
             // sparse triangular filterbank (vDSP_mmul row, :270-283, zeros skipped): lane l owns the mels l + 16 i; weights are
             // fetched two global slots (2 p, 2 p + 1) per register pair, so a pair may straddle two mel groups
             f2 acc[kFastGroups];
@@ -758,6 +770,13 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         a.preemph = cfg->padding_mode == FA_MEL_PAD_LEGACY ? 0.0f : cfg->preemph;  // compute() has no pre-emphasis (:146-153)
         a.log_floor = cfg->log_floor;
         a.floor_clamped = cfg->floor_mode == FA_MEL_FLOOR_CLAMPED;
+        a.prio_lo = 0; a.prio_hi = 3; a.prio_pw = 1; a.prio_rd = 2;   // measured best of the sweep in DESIGN.md §3.1
+        if (const char *pe = getenv("FA_MEL_PRIO")) {   // diagnostics
+            int v4[4] = {0, 3, 1, 2};
+            const int got = sscanf(pe, "%d,%d,%d,%d", &v4[0], &v4[1], &v4[2], &v4[3]);
+            if (got == 2) { v4[2] = v4[0]; v4[3] = v4[1]; }
+            if (got >= 2) { a.prio_lo = v4[0] & 3; a.prio_hi = v4[1] & 3; a.prio_pw = v4[2] & 3; a.prio_rd = v4[3] & 3; }
+        }
         p->pk = fast && cfg->hop == kPkHop && getenv("FA_MEL_SCALAR") == nullptr;   // FA_MEL_SCALAR: diagnostics, one frame per lane
         p->lds_bytes = sizeof(float) * (a.stage_alloc + kRegions * (p->pk ? kRegionFloatsPk : kRegionFloats) + a.out_alloc) + sizeof(int32_t) * kMaxMels +
                        sizeof(float) * (static_cast<size_t>(a.n_weights) + 24 + 4 + (p->pk ? fa::melpk::kWindowTableFloats : 0));   // the paired weight reads of the packed kernel touch one slot row past the table
