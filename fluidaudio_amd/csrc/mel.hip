@@ -100,20 +100,35 @@ __device__ __forceinline__ void constexpr_for_slot(const int s, F &&fn) {
 // one sample later, x = the lane's pointer (frame start + 2 lane).  One ds_read2_b32 per register pair.  Written in assembly
 // because the load combiner pairs LDS reads by ascending offset — (x[32 n1], x[32 n1 + 32]) — which costs four register moves
 // per pair to re-pair by frame; the wait for the 32 reads is part of the block (the compiler does not track them).
+template <bool EZ>
 __device__ __forceinline__ void load_frame_pair(const float *x, fa::melpk::LanePk &v) {
     static_assert(kPkHop == 160, "offsets below are written for hop 160");
     const unsigned a0 = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const float *)x));
 #define FA_RD(i, b, o0, o1) "ds_read2_b32 %" #i ", %" #b " offset0:" #o0 " offset1:" #o1 "\n"
 #define FA_RD4(i0, i1, i2, i3, b) FA_RD(i0, b, 0, 160) FA_RD(i1, b, 1, 161) FA_RD(i2, b, 32, 192) FA_RD(i3, b, 33, 193)
-    asm volatile(FA_RD4(0, 1, 2, 3, 32) FA_RD4(4, 5, 6, 7, 33) FA_RD4(8, 9, 10, 11, 34) FA_RD4(12, 13, 14, 15, 35)
-                 FA_RD4(16, 17, 18, 19, 36) FA_RD4(20, 21, 22, 23, 37) FA_RD4(24, 25, 26, 27, 38) FA_RD4(28, 29, 30, 31, 39)
-                 "s_waitcnt lgkmcnt(0)\n"
-                 : "=&v"(v.re[0]), "=&v"(v.im[0]), "=&v"(v.re[1]), "=&v"(v.im[1]), "=&v"(v.re[2]), "=&v"(v.im[2]), "=&v"(v.re[3]), "=&v"(v.im[3]),
-                   "=&v"(v.re[4]), "=&v"(v.im[4]), "=&v"(v.re[5]), "=&v"(v.im[5]), "=&v"(v.re[6]), "=&v"(v.im[6]), "=&v"(v.re[7]), "=&v"(v.im[7]),
-                   "=&v"(v.re[8]), "=&v"(v.im[8]), "=&v"(v.re[9]), "=&v"(v.im[9]), "=&v"(v.re[10]), "=&v"(v.im[10]), "=&v"(v.re[11]), "=&v"(v.im[11]),
-                   "=&v"(v.re[12]), "=&v"(v.im[12]), "=&v"(v.re[13]), "=&v"(v.im[13]), "=&v"(v.re[14]), "=&v"(v.im[14]), "=&v"(v.re[15]), "=&v"(v.im[15])
-                 : "v"(a0), "v"(a0 + 256), "v"(a0 + 512), "v"(a0 + 768), "v"(a0 + 1024), "v"(a0 + 1280), "v"(a0 + 1536), "v"(a0 + 1792)
-                 : "memory");
+    if (EZ) {   // blocks n1 = 0 and n1 = 15 meet a zero window: literal zeros, 28 reads
+        const fa::melpk::f2 zero = {0.0f, 0.0f};
+        v.re[0] = zero; v.im[0] = zero; v.re[15] = zero; v.im[15] = zero;
+        asm volatile(FA_RD(0, 28, 32, 192) FA_RD(1, 28, 33, 193) FA_RD4(2, 3, 4, 5, 29) FA_RD4(6, 7, 8, 9, 30) FA_RD4(10, 11, 12, 13, 31)
+                     FA_RD4(14, 15, 16, 17, 32) FA_RD4(18, 19, 20, 21, 33) FA_RD4(22, 23, 24, 25, 34) FA_RD(26, 35, 0, 160) FA_RD(27, 35, 1, 161)
+                     "s_waitcnt lgkmcnt(0)\n"
+                     : "=&v"(v.re[1]), "=&v"(v.im[1]), "=&v"(v.re[2]), "=&v"(v.im[2]), "=&v"(v.re[3]), "=&v"(v.im[3]), "=&v"(v.re[4]), "=&v"(v.im[4]),
+                       "=&v"(v.re[5]), "=&v"(v.im[5]), "=&v"(v.re[6]), "=&v"(v.im[6]), "=&v"(v.re[7]), "=&v"(v.im[7]), "=&v"(v.re[8]), "=&v"(v.im[8]),
+                       "=&v"(v.re[9]), "=&v"(v.im[9]), "=&v"(v.re[10]), "=&v"(v.im[10]), "=&v"(v.re[11]), "=&v"(v.im[11]), "=&v"(v.re[12]), "=&v"(v.im[12]),
+                       "=&v"(v.re[13]), "=&v"(v.im[13]), "=&v"(v.re[14]), "=&v"(v.im[14])
+                     : "v"(a0), "v"(a0 + 256), "v"(a0 + 512), "v"(a0 + 768), "v"(a0 + 1024), "v"(a0 + 1280), "v"(a0 + 1536), "v"(a0 + 1792)
+                     : "memory");
+    } else {
+        asm volatile(FA_RD4(0, 1, 2, 3, 32) FA_RD4(4, 5, 6, 7, 33) FA_RD4(8, 9, 10, 11, 34) FA_RD4(12, 13, 14, 15, 35)
+                     FA_RD4(16, 17, 18, 19, 36) FA_RD4(20, 21, 22, 23, 37) FA_RD4(24, 25, 26, 27, 38) FA_RD4(28, 29, 30, 31, 39)
+                     "s_waitcnt lgkmcnt(0)\n"
+                     : "=&v"(v.re[0]), "=&v"(v.im[0]), "=&v"(v.re[1]), "=&v"(v.im[1]), "=&v"(v.re[2]), "=&v"(v.im[2]), "=&v"(v.re[3]), "=&v"(v.im[3]),
+                       "=&v"(v.re[4]), "=&v"(v.im[4]), "=&v"(v.re[5]), "=&v"(v.im[5]), "=&v"(v.re[6]), "=&v"(v.im[6]), "=&v"(v.re[7]), "=&v"(v.im[7]),
+                       "=&v"(v.re[8]), "=&v"(v.im[8]), "=&v"(v.re[9]), "=&v"(v.im[9]), "=&v"(v.re[10]), "=&v"(v.im[10]), "=&v"(v.re[11]), "=&v"(v.im[11]),
+                       "=&v"(v.re[12]), "=&v"(v.im[12]), "=&v"(v.re[13]), "=&v"(v.im[13]), "=&v"(v.re[14]), "=&v"(v.im[14]), "=&v"(v.re[15]), "=&v"(v.im[15])
+                     : "v"(a0), "v"(a0 + 256), "v"(a0 + 512), "v"(a0 + 768), "v"(a0 + 1024), "v"(a0 + 1280), "v"(a0 + 1536), "v"(a0 + 1792)
+                     : "memory");
+    }
 #undef FA_RD4
 #undef FA_RD
 }
@@ -126,8 +141,8 @@ __device__ __forceinline__ void set_prio(const int p) {   // s_setprio takes an 
 }
 
 // PK: frame-pair packed arithmetic (mel_pk.h): one pass of 2 frames per 16-lane group instead of two passes of one; needs
-// FAST and hop == kPkHop.
-template <int LAYOUT, bool FAST, bool PK>
+// FAST and hop == kPkHop.  PK == 2: additionally the window is zero on the outer 32 positions of the frame (fft256<EZ>).
+template <int LAYOUT, bool FAST, int PK>
 __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *samples = smem;
@@ -308,11 +323,11 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
             set_prio(a.prio_rd);
 #pragma unroll
             for (int q = 0; q < 8; ++q) w4[q] = reinterpret_cast<const float4 *>(wtab)[q * kGroup + l];
-            load_frame_pair(samples + f * kPkHop + 2 * l, v);
+            load_frame_pair<PK == 2>(samples + f * kPkHop + 2 * l, v);
             MEL_STAMP_FINE(8);
             f2 *P2 = reinterpret_cast<f2 *>(__builtin_assume_aligned(regions + grp * kRegionFloatsPk, 8));
             set_prio(a.prio_lo);   // VALU-bound stretch: yield issue slots to the co-resident wave's short latency-bound bursts
-            fft256(l, v, w4, kp, P2);
+            fft256<PK == 2>(l, v, w4, kp, P2);
             MEL_STAMP_FINE(9);
             set_prio(a.prio_pw);
             // power bins of both frames, pair k at P2[k], over the transpose buffer (its last reads are already issued)
@@ -608,6 +623,7 @@ struct fa_mel_plan {
     int grid = 0;
     bool fast = false;  // filterbank fits the compile-time slot profile
     bool pk = false;    // frame-pair packed kernel (fast bank, hop == kPkHop)
+    bool edge_zero = false;  // the zero-extended window vanishes on positions [0, 32) and [480, 512) of the frame
 };
 
 extern "C" {
@@ -690,6 +706,8 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         const int off = cfg->padding_mode == FA_MEL_PAD_LEGACY ? 0 : (cfg->n_fft - cfg->win) / 2;  // :234 / :148-153
         std::vector<float> windowz(kNfft, 0.0f);
         for (int i = 0; i < cfg->win; ++i) windowz[off + i] = hann[i];
+        p->edge_zero = getenv("FA_MEL_NO_EZ") == nullptr;
+        for (int i = 0; i < 32; ++i) if (windowz[i] != 0.0f || windowz[kNfft - 32 + i] != 0.0f) p->edge_zero = false;
         std::vector<float2> tw256(256), tw512(129);
         for (int k = 0; k < 256; ++k) { const double a = -2.0 * M_PI * k / 256.0; tw256[k] = make_float2((float)cos(a), (float)sin(a)); }
         for (int k = 0; k < 129; ++k) { const double a = -2.0 * M_PI * k / 512.0; tw512[k] = make_float2((float)cos(a), (float)sin(a)); }
@@ -783,12 +801,14 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         if (p->lds_bytes > 160 * 1024) { (void)hipFree(p->dev); delete p; return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel: hop too large for LDS staging"); }
         if (p->lds_bytes > 64 * 1024) {
             const int lb = static_cast<int>(p->lds_bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
         }
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, ctx->device);
@@ -841,12 +861,14 @@ fa_status fa_mel_execute_dev(fa_mel_plan *p, const float *d_pcm, const float *d_
     const bool mm = p->cfg.layout == FA_MEL_LAYOUT_MEL_MAJOR;
     const bool pk = p->pk;
     const dim3 grid(p->grid), block(kThreads);
-    if (mm && pk) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, true, true>), grid, block, p->lds_bytes, ctx->stream, a);
-    else if (pk) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, true, true>), grid, block, p->lds_bytes, ctx->stream, a);
-    else if (mm && p->fast) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, true, false>), grid, block, p->lds_bytes, ctx->stream, a);
-    else if (mm) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, false, false>), grid, block, p->lds_bytes, ctx->stream, a);
-    else if (p->fast) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, true, false>), grid, block, p->lds_bytes, ctx->stream, a);
-    else hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, false, false>), grid, block, p->lds_bytes, ctx->stream, a);
+    if (mm && pk && p->edge_zero) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, true, 2>), grid, block, p->lds_bytes, ctx->stream, a);
+    else if (pk && p->edge_zero) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, true, 2>), grid, block, p->lds_bytes, ctx->stream, a);
+    else if (mm && pk) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, true, 1>), grid, block, p->lds_bytes, ctx->stream, a);
+    else if (pk) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, true, 1>), grid, block, p->lds_bytes, ctx->stream, a);
+    else if (mm && p->fast) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, true, 0>), grid, block, p->lds_bytes, ctx->stream, a);
+    else if (mm) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, false, 0>), grid, block, p->lds_bytes, ctx->stream, a);
+    else if (p->fast) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, true, 0>), grid, block, p->lds_bytes, ctx->stream, a);
+    else hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, false, 0>), grid, block, p->lds_bytes, ctx->stream, a);
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }

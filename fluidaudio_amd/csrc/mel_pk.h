@@ -113,13 +113,16 @@ __device__ __forceinline__ void fft16(LanePk &v) {
 // window, first radix-16 pass, inter-pass twiddle, transpose through the group's LDS region (real parts, then imaginary parts:
 // the region holds 16 x 17 frame pairs = the footprint of ONE frame of the scalar kernel), second radix-16 pass.
 // On entry v holds the raw samples 32 n1 + 2 lane (re) and + 1 (im) of both frames and w4[q] the lane's window_table row;
-// on exit v.re/im[k2] = Z[lane + 16 k2].
+// on exit v.re/im[k2] = Z[lane + 16 k2].  EZ: the window is zero on the first and the last 32 positions of the frame (n1 = 0
+// and 15; true for a 400-sample window centred in 512): those blocks are literal zeros, never loaded or multiplied, and the
+// additions they feed in the first 16-point pass fold away.
+template <bool EZ>
 __device__ __forceinline__ void fft256(const int lane, LanePk &v, const float4 (&w4)[8], const LaneConstPk &k, f2 *region) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const f2 wa = f2{w4[q].x, w4[q].y}, wb = f2{w4[q].z, w4[q].w};
-        v.re[2 * q] = mul_lo(v.re[2 * q], wa); v.im[2 * q] = mul_hi(v.im[2 * q], wa);
-        v.re[2 * q + 1] = mul_lo(v.re[2 * q + 1], wb); v.im[2 * q + 1] = mul_hi(v.im[2 * q + 1], wb);
+        if (!(EZ && q == 0)) { v.re[2 * q] = mul_lo(v.re[2 * q], wa); v.im[2 * q] = mul_hi(v.im[2 * q], wa); }
+        if (!(EZ && q == 7)) { v.re[2 * q + 1] = mul_lo(v.re[2 * q + 1], wb); v.im[2 * q + 1] = mul_hi(v.im[2 * q + 1], wb); }
     }
     fft16(v);
 #pragma unroll
