@@ -117,3 +117,21 @@ def test_device_matches_restatement(fa, gpu_ctx, oracle_mod, T, V, W_, K, peaky,
         assert ids[b] == want, (b, ids[b], want)
         if total is not None:
             assert scores[b] == pytest.approx(total, rel=2e-6, abs=2e-5)
+
+
+@pytest.mark.gpu
+def test_limits_and_argument_errors(fa, gpu_ctx):
+    """Largest supported beam / candidate counts on a TDT-sized vocabulary: structural sanity (no oracle at this size), the
+    greedy path is among the hypotheses so the beam score can only be better, and out-of-range parameters are refused."""
+    rng = np.random.default_rng(3)
+    T, V, blank = 120, 8193, 8192
+    x = random_case(rng, T, V, 4.0)
+    ids, scores = fa.ctc_beam_search_ids_batch(x[None], None, None, 128, 0.0, 0.0, blank, 64, ctx=gpu_ctx)
+    assert len(ids[0]) <= T and all(0 <= t < V and t != blank for t in ids[0]) and np.isfinite(scores[0])
+    greedy_path = float(x.max(axis=1).sum())                      # log-prob of the best single alignment
+    assert scores[0] >= greedy_path - 1e-3                        # the prefix total sums over alignments incl. that one
+    ids1, _ = fa.ctc_beam_search_ids_batch(x[None], None, None, 1, 0.0, 0.0, blank, 1, ctx=gpu_ctx)   # beam 1, one candidate
+    assert len(ids1[0]) <= T
+    for bw, k in ((0, 40), (129, 40), (100, 65), (100, -1)):
+        with pytest.raises(fa.FluidAudioHipError):
+            fa.ctc_beam_search_ids_batch(x[None], None, None, bw, 0.0, 0.0, blank, k, ctx=gpu_ctx)
