@@ -8,8 +8,17 @@
 // (window, twiddles) are shared by both halves.  A lane constant pair (c0, c1) occupies ONE register pair and is broadcast to
 // both halves by the op_sel / op_sel_hi source selectors of the packed instructions — the compiler does not emit those for a
 // scalar * vector product (it materialises a (c, c) pair per constant: 2 x 78 registers), hence the inline-asm wrappers.
+// The arithmetic (everything except the DPP exchange) also compiles for the host with clang (ext_vector_type), where the
+// op_sel wrappers fall back to plain vector code: tests/cpu/mel_pk_emul.cpp replays the 16 lanes of a frame group on the CPU.
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#define FA_PK __device__ __forceinline__
+#else
+#define FA_PK inline
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+#endif
 
 #include "mel_core.h"
 
@@ -20,6 +29,15 @@ using melcore::kEStride;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host restatement of the op_sel-broadcast wrappers below (the host pass of hipcc never runs them; the CPU replay does)
+FA_PK f2 mul_lo(const f2 a, const f2 w) { return a * w.x; }
+FA_PK f2 mul_hi(const f2 a, const f2 w) { return a * w.y; }
+FA_PK f2 fma_lo(const f2 a, const f2 w, const f2 c) { return a * w.x + c; }
+FA_PK f2 fma_hi(const f2 a, const f2 w, const f2 c) { return a * w.y + c; }
+FA_PK f2 fms_lo(const f2 a, const f2 w, const f2 c) { return a * w.x - c; }
+FA_PK f2 fms_hi(const f2 a, const f2 w, const f2 c) { return a * w.y - c; }
+#else
 // d = a * w.lo / a * w.hi (both halves of a times the SAME scalar half of w)
 __device__ __forceinline__ f2 mul_lo(const f2 a, const f2 w) { f2 d; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(w)); return d; }
 __device__ __forceinline__ f2 mul_hi(const f2 a, const f2 w) { f2 d; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(w)); return d; }
@@ -28,6 +46,7 @@ __device__ __forceinline__ f2 fma_lo(const f2 a, const f2 w, const f2 c) { f2 d;
 __device__ __forceinline__ f2 fma_hi(const f2 a, const f2 w, const f2 c) { f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(w), "v"(c)); return d; }
 __device__ __forceinline__ f2 fms_lo(const f2 a, const f2 w, const f2 c) { f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(w), "v"(c)); return d; }
 __device__ __forceinline__ f2 fms_hi(const f2 a, const f2 w, const f2 c) { f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(w), "v"(c)); return d; }
+#endif
 
 struct LanePk {
     f2 re[16];
@@ -44,21 +63,21 @@ struct LaneConstPk {
 constexpr int kWindowTableFloats = 8 * 16 * 4;
 // LDS window table: float4 entry (q, lane) = windowz[32 (2 q) + 2 lane + {0, 1}], windowz[32 (2 q + 1) + 2 lane + {0, 1}];
 // a 16-lane group reads 256 contiguous bytes per q (conflict-free), all groups of a wavefront the same addresses (broadcast).
-__device__ __forceinline__ void window_table_fill(const int tid, const int threads, const float *windowz, float *tab) {
+FA_PK void window_table_fill(const int tid, const int threads, const float *windowz, float *tab) {
     for (int i = tid; i < kWindowTableFloats; i += threads) {
         const int c = i & 3, lane = (i >> 2) & 15, q = i >> 6;
         tab[i] = windowz[32 * (2 * q + (c >> 1)) + 2 * lane + (c & 1)];
     }
 }
 
-__device__ __forceinline__ void lane_const_init(const int lane, const float2 *tw256, const float2 *tw512, LaneConstPk &k) {
+FA_PK void lane_const_init(const int lane, const float2 *tw256, const float2 *tw512, LaneConstPk &k) {
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) { const float2 t = tw256[(lane * k1) & 255]; k.t1[k1 - 1] = f2{t.x, t.y}; }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float2 t = tw512[lane + 16 * j]; k.t2[j] = f2{t.x, t.y}; }
 }
 
-__device__ __forceinline__ void fft4(f2 &r0, f2 &i0, f2 &r1, f2 &i1, f2 &r2, f2 &i2, f2 &r3, f2 &i3) {
+FA_PK void fft4(f2 &r0, f2 &i0, f2 &r1, f2 &i1, f2 &r2, f2 &i2, f2 &r3, f2 &i3) {
     const f2 ar = r0 + r2, ai = i0 + i2;
     const f2 br = r0 - r2, bi = i0 - i2;
     const f2 cr = r1 + r3, ci = i1 + i3;
@@ -70,20 +89,20 @@ __device__ __forceinline__ void fft4(f2 &r0, f2 &i0, f2 &r1, f2 &i1, f2 &r2, f2 
 }
 
 // (r + i i) * (w.lo + i w.hi), w a lane constant pair
-__device__ __forceinline__ void cmul_w(f2 &r, f2 &i, const f2 w) {
+FA_PK void cmul_w(f2 &r, f2 &i, const f2 w) {
     const f2 tr = fms_lo(r, w, mul_hi(i, w));  // r wr - i wi
     const f2 ti = fma_hi(r, w, mul_lo(i, w));  // r wi + i wr
     r = tr; i = ti;
 }
 
-__device__ __forceinline__ void cmul_c(f2 &r, f2 &i, const float wr, const float wi) {  // literal twiddles of the 16-point DFT
+FA_PK void cmul_c(f2 &r, f2 &i, const float wr, const float wi) {  // literal twiddles of the 16-point DFT
     const f2 tr = r * wr - i * wi;
     const f2 ti = r * wi + i * wr;
     r = tr; i = ti;
 }
 
 // in-register 16-point forward DFT, natural order in and out (same factorisation as melcore::fft16)
-__device__ __forceinline__ void fft16(LanePk &v) {
+FA_PK void fft16(LanePk &v) {
     constexpr float C = 0.92387953251128674f, S = 0.38268343236508977f, R = 0.70710678118654752f;
 #pragma unroll
     for (int n2 = 0; n2 < 4; ++n2)
@@ -117,7 +136,7 @@ __device__ __forceinline__ void fft16(LanePk &v) {
 // and 15; true for a 400-sample window centred in 512): those blocks are literal zeros, never loaded or multiplied, and the
 // additions they feed in the first 16-point pass fold away.
 template <bool EZ>
-__device__ __forceinline__ void fft256(const int lane, LanePk &v, const float4 (&w4)[8], const LaneConstPk &k, f2 *region) {
+FA_PK void fft256_head(LanePk &v, const float4 (&w4)[8], const LaneConstPk &k) {   // window, first radix-16 pass, inter-pass twiddle
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const f2 wa = f2{w4[q].x, w4[q].y}, wb = f2{w4[q].z, w4[q].w};
@@ -127,18 +146,27 @@ __device__ __forceinline__ void fft256(const int lane, LanePk &v, const float4 (
     fft16(v);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) cmul_w(v.re[k1], v.im[k1], k.t1[k1 - 1]);
+}
+FA_PK void transpose_put(const int lane, const f2 (&c)[16], f2 *region) {
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) region[k1 * kEStride + lane] = c[k1];
+}
+FA_PK void transpose_get(const int lane, f2 (&c)[16], const f2 *region) {
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) c[n2] = region[lane * kEStride + n2];
+}
+template <bool EZ>
+FA_PK void fft256(const int lane, LanePk &v, const float4 (&w4)[8], const LaneConstPk &k, f2 *region) {
+    fft256_head<EZ>(v, w4, k);
     // LDS operations of one wavefront complete in program order: write re, read re, write im (over re), read im
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) region[k1 * kEStride + lane] = v.re[k1];
-#pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) v.re[n2] = region[lane * kEStride + n2];
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) region[k1 * kEStride + lane] = v.im[k1];
-#pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) v.im[n2] = region[lane * kEStride + n2];
+    transpose_put(lane, v.re, region);
+    transpose_get(lane, v.re, region);
+    transpose_put(lane, v.im, region);
+    transpose_get(lane, v.im, region);
     fft16(v);
 }
 
+#if defined(__HIPCC__)
 // lane l <- lane (16 - l) & 15 inside every row of 16 lanes (row_mirror, then row_ror:1), both halves
 __device__ __forceinline__ f2 partner(const f2 x) {
     int a = __float_as_int(x.x), b = __float_as_int(x.y);
@@ -148,10 +176,11 @@ __device__ __forceinline__ f2 partner(const f2 x) {
     b = __builtin_amdgcn_update_dpp(0, b, 0x121, 0xf, 0xf, true);
     return f2{__int_as_float(a), __int_as_float(b)};
 }
+#endif
 
 // 4 |X[k]|^2 and 4 |X[256 - k]|^2 from A = Z[k], B = conj(Z[256 - k]) (bi_src = Im Z[256 - k]), w = exp(-2 pi i k / 512):
 // 2 X[k] = (A + B) - i w (A - B), 2 conj(X[256 - k]) = (A + B) + i w (A - B).  The factor 4 (exact) is folded into the filterbank.
-__device__ __forceinline__ void pair_power4(const f2 ar, const f2 ai, const f2 br, const f2 bi_src, const f2 w, f2 &p_lo, f2 &p_hi) {
+FA_PK void pair_power4(const f2 ar, const f2 ai, const f2 br, const f2 bi_src, const f2 w, f2 &p_lo, f2 &p_hi) {
     const f2 sr = ar + br, si = ai - bi_src;
     const f2 dr = ar - br, di = ai + bi_src;
     const f2 a1 = fma_lo(di, w, mul_hi(dr, w));   // wr di + wi dr
