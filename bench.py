@@ -133,7 +133,25 @@ def ctc_leg(fa, ctx, torch, batch, steps=3):
     ctx.synchronize()
     ms = e0.elapsed_time(e1) / steps
     gbs = batch * CTC_BYTES_PER_MATRIX / (ms * 1e-3) / 1e9
-    return {"matrices": batch, "T": T, "V": V, "dtype": "f32", "ms_per_pass": ms, "matrices_per_s": batch / (ms * 1e-3),
+    # the row kernel next to it (§8f-3): log-softmax with temperature / blank bias, one read + one write of the matrix
+    lsm = None
+    try:
+        out = torch.empty_like(x)
+        fa.ctc_log_probs_dev(ctx, x, 1.0, 0.0, V - 1, d_out=out)
+        ctx.synchronize()
+        e0.record(stream)
+        for _ in range(steps):
+            fa.ctc_log_probs_dev(ctx, x, 1.0, 0.0, V - 1, d_out=out)
+        e1.record(stream)
+        ctx.synchronize()
+        ms2 = e0.elapsed_time(e1) / steps
+        g2 = 2 * batch * CTC_BYTES_PER_MATRIX / (ms2 * 1e-3) / 1e9
+        lsm = {"ms_per_pass": ms2, "roofline": {"bound": "hbm", "achieved": g2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g2 / HBM_PEAK_GBS,
+                                                "traffic": None}, "algorithmic_bytes_per_matrix": 2 * CTC_BYTES_PER_MATRIX}
+        del out
+    except Exception as e:  # noqa: BLE001
+        lsm = {"error": repr(e)}
+    return {"log_softmax": lsm, "matrices": batch, "T": T, "V": V, "dtype": "f32", "ms_per_pass": ms, "matrices_per_s": batch / (ms * 1e-3),
             "audio_hours_per_s": batch * 15.0 / 3600.0 / (ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None},
             "mean_tokens_per_matrix": float(lens.float().mean())}
