@@ -241,6 +241,54 @@ __global__ __launch_bounds__(kThreads) void ctc_log_softmax_kernel(const LsmArgs
     }
 }
 
+// fp32 rows that are 16-byte aligned with V a multiple of 4 and V <= 2048: the same computation with 16-byte loads and stores
+// (lane l owns the float4 groups l, l + 64, ...: 4x fewer memory instructions than the strided scalar form)
+__global__ __launch_bounds__(kThreads) void ctc_log_softmax_vec4_kernel(const LsmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kWaves + (threadIdx.x >> 6);
+    if (r >= a.rows_total) return;
+    const int64_t b = r / a.frames, t = r % a.frames;
+    const float4 *row = reinterpret_cast<const float4 *>(static_cast<const float *>(a.logits) + b * a.matrix_stride + t * a.row_stride);
+    float4 *orow = reinterpret_cast<float4 *>(a.out + b * a.out_matrix_stride + t * a.out_row_stride);
+    const int nvec = a.vocab >> 2;
+    const bool scale = a.temperature != 1.0f;
+    constexpr int kVecRegs = kLsmRegs / 4;
+    float4 x[kVecRegs];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < kVecRegs; ++j) {
+        const int i = lane + 64 * j;
+        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (i < nvec) {
+            v = row[i];
+            if (scale) { v.x = v.x / a.temperature; v.y = v.y / a.temperature; v.z = v.z / a.temperature; v.w = v.w / a.temperature; }
+        }
+        x[j] = v;
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kVecRegs; ++j)
+        if (lane + 64 * j < nvec) sum += (expf(x[j].x - mx) + expf(x[j].y - mx)) + (expf(x[j].z - mx) + expf(x[j].w - mx));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float lse = logf(sum);
+    const bool bias = a.blank_bias != 0.0f && a.blank_id >= 0;
+#pragma unroll
+    for (int j = 0; j < kVecRegs; ++j) {
+        const int i = lane + 64 * j;
+        if (i >= nvec) continue;
+        float4 o = make_float4((x[j].x - mx) - lse, (x[j].y - mx) - lse, (x[j].z - mx) - lse, (x[j].w - mx) - lse);
+        if (bias && (a.blank_id >> 2) == i) {
+            const int c = a.blank_id & 3;
+            if (c == 0) o.x -= a.blank_bias; else if (c == 1) o.y -= a.blank_bias; else if (c == 2) o.z -= a.blank_bias; else o.w -= a.blank_bias;
+        }
+        orow[i] = o;
+    }
+}
+
 fa_status check_args(fa_ctx *ctx, const void *logits, int dtype, int batch, int frames, int vocab, int64_t row_stride,
                      int64_t matrix_stride, const int32_t *token_ids, const int32_t *token_lens) {
     if (!ctx || !token_ids || !token_lens) return FA_INVALID_ARGUMENT;
@@ -323,7 +371,10 @@ fa_status fa_ctc_log_softmax_batch_dev(fa_ctx *ctx, const void *d_logits, int32_
     a.rows_total = static_cast<int64_t>(batch) * frames; a.frames = frames; a.vocab = vocab; a.blank_id = blank_id;
     a.temperature = temperature; a.blank_bias = blank_bias;
     const unsigned grid = static_cast<unsigned>((a.rows_total + kWaves - 1) / kWaves);
-    if (dtype == FA_DTYPE_F16) hipLaunchKernelGGL(ctc_log_softmax_kernel<true>, dim3(grid), dim3(kThreads), 0, ctx->stream, a);
+    const bool vec4 = dtype == FA_DTYPE_F32 && vocab % 4 == 0 && vocab <= 64 * kLsmRegs && row_stride % 4 == 0 && matrix_stride % 4 == 0 &&
+                      reinterpret_cast<uintptr_t>(d_logits) % 16 == 0 && reinterpret_cast<uintptr_t>(d_log_probs) % 16 == 0;
+    if (vec4) hipLaunchKernelGGL(ctc_log_softmax_vec4_kernel, dim3(grid), dim3(kThreads), 0, ctx->stream, a);
+    else if (dtype == FA_DTYPE_F16) hipLaunchKernelGGL(ctc_log_softmax_kernel<true>, dim3(grid), dim3(kThreads), 0, ctx->stream, a);
     else hipLaunchKernelGGL(ctc_log_softmax_kernel<false>, dim3(grid), dim3(kThreads), 0, ctx->stream, a);
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
