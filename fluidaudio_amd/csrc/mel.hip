@@ -527,7 +527,10 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
 // NeMo per_feature normalisation as done by UnifiedMelExtractor.normalizePerFeature
 // (reference: Sources/FluidAudio/ASR/Parakeet/Unified/UnifiedMelExtractor.swift:91-113): for every mel bin subtract the
 // mean and divide by the unbiased std (+1e-5) over the valid frames; frames >= valid become 0; valid == 0 zeroes the row.
-// One wavefront per (utterance, mel) row of a [B][n_mels][frame_stride] tensor; the row (<= a few KB) stays in L2.
+// One wavefront per (utterance, mel) row of a [B][n_mels][frame_stride] tensor; rows of up to 2048 frames are held in
+// registers between the three passes (sum, centred squares, write): one HBM read and one write per element.
+constexpr int kNormRegs = 32;   // frames per lane held in registers: rows up to 2048 frames are read from HBM once
+
 __global__ __launch_bounds__(256) void mel_norm_kernel(float *__restrict__ mel, const int32_t *__restrict__ valid_frames, int64_t rows,
                                                          int32_t n_mels, int32_t frame_stride, int32_t frames) {
     const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -537,21 +540,38 @@ __global__ __launch_bounds__(256) void mel_norm_kernel(float *__restrict__ mel, 
     int valid = valid_frames[b];
     valid = valid < 0 ? 0 : (valid > frames ? frames : valid);
     float *x = mel + row * frame_stride;
+    const bool in_regs = frames <= 64 * kNormRegs;
+    float v[kNormRegs];
     float mean = 0.0f, inv_std = 0.0f;
     if (valid > 0) {
         float sum = 0.0f;
-        for (int t = lane; t < valid; t += 64) sum += x[t];
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < kNormRegs; ++j) { const int t = lane + 64 * j; v[j] = t < valid ? x[t] : 0.0f; sum += v[j]; }
+        } else {
+            for (int t = lane; t < valid; t += 64) sum += x[t];
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
         mean = sum / static_cast<float>(valid);
         float var = 0.0f;
-        for (int t = lane; t < valid; t += 64) { const float dlt = x[t] - mean; var += dlt * dlt; }
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < kNormRegs; ++j) if (lane + 64 * j < valid) { const float dlt = v[j] - mean; var += dlt * dlt; }
+        } else {
+            for (int t = lane; t < valid; t += 64) { const float dlt = x[t] - mean; var += dlt * dlt; }
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off);
         const float denom = static_cast<float>(valid > 1 ? valid - 1 : 1);
         inv_std = 1.0f / (sqrtf(var / denom) + 1e-5f);
     }
-    for (int t = lane; t < frames; t += 64) x[t] = t < valid ? (x[t] - mean) * inv_std : 0.0f;
+    if (in_regs && valid > 0) {
+#pragma unroll
+        for (int j = 0; j < kNormRegs; ++j) { const int t = lane + 64 * j; if (t < frames) x[t] = t < valid ? (v[j] - mean) * inv_std : 0.0f; }
+    } else {
+        for (int t = lane; t < frames; t += 64) x[t] = t < valid ? (x[t] - mean) * inv_std : 0.0f;
+    }
 }
 
 // ----------------------------------------------------------------------------- host tables
