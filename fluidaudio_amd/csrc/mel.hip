@@ -834,7 +834,12 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         e = hipGetDeviceProperties(&prop, ctx->device);
         const int cus = e == hipSuccess ? prop.multiProcessorCount : 256;
         const char *rounds_env = getenv("FA_MEL_ROUNDS");  // diagnostics
-        const int rounds = rounds_env && atoi(rounds_env) > 0 ? atoi(rounds_env) : 4;
+        // Equal-length batches: one persistent round (the per-workgroup prologue — tables, lane constants — is paid once:
+        // 0.663 vs 0.685 ms with four rounds on the bench workload).  Ragged batches keep four rounds, so that the hardware
+        // scheduler evens out ranges that hold many empty tiles of short utterances.
+        bool uniform = true;
+        for (int b = 1; b < batch; ++b) if (frames[b] != frames[0]) { uniform = false; break; }
+        const int rounds = rounds_env && atoi(rounds_env) > 0 ? atoi(rounds_env) : (uniform ? 1 : 4);
         const int64_t want = static_cast<int64_t>(cus) * 2 * rounds;  // 2 resident workgroups per CU, `rounds` rounds of them
         p->grid = static_cast<int>(a.total_tiles < want ? a.total_tiles : want);
         if (p->grid < 1) p->grid = 1;
