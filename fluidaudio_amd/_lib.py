@@ -5,6 +5,7 @@ path raises.  (The oracle under oracle/ is test infrastructure and is never impo
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -209,6 +210,29 @@ class Context:
 
     def synchronize(self):
         self.check(lib().fa_ctx_synchronize(self._h), "fa_ctx_synchronize")
+
+    @contextlib.contextmanager
+    def torch_ordered(self, enabled: bool = True):
+        """Stream ordering for the `*_dev` entries called with torch tensors: the context's stream first waits for
+        everything already enqueued on torch's current stream (producers of the inputs, `.contiguous()` copies), and
+        torch's current stream afterwards waits for what the body enqueued on the context's stream — so later torch ops
+        (and the caching allocator's reuse of freed blocks) are ordered behind the kernels.  Two event record/wait pairs,
+        no host synchronisation.  `enabled=False`: the caller orders the streams itself (bench.py's timed loop)."""
+        if not enabled:
+            yield
+            return
+        import torch
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream()
+            own = torch.cuda.ExternalStream(self.stream, device=self.device)
+        if cur.cuda_stream == own.cuda_stream:
+            yield
+            return
+        own.wait_stream(cur)
+        try:
+            yield
+        finally:
+            cur.wait_stream(own)
 
     def last_error(self) -> str:
         return (lib().fa_ctx_last_error(self._h) or b"").decode()

@@ -424,6 +424,7 @@ struct fa_arpa_lm {
     std::vector<BiEntry> bi;
     int64_t n_uni = 0, n_bi_ctx = 0, n_bi = 0;
     void *d_uni = nullptr, *d_bi = nullptr;
+    int dev_id = -1;   // device holding d_uni / d_bi
     LmView host_view() const { return LmView{uni.empty() ? nullptr : uni.data(), bi.empty() ? nullptr : bi.data(), static_cast<uint32_t>(uni.size() - 1), static_cast<uint32_t>(bi.size() - 1)}; }
     LmView dev_view() const { return LmView{static_cast<const UniEntry *>(d_uni), static_cast<const BiEntry *>(d_bi), static_cast<uint32_t>(uni.size() - 1), static_cast<uint32_t>(bi.size() - 1)}; }
 };
@@ -508,7 +509,7 @@ fa_status fa_arpa_parse(fa_ctx *ctx, const char *text, int64_t len, fa_arpa_lm *
 
 void fa_arpa_destroy(fa_arpa_lm *lm) {
     if (!lm) return;
-    if ((lm->d_uni || lm->d_bi) && lm->ctx) { (void)hipSetDevice(lm->ctx->device); (void)hipFree(lm->d_uni); (void)hipFree(lm->d_bi); }
+    if (lm->d_uni || lm->d_bi) { fa::DeviceGuard guard(lm->dev_id); (void)hipFree(lm->d_uni); (void)hipFree(lm->d_bi); }
     delete lm;
 }
 
@@ -552,7 +553,7 @@ fa_status fa_ctc_vocab_create(fa_ctx *ctx, const int32_t *ids, const char *const
 
 void fa_ctc_vocab_destroy(fa_ctc_vocab *v) {
     if (!v) return;
-    if (v->d_tok) { (void)hipSetDevice(v->ctx->device); (void)hipFree(v->d_tok); }
+    if (v->d_tok) { fa::DeviceGuard guard(v->ctx->device); (void)hipFree(v->d_tok); }
     delete v;
 }
 
@@ -569,12 +570,21 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
     if (lm && (!vocabulary || vocabulary->vocab_size < vocab)) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "beam search: the language model needs a vocabulary covering all tokens");
     if (row_stride < vocab) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "beam search: row stride < vocab");
     fa::DeviceGuard guard(ctx->device);
-    if (lm && !lm->d_uni) {   // first use: upload the tables to this context's device
-        lm->ctx = ctx;
-        FA_HIP_TRY(ctx, hipMalloc(&lm->d_uni, sizeof(UniEntry) * lm->uni.size()));
-        FA_HIP_TRY(ctx, hipMalloc(&lm->d_bi, sizeof(BiEntry) * lm->bi.size()));
-        FA_HIP_TRY(ctx, hipMemcpy(lm->d_uni, lm->uni.data(), sizeof(UniEntry) * lm->uni.size(), hipMemcpyHostToDevice));
-        FA_HIP_TRY(ctx, hipMemcpy(lm->d_bi, lm->bi.data(), sizeof(BiEntry) * lm->bi.size(), hipMemcpyHostToDevice));
+    if (lm && (!lm->d_uni || lm->dev_id != ctx->device)) {   // first use on this device: upload the tables (all or nothing)
+        if (lm->d_uni || lm->d_bi) {   // tables of another device: release them there
+            fa::DeviceGuard other(lm->dev_id);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(lm->d_uni); (void)hipFree(lm->d_bi);
+            lm->d_uni = nullptr; lm->d_bi = nullptr;
+        }
+        void *du = nullptr, *db = nullptr;
+        hipError_t e = hipMalloc(&du, sizeof(UniEntry) * lm->uni.size());
+        if (e == hipSuccess) e = hipMalloc(&db, sizeof(BiEntry) * lm->bi.size());
+        if (e == hipSuccess) e = hipMemcpy(du, lm->uni.data(), sizeof(UniEntry) * lm->uni.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(db, lm->bi.data(), sizeof(BiEntry) * lm->bi.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(du); (void)hipFree(db); return fa::hip_status(ctx, e, "arpa table upload"); }
+        lm->d_uni = du; lm->d_bi = db;
+        lm->ctx = ctx; lm->dev_id = ctx->device;
     }
     BeamArgs a{};
     a.logp = d_log_probs; a.valid = d_valid_frames; a.tok = vocabulary ? static_cast<const TokInfo *>(vocabulary->d_tok) : nullptr;

@@ -29,7 +29,7 @@ fa_status fa_ctx_create(int device, void *stream, fa_ctx **out) {
     fa_ctx *ctx = new (std::nothrow) fa_ctx();
     if (!ctx) return FA_ALLOCATION_FAILURE;
     ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess) { delete ctx; return FA_RUNTIME_ERROR; }
+    fa::DeviceGuard guard(device);   // the caller's current device is restored on return
     if (stream) {
         ctx->stream = static_cast<hipStream_t>(stream);
     } else {
@@ -42,7 +42,7 @@ fa_status fa_ctx_create(int device, void *stream, fa_ctx **out) {
 
 void fa_ctx_destroy(fa_ctx *ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    fa::DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ahc_ws) (void)hipFree(ctx->ahc_ws);

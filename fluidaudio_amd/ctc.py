@@ -45,16 +45,18 @@ def ctc_greedy_ids_batch(logits, blank_id: int, vocab: int | None = None, valid_
 
 
 def ctc_greedy_ids_dev(ctx: L.Context, d_logits, blank_id: int, d_token_ids, d_token_lens, d_frame_ids=None,
-                       d_valid_frames=None, vocab: int | None = None):
-    """Device-resident batch: d_logits torch CUDA tensor [B,T,W] (fp32/fp16, contiguous). Enqueues on ctx.stream."""
+                       d_valid_frames=None, vocab: int | None = None, order: bool = True):
+    """Device-resident batch: d_logits torch CUDA tensor [B,T,W] (fp32/fp16, contiguous).  Enqueues on ctx.stream, ordered
+    against torch's current stream (Context.torch_ordered) unless order=False."""
     import torch
     B, T, W = d_logits.shape
     V = W if vocab is None else vocab
     dtype = L.DTYPE_F16 if d_logits.dtype == torch.float16 else L.DTYPE_F32
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-    ctx.check(L.lib().fa_ctc_greedy_batch_dev(ctx.handle, p(d_logits), dtype, B, T, V, W, T * W, p(d_valid_frames),
-                                              blank_id, p(d_frame_ids), p(d_token_ids), p(d_token_lens)),
-              "fa_ctc_greedy_batch_dev")
+    with ctx.torch_ordered(order):
+        ctx.check(L.lib().fa_ctc_greedy_batch_dev(ctx.handle, p(d_logits), dtype, B, T, V, W, T * W, p(d_valid_frames),
+                                                  blank_id, p(d_frame_ids), p(d_token_ids), p(d_token_lens)),
+                  "fa_ctc_greedy_batch_dev")
 
 
 class LogitsArgmax:
@@ -96,7 +98,8 @@ def ctc_greedy_decode(log_probs, vocabulary: dict[int, str], blank_id: int = 102
     return decode_ctc_token_ids(ids, vocabulary)
 
 
-def ctc_log_probs_dev(ctx, d_logits, temperature: float = 1.0, blank_bias: float = 0.0, blank_id: int = -1, d_out=None):
+def ctc_log_probs_dev(ctx, d_logits, temperature: float = 1.0, blank_bias: float = 0.0, blank_id: int = -1, d_out=None,
+                      order: bool = True):
     """makeLogProbs (CtcKeywordSpotter+Inference.swift:350-405) for a batch: d_logits torch CUDA [B, T, V] fp32/fp16
     (last dim contiguous) -> float32 CUDA tensor [B, T, V].  Enqueues on ctx.stream."""
     import torch
@@ -105,7 +108,8 @@ def ctc_log_probs_dev(ctx, d_logits, temperature: float = 1.0, blank_bias: float
     if d_out is None:
         d_out = torch.empty((B, T, V), dtype=torch.float32, device=d_logits.device)
     dt = L.DTYPE_F16 if d_logits.dtype == torch.float16 else L.DTYPE_F32
-    ctx.check(L.lib().fa_ctc_log_softmax_batch_dev(ctx.handle, C.c_void_p(d_logits.data_ptr()), dt, B, T, V, d_logits.stride(1),
-                                                   d_logits.stride(0), float(temperature), float(blank_bias), int(blank_id),
-                                                   C.c_void_p(d_out.data_ptr())), "fa_ctc_log_softmax_batch_dev")
+    with ctx.torch_ordered(order):
+        ctx.check(L.lib().fa_ctc_log_softmax_batch_dev(ctx.handle, C.c_void_p(d_logits.data_ptr()), dt, B, T, V, d_logits.stride(1),
+                                                       d_logits.stride(0), float(temperature), float(blank_bias), int(blank_id),
+                                                       C.c_void_p(d_out.data_ptr())), "fa_ctc_log_softmax_batch_dev")
     return d_out

@@ -40,10 +40,12 @@ class MelPlan:
             return (self.batch, self.cfg.n_mels, self.frame_stride)
         return (self.batch, self.frame_stride, self.cfg.n_mels)
 
-    def execute(self, d_pcm, d_mel, d_lengths=None, d_last=None):
-        """All arguments are torch CUDA tensors (float32 pcm/mel/last, int32 lengths). Enqueues on ctx.stream."""
-        self.ctx.check(L.lib().fa_mel_execute_dev(self._h, _ptr(d_pcm), _ptr(d_last), _ptr(d_mel), _ptr(d_lengths)),
-                       "fa_mel_execute_dev")
+    def execute(self, d_pcm, d_mel, d_lengths=None, d_last=None, order: bool = True):
+        """All arguments are torch CUDA tensors (float32 pcm/mel/last, int32 lengths).  Enqueues on ctx.stream, ordered
+        after torch's current stream and before its later work (Context.torch_ordered); `order=False` skips that."""
+        with self.ctx.torch_ordered(order):
+            self.ctx.check(L.lib().fa_mel_execute_dev(self._h, _ptr(d_pcm), _ptr(d_last), _ptr(d_mel), _ptr(d_lengths)),
+                           "fa_mel_execute_dev")
 
     def close(self):
         if self._h:
@@ -153,12 +155,14 @@ class UnifiedMelExtractor:
                              frame_stride=self.total_frames)
         d_mel = torch.empty((B, self.n_mels, self.total_frames), dtype=torch.float32, device=d_windows.device)
         d_len = torch.empty(B, dtype=torch.int32, device=d_windows.device)
-        plan.execute(d_windows.contiguous().view(-1), d_mel, d_len)
         valid = np.minimum(np.asarray(valid_counts, np.int64) // self.hop_length, self.total_frames).astype(np.int32)   # :66
         d_valid = torch.from_numpy(valid).to(d_windows.device)
+        d_flat = d_windows.contiguous().view(-1)
         ctx = self.mel.ctx
-        ctx.check(L.lib().fa_mel_normalize_per_feature_dev(ctx.handle, _ptr(d_mel), B, self.n_mels, self.total_frames,
-                                                           self.total_frames, _ptr(d_valid)), "fa_mel_normalize_per_feature_dev")
+        with ctx.torch_ordered():   # the copies above run on torch's stream, the two kernels on the context's
+            plan.execute(d_flat, d_mel, d_len, order=False)
+            ctx.check(L.lib().fa_mel_normalize_per_feature_dev(ctx.handle, _ptr(d_mel), B, self.n_mels, self.total_frames,
+                                                               self.total_frames, _ptr(d_valid)), "fa_mel_normalize_per_feature_dev")
         ctx.synchronize()
         plan.close()
         return d_mel, valid

@@ -88,9 +88,11 @@ def decode_tables(d_tok, d_bin, d_prob, enc_len, audio_frames=None, t0=None, is_
     o_conf = torch.zeros((B, max_out), dtype=torch.float32, device=dev)
     o_cnt, o_ft, o_fu, o_st = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(4))
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-    ctx.check(L.lib().fa_tdt_greedy_tables_dev(ctx.handle, C.byref(cfg), p(d_tok.contiguous()), p(d_bin.contiguous()), p(d_prob.contiguous()),
-                                               B, U, T, p(v_enc), p(v_af), p(v_t0), p(v_last), p(v_go), p(v_ea), max_out, p(o_tok),
-                                               p(o_time), p(o_dur), p(o_conf), p(o_cnt), p(o_ft), p(o_fu), p(o_st)), "fa_tdt_greedy_tables_dev")
+    c_tok, c_bin, c_prob = d_tok.contiguous(), d_bin.contiguous(), d_prob.contiguous()   # may launch copies on torch's stream
+    with ctx.torch_ordered():
+        ctx.check(L.lib().fa_tdt_greedy_tables_dev(ctx.handle, C.byref(cfg), p(c_tok), p(c_bin), p(c_prob),
+                                                   B, U, T, p(v_enc), p(v_af), p(v_t0), p(v_last), p(v_go), p(v_ea), max_out, p(o_tok),
+                                                   p(o_time), p(o_dur), p(o_conf), p(o_cnt), p(o_ft), p(o_fu), p(o_st)), "fa_tdt_greedy_tables_dev")
     ctx.synchronize()
     tok, tim, dur, conf = o_tok.cpu().numpy(), o_time.cpu().numpy(), o_dur.cpu().numpy(), o_conf.cpu().numpy()
     cnt, ft, fu, st = o_cnt.cpu().numpy(), o_ft.cpu().numpy(), o_fu.cpu().numpy(), o_st.cpu().numpy()

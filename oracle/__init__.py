@@ -709,3 +709,68 @@ def ctc_beam_search(log_probs, vocabulary: dict, lm=None, beam_width=100, lm_wei
 
 def decode_ctc_token_ids(ids, vocabulary: dict) -> str:                             # CtcDecoder.swift:289-294
     return "".join(vocabulary[i] for i in ids if i in vocabulary).replace(WORD_BOUNDARY, " ").strip(" \t")
+
+
+# ------------------------------------------------------------------ float64 evaluation of the mel path
+def mel_f64(audio, cfg: MelConfig = MelConfig(), last: float = 0.0, padding: str = "center", expected_frames: int | None = None):
+    """The reference's formula (AudioMelSpectrogram.swift:185-292 / :325-456 / :132-178) evaluated in float64 on the
+    reference's own fp32 constants: the Hann window and Slaney filterbank are the fp32 tables of :553-642 (part of the
+    definition), the pre-emphasis coefficient and log floor are the fp32 numbers, the INPUT is fp32 — but every sum and
+    product, the DFT and the log run in float64.  It is what an fp32 implementation is an approximation OF, so
+    |fp32 path - mel_f64| measures that path's arithmetic error (used as the 1e-4 gate of north_star for both the fp32
+    restatement and the device).  Returns [T, n_mels] float64 (T = reference frame count; no padTo padding).
+    padding: 'center' (computeFlat/-Transposed .center), 'prepadded' (:345), 'legacy' (compute(), :132-178)."""
+    a = np.ascontiguousarray(audio, np.float32).astype(np.float64)
+    n_fft, hop, win = cfg.n_fft, cfg.hop, cfg.win
+    w = hann(win, cfg.window_periodic).astype(np.float64)
+    fb = slaney_filterbank(n_fft, cfg.n_mels, cfg.sample_rate).astype(np.float64)
+    if padding == "legacy":
+        T = 1 + int((a.size - win) / hop) if a.size >= win else 0
+        y, pad, off = a, 0, 0
+    else:
+        T = mel_frames(cfg, a.size, prepadded=(padding == "prepadded"))
+        p = float(np.float32(cfg.preemph))
+        if p != 0.0:                                                   # :211,:219-225 (:363-371: plain copy when preemph == 0)
+            y = a.copy()
+            if a.size:
+                y[0] = a[0] - p * float(np.float32(last))
+                y[1:] = a[1:] - p * a[:-1]
+        else:
+            y = a
+        pad = n_fft // 2 if padding == "center" else 0
+        off = (n_fft - win) // 2                                       # :234
+    if expected_frames is not None and a.size > 0:
+        T = max(int(expected_frames), 0)
+    if T <= 0:
+        return np.zeros((0, cfg.n_mels))
+    buf = np.zeros(pad + max(y.size, 0) + pad + n_fft + T * hop)      # zero beyond the signal (= truncated windows, :412)
+    buf[pad:pad + y.size] = y
+    idx = np.arange(T)[:, None] * hop + off + np.arange(win)[None, :]
+    frames = np.zeros((T, n_fft))
+    frames[:, off:off + win] = buf[idx] * w[None, :]
+    power = np.abs(np.fft.rfft(frames, axis=1)) ** 2
+    v = power @ fb.T
+    floor = float(np.float32(cfg.log_floor))
+    return np.log(np.maximum(v, floor)) if cfg.floor_clamped else np.log(v + floor)
+
+
+def mel_f64_error(got, ref64) -> float:
+    """max over elements of |got - f64| / max(|f64|, 1e-2): pure relative error wherever |log-mel| >= 1e-2."""
+    got, ref64 = np.asarray(got, np.float64), np.asarray(ref64, np.float64)
+    return float(np.max(np.abs(got - ref64) / np.maximum(np.abs(ref64), 1e-2))) if got.size else 0.0
+
+
+def unified_mel_features_f64(window, valid_count: int, n_mels: int = 128, hop: int = 160):
+    """UnifiedMelExtractor.features (:52-113) in float64 on the fp32 input: mel_f64 + per-feature mean / unbiased std over
+    the valid frames (+1e-5), frames >= valid -> 0.  Returns ([n_mels, totalFrames] float64, valid frames)."""
+    w = np.ascontiguousarray(window, np.float32)
+    total = w.size // hop + 1                                             # :29
+    m = mel_f64(w, MelConfig(n_mels=n_mels), expected_frames=total).T     # [n_mels, T]
+    valid = min(valid_count // hop, total)                                # :66
+    out = np.zeros_like(m)
+    if valid > 0:
+        x = m[:, :valid]
+        mean = x.sum(axis=1, keepdims=True) / valid
+        var = ((x - mean) ** 2).sum(axis=1, keepdims=True) / max(valid - 1, 1)
+        out[:, :valid] = (x - mean) / (np.sqrt(var) + float(np.float32(1e-5)))
+    return out, valid

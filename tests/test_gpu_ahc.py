@@ -161,3 +161,51 @@ def test_full_size_config3_known_prefix_and_structure(fa, gpu_ctx):
     assert st2 == 0 and np.array_equal(z, z2)
     labels = fa.cut(z, n, 0.25)
     assert len(set(labels.tolist())) == n // 2 and (labels[pos[:, 0]] == labels[pos[:, 1]]).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2] at FULL size against the reference itself: tests/golden/ahc_full_<dist>_<n>.json hold SHA-256 digests
+# of what the reference's own C++ (oracle/_ref, built from /root/reference) returned for the seeded inputs of
+# tests/golden/ahc_full_inputs.py (generated by tests/golden/make_ahc_full_digest.py, ~15 CPU-minutes per 50 k run).
+import glob  # noqa: E402
+import json  # noqa: E402
+import sys  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+FULL = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ahc_full_*_*.json")))
+
+
+def _first_mismatch(z, stem):
+    """Row of the first differing merge pair, from the committed pair list (diagnostics for a failing digest)."""
+    ref = np.load(stem + "_pairs.npz")["pairs"]
+    bad = np.nonzero((z[:, :2].astype(np.int32) != ref).any(axis=1))[0]
+    return None if bad.size == 0 else (int(bad[0]), z[bad[0]].tolist(), ref[bad[0]].tolist())
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["auto", "exact"])
+@pytest.mark.parametrize("path", FULL, ids=[os.path.basename(p)[9:-5] for p in FULL])
+def test_full_size_dendrogram_digest_vs_reference(fa, gpu_ctx, path, mode):
+    """Bit-exact at the configured size: dendrogram bytes (merge order, ids, heights, sizes) and the label vectors after
+    AHCClustering's cut at thr 0.6 / 1.0 / 1.05 / 1.2 hash to what the reference build produced — in AUTO mode (Gram
+    start-up, Lance-Williams filter + exact certification windows: the path only large N exercises) and in EXACT mode."""
+    from ahc_full_inputs import ahc_input, dendrogram_digest, sha256
+    want = json.load(open(path))
+    n, d = want["n"], want["d"]
+    x = ahc_input(want["dist"], n, d)
+    assert sha256(x) == want["input_sha256"], "the seeded input did not regenerate bit-for-bit (numpy version?)"
+    st, z, stats = fa.linkage(x, mode=mode, ctx=gpu_ctx, return_stats=True)
+    assert st == 0
+    got = dendrogram_digest(z)
+    if got["dendrogram_sha256"] != want["dendrogram_sha256"]:
+        pytest.fail(f"dendrogram differs from the reference: pairs equal {got['pairs_sha256'] == want['pairs_sha256']}, heights equal "
+                    f"{got['heights_sha256'] == want['heights_sha256']}, first differing merge {_first_mismatch(z, path[:-5])}, stats {stats}")
+    for thr, c in want["cuts"].items():
+        lab = fa.cut(z, n, float(thr))
+        assert int(lab.max()) + 1 == c["clusters"]
+        assert sha256(lab.astype(np.int32)) == c["labels_sha256"], f"labels at thr {thr}"
+    print(f"{os.path.basename(path)} mode {mode}: bit-exact vs the reference; {stats}")
+
+
+def test_full_size_digests_are_committed():
+    names = {os.path.basename(p) for p in FULL}
+    assert {"ahc_full_iid_50000.json", "ahc_full_mix_50000.json"} <= names, "the 50 000 x 256 reference digests are missing"

@@ -133,3 +133,43 @@ def test_committed_golden_matches_oracle(oracle_mod):
     np.testing.assert_array_equal(m1, g["flat1"])
     m2, l2, _ = oracle_mod.mel_flat_transposed(g["a2"], last=0.25)
     np.testing.assert_array_equal(m2, g["tr2"])
+
+
+@pytest.mark.parametrize("n", [1, 400, 513, 16000, 24001, 160000])
+def test_fp32_restatement_within_1e4_of_float64(oracle_mod, n):
+    """The fp32 restatement against the float64 evaluation of the same formula on the same fp32 tables
+    (oracle.mel_f64): pure relative error <= 1e-4 wherever |log-mel| >= 1e-2 -- the gate the device has to pass too
+    (tests/test_gpu_mel.py::close64), so 'both fp32 paths agree' is not all that is shown."""
+    from conftest import synth_audio
+    a = synth_audio(n, seed=n)
+    ref, ml, nf = oracle_mod.mel_flat(a, last=0.3)
+    f = oracle_mod.mel_f64(a, last=0.3)
+    assert f.shape == (ml, 128)
+    assert oracle_mod.mel_f64_error(ref[:, :ml].T, f) <= 1e-4
+    tr, ml2, _ = oracle_mod.mel_flat_transposed(a, prepadded=True)
+    f2 = oracle_mod.mel_f64(a, padding="prepadded")
+    assert f2.shape[0] == ml2
+    if ml2:
+        assert oracle_mod.mel_f64_error(tr[:ml2], f2) <= 1e-4
+
+
+def test_float64_evaluation_other_configs(oracle_mod):
+    from conftest import synth_audio
+    a = synth_audio(20000, 8)
+    cfg = oracle_mod.MelConfig(preemph=0.0, log_floor=1e-10, floor_clamped=True, window_periodic=True)
+    ref, ml, _ = oracle_mod.mel_flat_transposed(a, cfg)
+    assert oracle_mod.mel_f64_error(ref[:ml], oracle_mod.mel_f64(a, cfg=cfg)) <= 1e-4
+    leg, T = oracle_mod.mel_legacy(a[:16000])
+    assert oracle_mod.mel_f64_error(leg.T, oracle_mod.mel_f64(a[:16000], padding="legacy")) <= 1e-4
+    ex, ml, nf = oracle_mod.mel_flat_transposed(a, expected_frames=140)
+    assert oracle_mod.mel_f64_error(ex[:140], oracle_mod.mel_f64(a, expected_frames=140)) <= 1e-4
+    # per-feature normalisation: fp32 restatement vs float64, within the north-star tolerance propagated through (x - mean) / std
+    w = np.zeros(32000, np.float32)
+    w[:12345] = synth_audio(12345, 41)
+    z32, v = oracle_mod.unified_mel_features(w, 12345)
+    z64, v64 = oracle_mod.unified_mel_features_f64(w, 12345)
+    assert v == v64 == 77
+    x64 = oracle_mod.mel_f64(w, expected_frames=201).T[:, :v]
+    tol = 1e-4 * (np.abs(x64) + np.abs(x64.mean(1, keepdims=True))) / (x64.std(1, ddof=1, keepdims=True) + 1e-5) + 1e-4 * np.abs(z64[:, :v])
+    assert np.all(np.abs(z32[:, :v] - z64[:, :v]) <= tol)
+    assert not z64[:, v:].any() and not z32[:, v:].any()
