@@ -21,6 +21,9 @@ STATUS_NAMES = {0: "SUCCESS", 1: "INVALID_ARGUMENT", 2: "INDEX_OVERFLOW", 3: "OU
 MEL_FLOOR_ADDITIVE, MEL_FLOOR_CLAMPED = 0, 1
 MEL_PAD_CENTER, MEL_PAD_PREPADDED, MEL_PAD_LEGACY = 0, 1, 2
 MEL_LAYOUT_MEL_MAJOR, MEL_LAYOUT_FRAME_MAJOR = 0, 1
+MEL_CENTER_ZERO, MEL_CENTER_REFLECT = 0, 1
+MEL_SCALE_SLANEY, MEL_SCALE_HTK_NONORM = 0, 1
+MEL_TAIL_ZERO, MEL_TAIL_REPLICATE = 0, 1
 DTYPE_F32, DTYPE_F16 = 0, 1
 AHC_MODE_AUTO, AHC_MODE_EXACT = 0, 1
 
@@ -54,7 +57,8 @@ class MelConfig(C.Structure):
     _fields_ = [("sample_rate", C.c_int32), ("n_mels", C.c_int32), ("n_fft", C.c_int32), ("hop", C.c_int32),
                 ("win", C.c_int32), ("preemph", C.c_float), ("pad_to", C.c_int32), ("log_floor", C.c_float),
                 ("floor_mode", C.c_int32), ("window_periodic", C.c_int32), ("padding_mode", C.c_int32),
-                ("layout", C.c_int32)]
+                ("layout", C.c_int32), ("power", C.c_float), ("center_pad", C.c_int32), ("mel_scale", C.c_int32),
+                ("tail_mode", C.c_int32), ("filterbank", C.c_void_p)]
 
 
 class TdtConfig(C.Structure):

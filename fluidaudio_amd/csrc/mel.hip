@@ -11,12 +11,14 @@
 // LDS region only to be gathered by the sparse triangular filterbank.  Log-mel values are staged in LDS
 // and stored by the whole workgroup as full rows ([n_mels, T]: 128-byte runs; [T, n_mels]: contiguous).
 // HBM traffic per 15 s utterance = 960 000 B read + 768 512 B written.
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <vector>
 
 #include "fa_common.h"
 #include "mel_core.h"
+#include "mel_generic.h"
 #include "mel_pk.h"
 
 using namespace fa::melcore;
@@ -53,6 +55,8 @@ struct MelArgs {
     int32_t hop, pad, stage_count, stage_alloc, out_alloc;
     float preemph, log_floor;
     int32_t floor_clamped;
+    unsigned long long *queue;       // mel_kernel_v4: tile counter (never reset) ...
+    unsigned long long queue_base;   // ... and the first value that belongs to this launch
     unsigned long long *prof;  // FA_MEL_PROF env (diagnostics): per-phase cycle sums of one workgroup's wave 0
     int32_t prio_lo, prio_hi, prio_pw, prio_rd;  // wave priorities: FFT / filterbank..store / power / sample reads (FA_MEL_PRIO=a,b,c,d)
 };
@@ -524,6 +528,8 @@ __global__ __launch_bounds__(kThreads, 2) void mel_kernel(const MelArgs a) {
 #undef MEL_STAMP
 }
 
+#include "mel_v4.inc"
+
 // NeMo per_feature normalisation as done by UnifiedMelExtractor.normalizePerFeature
 // (reference: Sources/FluidAudio/ASR/Parakeet/Unified/UnifiedMelExtractor.swift:91-113): for every mel bin subtract the
 // mean and divide by the unbiased std (+1e-5) over the valid frames; frames >= valid become 0; valid == 0 zeroes the row.
@@ -617,14 +623,50 @@ void make_filterbank(int n_fft, int n_mels, int sr, std::vector<float> &fb) {
     }
 }
 
+// torchaudio melscale_fbanks(norm: nil, mel_scale: "htk") as built by LuxTtsMelExtractor.htkMelFilterbank
+// (Sources/FluidAudio/TTS/LuxTts/LuxTtsMelExtractor.swift:160-189): double arithmetic, rounded to float at the end
+void make_filterbank_htk(int n_fft, int n_mels, int sr, std::vector<float> &fb) {
+    const int bins = n_fft / 2 + 1;
+    fb.assign(static_cast<size_t>(n_mels) * bins, 0.0f);
+    const double f_max = static_cast<double>(sr) / 2.0;
+    auto hz_to_mel_htk = [](double hz) { return 2595.0 * log10(1.0 + hz / 700.0); };
+    auto mel_to_hz_htk = [](double mel) { return 700.0 * (pow(10.0, mel / 2595.0) - 1.0); };
+    const double mel_min = hz_to_mel_htk(0.0), mel_max = hz_to_mel_htk(f_max);
+    std::vector<double> pts(n_mels + 2), freqs(bins);
+    for (int i = 0; i < n_mels + 2; ++i) pts[i] = mel_to_hz_htk(mel_min + static_cast<double>(i) * (mel_max - mel_min) / static_cast<double>(n_mels + 1));
+    for (int b = 0; b < bins; ++b) freqs[b] = static_cast<double>(b) * f_max / static_cast<double>(bins - 1);
+    for (int m = 0; m < n_mels; ++m)
+        for (int b = 0; b < bins; ++b) {
+            const double up = (freqs[b] - pts[m]) / (pts[m + 1] - pts[m]), down = (pts[m + 2] - freqs[b]) / (pts[m + 2] - pts[m + 1]);
+            const double v = up < down ? up : down;
+            fb[static_cast<size_t>(m) * bins + b] = static_cast<float>(v > 0.0 ? v : 0.0);
+        }
+}
+
+// the bank a configuration asks for: caller's table, HTK/no-norm, or the reference's Slaney bank
+void config_filterbank(const fa_mel_config *c, std::vector<float> &fb) {
+    const size_t n = static_cast<size_t>(c->n_mels) * (c->n_fft / 2 + 1);
+    if (c->filterbank) fb.assign(c->filterbank, c->filterbank + n);
+    else if (c->mel_scale == FA_MEL_SCALE_HTK_NONORM) make_filterbank_htk(c->n_fft, c->n_mels, c->sample_rate, fb);
+    else make_filterbank(c->n_fft, c->n_mels, c->sample_rate, fb);
+}
+
 fa_status validate(const fa_mel_config *c) {
     if (!c) return FA_INVALID_ARGUMENT;
-    if (c->n_fft != kNfft) return FA_INVALID_ARGUMENT;  // device kernel generation: 512 only
+    if (c->n_fft < 64 || c->n_fft > 2048 || (c->n_fft & (c->n_fft - 1)) != 0) return FA_INVALID_ARGUMENT;  // power of two
     if (c->win < 2 || c->win > c->n_fft || c->hop < 1 || c->hop > 4096) return FA_INVALID_ARGUMENT;
     if (c->n_mels < 1 || c->n_mels > kMaxMels || c->sample_rate < 1) return FA_INVALID_ARGUMENT;
     if (c->padding_mode < 0 || c->padding_mode > 2 || c->layout < 0 || c->layout > 1) return FA_INVALID_ARGUMENT;
     if (c->floor_mode < 0 || c->floor_mode > 1) return FA_INVALID_ARGUMENT;
+    if (c->power != 0.0f && c->power != 1.0f && c->power != 2.0f) return FA_INVALID_ARGUMENT;
+    if (c->center_pad < 0 || c->center_pad > 1 || c->mel_scale < 0 || c->mel_scale > 1 || c->tail_mode < 0 || c->tail_mode > 1) return FA_INVALID_ARGUMENT;
     return FA_SUCCESS;
+}
+
+// configurations the tuned n_fft = 512 kernels do not cover take mel_generic_kernel
+bool needs_generic(const fa_mel_config *c) {
+    return c->n_fft != kNfft || c->power == 1.0f || (c->center_pad == FA_MEL_CENTER_REFLECT && c->padding_mode == FA_MEL_PAD_CENTER) ||
+           c->tail_mode == FA_MEL_TAIL_REPLICATE || getenv("FA_MEL_GENERIC") != nullptr;
 }
 
 }  // namespace
@@ -644,6 +686,10 @@ struct fa_mel_plan {
     bool fast = false;  // filterbank fits the compile-time slot profile
     bool pk = false;    // frame-pair packed kernel (fast bank, hop == kPkHop)
     bool edge_zero = false;  // the zero-extended window vanishes on positions [0, 32) and [480, 512) of the frame
+    int v4_wps = 0;          // > 0: mel_kernel_v4 with that many workgroups per CU (packed kernel, 128 mels, hop 160)
+    unsigned long long launches = 0;   // v4 launches made so far (spaces the tile-queue ranges)
+    bool generic = false;    // mel_generic_kernel (any n_fft, magnitude, reflect padding, replicated tail)
+    fa::melgen::GenArgs gargs{};
 };
 
 extern "C" {
@@ -654,6 +700,8 @@ void fa_mel_default_config(fa_mel_config *c) {
     c->preemph = 0.97f; c->pad_to = 0; c->log_floor = ldexpf(1.0f, -24);
     c->floor_mode = FA_MEL_FLOOR_ADDITIVE; c->window_periodic = 0;
     c->padding_mode = FA_MEL_PAD_CENTER; c->layout = FA_MEL_LAYOUT_MEL_MAJOR;
+    c->power = 2.0f; c->center_pad = FA_MEL_CENTER_ZERO; c->mel_scale = FA_MEL_SCALE_SLANEY; c->tail_mode = FA_MEL_TAIL_ZERO;
+    c->filterbank = nullptr;
 }
 
 int32_t fa_mel_num_frames(const fa_mel_config *c, int64_t n) {
@@ -685,7 +733,7 @@ fa_status fa_mel_hann_window(const fa_mel_config *c, float *out) {
 fa_status fa_mel_filterbank(const fa_mel_config *c, float *out) {
     if (!c || !out || c->n_fft < 2 || c->n_mels < 1) return FA_INVALID_ARGUMENT;
     std::vector<float> fb;
-    make_filterbank(c->n_fft, c->n_mels, c->sample_rate, fb);
+    config_filterbank(c, fb);
     memcpy(out, fb.data(), sizeof(float) * fb.size());
     return FA_SUCCESS;
 }
@@ -700,13 +748,14 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
     try {
         fa_mel_plan *p = new fa_mel_plan();
         p->ctx = ctx; p->cfg = *cfg; p->batch = batch;
-        const int bins = kBins;
-        std::vector<int32_t> frames(batch);
+        const int bins = cfg->n_fft / 2 + 1;
+        std::vector<int32_t> frames(batch), natural(batch);
         int32_t max_padded = 1;
         for (int b = 0; b < batch; ++b) {
             const int64_t len = offsets[b + 1] - offsets[b];
             if (len < 0) { delete p; return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel: offsets not monotone"); }
             int32_t T = fa_mel_num_frames(cfg, len);
+            natural[b] = T;
             if (expected_frames && len > 0) T = expected_frames[b] > 0 ? expected_frames[b] : 0;  // :347
             frames[b] = T;
             p->total_frames += T;
@@ -722,8 +771,70 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         // tables
         std::vector<float> hann, fb;
         make_hann(cfg->win, cfg->window_periodic != 0, hann);
-        make_filterbank(cfg->n_fft, cfg->n_mels, cfg->sample_rate, fb);
+        config_filterbank(cfg, fb);
         const int off = cfg->padding_mode == FA_MEL_PAD_LEGACY ? 0 : (cfg->n_fft - cfg->win) / 2;  // :234 / :148-153
+        if (needs_generic(cfg)) {
+            // sparse rows (support lo..hi of every mel, interior zeros kept), window, twiddles exp(-2 pi i k / n_fft)
+            const int N = cfg->n_fft;
+            std::vector<int32_t> lo(cfg->n_mels, 0), cnt(cfg->n_mels, 0), start(cfg->n_mels, 0);
+            std::vector<float> wts;
+            for (int m = 0; m < cfg->n_mels; ++m) {
+                int l0 = -1, h0 = -1;
+                for (int k = 0; k < bins; ++k) if (fb[static_cast<size_t>(m) * bins + k] != 0.0f) { if (l0 < 0) l0 = k; h0 = k; }
+                start[m] = static_cast<int32_t>(wts.size());
+                if (l0 >= 0) { lo[m] = l0; cnt[m] = h0 - l0 + 1; for (int k = l0; k <= h0; ++k) wts.push_back(fb[static_cast<size_t>(m) * bins + k]); }
+            }
+            if (wts.empty()) wts.push_back(0.0f);
+            std::vector<float2> tw(N / 2 + 1);
+            for (int k = 0; k <= N / 2; ++k) { const double ang = -2.0 * M_PI * k / N; tw[k] = make_float2((float)cos(ang), (float)sin(ang)); }
+            auto align = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+            const size_t o_off = 0, o_fr = align(o_off + sizeof(int64_t) * (batch + 1)), o_nat = align(o_fr + sizeof(int32_t) * batch),
+                         o_win = align(o_nat + sizeof(int32_t) * batch), o_tw = align(o_win + sizeof(float) * cfg->win), o_lo = align(o_tw + sizeof(float2) * tw.size()),
+                         o_cnt = align(o_lo + sizeof(int32_t) * cfg->n_mels), o_st = align(o_cnt + sizeof(int32_t) * cfg->n_mels),
+                         o_w = align(o_st + sizeof(int32_t) * cfg->n_mels), total = align(o_w + sizeof(float) * wts.size());
+            std::vector<char> blob(total, 0);
+            memcpy(blob.data() + o_off, offsets, sizeof(int64_t) * (batch + 1));
+            memcpy(blob.data() + o_fr, frames.data(), sizeof(int32_t) * batch);
+            memcpy(blob.data() + o_nat, natural.data(), sizeof(int32_t) * batch);
+            memcpy(blob.data() + o_win, hann.data(), sizeof(float) * cfg->win);
+            memcpy(blob.data() + o_tw, tw.data(), sizeof(float2) * tw.size());
+            memcpy(blob.data() + o_lo, lo.data(), sizeof(int32_t) * cfg->n_mels);
+            memcpy(blob.data() + o_cnt, cnt.data(), sizeof(int32_t) * cfg->n_mels);
+            memcpy(blob.data() + o_st, start.data(), sizeof(int32_t) * cfg->n_mels);
+            memcpy(blob.data() + o_w, wts.data(), sizeof(float) * wts.size());
+            hipError_t e = hipMalloc(&p->dev, total);
+            if (e != hipSuccess) { delete p; return fa::hip_status(ctx, e, "mel plan hipMalloc"); }
+            e = hipMemcpy(p->dev, blob.data(), total, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(p->dev); delete p; return fa::hip_status(ctx, e, "mel plan upload"); }
+            char *d = static_cast<char *>(p->dev);
+            fa::melgen::GenArgs &g = p->gargs;
+            g.offsets = reinterpret_cast<const int64_t *>(d + o_off);
+            g.frames = reinterpret_cast<const int32_t *>(d + o_fr);
+            g.stft_frames = reinterpret_cast<const int32_t *>(d + o_nat);
+            g.window = reinterpret_cast<const float *>(d + o_win);
+            g.tw = reinterpret_cast<const float2 *>(d + o_tw);
+            g.mel_lo = reinterpret_cast<const int32_t *>(d + o_lo);
+            g.mel_cnt = reinterpret_cast<const int32_t *>(d + o_cnt);
+            g.mel_start = reinterpret_cast<const int32_t *>(d + o_st);
+            g.mel_w = reinterpret_cast<const float *>(d + o_w);
+            g.utt_stride = p->utt_stride; g.batch = batch; g.frame_stride = frame_stride; g.n_mels = cfg->n_mels; g.n_fft = N;
+            g.log2_m = 0; while ((2 << g.log2_m) < N) ++g.log2_m;           // log2(N / 2)
+            g.win = cfg->win; g.off = off; g.hop = cfg->hop;
+            g.pad = cfg->padding_mode == FA_MEL_PAD_CENTER ? N / 2 : 0;
+            g.preemph = cfg->padding_mode == FA_MEL_PAD_LEGACY ? 0.0f : cfg->preemph;
+            g.log_floor = cfg->log_floor; g.floor_clamped = cfg->floor_mode == FA_MEL_FLOOR_CLAMPED;
+            g.reflect = cfg->center_pad == FA_MEL_CENTER_REFLECT && cfg->padding_mode == FA_MEL_PAD_CENTER;
+            g.magnitude = cfg->power == 1.0f; g.tail_replicate = cfg->tail_mode == FA_MEL_TAIL_REPLICATE;
+            g.frame_major = cfg->layout == FA_MEL_LAYOUT_FRAME_MAJOR;
+            p->generic = true;
+            p->lds_bytes = sizeof(float) * fa::melgen::kWaves * (2 * static_cast<size_t>(N) + 8);
+            if (p->lds_bytes > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fa::melgen::mel_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(p->lds_bytes));
+            const int64_t items = (static_cast<int64_t>(batch) * frame_stride + fa::melgen::kWaves - 1) / fa::melgen::kWaves;
+            p->grid = static_cast<int>(items < 256 * 16 ? (items < 1 ? 1 : items) : 256 * 16);
+            *out = p;
+            return FA_SUCCESS;
+        }
         std::vector<float> windowz(kNfft, 0.0f);
         for (int i = 0; i < cfg->win; ++i) windowz[off + i] = hann[i];
         p->edge_zero = getenv("FA_MEL_NO_EZ") == nullptr;
@@ -767,7 +878,7 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         size_t o_off = 0, o_fr = align(o_off + sizeof(int64_t) * (batch + 1)), o_wz = align(o_fr + sizeof(int32_t) * batch),
                o_t256 = align(o_wz + sizeof(float) * kNfft), o_t512 = align(o_t256 + sizeof(float2) * 256),
                o_tab = align(o_t512 + sizeof(float2) * 129), o_w = align(o_tab + sizeof(int32_t) * cfg->n_mels),
-               total = align(o_w + sizeof(float) * weights.size());
+               o_q = align(o_w + sizeof(float) * weights.size()), total = align(o_q + 8);
         std::vector<char> blob(total, 0);
         memcpy(blob.data() + o_off, offsets, sizeof(int64_t) * (batch + 1));
         memcpy(blob.data() + o_fr, frames.data(), sizeof(int32_t) * batch);
@@ -790,6 +901,7 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         a.tw512 = reinterpret_cast<const float2 *>(d + o_t512);
         a.mel_tab = reinterpret_cast<const int32_t *>(d + o_tab);
         a.mel_w = reinterpret_cast<const float *>(d + o_w);
+        a.queue = reinterpret_cast<unsigned long long *>(d + o_q);   // zero in the blob
         a.utt_stride = p->utt_stride;
         a.tiles_per_utt = (frame_stride + kTileFrames - 1) / kTileFrames;
         a.total_tiles = static_cast<int64_t>(a.tiles_per_utt) * batch;
@@ -816,8 +928,17 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
             if (got >= 2) { a.prio_lo = v4[0] & 3; a.prio_hi = v4[1] & 3; a.prio_pw = v4[2] & 3; a.prio_rd = v4[3] & 3; }
         }
         p->pk = fast && cfg->hop == kPkHop && getenv("FA_MEL_SCALAR") == nullptr;   // FA_MEL_SCALAR: diagnostics, one frame per lane
+        if (p->pk && cfg->n_mels == kFastGroups * kGroup) {   // FA_MEL_V4=0: the v3 kernel (diagnostics); FA_MEL_V4=4: four workgroups per CU
+            const char *ve = getenv("FA_MEL_V4");
+            p->v4_wps = ve ? atoi(ve) : 3;
+            if (p->v4_wps != 3 && p->v4_wps != 4) p->v4_wps = 0;
+        }
         p->lds_bytes = sizeof(float) * (a.stage_alloc + kRegions * (p->pk ? kRegionFloatsPk : kRegionFloats) + a.out_alloc) + sizeof(int32_t) * kMaxMels +
                        sizeof(float) * (static_cast<size_t>(a.n_weights) + 24 + 4 + (p->pk ? fa::melpk::kWindowTableFloats : 0));   // the paired weight reads of the packed kernel touch one slot row past the table
+        if (p->v4_wps) {
+            p->lds_bytes = kV4LdsBytes;
+            if (const char *pe = getenv("FA_MEL_V4_LDS_PAD")) p->lds_bytes += static_cast<size_t>(atoi(pe));   // diagnostics: fewer resident workgroups per CU
+        }
         if (p->lds_bytes > 160 * 1024) { (void)hipFree(p->dev); delete p; return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel: hop too large for LDS staging"); }
         if (p->lds_bytes > 64 * 1024) {
             const int lb = static_cast<int>(p->lds_bytes);
@@ -829,6 +950,12 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
+#define FA_V4_ATTR(L, E, W, A) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel_v4<L, E, W, A>), hipFuncAttributeMaxDynamicSharedMemorySize, lb)
+            FA_V4_ATTR(0, true, 3, true); FA_V4_ATTR(0, true, 3, false); FA_V4_ATTR(0, false, 3, true); FA_V4_ATTR(0, false, 3, false);
+            FA_V4_ATTR(0, true, 4, true); FA_V4_ATTR(0, true, 4, false); FA_V4_ATTR(0, false, 4, true); FA_V4_ATTR(0, false, 4, false);
+            FA_V4_ATTR(1, true, 3, true); FA_V4_ATTR(1, true, 3, false); FA_V4_ATTR(1, false, 3, true); FA_V4_ATTR(1, false, 3, false);
+            FA_V4_ATTR(1, true, 4, true); FA_V4_ATTR(1, true, 4, false); FA_V4_ATTR(1, false, 4, true); FA_V4_ATTR(1, false, 4, false);
+#undef FA_V4_ATTR
         }
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, ctx->device);
@@ -840,7 +967,7 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         bool uniform = true;
         for (int b = 1; b < batch; ++b) if (frames[b] != frames[0]) { uniform = false; break; }
         const int rounds = rounds_env && atoi(rounds_env) > 0 ? atoi(rounds_env) : (uniform ? 1 : 4);
-        const int64_t want = static_cast<int64_t>(cus) * 2 * rounds;  // 2 resident workgroups per CU, `rounds` rounds of them
+        const int64_t want = static_cast<int64_t>(cus) * (p->v4_wps ? p->v4_wps : 2) * rounds;  // resident workgroups per CU, `rounds` rounds of them
         p->grid = static_cast<int>(a.total_tiles < want ? a.total_tiles : want);
         if (p->grid < 1) p->grid = 1;
         *out = p;
@@ -866,26 +993,81 @@ fa_status fa_mel_execute_dev(fa_mel_plan *p, const float *d_pcm, const float *d_
     if (!p || !d_mel || (!d_pcm && p->total_samples > 0)) return FA_INVALID_ARGUMENT;
     fa_ctx *ctx = p->ctx;
     fa::DeviceGuard guard(ctx->device);
+    if (p->generic) {
+        fa::melgen::GenArgs g = p->gargs;
+        g.pcm = d_pcm; g.last = d_last; g.out = d_mel; g.lengths = d_lengths;
+        hipLaunchKernelGGL(fa::melgen::mel_generic_kernel, dim3(p->grid), dim3(fa::melgen::kThreads), p->lds_bytes, ctx->stream, g);
+        FA_HIP_TRY(ctx, hipGetLastError());
+        return FA_SUCCESS;
+    }
     MelArgs a = p->args;
     a.pcm = d_pcm; a.last = d_last; a.out = d_mel; a.lengths = d_lengths;
     static unsigned long long *s_prof = nullptr;
     static int s_prof_calls = 0;
+    static unsigned long long s_last_span[4] = {0, 0, 0, 0};
     if (getenv("FA_MEL_PROF")) {  // diagnostics only: per-phase cycles of one workgroup, printed every 10 launches
-        if (!s_prof) { (void)hipMalloc(&s_prof, 128); (void)hipMemset(s_prof, 0, 128); }
+        if (!s_prof) { (void)hipMalloc(&s_prof, 128 + 4 * 8192); (void)hipMemset(s_prof, 0, 128 + 4 * 8192); }
         a.prof = s_prof;
+        {   // slots 2..5: min / max of the workgroup start and end times of the launch about to be made
+            const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
+            unsigned long long keep[4];
+            (void)hipMemcpy(keep, s_prof + 2, 32, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(s_prof + 2, init, 32, hipMemcpyHostToDevice);
+            if (s_prof_calls % 10 == 9) memcpy(s_last_span, keep, 32);
+        }
         if (++s_prof_calls % 10 == 0) {
             unsigned long long h[16];
             (void)hipMemcpy(h, s_prof, 128, hipMemcpyDeviceToHost);
             const double n = h[7] ? static_cast<double>(h[7]) : 1.0;
+            if (p->v4_wps) {
+                fprintf(stderr, "mel v4 profile (cycles per tile, wave 0 of one workgroup, %llu tiles): stage %.0f | B1 %.0f | reads+pass1 %.0f | B2 %.0f | pass2..log %.0f | B3 %.0f | loads+stores %.0f | B4 %.0f\n",
+                        h[7], h[8] / n, h[9] / n, h[10] / n, h[11] / n, h[12] / n, h[13] / n, h[14] / n, h[15] / n);
+                fprintf(stderr, "mel v4 profile: workgroup starts spread over %.1f us, ends over %.1f us, first start -> last end %.1f us (last launch)\n",
+                        (s_last_span[1] - s_last_span[0]) / 100.0, (s_last_span[3] - s_last_span[2]) / 100.0, (s_last_span[3] - s_last_span[0]) / 100.0);
+                {
+                    std::vector<unsigned> dur(p->grid);
+                    (void)hipMemcpy(dur.data(), s_prof + 16, sizeof(unsigned) * dur.size(), hipMemcpyDeviceToHost);
+                    std::vector<unsigned> srt(dur);
+                    std::sort(srt.begin(), srt.end());
+                    fprintf(stderr, "mel v4 profile: workgroup durations (us): min %.1f | p10 %.1f | median %.1f | p90 %.1f | max %.1f ; slowest blocks:", srt.front() / 100.0,
+                            srt[srt.size() / 10] / 100.0, srt[srt.size() / 2] / 100.0, srt[srt.size() * 9 / 10] / 100.0, srt.back() / 100.0);
+                    int shown = 0;
+                    for (size_t b = 0; b < dur.size() && shown < 12; ++b) if (dur[b] >= srt[srt.size() - 12]) { fprintf(stderr, " %zu", b); ++shown; }
+                    double byx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (size_t b = 0; b < dur.size(); ++b) byx[b & 7] += dur[b];
+                    fprintf(stderr, "\n   mean by 64-block bucket (us):");
+                    for (size_t b0 = 0; b0 < dur.size(); b0 += 64) { double m = 0; size_t c = 0; for (size_t b = b0; b < b0 + 64 && b < dur.size(); ++b, ++c) m += dur[b]; fprintf(stderr, " %.0f", m / c / 100.0); }
+                    fprintf(stderr, "\n   mean by blockIdx %% 8 (us):");
+                    for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", byx[x] / (dur.size() / 8.0) / 100.0);
+                    fprintf(stderr, "\n");
+                }
+                if (h[1]) fprintf(stderr, "mel v4 profile: shader clock during the kernel %.0f MHz (clock64 / wall_clock64 at 100 MHz)\n", 100.0 * static_cast<double>(h[0]) / static_cast<double>(h[1]));
+            } else {
             fprintf(stderr, "mel profile (cycles per tile, wave 0 of one workgroup, %llu tiles): stage-write %.0f | barrier1 %.0f | prefetch issue %.0f | passes %.0f | barrier2 %.0f | store %.0f\n",
                     h[7], h[0] / n, h[1] / n, (h[2] + h[6]) / n, (h[3] + h[8] + h[9] + h[10] + h[11]) / n, h[4] / n, h[5] / n);
             if (h[8]) fprintf(stderr, "mel profile, packed pass: sample reads %.0f | fft256 %.0f | partner + power %.0f | filterbank %.0f | log + stage %.0f\n",
                               h[8] / n, h[9] / n, h[10] / n, h[11] / n, h[3] / n);
+            }
         }
     } else a.prof = nullptr;
     const bool mm = p->cfg.layout == FA_MEL_LAYOUT_MEL_MAJOR;
     const bool pk = p->pk;
     const dim3 grid(p->grid), block(kThreads);
+    if (p->v4_wps) {
+        // every workgroup draws one index per tile it processes plus the one that tells it to stop: a launch advances the
+        // counter by exactly total_tiles + grid
+        a.queue_base = p->launches++ * (static_cast<unsigned long long>(a.total_tiles) + static_cast<unsigned long long>(p->grid));
+        const bool ez = p->edge_zero, w4 = p->v4_wps == 4;
+#define FA_V4(L, E, W) do { if (p->cfg.floor_mode == FA_MEL_FLOOR_CLAMPED) hipLaunchKernelGGL((mel_kernel_v4<L, E, W, true>), grid, block, p->lds_bytes, ctx->stream, a); \
+                             else hipLaunchKernelGGL((mel_kernel_v4<L, E, W, false>), grid, block, p->lds_bytes, ctx->stream, a); } while (0)
+        if (mm) { if (ez) { if (w4) FA_V4(FA_MEL_LAYOUT_MEL_MAJOR, true, 4); else FA_V4(FA_MEL_LAYOUT_MEL_MAJOR, true, 3); }
+                  else { if (w4) FA_V4(FA_MEL_LAYOUT_MEL_MAJOR, false, 4); else FA_V4(FA_MEL_LAYOUT_MEL_MAJOR, false, 3); } }
+        else { if (ez) { if (w4) FA_V4(FA_MEL_LAYOUT_FRAME_MAJOR, true, 4); else FA_V4(FA_MEL_LAYOUT_FRAME_MAJOR, true, 3); }
+               else { if (w4) FA_V4(FA_MEL_LAYOUT_FRAME_MAJOR, false, 4); else FA_V4(FA_MEL_LAYOUT_FRAME_MAJOR, false, 3); } }
+#undef FA_V4
+        FA_HIP_TRY(ctx, hipGetLastError());
+        return FA_SUCCESS;
+    }
     if (mm && pk && p->edge_zero) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, true, 2>), grid, block, p->lds_bytes, ctx->stream, a);
     else if (pk && p->edge_zero) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_FRAME_MAJOR, true, 2>), grid, block, p->lds_bytes, ctx->stream, a);
     else if (mm && pk) hipLaunchKernelGGL((mel_kernel<FA_MEL_LAYOUT_MEL_MAJOR, true, 1>), grid, block, p->lds_bytes, ctx->stream, a);

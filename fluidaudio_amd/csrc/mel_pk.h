@@ -176,6 +176,16 @@ __device__ __forceinline__ f2 partner(const f2 x) {
     b = __builtin_amdgcn_update_dpp(0, b, 0x121, 0xf, 0xf, true);
     return f2{__int_as_float(a), __int_as_float(b)};
 }
+// the same exchange with lane 0 of every row keeping `own` (its partner is one of its own registers): row_mirror, then
+// row_shr:1 — a shift has no source for lane 0, which therefore keeps the `old` operand.  Saves the select per value.
+__device__ __forceinline__ f2 partner_or(const f2 x, const f2 own) {
+    int a = __float_as_int(x.x), b = __float_as_int(x.y);
+    a = __builtin_amdgcn_update_dpp(0, a, 0x140, 0xf, 0xf, true);
+    b = __builtin_amdgcn_update_dpp(0, b, 0x140, 0xf, 0xf, true);
+    a = __builtin_amdgcn_update_dpp(__float_as_int(own.x), a, 0x111, 0xf, 0xf, false);
+    b = __builtin_amdgcn_update_dpp(__float_as_int(own.y), b, 0x111, 0xf, 0xf, false);
+    return f2{__int_as_float(a), __int_as_float(b)};
+}
 #endif
 
 // 4 |X[k]|^2 and 4 |X[256 - k]|^2 from A = Z[k], B = conj(Z[256 - k]) (bi_src = Im Z[256 - k]), w = exp(-2 pi i k / 512):

@@ -61,7 +61,8 @@ enum { FA_MEL_LAYOUT_MEL_MAJOR = 0,   /* [n_mels, frames]  computeFlat  (mel[m*s
 typedef struct {
     int32_t sample_rate;     /* 16000 */
     int32_t n_mels;          /* 128   (1..256) */
-    int32_t n_fft;           /* 512   (only 512 is implemented on device) */
+    int32_t n_fft;           /* 512   (any power of two 64..2048: LS-EEND uses nextPow2(winLength), LSEENDTypes.swift:55-57;
+                                       the batched NeMo configuration n_fft = 512 takes the tuned kernels) */
     int32_t hop;             /* 160 */
     int32_t win;             /* 400   (<= n_fft) */
     float preemph;           /* 0.97 */
@@ -71,7 +72,21 @@ typedef struct {
     int32_t window_periodic; /* 0 symmetric / 1 periodic (:553-562) */
     int32_t padding_mode;    /* FA_MEL_PAD_* */
     int32_t layout;          /* FA_MEL_LAYOUT_* */
+    /* Extensions beyond AudioMelSpectrogram (fa_mel_default_config sets the values that reproduce it): the torchaudio-
+     * flavoured front end of LuxTtsMelExtractor.extract (FluidAudio/TTS/LuxTts/LuxTtsMelExtractor.swift:52-132), the
+     * reference's only mel path with a golden vector in its tests. */
+    float power;             /* 2 = power spectrum (:459-481; 0 is read as 2), 1 = magnitude (LuxTts :90-96) */
+    int32_t center_pad;      /* FA_MEL_CENTER_* ; only meaningful with FA_MEL_PAD_CENTER */
+    int32_t mel_scale;       /* FA_MEL_SCALE_* */
+    int32_t tail_mode;       /* FA_MEL_TAIL_* */
+    const float *filterbank; /* optional HOST table [n_mels][n_fft/2 + 1] that replaces the built-in bank; NULL = mel_scale */
 } fa_mel_config;
+enum { FA_MEL_CENTER_ZERO = 0,     /* zero padding of n_fft/2 (:206-217) */
+       FA_MEL_CENTER_REFLECT = 1   /* torch pad_mode="reflect" (LuxTts :58-66) */ };
+enum { FA_MEL_SCALE_SLANEY = 0,    /* Slaney scale, area-normalised triangles (:564-642) */
+       FA_MEL_SCALE_HTK_NONORM = 1 /* torchaudio melscale_fbanks(norm: nil, mel_scale: "htk") (LuxTts :160-189) */ };
+enum { FA_MEL_TAIL_ZERO = 0,       /* frames past the signal see zeros (truncated windows, :412) */
+       FA_MEL_TAIL_REPLICATE = 1   /* frames >= the signal's own frame count repeat its last frame (lhotse alignment, LuxTts :124-128) */ };
 
 void fa_mel_default_config(fa_mel_config *cfg);
 /* Frame count T the reference would emit for n_samples (:192-197, :335-347, :133); 0 when its guard fires. */
