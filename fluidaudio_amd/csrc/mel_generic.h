@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kThreads) void mel_generic_kernel(const GenArgs a) 
             int tt = t;
             if (a.tail_replicate) { const int s = a.stft_frames[b]; if (tt > s - 1) tt = s > 0 ? s - 1 : 0; }
             const float lastv = a.last ? a.last[b] : 0.0f;
-            const int64_t f0 = static_cast<int64_t>(tt) * a.hop - a.pad - a.off;   // signal index of frame position 0
+            const int64_t f0 = static_cast<int64_t>(tt) * a.hop - a.pad;   // signal index of frame position 0 (:234: frame[j] = padded[t hop + j])
             for (int n = lane; n < N; n += 64) {
                 float v = 0.0f;
                 if (n >= a.off && n < a.off + a.win) v = gen_sample(x, len, f0 + n, lastv, a.preemph, a.reflect != 0) * a.window[n - a.off];

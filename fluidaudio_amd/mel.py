@@ -73,7 +73,7 @@ class AudioMelSpectrogram:
                           window_periodic=int(window_periodic))
 
     def config(self, padding_mode=L.MEL_PAD_CENTER, layout=L.MEL_LAYOUT_MEL_MAJOR) -> L.MelConfig:
-        return L.MelConfig(padding_mode=padding_mode, layout=layout, **self._base)
+        return L.MelConfig(padding_mode=padding_mode, layout=layout, power=2.0, **self._base)
 
     # -- single-utterance entries with the reference's return tuples ---------------------------
     def _run(self, audio, last, cfg, expected):
@@ -174,3 +174,42 @@ class UnifiedMelExtractor:
         assert w.shape[1] == self.window_samples
         d_mel, valid = self.features_batch(torch.from_numpy(w).cuda(self.mel.ctx.device), [valid_count])
         return d_mel.cpu().numpy(), int(valid[0])
+
+
+class LuxTtsMelExtractor:
+    """Mirror of ``LuxTtsMelExtractor`` (reference: Sources/FluidAudio/TTS/LuxTts/LuxTtsMelExtractor.swift:15-189), the
+    torchaudio-flavoured front end (24 kHz, n_fft 1024, hop 256, 100 mels, periodic Hann of n_fft, reflect padding,
+    magnitude spectrum, HTK mel scale without normalisation, log(max(v, 1e-7)), lhotse frame count with the last frame
+    replicated).  It is the reference's only mel path with a golden vector in its tests; here it runs through the same
+    C ABI (fa_mel_batch with the extension fields of fa_mel_config) on mel_generic_kernel."""
+
+    n_fft, hop, n_mels, sample_rate, log_mel_floor = 1024, 256, 100, 24000, 1e-7   # LuxTtsConstants
+
+    def __init__(self, ctx: L.Context | None = None):
+        self.ctx = ctx or L.default_context()
+
+    def frame_count(self, sample_count: int) -> int:
+        """frameCount(sampleCount:) (:45-47): lhotse compute_num_frames."""
+        return (sample_count + self.hop // 2) // self.hop
+
+    def config(self) -> L.MelConfig:
+        return L.MelConfig(sample_rate=self.sample_rate, n_mels=self.n_mels, n_fft=self.n_fft, hop=self.hop, win=self.n_fft,
+                           preemph=0.0, pad_to=0, log_floor=self.log_mel_floor, floor_mode=L.MEL_FLOOR_CLAMPED,
+                           window_periodic=1, padding_mode=L.MEL_PAD_CENTER, layout=L.MEL_LAYOUT_FRAME_MAJOR, power=1.0,
+                           center_pad=L.MEL_CENTER_REFLECT, mel_scale=L.MEL_SCALE_HTK_NONORM, tail_mode=L.MEL_TAIL_REPLICATE)
+
+    def extract(self, audio) -> np.ndarray:
+        """extract(audio:) (:52-132) -> [T, n_mels] log-mel (unscaled), T = frame_count(len(audio)); [] for empty input."""
+        a = np.ascontiguousarray(audio, np.float32).reshape(-1)
+        T = self.frame_count(a.size)
+        if a.size == 0 or T <= 0:
+            return np.zeros((0, self.n_mels), np.float32)
+        cfg = self.config()
+        out = np.zeros((T, self.n_mels), np.float32)
+        lens = np.zeros(1, np.int32)
+        offs = np.array([0, a.size], np.int64)
+        exp = np.array([T], np.int32)
+        self.ctx.check(L.lib().fa_mel_batch(self.ctx.handle, C.byref(cfg), a.ctypes.data, offs.ctypes.data, 1, None, exp.ctypes.data, T,
+                                            out.ctypes.data, lens.ctypes.data), "fa_mel_batch")
+        assert int(lens[0]) == T
+        return out

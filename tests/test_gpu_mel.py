@@ -291,3 +291,94 @@ def test_dev_entries_are_ordered_against_torch_stream(fa, gpu_ctx, oracle_mod):
     plan.execute(base.repeat(B), d_out)
     close(d_out[B - 1].cpu().numpy(), ref, "ordered launch")
     plan.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# mel_generic_kernel: any power-of-two n_fft, magnitude spectra, reflect padding, HTK bank, replicated tail
+def test_luxtts_reference_golden_on_device(fa, gpu_ctx, oracle_mod):
+    """The reference's ONLY mel golden vector (LuxTtsMelExtractorTests.swift:18-41: 103 936 samples at 24 kHz -> 406 x 100
+    log-mel x 0.1, gate max-abs < 1e-3), run through the DEVICE: fa_mel_batch with n_fft 1024, periodic Hann, reflect
+    padding, magnitude, HTK no-norm bank, clamped floor 1e-7, lhotse frame count with the last frame replicated."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "luxtts_prompt.npz"))
+    ex = fa.LuxTtsMelExtractor(ctx=gpu_ctx)
+    assert ex.frame_count(g["audio"].size) == 406
+    out = ex.extract(g["audio"])
+    assert out.shape == (406, 100)
+    err = np.abs(out * g["feat_scale"] - g["mel_scaled"]).max()
+    assert err < 1e-3, err                                       # the reference's own gate
+    # and against the fp32 restatement of the same machinery (fa_oracle_logmel_generic, pinned by the same fixture on the CPU)
+    a = g["audio"]
+    cfgc = ex.config()
+    win, fb = np.zeros(1024, np.float32), np.zeros((100, 513), np.float32)
+    gpu_ctx.check(fa.lib().fa_mel_hann_window(cfgc, win.ctypes.data), "window")
+    gpu_ctx.check(fa.lib().fa_mel_filterbank(cfgc, fb.ctypes.data), "bank")
+    ref = oracle_mod.logmel_generic(a, 1024, 256, win, fb, 1, 1e-7, 406)
+    # float64 evaluation of the same formula on the same fp32 tables: bins far below the frame's strongest component carry
+    # the fp32 DFT's absolute error (relative to the frame, not to the bin), so the 1e-4 relative gate applies where the mel
+    # value is within 40 dB of the frame maximum (the -80 dB tail carries ~1e-3); everywhere the device must be at least as close to float64 as the reference's
+    # own gate (1e-3 on the x0.1 scaled features = 1e-2 here) and as the fp32 restatement is
+    pad = 512
+    padded = np.concatenate([a[1:pad + 1][::-1], a, a[-pad - 1:-1][::-1]]).astype(np.float64)
+    stft = min(1 + a.size // 256, 406)
+    fr = padded[np.arange(stft)[:, None] * 256 + np.arange(1024)[None, :]] * win.astype(np.float64)[None, :]
+    v = np.abs(np.fft.rfft(fr, axis=1)) @ fb.astype(np.float64).T
+    f64 = np.log(np.maximum(v, float(np.float32(1e-7))))
+    f64 = np.concatenate([f64, np.repeat(f64[-1:], 406 - stft, axis=0)])
+    strong = v >= 1e-2 * v.max(axis=1, keepdims=True)
+    strong = np.concatenate([strong, np.repeat(strong[-1:], 406 - stft, axis=0)])
+    e_dev, e_ref = np.abs(out - f64), np.abs(ref - f64)
+    # (log-mel values near 0 = mel magnitudes near 1: the error of the log IS the relative error of the magnitude, ~1e-6
+    # for a sum of fp32 bins, so the denominator floor is 0.1 here instead of the 1e-2 of close64)
+    assert (e_dev[strong] / np.maximum(np.abs(f64[strong]), 1e-1)).max() <= 1e-4 and e_dev[strong].max() <= 2e-5
+    assert e_dev.max() < 1e-2 and e_dev.max() <= max(2.0 * e_ref.max(), 1e-3), (e_dev.max(), e_ref.max())
+    print(f"LuxTTS vs float64: device max abs {e_dev.max():.2e} (strong bins rel {(e_dev[strong] / np.maximum(np.abs(f64[strong]), 1e-2)).max():.2e}), fp32 restatement max abs {e_ref.max():.2e}")
+    print(f"LuxTTS golden on device: max abs err {err:.2e} (gate 1e-3)")
+    assert fa.LuxTtsMelExtractor(ctx=gpu_ctx).extract(np.zeros(0, np.float32)).shape == (0, 100)
+    # lhotse tail: 300 samples -> stft frames 2, target (300 + 128) / 256 = 1 ; 128 samples -> stft 1, target 1; 1000 -> stft 4, target 4
+    for n in (300, 128, 1000, 1153):
+        o = ex.extract(g["audio"][:n])
+        assert o.shape[0] == ex.frame_count(n) and np.isfinite(o).all()
+
+
+@pytest.mark.parametrize("n_fft,win,hop,n_mels,sr", [(256, 200, 80, 23, 8000), (1024, 800, 320, 80, 16000), (64, 64, 32, 10, 8000), (2048, 2048, 512, 64, 16000)])
+def test_other_fft_sizes_vs_oracle_and_float64(fa, gpu_ctx, oracle_mod, n_fft, win, hop, n_mels, sr):
+    """AudioMelSpectrogram with a metadata-driven nFFT (LS-EEND: nextPow2(winLength), LSEENDTypes.swift:55-57 with the
+    LSEENDPreprocessor.swift:70-82 flavour) and the NeMo flavour at other sizes: device vs fp32 restatement vs float64."""
+    a = synth_audio(12000, n_fft)
+    for kw_dev, kw_or in ((dict(preemph=0.0, log_floor=1e-10, log_floor_mode="clamped", window_periodic=True),
+                           dict(preemph=0.0, log_floor=1e-10, floor_clamped=True, window_periodic=True)),
+                          (dict(), dict())):
+        m = fa.AudioMelSpectrogram(sample_rate=sr, n_mels=n_mels, n_fft=n_fft, hop_length=hop, win_length=win, ctx=gpu_ctx, **kw_dev)
+        cfg = oracle_mod.MelConfig(sample_rate=sr, n_mels=n_mels, n_fft=n_fft, hop=hop, win=win, **kw_or)
+        got, ml, nf = m.compute_flat_transposed(a, last_audio_sample=0.1)
+        ref, rml, _ = oracle_mod.mel_flat_transposed(a, cfg, last=0.1)
+        assert ml == rml
+        close(got.reshape(nf, n_mels)[:ml], ref[:ml], f"n_fft {n_fft} transposed")
+        close64(oracle_mod, got.reshape(nf, n_mels)[:ml], a, f"n_fft {n_fft}", cfg=cfg, last=0.1)
+        got, ml, nf = m.compute_flat(a)
+        ref, rml, _ = oracle_mod.mel_flat(a, cfg)
+        assert ml == rml
+        close(got.reshape(n_mels, nf)[:, :ml], ref[:, :ml], f"n_fft {n_fft} flat")
+        got, ml, nf = m.compute_flat_transposed(a, padding_mode="prePadded")
+        ref, rml, _ = oracle_mod.mel_flat_transposed(a, cfg, prepadded=True)
+        assert ml == rml
+        close(got.reshape(nf, n_mels)[:ml], ref[:ml], f"n_fft {n_fft} prepadded")
+
+
+def test_generic_kernel_equals_tuned_kernels(fa, gpu_ctx, oracle_mod, monkeypatch):
+    """FA_MEL_GENERIC=1 routes the NeMo configuration (n_fft 512) through mel_generic_kernel: the two independent device
+    implementations (radix-2 Stockham vs radix-16 packed) agree within the fp32 tolerance and both pass the float64 gate."""
+    lens = [16000, 12370, 1, 0, 52000, 4801]
+    audios = [synth_audio(n, 300 + i) for i, n in enumerate(lens)]
+    outs = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("FA_MEL_GENERIC", "1")
+        mel = fa.AudioMelSpectrogram(ctx=gpu_ctx)
+        outs.append([mel.compute_flat(a, last_audio_sample=0.2) for a in audios])
+    monkeypatch.delenv("FA_MEL_GENERIC")
+    for a, (m0, l0, n0), (m1, l1, n1) in zip(audios, outs[0], outs[1]):
+        assert (l0, n0) == (l1, n1)
+        if l0:
+            close(m1.reshape(128, n1)[:, :l1], m0.reshape(128, n0)[:, :l0], "generic vs tuned")
+            close64(oracle_mod, m1.reshape(128, n1)[:, :l1].T, a, "generic kernel", last=0.2)

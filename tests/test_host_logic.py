@@ -115,3 +115,29 @@ def test_vbx_output_cluster_counts(fa):
     cons = fa.SpeakerCountConstraints.resolve(6, 5)
     assert out.active_cluster_count == 5 and out.assigned_cluster_count == 3
     assert not cons.needs_adjustment(out.active_cluster_count) and cons.needs_adjustment(out.assigned_cluster_count)
+
+
+def test_htk_filterbank_and_config_validation(fa):
+    """fa_mel_filterbank with FA_MEL_SCALE_HTK_NONORM = LuxTtsMelExtractor.htkMelFilterbank (LuxTtsMelExtractor.swift:160-189);
+    the extended fa_mel_config fields are validated host-side (no GPU needed: plan creation fails before any device call)."""
+    import ctypes as C
+    L = fa._lib
+    cfg = L.MelConfig(sample_rate=24000, n_mels=100, n_fft=1024, hop=256, win=1024, mel_scale=L.MEL_SCALE_HTK_NONORM, power=1.0)
+    got = np.zeros((100, 513), np.float32)
+    assert fa.lib().fa_mel_filterbank(C.byref(cfg), got.ctypes.data) == 0
+    h2m = lambda hz: 2595 * np.log10(1 + hz / 700)  # noqa: E731
+    m2h = lambda m: 700 * (10 ** (m / 2595) - 1)  # noqa: E731
+    pts = m2h(h2m(0) + np.arange(102) * (h2m(12000.0) - h2m(0)) / 101)
+    fr = np.arange(513) * 12000.0 / 512
+    ref = np.stack([np.maximum(0, np.minimum((fr - pts[m]) / (pts[m + 1] - pts[m]), (pts[m + 2] - fr) / (pts[m + 2] - pts[m + 1]))) for m in range(100)])
+    np.testing.assert_allclose(got, ref.astype(np.float32), rtol=0, atol=1e-7)
+    assert (got >= 0).all() and got.max() <= 1.0 and (got.sum(axis=1) > 0).all()
+    # a caller-supplied table wins over mel_scale
+    custom = np.ascontiguousarray(np.random.default_rng(0).random((100, 513)), np.float32)
+    cfg.filterbank = custom.ctypes.data
+    assert fa.lib().fa_mel_filterbank(C.byref(cfg), got.ctypes.data) == 0
+    np.testing.assert_array_equal(got, custom)
+    # frame counts of the extension follow the same centre formula: win == n_fft -> 1 + n / hop (torch.stft, LuxTts :68)
+    cfg.filterbank = None
+    for n in (1, 255, 256, 103936):
+        assert fa.lib().fa_mel_num_frames(C.byref(cfg), n) == 1 + n // 256
