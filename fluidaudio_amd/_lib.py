@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = [
     "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_cluster", "fa_ahc_cut",
     "fa_vbx_speaker_count", "fa_vbx_refine",
     "fa_vbx_weighted_centroids", "fa_assign_cosine", "fa_centroid_scores", "fa_constrained_assign",
+    "fa_offline_cluster_default_config", "fa_offline_cluster",
     "fa_arpa_parse", "fa_arpa_destroy", "fa_arpa_unigram_count", "fa_arpa_bigram_context_count", "fa_arpa_score",
     "fa_ctc_vocab_create", "fa_ctc_vocab_destroy", "fa_ctc_beam_search_batch_dev", "fa_ctc_beam_search_batch",
     "fa_wav_pcm16_size", "fa_wav_encode_pcm16", "fa_wav_decode", "fa_rttm_parse", "fa_rttm_format", "fa_export_embeddings_json",
@@ -72,6 +73,18 @@ class AhcStats(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class OfflineClusterConfig(C.Structure):
+    _fields_ = [("clustering_threshold", C.c_double), ("warm_start_fa", C.c_double), ("warm_start_fb", C.c_double),
+                ("max_vbx_iterations", C.c_int32), ("convergence_tolerance", C.c_double), ("constrained_assignment", C.c_int32),
+                ("num_speakers", C.c_int64), ("min_speakers", C.c_int64), ("max_speakers", C.c_int64), ("ahc_mode", C.c_int32)]
+
+
+class OfflineClusterInfo(C.Structure):
+    _fields_ = [("training_rows", C.c_int64), ("initial_clusters", C.c_int32), ("vbx_iterations", C.c_int32),
+                ("was_adjusted", C.c_int32), ("constrained", C.c_int32), ("inputs_s", C.c_double), ("ahc_s", C.c_double),
+                ("vbx_s", C.c_double), ("assign_s", C.c_double), ("total_s", C.c_double), ("ahc", AhcStats)]
 
 
 def build(force: bool = False) -> str:
@@ -152,6 +165,10 @@ def lib() -> C.CDLL:
     L.fa_assign_cosine.argtypes = [vp, vp, i64, i32, vp, i32, vp]
     L.fa_centroid_scores.argtypes = [vp, vp, i64, i32, vp, i32, vp]
     L.fa_constrained_assign.argtypes = [vp, vp, i64, i32, vp, vp]
+    L.fa_offline_cluster_default_config.argtypes = [C.POINTER(OfflineClusterConfig)]
+    L.fa_offline_cluster_default_config.restype = None
+    L.fa_offline_cluster.argtypes = [vp, vp, i64, i32, vp, i32, vp, vp, C.POINTER(OfflineClusterConfig), i32, vp, vp, i32,
+                                     C.POINTER(i32), C.POINTER(OfflineClusterInfo)]
     u64 = C.c_uint64
     L.fa_arpa_parse.argtypes = [vp, C.c_char_p, i64, C.POINTER(vp)]
     L.fa_arpa_destroy.argtypes = [vp]

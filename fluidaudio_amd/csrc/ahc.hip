@@ -991,7 +991,9 @@ fa_status exact_rebuild(fa_ctx *ctx, const Ws &w, double *gram_norms = nullptr) 
 }
 
 // d_data: device [N][d]; d_Z: device [(N-1)*4] (heights already square-rooted on return).
-fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, int mode, fa_ahc_stats *stats) {
+}  // namespace (reopened below: the next function is one of the device-level cores declared in fa_common.h)
+
+fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, int mode, fa_ahc_stats *stats) {
     const size_t Np = (N + kBlk - 1) / kBlk * kBlk;
     const size_t nblk = Np / kBlk;
     if (nblk > kMaxBlocks) return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: N too large for the resident distance matrix");
@@ -1140,6 +1142,31 @@ fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     return FA_SUCCESS;
 }
 
+namespace {
+
+// normalizeFeatures (AHCClustering.swift:70-105): one thread per row, the reference's sequential sum of squares (this file
+// is compiled with -ffp-contract=off), scale = norm > 0 ? 1 / sqrt(norm) : 0 — bit-identical to the host loop of fa_ahc_cluster.
+__global__ void ahc_normalize_rows(const double *__restrict__ x, double *__restrict__ out, int64_t n, int d) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *row = x + i * d;
+    double ss = 0.0;
+    for (int k = 0; k < d; ++k) ss += row[k] * row[k];
+    const double scale = ss > 0 ? 1.0 / sqrt(ss) : 0.0;
+    for (int k = 0; k < d; ++k) out[i * d + k] = row[k] * scale;
+}
+
+}  // namespace
+
+fa_status fa::ahc_normalize_dev(fa_ctx *ctx, const double *d_x, double *d_out, int64_t n, int32_t d) {
+    if (n <= 0) return FA_SUCCESS;
+    hipLaunchKernelGGL(ahc_normalize_rows, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(64), 0, ctx->stream, d_x, d_out, n, d);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+
+namespace {
+
 fa_status linkage_checks(const double *data, size_t n, size_t d, double *z, size_t zlen, bool *trivial) {
     // status contract of FastClusterWrapper.cpp:203-226
     *trivial = true;
@@ -1170,14 +1197,14 @@ fa_status fa_ahc_linkage(fa_ctx *ctx, const double *data, size_t n, size_t d, do
     if (stats) memset(stats, 0, sizeof(*stats));
     try {
         fa::DeviceGuard guard(ctx->device);
-        if (device_pointers) return ahc_run_device(ctx, data, n, d, dendrogram, mode, stats);
+        if (device_pointers) return fa::ahc_run_device(ctx, data, n, d, dendrogram, mode, stats);
         fa::DevBuf d_in, d_z;
         if (d_in.alloc(sizeof(double) * n * d) != hipSuccess || d_z.alloc(sizeof(double) * 4 * (n - 1)) != hipSuccess) {
             (void)hipGetLastError();
             return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: input staging allocation failed");
         }
         FA_HIP_TRY(ctx, hipMemcpyAsync(d_in.p, data, sizeof(double) * n * d, hipMemcpyHostToDevice, ctx->stream));
-        FA_TRY(ahc_run_device(ctx, d_in.as<double>(), n, d, d_z.as<double>(), mode, stats));
+        FA_TRY(fa::ahc_run_device(ctx, d_in.as<double>(), n, d, d_z.as<double>(), mode, stats));
         FA_HIP_TRY(ctx, hipMemcpyAsync(dendrogram, d_z.p, sizeof(double) * 4 * (n - 1), hipMemcpyDeviceToHost, ctx->stream));
         FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return FA_SUCCESS;

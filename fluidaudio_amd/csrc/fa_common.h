@@ -66,6 +66,25 @@ struct DevBuf {
 
 fa_status ensure_scratch(fa_ctx *ctx, size_t bytes);
 
+// ---- device-level cores shared by the host-pointer entries and fa_offline_cluster (internal, not part of the C ABI).
+// All pointers prefixed d_ are DEVICE pointers; everything is enqueued on ctx->stream; results stay on the device.
+fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, int mode, fa_ahc_stats *stats);   // ahc.hip
+fa_status ahc_normalize_dev(fa_ctx *ctx, const double *d_x, double *d_out, int64_t n, int32_t d);                              // ahc.hip (:70-105)
+
+struct VbxDevice {   // buffers of one VBx run; gamma [T][S], pi [S] and hard [T] stay on the device for the stages behind it
+    DevBuf phi, rho, G, gamma, pi, logpi, part, alpha, invL, phiT, ll, scal, hard;
+    int64_t T = 0;
+    int32_t D = 0, S = 0;
+};
+fa_status vbx_run_dev(fa_ctx *ctx, const double *d_X, int64_t T, int32_t D, const int32_t *d_labels, int32_t S, const double *phi_host,
+                      double Fa, double Fb, int32_t max_iter, double epsilon, double *elbos_host, int32_t *n_iters, VbxDevice &out);   // vbx.hip
+
+fa_status centroids_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_gamma, int32_t S, const int32_t *d_spk, int32_t K,
+                        double *d_cent);                                                                                             // post.hip
+fa_status scores_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_cent, int32_t K, double *d_cn, double *d_scores);
+fa_status assign_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_cent, int32_t K, double *d_cn, int32_t *d_out);
+fa_status constrained_assign_dev(fa_ctx *ctx, const double *d_scores, int64_t n, int32_t K, const int32_t *chunk_indices_host, int32_t *d_out);
+
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) {

@@ -210,6 +210,7 @@ fa_status fa_vbx_weighted_centroids(fa_ctx *ctx, const double *emb, int64_t n, i
         fa::DeviceGuard guard(ctx->device);
         fa::DevBuf d_emb, d_gamma, d_spk, d_cent;
         hipError_t e;
+        fa_status st = FA_SUCCESS;
         do {
             if ((e = d_emb.alloc(sizeof(double) * n * d)) != hipSuccess) break;
             if ((e = d_gamma.alloc(sizeof(double) * n * S)) != hipSuccess) break;
@@ -218,12 +219,11 @@ fa_status fa_vbx_weighted_centroids(fa_ctx *ctx, const double *emb, int64_t n, i
             if (n > 0 && (e = hipMemcpyAsync(d_emb.p, emb, sizeof(double) * n * d, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
             if (n > 0 && (e = hipMemcpyAsync(d_gamma.p, gamma, sizeof(double) * n * S, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
             if ((e = hipMemcpyAsync(d_spk.p, spk.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-            hipLaunchKernelGGL(centroid_kernel, dim3((d + 63) / 64, K), dim3(64), 0, ctx->stream, d_emb.as<double>(), d_gamma.as<double>(),
-                               d_spk.as<int32_t>(), d_cent.as<double>(), n, d, S, K);
-            if ((e = hipGetLastError()) != hipSuccess) break;
+            if ((st = fa::centroids_dev(ctx, d_emb.as<double>(), n, d, d_gamma.as<double>(), S, d_spk.as<int32_t>(), K, d_cent.as<double>())) != FA_SUCCESS) break;
             if ((e = hipMemcpyAsync(centroids, d_cent.p, sizeof(double) * K * d, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
             e = hipStreamSynchronize(ctx->stream);
         } while (0);
+        if (st != FA_SUCCESS) return st;
         return fa::hip_status(ctx, e, "fa_vbx_weighted_centroids");
     } catch (const std::bad_alloc &) {
         return FA_ALLOCATION_FAILURE;
@@ -241,6 +241,7 @@ fa_status fa_assign_cosine(fa_ctx *ctx, const double *emb, int64_t n, int32_t d,
     fa::DeviceGuard guard(ctx->device);
     fa::DevBuf d_emb, d_c, d_cn, d_out;
     hipError_t e;
+    fa_status st = FA_SUCCESS;
     do {
         if ((e = d_emb.alloc(sizeof(double) * n * d)) != hipSuccess) break;
         if ((e = d_c.alloc(sizeof(double) * K * d)) != hipSuccess) break;
@@ -248,13 +249,11 @@ fa_status fa_assign_cosine(fa_ctx *ctx, const double *emb, int64_t n, int32_t d,
         if ((e = d_out.alloc(sizeof(int32_t) * n)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d_emb.p, emb, sizeof(double) * n * d, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d_c.p, centroids, sizeof(double) * K * d, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-        hipLaunchKernelGGL(normalize_rows, dim3((K + 63) / 64), dim3(64), 0, ctx->stream, d_c.as<double>(), d_cn.as<double>(), static_cast<int64_t>(K), d);
-        hipLaunchKernelGGL(assign_kernel, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
-                           d_emb.as<double>(), d_cn.as<double>(), d_out.as<int32_t>(), n, d, K);
-        if ((e = hipGetLastError()) != hipSuccess) break;
+        if ((st = fa::assign_dev(ctx, d_emb.as<double>(), n, d, d_c.as<double>(), K, d_cn.as<double>(), d_out.as<int32_t>())) != FA_SUCCESS) break;
         if ((e = hipMemcpyAsync(out, d_out.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
         e = hipStreamSynchronize(ctx->stream);
     } while (0);
+    if (st != FA_SUCCESS) return st;
     return fa::hip_status(ctx, e, "fa_assign_cosine");
 }
 
@@ -265,6 +264,7 @@ fa_status fa_centroid_scores(fa_ctx *ctx, const double *emb, int64_t n, int32_t 
     fa::DeviceGuard guard(ctx->device);
     fa::DevBuf d_emb, d_c, d_cn, d_s;
     hipError_t e;
+    fa_status st = FA_SUCCESS;
     do {
         if ((e = d_emb.alloc(sizeof(double) * n * d)) != hipSuccess) break;
         if ((e = d_c.alloc(sizeof(double) * K * d)) != hipSuccess) break;
@@ -272,13 +272,11 @@ fa_status fa_centroid_scores(fa_ctx *ctx, const double *emb, int64_t n, int32_t 
         if ((e = d_s.alloc(sizeof(double) * n * K)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d_emb.p, emb, sizeof(double) * n * d, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d_c.p, centroids, sizeof(double) * K * d, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-        hipLaunchKernelGGL(normalize_rows, dim3((K + 63) / 64), dim3(64), 0, ctx->stream, d_c.as<double>(), d_cn.as<double>(), static_cast<int64_t>(K), d);
-        hipLaunchKernelGGL(scores_kernel, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
-                           d_emb.as<double>(), d_cn.as<double>(), d_s.as<double>(), n, d, K);
-        if ((e = hipGetLastError()) != hipSuccess) break;
+        if ((st = fa::scores_dev(ctx, d_emb.as<double>(), n, d, d_c.as<double>(), K, d_cn.as<double>(), d_s.as<double>())) != FA_SUCCESS) break;
         if ((e = hipMemcpyAsync(scores, d_s.p, sizeof(double) * n * K, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
         e = hipStreamSynchronize(ctx->stream);
     } while (0);
+    if (st != FA_SUCCESS) return st;
     return fa::hip_status(ctx, e, "fa_centroid_scores");
 }
 
@@ -286,6 +284,54 @@ fa_status fa_constrained_assign(fa_ctx *ctx, const double *scores, int64_t n, in
     if (!ctx) return FA_INVALID_ARGUMENT;
     if (n == 0) return FA_SUCCESS;
     if (n < 0 || n > INT32_MAX || K < 0 || !chunk_indices || !out || (K > 0 && !scores)) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "constrained assign: bad arguments");
+    fa::DeviceGuard guard(ctx->device);
+    fa::DevBuf d_s, d_out;
+    hipError_t e;
+    fa_status st = FA_SUCCESS;
+    do {
+        if ((e = d_s.alloc(sizeof(double) * n * (K > 0 ? K : 1))) != hipSuccess) break;
+        if ((e = d_out.alloc(sizeof(int32_t) * n)) != hipSuccess) break;
+        if (K > 0 && (e = hipMemcpyAsync(d_s.p, scores, sizeof(double) * n * K, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        if ((st = fa::constrained_assign_dev(ctx, d_s.as<double>(), n, K, chunk_indices, d_out.as<int32_t>())) != FA_SUCCESS) break;
+        if ((e = hipMemcpyAsync(out, d_out.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    if (st != FA_SUCCESS) return st;
+    return fa::hip_status(ctx, e, "fa_constrained_assign");
+}
+
+}  // extern "C"
+
+// ---- device-level cores (fa_common.h): inputs and outputs are device pointers, work is enqueued on ctx->stream
+fa_status fa::centroids_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_gamma, int32_t S, const int32_t *d_spk, int32_t K,
+                            double *d_cent) {
+    if (K <= 0) return FA_SUCCESS;
+    hipLaunchKernelGGL(centroid_kernel, dim3((d + 63) / 64, K), dim3(64), 0, ctx->stream, d_emb, d_gamma, d_spk, d_cent, n, d, S, K);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+
+fa_status fa::scores_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_cent, int32_t K, double *d_cn, double *d_scores) {
+    if (n <= 0 || K <= 0) return FA_SUCCESS;
+    hipLaunchKernelGGL(normalize_rows, dim3((K + 63) / 64), dim3(64), 0, ctx->stream, d_cent, d_cn, static_cast<int64_t>(K), d);
+    hipLaunchKernelGGL(scores_kernel, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_emb, d_cn, d_scores, n, d, K);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+
+fa_status fa::assign_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_cent, int32_t K, double *d_cn, int32_t *d_out) {
+    if (n <= 0) return FA_SUCCESS;
+    if (K <= 0) { FA_HIP_TRY(ctx, hipMemsetAsync(d_out, 0, sizeof(int32_t) * n, ctx->stream)); return FA_SUCCESS; }   // guard (:795-797)
+    hipLaunchKernelGGL(normalize_rows, dim3((K + 63) / 64), dim3(64), 0, ctx->stream, d_cent, d_cn, static_cast<int64_t>(K), d);
+    hipLaunchKernelGGL(assign_kernel, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_emb, d_cn, d_out, n, d, K);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+
+// chunk_indices is a HOST array (it is the caller's bookkeeping, not a device product): the grouping of rows by chunk is host
+// work, the tables go up (8 n bytes) and stay alive until the kernel has run (the call synchronises the stream before it returns).
+fa_status fa::constrained_assign_dev(fa_ctx *ctx, const double *d_scores, int64_t n, int32_t K, const int32_t *chunk_indices, int32_t *d_out) {
+    if (n <= 0) return FA_SUCCESS;
     try {
         // rows grouped by chunk, ascending row order inside a chunk (rowsByChunk[chunk].append(row), :27-30)
         std::vector<int32_t> order(static_cast<size_t>(n));
@@ -300,30 +346,21 @@ fa_status fa_constrained_assign(fa_ctx *ctx, const double *scores, int64_t n, in
         for (int c = 0; c < n_chunks; ++c) max_rows = std::max(max_rows, starts[c + 1] - starts[c]);
         if (std::max(max_rows, static_cast<int>(K)) > kHungMaxN)
             return fa::set_error(ctx, FA_RUNTIME_ERROR, "constrained assign: more than %d rows per chunk or clusters", kHungMaxN);
-        fa::DeviceGuard guard(ctx->device);
-        fa::DevBuf d_s, d_start, d_rows, d_out;
-        hipError_t e;
-        do {
-            if ((e = d_s.alloc(sizeof(double) * n * (K > 0 ? K : 1))) != hipSuccess) break;
-            if ((e = d_start.alloc(sizeof(int32_t) * starts.size())) != hipSuccess) break;
-            if ((e = d_rows.alloc(sizeof(int32_t) * n)) != hipSuccess) break;
-            if ((e = d_out.alloc(sizeof(int32_t) * n)) != hipSuccess) break;
-            if (K > 0 && (e = hipMemcpyAsync(d_s.p, scores, sizeof(double) * n * K, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-            if ((e = hipMemcpyAsync(d_start.p, starts.data(), sizeof(int32_t) * starts.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-            if ((e = hipMemcpyAsync(d_rows.p, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-            if ((e = hipMemsetAsync(d_out.p, 0xfe, sizeof(int32_t) * n, ctx->stream)) != hipSuccess) break;  // placeholder, every row is written
-            hipLaunchKernelGGL(hungarian_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, ctx->stream, d_s.as<double>(), d_start.as<int32_t>(),
-                               d_rows.as<int32_t>(), d_out.as<int32_t>(), n_chunks, K);
-            if ((e = hipGetLastError()) != hipSuccess) break;
-            if ((e = hipMemcpyAsync(out, d_out.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
-            e = hipStreamSynchronize(ctx->stream);
-        } while (0);
-        return fa::hip_status(ctx, e, "fa_constrained_assign");
+        fa::DevBuf d_start, d_rows;
+        if (d_start.alloc(sizeof(int32_t) * starts.size()) != hipSuccess || d_rows.alloc(sizeof(int32_t) * n) != hipSuccess) {
+            (void)hipGetLastError();
+            return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "constrained assign: device allocation failed");
+        }
+        FA_HIP_TRY(ctx, hipMemcpyAsync(d_start.p, starts.data(), sizeof(int32_t) * starts.size(), hipMemcpyHostToDevice, ctx->stream));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(d_rows.p, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+        FA_HIP_TRY(ctx, hipMemsetAsync(d_out, 0xfe, sizeof(int32_t) * n, ctx->stream));  // placeholder, every row is written
+        hipLaunchKernelGGL(hungarian_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, ctx->stream, d_scores, d_start.as<int32_t>(), d_rows.as<int32_t>(), d_out, n_chunks, K);
+        FA_HIP_TRY(ctx, hipGetLastError());
+        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the tables above are released on return
+        return FA_SUCCESS;
     } catch (const std::bad_alloc &) {
         return FA_ALLOCATION_FAILURE;
     } catch (...) {
         return FA_UNKNOWN_ERROR;
     }
 }
-
-}  // extern "C"

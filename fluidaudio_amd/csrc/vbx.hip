@@ -246,60 +246,18 @@ fa_status fa_vbx_refine(fa_ctx *ctx, const double *rho, int64_t T, int32_t D, co
     *n_speakers = S;
     fa::DeviceGuard guard(ctx->device);
     try {
-        std::vector<double> phic(D);
-        for (int d = 0; d < D; ++d) phic[d] = phi[d] > 1e-12 ? phi[d] : 1e-12;  // :241
-        const size_t TD = static_cast<size_t>(T) * D, TS = static_cast<size_t>(T) * S, SD = static_cast<size_t>(S) * D;
-        fa::DevBuf bX, bphi, brho, bG, bgam, bpi, blpi, bpart, balpha, binvL, bphiT, bll, bscal, blab, bhard;
-        hipError_t e = hipSuccess;
-        auto A = [&](fa::DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.alloc(bytes); };
-        A(bX, 8 * TD); A(bphi, 8 * D); A(brho, 8 * TD); A(bG, 8 * T); A(bgam, 8 * TS); A(bpi, 8 * S); A(blpi, 8 * S);
-        A(bpart, 8 * static_cast<size_t>(kSplit) * S * (D + 1)); A(balpha, 8 * SD); A(binvL, 8 * SD); A(bphiT, 8 * S);
-        A(bll, 8 * T); A(bscal, 64); A(blab, 4 * T); A(bhard, 4 * T);
-        if (e != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "vbx: device allocation failed"); }
+        const size_t TD = static_cast<size_t>(T) * D, TS = static_cast<size_t>(T) * S;
+        fa::DevBuf bX, blab;
+        if (bX.alloc(8 * TD) != hipSuccess || blab.alloc(4 * T) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "vbx: device allocation failed"); }
         hipStream_t st = ctx->stream;
         FA_HIP_TRY(ctx, hipMemcpyAsync(bX.p, rho, 8 * TD, hipMemcpyHostToDevice, st));
-        FA_HIP_TRY(ctx, hipMemcpyAsync(bphi.p, phic.data(), 8 * D, hipMemcpyHostToDevice, st));
         FA_HIP_TRY(ctx, hipMemcpyAsync(blab.p, initial, 4 * T, hipMemcpyHostToDevice, st));
-        VbxWs w{};
-        w.X = bX.as<double>(); w.phi = bphi.as<double>(); w.rho = brho.as<double>(); w.G = bG.as<double>();
-        w.gamma = bgam.as<double>(); w.pi = bpi.as<double>(); w.logpi = blpi.as<double>(); w.part = bpart.as<double>();
-        w.alpha = balpha.as<double>(); w.invL = binvL.as<double>(); w.phiT = bphiT.as<double>(); w.llrow = bll.as<double>();
-        w.scal = bscal.as<double>(); w.T = T; w.D = D; w.S = S; w.Fa = Fa; w.Fb = Fb;
-        const int wave_blocks = static_cast<int>((T + 3) / 4);
-        hipLaunchKernelGGL(vbx_prepare, dim3(wave_blocks), dim3(kThreads), 0, st, w);
-        hipLaunchKernelGGL(vbx_init_gamma, dim3(wave_blocks), dim3(kThreads), 0, st, w, blab.as<int32_t>(), 7.0);
-        hipLaunchKernelGGL(vbx_fill, dim3((S + 255) / 256), dim3(256), 0, st, w.pi, S, 1.0 / static_cast<double>(S));  // :239
-        FA_HIP_TRY(ctx, hipGetLastError());
-        const dim3 ggrid((D + 1 + 63) / 64, (S + 3) / 4, kSplit);
-        const size_t estep_lds = sizeof(double) * 4 * static_cast<size_t>(D);
-        if (estep_lds > 64 * 1024) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "vbx: feature dimension too large");
-        double prev = -1.7976931348623157e308;
-        int iters = 0;
-        for (int it = 0; it < max_iter; ++it) {
-            iters = it + 1;
-            hipLaunchKernelGGL(vbx_gt_rho, ggrid, dim3(kThreads), 0, st, w, 0);
-            hipLaunchKernelGGL(vbx_speaker, dim3(S), dim3(kThreads), 0, st, w, 0);
-            hipLaunchKernelGGL(vbx_logpi, dim3((S + 255) / 256), dim3(256), 0, st, w);
-            hipLaunchKernelGGL(vbx_estep, dim3(wave_blocks), dim3(kThreads), estep_lds, st, w);
-            // only the column tile that holds column D of the partials: sum_t gamma of the NEW gamma (pi, :586-603)
-            hipLaunchKernelGGL(vbx_gt_rho, dim3(1, ggrid.y, kSplit), dim3(kThreads), 0, st, w, D / 64);
-            hipLaunchKernelGGL(vbx_speaker, dim3(S), dim3(kThreads), 0, st, w, 1);
-            hipLaunchKernelGGL(vbx_scalars, dim3(1), dim3(kThreads), 0, st, w);
-            FA_HIP_TRY(ctx, hipGetLastError());
-            double elbo = 0.0;
-            FA_HIP_TRY(ctx, hipMemcpyAsync(&elbo, w.scal, sizeof(double), hipMemcpyDeviceToHost, st));
-            FA_HIP_TRY(ctx, hipStreamSynchronize(st));
-            elbos[it] = elbo;
-            if (it > 0 && std::fabs(elbo - prev) < epsilon) { prev = elbo; break; }  // :653-659
-            prev = elbo;
-        }
-        hipLaunchKernelGGL(vbx_hard, dim3(static_cast<int>((T + 255) / 256)), dim3(256), 0, st, w, bhard.as<int32_t>());
-        FA_HIP_TRY(ctx, hipGetLastError());
-        FA_HIP_TRY(ctx, hipMemcpyAsync(gamma, w.gamma, 8 * TS, hipMemcpyDeviceToHost, st));
-        FA_HIP_TRY(ctx, hipMemcpyAsync(pi, w.pi, 8 * S, hipMemcpyDeviceToHost, st));
-        FA_HIP_TRY(ctx, hipMemcpyAsync(hard, bhard.p, 4 * T, hipMemcpyDeviceToHost, st));
+        fa::VbxDevice dev;
+        FA_TRY(fa::vbx_run_dev(ctx, bX.as<double>(), T, D, blab.as<int32_t>(), S, phi, Fa, Fb, max_iter, epsilon, elbos, n_iters, dev));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(gamma, dev.gamma.p, 8 * TS, hipMemcpyDeviceToHost, st));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(pi, dev.pi.p, 8 * S, hipMemcpyDeviceToHost, st));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(hard, dev.hard.p, 4 * T, hipMemcpyDeviceToHost, st));
         FA_HIP_TRY(ctx, hipStreamSynchronize(st));
-        *n_iters = iters;
         return FA_SUCCESS;
     } catch (const std::bad_alloc &) {
         return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "vbx: host allocation failed");
@@ -309,3 +267,61 @@ fa_status fa_vbx_refine(fa_ctx *ctx, const double *rho, int64_t T, int32_t D, co
 }
 
 }  // extern "C"
+
+// The EM loop on device-resident inputs (d_X: [T][D] rho features, d_labels: [T] AHC labels with S distinct values); gamma, pi and
+// the hard assignment stay on the device in `out`.  The ELBO of every iteration crosses to the host (8 bytes) for the
+// convergence test of the reference (:653-659).
+fa_status fa::vbx_run_dev(fa_ctx *ctx, const double *d_X, int64_t T, int32_t D, const int32_t *d_labels, int32_t S, const double *phi_host,
+                          double Fa, double Fb, int32_t max_iter, double epsilon, double *elbos, int32_t *n_iters, fa::VbxDevice &o) {
+    if (n_iters) *n_iters = 0;
+    std::vector<double> phic(D);
+    for (int d = 0; d < D; ++d) phic[d] = phi_host[d] > 1e-12 ? phi_host[d] : 1e-12;  // :241
+    const size_t TD = static_cast<size_t>(T) * D, TS = static_cast<size_t>(T) * S, SD = static_cast<size_t>(S) * D;
+    hipError_t e = hipSuccess;
+    auto A = [&](fa::DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.alloc(bytes); };
+    A(o.phi, 8 * D); A(o.rho, 8 * TD); A(o.G, 8 * T); A(o.gamma, 8 * TS); A(o.pi, 8 * S); A(o.logpi, 8 * S);
+    A(o.part, 8 * static_cast<size_t>(kSplit) * S * (D + 1)); A(o.alpha, 8 * SD); A(o.invL, 8 * SD); A(o.phiT, 8 * S);
+    A(o.ll, 8 * T); A(o.scal, 64); A(o.hard, 4 * T);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "vbx: device allocation failed"); }
+    o.T = T; o.D = D; o.S = S;
+    hipStream_t st = ctx->stream;
+    FA_HIP_TRY(ctx, hipMemcpyAsync(o.phi.p, phic.data(), 8 * D, hipMemcpyHostToDevice, st));
+    VbxWs w{};
+    w.X = d_X; w.phi = o.phi.as<double>(); w.rho = o.rho.as<double>(); w.G = o.G.as<double>();
+    w.gamma = o.gamma.as<double>(); w.pi = o.pi.as<double>(); w.logpi = o.logpi.as<double>(); w.part = o.part.as<double>();
+    w.alpha = o.alpha.as<double>(); w.invL = o.invL.as<double>(); w.phiT = o.phiT.as<double>(); w.llrow = o.ll.as<double>();
+    w.scal = o.scal.as<double>(); w.T = T; w.D = D; w.S = S; w.Fa = Fa; w.Fb = Fb;
+    const int wave_blocks = static_cast<int>((T + 3) / 4);
+    hipLaunchKernelGGL(vbx_prepare, dim3(wave_blocks), dim3(kThreads), 0, st, w);
+    hipLaunchKernelGGL(vbx_init_gamma, dim3(wave_blocks), dim3(kThreads), 0, st, w, d_labels, 7.0);
+    hipLaunchKernelGGL(vbx_fill, dim3((S + 255) / 256), dim3(256), 0, st, w.pi, S, 1.0 / static_cast<double>(S));  // :239
+    FA_HIP_TRY(ctx, hipGetLastError());
+    FA_HIP_TRY(ctx, hipStreamSynchronize(st));   // phic (a host temporary) has been consumed
+    const dim3 ggrid((D + 1 + 63) / 64, (S + 3) / 4, kSplit);
+    const size_t estep_lds = sizeof(double) * 4 * static_cast<size_t>(D);
+    if (estep_lds > 64 * 1024) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "vbx: feature dimension too large");
+    double prev = -1.7976931348623157e308;
+    int iters = 0;
+    for (int it = 0; it < max_iter; ++it) {
+        iters = it + 1;
+        hipLaunchKernelGGL(vbx_gt_rho, ggrid, dim3(kThreads), 0, st, w, 0);
+        hipLaunchKernelGGL(vbx_speaker, dim3(S), dim3(kThreads), 0, st, w, 0);
+        hipLaunchKernelGGL(vbx_logpi, dim3((S + 255) / 256), dim3(256), 0, st, w);
+        hipLaunchKernelGGL(vbx_estep, dim3(wave_blocks), dim3(kThreads), estep_lds, st, w);
+        // only the column tile that holds column D of the partials: sum_t gamma of the NEW gamma (pi, :586-603)
+        hipLaunchKernelGGL(vbx_gt_rho, dim3(1, ggrid.y, kSplit), dim3(kThreads), 0, st, w, D / 64);
+        hipLaunchKernelGGL(vbx_speaker, dim3(S), dim3(kThreads), 0, st, w, 1);
+        hipLaunchKernelGGL(vbx_scalars, dim3(1), dim3(kThreads), 0, st, w);
+        FA_HIP_TRY(ctx, hipGetLastError());
+        double elbo = 0.0;
+        FA_HIP_TRY(ctx, hipMemcpyAsync(&elbo, w.scal, sizeof(double), hipMemcpyDeviceToHost, st));
+        FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (elbos) elbos[it] = elbo;
+        if (it > 0 && std::fabs(elbo - prev) < epsilon) { prev = elbo; break; }  // :653-659
+        prev = elbo;
+    }
+    hipLaunchKernelGGL(vbx_hard, dim3(static_cast<int>((T + 255) / 256)), dim3(256), 0, st, w, o.hard.as<int32_t>());
+    FA_HIP_TRY(ctx, hipGetLastError());
+    if (n_iters) *n_iters = iters;
+    return FA_SUCCESS;
+}

@@ -1,6 +1,9 @@
 """The arithmetic of ``OfflineDiarizerManager.cluster`` (reference:
-Sources/FluidAudio/Diarizer/Offline/Core/OfflineDiarizerManager.swift:270-375) on precomputed embeddings, composed from
-the library's device stages — the "embeddings in -> final per-embedding cluster ids out" path of BASELINE config 5:
+Sources/FluidAudio/Diarizer/Offline/Core/OfflineDiarizerManager.swift:270-375) on precomputed embeddings — the "embeddings in
+-> final per-embedding cluster ids out" path of BASELINE config 5.  ``cluster_embeddings`` is ONE call into the library
+(``fa_offline_cluster``, csrc/offline.hip: inputs go up once, the intermediates stay in HBM); ``cluster_embeddings_stagewise``
+is the same composition made of the single-stage entries (every intermediate crosses PCIe), kept because it exposes the
+intermediate results (AHC labels, VBx posteriors) the tests compare with the CPU restatement:
 
     select finite embeddings (:591-611) -> AHC (AHCClustering.cluster, threshold 0.6) -> VBx refine (Fa 0.07, Fb 0.8,
     <= 20 iterations) -> gamma-weighted centroids of the active speakers (:613-691) -> cosine scores (:789-798) ->
@@ -44,6 +47,7 @@ class ClusteringResult:
     vbx: VBxOutput
     training_indices: list = field(default_factory=list)
     timings: dict = field(default_factory=dict)
+    info: dict = field(default_factory=dict)
 
 
 def select_training_embeddings(embedding256) -> list:
@@ -56,6 +60,45 @@ def select_training_embeddings(embedding256) -> list:
 
 def cluster_embeddings(embedding256, rho128, chunk_indices, phi, config: OfflineClusteringConfig | None = None,
                        ctx: L.Context | None = None) -> ClusteringResult:
+    """One device-resident call (fa_offline_cluster).  ``initial_clusters`` / ``vbx`` of the result are not populated (they never
+    leave the device); ``timings`` carries the library's per-stage wall-clock and ``info`` its counters."""
+    import ctypes as C
+    cfg = config or OfflineClusteringConfig()
+    ctx = ctx or L.default_context()
+    emb = np.ascontiguousarray(embedding256, np.float32)
+    if emb.ndim != 2 or emb.shape[0] == 0:
+        raise ValueError("noSpeechDetected")                                 # :281-283
+    n, d = emb.shape
+    rho = np.ascontiguousarray(rho128, np.float64)
+    rd = rho.shape[1] if rho.ndim == 2 and rho.size else 0
+    ph = np.ascontiguousarray(phi, np.float64)
+    if rd and ph.size != rd:
+        ph = np.ones(rd)                                                      # dimension mismatch -> identity (VBxClustering.swift:72-76)
+    chunks = np.ascontiguousarray(chunk_indices, np.int32)
+    c = L.OfflineClusterConfig()
+    L.lib().fa_offline_cluster_default_config(C.byref(c))
+    c.clustering_threshold, c.warm_start_fa, c.warm_start_fb = cfg.clustering_threshold, cfg.warm_start_fa, cfg.warm_start_fb
+    c.max_vbx_iterations, c.convergence_tolerance = cfg.max_vbx_iterations, cfg.convergence_tolerance
+    c.constrained_assignment = int(cfg.constrained_assignment)
+    c.num_speakers = -1 if cfg.num_speakers is None else cfg.num_speakers
+    c.min_speakers = -1 if cfg.min_speakers is None else cfg.min_speakers
+    c.max_speakers = -1 if cfg.max_speakers is None else cfg.max_speakers
+    labels = np.zeros(n, np.int32)
+    cap = 256
+    cen = np.zeros((cap, d), np.float64)
+    k, info = C.c_int32(), L.OfflineClusterInfo()
+    ctx.check(L.lib().fa_offline_cluster(ctx.handle, emb.ctypes.data, n, d, rho.ctypes.data if rd else None, rd, chunks.ctypes.data,
+                                         ph.ctypes.data if rd else None, C.byref(c), 0, labels.ctypes.data, cen.ctypes.data, cap, C.byref(k),
+                                         C.byref(info)), "fa_offline_cluster")
+    t = {"inputs_s": info.inputs_s, "ahc_s": info.ahc_s, "vbx_s": info.vbx_s, "assign_s": info.assign_s, "total_s": info.total_s}
+    res = ClusteringResult([int(v) for v in labels], cen[:k.value].copy(), [], None, [], t)
+    res.info = {f: getattr(info, f) for f, _ in info._fields_ if f != "ahc"}
+    res.info["ahc"] = info.ahc.as_dict()
+    return res
+
+
+def cluster_embeddings_stagewise(embedding256, rho128, chunk_indices, phi, config: OfflineClusteringConfig | None = None,
+                                 ctx: L.Context | None = None) -> ClusteringResult:
     import time
     cfg = config or OfflineClusteringConfig()
     ctx = ctx or L.default_context()
@@ -89,7 +132,8 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, config: Offline
         centroids, _ = compute_centroids(temb, vbx.gamma, vbx.pi, ctx=ctx)  # :613-684
     if centroids.shape[0] == 0:                                              # computeCentroidsFromClusters (:686-) fallback
         labs = np.asarray(initial)
-        centroids = np.stack([temb[labs == k].mean(0) for k in sorted(set(initial))]) if len(initial) else centroids
+        # sequential sums in row order (cblas_daxpy per row, :700-728), then one division: numpy's mean() sums pairwise
+        centroids = np.stack([np.cumsum(temb[labs == k], axis=0)[-1] / float((labs == k).sum()) for k in sorted(set(initial))]) if len(initial) else centroids
     use_constrained = cfg.constrained_assignment and not vbx.was_adjusted and centroids.shape[0] > 1  # :355-358
     if use_constrained:
         scores = centroid_scores(emb, centroids, ctx=ctx)

@@ -271,6 +271,44 @@ fa_status fa_centroid_scores(fa_ctx *ctx, const double *emb, int64_t n, int32_t 
 fa_status fa_constrained_assign(fa_ctx *ctx, const double *scores, int64_t n, int32_t K, const int32_t *chunk_indices,
                                 int32_t *out);
 
+/* ------------------------------------------------------------------ the clustering stage, composed ---- */
+/* OfflineDiarizerManager.cluster (FluidAudio/Diarizer/Offline/Core/OfflineDiarizerManager.swift:270-375) on precomputed
+ * embeddings as ONE call whose intermediates never leave HBM: selectTrainingEmbeddings (:591-611) -> AHCClustering.cluster
+ * (:301-306) -> VBxClustering.refineWithConstraints (:308-333) -> computeCentroids / computeCentroidsFromClusters (:613-740)
+ * -> constrained per-chunk assignment or cosine argmax of every embedding (:345-375, :789-822).  Config defaults =
+ * OfflineDiarizerTypes.swift:155-163,189-192. */
+typedef struct {
+    double clustering_threshold;     /* 0.6 */
+    double warm_start_fa;            /* 0.07 */
+    double warm_start_fb;            /* 0.8 */
+    int32_t max_vbx_iterations;      /* 20 */
+    double convergence_tolerance;    /* 1e-4 */
+    int32_t constrained_assignment;  /* 1 */
+    int64_t num_speakers;            /* -1 = nil */
+    int64_t min_speakers;            /* -1 = nil */
+    int64_t max_speakers;            /* -1 = nil */
+    int32_t ahc_mode;                /* FA_AHC_MODE_AUTO */
+} fa_offline_cluster_config;
+typedef struct {
+    int64_t training_rows;           /* rows that passed selectTrainingEmbeddings */
+    int32_t initial_clusters;        /* distinct AHC labels */
+    int32_t vbx_iterations;
+    int32_t was_adjusted;            /* the K-Means fallback replaced the VBx posteriors (VBxOutput.wasAdjusted) */
+    int32_t constrained;             /* the constrained per-chunk assignment was used */
+    double inputs_s, ahc_s, vbx_s, assign_s, total_s;   /* host wall-clock per stage (copies included) */
+    fa_ahc_stats ahc;
+} fa_offline_cluster_info;
+void fa_offline_cluster_default_config(fa_offline_cluster_config *cfg);
+/* embeddings: float[n*d] (the 256-d speaker embeddings, widened to fp64 on the device like :286); rho: double[n*rho_dim]
+ * PLDA features (rho_dim == 0: no VBx, centroids come from the AHC labels); chunk_indices: HOST int32[n] (needed when
+ * constrained_assignment != 0); phi: HOST double[rho_dim].  embeddings / rho are HOST pointers unless device_pointers != 0.
+ * labels: HOST int32[n] out (-2 = slot dropped by the constrained assignment); centroids: HOST double[max_centroids*d] out or
+ * NULL; *n_centroids out; info may be NULL.  n == 0 -> INVALID_ARGUMENT (the reference throws noSpeechDetected, :281-283). */
+fa_status fa_offline_cluster(fa_ctx *ctx, const float *embeddings, int64_t n, int32_t d, const double *rho, int32_t rho_dim,
+                             const int32_t *chunk_indices, const double *phi, const fa_offline_cluster_config *config,
+                             int32_t device_pointers, int32_t *labels, double *centroids, int32_t max_centroids,
+                             int32_t *n_centroids, fa_offline_cluster_info *info);
+
 /* ------------------------------------------------ speaker-count constraints + K-Means fallback ------ */
 /* KMeansClustering.SeededRNG.next (FluidAudio/Diarizer/Offline/Clustering/KMeansClustering.swift:212-223) and the Swift
  * standard library's RandomNumberGenerator.next(upperBound:) over it (Lemire's method; the draw behind shuffle(using:) and

@@ -67,3 +67,25 @@ def test_cpp_host_runs_the_reference_test_cases(fa):
     r = subprocess.run([build_cpp_host(fa)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FAIL" not in r.stdout and "0 failed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("PASS") >= 50
+
+
+@pytest.mark.gpu
+def test_c_host_runs_the_whole_clustering_stage(fa, oracle_mod, tmp_path):
+    """fa_offline_cluster from a plain C host (no Python between the caller and the library): labels equal the CPU restatement of
+    OfflineDiarizerManager.cluster on the same session."""
+    import struct
+    from test_gpu_pipeline import synth_session
+    emb, rho, chunks, phi, _ = synth_session(250, 5, 7)
+    path = tmp_path / "session.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<qii", emb.shape[0], emb.shape[1], rho.shape[1]))
+        f.write(np.ascontiguousarray(emb, np.float32).tobytes())
+        f.write(np.ascontiguousarray(rho, np.float64).tobytes())
+        f.write(np.ascontiguousarray(chunks, np.int32).tobytes())
+        f.write(np.ascontiguousarray(phi, np.float64).tobytes())
+    r = subprocess.run([build(fa), "cluster", str(path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    ref = oracle_mod.cluster_embeddings(emb, rho, chunks, phi)
+    assert lines[0].startswith("status 0 clusters %d training %d " % (ref["centroids"].shape[0], emb.shape[0])) and lines[0].endswith("constrained 1")
+    assert [int(v) for v in lines[1:]] == ref["assignments"].tolist()

@@ -26,9 +26,13 @@ def synth_session(n_chunks, speakers, seed, d=256, dr=128):
 def test_cluster_stage_matches_cpu_restatement(fa, gpu_ctx, oracle_mod, n_chunks, speakers, seed):
     emb, rho, chunks, phi, spk = synth_session(n_chunks, speakers, seed)
     emb[5] = np.nan                                     # filtered from training (:591-611), still assigned at the end
-    res = fa.cluster_embeddings(emb, rho, chunks, phi, ctx=gpu_ctx)
+    res = fa.cluster_embeddings_stagewise(emb, rho, chunks, phi, ctx=gpu_ctx)
+    one = fa.cluster_embeddings(emb, rho, chunks, phi, ctx=gpu_ctx)       # the single device-resident call (fa_offline_cluster)
+    assert one.assignments == res.assignments and np.array_equal(one.centroids, res.centroids)   # same cores, same bits
+    assert one.info["training_rows"] == len(emb) - 1 and one.info["constrained"] == 1 and one.info["was_adjusted"] == 0
     ref = oracle_mod.cluster_embeddings(emb, rho, chunks, phi)
     assert res.initial_clusters == ref["initial"].tolist()              # AHC labels bit-exact
+    assert one.info["initial_clusters"] == len(set(ref["initial"].tolist()))
     assert res.centroids.shape == ref["centroids"].shape
     np.testing.assert_allclose(res.centroids, ref["centroids"], rtol=0, atol=1e-9)   # VBx gamma differs at 1e-12 (parity unpinned)
     assert res.assignments == ref["assignments"].tolist()
@@ -37,3 +41,28 @@ def test_cluster_stage_matches_cpu_restatement(fa, gpu_ctx, oracle_mod, n_chunks
     keep = np.arange(len(lab)) != 5
     assert len(set(zip(spk[keep].tolist(), lab[keep].tolist()))) == speakers
     assert all(len(set(lab[3 * c:3 * c + 3].tolist())) == 3 for c in range(n_chunks) if 5 // 3 != c)
+
+
+def test_single_call_speaker_count_constraints_and_edge_cases(fa, gpu_ctx, oracle_mod):
+    """fa_offline_cluster with numSpeakers forced (K-Means fallback, constrained assignment skipped, :355-358), without PLDA
+    features (centroids = per-cluster means of the AHC labels), with one row, and with no finite row at all."""
+    emb, rho, chunks, phi, spk = synth_session(200, 5, 3)
+    for kw in (dict(num_speakers=3), dict(min_speakers=7), dict(max_speakers=2)):
+        cfg = fa.OfflineClusteringConfig(**kw)
+        one = fa.cluster_embeddings(emb, rho, chunks, phi, cfg, ctx=gpu_ctx)
+        ref = oracle_mod.cluster_embeddings(emb, rho, chunks, phi, **kw)
+        st = fa.cluster_embeddings_stagewise(emb, rho, chunks, phi, cfg, ctx=gpu_ctx)
+        assert one.info["was_adjusted"] == int(ref["was_adjusted"]) == int(st.vbx.was_adjusted) == 1
+        assert one.assignments == st.assignments == ref["assignments"].tolist()
+        np.testing.assert_array_equal(one.centroids, st.centroids)
+    # no PLDA features: AHC labels -> cluster means -> assignment
+    one = fa.cluster_embeddings(emb, np.zeros((len(emb), 0)), chunks, phi, ctx=gpu_ctx)
+    init = oracle_mod.ahc_cluster(emb.astype(np.float64), 0.6)
+    cen = np.stack([np.cumsum(emb.astype(np.float64)[init == k], axis=0)[-1] / (init == k).sum() for k in sorted(set(init.tolist()))])
+    np.testing.assert_array_equal(one.centroids, cen)
+    assert one.assignments == oracle_mod.constrained_assign(oracle_mod.centroid_scores(emb.astype(np.float64), cen), chunks).tolist()
+    # a single embedding; all rows non-finite (training set falls back to all rows, :606-609)
+    one = fa.cluster_embeddings(emb[:1], rho[:1], chunks[:1], phi, ctx=gpu_ctx)
+    assert one.assignments == [0] and one.centroids.shape == (1, 256)
+    with pytest.raises(ValueError):
+        fa.cluster_embeddings(emb[:0], rho[:0], chunks[:0], phi, ctx=gpu_ctx)
