@@ -29,7 +29,7 @@ AHC_MODE_AUTO, AHC_MODE_EXACT = 0, 1
 
 # Every symbol include/fluidaudio_hip.h + include/FastClusterWrapper.h declare (checked by tests/test_abi.py).
 EXPORTED_SYMBOLS = [
-    "fa_version", "fa_ctx_create", "fa_ctx_destroy", "fa_ctx_synchronize", "fa_ctx_stream", "fa_ctx_last_error",
+    "fa_version", "fa_host_alloc", "fa_host_free", "fa_ctx_create", "fa_ctx_destroy", "fa_ctx_synchronize", "fa_ctx_stream", "fa_ctx_last_error",
     "fa_mel_default_config", "fa_mel_num_frames", "fa_mel_padded_frames", "fa_mel_plan_create", "fa_mel_plan_destroy",
     "fa_mel_plan_utt_stride", "fa_mel_plan_frame_stride", "fa_mel_plan_total_frames", "fa_mel_execute_dev",
     "fa_mel_batch", "fa_mel_hann_window", "fa_mel_filterbank", "fa_mel_normalize_per_feature_dev",
@@ -110,6 +110,10 @@ def lib() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
     L.fa_version.restype = C.c_char_p
+    L.fa_host_alloc.argtypes = [sz]
+    L.fa_host_alloc.restype = vp
+    L.fa_host_free.argtypes = [vp]
+    L.fa_host_free.restype = None
     L.fa_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     L.fa_ctx_destroy.argtypes = [vp]
     L.fa_ctx_destroy.restype = None
@@ -272,6 +276,27 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def pinned_array(shape, dtype):
+    """numpy array over page-locked host memory from fa_host_alloc (freed when the array and its views are gone)."""
+    import numpy as np
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape))
+    p = lib().fa_host_alloc(max(n * dt.itemsize, 1))
+    if not p:
+        raise MemoryError("fa_host_alloc failed")
+
+    class _Owner:
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+        def __del__(self):
+            lib().fa_host_free(self.ptr)
+
+    buf = (C.c_char * max(n * dt.itemsize, 1)).from_address(p)
+    buf._owner = _Owner(p)
+    return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
 
 
 _default_ctx: dict[int, Context] = {}

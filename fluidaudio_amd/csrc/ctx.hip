@@ -56,6 +56,18 @@ fa_status fa_ctx_synchronize(fa_ctx *ctx) {
     return FA_SUCCESS;
 }
 
+// Pinned (page-locked) host memory: buffers allocated here are DMA targets, so the host-pointer entries can move them at the full
+// PCIe rate and overlap uploads with downloads (fa_mel_batch).  Plain malloc'ed buffers keep working (staged copies).
+void *fa_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void fa_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 void *fa_ctx_stream(const fa_ctx *ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
 
 const char *fa_ctx_last_error(const fa_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }

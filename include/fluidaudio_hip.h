@@ -44,6 +44,10 @@ void fa_ctx_destroy(fa_ctx *ctx);
 fa_status fa_ctx_synchronize(fa_ctx *ctx);
 /* The hipStream_t every _dev entry of this context enqueues on (for events / stream-ordered callers). */
 void *fa_ctx_stream(const fa_ctx *ctx);
+/* Page-locked host memory (hipHostMalloc).  Optional: every host-pointer entry accepts ordinary memory; buffers from
+ * fa_host_alloc are moved by DMA at the full PCIe rate and let fa_mel_batch overlap its uploads with its downloads. */
+void *fa_host_alloc(size_t bytes);
+void fa_host_free(void *p);
 /* Last error text recorded on this context ("" if none). */
 const char *fa_ctx_last_error(const fa_ctx *ctx);
 /* Library build identification, e.g. "fluidaudio_hip 0.1 gfx950". */
@@ -120,7 +124,8 @@ fa_status fa_mel_execute_dev(fa_mel_plan *plan, const float *d_pcm, const float 
                              float *d_mel, int32_t *d_mel_lengths);
 
 /* Host-buffer convenience (the shape of a loop of computeFlat calls): copies pcm in, runs
- * the plan, copies mel (+lengths) out, synchronises. */
+ * the plan, copies mel (+lengths) out, synchronises.  When pcm AND mel are page-locked (fa_host_alloc) the batch is
+ * processed in ~64 MB slices whose uploads overlap the downloads of the slices before them (both PCIe directions busy). */
 fa_status fa_mel_batch(fa_ctx *ctx, const fa_mel_config *cfg, const float *pcm, const int64_t *offsets,
                        int32_t batch, const float *last_samples, const int32_t *expected_frames,
                        int32_t frame_stride, float *mel, int32_t *mel_lengths);

@@ -382,3 +382,29 @@ def test_generic_kernel_equals_tuned_kernels(fa, gpu_ctx, oracle_mod, monkeypatc
         if l0:
             close(m1.reshape(128, n1)[:, :l1], m0.reshape(128, n0)[:, :l0], "generic vs tuned")
             close64(oracle_mod, m1.reshape(128, n1)[:, :l1].T, a, "generic kernel", last=0.2)
+
+
+def test_host_pointer_entry_pipelined_slices_equal_one_slice(fa, gpu_ctx, monkeypatch):
+    """fa_mel_batch cuts large batches into slices (upload of slice k+1 overlaps the download of slice k on a helper thread):
+    forced 1 MB slices over a ragged batch give byte-identical output and lengths to the single-slice path."""
+    import ctypes as C
+    L = fa._lib
+    lens = [16000, 40000, 1, 0, 240000, 4801, 100000, 7, 52000, 240000, 3999]
+    audios = [synth_audio(n, 500 + i) for i, n in enumerate(lens)]
+    pcm = np.concatenate(audios)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    lasts = np.linspace(-0.3, 0.3, len(lens)).astype(np.float32)
+    cfg = fa.AudioMelSpectrogram(ctx=gpu_ctx).config()
+    stride = 1501
+    outs = []
+    for mb in ("0", "1"):
+        monkeypatch.setenv("FA_MEL_SLICE_MB", mb)
+        mel = np.full((len(lens), 128, stride), 9.0, np.float32)
+        ln = np.zeros(len(lens), np.int32)
+        gpu_ctx.check(fa.lib().fa_mel_batch(gpu_ctx.handle, C.byref(cfg), pcm.ctypes.data, offs.ctypes.data, len(lens), lasts.ctypes.data, None, stride,
+                                            mel.ctypes.data, ln.ctypes.data), "fa_mel_batch")
+        outs.append((mel, ln))
+    monkeypatch.delenv("FA_MEL_SLICE_MB")
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1].tolist() == [fa.lib().fa_mel_num_frames(C.byref(cfg), n) for n in lens]
