@@ -25,6 +25,29 @@ def linkage(data, mode: int = L.AHC_MODE_AUTO, ctx: L.Context | None = None, ret
     return (st, z, stats.as_dict()) if return_stats else (st, z)
 
 
+def linkage_batch(problems, mode: int = L.AHC_MODE_AUTO, ctx: L.Context | None = None, return_stats: bool = False):
+    """Centroid-linkage dendrograms of several independent problems ([N_k, d] fp64 each, same d) in one call
+    (fa_ahc_linkage_batch: the merge chains advance together).  Returns (statuses list, [Z_k]) (+ stats dicts)."""
+    ctx = ctx or L.default_context()
+    xs = [np.ascontiguousarray(p, np.float64) for p in problems]
+    k = len(xs)
+    if k == 0:
+        return ([], [], []) if return_stats else ([], [])
+    d = xs[0].shape[1]
+    assert all(x.ndim == 2 and x.shape[1] == d for x in xs)
+    zs = [np.zeros((max(x.shape[0] - 1, 0), 4), np.float64) for x in xs]
+    dp = (C.c_void_p * k)(*[x.ctypes.data for x in xs])
+    dummy = np.zeros(4)   # the reference contract rejects a NULL output pointer even when nothing is written (n <= 1)
+    zp = (C.c_void_p * k)(*[z.ctypes.data if z.size else dummy.ctypes.data for z in zs])
+    dp = (C.c_void_p * k)(*[x.ctypes.data if x.size else dummy.ctypes.data for x in xs])
+    ns = (C.c_size_t * k)(*[x.shape[0] for x in xs])
+    st = (C.c_int32 * k)()
+    stats = (L.AhcStats * k)()
+    L.lib().fa_ahc_linkage_batch(ctx.handle, k, dp, ns, d, zp, mode, 0, stats, st)
+    out = ([int(v) for v in st], zs)
+    return out + ([s.as_dict() for s in stats],) if return_stats else out
+
+
 def fastcluster_compute_centroid_linkage(data) -> tuple[int, np.ndarray]:
     """The exact reference symbol (no context argument, library-owned default context)."""
     x = np.ascontiguousarray(data, np.float64)

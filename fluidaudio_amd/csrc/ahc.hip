@@ -583,7 +583,11 @@ struct WaveDec {
     int ps[kPend], pn[kPend];
 };
 
-__global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round index & 3 */) {
+// BATCH: the same round for several independent problems at once (fa_ahc_linkage_batch): workgroup b works on problem
+// blkmap[b].x as its block blkmap[b].y; the problem's workspace descriptor comes from a table in HBM (written before the
+// first launch, constant afterwards: read through the constant address space, i.e. with scalar loads, like a kernel argument).
+template <bool BATCH>
+__global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__restrict__ table, const int2 *__restrict__ blkmap, const int ph /* round index & 3 */) {
     extern __shared__ double s_cvec[];  // [d] merged centroid (EXACT rows)
     __shared__ WaveOut s_out[kWaves];
     __shared__ WaveDec s_dec[kWaves];
@@ -591,11 +595,26 @@ __global__ __launch_bounds__(kBlk) void ahc_round(Ws w, const int ph /* round in
     __shared__ double s_val[kWaves];
     __shared__ int s_idx[kWaves];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x, x = blk * kBlk + tid;
+    int blk_ = blockIdx.x;
+    Ws w_ = w_one;
+    if (BATCH) {
+        static_assert(sizeof(Ws) % 8 == 0, "Ws is copied as 64-bit words");
+        typedef const int __attribute__((address_space(4))) *c_i32;
+        typedef const unsigned long long __attribute__((address_space(4))) *c_u64;
+        const int prob = ((c_i32)reinterpret_cast<const int *>(blkmap))[2 * blockIdx.x];
+        blk_ = ((c_i32)reinterpret_cast<const int *>(blkmap))[2 * blockIdx.x + 1];
+        unsigned long long words[sizeof(Ws) / 8];
+        c_u64 src = (c_u64)reinterpret_cast<const unsigned long long *>(table) + static_cast<size_t>(prob) * (sizeof(Ws) / 8);
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(Ws) / 8; ++i) words[i] = src[i];
+        __builtin_memcpy(&w_, words, sizeof(Ws));
+    }
+    const Ws w = w_;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blk_, x = blk * kBlk + tid;
     const int par = ph & 1, npar = par ^ 1;
     const int Np = w.Np, nblk = w.nblk, d = w.d, N = w.N;
 #ifdef FA_AHC_PROFILE
-    const int prof_blk = gridDim.x / 2;
+    const int prof_blk = nblk / 2;
     unsigned long long t_seg[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = clock64();
 #endif
@@ -993,20 +1012,38 @@ fa_status exact_rebuild(fa_ctx *ctx, const Ws &w, double *gram_norms = nullptr) 
 // d_data: device [N][d]; d_Z: device [(N-1)*4] (heights already square-rooted on return).
 }  // namespace (reopened below: the next function is one of the device-level cores declared in fa_common.h)
 
-fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, int mode, fa_ahc_stats *stats) {
-    const size_t Np = (N + kBlk - 1) / kBlk * kBlk;
-    const size_t nblk = Np / kBlk;
-    if (nblk > kMaxBlocks) return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: N too large for the resident distance matrix");
-    if (d * sizeof(double) > 60 * 1024) return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: dimension too large for the LDS centroid buffer");
-    const Layout L = make_layout(N, Np, d, nblk);
-    if (ctx->ahc_ws_bytes < L.total) {
-        if (ctx->ahc_ws) { FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ahc_ws); ctx->ahc_ws = nullptr; ctx->ahc_ws_bytes = 0; }
-        const hipError_t e = hipMalloc(&ctx->ahc_ws, L.total);
-        if (e != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: cannot allocate %zu bytes of HBM", L.total); }
-        ctx->ahc_ws_bytes = L.total;
-    }
-    char *base = static_cast<char *>(ctx->ahc_ws);
+namespace {
+
+struct Prob {   // one linkage problem: its workspace, its copy of the device state, its outcome
     Ws w{};
+    Layout L{};
+    char *base = nullptr;
+    size_t N = 0, Np = 0, d = 0;
+    const double *d_data = nullptr;
+    double *d_Z = nullptr;
+    int mode = FA_AHC_MODE_AUTO;
+    AhcState h{};
+    long long fallback = 0;
+    fa_status st = FA_SUCCESS;
+    bool active = true;
+};
+
+void window_counter_init(WinCounters (&c)[4]) { for (auto &x : c) { x.stale_key = ~0ULL; x.ncand = 0; x.npairs = 0; } }
+
+fa_status prob_check_shape(fa_ctx *ctx, size_t N, size_t d) {
+    const size_t Np = (N + kBlk - 1) / kBlk * kBlk;
+    if (Np / kBlk > static_cast<size_t>(kMaxBlocks)) return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: N too large for the resident distance matrix");
+    if (d * sizeof(double) > 60 * 1024) return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: dimension too large for the LDS centroid buffer");
+    return FA_SUCCESS;
+}
+
+// binds the workspace at `base`, uploads the initial state and runs the start-up kernels (matrix, row minima, records, eps)
+fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
+    const size_t N = p.N, d = p.d, Np = p.Np;
+    const Layout &L = p.L;
+    p.base = base;
+    Ws &w = p.w;
+    w = Ws{};
     w.state = reinterpret_cast<AhcState *>(base + L.state);
     w.cnt = reinterpret_cast<WinCounters *>(base + L.cnt);
     w.flags = reinterpret_cast<int32_t *>(base + L.flags);
@@ -1024,104 +1061,149 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     w.C = reinterpret_cast<double *>(base + L.c);
     w.XT = reinterpret_cast<double *>(base + L.xt);
     w.M = reinterpret_cast<double *>(base + L.m);
-    w.N = static_cast<int32_t>(N); w.Np = static_cast<int32_t>(Np); w.d = static_cast<int32_t>(d); w.nblk = static_cast<int32_t>(nblk);
-    const size_t lds = sizeof(double) * d;
-
-    hipEvent_t ev[3];
-    for (auto &e : ev) FA_HIP_TRY(ctx, hipEventCreate(&e));
-    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
+    w.N = static_cast<int32_t>(N); w.Np = static_cast<int32_t>(Np); w.d = static_cast<int32_t>(d); w.nblk = static_cast<int32_t>(Np / kBlk);
 
     AhcState init[2]{};
-    init[0].mode = mode == FA_AHC_MODE_EXACT ? FA_AHC_MODE_EXACT : FA_AHC_MODE_AUTO;
+    init[0].mode = p.mode == FA_AHC_MODE_EXACT ? FA_AHC_MODE_EXACT : FA_AHC_MODE_AUTO;
     for (int k = 0; k < kPend; ++k) { init[0].pend_row[k] = -1; init[0].pend_node[k] = -1; }
     init[0].prev_op = OP_NONE;
     init[1] = init[0];
     WinCounters cinit[4];
-    for (auto &c : cinit) { c.stale_key = ~0ULL; c.ncand = 0; c.npairs = 0; }
-    FA_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+    window_counter_init(cinit);
     FA_HIP_TRY(ctx, hipMemcpyAsync(w.state, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
     FA_HIP_TRY(ctx, hipMemcpyAsync(w.cnt, cinit, sizeof(cinit), hipMemcpyHostToDevice, ctx->stream));
     FA_HIP_TRY(ctx, hipMemsetAsync(w.flags, 0, sizeof(int32_t) * 4, ctx->stream));
     FA_HIP_TRY(ctx, hipMemsetAsync(w.prof, 0, sizeof(unsigned long long) * 16, ctx->stream));
-    FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, ctx->stream));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, p.d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(ahc_init_rows, dim3((std::max(Np, 2 * N) + 255) / 256), dim3(256), 0, ctx->stream, w);
-    hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, ctx->stream, d_data, w.XT, w.N, w.Np, w.d);
+    hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, ctx->stream, p.d_data, w.XT, w.N, w.Np, w.d);
     double *d_norms = reinterpret_cast<double *>(base + L.norms);
     FA_TRY(exact_rebuild(ctx, w, init[0].mode == FA_AHC_MODE_AUTO ? d_norms : nullptr));
-    AhcState h{};
     int32_t hflag = 0;
-    FA_HIP_TRY(ctx, hipMemcpyAsync(&h, w.state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(&p.h, w.state, sizeof(p.h), hipMemcpyDeviceToHost, ctx->stream));
     FA_HIP_TRY(ctx, hipMemcpyAsync(&hflag, w.flags, sizeof(hflag), hipMemcpyDeviceToHost, ctx->stream));
-    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // init / cinit are host temporaries; the state feeds eps below
     if (hflag) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
     if (init[0].mode == FA_AHC_MODE_AUTO) {
         double dmax;
-        const long long bits = static_cast<long long>(h.dmax_bits);
+        const long long bits = static_cast<long long>(p.h.dmax_bits);
         memcpy(&dmax, &bits, sizeof(dmax));
         // rounding bound of the Lance-Williams recurrence: <= 8 u dmax per merge level (3 products, 2 sums, 3 rounded
         // weights, the tree-summed d(a,b)), errors of the two parents enter with weights wa + wb = 1, tree depth <= N;
         // factor 2 of margin.
         // Start-up matrix in Gram form: |x|^2 + |y|^2 - 2 x.y carries <= (d + 2) u (|x|^2 + |y|^2 + 2 |x||y|) <= 4 (d + 2) u nmax.
         double nmax;
-        const long long nbits = static_cast<long long>(h.nmax_bits);
+        const long long nbits = static_cast<long long>(p.h.nmax_bits);
         memcpy(&nmax, &nbits, sizeof(nmax));
         const double u = 1.1102230246251565e-16;
         const double eps = 16.0 * static_cast<double>(N) * u * dmax + 8.0 * (static_cast<double>(d) + 2.0) * u * nmax;
         FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state) + offsetof(AhcState, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
         FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state + 1) + offsetof(AhcState, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(ahc_records, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);  // window counts need eps
+        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // eps is a host temporary
     }
-    FA_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
+    return FA_SUCCESS;
+}
 
-    // one graph = kRoundsPerGraph rounds; replayed until the device reports done
+// p.h holds the state after a replay of the round graph: finished, failed, or to be switched to exact rows
+fa_status prob_after_replay(fa_ctx *ctx, Prob &p) {
+    const AhcState &h = p.h;
+    if (h.error == 1) { p.active = false; return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance"); }
+    if (h.error) { p.active = false; return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: internal selection failure (%d)", h.error); }
+    if (h.done) { p.active = false; return FA_SUCCESS; }
+    if (h.halt && h.need_exact) {  // ambiguity window overflow under the Lance-Williams filter: exact rows from here on
+        ++p.fallback;
+        AhcState patch[2];
+        patch[0] = h;
+        patch[0].halt = 0; patch[0].need_exact = 0; patch[0].mode = FA_AHC_MODE_EXACT; patch[0].eps = 0.0;
+        patch[0].prev_op = OP_NONE;
+        for (int k = 0; k < kPend; ++k) { patch[0].pend_row[k] = -1; patch[0].pend_node[k] = -1; }
+        patch[1] = patch[0];
+        WinCounters cinit[4];
+        window_counter_init(cinit);
+        FA_HIP_TRY(ctx, hipMemcpyAsync(p.w.state, patch, sizeof(patch), hipMemcpyHostToDevice, ctx->stream));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(p.w.cnt, cinit, sizeof(cinit), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(ahc_gather_xt, dim3((p.Np + 255) / 256), dim3(256), 0, ctx->stream, p.w);
+        FA_TRY(exact_rebuild(ctx, p.w));
+        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // patch / cinit are host temporaries
+    } else if (h.halt) { p.active = false; return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: halted without a reason"); }
+    return FA_SUCCESS;
+}
+
+fa_status prob_finish(fa_ctx *ctx, Prob &p) {   // heights from the stored centroids, dendrogram to the caller's device buffer
+    if (p.st != FA_SUCCESS) return p.st;
+    if (!p.h.done) return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: round budget exhausted at step %d", p.h.step);
+    int32_t hflag = 0;
+    hipLaunchKernelGGL(ahc_heights, dim3((p.N + 255) / 256), dim3(256), 0, ctx->stream, p.w);
+    FA_HIP_TRY(ctx, hipMemcpyAsync(p.d_Z, p.w.Z, sizeof(double) * 4 * (p.N - 1), hipMemcpyDeviceToDevice, ctx->stream));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(&hflag, p.w.flags, sizeof(hflag), hipMemcpyDeviceToHost, ctx->stream));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (hflag) return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
+    return FA_SUCCESS;
+}
+
+fa_status ensure_ahc_workspace(fa_ctx *ctx, size_t bytes) {
+    if (ctx->ahc_ws_bytes >= bytes) return FA_SUCCESS;
+    if (ctx->ahc_ws) { FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ahc_ws); ctx->ahc_ws = nullptr; ctx->ahc_ws_bytes = 0; }
+    const hipError_t e = hipMalloc(&ctx->ahc_ws, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: cannot allocate %zu bytes of HBM", bytes); }
+    ctx->ahc_ws_bytes = bytes;
+    return FA_SUCCESS;
+}
+
+struct RoundGraph {   // kRoundsPerGraph rounds captured once, replayed until every problem reports done
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    bool use_graph = true;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        for (int i = 0; i < kRoundsPerGraph; ++i)
-            hipLaunchKernelGGL(ahc_round, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, w, i & 3);
-        if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || !graph) use_graph = false;
-        else if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) use_graph = false;
-    } else use_graph = false;
-    (void)hipGetLastError();
-    struct GraphGuard { hipGraph_t &g; hipGraphExec_t &e; ~GraphGuard() { if (e) (void)hipGraphExecDestroy(e); if (g) (void)hipGraphDestroy(g); } } gg{graph, exec};
-
-    long long fallback = 0;
-    const long long max_batches = 64 + 8 * static_cast<long long>(N) / kRoundsPerGraph;  // bound on rounds (merges + rescans + windows)
-    fa_status st = FA_SUCCESS;
-    for (long long it = 0; it < max_batches; ++it) {
-        if (use_graph) FA_HIP_TRY(ctx, hipGraphLaunch(exec, ctx->stream));
-        else
-            for (int i = 0; i < kRoundsPerGraph; ++i)
-                hipLaunchKernelGGL(ahc_round, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, w, i & 3);
-        FA_HIP_TRY(ctx, hipMemcpyAsync(&h, w.state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (h.error == 1) { st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance"); break; }
-        if (h.error) { st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: internal selection failure (%d)", h.error); break; }
-        if (h.done) break;
-        if (h.halt && h.need_exact) {  // ambiguity window overflow under the Lance-Williams filter: exact rows from here on
-            ++fallback;
-            AhcState patch[2];
-            patch[0] = h;
-            patch[0].halt = 0; patch[0].need_exact = 0; patch[0].mode = FA_AHC_MODE_EXACT; patch[0].eps = 0.0;
-            patch[0].prev_op = OP_NONE;
-            for (int k = 0; k < kPend; ++k) { patch[0].pend_row[k] = -1; patch[0].pend_node[k] = -1; }
-            patch[1] = patch[0];
-            FA_HIP_TRY(ctx, hipMemcpyAsync(w.state, patch, sizeof(patch), hipMemcpyHostToDevice, ctx->stream));
-            FA_HIP_TRY(ctx, hipMemcpyAsync(w.cnt, cinit, sizeof(cinit), hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(ahc_gather_xt, dim3((Np + 255) / 256), dim3(256), 0, ctx->stream, w);
-            FA_TRY(exact_rebuild(ctx, w));
-        } else if (h.halt) { st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: halted without a reason"); break; }
+    bool ok = false;
+    ~RoundGraph() { if (exec) (void)hipGraphExecDestroy(exec); if (graph) (void)hipGraphDestroy(graph); }
+    template <class Launch> void capture(fa_ctx *ctx, Launch &&launch) {
+        ok = true;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            for (int i = 0; i < kRoundsPerGraph; ++i) launch(i & 3);
+            if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || !graph) ok = false;
+            else if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) ok = false;
+        } else ok = false;
+        (void)hipGetLastError();
     }
-    if (st == FA_SUCCESS && !h.done) st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: round budget exhausted at step %d", h.step);
-    if (st != FA_SUCCESS) return st;
-    hipLaunchKernelGGL(ahc_heights, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, w);
-    FA_HIP_TRY(ctx, hipMemcpyAsync(d_Z, w.Z, sizeof(double) * 4 * (N - 1), hipMemcpyDeviceToDevice, ctx->stream));
-    FA_HIP_TRY(ctx, hipMemcpyAsync(&hflag, w.flags, sizeof(hflag), hipMemcpyDeviceToHost, ctx->stream));
+    template <class Launch> fa_status replay(fa_ctx *ctx, Launch &&launch) {
+        if (ok) FA_HIP_TRY(ctx, hipGraphLaunch(exec, ctx->stream));
+        else for (int i = 0; i < kRoundsPerGraph; ++i) launch(i & 3);
+        return FA_SUCCESS;
+    }
+};
+
+}  // namespace
+
+fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, int mode, fa_ahc_stats *stats) {
+    FA_TRY(prob_check_shape(ctx, N, d));
+    Prob p;
+    p.N = N; p.d = d; p.Np = (N + kBlk - 1) / kBlk * kBlk; p.d_data = d_data; p.d_Z = d_Z; p.mode = mode;
+    p.L = make_layout(N, p.Np, d, p.Np / kBlk);
+    FA_TRY(ensure_ahc_workspace(ctx, p.L.total));
+    const size_t lds = sizeof(double) * d;
+
+    hipEvent_t ev[3];
+    for (auto &e : ev) FA_HIP_TRY(ctx, hipEventCreate(&e));
+    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
+    FA_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+    FA_TRY(prob_setup(ctx, p, static_cast<char *>(ctx->ahc_ws)));
+    FA_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
+
+    const Ws w = p.w;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    auto launch = [&](const int ph) { hipLaunchKernelGGL(ahc_round_t<false>, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr), ph); };
+    RoundGraph rg;
+    rg.capture(ctx, launch);
+    const long long max_batches = 64 + 8 * static_cast<long long>(N) / kRoundsPerGraph;  // bound on rounds (merges + rescans + windows)
+    for (long long it = 0; it < max_batches && p.active; ++it) {
+        FA_TRY(rg.replay(ctx, launch));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(&p.h, w.state, sizeof(p.h), hipMemcpyDeviceToHost, ctx->stream));
+        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        FA_TRY(prob_after_replay(ctx, p));
+    }
+    FA_TRY(prob_finish(ctx, p));
     FA_HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
     FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (hflag) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
 #ifdef FA_AHC_PROFILE
     {
         unsigned long long hp[16];
@@ -1135,11 +1217,108 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
         float t01 = 0, t12 = 0;
         (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
         (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
-        stats->merges = h.step; stats->rounds = h.rounds; stats->rescans = h.rescans; stats->exact_fallback = fallback;
-        stats->windows = h.windows;
+        stats->merges = p.h.step; stats->rounds = p.h.rounds; stats->rescans = p.h.rescans; stats->exact_fallback = p.fallback;
+        stats->windows = p.h.windows;
         stats->init_ms = t01; stats->merge_ms = t12; stats->total_ms = t01 + t12;
     }
     return FA_SUCCESS;
+}
+
+// Several independent problems (recordings) advanced by the SAME round launches: one launch = one round of every unfinished
+// problem (grid = sum of their blocks), so K serial merge chains share the machine instead of queueing behind each other —
+// a chain alone keeps ~N/256 of the 256 CUs busy at one wavefront per SIMD.  Start-up and finish run per problem.
+fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
+                                   fa_ahc_stats *stats, fa_status *statuses) {
+    std::vector<Prob> probs(static_cast<size_t>(count));
+    size_t total = 0, total_blocks = 0;
+    std::vector<size_t> at(count, 0);
+    for (int k = 0; k < count; ++k) {
+        Prob &p = probs[k];
+        p.N = n[k]; p.d = d; p.Np = (n[k] + kBlk - 1) / kBlk * kBlk; p.d_data = d_data[k]; p.d_Z = d_Z[k]; p.mode = mode;
+        if (statuses) statuses[k] = FA_SUCCESS;
+        p.st = prob_check_shape(ctx, p.N, d);
+        if (p.st != FA_SUCCESS || p.N < 2) { p.active = false; continue; }
+        p.L = make_layout(p.N, p.Np, d, p.Np / kBlk);
+        at[k] = total;
+        total += (p.L.total + 4095) & ~static_cast<size_t>(4095);
+        total_blocks += p.Np / kBlk;
+    }
+    const size_t o_table = total;
+    total += (sizeof(Ws) * count + 255) & ~static_cast<size_t>(255);
+    const size_t o_map = total;
+    total += (sizeof(int2) * std::max<size_t>(total_blocks, 1) + 255) & ~static_cast<size_t>(255);
+    FA_TRY(ensure_ahc_workspace(ctx, total));
+    char *base = static_cast<char *>(ctx->ahc_ws);
+    hipEvent_t ev[3];
+    for (auto &e : ev) FA_HIP_TRY(ctx, hipEventCreate(&e));
+    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
+    FA_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+    for (int k = 0; k < count; ++k) {
+        Prob &p = probs[k];
+        if (!p.active) continue;
+        const fa_status st = prob_setup(ctx, p, base + at[k]);
+        if (st != FA_SUCCESS) { p.st = st; p.active = false; }
+    }
+    FA_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
+    // table of workspaces + block map of the problems still running (rebuilt only when the set changes a lot: finished problems'
+    // workgroups return after one state load, so a stale map is merely idle workgroups)
+    std::vector<Ws> table(count);
+    for (int k = 0; k < count; ++k) table[k] = probs[k].w;
+    const Ws *d_table = reinterpret_cast<const Ws *>(base + o_table);
+    int2 *d_map = reinterpret_cast<int2 *>(base + o_map);
+    FA_HIP_TRY(ctx, hipMemcpyAsync(const_cast<Ws *>(d_table), table.data(), sizeof(Ws) * count, hipMemcpyHostToDevice, ctx->stream));
+    const size_t lds = sizeof(double) * d;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    long long max_batches = 64;
+    for (const Prob &p : probs) if (p.active) max_batches = std::max<long long>(max_batches, 64 + 8 * static_cast<long long>(p.N) / kRoundsPerGraph);
+    std::vector<int2> map;
+    int mapped_active = -1;
+    RoundGraph *rg = nullptr;
+    struct RgGuard { RoundGraph *&p; ~RgGuard() { delete p; } } rgg{rg};
+    int grid = 0;
+    auto launch = [&](const int ph) { hipLaunchKernelGGL(ahc_round_t<true>, dim3(grid), dim3(kBlk), lds, ctx->stream, Ws{}, d_table, static_cast<const int2 *>(d_map), ph); };
+    for (long long it = 0; it < max_batches; ++it) {
+        int n_active = 0;
+        for (const Prob &p : probs) n_active += p.active ? 1 : 0;
+        if (n_active == 0) break;
+        if (mapped_active < 0 || n_active * 2 <= mapped_active) {   // (re)build the map and the graph over the running problems
+            map.clear();
+            for (int k = 0; k < count; ++k)
+                if (probs[k].active) for (int b = 0; b < probs[k].w.nblk; ++b) map.push_back(make_int2(k, b));
+            grid = static_cast<int>(map.size());
+            FA_HIP_TRY(ctx, hipMemcpyAsync(d_map, map.data(), sizeof(int2) * map.size(), hipMemcpyHostToDevice, ctx->stream));
+            FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            delete rg;
+            rg = new RoundGraph();
+            rg->capture(ctx, launch);
+            mapped_active = n_active;
+        }
+        FA_TRY(rg->replay(ctx, launch));
+        for (Prob &p : probs) if (p.active) FA_HIP_TRY(ctx, hipMemcpyAsync(&p.h, p.w.state, sizeof(p.h), hipMemcpyDeviceToHost, ctx->stream));
+        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (Prob &p : probs) if (p.active) (void)prob_after_replay(ctx, p);
+    }
+    fa_status worst = FA_SUCCESS;
+    for (int k = 0; k < count; ++k) {
+        Prob &p = probs[k];
+        if (p.N >= 2 && p.st == FA_SUCCESS) (void)prob_finish(ctx, p);
+        if (statuses) statuses[k] = p.st;
+        if (p.st != FA_SUCCESS && worst == FA_SUCCESS) worst = p.st;
+    }
+    FA_HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        float t01 = 0, t12 = 0;
+        (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+        for (int k = 0; k < count; ++k) {
+            const Prob &p = probs[k];
+            stats[k] = fa_ahc_stats{};
+            stats[k].merges = p.h.step; stats[k].rounds = p.h.rounds; stats[k].rescans = p.h.rescans; stats[k].exact_fallback = p.fallback;
+            stats[k].windows = p.h.windows; stats[k].init_ms = t01; stats[k].merge_ms = t12; stats[k].total_ms = t01 + t12;   // times of the whole batch
+        }
+    }
+    return worst;
 }
 
 namespace {
@@ -1208,6 +1387,56 @@ fa_status fa_ahc_linkage(fa_ctx *ctx, const double *data, size_t n, size_t d, do
         FA_HIP_TRY(ctx, hipMemcpyAsync(dendrogram, d_z.p, sizeof(double) * 4 * (n - 1), hipMemcpyDeviceToHost, ctx->stream));
         FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return FA_SUCCESS;
+    } catch (const std::bad_alloc &) {
+        return FA_ALLOCATION_FAILURE;
+    } catch (const std::exception &) {
+        return FA_RUNTIME_ERROR;
+    } catch (...) {
+        return FA_UNKNOWN_ERROR;
+    }
+}
+
+// `count` independent linkage problems (recordings) of dimension d in one call: their serial merge chains advance together
+// (one launch = one round of every unfinished problem).  data[k]: n[k] x d row-major, dendrograms[k]: (n[k] - 1) x 4 — HOST
+// pointers unless device_pointers != 0 (the two pointer ARRAYS are always host arrays).  statuses[k] (nullable) carries the
+// per-problem status of the reference contract (n == 0 or 1 -> SUCCESS, nothing written); the return value is the first failure.
+fa_status fa_ahc_linkage_batch(fa_ctx *ctx, int32_t count, const double *const *data, const size_t *n, size_t d, double *const *dendrograms,
+                               int32_t mode, int32_t device_pointers, fa_ahc_stats *stats, int32_t *statuses) {
+    if (!ctx || count < 0 || (count > 0 && (!data || !n || !dendrograms))) return FA_INVALID_ARGUMENT;
+    if (count == 0) return FA_SUCCESS;
+    try {
+        fa::DeviceGuard guard(ctx->device);
+        std::vector<fa_status> st(count, FA_SUCCESS);
+        std::vector<const double *> d_in(count, nullptr);
+        std::vector<double *> d_z(count, nullptr);
+        std::vector<size_t> nn(count, 0);
+        std::vector<fa::DevBuf> bufs(static_cast<size_t>(2) * count);
+        for (int k = 0; k < count; ++k) {
+            bool trivial;
+            st[k] = linkage_checks(data[k], n[k], d, dendrograms[k], n[k] > 1 ? (n[k] - 1) * 4 : 0, &trivial);
+            if (st[k] != FA_SUCCESS || trivial) continue;
+            nn[k] = n[k];
+            if (device_pointers) { d_in[k] = data[k]; d_z[k] = dendrograms[k]; continue; }
+            if (bufs[2 * k].alloc(sizeof(double) * n[k] * d) != hipSuccess || bufs[2 * k + 1].alloc(sizeof(double) * 4 * (n[k] - 1)) != hipSuccess) {
+                (void)hipGetLastError();
+                st[k] = FA_ALLOCATION_FAILURE; nn[k] = 0;
+                continue;
+            }
+            FA_HIP_TRY(ctx, hipMemcpyAsync(bufs[2 * k].p, data[k], sizeof(double) * n[k] * d, hipMemcpyHostToDevice, ctx->stream));
+            d_in[k] = bufs[2 * k].as<double>(); d_z[k] = bufs[2 * k + 1].as<double>();
+        }
+        std::vector<fa_status> run(count, FA_SUCCESS);
+        (void)fa::ahc_run_device_batch(ctx, count, d_in.data(), nn.data(), d, d_z.data(), mode, stats, run.data());
+        fa_status first = FA_SUCCESS;
+        for (int k = 0; k < count; ++k) {
+            if (st[k] == FA_SUCCESS && nn[k] >= 2) st[k] = run[k];
+            if (st[k] == FA_SUCCESS && nn[k] >= 2 && !device_pointers)
+                FA_HIP_TRY(ctx, hipMemcpyAsync(dendrograms[k], d_z[k], sizeof(double) * 4 * (nn[k] - 1), hipMemcpyDeviceToHost, ctx->stream));
+            if (statuses) statuses[k] = st[k];
+            if (st[k] != FA_SUCCESS && first == FA_SUCCESS) first = st[k];
+        }
+        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return first;
     } catch (const std::bad_alloc &) {
         return FA_ALLOCATION_FAILURE;
     } catch (const std::exception &) {

@@ -70,6 +70,9 @@ fa_status ensure_scratch(fa_ctx *ctx, size_t bytes);
 // All pointers prefixed d_ are DEVICE pointers; everything is enqueued on ctx->stream; results stay on the device.
 fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, int mode, fa_ahc_stats *stats);   // ahc.hip
 fa_status ahc_normalize_dev(fa_ctx *ctx, const double *d_x, double *d_out, int64_t n, int32_t d);                              // ahc.hip (:70-105)
+// count independent problems advanced by the same round launches; d_data / d_Z: HOST arrays of device pointers; statuses, stats: per problem (nullable)
+fa_status ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
+                               fa_ahc_stats *stats, fa_status *statuses);
 
 struct VbxDevice {   // buffers of one VBx run; gamma [T][S], pi [S] and hard [T] stay on the device for the stages behind it
     DevBuf phi, rho, G, gamma, pi, logpi, part, alpha, invL, phiT, ll, scal, hard;

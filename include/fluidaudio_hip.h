@@ -235,6 +235,16 @@ enum { FA_AHC_MODE_AUTO = 0,   /* Lance-Williams filter + exact re-verification,
 fa_status fa_ahc_linkage(fa_ctx *ctx, const double *data, size_t n, size_t d, double *dendrogram,
                          size_t dendrogram_len, int32_t mode, int32_t device_pointers, fa_ahc_stats *stats);
 
+/* `count` independent problems (one per recording) of dimension d in ONE call: the serial merge chains advance together —
+ * one launch is one round of every unfinished problem — so many medium-sized recordings fill the machine that a single chain
+ * leaves idle.  data / dendrograms: HOST arrays of `count` pointers (to host buffers, or to device buffers when
+ * device_pointers != 0); n: HOST array of row counts; statuses (nullable): per-problem status with the contract of the
+ * reference symbol; stats (nullable): `count` entries (init_ms / merge_ms are those of the whole batch).  Returns the
+ * first per-problem failure.  Every dendrogram equals the one fa_ahc_linkage produces for that problem alone. */
+fa_status fa_ahc_linkage_batch(fa_ctx *ctx, int32_t count, const double *const *data, const size_t *n, size_t d,
+                               double *const *dendrograms, int32_t mode, int32_t device_pointers, fa_ahc_stats *stats,
+                               int32_t *statuses);
+
 /* AHCClustering.cluster (FluidAudio/Diarizer/Offline/Clustering/AHCClustering.swift:20-67): L2-normalise
  * (:70-105), linkage, threshold clamp (:112-121), top-down cut (:124-197), relabel (:200-210).
  * x: HOST double[n*d]; labels: HOST int32[n].  On linkage failure labels = 0..n-1 (:52-55) and

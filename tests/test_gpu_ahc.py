@@ -209,3 +209,27 @@ def test_full_size_dendrogram_digest_vs_reference(fa, gpu_ctx, path, mode):
 def test_full_size_digests_are_committed():
     names = {os.path.basename(p) for p in FULL}
     assert {"ahc_full_iid_50000.json", "ahc_full_mix_50000.json"} <= names, "the 50 000 x 256 reference digests are missing"
+
+
+def test_batched_problems_equal_single_problem_runs(fa, gpu_ctx, oracle_mod):
+    """fa_ahc_linkage_batch: K independent recordings advanced by the same round launches give, per recording, the dendrogram
+    of the reference build bit for bit (ragged sizes, both distributions, a 1-row, a 2-row and an empty problem, a NaN problem
+    that must fail alone)."""
+    rng = np.random.default_rng(3)
+    probs = [speaker_mixture(700, 64, 9, 0.04, 1), oracle_mod.ahc_normalize(rng.standard_normal((1300, 64))), speaker_mixture(257, 64, 5, 0.05, 2),
+             np.ones((1, 64)), np.eye(2, 64), np.zeros((0, 64)), speaker_mixture(2100, 64, 20, 0.03, 4), speaker_mixture(300, 64, 4, 0.05, 6)]
+    bad = speaker_mixture(300, 64, 4, 0.05, 5).copy()
+    bad[17, 3] = np.nan
+    probs.append(bad)
+    for mode in (0, 1):
+        st, zs, stats = fa.linkage_batch(probs, mode=mode, ctx=gpu_ctx, return_stats=True)
+        assert st[:-1] == [0] * (len(probs) - 1) and st[-1] == 5           # NaN -> RUNTIME_ERROR for that problem only
+        for x, z in zip(probs[:-1], zs[:-1]):
+            if x.shape[0] >= 2:
+                sr, zr = oracle_mod.linkage_ref(x)
+                assert sr == 0
+                np.testing.assert_array_equal(z, zr)
+        assert stats[0]["merges"] == 699 and stats[6]["merges"] == 2099
+    # and equal to the single-problem entry (same kernels, same order)
+    st1, z1 = fa.linkage(probs[6], ctx=gpu_ctx)
+    assert st1 == 0 and np.array_equal(z1, zs[6])
