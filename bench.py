@@ -9,12 +9,19 @@ A "step" = one pass of the batched STFT->mel featurizer over BASELINE.json confi
 `value` = audio hours featurized per second over all ranks (weak scaling: every rank owns its own 1024 chunks,
 no data-path collective).  Rank 0 prints ONE JSON line which also carries
   roofline      — the mel kernel's measured HBM fraction (algorithmic bytes / HIP-event kernel time / 8 TB/s)
-  cpu_baseline  — the CPU oracle (a restatement of the Swift/Accelerate path, NOT Apple's vDSP) timed on this box
-  ahc_50k       — wall-clock of centroid-linkage AHC on 50 000 x 256 embeddings (the metric's second half; rank 0)
-  ctc           — greedy CTC decode rate on [T=1500, V=1024] matrices (BASELINE configs[3]; rank 0)
-  e2e_8h        — BASELINE configs[4] on one GPU: 8 h audio -> mel -> precomputed embeddings -> AHC + VBx + assignment (rank 0)
+  cpu_baseline  — the CPU oracle (a restatement of the Swift/Accelerate path, NOT Apple's vDSP) timed on this box: mel on 1 and
+                  8 threads (value = 1 thread), CTC greedy and VBx restatements beside it
+  ctc           — greedy CTC decode on [T=1500, V=1024] matrices (BASELINE configs[3]); at N > 1 the 10 000 matrices are SHARDED
+                  over the ranks (strong scaling) and the token ids are gathered on rank 0 over RCCL
+  ahc_50k       — centroid-linkage AHC on 50 000 x 256 embeddings (the metric's second half; rank 0): the numpy-seeded input whose
+                  reference dendrogram digest is committed (tests/golden/ahc_full_iid_50000.json), bit_exact_vs_reference_digest
+  ahc_batch     — 16 recordings x 5400 x 256 through fa_ahc_linkage_batch vs sequential calls (rank 0)
+  e2e_8h        — BASELINE configs[4]: 8 h audio -> mel -> precomputed embeddings -> AHC + VBx + assignment (fa_offline_cluster);
+                  one 8 h recording per rank (replicas: the merge chain of one recording does not shard), labels gathered on rank 0
+  featurized_plus_clustered_audio_hours_per_s — the metric's first half on the e2e leg (all ranks)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,6 +37,7 @@ CHUNKS_PER_GPU = 1024
 MEL_BYTES_PER_CHUNK = 240000 * 4 + 128 * 1501 * 4   # 1 728 512 B
 CTC_BYTES_PER_MATRIX = 1500 * 1024 * 4               # 6 144 000 B
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
+MEL_KERNEL_SOURCES = ("mel.hip", "mel_v4.inc", "mel_pk.h", "mel_core.h")
 
 
 def synth_pcm(torch, n_chunks, seed):
@@ -43,47 +51,92 @@ def synth_pcm(torch, n_chunks, seed):
     return x
 
 
+def mel_kernel_sources_sha256():
+    h = hashlib.sha256()
+    for f in MEL_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "fluidaudio_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def measured_traffic():
     """HBM bytes per launch of the mel kernel from the committed rocprofv3 PMC passes (profiles/*_mel_pmc.json, written by
-    scripts/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction of MI355X_MICROARCH.md); None if absent.
-    PMC collection needs its own rocprofv3 runs, so bench.py reports the value measured for the committed kernel."""
+    scripts/pmc_summary.py + scripts/gpu_mel_pmc.sh: 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction of
+    MI355X_MICROARCH.md).  PMC collection needs its own rocprofv3 runs, so the figure is read from the newest summary —
+    and REFUSED (None) when the kernel sources have changed since it was measured (kernel_sources_sha256 in the summary)."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mel_pmc.json"))):
+    now = mel_kernel_sources_sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mel_pmc.json")), reverse=True):
         try:
             with open(f) as fh:
-                best = json.load(fh).get("hbm_traffic_bytes_per_launch", best)
+                j = json.load(fh)
         except Exception:  # noqa: BLE001
-            pass
-    return best
+            continue
+        if j.get("kernel_sources_sha256") == now and j.get("hbm_traffic_bytes_per_launch"):
+            return j["hbm_traffic_bytes_per_launch"], {"file": os.path.relpath(f, ROOT), "kernel_sources_sha256": now}
+    return None, {"file": None, "note": "no PMC summary for the present kernel sources (sha256 %s...)" % now[:12]}
 
 
-def cpu_mel_baseline(budget_s=12.0):
-    """Time the CPU oracle (1 thread) on a bounded sample of the same workload."""
+def _timed_pool(fn, items, threads):
+    from concurrent.futures import ThreadPoolExecutor
+    t0 = time.perf_counter()
+    if threads == 1:
+        for it in items:
+            fn(it)
+    else:
+        with ThreadPoolExecutor(threads) as ex:   # the oracle calls are ctypes calls: the GIL is released inside them
+            list(ex.map(fn, items))
+    return time.perf_counter() - t0
+
+
+def cpu_baselines(budget_s=8.0):
+    """CPU restatements (oracle/, `kind: port`: Swift/Accelerate cannot run on this box) on bounded samples of the same
+    workloads, 1 thread and 8 threads.  The top-level value is the 1-thread mel rate."""
     import oracle
     rng = np.random.default_rng(1234)
     t = np.arange(CHUNK_SAMPLES) / 16000.0
     chunk = (rng.uniform(-1, 1, CHUNK_SAMPLES) * 0.1 + 0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3000 * t)).astype(np.float32)
     oracle.mel_flat(chunk[:16000])
-    n, t0 = 0, time.perf_counter()
-    while True:
-        oracle.mel_flat(chunk)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 256:
-            break
-    return {"value": n * 15.0 / 3600.0 / el, "unit": "audio_hours/s", "cores": 1, "kind": "port",
-            "sample": f"{n} x 15 s chunks, oracle/fa_oracle.c computeFlat restatement (fp32 radix-2 FFT + dense 128x257 filterbank), "
-                      f"{el:.1f} s on 1 of {os.cpu_count()} host cores; Swift/Accelerate itself cannot run on this box"}
+    t1 = _timed_pool(lambda _: oracle.mel_flat(chunk), range(1), 1)
+    n1 = max(2, min(256, int(budget_s / max(t1, 1e-3))))
+    e1 = _timed_pool(lambda _: oracle.mel_flat(chunk), range(n1), 1)
+    n8 = 8 * max(1, n1 // 2)
+    e8 = _timed_pool(lambda _: oracle.mel_flat(chunk), range(n8), 8)
+    out = {"value": n1 * 15.0 / 3600.0 / e1, "unit": "audio_hours/s", "cores": 1, "kind": "port",
+           "sample": f"{n1} x 15 s chunks, oracle/fa_oracle.c computeFlat restatement (fp32 radix-2 FFT + dense 128x257 filterbank), "
+                     f"{e1:.1f} s on 1 of {os.cpu_count()} host cores; Swift/Accelerate itself cannot run on this box",
+           "mel_8_threads": {"value": n8 * 15.0 / 3600.0 / e8, "unit": "audio_hours/s", "cores": 8, "sample": f"{n8} chunks in {e8:.1f} s"}}
+    # CTC greedy (LogitsArgmax.swift:16-55 + CtcDecoder.swift:45-70 restated): [1500, 1024] fp32 matrices
+    lg = rng.standard_normal((8, 1500, 1024)).astype(np.float32)
+    lg[:, :, 1023] += 2.0
+    oracle.ctc_greedy(lg[0], 1023)
+    reps = 6
+    c1 = _timed_pool(lambda i: oracle.ctc_greedy(lg[i % 8], 1023), range(8 * reps), 1)
+    c8 = _timed_pool(lambda i: oracle.ctc_greedy(lg[i % 8], 1023), range(8 * reps * 4), 8)
+    out["ctc_greedy"] = {"unit": "matrices/s", "threads_1": 8 * reps / c1, "threads_8": 8 * reps * 4 / c8, "kind": "port",
+                         "sample": f"{8 * reps} / {8 * reps * 4} matrices [1500,1024] fp32, oracle argmax + collapse"}
+    # VBx (VBxClustering.swift:167-664 restated): N = 6000 frames x 128, 12 initial clusters, <= 20 iterations
+    n, spk = 6000, 12
+    lab = (np.arange(n) % spk).astype(np.int32)
+    phi = np.linspace(2.0, 1.0, 128)
+    rho = (rng.standard_normal((spk, 128)) * np.sqrt(phi))[lab] + rng.standard_normal((n, 128))
+    v1 = _timed_pool(lambda _: oracle.vbx_refine(rho, lab, phi), range(2), 1)
+    v8 = _timed_pool(lambda _: oracle.vbx_refine(rho, lab, phi), range(16), 8)
+    out["vbx"] = {"unit": "refinements/s (6000 x 128, 12 clusters)", "threads_1": 2 / v1, "threads_8": 16 / v8, "kind": "port",
+                  "sample": "oracle VBx restatement (scalar C, no BLAS); 8 threads = 8 independent recordings"}
+    return out
 
 
 def ahc_leg(fa, ctx, torch, n=50000, d=256, ref_n=3000):
     import ctypes as C
     import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from ahc_full_inputs import ahc_input, dendrogram_digest, sha256
     out = {}
-    g = torch.Generator(device="cuda").manual_seed(0)
-    x = torch.randn((n, d), generator=g, device="cuda", dtype=torch.float64)
-    x /= x.norm(dim=1, keepdim=True)
+    gold_path = os.path.join(ROOT, "tests", "golden", f"ahc_full_iid_{n}.json")
+    gold = json.load(open(gold_path)) if os.path.exists(gold_path) else None
+    xh = ahc_input("iid", n, d)                      # numpy PCG64 seed 0, bytes reproducible on any box
+    x = torch.from_numpy(xh).cuda()
     z = torch.zeros((n - 1, 4), dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     for rep in range(2):  # first call allocates the 20 GB workspace; second is the steady-state number
@@ -97,85 +150,137 @@ def ahc_leg(fa, ctx, torch, n=50000, d=256, ref_n=3000):
             return {"status": int(st), "error": ctx.last_error()}
     s = stats.as_dict()
     zz = z.cpu().numpy()
-    out.update({"n": n, "d": d, "distribution": "iid N(0,1) rows, L2-normalised, seed 0", "inputs": "resident in HBM",
-                "device_init_ms": s["init_ms"], "device_merge_ms": s["merge_ms"], "rounds": s["rounds"], "rescans": s["rescans"],
-                "exact_fallback": s["exact_fallback"], "height_inversions": int((np.diff(zz[:, 2]) < 0).sum()),
-                "us_per_round": 1e3 * s["merge_ms"] / max(1, s["rounds"])})
+    dig = dendrogram_digest(zz)
+    out.update({"n": n, "d": d, "distribution": "iid N(0,1) rows, L2-normalised, numpy default_rng(0) (tests/golden/ahc_full_inputs.py)", "inputs": "resident in HBM",
+                "device_init_ms": s["init_ms"], "device_merge_ms": s["merge_ms"], "rounds": s["rounds"], "rescans": s["rescans"], "windows": s["windows"],
+                "exact_fallback": s["exact_fallback"], "height_inversions": dig["height_inversions"],
+                "us_per_round": 1e3 * s["merge_ms"] / max(1, s["rounds"]),
+                "dendrogram_sha256": dig["dendrogram_sha256"],
+                "bit_exact_vs_reference_digest": None if gold is None else bool(gold["input_sha256"] == sha256(xh) and gold["dendrogram_sha256"] == dig["dendrogram_sha256"]),
+                "reference_digest": None if gold is None else {"file": os.path.relpath(gold_path, ROOT), "reference_seconds_1_core": gold["reference_seconds_1_core"]}})
     # the reference's own C++ (oracle/_ref, 1 thread) on a bounded size, next to the GPU at the same size
-    xs = x[:ref_n].cpu().numpy()
+    xs = xh[:ref_n]
     t0 = time.perf_counter()
     sr, zr = oracle.linkage_ref(xs)
     out["cpu_reference"] = {"n": ref_n, "seconds": time.perf_counter() - t0, "cores": 1, "kind": "reference",
-                            "note": "FastClusterWrapper.cpp built -O2 from /root/reference (oracle/_ref); "
-                                    "50k x 256 on 1 core measured at 1001.7 s in BASELINE.md §2"}
+                            "note": "FastClusterWrapper.cpp built -O2 from /root/reference (oracle/_ref); the full 50k x 256 run took "
+                                    "937 s on 1 core when the committed digest was generated"}
     t0 = time.perf_counter()
     sg, zg = fa.linkage(xs, ctx=ctx)
     out["gpu_same_n"] = {"n": ref_n, "seconds": time.perf_counter() - t0, "bit_exact_vs_reference": bool(sr == 0 and sg == 0 and np.array_equal(zr, zg))}
     return out
 
 
-def ctc_leg(fa, ctx, torch, batch, steps=3):
+def ahc_batch_leg(fa, ctx, recordings=16, n=5400, d=256, speakers=8):
+    """Many medium-sized recordings: fa_ahc_linkage_batch (one launch = one round of every recording) vs sequential calls."""
+    import oracle
+    rng = np.random.default_rng(21)
+    probs = []
+    for _ in range(recordings):
+        c = rng.standard_normal((speakers, d))
+        c /= np.linalg.norm(c, axis=1, keepdims=True)
+        x = c[np.arange(n) % speakers] + 0.03 * rng.standard_normal((n, d))
+        probs.append(x / np.linalg.norm(x, axis=1, keepdims=True))
+    fa.linkage_batch(probs[:2], ctx=ctx)
+    t0 = time.perf_counter()
+    st, zs, stats = fa.linkage_batch(probs, ctx=ctx, return_stats=True)
+    tb = time.perf_counter() - t0
+    fa.linkage(probs[0], ctx=ctx)
+    t0 = time.perf_counter()
+    seq = [fa.linkage(p, ctx=ctx) for p in probs]
+    ts = time.perf_counter() - t0
+    sr, zr = oracle.linkage_ref(probs[0][:2000])
+    sg, zg = fa.linkage_batch([probs[0][:2000], probs[1][:1500]], ctx=ctx)
+    return {"recordings": recordings, "embeddings_each": n, "d": d, "batch_s": tb, "batch_device_ms": stats[0]["total_ms"], "sequential_s": ts,
+            "speedup_vs_sequential": ts / tb, "statuses_ok": all(s == 0 for s in st),
+            "identical_to_sequential": all(np.array_equal(z, s[1]) for z, s in zip(zs, seq)),
+            "bit_exact_vs_reference_at_2000": bool(sr == 0 and sg[0] == 0 and np.array_equal(zr, zg[0])),
+            "clustered_audio_hours_per_s": recordings * (n / 3 * 2.0 / 3600.0) / tb,
+            "note": "host-pointer entries (PCIe copies included); n embeddings = n/3 two-second windows of 3 local speaker slots"}
+
+
+def ctc_leg(fa, ctx, torch, dist, rank, world, total, steps=3):
+    """BASELINE configs[3]: `total` matrices [1500, 1024] fp32 sharded over the ranks (contiguous slices, no data-path
+    collective); every rank times its own passes, the slowest rank sets the rate; token ids gather on rank 0 (RCCL)."""
     T, V = 1500, 1024
-    g = torch.Generator(device="cuda").manual_seed(7)
+    lo, hi = fa.shard_range(total, rank, world)
+    batch = hi - lo
+    g = torch.Generator(device="cuda").manual_seed(7 + rank)
     x = torch.randn((batch, T, V), generator=g, device="cuda", dtype=torch.float32)
     x[:, :, V - 1] += 2.0
     tok = torch.zeros((batch, T), dtype=torch.int32, device="cuda")
     lens = torch.zeros(batch, dtype=torch.int32, device="cuda")
     stream = torch.cuda.ExternalStream(ctx.stream)
     torch.cuda.synchronize()
-    fa.ctc_greedy_ids_dev(ctx, x, V - 1, tok, lens)
+    fa.ctc_greedy_ids_dev(ctx, x, V - 1, tok, lens, order=False)
     ctx.synchronize()
+    if dist is not None:
+        dist.barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
     e0.record(stream)
     for _ in range(steps):
-        fa.ctc_greedy_ids_dev(ctx, x, V - 1, tok, lens)
+        fa.ctc_greedy_ids_dev(ctx, x, V - 1, tok, lens, order=False)
     e1.record(stream)
     ctx.synchronize()
+    wall = (time.perf_counter() - t0) / steps
     ms = e0.elapsed_time(e1) / steps
-    gbs = batch * CTC_BYTES_PER_MATRIX / (ms * 1e-3) / 1e9
-    # the row kernel next to it (§8f-3): log-softmax with temperature / blank bias, one read + one write of the matrix
-    lsm = None
-    try:
-        out = torch.empty_like(x)
-        fa.ctc_log_probs_dev(ctx, x, 1.0, 0.0, V - 1, d_out=out)
-        ctx.synchronize()
-        e0.record(stream)
-        for _ in range(steps):
-            fa.ctc_log_probs_dev(ctx, x, 1.0, 0.0, V - 1, d_out=out)
-        e1.record(stream)
-        ctx.synchronize()
-        ms2 = e0.elapsed_time(e1) / steps
-        g2 = 2 * batch * CTC_BYTES_PER_MATRIX / (ms2 * 1e-3) / 1e9
-        lsm = {"ms_per_pass": ms2, "roofline": {"bound": "hbm", "achieved": g2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g2 / HBM_PEAK_GBS,
-                                                "traffic": None}, "algorithmic_bytes_per_matrix": 2 * CTC_BYTES_PER_MATRIX}
-        del out
-    except Exception as e:  # noqa: BLE001
-        lsm = {"error": repr(e)}
-    return {"log_softmax": lsm, "matrices": batch, "T": T, "V": V, "dtype": "f32", "ms_per_pass": ms, "matrices_per_s": batch / (ms * 1e-3),
-            "audio_hours_per_s": batch * 15.0 / 3600.0 / (ms * 1e-3),
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None},
-            "mean_tokens_per_matrix": float(lens.float().mean())}
+    t_gather = None
+    gathered = None
+    if dist is not None:
+        tt = torch.tensor([wall, ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, ms = float(tt[0]), float(tt[1])
+        rows_n = min(batch, 64)                      # the gather of ALL ids is 4 bytes x 1320 tokens per matrix; a 64-matrix sample per rank shows the path
+        tk, ln = tok[:rows_n].cpu().numpy(), lens[:rows_n].cpu().numpy()
+        rows = [tk[i, :ln[i]] for i in range(rows_n)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = fa.gather_ragged_int32(rows, dist, dst=0)
+        t_gather = time.perf_counter() - t0
+        gathered = None if got is None else len(got)
+    gbs_rank = batch * CTC_BYTES_PER_MATRIX / (ms * 1e-3) / 1e9
+    out = {"matrices": total, "matrices_per_rank": batch, "T": T, "V": V, "dtype": "f32", "ms_per_pass": ms, "wall_ms_per_pass": 1e3 * wall,
+           "matrices_per_s": total / wall, "audio_hours_per_s": total * 15.0 / 3600.0 / wall, "scaling": "strong" if world > 1 else "single",
+           "roofline": {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_rank / HBM_PEAK_GBS, "traffic": None,
+                        "note": "per GPU (slowest rank)"},
+           "mean_tokens_per_matrix": float(lens.float().mean()), "gather_token_ids_s": t_gather, "gathered_rows_on_rank0": gathered}
+    if world == 1:   # the row kernel next to it (§8f-3): log-softmax with temperature / blank bias, one read + one write of the matrix
+        try:
+            sub = x[: min(batch, 2500)]
+            o = torch.empty_like(sub)
+            fa.ctc_log_probs_dev(ctx, sub, 1.0, 0.0, V - 1, d_out=o, order=False)
+            ctx.synchronize()
+            e0.record(stream)
+            for _ in range(steps):
+                fa.ctc_log_probs_dev(ctx, sub, 1.0, 0.0, V - 1, d_out=o, order=False)
+            e1.record(stream)
+            ctx.synchronize()
+            ms2 = e0.elapsed_time(e1) / steps
+            g2 = 2 * sub.shape[0] * CTC_BYTES_PER_MATRIX / (ms2 * 1e-3) / 1e9
+            out["log_softmax"] = {"matrices": int(sub.shape[0]), "ms_per_pass": ms2,
+                                  "roofline": {"bound": "hbm", "achieved": g2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g2 / HBM_PEAK_GBS, "traffic": None},
+                                  "algorithmic_bytes_per_matrix": 2 * CTC_BYTES_PER_MATRIX}
+        except Exception as e:  # noqa: BLE001
+            out["log_softmax"] = {"error": repr(e)}
+    return out
 
 
-def e2e_leg(fa, ctx, torch, hours=8.0, speakers=12):
-    """BASELINE configs[4] on ONE GPU: `hours` of synthetic 16 kHz audio -> mel (15 s chunks) -> precomputed embeddings
+def e2e_leg(fa, ctx, torch, dist, rank, world, hours=8.0, speakers=12):
+    """BASELINE configs[4]: `hours` of synthetic 16 kHz audio per rank -> mel (15 s chunks) -> precomputed embeddings
     (3 local speaker slots per 2 s step, OfflineDiarizerTypes.swift:46-55) -> AHC + VBx + centroids + constrained
-    assignment.  Embeddings/PLDA features are synthetic (the reference computes them with CoreML nets, out of scope)."""
+    assignment in ONE library call (fa_offline_cluster).  One recording per rank (the merge chain of a recording does not
+    shard); the labels gather on rank 0.  Embeddings/PLDA features are synthetic (the reference computes them with CoreML nets)."""
     n_chunks15 = int(hours * 3600 / 15)
-    d_pcm = synth_pcm(torch, n_chunks15, 99)
+    d_pcm = synth_pcm(torch, n_chunks15, 99 + rank)
     mel = fa.AudioMelSpectrogram(ctx=ctx)
     plan = mel.plan(np.arange(n_chunks15 + 1, dtype=np.int64) * CHUNK_SAMPLES, layout="mel_major")
     d_out = torch.empty(plan.out_shape(), dtype=torch.float32, device="cuda")
     d_len = torch.empty(n_chunks15, dtype=torch.int32, device="cuda")
-    plan.execute(d_pcm, d_out, d_len)
+    torch.cuda.synchronize()
+    plan.execute(d_pcm, d_out, d_len, order=False)
     ctx.synchronize()
-    t0 = time.perf_counter()
-    plan.execute(d_pcm, d_out, d_len)
-    ctx.synchronize()
-    t_mel = time.perf_counter() - t0
-    del d_out, d_pcm
-    torch.cuda.empty_cache()
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + rank)
     n_win = int(hours * 3600 / 2)
     n = 3 * n_win
     centers = rng.standard_normal((speakers, 256))
@@ -186,22 +291,79 @@ def e2e_leg(fa, ctx, torch, hours=8.0, speakers=12):
     rho = (rng.standard_normal((speakers, 128)) * np.sqrt(phi))[spk] + rng.standard_normal((n, 128))
     chunks = np.repeat(np.arange(n_win), 3)
     fa.cluster_embeddings(emb[:3000], rho[:3000], chunks[:3000], phi, ctx=ctx)   # warm-up (workspace, code objects)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    plan.execute(d_pcm, d_out, d_len, order=False)
+    ctx.synchronize()
+    t_mel = time.perf_counter() - t0
     t0 = time.perf_counter()
     res = fa.cluster_embeddings(emb, rho, chunks, phi, ctx=ctx)
     t_cl = time.perf_counter() - t0
+    del d_out, d_pcm
     lab = np.asarray(res.assignments)
     pure = len(set(zip(spk.tolist(), lab.tolist()))) == speakers
-    # the speaker-count fallback on the same embeddings: best-of-10 K-Means to speakers - 2 (VBxClustering.swift:716-722)
-    emb64 = emb.astype(np.float64)
-    fa.KMeansClustering.cluster_with_centroids_n_init(emb64[:3000], speakers - 2, 100, 10, 0, ctx=ctx)
+    t_all = t_mel + t_cl
+    gathered = None
+    if dist is not None:
+        tt = torch.tensor([t_all, t_mel, t_cl], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_all, t_mel, t_cl = float(tt[0]), float(tt[1]), float(tt[2])
+        ok = torch.tensor([1.0 if pure else 0.0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        pure = bool(ok.item() > 0.5)
+        got = fa.gather_ragged_int32([lab.astype(np.int32)], dist, dst=0)
+        gathered = None if got is None else [int(len(g)) for g in got]
+    out = {"audio_hours_per_rank": hours, "recordings": world, "mel_chunks_per_rank": n_chunks15, "mel_s": t_mel, "embeddings_per_recording": n, "cluster_s": t_cl,
+           "stages_s": res.timings, "speakers_true": speakers, "clusters_found": int(res.centroids.shape[0]),
+           "labels_match_speakers": bool(pure), "audio_hours_per_s": world * hours / t_all, "gathered_label_rows": gathered,
+           "note": "fa_offline_cluster: embeddings and PLDA features go up once (host pointers, PCIe included), intermediates stay in HBM; mel inputs resident in HBM"}
+    if world == 1:
+        # the speaker-count fallback on the same embeddings: best-of-10 K-Means to speakers - 2 (VBxClustering.swift:716-722)
+        emb64 = emb.astype(np.float64)
+        fa.KMeansClustering.cluster_with_centroids_n_init(emb64[:3000], speakers - 2, 100, 10, 0, ctx=ctx)
+        t0 = time.perf_counter()
+        km, _ = fa.KMeansClustering.cluster_with_centroids_n_init(emb64, speakers - 2, 100, 10, 0, ctx=ctx)
+        out["kmeans_fallback_s"] = time.perf_counter() - t0
+        out["kmeans_clusters"] = len(set(km))
+    return out
+
+
+def sharded_start_leg(fa, ctx, torch, dist, rank, world, n=50000, d=256):
+    """SURVEY.md §8e, one 50 k problem: all-gather X over RCCL, per-rank row slab of the nearest-neighbour table
+    (fa_ahc_row_minima), all-gather of (min, idx) — next to the same table computed by ONE rank.  The merge chain stays on one GPU."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from ahc_full_inputs import ahc_input
+    x = ahc_input("iid", n, d)
+    d_x = torch.from_numpy(x).cuda()
+
+    def slab_dev(_x_all, lo, hi):
+        m = torch.empty(hi - lo, dtype=torch.float64, device="cuda")
+        a = torch.empty(hi - lo, dtype=torch.int32, device="cuda")
+        ctx.check(fa.lib().fa_ahc_row_minima(ctx.handle, C.c_void_p(d_x.data_ptr()), n, d, lo, hi, C.c_void_p(m.data_ptr()), C.c_void_p(a.data_ptr()), 1), "fa_ahc_row_minima")
+        ctx.synchronize()
+        return m.cpu().numpy(), a.cpu().numpy()
+
+    lo, hi = fa.shard_range(n, rank, world)
+    slab_dev(None, lo, min(hi, lo + 256))
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
-    det = {}
-    km, _ = fa.KMeansClustering.cluster_with_centroids_n_init(emb64, speakers - 2, 100, 10, 0, ctx=ctx, details=det)
-    t_km = time.perf_counter() - t0
-    return {"audio_hours": hours, "kmeans_fallback_s": t_km, "kmeans_clusters": len(set(km)), "mel_chunks": n_chunks15, "mel_s": t_mel, "embeddings": n, "cluster_s": t_cl,
-            "stages_s": res.timings, "speakers_true": speakers, "clusters_found": int(res.centroids.shape[0]),
-            "labels_match_speakers": bool(pure), "audio_hours_per_s": hours / (t_mel + t_cl),
-            "note": "host-pointer clustering entries (PCIe copies included); mel inputs resident in HBM"}
+    m, a = fa.sharding.row_minima_sharded(x[lo:hi], lo, n, slab_dev, dist)
+    t_sh = time.perf_counter() - t0
+    out = {"n": n, "d": d, "ranks": world, "sharded_s": t_sh}
+    if rank == 0:
+        t0 = time.perf_counter()
+        m1, a1 = slab_dev(None, 0, n)
+        out["single_rank_s"] = time.perf_counter() - t0
+        out["tables_equal"] = bool(np.array_equal(m, m1) and np.array_equal(a, a1))
+        out["note"] = ("exact (difference-form) fp64 distances; the production start-up is the Gram-form MFMA kernel (40 ms at 50k on one GPU) and the "
+                       "serial merge chain (570 ms) does not shard: see DESIGN.md §4")
+    if dist is not None:
+        dist.barrier()
+    return out
 
 
 def main():
@@ -217,6 +379,7 @@ def main():
     ap.add_argument("--skip-ctc", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-e2e", action="store_true")
+    ap.add_argument("--skip-sharded-start", action="store_true", help="N > 1 only: the sharded nearest-neighbour start-up of one 50k problem")
     ap.add_argument("--ctc-matrices", type=int, default=10000)
     args = ap.parse_args()
 
@@ -254,18 +417,20 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    # inside the timed loops the launches go straight to the context's stream (order=False): inputs are complete (synchronised
+    # above) and nothing on torch's stream touches the buffers until the loop has been synchronised
     t_warm = time.perf_counter() + max(0.0, args.clock_warm_s)   # set-up: bring the device to sustained clocks (not timed, not a step)
     while time.perf_counter() < t_warm:
-        plan.execute(d_pcm, d_out, d_len)
+        plan.execute(d_pcm, d_out, d_len, order=False)
         ctx.synchronize()
     for _ in range(args.warmup):
-        plan.execute(d_pcm, d_out, d_len)
+        plan.execute(d_pcm, d_out, d_len, order=False)
     barrier()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     ev[0].record(stream)
     for i in range(args.steps):
-        plan.execute(d_pcm, d_out, d_len)
+        plan.execute(d_pcm, d_out, d_len, order=False)
         ev[i + 1].record(stream)
     ctx.synchronize()
     torch.cuda.synchronize()
@@ -279,49 +444,66 @@ def main():
     kernel_ms_avg = float(np.mean(kernel_ms))
     assert int(d_len[0]) == 1501 and bool(torch.isfinite(d_out[B // 2]).all())
 
-    if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
     hours = world * B * 15.0 / 3600.0
     value = hours * args.steps / elapsed
     ach = B * MEL_BYTES_PER_CHUNK / (kernel_ms_avg * 1e-3) / 1e9
+    traffic, traffic_source = measured_traffic()
     line = {
-        "metric": "audio hours/sec featurized (batched STFT->mel, 1024 x 15 s chunks per GPU); AHC wall-clock @ 50k x 256 in ahc_50k",
+        "metric": "audio hours/sec featurized (batched STFT->mel, 1024 x 15 s chunks per GPU); featurized+clustered in "
+                  "featurized_plus_clustered_audio_hours_per_s; AHC wall-clock @ 50k x 256 in ahc_50k",
         "value": value, "unit": "audio_hours/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: batched STFT->mel, 1024 x 15 s 16 kHz chunks per GPU, NeMo config "
                                "(n_fft 512, hop 160, win 400, 128 mels, preemph 0.97), output [B,128,1501] fp32, inputs resident in HBM",
                    "chunks_per_gpu": B, "realtime_factor": value * 3600.0, "clock_warm_s": args.clock_warm_s, "parallelism": f"dp{world} (independent utterance shards, no collective)"},
-        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                     "kernel": "mel_kernel<MEL_MAJOR>", "kernel_ms_avg": kernel_ms_avg, "kernel_ms_min": float(np.min(kernel_ms)),
-                     "algorithmic_bytes_per_launch": B * MEL_BYTES_PER_CHUNK},
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": "mel_kernel_v4<MEL_MAJOR>", "kernel_ms_avg": kernel_ms_avg, "kernel_ms_min": float(np.min(kernel_ms)),
+                     "algorithmic_bytes_per_launch": B * MEL_BYTES_PER_CHUNK,
+                     "note": "the kernel is VALU/LDS-issue bound, not HBM bound: 0.33 ms of pure VALU issue at the measured 4 cycles per wave64 instruction "
+                             "(profiles/r02_ubench_peak.txt) vs 0.22 ms of HBM time; see DESIGN.md §3.1"},
     }
-    solo = world == 1  # baseline / extra legs only at N=1 (rank 0), so multi-GPU runs stay short
-    if solo and not args.skip_cpu:
-        line["cpu_baseline"] = cpu_mel_baseline()
+    solo = world == 1
     del d_out, d_pcm
     torch.cuda.empty_cache()
-    if solo and not args.skip_ctc:
+    if solo and not args.skip_cpu and rank == 0:
+        line["cpu_baseline"] = cpu_baselines()
+    if not args.skip_ctc:
         try:
-            line["ctc"] = ctc_leg(fa, ctx, torch, args.ctc_matrices)
+            r = ctc_leg(fa, ctx, torch, dist, rank, world, args.ctc_matrices)
         except Exception as e:  # noqa: BLE001
-            line["ctc"] = {"error": repr(e)}
+            r = {"error": repr(e)}
+        line["ctc"] = r
         torch.cuda.empty_cache()
+    if not args.skip_e2e:
+        try:
+            r = e2e_leg(fa, ctx, torch, dist, rank, world)
+        except Exception as e:  # noqa: BLE001
+            r = {"error": repr(e)}
+        line["e2e_8h"] = r
+        line["featurized_plus_clustered_audio_hours_per_s"] = r.get("audio_hours_per_s") if isinstance(r, dict) else None
+        torch.cuda.empty_cache()
+    if world > 1 and not args.skip_sharded_start:
+        try:
+            line["ahc_sharded_start"] = sharded_start_leg(fa, ctx, torch, dist, rank, world)
+        except Exception as e:  # noqa: BLE001
+            line["ahc_sharded_start"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if solo and not args.skip_ahc:
         try:
             line["ahc_50k"] = ahc_leg(fa, ctx, torch)
         except Exception as e:  # noqa: BLE001
             line["ahc_50k"] = {"error": repr(e)}
         torch.cuda.empty_cache()
-    if solo and not args.skip_e2e:
         try:
-            line["e2e_8h"] = e2e_leg(fa, ctx, torch)
+            line["ahc_batch"] = ahc_batch_leg(fa, ctx)
         except Exception as e:  # noqa: BLE001
-            line["e2e_8h"] = {"error": repr(e)}
+            line["ahc_batch"] = {"error": repr(e)}
     print(json.dumps(line))
     if dist is not None:
         dist.barrier()

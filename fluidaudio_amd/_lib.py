@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "fa_ctc_greedy_batch_dev", "fa_ctc_greedy_batch", "fa_ctc_log_softmax_batch_dev",
     "fa_tdt_default_config", "fa_tdt_initial_time_index", "fa_tdt_navigation_state", "fa_tdt_final_time_jump",
     "fa_tdt_map_duration_bin", "fa_tdt_clamp_probability", "fa_tdt_greedy_tables_dev",
-    "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_linkage_batch", "fa_ahc_cluster", "fa_ahc_cut",
+    "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_linkage_batch", "fa_ahc_row_minima", "fa_ahc_cluster", "fa_ahc_cut",
     "fa_vbx_speaker_count", "fa_vbx_refine",
     "fa_vbx_weighted_centroids", "fa_assign_cosine", "fa_centroid_scores", "fa_constrained_assign",
     "fa_offline_cluster_default_config", "fa_offline_cluster",
@@ -161,6 +161,7 @@ def lib() -> C.CDLL:
     L.fastcluster_compute_centroid_linkage.restype = C.c_int
     L.fa_ahc_linkage.argtypes = [vp, vp, sz, sz, vp, sz, i32, i32, C.POINTER(AhcStats)]
     L.fa_ahc_linkage_batch.argtypes = [vp, i32, vp, vp, sz, vp, i32, i32, vp, vp]
+    L.fa_ahc_row_minima.argtypes = [vp, vp, sz, sz, sz, sz, vp, vp, i32]
     L.fa_ahc_cluster.argtypes = [vp, vp, sz, sz, f64, i32, vp, C.POINTER(AhcStats)]
     L.fa_ahc_cut.argtypes = [vp, sz, f64, vp]
     L.fa_vbx_speaker_count.argtypes = [vp, i64]

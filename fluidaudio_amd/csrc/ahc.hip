@@ -1556,3 +1556,104 @@ fa_status fa_ahc_cluster(fa_ctx *ctx, const double *x, size_t n, size_t d, doubl
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row minima of a SLAB of the pairwise distance matrix: for rows [row0, row1) the nearest other point among all n (the
+// reference's distance: sequential fp64 sum of squared differences, FastClusterWrapper.cpp:45-52; lowest index on ties).
+// This is the start-up of the linkage (fastcluster_internal.hpp:1653-1678 builds the same nearest-neighbour table) in a form
+// that shards by rows across GPUs (all-gather X, per-rank slab, gather (min, idx)); fluidaudio_amd/sharding.py
+// drives it.  64 x 64 output tile per workgroup step, 4 x 4 per thread, operands staged k-major in LDS.
+namespace {
+
+constexpr int kSlabT = 64, kSlabK = 16;
+
+__global__ __launch_bounds__(256) void slab_row_minima_kernel(const double *__restrict__ x, int n, int d, int row0, int row1, double *__restrict__ out_min,
+                                                              int32_t *__restrict__ out_arg) {
+    __shared__ double sa[kSlabK][kSlabT + 1], sb[kSlabK][kSlabT + 1];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;   // tx: column quad, ty: row quad
+    const int i0 = row0 + blockIdx.x * kSlabT;
+    double best[4];
+    int arg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { best[r] = __longlong_as_double(0x7ff0000000000000LL); arg[r] = -1; }
+    for (int j0 = 0; j0 < n; j0 += kSlabT) {
+        double acc[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+        for (int k0 = 0; k0 < d; k0 += kSlabK) {
+            for (int e = tid; e < kSlabT * kSlabK; e += 256) {   // 64 rows x 16 dims of both operands
+                const int rr = e / kSlabK, kk = e % kSlabK;
+                const int gi = i0 + rr, gj = j0 + rr, gk = k0 + kk;
+                sa[kk][rr] = gi < row1 && gk < d ? x[static_cast<size_t>(gi) * d + gk] : 0.0;
+                sb[kk][rr] = gj < n && gk < d ? x[static_cast<size_t>(gj) * d + gk] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < kSlabK; ++kk) {   // ascending k, one rounding per operation: the reference's sum
+                double a[4], b[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a[r] = sa[kk][4 * ty + r]; b[r] = sb[kk][4 * tx + r]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const double df = a[r] - b[c]; acc[r][c] = acc[r][c] + df * df; }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int gi = i0 + 4 * ty + r, gj = j0 + 4 * tx + c;
+                if (gi < row1 && gj < n && gj != gi && (acc[r][c] < best[r] || (acc[r][c] == best[r] && gj < arg[r]))) { best[r] = acc[r][c]; arg[r] = gj; }
+            }
+    }
+    // the 16 threads of a row quad (tx = 0..15, consecutive lanes) combine: lowest value, then lowest index
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double v = best[r];
+        int a = arg[r];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(v, off, 16);
+            const int oa = __shfl_xor(a, off, 16);
+            if (oa >= 0 && (a < 0 || ov < v || (ov == v && oa < a))) { v = ov; a = oa; }
+        }
+        const int gi = i0 + 4 * ty + r;
+        if (tx == 0 && gi < row1) { out_min[gi - row0] = v; out_arg[gi - row0] = a; }
+    }
+}
+
+}  // namespace
+
+extern "C" fa_status fa_ahc_row_minima(fa_ctx *ctx, const double *x, size_t n, size_t d, size_t row0, size_t row1, double *mins, int32_t *args,
+                                       int32_t device_pointers) {
+    if (!ctx || !x || !mins || !args) return FA_INVALID_ARGUMENT;
+    if (row0 > row1 || row1 > n || d == 0 || n > static_cast<size_t>(INT32_MAX) || d > static_cast<size_t>(INT32_MAX)) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "row minima: bad range");
+    if (row0 == row1) return FA_SUCCESS;
+    fa::DeviceGuard guard(ctx->device);
+    const size_t rows = row1 - row0;
+    fa::DevBuf bx, bm, ba;
+    const double *d_x = x;
+    double *d_m = mins;
+    int32_t *d_a = args;
+    if (!device_pointers) {
+        if (bx.alloc(sizeof(double) * n * d) != hipSuccess || bm.alloc(sizeof(double) * rows) != hipSuccess || ba.alloc(sizeof(int32_t) * rows) != hipSuccess) {
+            (void)hipGetLastError();
+            return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "row minima: device allocation failed");
+        }
+        FA_HIP_TRY(ctx, hipMemcpyAsync(bx.p, x, sizeof(double) * n * d, hipMemcpyHostToDevice, ctx->stream));
+        d_x = bx.as<double>(); d_m = bm.as<double>(); d_a = ba.as<int32_t>();
+    }
+    hipLaunchKernelGGL(slab_row_minima_kernel, dim3(static_cast<unsigned>((rows + kSlabT - 1) / kSlabT)), dim3(256), 0, ctx->stream, d_x, static_cast<int>(n),
+                       static_cast<int>(d), static_cast<int>(row0), static_cast<int>(row1), d_m, d_a);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    if (!device_pointers) {
+        FA_HIP_TRY(ctx, hipMemcpyAsync(mins, d_m, sizeof(double) * rows, hipMemcpyDeviceToHost, ctx->stream));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(args, d_a, sizeof(int32_t) * rows, hipMemcpyDeviceToHost, ctx->stream));
+        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FA_SUCCESS;
+}

@@ -245,6 +245,14 @@ fa_status fa_ahc_linkage_batch(fa_ctx *ctx, int32_t count, const double *const *
                                double *const *dendrograms, int32_t mode, int32_t device_pointers, fa_ahc_stats *stats,
                                int32_t *statuses);
 
+/* Nearest other point of rows [row0, row1) among all n rows of x (n x d, row-major fp64): mins[i - row0] = the reference's
+ * distance (sequential sum of squared differences, FastClusterWrapper.cpp:45-52; the SQUARED distance like the linkage uses
+ * before its final sqrt), args[i - row0] = its index (lowest on ties).  The start-up table of the linkage
+ * (fastcluster_internal.hpp:1653-1678) in a form that shards by rows across GPUs: every rank holds all of x (all-gather),
+ * computes its slab, and the (min, arg) pairs are gathered (fluidaudio_amd/sharding.py::row_minima_sharded). */
+fa_status fa_ahc_row_minima(fa_ctx *ctx, const double *x, size_t n, size_t d, size_t row0, size_t row1, double *mins, int32_t *args,
+                            int32_t device_pointers);
+
 /* AHCClustering.cluster (FluidAudio/Diarizer/Offline/Clustering/AHCClustering.swift:20-67): L2-normalise
  * (:70-105), linkage, threshold clamp (:112-121), top-down cut (:124-197), relabel (:200-210).
  * x: HOST double[n*d]; labels: HOST int32[n].  On linkage failure labels = 0..n-1 (:52-55) and

@@ -233,3 +233,31 @@ def test_batched_problems_equal_single_problem_runs(fa, gpu_ctx, oracle_mod):
     # and equal to the single-problem entry (same kernels, same order)
     st1, z1 = fa.linkage(probs[6], ctx=gpu_ctx)
     assert st1 == 0 and np.array_equal(z1, zs[6])
+
+
+def test_row_minima_slabs_equal_restatement_and_linkage_first_merge(fa, gpu_ctx, oracle_mod):
+    """fa_ahc_row_minima (the shardable start-up table): slabs concatenate to the full table, the table equals the CPU
+    restatement (same sequential sums -> same bits), and its global minimum is the first merge of the reference build."""
+    import ctypes as C
+    from fluidaudio_amd.sharding import row_minima_numpy
+    x = speaker_mixture(1100, 96, 11, 0.05, 8)
+    x[300] = x[77]                                         # exact tie
+    n, d = x.shape
+    def slab(lo, hi):
+        m, a = np.zeros(hi - lo), np.zeros(hi - lo, np.int32)
+        gpu_ctx.check(fa.lib().fa_ahc_row_minima(gpu_ctx.handle, x.ctypes.data, n, d, lo, hi, m.ctypes.data, a.ctypes.data, 0), "fa_ahc_row_minima")
+        return m, a
+    full_m, full_a = slab(0, n)
+    parts = [slab(lo, hi) for lo, hi in ((0, 137), (137, 138), (138, 700), (700, n))]
+    np.testing.assert_array_equal(np.concatenate([p[0] for p in parts]), full_m)
+    np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), full_a)
+    rm, ra = row_minima_numpy(x, 0, n)
+    np.testing.assert_array_equal(full_a, ra)
+    np.testing.assert_array_equal(full_m, rm)
+    assert full_a[300] == 77 and full_a[77] == 300 and full_m[300] == 0.0
+    y = speaker_mixture(900, 64, 7, 0.05, 9)               # tie-free: the closest pair is the reference's first merge
+    m, a = np.zeros(900), np.zeros(900, np.int32)
+    gpu_ctx.check(fa.lib().fa_ahc_row_minima(gpu_ctx.handle, y.ctypes.data, 900, 64, 0, 900, m.ctypes.data, a.ctypes.data, 0), "fa_ahc_row_minima")
+    st, z = oracle_mod.linkage_ref(y)
+    i = int(np.argmin(m))
+    assert st == 0 and {int(z[0, 0]), int(z[0, 1])} == {i, int(a[i])} and z[0, 2] == np.sqrt(m[i])
