@@ -77,7 +77,9 @@ def test_n_init_matches_oracle(fa, gpu_ctx, oracle_mod, n, k, seed):
 def test_constrained_stage_matches_cpu_restatement(fa, gpu_ctx, oracle_mod, forced):
     emb, rho, chunks, phi, spk = synth_session(300, 4, 0)
     cfg = fa.OfflineClusteringConfig(num_speakers=forced)
-    res = fa.cluster_embeddings(emb, rho, chunks, phi, cfg, ctx=gpu_ctx)
+    res = fa.cluster_embeddings_stagewise(emb, rho, chunks, phi, cfg, ctx=gpu_ctx)   # exposes the K-Means intermediates
+    one = fa.cluster_embeddings(emb, rho, chunks, phi, cfg, ctx=gpu_ctx)              # the single device-resident call
+    assert one.assignments == res.assignments and np.array_equal(one.centroids, res.centroids) and one.info["was_adjusted"] == 1
     ref = oracle_mod.cluster_embeddings(emb, rho, chunks, phi, num_speakers=forced)
     assert res.vbx.was_adjusted and ref["was_adjusted"] and res.vbx.original_cluster_count == ref["detected"] == 4
     assert res.vbx.hard_clusters[0] == ref["kmeans_clusters"].tolist()
@@ -86,4 +88,4 @@ def test_constrained_stage_matches_cpu_restatement(fa, gpu_ctx, oracle_mod, forc
     # within bounds: nothing is adjusted and the constrained assignment stays on
     cfg = fa.OfflineClusteringConfig(min_speakers=2, max_speakers=6)
     res = fa.cluster_embeddings(emb, rho, chunks, phi, cfg, ctx=gpu_ctx)
-    assert not res.vbx.was_adjusted and res.assignments == oracle_mod.cluster_embeddings(emb, rho, chunks, phi)["assignments"].tolist()
+    assert not res.info["was_adjusted"] and res.assignments == oracle_mod.cluster_embeddings(emb, rho, chunks, phi)["assignments"].tolist()
