@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "fa_ctc_vocab_create", "fa_ctc_vocab_destroy", "fa_ctc_beam_search_batch_dev", "fa_ctc_beam_search_batch",
     "fa_wav_pcm16_size", "fa_wav_encode_pcm16", "fa_wav_decode", "fa_rttm_parse", "fa_rttm_format", "fa_export_embeddings_json",
     "fa_seeded_rng_next", "fa_seeded_rng_below", "fa_kmeans_cluster", "fa_kmeans_cluster_ninit", "fa_speaker_constraints_resolve",
-    "fa_resample_linear_frames", "fa_resample_linear", "fa_resample_poly_frames", "fa_resample_poly_taps", "fa_resample_poly",
+    "fa_resample_linear_frames", "fa_resample_linear", "fa_resample_poly_frames", "fa_resample_poly_taps", "fa_resample_poly", "fa_resample_poly_dev",
 ]
 
 
@@ -213,6 +213,7 @@ def lib() -> C.CDLL:
     L.fa_resample_poly_frames.restype = i64
     L.fa_resample_poly_taps.argtypes = [i32, i32, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.fa_resample_poly.argtypes = [vp, vp, i64, i32, i32, vp, i64, C.POINTER(i64)]
+    L.fa_resample_poly_dev.argtypes = [vp, vp, i64, i32, i32, vp, i64, C.POINTER(i64)]
     _lib = L
     return L
 

@@ -54,6 +54,45 @@ __global__ void poly_kernel(const float *__restrict__ x, const float *__restrict
     y[m] = acc;
 }
 
+// LDS-staged polyphase FIR: persistent workgroups keep ALL taps in LDS (loaded once per workgroup), walk tiles of kPolyTile
+// outputs, and stage the input span a tile needs (tile * down / up + h_len / up samples) in LDS with coalesced loads: every
+// input sample is read from HBM once per tile it touches, every output written once; the h_len / up multiply-adds of an output
+// read both operands from LDS.  Same summation order (ascending input index) as poly_kernel: bit-identical results.
+// Algorithmic HBM bytes = 4 (n_in + n_out).
+constexpr int kPolyTile = 2048;
+
+__global__ __launch_bounds__(kThreads) void poly_lds_kernel(const float *__restrict__ x, const float *__restrict__ h, float *__restrict__ y, int64_t n_in,
+                                                            int64_t n_out, int h_len, int up, int down, int64_t pre_remove, int span_alloc) {
+    extern __shared__ float sm[];
+    float *taps = sm, *xs = sm + ((h_len + 3) & ~3);
+    for (int i = threadIdx.x; i < h_len; i += kThreads) taps[i] = h[i];
+    const int64_t tiles = (n_out + kPolyTile - 1) / kPolyTile;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t m0 = tile * kPolyTile;
+        const int64_t m1 = m0 + kPolyTile < n_out ? m0 + kPolyTile : n_out;
+        const int64_t p_first = (m0 + pre_remove) * down, p_last = (m1 - 1 + pre_remove) * down;
+        int64_t k0 = p_first - (h_len - 1) < 0 ? 0 : (p_first - (h_len - 1) + up - 1) / up;
+        int64_t k1 = p_last / up;
+        if (k1 > n_in - 1) k1 = n_in - 1;
+        const int span = k1 >= k0 ? static_cast<int>(k1 - k0 + 1) : 0;
+        __syncthreads();   // the previous tile's reads of xs are complete (and the taps are in place)
+        for (int i = threadIdx.x; i < span && i < span_alloc; i += kThreads) xs[i] = x[k0 + i];
+        __syncthreads();
+        for (int64_t m = m0 + threadIdx.x; m < m1; m += kThreads) {
+            const int64_t p = (m + pre_remove) * down;
+            int64_t k_hi = p / up;
+            int64_t k_lo = p - (h_len - 1) < 0 ? 0 : (p - (h_len - 1) + up - 1) / up;
+            if (k_hi > n_in - 1) k_hi = n_in - 1;
+            int ti = static_cast<int>(p - k_lo * up);       // tap of the first term, then -up per input sample
+            const float *xp = xs + (k_lo - k0);
+            const int cnt = static_cast<int>(k_hi - k_lo + 1);
+            float acc = 0.0f;
+            for (int j = 0; j < cnt; ++j, ti -= up) acc = fmaf(taps[ti], xp[j], acc);
+            y[m] = acc;
+        }
+    }
+}
+
 double bessel_i0(double x) {  // power series, converges fast for the beta used here
     double sum = 1.0, term = 1.0;
     const double q = x * x / 4.0;
@@ -145,8 +184,8 @@ fa_status fa_resample_poly_taps(int32_t up, int32_t down, float *taps, int64_t c
     }
 }
 
-fa_status fa_resample_poly(fa_ctx *ctx, const float *x, int64_t frames, int32_t up, int32_t down, float *out, int64_t out_capacity,
-                           int64_t *out_frames) {
+// Device-resident form: d_x (frames samples) -> d_y (fa_resample_poly_frames samples), enqueued on the context's stream.
+fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, int32_t up, int32_t down, float *d_y, int64_t out_capacity, int64_t *out_frames) {
     if (!ctx || !out_frames) return FA_INVALID_ARGUMENT;
     *out_frames = 0;
     if (frames < 0 || up < 1 || down < 1) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "resample_poly: bad arguments");
@@ -156,33 +195,61 @@ fa_status fa_resample_poly(fa_ctx *ctx, const float *x, int64_t frames, int32_t 
     if (n_out > out_capacity) return fa::set_error(ctx, FA_OUTPUT_TOO_SMALL, "resample_poly: output buffer too small");
     *out_frames = n_out;
     if (frames == 0) return FA_SUCCESS;
-    if (!x || !out) return FA_INVALID_ARGUMENT;
+    if (!d_x || !d_y) return FA_INVALID_ARGUMENT;
     try {
         int64_t n_taps = 0, pre_remove = 0;
         FA_TRY(fa_resample_poly_taps(u, dn, nullptr, 0, &n_taps, &pre_remove));
         std::vector<float> taps(n_taps);
         FA_TRY(fa_resample_poly_taps(u, dn, taps.data(), n_taps, &n_taps, &pre_remove));
         fa::DeviceGuard guard(ctx->device);
-        fa::DevBuf d_x, d_h, d_y;
-        hipError_t e;
-        do {
-            if ((e = d_x.alloc(sizeof(float) * frames)) != hipSuccess) break;
-            if ((e = d_h.alloc(sizeof(float) * n_taps)) != hipSuccess) break;
-            if ((e = d_y.alloc(sizeof(float) * n_out)) != hipSuccess) break;
-            if ((e = hipMemcpyAsync(d_x.p, x, sizeof(float) * frames, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-            if ((e = hipMemcpyAsync(d_h.p, taps.data(), sizeof(float) * n_taps, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-            hipLaunchKernelGGL(poly_kernel, dim3(static_cast<unsigned>((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream,
-                               d_x.as<float>(), d_h.as<float>(), d_y.as<float>(), frames, n_out, n_taps, u, dn, pre_remove);
-            if ((e = hipGetLastError()) != hipSuccess) break;
-            if ((e = hipMemcpyAsync(out, d_y.p, sizeof(float) * n_out, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
-            e = hipStreamSynchronize(ctx->stream);
-        } while (0);
-        return fa::hip_status(ctx, e, "fa_resample_poly");
+        FA_TRY(fa::ensure_scratch(ctx, sizeof(float) * n_taps));
+        float *d_h = static_cast<float *>(ctx->scratch);
+        FA_HIP_TRY(ctx, hipMemcpyAsync(d_h, taps.data(), sizeof(float) * n_taps, hipMemcpyHostToDevice, ctx->stream));
+        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // taps is a host temporary
+        const int64_t span = (static_cast<int64_t>(kPolyTile) * dn + u - 1) / u + (n_taps + u - 1) / u + 4;
+        const size_t lds = sizeof(float) * (static_cast<size_t>((n_taps + 3) & ~static_cast<int64_t>(3)) + static_cast<size_t>(span));
+        if (lds <= 150 * 1024 && getenv("FA_RESAMPLE_SIMPLE") == nullptr) {
+            if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(poly_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            const int64_t tiles = (n_out + kPolyTile - 1) / kPolyTile;
+            const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
+            const int grid = static_cast<int>(tiles < 256 * per_cu ? tiles : 256 * per_cu);
+            hipLaunchKernelGGL(poly_lds_kernel, dim3(grid), dim3(kThreads), lds, ctx->stream, d_x, d_h, d_y, frames, n_out, static_cast<int>(n_taps), u, dn, pre_remove,
+                               static_cast<int>(span));
+        } else {   // very long filters (extreme rate ratios): one thread per output straight from global memory
+            hipLaunchKernelGGL(poly_kernel, dim3(static_cast<unsigned>((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, frames, n_out,
+                               n_taps, u, dn, pre_remove);
+        }
+        FA_HIP_TRY(ctx, hipGetLastError());
+        return FA_SUCCESS;
     } catch (const std::bad_alloc &) {
         return FA_ALLOCATION_FAILURE;
     } catch (...) {
         return FA_UNKNOWN_ERROR;
     }
+}
+
+fa_status fa_resample_poly(fa_ctx *ctx, const float *x, int64_t frames, int32_t up, int32_t down, float *out, int64_t out_capacity,
+                           int64_t *out_frames) {
+    if (!ctx || !out_frames) return FA_INVALID_ARGUMENT;
+    *out_frames = 0;
+    if (frames < 0 || up < 1 || down < 1) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "resample_poly: bad arguments");
+    const int64_t n_out = fa_resample_poly_frames(frames, up, down);
+    if (n_out > out_capacity) return fa::set_error(ctx, FA_OUTPUT_TOO_SMALL, "resample_poly: output buffer too small");
+    *out_frames = n_out;
+    if (frames == 0) return FA_SUCCESS;
+    if (!x || !out) return FA_INVALID_ARGUMENT;
+    fa::DeviceGuard guard(ctx->device);
+    fa::DevBuf d_x, d_y;
+    if (d_x.alloc(sizeof(float) * frames) != hipSuccess || d_y.alloc(sizeof(float) * n_out) != hipSuccess) {
+        (void)hipGetLastError();
+        return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "resample_poly: device allocation failed");
+    }
+    FA_HIP_TRY(ctx, hipMemcpyAsync(d_x.p, x, sizeof(float) * frames, hipMemcpyHostToDevice, ctx->stream));
+    int64_t got = 0;
+    FA_TRY(fa_resample_poly_dev(ctx, d_x.as<float>(), frames, up, down, d_y.as<float>(), n_out, &got));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(out, d_y.p, sizeof(float) * n_out, hipMemcpyDeviceToHost, ctx->stream));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FA_SUCCESS;
 }
 
 }  // extern "C"

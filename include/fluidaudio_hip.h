@@ -439,6 +439,10 @@ int64_t fa_resample_poly_frames(int64_t frames, int32_t up, int32_t down);
 fa_status fa_resample_poly_taps(int32_t up, int32_t down, float *taps, int64_t capacity, int64_t *n_taps, int64_t *pre_remove);
 fa_status fa_resample_poly(fa_ctx *ctx, const float *x, int64_t frames, int32_t up, int32_t down, float *out,
                            int64_t out_capacity, int64_t *out_frames);
+/* The same on device-resident buffers, enqueued on the context's stream (no synchronisation): d_x float[frames] ->
+ * d_y float[fa_resample_poly_frames(frames, up, down)]. */
+fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, int32_t up, int32_t down, float *d_y,
+                               int64_t out_capacity, int64_t *out_frames);
 
 #ifdef __cplusplus
 }
