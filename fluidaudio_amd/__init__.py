@@ -17,7 +17,8 @@ from .post import (ConstrainedClusterAssignment, HungarianAssignment, assign_emb
                    compute_centroids)
 from .resample import linear_resample, poly_taps, resample_poly  # noqa: F401
 from .sharding import gather_ragged_int32, shard_offsets, shard_range  # noqa: F401
-from .tdt import TdtConfig, TdtDurationMapping, TdtFrameNavigation, decode_tables as tdt_decode_tables  # noqa: F401
+from .tdt import (TdtConfig, TdtDurationMapping, TdtFrameNavigation, decode_logits as tdt_decode_logits,  # noqa: F401
+                  decode_tables as tdt_decode_tables)
 from .vbx import VBxClustering, VBxOutput  # noqa: F401
 
 __version__ = "0.1.0"

@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "fa_mel_batch", "fa_mel_hann_window", "fa_mel_filterbank", "fa_mel_normalize_per_feature_dev",
     "fa_ctc_greedy_batch_dev", "fa_ctc_greedy_batch", "fa_ctc_log_softmax_batch_dev",
     "fa_tdt_default_config", "fa_tdt_initial_time_index", "fa_tdt_navigation_state", "fa_tdt_final_time_jump",
-    "fa_tdt_map_duration_bin", "fa_tdt_clamp_probability", "fa_tdt_greedy_tables_dev",
+    "fa_tdt_map_duration_bin", "fa_tdt_clamp_probability", "fa_tdt_greedy_tables_dev", "fa_tdt_greedy_logits_dev",
     "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_linkage_batch", "fa_ahc_row_minima", "fa_ahc_cluster", "fa_ahc_cut",
     "fa_vbx_speaker_count", "fa_vbx_refine",
     "fa_vbx_weighted_centroids", "fa_assign_cosine", "fa_centroid_scores", "fa_constrained_assign",
@@ -157,6 +157,7 @@ def lib() -> C.CDLL:
     L.fa_tdt_clamp_probability.argtypes = [f32]
     L.fa_tdt_clamp_probability.restype = f32
     L.fa_tdt_greedy_tables_dev.argtypes = [vp, C.POINTER(TdtConfig), vp, vp, vp, i32, i32, i32] + [vp] * 6 + [i32] + [vp] * 8
+    L.fa_tdt_greedy_logits_dev.argtypes = [vp, C.POINTER(TdtConfig), vp, i32, i32, i32, i32, i32, i64] + [vp] * 6 + [i32] + [vp] * 8
     L.fastcluster_compute_centroid_linkage.argtypes = [vp, sz, sz, vp, sz]
     L.fastcluster_compute_centroid_linkage.restype = C.c_int
     L.fa_ahc_linkage.argtypes = [vp, vp, sz, sz, vp, sz, i32, i32, C.POINTER(AhcStats)]

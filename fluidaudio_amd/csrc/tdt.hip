@@ -12,6 +12,8 @@
 // its greedy path — and replays the loop for a whole batch of chunks, one thread per chunk (the loop is a serial walk of
 // <= T + maxTokens table look-ups; the batch is the parallel axis).  PARITY of token outputs against the real models is
 // UNPINNED (models absent); the navigation helpers are pinned by TdtRefactoredComponentsTests.swift:12-195.
+#include <hip/hip_fp16.h>
+
 #include "fa_common.h"
 
 namespace {
@@ -34,11 +36,12 @@ __host__ __device__ inline float clamp_probability(const float v) {  // TdtDurat
     return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
 }
 
-__global__ void tdt_kernel(const TdtArgs a) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
+// The control loop for chunk b.  `raw(u, frame, tok, prob, bin)` supplies one joint decision (false: out of the supplied range);
+// `writer` is true for the thread that stores the outputs (the table walk runs one thread per chunk; the logits walk runs a
+// whole workgroup per chunk through the same, workgroup-uniform, control flow).
+template <class Raw>
+__device__ __forceinline__ void tdt_walk(const TdtArgs &a, const int b, const bool writer, Raw &&raw) {
     const fa_tdt_config &c = a.cfg;
-    const int64_t tb = static_cast<int64_t>(b) * a.U * a.T;
     int32_t *otok = a.out_tok + static_cast<int64_t>(b) * a.max_out, *otime = a.out_time + static_cast<int64_t>(b) * a.max_out;
     int32_t *odur = a.out_dur + static_cast<int64_t>(b) * a.max_out;
     float *oconf = a.out_conf + static_cast<int64_t>(b) * a.max_out;
@@ -47,8 +50,8 @@ __global__ void tdt_kernel(const TdtArgs a) {
     const int goff = a.global_offset ? a.global_offset[b] : 0;
     const int emit_after = a.emit_after ? a.emit_after[b] : -1;
     int t = a.t0 ? a.t0[b] : 0;
-    a.final_time[b] = INT32_MIN;  // "timeJump not updated" (early returns, :110-112,:150-152)
-    auto finish = [&]() { a.out_count[b] = count; a.final_u[b] = u; a.status[b] = st; };
+    if (writer) a.final_time[b] = INT32_MIN;  // "timeJump not updated" (early returns, :110-112,:150-152)
+    auto finish = [&]() { if (writer) { a.out_count[b] = count; a.final_u[b] = u; a.status[b] = st; } };
     if (enc_len <= 1) { finish(); return; }                        // :110-112
     const int Teff = min(enc_len, a.audio_frames ? a.audio_frames[b] : enc_len);  // TdtFrameNavigation.swift:59-78
     if (t >= Teff) { finish(); return; }                           // :150-152
@@ -59,17 +62,17 @@ __global__ void tdt_kernel(const TdtArgs a) {
     float score = 0.0f;
     auto joint = [&](const int frame) -> bool {  // one joint decision; false on a table / duration-bin error
         if (u >= a.U || frame < 0 || frame >= a.T) { st = FA_OUTPUT_TOO_SMALL; return false; }
-        const int64_t i = tb + static_cast<int64_t>(u) * a.T + frame;
-        tok = a.tok[i];
-        score = clamp_probability(a.prob[i]);
-        const int bi = a.bin[i];
+        float pr = 0.0f;
+        int bi = 0;
+        raw(u, frame, tok, pr, bi);
+        score = clamp_probability(pr);
         if (bi < 0 || bi >= c.n_duration_bins) { st = FA_RUNTIME_ERROR; return false; }  // mapDurationBin throws (:17-22)
         dur = c.duration_bins[bi];
         return true;
     };
     auto emit = [&](const int ts) {
         if (emit_after >= 0 && ts < emit_after) return;  // shouldEmitToken (:600-606)
-        if (count < a.max_out) { otok[count] = tok; otime[count] = ts; odur[count] = dur; oconf[count] = score; }
+        if (count < a.max_out) { if (writer) { otok[count] = tok; otime[count] = ts; odur[count] = dur; oconf[count] = score; } }
         else st = FA_OUTPUT_TOO_SMALL;
         ++count;
     };
@@ -122,8 +125,79 @@ __global__ void tdt_kernel(const TdtArgs a) {
             ++steps;
         }
     }
-    a.final_time[b] = t;
+    if (writer) a.final_time[b] = t;
     finish();
+}
+
+__global__ void tdt_kernel(const TdtArgs a) {   // joint decisions from tables [B][U][T], one thread per chunk
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int64_t tb = static_cast<int64_t>(b) * a.U * a.T;
+    tdt_walk(a, b, true, [&](const int u, const int frame, int &tok, float &prob, int &bin) {
+        const int64_t i = tb + static_cast<int64_t>(u) * a.T + frame;
+        tok = a.tok[i]; prob = a.prob[i]; bin = a.bin[i];
+    });
+}
+
+// Joint decisions computed on the fly from joint LOGITS [B][U][T][row_stride] (token logits [0, V1), duration logits [V1, V1 + nd)):
+// what the reference's JointDecision model hands back (TdtModelInference.swift:84-188: token_id, token_prob, duration) —
+// token = first-index argmax over the V1 token logits (strict '>', NaN never wins: the rule of LogitsArgmax.swift:16-55),
+// probability = softmax probability of that token, duration bin = first-index argmax over the nd duration logits.  One
+// workgroup per chunk walks the greedy path and touches ONLY the rows on it (~T + tokens rows of V1 + nd logits) instead of the
+// U x T x (V1 + nd) grid a table-building pre-pass would need.  The models themselves are not in the reference tree: PARITY UNPINNED.
+struct TdtLogitArgs {
+    const void *logits;
+    int32_t f16, V1, nd;
+    int64_t row_stride;
+};
+
+template <bool F16>
+__global__ __launch_bounds__(256) void tdt_logits_kernel(const TdtArgs a, const TdtLogitArgs g) {
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
+    __shared__ float s_sum[4];
+    __shared__ float s_dv[8];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t tb = static_cast<int64_t>(b) * a.U * a.T;
+    auto at = [&](const int64_t row, const int k) -> float {
+        if (F16) return __half2float(static_cast<const __half *>(g.logits)[row * g.row_stride + k]);
+        return static_cast<const float *>(g.logits)[row * g.row_stride + k];
+    };
+    tdt_walk(a, b, tid == 0, [&](const int u, const int frame, int &tok, float &prob, int &bin) {
+        const int64_t row = tb + static_cast<int64_t>(u) * a.T + frame;
+        // per-thread first maximum over k = tid, tid + 256, ... (ascending, strict '>')
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int k = tid; k < g.V1; k += 256) { const float v = at(row, k); if (v > bv) { bv = v; bi = k; } }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();   // the previous step's reads of the shared slots are complete
+        if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+        if (tid < g.nd) s_dv[tid] = at(row, g.V1 + tid);
+        __syncthreads();
+        float mv = s_v[0];
+        int mi = s_i[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) if (s_v[w] > mv || (s_v[w] == mv && s_i[w] < mi)) { mv = s_v[w]; mi = s_i[w]; }
+        if (mi == 0x7fffffff) mi = 0;              // all NaN / -inf: index 0 (LogitsArgmax semantics)
+        float sum = 0.0f;                           // softmax denominator, fixed order: per-thread ascending, lanes, waves
+        for (int k = tid; k < g.V1; k += 256) sum += __expf(at(row, k) - mv);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if (lane == 0) s_sum[wave] = sum;
+        __syncthreads();
+        const float total = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        tok = mi;
+        prob = 1.0f / total;
+        float dv = -INFINITY;
+        int di = 0;
+        for (int k = 0; k < g.nd; ++k) if (s_dv[k] > dv) { dv = s_dv[k]; di = k; }
+        bin = di;
+    });
 }
 
 }  // namespace
@@ -189,6 +263,31 @@ fa_status fa_tdt_greedy_tables_dev(fa_ctx *ctx, const fa_tdt_config *cfg, const 
     a.final_time = d_final_time; a.final_u = d_final_u; a.status = d_status;
     a.B = batch; a.U = U; a.T = T; a.max_out = max_out; a.cfg = *cfg;
     hipLaunchKernelGGL(tdt_kernel, dim3((batch + 63) / 64), dim3(64), 0, ctx->stream, a);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+
+fa_status fa_tdt_greedy_logits_dev(fa_ctx *ctx, const fa_tdt_config *cfg, const void *d_logits, int32_t dtype, int32_t batch, int32_t U, int32_t T,
+                                   int32_t vocab_with_blank, int64_t row_stride, const int32_t *d_enc_len, const int32_t *d_audio_frames,
+                                   const int32_t *d_t0, const int32_t *d_is_last, const int32_t *d_global_offset, const int32_t *d_emit_after,
+                                   int32_t max_out, int32_t *d_out_tok, int32_t *d_out_time, int32_t *d_out_dur, float *d_out_conf,
+                                   int32_t *d_out_count, int32_t *d_final_time, int32_t *d_final_u, int32_t *d_status) {
+    if (!ctx || !cfg) return FA_INVALID_ARGUMENT;
+    if (batch == 0) return FA_SUCCESS;
+    if (batch < 0 || U < 1 || T < 1 || max_out < 0 || cfg->n_duration_bins < 1 || cfg->n_duration_bins > 8 || vocab_with_blank < 1 ||
+        row_stride < static_cast<int64_t>(vocab_with_blank) + cfg->n_duration_bins || (dtype != FA_DTYPE_F32 && dtype != FA_DTYPE_F16) || !d_logits ||
+        !d_enc_len || !d_out_count || !d_final_time || !d_final_u || !d_status || (max_out > 0 && (!d_out_tok || !d_out_time || !d_out_dur || !d_out_conf)))
+        return fa::set_error(ctx, FA_INVALID_ARGUMENT, "tdt: bad arguments");
+    fa::DeviceGuard guard(ctx->device);
+    TdtArgs a{};
+    a.enc_len = d_enc_len; a.audio_frames = d_audio_frames; a.t0 = d_t0;
+    a.is_last = d_is_last; a.global_offset = d_global_offset; a.emit_after = d_emit_after;
+    a.out_tok = d_out_tok; a.out_time = d_out_time; a.out_dur = d_out_dur; a.out_conf = d_out_conf; a.out_count = d_out_count;
+    a.final_time = d_final_time; a.final_u = d_final_u; a.status = d_status;
+    a.B = batch; a.U = U; a.T = T; a.max_out = max_out; a.cfg = *cfg;
+    TdtLogitArgs g{d_logits, dtype == FA_DTYPE_F16 ? 1 : 0, vocab_with_blank, cfg->n_duration_bins, row_stride};
+    if (g.f16) hipLaunchKernelGGL(tdt_logits_kernel<true>, dim3(batch), dim3(256), 0, ctx->stream, a, g);
+    else hipLaunchKernelGGL(tdt_logits_kernel<false>, dim3(batch), dim3(256), 0, ctx->stream, a, g);
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }

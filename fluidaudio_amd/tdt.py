@@ -69,6 +69,43 @@ class TdtDurationMapping:
         return float(L.lib().fa_tdt_clamp_probability(float(value)))
 
 
+def decode_logits(d_logits, vocab_with_blank: int, enc_len, audio_frames=None, t0=None, is_last=None, global_offset=None, emit_after=None,
+                  config: TdtConfig | None = None, max_out: int = 256, ctx: L.Context | None = None):
+    """Batched greedy walk on joint LOGITS: d_logits torch CUDA tensor [B, U, T, W] (fp32 / fp16, last dim contiguous, W >=
+    vocab_with_blank + number of duration bins).  Same result structure as decode_tables."""
+    import torch
+    ctx = ctx or L.default_context()
+    cfg = (config or TdtConfig()).c()
+    B, U, T, W = d_logits.shape
+    assert d_logits.is_contiguous()
+    dev = d_logits.device
+
+    def vec(v):
+        return None if v is None else torch.as_tensor(np.asarray(v, np.int32)).to(dev)
+
+    v_enc, v_af, v_t0, v_last, v_go, v_ea = (vec(enc_len), vec(audio_frames), vec(t0), vec(is_last), vec(global_offset),
+                                             vec(None if emit_after is None else [-1 if e is None else e for e in emit_after]))
+    o_tok, o_time, o_dur = (torch.zeros((B, max_out), dtype=torch.int32, device=dev) for _ in range(3))
+    o_conf = torch.zeros((B, max_out), dtype=torch.float32, device=dev)
+    o_cnt, o_ft, o_fu, o_st = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(4))
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+    dt = L.DTYPE_F16 if d_logits.dtype == torch.float16 else L.DTYPE_F32
+    with ctx.torch_ordered():
+        ctx.check(L.lib().fa_tdt_greedy_logits_dev(ctx.handle, C.byref(cfg), p(d_logits), dt, B, U, T, int(vocab_with_blank), W, p(v_enc), p(v_af), p(v_t0),
+                                                   p(v_last), p(v_go), p(v_ea), max_out, p(o_tok), p(o_time), p(o_dur), p(o_conf), p(o_cnt), p(o_ft),
+                                                   p(o_fu), p(o_st)), "fa_tdt_greedy_logits_dev")
+    ctx.synchronize()
+    tok, tim, dur, conf = o_tok.cpu().numpy(), o_time.cpu().numpy(), o_dur.cpu().numpy(), o_conf.cpu().numpy()
+    cnt, ft, fu, st = o_cnt.cpu().numpy(), o_ft.cpu().numpy(), o_fu.cpu().numpy(), o_st.cpu().numpy()
+    out = []
+    for b in range(B):
+        n = min(int(cnt[b]), max_out)
+        out.append(dict(status=int(st[b]), tokens=tok[b, :n].copy(), timestamps=tim[b, :n].copy(), durations=dur[b, :n].copy(),
+                        confidences=conf[b, :n].copy(), count=int(cnt[b]), final_time=None if ft[b] == -2 ** 31 else int(ft[b]),
+                        final_u=int(fu[b])))
+    return out
+
+
 def decode_tables(d_tok, d_bin, d_prob, enc_len, audio_frames=None, t0=None, is_last=None, global_offset=None, emit_after=None,
                   config: TdtConfig | None = None, max_out: int = 256, ctx: L.Context | None = None):
     """Batched greedy walk.  d_tok/d_bin (int32) and d_prob (float32): torch CUDA tensors [B, U, T]; per-chunk int

@@ -209,6 +209,19 @@ fa_status fa_tdt_greedy_tables_dev(fa_ctx *ctx, const fa_tdt_config *cfg, const 
                                    int32_t *d_out_tok, int32_t *d_out_time, int32_t *d_out_dur, float *d_out_conf,
                                    int32_t *d_out_count, int32_t *d_final_time, int32_t *d_final_u, int32_t *d_status);
 
+/* The same walk with the joint decisions computed on the fly from joint LOGITS: d_logits[batch][U][T][row_stride] (fp32 or
+ * fp16), token logits in [0, vocab_with_blank), the n_duration_bins duration logits right behind them.  Per visited (u, t):
+ * token = first-index argmax of the token logits (the tie / NaN rule of LogitsArgmax.argmaxPerFrame), probability = its
+ * softmax probability, duration bin = first-index argmax of the duration logits — what the reference's JointDecision model
+ * returns (TdtModelInference.swift:84-188).  One workgroup per chunk reads only the rows on the greedy path.  The joint /
+ * decoder networks are not in the reference tree: token parity UNPINNED. */
+fa_status fa_tdt_greedy_logits_dev(fa_ctx *ctx, const fa_tdt_config *cfg, const void *d_logits, int32_t dtype, int32_t batch,
+                                   int32_t U, int32_t T, int32_t vocab_with_blank, int64_t row_stride, const int32_t *d_enc_len,
+                                   const int32_t *d_audio_frames, const int32_t *d_t0, const int32_t *d_is_last,
+                                   const int32_t *d_global_offset, const int32_t *d_emit_after, int32_t max_out,
+                                   int32_t *d_out_tok, int32_t *d_out_time, int32_t *d_out_dur, float *d_out_conf,
+                                   int32_t *d_out_count, int32_t *d_final_time, int32_t *d_final_u, int32_t *d_status);
+
 /* ------------------------------------------------------------------ AHC ------------- */
 /* Exact signature + status contract of the reference FFI
  * (FastClusterWrapper/include/FastClusterWrapper.h:35-41, FastClusterWrapper.cpp:196-244):

@@ -36,3 +36,39 @@ def test_batched_walk_matches_oracle(fa, gpu_ctx, oracle_mod, B, U, T, p_blank, 
         np.testing.assert_array_equal(g["confidences"], ref["confidences"])
     assert got[0]["final_time"] is None and got[1]["final_time"] is None and got[2]["status"] == 5
     assert sum(g["count"] for g in got) > B   # the tables do produce tokens
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float16"])
+def test_walk_on_joint_logits_equals_walk_on_tables(fa, gpu_ctx, oracle_mod, dtype):
+    """fa_tdt_greedy_logits_dev: the joint decisions (first-index argmax over the token logits, its softmax probability,
+    first-index argmax over the duration logits) are taken inside the walk, on the visited rows only — the same result as
+    building the decision tables for the whole (u, t) grid first (numpy) and walking those (CPU restatement)."""
+    import torch
+    rng = np.random.default_rng(11)
+    B, U, T, V1, nd = 24, 40, 50, 130, 5
+    blank = V1 - 1
+    lg = rng.standard_normal((B, U, T, V1 + nd)).astype(np.float32)
+    lg[..., blank] += 3.2                                  # ~75 % blanks
+    lg[3, 0, 0, 5] = lg[3, 0, 0, 9] = 9.0                  # exact tie -> lowest index
+    lg[4, 0, 1, :V1] = np.nan                              # NaN never wins: an all-NaN row decodes to token 0, probability 0
+    lg = lg.astype(dtype)
+    x = lg.astype(np.float32)
+    tok = np.argmax(np.where(np.isnan(x[..., :V1]), -np.inf, x[..., :V1]), axis=-1).astype(np.int32)
+    bn = np.argmax(x[..., V1:], axis=-1).astype(np.int32)
+    mx = np.max(np.where(np.isnan(x[..., :V1]), -np.inf, x[..., :V1]), axis=-1, keepdims=True)
+    with np.errstate(invalid="ignore"):
+        pr = (1.0 / np.exp(x[..., :V1].astype(np.float64) - mx).sum(-1)).astype(np.float32)
+    assert tok[3, 0, 0] == 5 and tok[4, 0, 1] == 0
+    enc = rng.integers(T // 2, T + 1, B).astype(np.int32)
+    t0 = rng.integers(0, 4, B).astype(np.int32)
+    last = (rng.random(B) < 0.5).astype(np.int32)
+    cfg = fa.TdtConfig(blank_id=blank)
+    got = fa.tdt_decode_logits(torch.from_numpy(lg).cuda(), V1, enc, None, t0, last, None, None, config=cfg, max_out=256, ctx=gpu_ctx)
+    for b in range(B):
+        ref = oracle_mod.tdt_greedy(tok[b], bn[b], pr[b], enc[b], None, t0[b], bool(last[b]), 0, None, max_out=256, blank_id=blank)
+        g = got[b]
+        assert (g["status"], g["count"], g["final_u"], g["final_time"]) == (ref["status"], ref["count"], ref["final_u"], ref["final_time"]), b
+        for k in ("tokens", "timestamps", "durations"):
+            np.testing.assert_array_equal(g[k], ref[k])
+        np.testing.assert_allclose(g["confidences"], ref["confidences"], rtol=2e-5, atol=1e-7)
+    assert sum(g["count"] for g in got) > B
