@@ -52,9 +52,9 @@ __global__ void km_normalize(const double *__restrict__ x, double *__restrict__ 
 
 // assignToCentroids (:154-168): first strict minimum of the sequentially accumulated squared distances.
 __global__ void __launch_bounds__(kThreads) km_assign(const double *__restrict__ xt, const double *__restrict__ cen, int32_t *__restrict__ assign,
-                                                      int32_t *__restrict__ changed, int64_t n, int d, int k, uint64_t active) {
+                                                      int32_t *__restrict__ changed, int64_t n, int d, int k, const int32_t *__restrict__ done) {
     const int r = blockIdx.y;
-    if (!((active >> r) & 1)) return;
+    if (done[r]) return;
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool live = i < n;
     const int64_t ii = live ? i : n - 1;
@@ -92,9 +92,9 @@ __global__ void __launch_bounds__(kThreads) km_assign(const double *__restrict__
 // members of cluster c of run r, counted (pass 0) or written in index order at the cluster's offset (pass 1); one wave each
 template <int PASS>
 __global__ void __launch_bounds__(64) km_members(const int32_t *__restrict__ assign, const int32_t *__restrict__ changed, int32_t *__restrict__ counts,
-                                                 int32_t *__restrict__ list, int64_t n, int k, uint64_t active) {
+                                                 int32_t *__restrict__ list, int64_t n, int k, const int32_t *__restrict__ done) {
     const int r = blockIdx.y, c = blockIdx.x, lane = threadIdx.x;
-    if (!((active >> r) & 1) || !changed[r]) return;
+    if (done[r] || !changed[r]) return;
     const int32_t *a = assign + static_cast<int64_t>(r) * n;
     int64_t base = 0;
     if (PASS == 1) {
@@ -117,12 +117,12 @@ __global__ void __launch_bounds__(64) km_members(const int32_t *__restrict__ ass
 // updateCentroids (:179-207) for the non-empty clusters: sums in embedding-index order, times 1 / count.
 __global__ void __launch_bounds__(kThreads) km_update(const double *__restrict__ xn, const int32_t *__restrict__ changed, const int32_t *__restrict__ counts,
                                                       const int32_t *__restrict__ list, double *__restrict__ cen, int64_t n, int d, int k,
-                                                      uint64_t active) {
+                                                      const int32_t *__restrict__ done) {
     const int r = blockIdx.y, c = blockIdx.x;
-    if (!((active >> r) & 1) || !changed[r]) return;
+    if (done[r] || !changed[r]) return;
     const int32_t *cnts = counts + static_cast<int64_t>(r) * k;
     const int cnt = cnts[c];
-    if (cnt == 0) return;                       // re-seeded by the host from the run's random stream
+    if (cnt == 0) return;                       // re-seeded by km_step_end from the run's pre-drawn random stream
     int64_t base = 0;
     for (int j = 0; j < c; ++j) base += cnts[j];
     const int32_t *mine = list + static_cast<int64_t>(r) * n + base;
@@ -140,6 +140,29 @@ __global__ void __launch_bounds__(kThreads) km_update(const double *__restrict__
         for (; j < cnt; ++j) s = __dadd_rn(s, xn[static_cast<int64_t>(mine[j]) * d + q]);
         cen[(static_cast<int64_t>(r) * k + c) * d + q] = __dmul_rn(s, inv);
     }
+}
+
+// End of a Lloyd iteration for run r (one wavefront): convergence (newAssignments == assignments, :70-73) and the re-seeding of
+// empty clusters in cluster order from the run's random stream (randomElement, :196-199).  The draws do not depend on the data
+// — every one is below(n) on the same generator — so the host pre-draws the sequence (picks[r][0..kPicks)) and the device only
+// keeps a cursor: no host synchronisation inside the iteration loop.  status[1] is raised if a run needs more than kPicks draws.
+constexpr int kPicks = 1024;
+__global__ void __launch_bounds__(64) km_step_end(const int32_t *__restrict__ changed, const int32_t *__restrict__ counts, int32_t *__restrict__ done,
+                                                  int32_t *__restrict__ iters, const int32_t *__restrict__ picks, int32_t *__restrict__ cursor,
+                                                  const double *__restrict__ xn, double *__restrict__ cen, int32_t *__restrict__ status, int it, int d, int k) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (done[r]) return;
+    if (lane == 0) iters[r] = it + 1;
+    if (!changed[r]) { if (lane == 0) done[r] = 1; return; }
+    int cur = cursor[r];
+    for (int c = 0; c < k; ++c) {   // wave-uniform walk over the clusters, the row copy spread over the lanes
+        if (counts[static_cast<int64_t>(r) * k + c] != 0) continue;
+        if (cur >= kPicks) { if (lane == 0) status[1] = 1; break; }
+        const int64_t pick = picks[static_cast<int64_t>(r) * kPicks + cur];
+        ++cur;
+        for (int q = lane; q < d; q += 64) cen[(static_cast<int64_t>(r) * k + c) * d + q] = xn[pick * d + q];
+    }
+    if (lane == 0) cursor[r] = cur;
 }
 
 // per-embedding squared distance to its own centroid (the terms of the inertia, :118-121)
@@ -198,32 +221,40 @@ fa_status lloyd_batch(fa_ctx *ctx, const double *d_xn, const double *d_xt, int64
                                            hipMemcpyDeviceToDevice, st));
     }
     FA_HIP_TRY(ctx, hipMemsetAsync(d_assign, 0, sizeof(int32_t) * runs * n, st));
-    std::vector<int32_t> h_changed(runs), h_counts(static_cast<size_t>(runs) * k);
-    uint64_t active = runs == 64 ? ~0ull : ((1ull << runs) - 1);
+    // pre-drawn re-seeding picks + device-side bookkeeping: done[runs] | iters[runs] | cursor[runs] | status[2] | picks[runs][kPicks]
+    std::vector<int32_t> h_picks(static_cast<size_t>(runs) * kPicks);
+    for (int r = 0; r < runs; ++r)
+        for (int j = 0; j < kPicks; ++j) h_picks[static_cast<size_t>(r) * kPicks + j] = static_cast<int32_t>(rng[r].below(static_cast<uint64_t>(n)));
+    fa::DevBuf d_book;
+    const size_t book_ints = static_cast<size_t>(3) * runs + 2;
+    FA_HIP_TRY(ctx, d_book.alloc(sizeof(int32_t) * (book_ints + h_picks.size())));
+    int32_t *d_done = d_book.as<int32_t>(), *d_iters = d_done + runs, *d_cursor = d_iters + runs, *d_status = d_cursor + runs, *d_picks = d_status + 2;
+    FA_HIP_TRY(ctx, hipMemsetAsync(d_done, 0, sizeof(int32_t) * book_ints, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(d_picks, h_picks.data(), sizeof(int32_t) * h_picks.size(), hipMemcpyHostToDevice, st));
     res.assign(runs, RunResult());
     const dim3 pgrid(static_cast<unsigned>((n + kThreads - 1) / kThreads), runs), cgrid(k, runs);
-    for (int it = 0; it < max_iter && active; ++it) {
+    std::vector<int32_t> h_book(book_ints);
+    constexpr int kSyncEvery = 8;   // iterations between host checks (launches behind the convergence of every run are no-ops)
+    for (int it = 0; it < max_iter; ++it) {
         FA_HIP_TRY(ctx, hipMemsetAsync(d_changed, 0, sizeof(int32_t) * runs, st));
-        hipLaunchKernelGGL(km_assign, pgrid, dim3(kThreads), 0, st, d_xt, d_cen, d_assign, d_changed, n, d, k, active);
-        hipLaunchKernelGGL(km_members<0>, cgrid, dim3(64), 0, st, d_assign, d_changed, d_counts, d_list, n, k, active);
-        hipLaunchKernelGGL(km_members<1>, cgrid, dim3(64), 0, st, d_assign, d_changed, d_counts, d_list, n, k, active);
-        hipLaunchKernelGGL(km_update, cgrid, dim3(std::min(kThreads, ((d + 63) / 64) * 64)), 0, st, d_xn, d_changed, d_counts, d_list, d_cen, n, d, k, active);
+        hipLaunchKernelGGL(km_assign, pgrid, dim3(kThreads), 0, st, d_xt, d_cen, d_assign, d_changed, n, d, k, d_done);
+        hipLaunchKernelGGL(km_members<0>, cgrid, dim3(64), 0, st, d_assign, d_changed, d_counts, d_list, n, k, d_done);
+        hipLaunchKernelGGL(km_members<1>, cgrid, dim3(64), 0, st, d_assign, d_changed, d_counts, d_list, n, k, d_done);
+        hipLaunchKernelGGL(km_update, cgrid, dim3(std::min(kThreads, ((d + 63) / 64) * 64)), 0, st, d_xn, d_changed, d_counts, d_list, d_cen, n, d, k, d_done);
+        hipLaunchKernelGGL(km_step_end, dim3(runs), dim3(64), 0, st, d_changed, d_counts, d_done, d_iters, d_picks, d_cursor, d_xn, d_cen, d_status, it, d, k);
         FA_HIP_TRY(ctx, hipGetLastError());
-        FA_HIP_TRY(ctx, hipMemcpyAsync(h_changed.data(), d_changed, sizeof(int32_t) * runs, hipMemcpyDeviceToHost, st));
-        FA_HIP_TRY(ctx, hipMemcpyAsync(h_counts.data(), d_counts, sizeof(int32_t) * runs * k, hipMemcpyDeviceToHost, st));
-        FA_HIP_TRY(ctx, hipStreamSynchronize(st));
-        for (int r = 0; r < runs; ++r) {
-            if (!((active >> r) & 1)) continue;
-            res[r].iterations = it + 1;
-            if (!h_changed[r]) { active &= ~(1ull << r); continue; }      // newAssignments == assignments (:70-73)
-            for (int c = 0; c < k; ++c) {
-                if (h_counts[static_cast<size_t>(r) * k + c] != 0) continue;
-                const int64_t pick = static_cast<int64_t>(rng[r].below(static_cast<uint64_t>(n)));   // randomElement (:196-199)
-                FA_HIP_TRY(ctx, hipMemcpyAsync(d_cen + (static_cast<int64_t>(r) * k + c) * d, d_xn + pick * d, sizeof(double) * d,
-                                               hipMemcpyDeviceToDevice, st));
-            }
+        if ((it + 1) % kSyncEvery == 0 || it + 1 == max_iter) {
+            FA_HIP_TRY(ctx, hipMemcpyAsync(h_book.data(), d_done, sizeof(int32_t) * book_ints, hipMemcpyDeviceToHost, st));
+            FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (h_book[3 * runs + 1]) return fa::set_error(ctx, FA_RUNTIME_ERROR, "kmeans: more than %d empty-cluster re-seeds in one run", kPicks);
+            bool all = true;
+            for (int r = 0; r < runs; ++r) all = all && h_book[r] != 0;
+            if (all) break;
         }
     }
+    FA_HIP_TRY(ctx, hipMemcpyAsync(h_book.data(), d_done, sizeof(int32_t) * book_ints, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(st));   // also keeps h_picks alive until its upload has completed
+    for (int r = 0; r < runs; ++r) res[r].iterations = h_book[runs + r];
     return FA_SUCCESS;
 }
 

@@ -300,6 +300,67 @@ struct ConstrainedClusterAssignment {
     }
 };
 
+// OfflineDiarizerManager.cluster (…/Offline/Core/OfflineDiarizerManager.swift:270-375) on precomputed embeddings: one device-resident call
+struct OfflineClusteringConfig {   // OfflineDiarizerTypes.swift:155-163,189-192
+    double clusteringThreshold = 0.6, warmStartFa = 0.07, warmStartFb = 0.8, convergenceTolerance = 1e-4;
+    int maxVbxIterations = 20;
+    bool constrainedAssignment = true;
+    std::optional<int> numSpeakers, minSpeakers, maxSpeakers;
+};
+struct OfflineClusteringResult {
+    std::vector<int> assignments;   // -2: slot dropped by the constrained assignment
+    Matrix centroids;
+    fa_offline_cluster_info info{};
+};
+inline OfflineClusteringResult clusterEmbeddings(Context &ctx, const std::vector<std::vector<float>> &embeddings, const Matrix &rhoFeatures, const std::vector<int> &chunkIndices,
+                                                 const std::vector<double> &phi, const OfflineClusteringConfig &config = {}) {
+    if (embeddings.empty()) throw Error(FA_INVALID_ARGUMENT, "noSpeechDetected");   // :281-283
+    const size_t n = embeddings.size(), d = embeddings[0].size();
+    std::vector<float> e(n * d);
+    for (size_t i = 0; i < n; ++i) std::copy(embeddings[i].begin(), embeddings[i].end(), e.begin() + i * d);
+    size_t rn = 0, rd = 0;
+    const std::vector<double> rho = flatten(rhoFeatures, rn, rd);
+    std::vector<double> ph = phi.size() == rd ? phi : std::vector<double>(rd, 1.0);   // VBxClustering.swift:72-76
+    std::vector<int32_t> chunks(chunkIndices.begin(), chunkIndices.end()), labels(n);
+    fa_offline_cluster_config c;
+    fa_offline_cluster_default_config(&c);
+    c.clustering_threshold = config.clusteringThreshold; c.warm_start_fa = config.warmStartFa; c.warm_start_fb = config.warmStartFb;
+    c.max_vbx_iterations = config.maxVbxIterations; c.convergence_tolerance = config.convergenceTolerance; c.constrained_assignment = config.constrainedAssignment ? 1 : 0;
+    c.num_speakers = config.numSpeakers.value_or(-1); c.min_speakers = config.minSpeakers.value_or(-1); c.max_speakers = config.maxSpeakers.value_or(-1);
+    OfflineClusteringResult out;
+    std::vector<double> cen(256 * d);
+    int32_t k = 0;
+    ctx.check(fa_offline_cluster(ctx.handle(), e.data(), static_cast<int64_t>(n), static_cast<int32_t>(d), rd ? rho.data() : nullptr, static_cast<int32_t>(rd), chunks.data(),
+                                 rd ? ph.data() : nullptr, &c, 0, labels.data(), cen.data(), 256, &k, &out.info), "fa_offline_cluster");
+    out.assignments.assign(labels.begin(), labels.end());
+    out.centroids.assign(k, std::vector<double>(d));
+    for (int i = 0; i < k; ++i) std::copy(cen.begin() + static_cast<size_t>(i) * d, cen.begin() + static_cast<size_t>(i + 1) * d, out.centroids[i].begin());
+    return out;
+}
+
+// LuxTtsMelExtractor (Sources/FluidAudio/TTS/LuxTts/LuxTtsMelExtractor.swift:15-132): the torchaudio-flavoured front end, same C ABI
+struct LuxTtsMelExtractor {
+    Context &ctx;
+    static constexpr int nFFT = 1024, hop = 256, nMels = 100, sampleRate = 24000;
+    int frameCount(int sampleCount) const { return (sampleCount + hop / 2) / hop; }   // :45-47
+    std::vector<std::vector<float>> extract(const std::vector<float> &audio) const {
+        const int T = frameCount(static_cast<int>(audio.size()));
+        if (audio.empty() || T <= 0) return {};
+        fa_mel_config c;
+        fa_mel_default_config(&c);
+        c.sample_rate = sampleRate; c.n_mels = nMels; c.n_fft = nFFT; c.hop = hop; c.win = nFFT; c.preemph = 0.0f; c.log_floor = 1e-7f; c.floor_mode = FA_MEL_FLOOR_CLAMPED;
+        c.window_periodic = 1; c.layout = FA_MEL_LAYOUT_FRAME_MAJOR; c.power = 1.0f; c.center_pad = FA_MEL_CENTER_REFLECT; c.mel_scale = FA_MEL_SCALE_HTK_NONORM;
+        c.tail_mode = FA_MEL_TAIL_REPLICATE;
+        std::vector<float> flat(static_cast<size_t>(T) * nMels);
+        const int64_t offs[2] = {0, static_cast<int64_t>(audio.size())};
+        int32_t len = 0, exp = T;
+        ctx.check(fa_mel_batch(ctx.handle(), &c, audio.data(), offs, 1, nullptr, &exp, T, flat.data(), &len), "fa_mel_batch");
+        std::vector<std::vector<float>> out(T, std::vector<float>(nMels));
+        for (int t = 0; t < T; ++t) std::copy(flat.begin() + static_cast<size_t>(t) * nMels, flat.begin() + static_cast<size_t>(t + 1) * nMels, out[t].begin());
+        return out;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------------------------ wire formats
 // AudioWAV.data(from:sampleRate:normalize:) (Sources/FluidAudio/Shared/AudioConverter.swift:474-532)
 struct AudioWAV {

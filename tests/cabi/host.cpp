@@ -114,6 +114,47 @@ static void assignmentAndVbxTests(Context &ctx) {   // ConstrainedClusterAssignm
     CHECK(f.wasAdjusted && f.numClusters == 3 && f.originalClusterCount == 2 && distinct(f.hardClusters, 0, 40) == 3 && f.centroids.size() == 3);
 }
 
+static void composedStageTests(Context &ctx) {   // OfflineDiarizerManager.cluster (:270-375) through the single call; LuxTtsMelExtractorTests.swift:18-41 (shapes)
+    // 3 speakers, 30 two-second windows with 3 local slots each: unit centres + small deterministic jitter
+    std::vector<std::vector<float>> emb;
+    Matrix rho;
+    std::vector<int> chunks, truth;
+    const double centre[3][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}};
+    for (int w = 0; w < 30; ++w)
+        for (int s = 0; s < 3; ++s) {
+            const int spk = (s + w) % 3;
+            std::vector<float> e(8, 0.0f);
+            std::vector<double> r(6, 0.0);
+            for (int k = 0; k < 4; ++k) e[k] = static_cast<float>(centre[spk][k] + 0.01 * (((w * 7 + s * 3 + k) % 5) - 2));
+            for (int k = 0; k < 6; ++k) r[k] = 6.0 * ((spk == k % 3) ? 1.0 : -0.5) + 0.05 * (((w * 5 + k) % 7) - 3);
+            emb.push_back(e); rho.push_back(r); chunks.push_back(w); truth.push_back(spk);
+        }
+    const std::vector<double> phi{2.0, 1.8, 1.6, 1.4, 1.2, 1.0};
+    auto res = clusterEmbeddings(ctx, emb, rho, chunks, phi);
+    bool pure = res.centroids.size() == 3 && res.info.constrained == 1 && res.info.training_rows == 90;
+    for (size_t i = 0; pure && i < truth.size(); ++i) for (size_t j = 0; pure && j < truth.size(); ++j) pure = (truth[i] == truth[j]) == (res.assignments[i] == res.assignments[j]);
+    CHECK(pure);
+    // the same through the single-stage mirrors (AHCClustering -> VBxClustering -> ...): identical initial partition size
+    Matrix e64;
+    for (const auto &e : emb) e64.emplace_back(e.begin(), e.end());
+    CHECK(static_cast<int>(distinct(AHCClustering{ctx}.cluster(e64, 0.6), 0, 90)) == res.info.initial_clusters);
+    OfflineClusteringConfig forced;
+    forced.numSpeakers = 2;
+    auto f2 = clusterEmbeddings(ctx, emb, rho, chunks, phi, forced);
+    CHECK(f2.info.was_adjusted == 1 && f2.info.constrained == 0 && f2.centroids.size() == 2 && distinct(f2.assignments, 0, 90) == 2);
+    bool threw = false;
+    try { clusterEmbeddings(ctx, {}, {}, {}, phi); } catch (const Error &) { threw = true; }
+    CHECK(threw);
+    LuxTtsMelExtractor lux{ctx};
+    std::vector<float> a(24000);
+    for (size_t i = 0; i < a.size(); ++i) a[i] = 0.2f * std::sin(0.03f * static_cast<float>(i));
+    auto m = lux.extract(a);
+    CHECK(lux.frameCount(24000) == 94 && m.size() == 94 && m[0].size() == 100 && lux.extract({}).empty());
+    bool finite = true;
+    for (const auto &row : m) for (float v : row) finite = finite && std::isfinite(v) && v >= std::log(1e-7f) - 1e-3f;
+    CHECK(finite);
+}
+
 static void melAndFormatTests(Context &ctx) {   // AudioMelSpectrogramTests.swift:22-122 (shapes, frame counts); AudioConverter.swift:474-532
     AudioMelSpectrogram mel(ctx);
     std::vector<float> a(16000);
@@ -156,6 +197,7 @@ int main(int argc, char **argv) {
     speakerCountAndKMeansTests(ctx);
     assignmentAndVbxTests(ctx);
     melAndFormatTests(ctx);
+    composedStageTests(ctx);
     std::printf("%d failed\n", failures);
     return failures;
 }
