@@ -688,6 +688,7 @@ struct fa_mel_plan {
     bool edge_zero = false;  // the zero-extended window vanishes on positions [0, 32) and [480, 512) of the frame
     int v4_wps = 0;          // > 0: mel_kernel_v4 with that many workgroups per CU (packed kernel, 128 mels, hop 160)
     unsigned long long launches = 0;   // v4 launches made so far (spaces the tile-queue ranges)
+    bool v4_deep = false;              // tile queue two tiles ahead (FA_MEL_V4_DEEP=1)
     bool generic = false;    // mel_generic_kernel (any n_fft, magnitude, reflect padding, replicated tail)
     fa::melgen::GenArgs gargs{};
 };
@@ -931,7 +932,8 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         if (p->pk && cfg->n_mels == kFastGroups * kGroup) {   // FA_MEL_V4=0: the v3 kernel (diagnostics); FA_MEL_V4=4: four workgroups per CU
             const char *ve = getenv("FA_MEL_V4");
             p->v4_wps = ve ? atoi(ve) : 3;
-            if (p->v4_wps != 3 && p->v4_wps != 4) p->v4_wps = 0;
+            if (p->v4_wps != 3) p->v4_wps = 0;
+            if (const char *de = getenv("FA_MEL_V4_DEEP")) p->v4_deep = atoi(de) != 0;
         }
         p->lds_bytes = sizeof(float) * (a.stage_alloc + kRegions * (p->pk ? kRegionFloatsPk : kRegionFloats) + a.out_alloc) + sizeof(int32_t) * kMaxMels +
                        sizeof(float) * (static_cast<size_t>(a.n_weights) + 24 + 4 + (p->pk ? fa::melpk::kWindowTableFloats : 0));   // the paired weight reads of the packed kernel touch one slot row past the table
@@ -950,11 +952,11 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<0, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel<1, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lb);
-#define FA_V4_ATTR(L, E, W, A) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel_v4<L, E, W, A>), hipFuncAttributeMaxDynamicSharedMemorySize, lb)
-            FA_V4_ATTR(0, true, 3, true); FA_V4_ATTR(0, true, 3, false); FA_V4_ATTR(0, false, 3, true); FA_V4_ATTR(0, false, 3, false);
-            FA_V4_ATTR(0, true, 4, true); FA_V4_ATTR(0, true, 4, false); FA_V4_ATTR(0, false, 4, true); FA_V4_ATTR(0, false, 4, false);
-            FA_V4_ATTR(1, true, 3, true); FA_V4_ATTR(1, true, 3, false); FA_V4_ATTR(1, false, 3, true); FA_V4_ATTR(1, false, 3, false);
-            FA_V4_ATTR(1, true, 4, true); FA_V4_ATTR(1, true, 4, false); FA_V4_ATTR(1, false, 4, true); FA_V4_ATTR(1, false, 4, false);
+#define FA_V4_ATTR(L, E) do { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel_v4<L, E, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb); \
+                              (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel_v4<L, E, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb); \
+                              (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel_v4<L, E, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb); \
+                              (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mel_kernel_v4<L, E, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb); } while (0)
+            FA_V4_ATTR(0, true); FA_V4_ATTR(0, false); FA_V4_ATTR(1, true); FA_V4_ATTR(1, false);
 #undef FA_V4_ATTR
         }
         hipDeviceProp_t prop;
@@ -1056,14 +1058,14 @@ fa_status fa_mel_execute_dev(fa_mel_plan *p, const float *d_pcm, const float *d_
     if (p->v4_wps) {
         // every workgroup draws one index per tile it processes plus the one that tells it to stop: a launch advances the
         // counter by exactly total_tiles + grid
-        a.queue_base = p->launches++ * (static_cast<unsigned long long>(a.total_tiles) + static_cast<unsigned long long>(p->grid));
-        const bool ez = p->edge_zero, w4 = p->v4_wps == 4;
-#define FA_V4(L, E, W) do { if (p->cfg.floor_mode == FA_MEL_FLOOR_CLAMPED) hipLaunchKernelGGL((mel_kernel_v4<L, E, W, true>), grid, block, p->lds_bytes, ctx->stream, a); \
-                             else hipLaunchKernelGGL((mel_kernel_v4<L, E, W, false>), grid, block, p->lds_bytes, ctx->stream, a); } while (0)
-        if (mm) { if (ez) { if (w4) FA_V4(FA_MEL_LAYOUT_MEL_MAJOR, true, 4); else FA_V4(FA_MEL_LAYOUT_MEL_MAJOR, true, 3); }
-                  else { if (w4) FA_V4(FA_MEL_LAYOUT_MEL_MAJOR, false, 4); else FA_V4(FA_MEL_LAYOUT_MEL_MAJOR, false, 3); } }
-        else { if (ez) { if (w4) FA_V4(FA_MEL_LAYOUT_FRAME_MAJOR, true, 4); else FA_V4(FA_MEL_LAYOUT_FRAME_MAJOR, true, 3); }
-               else { if (w4) FA_V4(FA_MEL_LAYOUT_FRAME_MAJOR, false, 4); else FA_V4(FA_MEL_LAYOUT_FRAME_MAJOR, false, 3); } }
+        a.queue_base = p->launches++ * (static_cast<unsigned long long>(a.total_tiles) + static_cast<unsigned long long>(p->v4_deep ? 2 : 1) * static_cast<unsigned long long>(p->grid));
+        const bool ez = p->edge_zero, w4 = p->v4_deep;   // w4: the deep-queue variant
+#define FA_V4(L, E, D) do { if (p->cfg.floor_mode == FA_MEL_FLOOR_CLAMPED) hipLaunchKernelGGL((mel_kernel_v4<L, E, D, true>), grid, block, p->lds_bytes, ctx->stream, a); \
+                             else hipLaunchKernelGGL((mel_kernel_v4<L, E, D, false>), grid, block, p->lds_bytes, ctx->stream, a); } while (0)
+        if (mm) { if (ez) { if (w4) FA_V4(FA_MEL_LAYOUT_MEL_MAJOR, true, true); else FA_V4(FA_MEL_LAYOUT_MEL_MAJOR, true, false); }
+                  else { if (w4) FA_V4(FA_MEL_LAYOUT_MEL_MAJOR, false, true); else FA_V4(FA_MEL_LAYOUT_MEL_MAJOR, false, false); } }
+        else { if (ez) { if (w4) FA_V4(FA_MEL_LAYOUT_FRAME_MAJOR, true, true); else FA_V4(FA_MEL_LAYOUT_FRAME_MAJOR, true, false); }
+               else { if (w4) FA_V4(FA_MEL_LAYOUT_FRAME_MAJOR, false, true); else FA_V4(FA_MEL_LAYOUT_FRAME_MAJOR, false, false); } }
 #undef FA_V4
         FA_HIP_TRY(ctx, hipGetLastError());
         return FA_SUCCESS;
