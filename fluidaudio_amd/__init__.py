@@ -13,6 +13,7 @@ from .kmeans import KMeansClustering, SeededRNG, SpeakerCountConstraints  # noqa
 from .mel import AudioMelSpectrogram, LuxTtsMelExtractor, MelPlan, UnifiedMelExtractor  # noqa: F401
 from .pipeline import (ClusteringResult, OfflineClusteringConfig, cluster_embeddings, cluster_embeddings_stagewise,  # noqa: F401
                        select_training_embeddings)
+from .pool import Pool, device_count  # noqa: F401
 from .post import (ConstrainedClusterAssignment, HungarianAssignment, assign_embeddings, centroid_scores,  # noqa: F401
                    compute_centroids)
 from .resample import linear_resample, poly_taps, resample_poly  # noqa: F401

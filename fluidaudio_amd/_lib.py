@@ -45,6 +45,8 @@ EXPORTED_SYMBOLS = [
     "fa_wav_pcm16_size", "fa_wav_encode_pcm16", "fa_wav_decode", "fa_rttm_parse", "fa_rttm_format", "fa_export_embeddings_json",
     "fa_seeded_rng_next", "fa_seeded_rng_below", "fa_kmeans_cluster", "fa_kmeans_cluster_ninit", "fa_speaker_constraints_resolve",
     "fa_resample_linear_frames", "fa_resample_linear", "fa_resample_poly_frames", "fa_resample_poly_taps", "fa_resample_poly", "fa_resample_poly_dev",
+    "fa_device_count", "fa_pool_create", "fa_pool_destroy", "fa_pool_size", "fa_pool_context", "fa_ctx_device", "fa_pool_acquire", "fa_pool_release",
+    "fa_mel_batch_sharded", "fa_ctc_greedy_batch_sharded", "fa_ahc_linkage_many",
 ]
 
 
@@ -107,6 +109,12 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the product path)")
+    try:
+        # torch's wheel bundles its own ROCm runtime: when libfluidaudio_hip.so pulls /opt/rocm's libamdhip64 into the process
+        # FIRST, a later `import torch` sees no device (measured on the MI355X box).  Loading torch first makes both use one runtime.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
     L.fa_version.restype = C.c_char_p
@@ -215,6 +223,22 @@ def lib() -> C.CDLL:
     L.fa_resample_poly_taps.argtypes = [i32, i32, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.fa_resample_poly.argtypes = [vp, vp, i64, i32, i32, vp, i64, C.POINTER(i64)]
     L.fa_resample_poly_dev.argtypes = [vp, vp, i64, i32, i32, vp, i64, C.POINTER(i64)]
+    L.fa_device_count.argtypes = [C.POINTER(i32)]
+    L.fa_pool_create.argtypes = [vp, i32, C.POINTER(vp)]
+    L.fa_pool_destroy.argtypes = [vp]
+    L.fa_pool_destroy.restype = None
+    L.fa_pool_size.argtypes = [vp]
+    L.fa_pool_size.restype = i32
+    L.fa_pool_context.argtypes = [vp, i32]
+    L.fa_pool_context.restype = vp
+    L.fa_ctx_device.argtypes = [vp]
+    L.fa_ctx_device.restype = i32
+    L.fa_pool_acquire.argtypes = [vp, C.POINTER(vp)]
+    L.fa_pool_release.argtypes = [vp, vp]
+    L.fa_pool_release.restype = None
+    L.fa_mel_batch_sharded.argtypes = [vp, C.POINTER(MelConfig), vp, vp, i32, vp, vp, i32, vp, vp]
+    L.fa_ctc_greedy_batch_sharded.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, vp, i32, vp, vp, vp]
+    L.fa_ahc_linkage_many.argtypes = [vp, i32, vp, vp, sz, vp, i32, vp, vp]
     _lib = L
     return L
 

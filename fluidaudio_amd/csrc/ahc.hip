@@ -1360,9 +1360,6 @@ fa_status linkage_checks(const double *data, size_t n, size_t d, double *z, size
     return FA_SUCCESS;
 }
 
-std::mutex g_default_mutex;
-fa_ctx *g_default_ctx = nullptr;
-
 }  // namespace
 
 extern "C" {
@@ -1452,15 +1449,16 @@ fastcluster_wrapper_status fastcluster_compute_centroid_linkage(const double *da
     const fa_status pre = linkage_checks(data, pointCount, dimension, dendrogramOut, dendrogramLength, &trivial);
     if (pre != FA_SUCCESS || trivial) return static_cast<fastcluster_wrapper_status>(pre);
     try {
-        std::lock_guard<std::mutex> lock(g_default_mutex);  // re-entrant from any thread; calls are serialised on the one device
-        if (!g_default_ctx) {
-            int dev = 0;
-            if (const char *env = getenv("FLUIDAUDIO_HIP_DEVICE")) dev = atoi(env);
-            const fa_status st = fa_ctx_create(dev, nullptr, &g_default_ctx);
-            if (st != FA_SUCCESS) return static_cast<fastcluster_wrapper_status>(st == FA_ALLOCATION_FAILURE ? st : FA_RUNTIME_ERROR);
-        }
+        // re-entrant from any thread: every call borrows one context of the default device set (pool.hip) for its duration, so
+        // concurrent callers run on different GPUs (FLUIDAUDIO_HIP_DEVICES) and queue only when all of them are taken
+        fa_pool *pool = nullptr;
+        const fa_status ps = fa::default_pool(&pool);
+        if (ps != FA_SUCCESS) return static_cast<fastcluster_wrapper_status>(ps == FA_ALLOCATION_FAILURE ? ps : FA_RUNTIME_ERROR);
+        fa_ctx *ctx = nullptr;
+        if (fa_pool_acquire(pool, &ctx) != FA_SUCCESS) return FASTCLUSTER_WRAPPER_RUNTIME_ERROR;
+        struct Release { fa_pool *p; fa_ctx *c; ~Release() { fa_pool_release(p, c); } } release{pool, ctx};
         return static_cast<fastcluster_wrapper_status>(
-            fa_ahc_linkage(g_default_ctx, data, pointCount, dimension, dendrogramOut, dendrogramLength, FA_AHC_MODE_AUTO, 0, nullptr));
+            fa_ahc_linkage(ctx, data, pointCount, dimension, dendrogramOut, dendrogramLength, FA_AHC_MODE_AUTO, 0, nullptr));
     } catch (const std::bad_alloc &) {
         return FASTCLUSTER_WRAPPER_ALLOCATION_FAILURE;
     } catch (const std::exception &) {

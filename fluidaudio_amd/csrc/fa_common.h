@@ -88,6 +88,8 @@ fa_status scores_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, con
 fa_status assign_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_cent, int32_t K, double *d_cn, int32_t *d_out);
 fa_status constrained_assign_dev(fa_ctx *ctx, const double *d_scores, int64_t n, int32_t K, const int32_t *chunk_indices_host, int32_t *d_out);
 
+fa_status default_pool(fa_pool **out);   // pool.hip: the device set behind the context-free drop-in symbol
+
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) {

@@ -688,7 +688,7 @@ struct fa_mel_plan {
     bool edge_zero = false;  // the zero-extended window vanishes on positions [0, 32) and [480, 512) of the frame
     int v4_wps = 0;          // > 0: mel_kernel_v4 with that many workgroups per CU (packed kernel, 128 mels, hop 160)
     unsigned long long launches = 0;   // v4 launches made so far (spaces the tile-queue ranges)
-    bool v4_deep = false;              // tile queue two tiles ahead (FA_MEL_V4_DEEP=1)
+    bool v4_deep = true;               // tile queue two tiles ahead: the next tile's samples travel during the second pass (FA_MEL_V4_DEEP=0: one ahead)
     bool generic = false;    // mel_generic_kernel (any n_fft, magnitude, reflect padding, replicated tail)
     fa::melgen::GenArgs gargs{};
 };

@@ -457,6 +457,36 @@ fa_status fa_resample_poly(fa_ctx *ctx, const float *x, int64_t frames, int32_t 
 fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, int32_t up, int32_t down, float *d_y,
                                int64_t out_capacity, int64_t *out_frames);
 
+/* ------------------------------------------------------------------ device set ------ */
+/* Multi-GPU for a single-process host (the reference has no multi-device notion; SURVEY §8e: utterances, logit matrices and
+ * recordings are independent units, nothing is exchanged).  A pool holds one context per listed device; listing a device
+ * twice gives two contexts (two streams) on it.  devices == NULL / n_devices == 0: every visible device.
+ *   * fa_pool_acquire blocks until a context is free and hands it to the calling thread; fa_pool_release returns it.
+ *     The context-free drop-in symbol fastcluster_compute_centroid_linkage does exactly this on a default pool built from
+ *     FLUIDAUDIO_HIP_DEVICES="0,1,.." (default: all devices; FLUIDAUDIO_HIP_DEVICE=<one id> is still honoured), so concurrent
+ *     AHCClustering.cluster calls (FluidAudio/Diarizer/Offline/Core/OfflineDiarizerManager.swift:270) run on different GPUs.
+ *   * the _sharded / _many entries split ONE host-pointer call across all contexts of the pool (contiguous utterance ranges
+ *     balanced by samples; matrices by count; recordings dealt longest-first), one host thread per context, results written
+ *     straight into the caller's buffers with the geometry of the unsharded entry; they return the first failure. */
+typedef struct fa_pool fa_pool;
+fa_status fa_device_count(int32_t *count);
+fa_status fa_pool_create(const int32_t *devices, int32_t n_devices, fa_pool **out);
+void fa_pool_destroy(fa_pool *pool);
+int32_t fa_pool_size(const fa_pool *pool);
+fa_ctx *fa_pool_context(fa_pool *pool, int32_t index);   /* the pool keeps ownership */
+int32_t fa_ctx_device(const fa_ctx *ctx);
+fa_status fa_pool_acquire(fa_pool *pool, fa_ctx **ctx);
+void fa_pool_release(fa_pool *pool, fa_ctx *ctx);
+fa_status fa_mel_batch_sharded(fa_pool *pool, const fa_mel_config *cfg, const float *pcm, const int64_t *offsets, int32_t batch,
+                               const float *last_samples, const int32_t *expected_frames, int32_t frame_stride, float *mel,
+                               int32_t *mel_lengths);
+fa_status fa_ctc_greedy_batch_sharded(fa_pool *pool, const void *logits, int32_t dtype, int32_t batch, int32_t frames, int32_t vocab,
+                                      int64_t row_stride, int64_t matrix_stride, const int32_t *valid_frames, int32_t blank_id,
+                                      int32_t *frame_ids, int32_t *token_ids, int32_t *token_lens);
+/* recordings across devices, and on each device advanced together by fa_ahc_linkage_batch; HOST pointers */
+fa_status fa_ahc_linkage_many(fa_pool *pool, int32_t count, const double *const *data, const size_t *n, size_t d,
+                              double *const *dendrograms, int32_t mode, fa_ahc_stats *stats, int32_t *statuses);
+
 #ifdef __cplusplus
 }
 #endif
