@@ -40,6 +40,55 @@ private:
     fa_ctx *h_ = nullptr;
 };
 
+// A set of devices for one host process (fa_pool): `lease()` hands the calling thread a context of a free device for the
+// lifetime of the returned object — what a host with several OfflineDiarizerManager instances (one per worker thread, the
+// reference's model: OfflineDiarizerManager.swift:270) needs to use every GPU; the *_sharded calls split one batch over all of them.
+class DevicePool {
+public:
+    DevicePool() { const fa_status st = fa_pool_create(nullptr, 0, &h_); if (st != FA_SUCCESS) throw Error(st, "fa_pool_create"); }
+    explicit DevicePool(const std::vector<int32_t> &devices) {
+        const fa_status st = fa_pool_create(devices.data(), static_cast<int32_t>(devices.size()), &h_);
+        if (st != FA_SUCCESS) throw Error(st, "fa_pool_create");
+    }
+    ~DevicePool() { fa_pool_destroy(h_); }
+    DevicePool(const DevicePool &) = delete;
+    DevicePool &operator=(const DevicePool &) = delete;
+    int size() const { return fa_pool_size(h_); }
+    fa_pool *handle() const { return h_; }
+    struct Lease {
+        fa_pool *pool; fa_ctx *ctx;
+        Lease(fa_pool *p, fa_ctx *c) : pool(p), ctx(c) {}
+        Lease(Lease &&o) noexcept : pool(o.pool), ctx(o.ctx) { o.ctx = nullptr; }
+        Lease(const Lease &) = delete;
+        Lease &operator=(const Lease &) = delete;
+        ~Lease() { if (ctx) fa_pool_release(pool, ctx); }
+        int device() const { return fa_ctx_device(ctx); }
+    };
+    Lease lease() { fa_ctx *c = nullptr; const fa_status st = fa_pool_acquire(h_, &c); if (st != FA_SUCCESS) throw Error(st, "fa_pool_acquire"); return Lease(h_, c); }
+    // recordings across the devices (fa_ahc_linkage_many): row-major fp64 matrices in, scipy-layout dendrograms out, per-problem statuses
+    std::vector<fa_status> linkageMany(const std::vector<std::vector<double>> &data, size_t d, std::vector<std::vector<double>> &dendrograms) {
+        const size_t k = data.size();
+        std::vector<const double *> dp(k);
+        std::vector<double *> zp(k);
+        std::vector<size_t> n(k);
+        std::vector<int32_t> st(k, 0);
+        dendrograms.assign(k, {});
+        static double dummy[4];
+        for (size_t i = 0; i < k; ++i) {
+            n[i] = d ? data[i].size() / d : 0;
+            dendrograms[i].assign(n[i] > 1 ? (n[i] - 1) * 4 : 0, 0.0);
+            dp[i] = data[i].empty() ? dummy : data[i].data();
+            zp[i] = dendrograms[i].empty() ? dummy : dendrograms[i].data();
+        }
+        (void)fa_ahc_linkage_many(h_, static_cast<int32_t>(k), dp.data(), n.data(), d, zp.data(), FA_AHC_MODE_AUTO, nullptr, st.data());
+        std::vector<fa_status> out(k);
+        for (size_t i = 0; i < k; ++i) out[i] = static_cast<fa_status>(st[i]);
+        return out;
+    }
+private:
+    fa_pool *h_ = nullptr;
+};
+
 // ------------------------------------------------------------------------------------------------------------------ mel
 // AudioMelSpectrogram (Sources/FluidAudio/Shared/AudioMelSpectrogram.swift:59-70 ctor, :185-292 computeFlat, :325-456 computeFlatTransposed)
 class AudioMelSpectrogram {

@@ -179,6 +179,29 @@ static void melAndFormatTests(Context &ctx) {   // AudioMelSpectrogramTests.swif
     CHECK(threw);
 }
 
+static void devicePoolTests() {   // several OfflineDiarizerManager-style workers in one process (OfflineDiarizerManager.swift:270), one lease each
+    DevicePool pool(std::vector<int32_t>{0, 0});
+    CHECK(pool.size() == 2);
+    {
+        auto a = pool.lease();
+        auto b = pool.lease();
+        CHECK(a.ctx != b.ctx && a.device() == 0 && b.device() == 0);
+    }
+    std::vector<std::vector<double>> data(3), z;
+    for (int p = 0; p < 3; ++p)
+        for (int i = 0; i < 40 + 13 * p; ++i) for (int k = 0; k < 5; ++k) data[static_cast<size_t>(p)].push_back(std::sin(0.37 * (i * 5 + k) + p) + 0.01 * i);
+    auto st = pool.linkageMany(data, 5, z);
+    bool ok = st.size() == 3;
+    for (int p = 0; ok && p < 3; ++p) {
+        const size_t n = data[static_cast<size_t>(p)].size() / 5;
+        std::vector<double> alone((n - 1) * 4);
+        ok = st[static_cast<size_t>(p)] == FA_SUCCESS &&
+             fastcluster_compute_centroid_linkage(data[static_cast<size_t>(p)].data(), n, 5, alone.data(), alone.size()) == FASTCLUSTER_WRAPPER_SUCCESS &&
+             alone == z[static_cast<size_t>(p)];
+    }
+    CHECK(ok);
+}
+
 int main(int argc, char **argv) {
     if (argc > 1 && std::strcmp(argv[1], "link") == 0) {   // CPU tier: the header compiles, the library links, host-only pieces work
         ARPALanguageModel lm("\\1-grams:\n-1.0\ta\n\\end\\\n");
@@ -198,6 +221,7 @@ int main(int argc, char **argv) {
     assignmentAndVbxTests(ctx);
     melAndFormatTests(ctx);
     composedStageTests(ctx);
+    devicePoolTests();
     std::printf("%d failed\n", failures);
     return failures;
 }

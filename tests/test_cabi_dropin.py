@@ -16,7 +16,7 @@ def build(fa):
     fa.lib()                                                    # makes sure the library is built
     src = os.path.join(ROOT, "tests", "cabi", "dropin.c")
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(LIBDIR, "libfluidaudio_hip.so"))):
-        subprocess.run(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", EXE, "-L", LIBDIR, "-lfluidaudio_hip",
+        subprocess.run(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", EXE, "-L", LIBDIR, "-lfluidaudio_hip", "-lpthread",
                         "-Wl,-rpath," + LIBDIR], check=True)
     return EXE
 
@@ -40,6 +40,14 @@ def test_c_host_dendrogram_equals_reference_build(fa, oracle_mod):
     assert st == 0
     np.testing.assert_array_equal(got, want)                    # %.17g round-trips doubles
     assert [tuple(int(v) for v in row[[0, 1, 3]]) for row in got] == [(0, 2, 2), (3, 5, 2), (1, 6, 3), (4, 7, 3), (8, 9, 6)]   # tie-free variant of the SURVEY §8(c) probe
+
+
+@pytest.mark.gpu
+def test_c_host_device_set(fa):
+    """fa_pool_* from plain C with pthreads: sharded mel == unsharded mel byte for byte; 6 concurrent callers of the context-free
+    drop-in symbol (default pool = device 0 twice) each get the dendrogram of a lone call."""
+    r = subprocess.run([build(fa), "pool"], capture_output=True, text=True, timeout=300, env=dict(os.environ, FLUIDAUDIO_HIP_DEVICES="0,0"))
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout + r.stderr
 
 
 HOST = os.path.join(ROOT, "tests", "cabi", "host")
