@@ -92,12 +92,16 @@ __device__ __forceinline__ uint32_t ord_f32(float f) {
 }
 __device__ __forceinline__ uint64_t desc_key(float value, uint32_t order) { return (static_cast<uint64_t>(~ord_f32(value)) << 32) | order; }
 
+// max + log(exp(a - max) + exp(b - max)) evaluated in double and rounded to float.  exp(0) is exactly 1, so the sum is 1 + exp(-|a - b|)
+// (one exp); and when |a - b| > 18.1 the correction log1p(exp(-d)) < 1.4e-8 is below half an ulp of any |max| >= 1, so the rounded
+// result IS max — the same bits as the full evaluation, without the two libm calls (most (pb, pnb) pairs late in an utterance).
 __device__ __forceinline__ float log_add_exp(float a, float b) {   // CtcDecoder.swift:279-284
     if (a == -INFINITY) return b;
     if (b == -INFINITY) return a;
-    const float m = fmaxf(a, b);
-    const double s = exp(static_cast<double>(a - m)) + exp(static_cast<double>(b - m));
-    return static_cast<float>(static_cast<double>(m) + log(s));
+    const float m = fmaxf(a, b), d = fabsf(a - b);
+    if (d > 18.1f && fabsf(m) >= 1.0f) return m;
+    const double sum = 1.0 + exp(-static_cast<double>(d));
+    return static_cast<float>(static_cast<double>(m) + log(sum));
 }
 
 struct Beams {   // structure of arrays in LDS
@@ -123,16 +127,32 @@ struct Shared {
     int32_t stay_ord[kMaxBeam]; float stay_pb[kMaxBeam], stay_pnb[kMaxBeam], tot[kMaxBeam];
     int32_t top_tok[kMaxTop], top_boundary[kMaxTop]; float top_lp[kMaxTop];
     unsigned long long sel_key[kMaxBeam];
-    int32_t hist[256];
+    int32_t rank_hi[kMaxBeam], wave_total[4];
+    int32_t hist2[2][256];
     int32_t map_node[kMapSlots], map_node_val[kMapSlots];
     int32_t map_pl_parent[kMapSlots], map_pl_tok[kMapSlots], map_pl_val[kMapSlots];
-    unsigned long long thr;
+    unsigned long long thr, all_and, all_or;
     int32_t sel_count, bin, remaining, done, n_beams;
+    float blank_lp;
 };
 
-// K smallest of `n` distinct 64-bit keys: returns (through s.thr) the K-th smallest key.  key(i) may be ~0ull for "absent".
+// OR over the wavefront of a 32-bit word (DPP row shifts + row broadcasts; lane 63 holds the result)
+__device__ __forceinline__ unsigned wave_or(unsigned v) {
+#define FA_BEAM_OR(CTRL, MASK) v |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, MASK, 0xf, false));
+    FA_BEAM_OR(0x111, 0xf) FA_BEAM_OR(0x112, 0xf) FA_BEAM_OR(0x114, 0xf) FA_BEAM_OR(0x118, 0xf) FA_BEAM_OR(0x142, 0xa) FA_BEAM_OR(0x143, 0xc)
+#undef FA_BEAM_OR
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+
+// K smallest of `n` distinct 64-bit keys: returns (through s.thr) a threshold such that the keys <= thr are the K smallest plus at most
+// `room - K` more (the caller sorts what it gathers and keeps the first K).  key(i) may be ~0ull for "absent".
+// Most-significant-digit radix select, 8 bits per pass, with two shortcuts that matter here:
+//   * the digits every present key agrees on are skipped (AND / OR of all keys): log-probabilities of one frame share sign and most
+//     of the exponent, so the first pass or two would send EVERY key to one histogram bin — 64 lanes on one LDS address, the
+//     slowest thing the LDS does;
+//   * the passes stop as soon as the keys below the threshold bin plus the bin itself fit into `room` (the gather buffer).
 template <class KeyFn>
-__device__ void radix_select(Shared &s, const int n, int k, KeyFn key) {
+__device__ void radix_select(Shared &s, const int n, int k, const int room, KeyFn key) {
     const int tid = threadIdx.x;
     unsigned long long prefix = 0;
     if (k <= 0) {   // nothing to select: no key is <= 0
@@ -140,19 +160,31 @@ __device__ void radix_select(Shared &s, const int n, int k, KeyFn key) {
         __syncthreads();
         return;
     }
-    if (tid == 0) { s.done = 0; s.remaining = k; }
-    for (int pass = 0; pass < 8; ++pass) {
+    if (tid == 0) { s.done = 0; s.remaining = k; s.all_and = ~0ull; s.all_or = 0; }
+    __syncthreads();
+    {
+        unsigned long long kand = ~0ull, kor = 0;
+        for (int i = tid; i < n; i += kThreads) { const unsigned long long kk = key(i); if (kk != ~0ull) { kand &= kk; kor |= kk; } }
+        const unsigned ah = ~wave_or(~static_cast<unsigned>(kand >> 32)), al = ~wave_or(~static_cast<unsigned>(kand));
+        const unsigned oh = wave_or(static_cast<unsigned>(kor >> 32)), ol = wave_or(static_cast<unsigned>(kor));
+        if ((tid & 63) == 0) { atomicAnd(&s.all_and, (static_cast<unsigned long long>(ah) << 32) | al); atomicOr(&s.all_or, (static_cast<unsigned long long>(oh) << 32) | ol); }
+    }
+    __syncthreads();
+    const unsigned long long differ = s.all_and ^ s.all_or;           // 0: at most one distinct key present
+    const int first_pass = differ ? __clzll(static_cast<long long>(differ)) >> 3 : 7;
+    if (first_pass > 0) prefix = s.all_or >> (64 - 8 * first_pass);   // the digits all present keys share
+    for (int pass = first_pass; pass < 8; ++pass) {
         const int shift = 56 - 8 * pass;
-        s.hist[tid] = 0;
+        s.hist2[0][tid] = 0;
         __syncthreads();
         if (s.done) break;
         for (int i = tid; i < n; i += kThreads) {   // plain LDS atomics: wave-aggregating the increments was measured slower
             const unsigned long long kk = key(i);
-            if (pass == 0 || (kk >> (shift + 8)) == prefix) atomicAdd(&s.hist[(kk >> shift) & 255], 1);
+            if (kk != ~0ull && (pass == 0 || (kk >> (shift + 8)) == prefix)) atomicAdd(&s.hist2[0][(kk >> shift) & 255], 1);
         }
         __syncthreads();
         if (tid < 64) {   // wave 0: bin where the running count reaches `remaining`
-            const int h0 = s.hist[4 * tid], h1 = s.hist[4 * tid + 1], h2 = s.hist[4 * tid + 2], h3 = s.hist[4 * tid + 3];
+            const int h0 = s.hist2[0][4 * tid], h1 = s.hist2[0][4 * tid + 1], h2 = s.hist2[0][4 * tid + 2], h3 = s.hist2[0][4 * tid + 3];
             const int mine = h0 + h1 + h2 + h3;
             int incl = mine;
 #pragma unroll
@@ -161,10 +193,11 @@ __device__ void radix_select(Shared &s, const int n, int k, KeyFn key) {
             if (excl < need && need <= incl) {
                 int c = excl, b = 4 * tid;
                 if (c + h0 >= need) { } else { c += h0; b += 1; if (c + h1 >= need) { } else { c += h1; b += 1; if (c + h2 >= need) { } else { c += h2; b += 1; } } }
-                const int hb = s.hist[b];
+                const int hb = s.hist2[0][b];
                 s.bin = b;
                 s.remaining = need - c;
-                if (hb == need - c || pass == 7) s.done = 1;   // the whole bin belongs to the selection
+                // the whole bin belongs to the selection, or everything up to and including it fits the caller's buffer
+                if (hb == need - c || pass == 7 || (k - need) + c + hb <= room) s.done = 1;
             }
             if (tid == 63 && incl < need) { s.bin = 255; s.done = 2; }   // fewer than k keys present: take everything
         }
@@ -178,21 +211,146 @@ __device__ void radix_select(Shared &s, const int n, int k, KeyFn key) {
     __syncthreads();
 }
 
-// ascending bitonic sort of s.sel_key[0 .. 128) (padded with ~0ull) by the first 128 threads
+// ascending sort of s.sel_key[0 .. 128) (real keys first, then the ~0ull padding).  The real keys are distinct (their low words are
+// distinct orders), so the rank of a key = the number of smaller keys: 128 broadcast LDS reads per thread and ONE barrier, instead of the
+// 28 barrier-separated stages of a bitonic network.
 __device__ void sort_selected(Shared &s) {
+    const int tid = threadIdx.x, me = tid & (kMaxBeam - 1), half = tid >> 7;   // two threads per key: each counts over one half of the keys
+    static_assert(kThreads == 2 * kMaxBeam, "two threads per selected key");
+    const unsigned long long mine = s.sel_key[me];
+    int part = 0;
+    if (mine != ~0ull) {
+        const unsigned long long *src = s.sel_key + half * (kMaxBeam / 2);
+#pragma unroll 16
+        for (int j = 0; j < kMaxBeam / 2; ++j) part += src[j] < mine ? 1 : 0;
+    }
+    if (half) s.rank_hi[me] = part;
+    __syncthreads();
+    if (!half && mine != ~0ull) s.sel_key[part + s.rank_hi[me]] = mine;
+    __syncthreads();
+}
+
+// inclusive prefix sum over the wavefront (DPP: Hillis-Steele inside the 16-lane rows, then the row totals)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+#define FA_BEAM_ADD(CTRL, MASK) v += __builtin_amdgcn_update_dpp(0, v, CTRL, MASK, 0xf, false);
+    FA_BEAM_ADD(0x111, 0xf) FA_BEAM_ADD(0x112, 0xf) FA_BEAM_ADD(0x114, 0xf) FA_BEAM_ADD(0x118, 0xf) FA_BEAM_ADD(0x142, 0xa) FA_BEAM_ADD(0x143, 0xc)
+#undef FA_BEAM_ADD
+    return v;
+}
+
+// One most-significant-digit selection over the keys a thread holds in registers: on return s.thr is a threshold such that the keys <= thr
+// are the `k` smallest plus at most `room - k` more (everything, if fewer than k keys are present).  All threads must call it.
+//   * the first digit starts at the first bit in which the present keys differ (AND / OR of all keys), not at a byte boundary: the first
+//     histogram already spreads over up to 256 bins (log-probabilities of one frame share sign and most of the exponent; byte-aligned
+//     digits sent every key to ONE bin — 64 lanes on one LDS address, the slowest thing the LDS does);
+//   * the passes stop as soon as the keys below the threshold bin plus the bin itself fit into `room`;
+//   * wave 0 finds the threshold bin with a DPP prefix sum (a ds_bpermute scan costs ~1 000 cycles per pass);
+//   * two histograms alternate, so the next one is cleared while the current one is filled: two barriers per pass.
+template <int MAXK>
+__device__ void select_threshold(Shared &s, const unsigned long long (&keys)[MAXK], const int k, const int room) {
     const int tid = threadIdx.x;
-    for (int k = 2; k <= kMaxBeam; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (tid < kMaxBeam) {
-                const int p = tid ^ j;
-                if (p > tid) {
-                    const unsigned long long a = s.sel_key[tid], b = s.sel_key[p];
-                    const bool up = (tid & k) == 0;
-                    if ((a > b) == up) { s.sel_key[tid] = b; s.sel_key[p] = a; }
-                }
-            }
-            __syncthreads();
+    if (tid == 0) { s.done = 0; s.remaining = k; s.all_and = ~0ull; s.all_or = 0; s.thr = 0; }
+    s.hist2[0][tid] = 0;
+    __syncthreads();
+    {
+        unsigned long long kand = ~0ull, kor = 0;
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j) if (keys[j] != ~0ull) { kand &= keys[j]; kor |= keys[j]; }
+        const unsigned ah = ~wave_or(~static_cast<unsigned>(kand >> 32)), al = ~wave_or(~static_cast<unsigned>(kand));
+        const unsigned oh = wave_or(static_cast<unsigned>(kor >> 32)), ol = wave_or(static_cast<unsigned>(kor));
+        if ((tid & 63) == 0) { atomicAnd(&s.all_and, (static_cast<unsigned long long>(ah) << 32) | al); atomicOr(&s.all_or, (static_cast<unsigned long long>(oh) << 32) | ol); }
+    }
+    __syncthreads();
+    const unsigned long long differ = s.all_and ^ s.all_or;                 // 0: at most one distinct key present
+    int hi = differ ? 64 - __clzll(static_cast<long long>(differ)) : 1;     // the present keys agree on every bit at or above `hi`
+    unsigned long long prefix = hi < 64 ? s.all_or >> hi : 0ull;
+    for (int pass = 0; hi > 0; ++pass) {
+        const int width = hi < 8 ? hi : 8, shift = hi - width;
+        int32_t *hist = s.hist2[pass & 1];
+        s.hist2[(pass + 1) & 1][tid] = 0;
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j) {
+            const unsigned long long kk = keys[j];
+            if (kk != ~0ull && (hi >= 64 || (kk >> hi) == prefix)) atomicAdd(&hist[(kk >> shift) & ((1u << width) - 1u)], 1);
         }
+        __syncthreads();
+        if (tid < 64) {   // wave 0: bin where the running count reaches `remaining`
+            const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const int mine = h0 + h1 + h2 + h3;
+            const int incl = wave_incl_scan(mine);
+            const int excl = incl - mine, need = s.remaining;
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (excl < need && need <= incl) {
+                int c = excl, b = 4 * tid;
+                if (c + h0 >= need) { } else { c += h0; b += 1; if (c + h1 >= need) { } else { c += h1; b += 1; if (c + h2 >= need) { } else { c += h2; b += 1; } } }
+                const int hb = b == 4 * tid ? h0 : (b == 4 * tid + 1 ? h1 : (b == 4 * tid + 2 ? h2 : h3));
+                s.bin = b;
+                s.remaining = need - c;
+                // the whole bin belongs to the selection, or everything up to and including it fits the caller's room
+                if (hb == need - c || shift == 0 || (k - need) + c + hb <= room) s.done = 1;
+            }
+            if (tid == 0 && total < need) { s.bin = (1 << width) - 1; s.done = 2; }   // fewer than k keys present: take everything
+        }
+        __syncthreads();
+        prefix = (prefix << width) | static_cast<unsigned>(s.bin);
+        hi = shift;
+        if (s.done) {
+            const unsigned long long low = shift ? ((1ull << shift) - 1) : 0ull;
+            if (tid == 0) s.thr = s.done == 2 ? ~0ull - 1 : ((prefix << shift) | low);
+            break;
+        }
+    }
+    __syncthreads();
+}
+
+// The k smallest of n <= 256 MAXK distinct keys, SORTED, in s.sel_key[0 .. count) (count >= min(k, present keys), at most kMaxBeam; the
+// caller keeps the first k).  Every thread computes its keys ONCE into registers (key() costs LDS reads and float ops).  With many keys per
+// thread a first selection runs over the 256 per-thread MINIMA only: the k-th smallest of those is an upper bound of the k-th smallest key,
+// so everything above it leaves the main selection — ~2 k survivors instead of 4 160 keys hammering the LDS histogram.
+template <int MAXK, class KeyFn>
+__device__ int select_sorted(Shared &s, const int n, const int k, KeyFn key, unsigned long long *acc = nullptr) {
+    const int tid = threadIdx.x;
+    unsigned long long t_prev = acc ? clock64() : 0;
+#define SEL_STAMP(i) do { if (acc) { const unsigned long long t_now = clock64(); acc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+    unsigned long long keys[MAXK];
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) { const int i = tid + kThreads * j; keys[j] = i < n ? key(i) : ~0ull; }
+    if (tid < kMaxBeam) s.sel_key[tid] = ~0ull;
+    if (tid == 0) s.sel_count = 0;
+    if (k <= 0) { __syncthreads(); return 0; }
+    SEL_STAMP(0);
+    if (MAXK >= 8) {
+        unsigned long long lo[1] = {~0ull};
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j) lo[0] = keys[j] < lo[0] ? keys[j] : lo[0];
+        select_threshold<1>(s, lo, k, kMaxBeam);
+        const unsigned long long bound = s.thr;
+        __syncthreads();                                   // s.thr is rewritten by the main selection
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j) if (keys[j] > bound) keys[j] = ~0ull;
+    }
+    SEL_STAMP(1);
+    select_threshold<MAXK>(s, keys, k, kMaxBeam);
+    SEL_STAMP(2);
+    const unsigned long long thr = s.thr;
+    int mine = 0;                                            // positions by prefix sums (wave scan + the four wave totals), no atomics
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) mine += keys[j] <= thr && keys[j] != ~0ull ? 1 : 0;
+    const int incl = wave_incl_scan(mine);
+    if ((tid & 63) == 63) s.wave_total[tid >> 6] = incl;
+    __syncthreads();
+    int pos = incl - mine;
+    for (int w = 0; w < (tid >> 6); ++w) pos += s.wave_total[w];
+    if (tid == kThreads - 1) s.sel_count = pos + mine;
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j)
+        if (keys[j] <= thr && keys[j] != ~0ull) { if (pos < kMaxBeam) s.sel_key[pos] = keys[j]; ++pos; }
+    __syncthreads();
+    SEL_STAMP(3);
+    sort_selected(s);
+    SEL_STAMP(4);
+#undef SEL_STAMP
+    return min(s.sel_count, kMaxBeam);
 }
 
 __device__ __forceinline__ uint32_t slot_of(uint32_t a, uint32_t b) { return static_cast<uint32_t>(mix64((static_cast<uint64_t>(a) << 32) | b)) & (kMapSlots - 1); }
@@ -217,31 +375,63 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
     }
     __syncthreads();
 
-    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = clock64();
+    unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = clock64();
 #define BEAM_STAMP(i) do { if (a.prof) { const unsigned long long t_now = clock64(); t_acc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
     int cur = 0;
+    constexpr int kPre = 5;                                   // values per thread requested one frame ahead (covers V <= 1280)
+    const bool staged = V <= kMaxCand / 2;                    // the frame's 64-bit keys fit the candidate array
+    float pre[kPre];
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) { const int i = tid + kThreads * j; pre[j] = T > 0 && i < V ? mat[i] : 0.0f; }
     for (int t = 0; t < T; ++t) {
         const float *frame = mat + static_cast<int64_t>(t) * a.row_stride;
         Beams &b = s.b[cur];
         Beams &nb = s.b[cur ^ 1];
         const int n = s.n_beams;
-        const float blank_lp = a.blank >= 0 && a.blank < V ? frame[a.blank] : -INFINITY;
-
         // ---- 1. top-K tokens, best first (sorted { frame[$0] > frame[$1] }, stable: ties by index) ----
-        auto tok_key = [&](const int i) -> unsigned long long { return i == a.blank ? ~0ull : desc_key(frame[i], static_cast<uint32_t>(i)); };
+        // The frame's keys are staged in LDS once (over the candidate array, which is dead here) from values that were requested
+        // one frame earlier: every pass of the select reads LDS, and the HBM latency of a frame hides behind the previous frame.
         BEAM_STAMP(7);
-        radix_select(s, V, K, tok_key);
-        BEAM_STAMP(0);
-        if (tid < kMaxBeam) s.sel_key[tid] = ~0ull;
-        if (tid == 0) s.sel_count = 0;
-        __syncthreads();
-        for (int i = tid; i < V; i += kThreads) {
-            const unsigned long long kk = tok_key(i);
-            if (kk <= s.thr && kk != ~0ull) { const int p = atomicAdd(&s.sel_count, 1); if (p < kMaxBeam) s.sel_key[p] = kk; }
+        unsigned long long *tkeys = reinterpret_cast<unsigned long long *>(s.cand_tot);
+        if (staged) {
+            if (tid == 0 && !(a.blank >= 0 && a.blank < V)) s.blank_lp = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < kPre; ++j) {
+                const int i = tid + kThreads * j;
+                if (i < V) { tkeys[i] = i == a.blank ? ~0ull : desc_key(pre[j], static_cast<uint32_t>(i)); if (i == a.blank) s.blank_lp = pre[j]; }
+            }
+            for (int i = tid + kThreads * kPre; i < V; i += kThreads) {
+                const float v = frame[i];
+                tkeys[i] = i == a.blank ? ~0ull : desc_key(v, static_cast<uint32_t>(i));
+                if (i == a.blank) s.blank_lp = v;
+            }
+            if (t + 1 < T) {
+#pragma unroll
+                for (int j = 0; j < kPre; ++j) { const int i = tid + kThreads * j; pre[j] = i < V ? frame[a.row_stride + i] : 0.0f; }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        sort_selected(s);
-        const int ntop = min(s.sel_count, K);
+        const float blank_lp = staged ? s.blank_lp : (a.blank >= 0 && a.blank < V ? frame[a.blank] : -INFINITY);
+        auto tok_key_direct = [&](const int i) -> unsigned long long { return i == a.blank ? ~0ull : desc_key(frame[i], static_cast<uint32_t>(i)); };
+        auto tok_key_lds = [&](const int i) -> unsigned long long { return tkeys[i]; };
+        int tok_sel;
+        if (V <= 5 * kThreads) tok_sel = select_sorted<5>(s, V, K, tok_key_lds);   // V <= 1 280 implies staged
+        else if (staged) tok_sel = select_sorted<(kMaxCand / 2 + kThreads - 1) / kThreads>(s, V, K, tok_key_lds);
+        else {
+            radix_select(s, V, K, kMaxBeam, tok_key_direct);
+            if (tid < kMaxBeam) s.sel_key[tid] = ~0ull;
+            if (tid == 0) s.sel_count = 0;
+            __syncthreads();
+            for (int i = tid; i < V; i += kThreads) {
+                const unsigned long long kk = tok_key_direct(i);
+                if (kk <= s.thr && kk != ~0ull) { const int p = atomicAdd(&s.sel_count, 1); if (p < kMaxBeam) s.sel_key[p] = kk; }
+            }
+            __syncthreads();
+            sort_selected(s);
+            tok_sel = min(s.sel_count, kMaxBeam);
+        }
+        BEAM_STAMP(0);
+        const int ntop = min(tok_sel, K);
         if (tid < ntop) {
             const int v = static_cast<int>(s.sel_key[tid] & 0xffffffffu);
             s.top_tok[tid] = v; s.top_lp[tid] = frame[v];
@@ -277,8 +467,18 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
         // ---- 3. candidate totals; candidate c = i (K + 1) + slot, slot 0 = the beam itself, slot 1 + r = beam + top token r ----
         BEAM_STAMP(2);
         const int stride = ntop + 1, ncand = n * stride;
-        // slot 0 of every beam first, one thread per beam: this path evaluates logAddExp in double and would otherwise run
-        // with one or two active lanes in every wavefront of the candidate loop
+        // extensions first (pure arithmetic, every thread busy), then slot 0 of every beam, one thread per beam: that path evaluates
+        // logAddExp in double and knows which extension merges into it — the extension (p, r) of the live beam p that is one token
+        // shorter — so it cancels that candidate itself instead of every one of the n x ntop extensions probing the (parent, token) map
+        for (int e = tid; e < n * ntop; e += kThreads) {
+            const int i = e / ntop, r = e - i * ntop, c = i * stride + 1 + r, v = s.top_tok[r];
+            s.cand_ord[c] = static_cast<unsigned short>(c);
+            const float pnb = (v == b.last[i] ? b.pb[i] : s.tot[i]) + s.top_lp[r];      // (:196-214)
+            float lm = b.lm[i];
+            if (s.top_boundary[r] && b.wlen[i] > 0) lm = lm + b.wscore[i];               // a word is completed (:185-189)
+            s.cand_tot[c] = pnb + lm;
+        }
+        __syncthreads();
         if (tid < n) {
             const int i = tid, c = i * stride;
             float pnb = -INFINITY;
@@ -292,21 +492,13 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
                     const float from_parent = (b.last[p] == last ? b.pb[p] : s.tot[p]) + s.top_lp[r];
                     pnb = log_add_exp(pnb, from_parent);
                     ord = min(ord, p * stride + 1 + r);
+                    s.cand_tot[p * stride + 1 + r] = NAN;                            // merged into this beam's slot 0
                 }
             }
             const float pb = s.tot[i] + blank_lp;                                    // blank extension (:172-176)
             s.stay_pb[i] = pb; s.stay_pnb[i] = pnb; s.stay_ord[i] = ord;
             s.cand_tot[c] = log_add_exp(pb, pnb) + b.lm[i];
             s.cand_ord[c] = static_cast<unsigned short>(ord);
-        }
-        for (int e = tid; e < n * ntop; e += kThreads) {
-            const int i = e / ntop, r = e - i * ntop, c = i * stride + 1 + r, v = s.top_tok[r];
-            s.cand_ord[c] = static_cast<unsigned short>(c);
-            if (find_child(b.node[i], v) >= 0) { s.cand_tot[c] = NAN; continue; }       // merged into that beam's slot 0
-            const float pnb = (v == b.last[i] ? b.pb[i] : s.tot[i]) + s.top_lp[r];      // (:196-214)
-            float lm = b.lm[i];
-            if (s.top_boundary[r] && b.wlen[i] > 0) lm = lm + b.wscore[i];               // a word is completed (:185-189)
-            s.cand_tot[c] = pnb + lm;
         }
         __syncthreads();
         // ---- 4. prune: W best totals, earlier candidate first on ties ----
@@ -315,22 +507,9 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
             return v != v ? ~0ull : desc_key(v, s.cand_ord[c]);
         };
         BEAM_STAMP(3);
-        radix_select(s, ncand, W, cand_key);
+        const int cand_sel = select_sorted<(kMaxCand + kThreads - 1) / kThreads>(s, ncand, W, cand_key, a.prof ? t_acc + 8 : nullptr);
         BEAM_STAMP(4);
-        if (tid < kMaxBeam) s.sel_key[tid] = ~0ull;
-        if (tid == 0) s.sel_count = 0;
-        __syncthreads();
-        for (int c = tid; c < ncand; c += kThreads) {
-            const unsigned long long kk = cand_key(c);
-            if (kk <= s.thr && kk != ~0ull) {
-                const int p = atomicAdd(&s.sel_count, 1);
-                // keep the candidate index next to the key: low 32 bits of the key are the ORDER, which for a merged beam is not c
-                if (p < kMaxBeam) { s.sel_key[p] = kk; }
-            }
-        }
-        __syncthreads();
-        sort_selected(s);
-        const int nsel = min(s.sel_count, W);
+        const int nsel = min(cand_sel, W);
         BEAM_STAMP(5);
         // ---- 5. survivors -> new beams (rank = sorted position) ----
         if (tid < nsel) {
@@ -379,7 +558,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
         __syncthreads();
         BEAM_STAMP(6);
     }
-    if (a.prof && blockIdx.x == 0 && tid == 0 && a.first == 0) for (int i = 0; i < 8; ++i) a.prof[i] = t_acc[i];
+    if (a.prof && blockIdx.x == 0 && tid == 0 && a.first == 0) for (int i = 0; i < 16; ++i) a.prof[i] = t_acc[i];
 #undef BEAM_STAMP
 
     // ---- finalize: trailing partial word (:222-229), first maximum in rank order, read the prefix back from the trie ----
@@ -602,7 +781,7 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
     a.arena = d_arena.as<unsigned long long>();
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_beam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(Shared)));
     fa::DevBuf d_prof;
-    if (getenv("FA_BEAM_PROF")) { FA_HIP_TRY(ctx, d_prof.alloc(64)); FA_HIP_TRY(ctx, hipMemsetAsync(d_prof.p, 0, 64, ctx->stream)); a.prof = d_prof.as<unsigned long long>(); }
+    if (getenv("FA_BEAM_PROF")) { FA_HIP_TRY(ctx, d_prof.alloc(128)); FA_HIP_TRY(ctx, hipMemsetAsync(d_prof.p, 0, 128, ctx->stream)); a.prof = d_prof.as<unsigned long long>(); }
     for (int first = 0; first < batch; first += chunk) {
         a.first = first;
         FA_HIP_TRY(ctx, hipMemsetAsync(d_arena.p, 0xff, static_cast<size_t>(per) * std::min(chunk, batch - first), ctx->stream));
@@ -611,11 +790,13 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
     }
     FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the arena is freed on return
     if (a.prof) {
-        unsigned long long h[8];
-        FA_HIP_TRY(ctx, hipMemcpy(h, d_prof.p, 64, hipMemcpyDeviceToHost));
+        unsigned long long h[16];
+        FA_HIP_TRY(ctx, hipMemcpy(h, d_prof.p, 128, hipMemcpyDeviceToHost));
         const double f = frames > 0 ? frames : 1;
         fprintf(stderr, "beam profile (cycles per frame, workgroup 0): token select %.0f | token gather+sort %.0f | maps %.0f | candidates %.0f | prune select %.0f | "
                         "prune gather+sort %.0f | new beams %.0f | loop head %.0f\n", h[0] / f, h[1] / f, h[2] / f, h[3] / f, h[4] / f, h[5] / f, h[6] / f, h[7] / f);
+        fprintf(stderr, "  inside the prune selection: keys %.0f | selection over the per-thread minima %.0f | main selection %.0f | gather %.0f | rank sort %.0f\n",
+                h[8] / f, h[9] / f, h[10] / f, h[11] / f, h[12] / f);
     }
     return FA_SUCCESS;
 }
