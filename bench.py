@@ -329,6 +329,36 @@ def e2e_leg(fa, ctx, torch, dist, rank, world, hours=8.0, speakers=12):
     return out
 
 
+def beam_leg(fa, ctx, torch, batch=512, frames=1500, vocab=1025):
+    """CTC prefix beam search + word-level ARPA LM (§8 f3): beam 100, 40 token candidates, one workgroup per utterance."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(batch, frames, vocab, device="cuda", generator=g) * 3.0
+    x[:, :, vocab - 1] += 4.0
+    lp = torch.log_softmax(x, dim=-1).contiguous()
+    del x
+    words = ["the", "cat", "sat", "dog", "on", "mat", "a", "in", "of", "to"]
+    voc = {v: ("\u2581" + words[v % len(words)] if v % 3 == 0 else "abcdefgh"[v % 8]) for v in range(vocab - 1)}
+    arpa = "\\data\\\n\\1-grams:\n" + "".join(f"-{1 + 0.1 * i:.1f}\t{w}\t-0.3\n" for i, w in enumerate(words)) + "\\2-grams:\n" + \
+        "".join(f"-0.{5 + i}\t{words[i]}\t{words[(i + 1) % len(words)]}\n" for i in range(len(words))) + "\\end\\\n"
+    lm = fa.ARPALanguageModel(arpa, ctx=ctx)
+    vocabulary = fa.CtcVocabulary(voc, vocab, ctx)
+    tok = torch.zeros(batch, frames, dtype=torch.int32, device="cuda")
+    lens = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    sc = torch.zeros(batch, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+
+    def run():
+        ctx.check(fa.lib().fa_ctc_beam_search_batch_dev(ctx.handle, lp.data_ptr(), batch, frames, vocab, vocab, frames * vocab, None, vocabulary.handle,
+                                                        lm.handle, 100, 0.3, 0.0, vocab - 1, 40, tok.data_ptr(), lens.data_ptr(), sc.data_ptr()), "beam")
+        torch.cuda.synchronize()
+    run()
+    t0 = time.perf_counter()
+    run()
+    dt = time.perf_counter() - t0
+    return {"workload": f"{batch} x [{frames},{vocab}] log-probs, beam 100, 40 candidates, ARPA LM", "seconds": dt, "utterances_per_s": batch / dt,
+            "audio_hours_per_s": batch * frames * 0.01 / 3600 / dt, "us_per_frame_step": dt / frames * 1e6, "mean_tokens": float(lens.float().mean())}
+
+
 def sharded_start_leg(fa, ctx, torch, dist, rank, world, n=50000, d=256):
     """SURVEY.md §8e, one 50 k problem: all-gather X over RCCL, per-rank row slab of the nearest-neighbour table
     (fa_ahc_row_minima), all-gather of (min, idx) — next to the same table computed by ONE rank.  The merge chain stays on one GPU."""
@@ -379,6 +409,7 @@ def main():
     ap.add_argument("--skip-ctc", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-e2e", action="store_true")
+    ap.add_argument("--skip-beam", action="store_true")
     ap.add_argument("--skip-sharded-start", action="store_true", help="N > 1 only: the sharded nearest-neighbour start-up of one 50k problem")
     ap.add_argument("--ctc-matrices", type=int, default=10000)
     args = ap.parse_args()
@@ -504,6 +535,12 @@ def main():
             line["ahc_batch"] = ahc_batch_leg(fa, ctx)
         except Exception as e:  # noqa: BLE001
             line["ahc_batch"] = {"error": repr(e)}
+    if solo and not args.skip_beam:
+        torch.cuda.empty_cache()
+        try:
+            line["beam_search"] = beam_leg(fa, ctx, torch)
+        except Exception as e:  # noqa: BLE001
+            line["beam_search"] = {"error": repr(e)}
     print(json.dumps(line))
     if dist is not None:
         dist.barrier()
