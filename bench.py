@@ -329,6 +329,49 @@ def e2e_leg(fa, ctx, torch, dist, rank, world, hours=8.0, speakers=12):
     return out
 
 
+def e2e_many_leg(fa, ctx, torch, recordings=16, hours_each=1.0, speakers=8):
+    """The serving shape of configs[4]: MANY recordings (a batch job over files) instead of one 8 h recording — mel over all their
+    15 s chunks in one launch, then fa_offline_cluster_batch (the merge chains of all recordings advance together)."""
+    n_chunks15 = int(recordings * hours_each * 3600 / 15)
+    d_pcm = synth_pcm(torch, n_chunks15, 7)
+    mel = fa.AudioMelSpectrogram(ctx=ctx)
+    plan = mel.plan(np.arange(n_chunks15 + 1, dtype=np.int64) * CHUNK_SAMPLES, layout="mel_major")
+    d_out = torch.empty(plan.out_shape(), dtype=torch.float32, device="cuda")
+    d_len = torch.empty(n_chunks15, dtype=torch.int32, device="cuda")
+    phi = np.linspace(2.0, 1.0, 128)
+    recs, truth = [], []
+    for r in range(recordings):
+        rng = np.random.default_rng(100 + r)
+        n_win = int(hours_each * 3600 / 2)
+        n = 3 * n_win
+        centers = rng.standard_normal((speakers, 256))
+        centers /= np.linalg.norm(centers, axis=1, keepdims=True)
+        spk = np.stack([rng.permutation(speakers)[:3] for _ in range(n_win)]).reshape(-1)
+        emb = (centers[spk] + 0.03 * rng.standard_normal((n, 256))).astype(np.float32)
+        rho = (rng.standard_normal((speakers, 128)) * np.sqrt(phi))[spk] + rng.standard_normal((n, 128))
+        recs.append((emb, rho, np.repeat(np.arange(n_win), 3)))
+        truth.append(spk)
+    plan.execute(d_pcm, d_out, d_len, order=False)
+    ctx.synchronize()
+    fa.cluster_embeddings_batch([(e[:600], r[:600], c[:600]) for e, r, c in recs[:2]], phi, ctx=ctx)   # warm-up
+    t0 = time.perf_counter()
+    plan.execute(d_pcm, d_out, d_len, order=False)
+    ctx.synchronize()
+    t_mel = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    st, out = fa.cluster_embeddings_batch(recs, phi, ctx=ctx)
+    t_cl = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    seq = [fa.cluster_embeddings(e, r, c, phi, ctx=ctx) for e, r, c in recs[:4]]
+    t_seq4 = time.perf_counter() - t0
+    pure = all(s == 0 and len(set(zip(t.tolist(), o.assignments))) == speakers for s, t, o in zip(st, truth, out))
+    same = all(a.assignments == b.assignments for a, b in zip(seq, out[:4]))
+    hours = recordings * hours_each
+    return {"recordings": recordings, "hours_each": hours_each, "embeddings_per_recording": len(truth[0]), "mel_s": t_mel, "cluster_batch_s": t_cl,
+            "cluster_sequential_s_extrapolated": t_seq4 * recordings / 4, "labels_match_speakers": bool(pure), "equals_single_calls": bool(same),
+            "audio_hours_per_s": hours / (t_mel + t_cl)}
+
+
 def beam_leg(fa, ctx, torch, batch=512, frames=1500, vocab=1025):
     """CTC prefix beam search + word-level ARPA LM (§8 f3): beam 100, 40 token candidates, one workgroup per utterance."""
     g = torch.Generator(device="cuda").manual_seed(3)
@@ -535,6 +578,12 @@ def main():
             line["ahc_batch"] = ahc_batch_leg(fa, ctx)
         except Exception as e:  # noqa: BLE001
             line["ahc_batch"] = {"error": repr(e)}
+    if solo and not args.skip_e2e:
+        torch.cuda.empty_cache()
+        try:
+            line["e2e_16x1h"] = e2e_many_leg(fa, ctx, torch)
+        except Exception as e:  # noqa: BLE001
+            line["e2e_16x1h"] = {"error": repr(e)}
     if solo and not args.skip_beam:
         torch.cuda.empty_cache()
         try:

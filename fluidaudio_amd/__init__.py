@@ -11,7 +11,7 @@ from .ctc import (LogitsArgmax, ctc_greedy_decode, ctc_greedy_ids_batch, ctc_gre
 from .formats import AudioWAV, RTTMParser, RTTMParserError, TimedSpeakerSegment, export_embeddings_json  # noqa: F401
 from .kmeans import KMeansClustering, SeededRNG, SpeakerCountConstraints  # noqa: F401
 from .mel import AudioMelSpectrogram, LuxTtsMelExtractor, MelPlan, UnifiedMelExtractor  # noqa: F401
-from .pipeline import (ClusteringResult, OfflineClusteringConfig, cluster_embeddings, cluster_embeddings_stagewise,  # noqa: F401
+from .pipeline import (ClusteringResult, OfflineClusteringConfig, cluster_embeddings, cluster_embeddings_batch, cluster_embeddings_stagewise,  # noqa: F401
                        select_training_embeddings)
 from .pool import Pool, device_count  # noqa: F401
 from .post import (ConstrainedClusterAssignment, HungarianAssignment, assign_embeddings, centroid_scores,  # noqa: F401

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_linkage_batch", "fa_ahc_row_minima", "fa_ahc_cluster", "fa_ahc_cut",
     "fa_vbx_speaker_count", "fa_vbx_refine",
     "fa_vbx_weighted_centroids", "fa_assign_cosine", "fa_centroid_scores", "fa_constrained_assign",
-    "fa_offline_cluster_default_config", "fa_offline_cluster",
+    "fa_offline_cluster_default_config", "fa_offline_cluster", "fa_offline_cluster_batch",
     "fa_arpa_parse", "fa_arpa_destroy", "fa_arpa_unigram_count", "fa_arpa_bigram_context_count", "fa_arpa_score",
     "fa_ctc_vocab_create", "fa_ctc_vocab_destroy", "fa_ctc_beam_search_batch_dev", "fa_ctc_beam_search_batch",
     "fa_wav_pcm16_size", "fa_wav_encode_pcm16", "fa_wav_decode", "fa_rttm_parse", "fa_rttm_format", "fa_export_embeddings_json",
@@ -223,6 +223,7 @@ def lib() -> C.CDLL:
     L.fa_resample_poly_taps.argtypes = [i32, i32, vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.fa_resample_poly.argtypes = [vp, vp, i64, i32, i32, vp, i64, C.POINTER(i64)]
     L.fa_resample_poly_dev.argtypes = [vp, vp, i64, i32, i32, vp, i64, C.POINTER(i64)]
+    L.fa_offline_cluster_batch.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, C.POINTER(OfflineClusterConfig), vp, vp, i32, vp, vp, vp]
     L.fa_device_count.argtypes = [C.POINTER(i32)]
     L.fa_pool_create.argtypes = [vp, i32, C.POINTER(vp)]
     L.fa_pool_destroy.argtypes = [vp]

@@ -49,33 +49,40 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-void fa_offline_cluster_default_config(fa_offline_cluster_config *c) {
-    if (!c) return;
-    c->clustering_threshold = 0.6; c->warm_start_fa = 0.07; c->warm_start_fb = 0.8;     // OfflineDiarizerTypes.swift:155-163,189-192
-    c->max_vbx_iterations = 20; c->convergence_tolerance = 1e-4; c->constrained_assignment = 1;
-    c->num_speakers = -1; c->min_speakers = -1; c->max_speakers = -1; c->ahc_mode = FA_AHC_MODE_AUTO;
-}
+// One recording's pass through the stage, split where the merge chains of several recordings can run together
+// (fa_offline_cluster_batch): prepare() = inputs + training rows + normalised rows on the device; the caller runs the linkage
+// (alone or batched); finish() = cut, VBx, centroids, assignment.  Everything is enqueued on the context's stream.
+struct ClusterJob {
+    fa_ctx *ctx;
+    const float *embeddings; int64_t n; int32_t d; const double *rho; int32_t rho_dim; const int32_t *chunk_indices; const double *phi;
+    const fa_offline_cluster_config *config; int32_t device_pointers;
+    int32_t *labels; double *centroids; int32_t max_centroids; int32_t *n_centroids; fa_offline_cluster_info *info;
 
-fa_status fa_offline_cluster(fa_ctx *ctx, const float *embeddings, int64_t n, int32_t d, const double *rho, int32_t rho_dim,
-                             const int32_t *chunk_indices, const double *phi, const fa_offline_cluster_config *config,
-                             int32_t device_pointers, int32_t *labels, double *centroids, int32_t max_centroids, int32_t *n_centroids,
-                             fa_offline_cluster_info *info) {
-    if (!ctx || !config || !labels || !n_centroids) return FA_INVALID_ARGUMENT;
-    *n_centroids = 0;
-    if (info) memset(info, 0, sizeof(*info));
-    if (n <= 0) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "offline cluster: no embeddings (noSpeechDetected, :281-283)");
-    if (n > INT32_MAX || d < 1 || rho_dim < 0 || !embeddings || (rho_dim > 0 && (!rho || !phi)) || (config->constrained_assignment && !chunk_indices))
-        return fa::set_error(ctx, FA_INVALID_ARGUMENT, "offline cluster: bad arguments");
-    fa::DeviceGuard guard(ctx->device);
-    hipStream_t st = ctx->stream;
-    try {
-        const double t_begin = now_s();
-        // ---- inputs to the device, once
-        fa::DevBuf b_emb32, b_rho_in, b_ok;
-        const float *d_emb32 = embeddings;
-        const double *d_rho_all = rho;
+    fa::DevBuf b_emb32, b_rho_in, b_ok, b_emb, b_temb, b_trho, b_train, b_norm, b_z;
+    const float *d_emb32 = nullptr;
+    const double *d_rho_all = nullptr, *d_temb = nullptr, *d_trho = nullptr;
+    int64_t nt = 0;
+    double t_begin = 0, t_inputs = 0, t_ahc = 0;
+    fa_ahc_stats ahc_stats{};
+
+    fa_status check_args() {
+        if (!ctx || !config || !labels || !n_centroids) return FA_INVALID_ARGUMENT;
+        *n_centroids = 0;
+        if (info) memset(info, 0, sizeof(*info));
+        if (n <= 0) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "offline cluster: no embeddings (noSpeechDetected, :281-283)");
+        if (n > INT32_MAX || d < 1 || rho_dim < 0 || !embeddings || (rho_dim > 0 && (!rho || !phi)) || (config->constrained_assignment && !chunk_indices))
+            return fa::set_error(ctx, FA_INVALID_ARGUMENT, "offline cluster: bad arguments");
+        return FA_SUCCESS;
+    }
+
+    // inputs to the device (once), selectTrainingEmbeddings, unit rows for the linkage (b_norm) and room for the dendrogram (b_z) when nt >= 2
+    fa_status prepare() {
+        hipStream_t st = ctx->stream;
+        t_begin = now_s();
+        d_emb32 = embeddings;
+        d_rho_all = rho;
         if (!device_pointers) {
             if (b_emb32.alloc(sizeof(float) * n * d) != hipSuccess || (rho_dim > 0 && b_rho_in.alloc(sizeof(double) * n * rho_dim) != hipSuccess)) {
                 (void)hipGetLastError();
@@ -97,13 +104,12 @@ fa_status fa_offline_cluster(fa_ctx *ctx, const float *embeddings, int64_t n, in
         for (int64_t i = 0; i < n; ++i) if (ok[i]) train.push_back(static_cast<int32_t>(i));
         const bool all_rows = train.empty() || static_cast<int64_t>(train.size()) == n;
         if (train.empty()) { train.resize(n); for (int64_t i = 0; i < n; ++i) train[i] = static_cast<int32_t>(i); }
-        const int64_t nt = static_cast<int64_t>(train.size());
-        fa::DevBuf b_emb, b_temb, b_trho, b_train;
+        nt = static_cast<int64_t>(train.size());
         if (b_emb.alloc(sizeof(double) * n * d) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
         const unsigned g_all = static_cast<unsigned>((n * d + 255) / 256);
         hipLaunchKernelGGL(widen_rows, dim3(g_all), dim3(256), 0, st, d_emb32, static_cast<const int32_t *>(nullptr), b_emb.as<double>(), n, d);   // Float -> Double (:286)
-        const double *d_temb = b_emb.as<double>();
-        const double *d_trho = d_rho_all;
+        d_temb = b_emb.as<double>();
+        d_trho = d_rho_all;
         if (!all_rows) {
             if (b_train.alloc(sizeof(int32_t) * nt) != hipSuccess || b_temb.alloc(sizeof(double) * nt * d) != hipSuccess ||
                 (rho_dim > 0 && b_trho.alloc(sizeof(double) * nt * rho_dim) != hipSuccess)) {
@@ -118,22 +124,26 @@ fa_status fa_offline_cluster(fa_ctx *ctx, const float *embeddings, int64_t n, in
             d_trho = b_trho.as<double>();
         }
         FA_HIP_TRY(ctx, hipGetLastError());
-        FA_HIP_TRY(ctx, hipStreamSynchronize(st));
-        const double t_inputs = now_s();
-
-        // ---- AHC (:301-306): normalise -> centroid linkage -> cut; fewer than 2 training rows -> all 0
-        std::vector<int32_t> initial(static_cast<size_t>(nt), 0);
-        fa_ahc_stats ahc_stats{};
-        if (nt >= 2) {
-            fa::DevBuf b_norm, b_z;
+        FA_HIP_TRY(ctx, hipStreamSynchronize(st));   // `train` is a host temporary
+        if (nt >= 2) {   // AHC input (:301-306): unit rows
             if (b_norm.alloc(sizeof(double) * nt * d) != hipSuccess || b_z.alloc(sizeof(double) * 4 * (nt - 1)) != hipSuccess) {
                 (void)hipGetLastError();
                 return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed");
             }
             FA_TRY(fa::ahc_normalize_dev(ctx, d_temb, b_norm.as<double>(), nt, d));
-            const fa_status ahc_st = fa::ahc_run_device(ctx, b_norm.as<double>(), static_cast<size_t>(nt), static_cast<size_t>(d), b_z.as<double>(), config->ahc_mode, &ahc_stats);
-            if (ahc_st != FA_SUCCESS) {
-                for (int64_t i = 0; i < nt; ++i) initial[i] = static_cast<int32_t>(i);   // degrade, don't crash (AHCClustering.swift:52-55)
+        }
+        t_inputs = now_s();
+        return FA_SUCCESS;
+    }
+
+    // ahc_status: what the linkage of b_norm into b_z returned (ignored when nt < 2)
+    fa_status finish(const fa_status ahc_status) {
+        hipStream_t st = ctx->stream;
+        // ---- cut (:301-306); fewer than 2 training rows -> all 0; a failed linkage degrades to singletons (AHCClustering.swift:52-55)
+        std::vector<int32_t> initial(static_cast<size_t>(nt), 0);
+        if (nt >= 2) {
+            if (ahc_status != FA_SUCCESS) {
+                for (int64_t i = 0; i < nt; ++i) initial[i] = static_cast<int32_t>(i);
             } else {
                 std::vector<double> z(static_cast<size_t>(4 * (nt - 1)));
                 FA_HIP_TRY(ctx, hipMemcpyAsync(z.data(), b_z.p, sizeof(double) * z.size(), hipMemcpyDeviceToHost, st));
@@ -141,8 +151,7 @@ fa_status fa_offline_cluster(fa_ctx *ctx, const float *embeddings, int64_t n, in
                 FA_TRY(fa_ahc_cut(z.data(), static_cast<size_t>(nt), config->clustering_threshold, initial.data()));
             }
         }
-        const double t_ahc = now_s();
-
+        t_ahc = now_s();
         // ---- VBx (:308-333)
         const int32_t S = nt > 0 ? std::max(1, fa_vbx_speaker_count(initial.data(), nt)) : 0;
         fa::VbxDevice vbx;
@@ -255,11 +264,86 @@ fa_status fa_offline_cluster(fa_ctx *ctx, const float *embeddings, int64_t n, in
             info->total_s = t_end - t_begin; info->ahc = ahc_stats;
         }
         return FA_SUCCESS;
+    }
+};
+
+template <class F>
+fa_status guarded(fa_ctx *ctx, F &&f) {
+    try {
+        return f();
     } catch (const std::bad_alloc &) {
         return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: host allocation failed");
     } catch (...) {
         return fa::set_error(ctx, FA_UNKNOWN_ERROR, "offline cluster: unexpected failure");
     }
+}
+
+}  // namespace
+
+extern "C" {
+
+void fa_offline_cluster_default_config(fa_offline_cluster_config *c) {
+    if (!c) return;
+    c->clustering_threshold = 0.6; c->warm_start_fa = 0.07; c->warm_start_fb = 0.8;     // OfflineDiarizerTypes.swift:155-163,189-192
+    c->max_vbx_iterations = 20; c->convergence_tolerance = 1e-4; c->constrained_assignment = 1;
+    c->num_speakers = -1; c->min_speakers = -1; c->max_speakers = -1; c->ahc_mode = FA_AHC_MODE_AUTO;
+}
+
+fa_status fa_offline_cluster(fa_ctx *ctx, const float *embeddings, int64_t n, int32_t d, const double *rho, int32_t rho_dim,
+                             const int32_t *chunk_indices, const double *phi, const fa_offline_cluster_config *config,
+                             int32_t device_pointers, int32_t *labels, double *centroids, int32_t max_centroids, int32_t *n_centroids,
+                             fa_offline_cluster_info *info) {
+    if (!ctx) return FA_INVALID_ARGUMENT;
+    ClusterJob job{ctx, embeddings, n, d, rho, rho_dim, chunk_indices, phi, config, device_pointers, labels, centroids, max_centroids, n_centroids, info};
+    FA_TRY(job.check_args());
+    fa::DeviceGuard guard(ctx->device);
+    return guarded(ctx, [&]() -> fa_status {
+        FA_TRY(job.prepare());
+        fa_status ahc_st = FA_SUCCESS;
+        if (job.nt >= 2)
+            ahc_st = fa::ahc_run_device(ctx, job.b_norm.as<double>(), static_cast<size_t>(job.nt), static_cast<size_t>(d), job.b_z.as<double>(), config->ahc_mode, &job.ahc_stats);
+        return job.finish(ahc_st);
+    });
+}
+
+fa_status fa_offline_cluster_batch(fa_ctx *ctx, int32_t count, const float *const *embeddings, const int64_t *n, int32_t d, const double *const *rho,
+                                   int32_t rho_dim, const int32_t *const *chunk_indices, const double *phi, const fa_offline_cluster_config *config,
+                                   int32_t *const *labels, double *const *centroids, int32_t max_centroids, int32_t *n_centroids,
+                                   fa_offline_cluster_info *infos, int32_t *statuses) {
+    if (!ctx || count < 0 || (count > 0 && (!embeddings || !n || !labels || !n_centroids || !config))) return FA_INVALID_ARGUMENT;
+    if (count == 0) return FA_SUCCESS;
+    fa::DeviceGuard guard(ctx->device);
+    return guarded(ctx, [&]() -> fa_status {
+        std::vector<ClusterJob> jobs;
+        jobs.reserve(static_cast<size_t>(count));
+        std::vector<fa_status> st(static_cast<size_t>(count), FA_SUCCESS);
+        for (int32_t r = 0; r < count; ++r) {
+            jobs.push_back(ClusterJob{ctx, embeddings[r], n[r], d, rho ? rho[r] : nullptr, rho_dim, chunk_indices ? chunk_indices[r] : nullptr, phi, config, 0,
+                                      labels[r], centroids ? centroids[r] : nullptr, max_centroids, &n_centroids[r], infos ? &infos[r] : nullptr});
+            st[r] = jobs.back().check_args();
+            if (st[r] == FA_SUCCESS) st[r] = jobs.back().prepare();
+        }
+        // the merge chains of all recordings advance together (one launch = one round of every unfinished recording)
+        std::vector<int32_t> who;
+        std::vector<const double *> din;
+        std::vector<double *> dz;
+        std::vector<size_t> rows;
+        for (int32_t r = 0; r < count; ++r)
+            if (st[r] == FA_SUCCESS && jobs[r].nt >= 2) { who.push_back(r); din.push_back(jobs[r].b_norm.as<double>()); dz.push_back(jobs[r].b_z.as<double>()); rows.push_back(static_cast<size_t>(jobs[r].nt)); }
+        std::vector<fa_status> ahc_st(who.size(), FA_SUCCESS);
+        std::vector<fa_ahc_stats> ahc_stats(who.size());
+        if (!who.empty())
+            (void)fa::ahc_run_device_batch(ctx, static_cast<int>(who.size()), din.data(), rows.data(), static_cast<size_t>(d), dz.data(), config->ahc_mode, ahc_stats.data(), ahc_st.data());
+        std::vector<fa_status> per_job_ahc(static_cast<size_t>(count), FA_SUCCESS);
+        for (size_t j = 0; j < who.size(); ++j) { per_job_ahc[who[j]] = ahc_st[j]; jobs[who[j]].ahc_stats = ahc_stats[j]; }
+        fa_status first = FA_SUCCESS;
+        for (int32_t r = 0; r < count; ++r) {
+            if (st[r] == FA_SUCCESS) st[r] = jobs[r].finish(per_job_ahc[r]);
+            if (statuses) statuses[r] = st[r];
+            if (first == FA_SUCCESS && st[r] != FA_SUCCESS) first = st[r];
+        }
+        return first;
+    });
 }
 
 }  // extern "C"

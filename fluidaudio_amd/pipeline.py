@@ -97,6 +97,65 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, config: Offline
     return res
 
 
+def _c_config(cfg: OfflineClusteringConfig):
+    import ctypes as C
+    c = L.OfflineClusterConfig()
+    L.lib().fa_offline_cluster_default_config(C.byref(c))
+    c.clustering_threshold, c.warm_start_fa, c.warm_start_fb = cfg.clustering_threshold, cfg.warm_start_fa, cfg.warm_start_fb
+    c.max_vbx_iterations, c.convergence_tolerance = cfg.max_vbx_iterations, cfg.convergence_tolerance
+    c.constrained_assignment = int(cfg.constrained_assignment)
+    c.num_speakers = -1 if cfg.num_speakers is None else cfg.num_speakers
+    c.min_speakers = -1 if cfg.min_speakers is None else cfg.min_speakers
+    c.max_speakers = -1 if cfg.max_speakers is None else cfg.max_speakers
+    return c
+
+
+def cluster_embeddings_batch(recordings, phi, config: OfflineClusteringConfig | None = None, ctx: L.Context | None = None):
+    """Several recordings through the clustering stage in one call (fa_offline_cluster_batch: their merge chains advance together).
+    recordings: iterable of (embedding256 [n, d] float32, rho128 [n, rho_dim] float64, chunk_indices [n]) with common d / rho_dim.
+    Returns (statuses, [ClusteringResult | None]) — per recording identical to cluster_embeddings()."""
+    import ctypes as C
+    cfg = config or OfflineClusteringConfig()
+    ctx = ctx or L.default_context()
+    recs = [(np.ascontiguousarray(e, np.float32), np.ascontiguousarray(r, np.float64), np.ascontiguousarray(c, np.int32)) for e, r, c in recordings]
+    k = len(recs)
+    if k == 0:
+        return [], []
+    d = recs[0][0].shape[1]
+    rd = recs[0][1].shape[1] if recs[0][1].ndim == 2 and recs[0][1].size else 0
+    ph = np.ascontiguousarray(phi, np.float64)
+    if rd and ph.size != rd:
+        ph = np.ones(rd)
+    cap = 256
+    labels = [np.zeros(max(e.shape[0], 1), np.int32) for e, _, _ in recs]
+    cens = [np.zeros((cap, d), np.float64) for _ in recs]
+    dummy = np.zeros(4, np.float32)
+    P = C.c_void_p * k
+    ep = P(*[e.ctypes.data if e.size else dummy.ctypes.data for e, _, _ in recs])
+    rp = P(*[r.ctypes.data if r.size else dummy.ctypes.data for _, r, _ in recs])
+    cp = P(*[c.ctypes.data if c.size else dummy.ctypes.data for _, _, c in recs])
+    lp = P(*[x.ctypes.data for x in labels])
+    zp = P(*[x.ctypes.data for x in cens])
+    ns = (C.c_int64 * k)(*[e.shape[0] for e, _, _ in recs])
+    kc = (C.c_int32 * k)()
+    infos = (L.OfflineClusterInfo * k)()
+    st = (C.c_int32 * k)()
+    c = _c_config(cfg)
+    L.lib().fa_offline_cluster_batch(ctx.handle, k, ep, ns, d, rp if rd else None, rd, cp, ph.ctypes.data if rd else None, C.byref(c), lp, zp, cap, kc, infos, st)
+    out = []
+    for i in range(k):
+        if st[i] != L.SUCCESS:
+            out.append(None)
+            continue
+        info = infos[i]
+        t = {"inputs_s": info.inputs_s, "ahc_s": info.ahc_s, "vbx_s": info.vbx_s, "assign_s": info.assign_s, "total_s": info.total_s}
+        res = ClusteringResult([int(v) for v in labels[i][:recs[i][0].shape[0]]], cens[i][:kc[i]].copy(), [], None, [], t)
+        res.info = {f: getattr(info, f) for f, _ in info._fields_ if f != "ahc"}
+        res.info["ahc"] = info.ahc.as_dict()
+        out.append(res)
+    return [int(v) for v in st], out
+
+
 def cluster_embeddings_stagewise(embedding256, rho128, chunk_indices, phi, config: OfflineClusteringConfig | None = None,
                                  ctx: L.Context | None = None) -> ClusteringResult:
     import time

@@ -344,6 +344,18 @@ fa_status fa_offline_cluster(fa_ctx *ctx, const float *embeddings, int64_t n, in
                              const int32_t *chunk_indices, const double *phi, const fa_offline_cluster_config *config,
                              int32_t device_pointers, int32_t *labels, double *centroids, int32_t max_centroids,
                              int32_t *n_centroids, fa_offline_cluster_info *info);
+/* `count` recordings through the same stage in ONE call: inputs and training rows of every recording are prepared, the merge
+ * chains of all of them advance together (fa_ahc_linkage_batch's round launches: a single chain leaves most of the machine
+ * idle), then every recording is cut / refined / assigned.  HOST pointers; all recordings share d, rho_dim, phi and config.
+ * embeddings / rho / chunk_indices / labels / centroids: arrays of `count` pointers (rho and centroids may be NULL as in the
+ * single call); n, n_centroids, infos (nullable), statuses (nullable): `count` entries.  Per recording the results equal
+ * fa_offline_cluster's bit for bit; a failing recording does not stop the others; the first failure is returned.
+ * infos[r].*_s of a batch are wall-clock marks of the shared phases, not per-recording costs. */
+fa_status fa_offline_cluster_batch(fa_ctx *ctx, int32_t count, const float *const *embeddings, const int64_t *n, int32_t d,
+                                   const double *const *rho, int32_t rho_dim, const int32_t *const *chunk_indices, const double *phi,
+                                   const fa_offline_cluster_config *config, int32_t *const *labels, double *const *centroids,
+                                   int32_t max_centroids, int32_t *n_centroids, fa_offline_cluster_info *infos, int32_t *statuses);
+
 
 /* ------------------------------------------------ speaker-count constraints + K-Means fallback ------ */
 /* KMeansClustering.SeededRNG.next (FluidAudio/Diarizer/Offline/Clustering/KMeansClustering.swift:212-223) and the Swift

@@ -66,3 +66,29 @@ def test_single_call_speaker_count_constraints_and_edge_cases(fa, gpu_ctx, oracl
     assert one.assignments == [0] and one.centroids.shape == (1, 256)
     with pytest.raises(ValueError):
         fa.cluster_embeddings(emb[:0], rho[:0], chunks[:0], phi, ctx=gpu_ctx)
+
+
+def test_batched_recordings_equal_single_calls(fa, gpu_ctx):
+    """fa_offline_cluster_batch: several recordings in one call (their merge chains advance together) give, per recording, exactly
+    what fa_offline_cluster gives — ragged sizes, a NaN row, a one-row recording; an empty recording fails alone."""
+    sessions = [synth_session(260, 4, 0), synth_session(90, 3, 1), synth_session(400, 6, 2), synth_session(33, 3, 3)]
+    phi = sessions[0][3]
+    sessions[2][0][17] = np.nan
+    recs = [(e, r, c) for e, r, c, _, _ in sessions]
+    recs.append((sessions[1][0][:1], sessions[1][1][:1], sessions[1][2][:1]))                 # one embedding
+    recs.append((sessions[1][0][:0], sessions[1][1][:0], sessions[1][2][:0]))                 # none: noSpeechDetected for that one
+    st, out = fa.cluster_embeddings_batch(recs, phi, ctx=gpu_ctx)
+    assert st[:-1] == [0] * (len(recs) - 1) and st[-1] == 1 and out[-1] is None
+    for (e, r, c), got in zip(recs[:-1], out[:-1]):
+        one = fa.cluster_embeddings(e, r, c, phi, ctx=gpu_ctx)
+        assert got.assignments == one.assignments
+        np.testing.assert_array_equal(got.centroids, one.centroids)
+        for key in ("training_rows", "initial_clusters", "vbx_iterations", "was_adjusted", "constrained"):
+            assert got.info[key] == one.info[key], key
+    assert out[2].info["training_rows"] == len(recs[2][0]) - 1
+    # forced speaker count goes through the K-Means fallback per recording
+    cfg = fa.OfflineClusteringConfig(num_speakers=2)
+    st2, out2 = fa.cluster_embeddings_batch(recs[:2], phi, cfg, ctx=gpu_ctx)
+    for (e, r, c), got in zip(recs[:2], out2):
+        one = fa.cluster_embeddings(e, r, c, phi, cfg, ctx=gpu_ctx)
+        assert st2 == [0, 0] and got.assignments == one.assignments and got.info["was_adjusted"] == one.info["was_adjusted"] == 1
