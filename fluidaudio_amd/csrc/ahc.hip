@@ -423,11 +423,10 @@ __global__ __launch_bounds__(kBlk) void ahc_row_minima(Ws w) {
 // smallest stale bound, and the block-partial minima of the rows being produced.  Per wave: 2 + kPend interleaved
 // DPP min-reductions (winner lanes by ballot); across the four waves: LDS + ONE __syncthreads; thread 0 writes.
 constexpr int kNQ = 2 + kPend;
-struct WaveOut {
-    double v1, sv;
-    double pv[kPend];
-    int cnt, r1, q1, nr1, nq1, srow, snode, pad;
-    int ps[kPend], pn[kPend];
+struct __attribute__((aligned(8))) QOut { double v; int a, b, c, d; };   // one reduced quantity of one wave: value + payload
+struct WaveOut {                                                          // quantity 0: smallest row minimum (r1, q1, node r1, node q1)
+    QOut q[kWaves][kNQ];                                                  //          1: smallest stale bound (row, node)
+    int cnt[kWaves];                                                      //      2 + p: partial minimum of produced row p (slot, node)
 };
 
 __device__ __forceinline__ void block_record(const Ws &w, const int par, const int blk, const double eps, const double key,
@@ -441,46 +440,53 @@ __device__ __forceinline__ void block_record(const Ws &w, const int par, const i
 #pragma unroll
     for (int p = 0; p < kPend; ++p) keys[2 + p] = pkey[p];
     wave_min_multi<kNQ>(keys, m, L);
-    WaveOut o;
-    o.v1 = m[0];
-    o.cnt = wave_count(key <= m[0] + 2.0 * eps && key < dinf());
-    o.r1 = lane_value(x, L[0]); o.q1 = lane_value(nnx, L[0]); o.nr1 = lane_value(nx, L[0]); o.nq1 = lane_value(nnnodex, L[0]);
-    o.sv = m[1]; o.srow = lane_value(x, L[1]); o.snode = lane_value(nx, L[1]); o.pad = 0;
+    QOut o[kNQ];
+    o[0].v = m[0]; o[0].a = lane_value(x, L[0]); o[0].b = lane_value(nnx, L[0]); o[0].c = lane_value(nx, L[0]); o[0].d = lane_value(nnnodex, L[0]);
+    o[1].v = m[1]; o[1].a = lane_value(x, L[1]); o[1].b = lane_value(nx, L[1]); o[1].c = 0; o[1].d = 0;
 #pragma unroll
-    for (int p = 0; p < kPend; ++p) { o.pv[p] = m[2 + p]; o.ps[p] = lane_value(pslot[p], L[2 + p]); o.pn[p] = lane_value(pnode[p], L[2 + p]); }
-    if (lane == 0) s_out[wave] = o;
-    __syncthreads();
-    if (tid != 0) return;
-    // merge of the four waves' results in registers (one batch of LDS reads; ties -> lowest wave == lowest rows)
-    WaveOut wo[kWaves];
+    for (int p = 0; p < kPend; ++p) { o[2 + p].v = m[2 + p]; o[2 + p].a = lane_value(pslot[p], L[2 + p]); o[2 + p].b = lane_value(pnode[p], L[2 + p]); o[2 + p].c = 0; o[2 + p].d = 0; }
+    const int cnt = wave_count(key <= m[0] + 2.0 * eps && key < dinf());
+    if (lane == 0) {
 #pragma unroll
-    for (int wv = 0; wv < kWaves; ++wv) wo[wv] = s_out[wv];
-    RecA ra; ra.v1 = dinf(); ra.cnt = 0; ra.pad = 0;
-    int4 ri = make_int4(-1, -1, -1, -1);
-    RecS rsv; rsv.sv = dinf(); rsv.srow = -1; rsv.snode = -1;
-    RecP rp[kPend];
-#pragma unroll
-    for (int p = 0; p < kPend; ++p) { rp[p].pv = dinf(); rp[p].slot = -1; rp[p].node = -1; }
-#pragma unroll
-    for (int wv = 0; wv < kWaves; ++wv) {
-        const WaveOut &f = wo[wv];
-        if (f.v1 < ra.v1) { ra.v1 = f.v1; ri = make_int4(f.r1, f.q1, f.nr1, f.nq1); }
-        if (f.sv < rsv.sv) { rsv.sv = f.sv; rsv.srow = f.srow; rsv.snode = f.snode; }
-#pragma unroll
-        for (int p = 0; p < kPend; ++p)
-            if (f.pv[p] < rp[p].pv) { rp[p].pv = f.pv[p]; rp[p].slot = f.ps[p]; rp[p].node = f.pn[p]; }
+        for (int q = 0; q < kNQ; ++q) s_out->q[wave][q] = o[q];
+        s_out->cnt[wave] = cnt;
     }
-    // rows within 2 eps of the block minimum, counted conservatively (a wave's rows were counted against ITS minimum)
+    __syncthreads();
+    if (tid >= kNQ) return;
+    // lane q of wave 0 merges quantity q of the four waves (ties -> lowest wave == lowest rows) and writes its own record:
+    // six short chains side by side instead of one thread walking all six
+    QOut best = s_out->q[0][tid];
+    QOut other[kWaves];
 #pragma unroll
-    for (int wv = 0; wv < kWaves; ++wv) if (wo[wv].v1 <= ra.v1 + 2.0 * eps) ra.cnt += wo[wv].cnt;
+    for (int wv = 1; wv < kWaves; ++wv) other[wv] = s_out->q[wv][tid];
+    const double v0 = best.v;
+#pragma unroll
+    for (int wv = 1; wv < kWaves; ++wv) if (other[wv].v < best.v) best = other[wv];
     const size_t o1 = static_cast<size_t>(par) * w.nblk + blk;
-    w.recA[o1] = ra; w.recI[o1] = ri; w.recS[o1] = rsv;
+    if (tid == 0) {
+        RecA ra; ra.v1 = best.v; ra.cnt = 0; ra.pad = 0;
+        // rows within 2 eps of the block minimum, counted conservatively (a wave's rows were counted against ITS minimum)
+        if (v0 <= best.v + 2.0 * eps) ra.cnt += s_out->cnt[0];
 #pragma unroll
-    for (int p = 0; p < kPend; ++p) w.recP[(static_cast<size_t>(par) * kPend + p) * w.nblk + blk] = rp[p];
+        for (int wv = 1; wv < kWaves; ++wv) if (other[wv].v <= best.v + 2.0 * eps) ra.cnt += s_out->cnt[wv];
+        const bool any = best.v < dinf();
+        w.recA[o1] = ra;
+        w.recI[o1] = any ? make_int4(best.a, best.b, best.c, best.d) : make_int4(-1, -1, -1, -1);
+    } else if (tid == 1) {
+        RecS rsv; rsv.sv = best.v;
+        const bool any = best.v < dinf();
+        rsv.srow = any ? best.a : -1; rsv.snode = any ? best.b : -1;
+        w.recS[o1] = rsv;
+    } else {
+        RecP rp; rp.pv = best.v;
+        const bool any = best.v < dinf();
+        rp.slot = any ? best.a : -1; rp.node = any ? best.b : -1;
+        w.recP[(static_cast<size_t>(par) * kPend + (tid - 2)) * w.nblk + blk] = rp;
+    }
 }
 
 __global__ __launch_bounds__(kBlk) void ahc_records(Ws w) {  // records of parity 0 from the row arrays
-    __shared__ WaveOut s_out[kWaves];
+    __shared__ WaveOut s_out[1];
     const int tid = threadIdx.x, blk = blockIdx.x, x = blk * kBlk + tid;
     const int nx = w.node[x];
     const RowSt r = w.row[x];
@@ -574,13 +580,19 @@ __device__ void exact_min_pair(const Ws &w, const int np, double *s_sq /*[kWaves
 #define AHC_STAMP(i) do {} while (0)
 #endif
 
-// what one wave extracts from its share of the block records (phase 1), merged across the four waves through LDS
-constexpr int kMaxC = (kMaxBlocks + 4 * 64 - 1) / (4 * 64);  // block records per lane
-struct WaveDec {
-    double v1, sv;
-    double pd[kPend];
-    int cnt, r1, q1, nr1, nq1, srow, snode, pad;
-    int ps[kPend], pn[kPend];
+// Phase 1 of a round: the block records of the previous round -> one decision, identical in every workgroup.  Each of the four waves
+// reduces ALL block records for its own share of the QUANTITIES (lane l owns the blocks [l c, (l + 1) c): lane order == row order, so
+// ballot + ffs breaks ties towards the lowest row): the results need no cross-wave merge — round 1/2 had every wave reduce a
+// quarter of the blocks for all six quantities and every thread then merged four partial results (~200 dependent instructions).
+//   wave 0: smallest row minimum (+ its row, neighbour, node ids) and the rows within 2 eps of it
+//   wave 1: the smallest stale bound of each QUARTER of the blocks (candidates for the piggy-backed re-scans)
+//   wave 2: partial minima of the produced rows 1, 2        wave 3: of the produced rows 0, 3
+constexpr int kMaxC = (kMaxBlocks + 63) / 64;  // block records per lane
+static_assert(kPend == 4 && kWaves == 4, "the wave roles of phase 1 are written for 4 waves and 4 produced rows");
+struct Dec {
+    double v1, sv[kWaves], pd[kPend];
+    int cnt, r1, q1, nr1, nq1, pad0, pad1, pad2;
+    int srow[kWaves], snode[kWaves], ps[kPend], pn[kPend];
 };
 
 // BATCH: the same round for several independent problems at once (fa_ahc_linkage_batch): workgroup b works on problem
@@ -589,8 +601,8 @@ struct WaveDec {
 template <bool BATCH>
 __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__restrict__ table, const int2 *__restrict__ blkmap, const int ph /* round index & 3 */) {
     extern __shared__ double s_cvec[];  // [d] merged centroid (EXACT rows)
-    __shared__ WaveOut s_out[kWaves];
-    __shared__ WaveDec s_dec[kWaves];
+    __shared__ WaveOut s_out[1];
+    __shared__ Dec s_dec;
     __shared__ double s_sq[kBlk];
     __shared__ double s_val[kWaves];
     __shared__ int s_idx[kWaves];
@@ -627,82 +639,102 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
     const int nanflag = w.flags[0];
 
     // ---- phase 1: every workgroup reduces the same records -> the same decision ------------------------------------
-    // wave v owns the blocks [v*perw, (v+1)*perw), lane l of it the contiguous run [.. + l*c, .. + (l+1)*c): lane and
-    // wave order == row order, so ballot+ffs and "lowest wave first" break ties towards the lowest row.
-    const int perw = (nblk + kWaves - 1) / kWaves, c = (perw + 63) >> 6;
-    double va[kMaxC];
-    int ca[kMaxC];
-    double keys[kNQ];
-    int4 ids = make_int4(-1, -1, -1, -1);
-    int ssrow = -1, ssnode = -1, lps[kPend], lpn[kPend];
-#pragma unroll
-    for (int q = 0; q < kNQ; ++q) keys[q] = dinf();
-#pragma unroll
-    for (int k = 0; k < kPend; ++k) { lps[k] = -1; lpn[k] = -1; }
-    {
-        const size_t ro = static_cast<size_t>(par) * nblk;
+    const int perw = (nblk + kWaves - 1) / kWaves, c = (nblk + 63) >> 6;
+    const size_t ro = static_cast<size_t>(par) * nblk;
+    if (wave == 0) {
+        double va[kMaxC], key = dinf();
+        int ca[kMaxC];
+        int4 ids = make_int4(-1, -1, -1, -1);
 #pragma unroll
         for (int j = 0; j < kMaxC; ++j) {
-            const int i = wave * perw + lane * c + j;
-            const bool ok = j < c && lane * c + j < perw && i < nblk;
             va[j] = dinf(); ca[j] = 0;
-            if (j > 0 && !(j < c)) continue;  // N <= 65 536: one record per lane, straight-line
+            if (j > 0 && !(j < c)) continue;   // N <= 16 384: one record per lane, straight-line
+            const int i = lane * c + j;
+            const bool ok = j < c && i < nblk;
             const int ii = ok ? i : 0;
             const RecA ra = w.recA[ro + ii];
             const int4 ri = w.recI[ro + ii];
-            const RecS rv = w.recS[ro + ii];
-            RecP rp[kPend];
-#pragma unroll
-            for (int k = 0; k < kPend; ++k) rp[k] = w.recP[(static_cast<size_t>(par) * kPend + k) * nblk + ii];
             if (!ok) continue;
             va[j] = ra.v1; ca[j] = ra.cnt;
-            if (ra.v1 < keys[0]) { keys[0] = ra.v1; ids = ri; }
-            if (rv.sv < keys[1]) { keys[1] = rv.sv; ssrow = rv.srow; ssnode = rv.snode; }
-#pragma unroll
-            for (int k = 0; k < kPend; ++k)
-                if (rp[k].pv < keys[2 + k]) { keys[2 + k] = rp[k].pv; lps[k] = rp[k].slot; lpn[k] = rp[k].node; }
+            if (ra.v1 < key) { key = ra.v1; ids = ri; }
         }
-    }
-    AHC_STAMP(0);
-    {   // wave level: 2 + kPend interleaved minimum reductions
-        double m[kNQ];
-        int L[kNQ];
-        wave_min_multi<kNQ>(keys, m, L);
-        WaveDec o;
-        o.v1 = m[0];
+        AHC_STAMP(0);
+        const double keys[1] = {key};
+        double m[1];
+        int L[1];
+        wave_min_multi<1>(keys, m, L);
         int cl = 0;
         const double wl = m[0] + 2.0 * st.eps;
 #pragma unroll
         for (int j = 0; j < kMaxC; ++j) if (va[j] <= wl && va[j] < dinf()) cl += ca[j];
-        o.cnt = wave_count(cl >= 1) + wave_count(cl >= 2) + wave_count(cl >= 3);  // exact up to 3 per lane; only "== 2" matters
-        o.r1 = lane_value(ids.x, L[0]); o.q1 = lane_value(ids.y, L[0]); o.nr1 = lane_value(ids.z, L[0]); o.nq1 = lane_value(ids.w, L[0]);
-        o.sv = m[1]; o.srow = lane_value(ssrow, L[1]); o.snode = lane_value(ssnode, L[1]); o.pad = 0;
+        const int cnt = wave_count(cl >= 1) + wave_count(cl >= 2) + wave_count(cl >= 3);  // exact up to 3 per lane; only "== 2" matters
+        const int r1 = lane_value(ids.x, L[0]), q1 = lane_value(ids.y, L[0]), nr1 = lane_value(ids.z, L[0]), nq1 = lane_value(ids.w, L[0]);
+        if (lane == 0) { s_dec.v1 = m[0]; s_dec.cnt = cnt; s_dec.r1 = r1; s_dec.q1 = q1; s_dec.nr1 = nr1; s_dec.nq1 = nq1; }
+    } else if (wave == 1) {
+        double keys[kWaves];
+        int srow[kWaves], snode[kWaves];
 #pragma unroll
-        for (int k = 0; k < kPend; ++k) { o.pd[k] = m[2 + k]; o.ps[k] = lane_value(lps[k], L[2 + k]); o.pn[k] = lane_value(lpn[k], L[2 + k]); }
-        if (lane == 0) s_dec[wave] = o;
+        for (int q = 0; q < kWaves; ++q) { keys[q] = dinf(); srow[q] = -1; snode[q] = -1; }
+#pragma unroll
+        for (int j = 0; j < kMaxC; ++j) {
+            if (j > 0 && !(j < c)) continue;
+            const int i = lane * c + j;
+            const bool ok = j < c && i < nblk;
+            const RecS rv = w.recS[ro + (ok ? i : 0)];
+            if (!ok) continue;
+            const int q = i / perw;   // the quarter of the blocks this record belongs to (< kWaves)
+#pragma unroll
+            for (int qq = 0; qq < kWaves; ++qq)
+                if (qq == q && rv.sv < keys[qq]) { keys[qq] = rv.sv; srow[qq] = rv.srow; snode[qq] = rv.snode; }
+        }
+        AHC_STAMP(0);
+        double m[kWaves];
+        int L[kWaves];
+        wave_min_multi<kWaves>(keys, m, L);
+#pragma unroll
+        for (int q = 0; q < kWaves; ++q) {
+            const int a = lane_value(srow[q], L[q]), b = lane_value(snode[q], L[q]);
+            if (lane == 0) { s_dec.sv[q] = m[q]; s_dec.srow[q] = a; s_dec.snode[q] = b; }
+        }
+    } else {
+        const int k0 = wave == 2 ? 1 : 0, k1 = wave == 2 ? 2 : 3;   // produced rows this wave finishes
+        double keys[2] = {dinf(), dinf()};
+        int ps[2] = {-1, -1}, pn[2] = {-1, -1};
+#pragma unroll
+        for (int j = 0; j < kMaxC; ++j) {
+            if (j > 0 && !(j < c)) continue;
+            const int i = lane * c + j;
+            const bool ok = j < c && i < nblk;
+            const int ii = ok ? i : 0;
+            const RecP p0 = w.recP[(static_cast<size_t>(par) * kPend + k0) * nblk + ii];
+            const RecP p1 = w.recP[(static_cast<size_t>(par) * kPend + k1) * nblk + ii];
+            if (!ok) continue;
+            if (p0.pv < keys[0]) { keys[0] = p0.pv; ps[0] = p0.slot; pn[0] = p0.node; }
+            if (p1.pv < keys[1]) { keys[1] = p1.pv; ps[1] = p1.slot; pn[1] = p1.node; }
+        }
+        AHC_STAMP(0);
+        double m[2];
+        int L[2];
+        wave_min_multi<2>(keys, m, L);
+        const int a0 = lane_value(ps[0], L[0]), b0 = lane_value(pn[0], L[0]), a1 = lane_value(ps[1], L[1]), b1 = lane_value(pn[1], L[1]);
+        if (lane == 0) { s_dec.pd[k0] = m[0]; s_dec.ps[k0] = a0; s_dec.pn[k0] = b0; s_dec.pd[k1] = m[1]; s_dec.ps[k1] = a1; s_dec.pn[k1] = b1; }
     }
     __syncthreads();
-    WaveDec dw[kWaves];  // one batch of LDS reads, everything below is register arithmetic on uniform values
-#pragma unroll
-    for (int wv = 0; wv < kWaves; ++wv) dw[wv] = s_dec[wv];
+    const Dec dv = s_dec;  // one batch of LDS reads, everything below is register arithmetic on uniform values
     // (a) finish the rows produced by the previous round
     double pd1[kPend];
     int pnn[kPend], pnnnode[kPend];
 #pragma unroll
     for (int k = 0; k < kPend; ++k) {
-        pd1[k] = dinf(); pnn[k] = -1; pnnnode[k] = -1;
-#pragma unroll
-        for (int wv = 0; wv < kWaves; ++wv)
-            if (dw[wv].pd[k] < pd1[k]) { pd1[k] = dw[wv].pd[k]; pnn[k] = dw[wv].ps[k]; pnnnode[k] = dw[wv].pn[k]; }
+        pd1[k] = dv.pd[k]; pnn[k] = dv.ps[k]; pnnnode[k] = dv.pn[k];
+        if (!(pd1[k] < dinf())) { pnn[k] = -1; pnnnode[k] = -1; }
         if (st.pend_row[k] < 0) { pd1[k] = dinf(); pnn[k] = -1; pnnnode[k] = -1; }
         else if (x == st.pend_row[k]) { rs.d1 = pd1[k]; rs.nn = pnn[k]; rs.nnnode = pnnnode[k]; }
     }
     // (b) smallest row minimum (with its row) over all blocks and the finished rows; rows within 2 eps of it
     double g1 = dinf();
     int R1 = -1, Q1 = -1, NR1 = -1, NQ1 = -1;
-#pragma unroll
-    for (int wv = 0; wv < kWaves; ++wv)  // ties -> lowest wave == lowest rows
-        if (dw[wv].v1 < g1) { g1 = dw[wv].v1; R1 = dw[wv].r1; Q1 = dw[wv].q1; NR1 = dw[wv].nr1; NQ1 = dw[wv].nq1; }
+    if (dv.v1 < g1) { g1 = dv.v1; R1 = dv.r1; Q1 = dv.q1; NR1 = dv.nr1; NQ1 = dv.nq1; }
 #pragma unroll
     for (int k = 0; k < kPend; ++k) {
         const int P = st.pend_row[k];
@@ -711,8 +743,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
     if (!(g1 < dinf())) R1 = -1;
     const double glim = g1 + 2.0 * st.eps;
     int nwin = 0;  // conservative (never too small): nested counts were taken against local minima
-#pragma unroll
-    for (int wv = 0; wv < kWaves; ++wv) if (dw[wv].v1 <= glim) nwin += dw[wv].cnt;
+    if (dv.v1 <= glim) nwin += dv.cnt;
 #pragma unroll
     for (int k = 0; k < kPend; ++k) if (st.pend_row[k] >= 0 && pd1[k] <= glim) nwin += 1;
 
@@ -777,17 +808,17 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
         bool used[kWaves];
 #pragma unroll
         for (int wv = 0; wv < kWaves; ++wv) {
-            const int sr = dw[wv].srow;
-            used[wv] = !(dw[wv].sv < dinf()) || sr < 0 || sr == D.a || (D.op == OP_MERGE && sr == D.b);
+            const int sr = dv.srow[wv];
+            used[wv] = !(dv.sv[wv] < dinf()) || sr < 0 || sr == D.a || (D.op == OP_MERGE && sr == D.b);
         }
 #pragma unroll
         for (int k = 1; k < kPend; ++k) {
             int bw = -1;
             double bv = dinf();
 #pragma unroll
-            for (int wv = 0; wv < kWaves; ++wv) if (!used[wv] && dw[wv].sv < bv) { bv = dw[wv].sv; bw = wv; }
+            for (int wv = 0; wv < kWaves; ++wv) if (!used[wv] && dv.sv[wv] < bv) { bv = dv.sv[wv]; bw = wv; }
 #pragma unroll
-            for (int wv = 0; wv < kWaves; ++wv) if (wv == bw) { used[wv] = true; prow[k] = dw[wv].srow; pnode_[k] = dw[wv].snode; }
+            for (int wv = 0; wv < kWaves; ++wv) if (wv == bw) { used[wv] = true; prow[k] = dv.srow[wv]; pnode_[k] = dv.snode[wv]; }
         }
     }
     AHC_STAMP(1);
