@@ -10,8 +10,8 @@ tail -6 gpurun_out/r2/pytest_gpu.log
 tail -4 gpurun_out/r2/bench.log | cut -c1-6000
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_mel gpurun_out/prof_ahc gpurun_out/prof_ctc gpurun_out/pmc
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_mel" -o mel -- python "$GRAFT_REPO_ROOT/bench.py" --skip-ahc --skip-ctc --skip-cpu --skip-e2e ) > gpurun_out/r2/rocprof_mel.log 2>&1; echo "rocprof mel rc=$?"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_ctc" -o ctc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --clock-warm-s 0 --skip-ahc --skip-cpu --skip-e2e ) > gpurun_out/r2/rocprof_ctc.log 2>&1; echo "rocprof ctc rc=$?"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_mel" -o mel -- python "$GRAFT_REPO_ROOT/bench.py" --skip-ahc --skip-ctc --skip-cpu --skip-e2e --skip-beam ) > gpurun_out/r2/rocprof_mel.log 2>&1; echo "rocprof mel rc=$?"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_ctc" -o ctc -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --clock-warm-s 0 --skip-ahc --skip-cpu --skip-e2e --skip-beam ) > gpurun_out/r2/rocprof_ctc.log 2>&1; echo "rocprof ctc rc=$?"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_ahc" -o ahc -- python "$GRAFT_REPO_ROOT/scripts/ahc_probe.py" 50000 --kinds iid --modes 0 --check 0 ) > gpurun_out/r2/rocprof_ahc.log 2>&1; echo "rocprof ahc rc=$?"
 bash scripts/gpu_mel_pmc.sh > gpurun_out/r2/pmc.log 2>&1; echo "pmc rc=$?"
 python scripts/rocprof_summary.py gpurun_out/prof_mel/mel_results.db --top 8 | tee gpurun_out/summary/mel_kernel_stats.txt
