@@ -65,7 +65,7 @@ constexpr int kPend = 1 + kPiggy;  // rows whose per-block partial minima one ro
 struct AhcState {  // double buffered by round parity; written by workgroup 0 only
     int32_t step, done, halt, need_exact, error, mode;
     int32_t prev_op;              // what the previous round executed
-    int32_t pad0;
+    int32_t sym_limit;            // nodes below this id existed when the matrix was last built in full: BOTH copies of their pairs are valid
     int32_t pend_row[kPend], pend_node[kPend];  // rows whose block-partial minima the previous round produced (-1: none)
     double eps, lim;              // lim: window limit carried COLLECT -> PAIRS -> evaluation
     unsigned long long dmax_bits, nmax_bits;  // largest matrix entry / largest squared norm seen by the start-up kernels
@@ -113,6 +113,16 @@ struct Ws {
 
 __device__ __forceinline__ double dinf() { return __longlong_as_double(0x7ff0000000000000LL); }
 __device__ __forceinline__ bool lt2(double v, int i, double ov, int oi) { return v < ov || (v == ov && i < oi); }
+
+// Matrix entry of the pair (row slot r holding node nr, column slot x holding node nx), read by the thread that owns column x.
+// The copy in row r is valid when r holds the younger node (a merge rewrites exactly that row) — and also when BOTH nodes already existed
+// at the last full build of the matrix (start-up, exact rebuild), which wrote both copies: taking the row copy then keeps the access
+// coalesced across the wavefront.  Without the second case the pairs of a single point r with the ~N/2 points of higher index were read
+// as M[x][r]: one 8-byte load per lane, each in a different 400 KB row (a different page) — the bulk of a round's memory time.
+__device__ __forceinline__ double pair_entry(const double *M, const int Np, const int r, const int nr, const int x, const int nx, const int sym_limit) {
+    const bool row_copy = nr > nx || (nr < sym_limit && nx < sym_limit);
+    return row_copy ? M[static_cast<size_t>(r) * Np + x] : M[static_cast<size_t>(x) * Np + r];
+}
 
 // ------------------------------------------------------------------------------ wave helpers (DPP)
 // A 64-lane reduction through __shfl_xor costs ~6 dependent ds_bpermute round trips per 32-bit word (measured
@@ -852,14 +862,14 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
         const bool act = nx != kDead && x != a && x != b;
         double da = 0.0, db = 0.0;
         if (act && st.mode == FA_AHC_MODE_AUTO) {  // valid copy of a pair lives in the row of the younger node
-            da = na > nx ? w.M[static_cast<size_t>(a) * Np + x] : w.M[static_cast<size_t>(x) * Np + a];
-            db = nb > nx ? w.M[static_cast<size_t>(b) * Np + x] : w.M[static_cast<size_t>(x) * Np + b];
+            da = pair_entry(w.M, Np, a, na, x, nx, st.sym_limit);
+            db = pair_entry(w.M, Np, b, nb, x, nx, st.sym_limit);
         }
 #pragma unroll
         for (int k = 1; k < kPend; ++k) {  // piggy-backed re-scans: pairs not touched by this merge
             const int S = prow[k];
             if (S >= 0 && act && x != S)
-                pkey[k] = pnode_[k] > nx ? w.M[static_cast<size_t>(S) * Np + x] : w.M[static_cast<size_t>(x) * Np + S];
+                pkey[k] = pair_entry(w.M, Np, S, pnode_[k], x, nx, st.sym_limit);
         }
         // merged centroid (FastClusterWrapper.cpp:89-100), and |ca - cb|^2 summed as a tree (error <= ~10 ulp,
         // independent of the merge depth).  Every wave evaluates the whole sum: no workgroup barrier.
@@ -926,7 +936,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
             const int S = prow[k];
             if (S < 0) continue;
             if (nx != kDead && x != S)
-                pkey[k] = pnode_[k] > nx ? w.M[static_cast<size_t>(S) * Np + x] : w.M[static_cast<size_t>(x) * Np + S];
+                pkey[k] = pair_entry(w.M, Np, S, pnode_[k], x, nx, st.sym_limit);
             if (x == S) in_flight = true;
         }
     } else if (D.op == OP_COLLECT) {
@@ -941,7 +951,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
         for (int j = 0; j < nc; ++j) {
             const int2 cj = w.cand[j];
             if (nx == kDead || x == cj.x) continue;
-            const double val = cj.y > nx ? w.M[static_cast<size_t>(cj.x) * Np + x] : w.M[static_cast<size_t>(x) * Np + cj.x];
+            const double val = pair_entry(w.M, Np, cj.x, cj.y, x, nx, st.sym_limit);
             if (val <= D.lim) {
                 const int slot = atomicAdd(&cw->npairs, 1);
                 if (slot < kMaxPairs) w.pairs[slot] = cj.x < x ? make_int4(cj.x, x, cj.y, nx) : make_int4(x, cj.x, nx, cj.y);
@@ -1098,6 +1108,7 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
     init[0].mode = p.mode == FA_AHC_MODE_EXACT ? FA_AHC_MODE_EXACT : FA_AHC_MODE_AUTO;
     for (int k = 0; k < kPend; ++k) { init[0].pend_row[k] = -1; init[0].pend_node[k] = -1; }
     init[0].prev_op = OP_NONE;
+    init[0].sym_limit = static_cast<int32_t>(N);          // the start-up writes the full matrix: every pair of points has both copies
     init[1] = init[0];
     WinCounters cinit[4];
     window_counter_init(cinit);
@@ -1148,6 +1159,7 @@ fa_status prob_after_replay(fa_ctx *ctx, Prob &p) {
         patch[0] = h;
         patch[0].halt = 0; patch[0].need_exact = 0; patch[0].mode = FA_AHC_MODE_EXACT; patch[0].eps = 0.0;
         patch[0].prev_op = OP_NONE;
+        patch[0].sym_limit = static_cast<int32_t>(p.N) + h.step;   // the rebuild below writes both copies of every pair of the nodes made so far
         for (int k = 0; k < kPend; ++k) { patch[0].pend_row[k] = -1; patch[0].pend_node[k] = -1; }
         patch[1] = patch[0];
         WinCounters cinit[4];

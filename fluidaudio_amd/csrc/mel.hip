@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "fa_common.h"
@@ -1007,7 +1008,10 @@ fa_status fa_mel_execute_dev(fa_mel_plan *p, const float *d_pcm, const float *d_
     static unsigned long long *s_prof = nullptr;
     static int s_prof_calls = 0;
     static unsigned long long s_last_span[4] = {0, 0, 0, 0};
+    static std::mutex s_prof_mutex;   // the diagnostics state is process-wide; entries of different contexts may run concurrently
+    std::unique_lock<std::mutex> prof_lock(s_prof_mutex, std::defer_lock);
     if (getenv("FA_MEL_PROF")) {  // diagnostics only: per-phase cycles of one workgroup, printed every 10 launches
+        prof_lock.lock();
         if (!s_prof) { (void)hipMalloc(&s_prof, 128 + 4 * 8192); (void)hipMemset(s_prof, 0, 128 + 4 * 8192); }
         a.prof = s_prof;
         {   // slots 2..5: min / max of the workgroup start and end times of the launch about to be made
