@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
     const int Np = w.Np, nblk = w.nblk, d = w.d, N = w.N;
 #ifdef FA_AHC_PROFILE
     const int prof_blk = nblk / 2;
-    unsigned long long t_seg[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = clock64();
 #endif
     // Every load of the round's first memory round trip is issued before anything is branched on: state, own row
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
             const bool ok = j < c && i < nblk;
             const RecS rv = w.recS[ro + (ok ? i : 0)];
             if (!ok) continue;
-            const int q = i / perw;   // the quarter of the blocks this record belongs to (< kWaves)
+            const int q = (i >= perw ? 1 : 0) + (i >= 2 * perw ? 1 : 0) + (i >= 3 * perw ? 1 : 0);   // i / perw (< kWaves) without the ~40-instruction integer division
 #pragma unroll
             for (int qq = 0; qq < kWaves; ++qq)
                 if (qq == q && rv.sv < keys[qq]) { keys[qq] = rv.sv; srow[qq] = rv.srow; snode[qq] = rv.snode; }
@@ -729,8 +729,11 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
         const int a0 = lane_value(ps[0], L[0]), b0 = lane_value(pn[0], L[0]), a1 = lane_value(ps[1], L[1]), b1 = lane_value(pn[1], L[1]);
         if (lane == 0) { s_dec.pd[k0] = m[0]; s_dec.ps[k0] = a0; s_dec.pn[k0] = b0; s_dec.pd[k1] = m[1]; s_dec.ps[k1] = a1; s_dec.pn[k1] = b1; }
     }
+    AHC_STAMP(6);
     __syncthreads();
-    const Dec dv = s_dec;  // one batch of LDS reads, everything below is register arithmetic on uniform values
+    const Dec dv = s_dec;  // one batch of LDS reads, everything below is register arithmetic on uniform values (moving it to the scalar
+                           // unit with readfirstlane was measured 9 % slower: the chain is latency-bound on either unit)
+    AHC_STAMP(7);
     // (a) finish the rows produced by the previous round
     double pd1[kPend];
     int pnn[kPend], pnnnode[kPend];
@@ -757,6 +760,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
 #pragma unroll
     for (int k = 0; k < kPend; ++k) if (st.pend_row[k] >= 0 && pd1[k] <= glim) nwin += 1;
 
+    AHC_STAMP(8);
     if (st.done || st.halt) {  // finished or waiting for the host: carry the state forward
         if (blk == 0 && tid == 0) {
             *nst = st; nst->prev_op = OP_NONE;
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
     AHC_STAMP(5);
 #ifdef FA_AHC_PROFILE
     if (blk == prof_blk && tid == 0) {
-        for (int i = 0; i < 6; ++i) atomicAdd(&w.prof[i], t_seg[i]);
+        for (int i = 0; i < 12; ++i) atomicAdd(&w.prof[i], t_seg[i]);
         atomicAdd(&w.prof[15], 1ULL);
     }
 #endif
@@ -1253,7 +1257,8 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
         (void)hipMemcpy(hp, w.prof, sizeof(hp), hipMemcpyDeviceToHost);
         const double n = hp[15] ? static_cast<double>(hp[15]) : 1.0;
         fprintf(stderr, "ahc profile (cycles/round, block %d of %d, %llu rounds): load+sync %.0f | decide %.0f | merge loads+dab %.0f | row update %.0f | block reduce %.0f | tail %.0f\n",
-                w.nblk / 2, w.nblk, hp[15], hp[0] / n, hp[1] / n, hp[2] / n, hp[3] / n, hp[4] / n, hp[5] / n);
+                w.nblk / 2, w.nblk, hp[15], hp[0] / n, (hp[1] + hp[6] + hp[7] + hp[8]) / n, hp[2] / n, hp[3] / n, hp[4] / n, hp[5] / n);
+        fprintf(stderr, "  decide = wave reduction %.0f | barrier + result read %.0f | finished rows + global minimum %.0f | state machine + piggy choice %.0f\n", hp[6] / n, hp[7] / n, hp[8] / n, hp[1] / n);
     }
 #endif
     if (stats) {
