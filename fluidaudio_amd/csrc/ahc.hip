@@ -321,11 +321,15 @@ __global__ void ahc_sqnorms(Ws w, double *__restrict__ norms) {
     if (s > 0.0) atomicMax(&w.state[0].nmax_bits, static_cast<unsigned long long>(__double_as_longlong(s)));
 }
 
-__global__ __launch_bounds__(256, 1) void ahc_gram_mfma(Ws w, const double *__restrict__ norms) {
+__global__ __launch_bounds__(256, 2) void ahc_gram_mfma(Ws w, const double *__restrict__ norms) {
     __shared__ double sA[GK][GS];
     __shared__ double sB[GK][GS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the matrix is symmetric: only the tiles on and below the diagonal are computed, an off-diagonal tile is written twice (as it is
+    // and mirrored) — half of the 1.28 TFLOP
+    if (blockIdx.x > blockIdx.y) return;
     const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+    const bool mirror = i0 != j0;
     const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
     const int Np = w.Np, d = w.d;
     v4f64 acc[4][4];
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void ahc_gram_mfma(Ws w, const double *__re
         }
         __syncthreads();
         if (k0 + GK < d) fetch(k0 + GK);
-#pragma unroll
+#pragma unroll 2
         for (int ks = 0; ks < GK / 4; ++ks) {
             const int kr = 4 * ks + (lane >> 4);
             double a[4], b[4];
@@ -376,6 +380,7 @@ __global__ __launch_bounds__(256, 1) void ahc_gram_mfma(Ws w, const double *__re
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+        __builtin_amdgcn_sched_barrier(0);   // one column strip at a time: hoisting the loads of all 64 outputs costs 50 spilled registers at 2 waves per SIMD
         const int j = j0 + wc + 16 * c + (lane & 15);
         const bool lj = w.node[j] != kDead;
         const double nj = norms[j];
@@ -390,6 +395,7 @@ __global__ __launch_bounds__(256, 1) void ahc_gram_mfma(Ws w, const double *__re
                 if (!(v > 0.0)) v = 0.0;  // duplicates can come out slightly negative; keeps -0.0 out of the bit-pattern reductions
                 if (ok && v > lmax) lmax = v;
                 w.M[static_cast<size_t>(i) * Np + j] = ok ? v : dinf();
+                if (mirror) w.M[static_cast<size_t>(j) * Np + i] = ok ? v : dinf();   // 4 consecutive doubles per row and store; the four e complete the lines in L2
             }
     }
     if (bad) w.flags[0] = 1;
