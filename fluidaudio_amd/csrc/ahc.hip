@@ -614,8 +614,8 @@ struct Dec {
 // BATCH: the same round for several independent problems at once (fa_ahc_linkage_batch): workgroup b works on problem
 // blkmap[b].x as its block blkmap[b].y; the problem's workspace descriptor comes from a table in HBM (written before the
 // first launch, constant afterwards: read through the constant address space, i.e. with scalar loads, like a kernel argument).
-template <bool BATCH>
-__global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__restrict__ table, const int2 *__restrict__ blkmap, const int ph /* round index & 3 */) {
+// the round itself; `w` = the problem's workspace, `blk` = this workgroup's block of 256 slots (see the three entry kernels below)
+__device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const int ph /* round index & 3 */) {
     extern __shared__ double s_cvec[];  // [d] merged centroid (EXACT rows)
     __shared__ WaveOut s_out[1];
     __shared__ Dec s_dec;
@@ -623,22 +623,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
     __shared__ double s_val[kWaves];
     __shared__ int s_idx[kWaves];
 
-    int blk_ = blockIdx.x;
-    Ws w_ = w_one;
-    if (BATCH) {
-        static_assert(sizeof(Ws) % 8 == 0, "Ws is copied as 64-bit words");
-        typedef const int __attribute__((address_space(4))) *c_i32;
-        typedef const unsigned long long __attribute__((address_space(4))) *c_u64;
-        const int prob = ((c_i32)reinterpret_cast<const int *>(blkmap))[2 * blockIdx.x];
-        blk_ = ((c_i32)reinterpret_cast<const int *>(blkmap))[2 * blockIdx.x + 1];
-        unsigned long long words[sizeof(Ws) / 8];
-        c_u64 src = (c_u64)reinterpret_cast<const unsigned long long *>(table) + static_cast<size_t>(prob) * (sizeof(Ws) / 8);
-#pragma unroll
-        for (unsigned i = 0; i < sizeof(Ws) / 8; ++i) words[i] = src[i];
-        __builtin_memcpy(&w_, words, sizeof(Ws));
-    }
-    const Ws w = w_;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blk_, x = blk * kBlk + tid;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = blk * kBlk + tid;
     const int par = ph & 1, npar = par ^ 1;
     const int Np = w.Np, nblk = w.nblk, d = w.d, N = w.N;
 #ifdef FA_AHC_PROFILE
@@ -998,6 +983,47 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
 #endif
 }
 
+// Entry kernels of the round.
+//   ahc_round_t<false>: one problem, workspace in the kernel arguments.
+//   ahc_round_t<true> : many problems; workgroup b looks up (problem, block) in a map and the problem's workspace in a table, both in HBM
+//                       (constant address space = scalar loads): two dependent memory round trips before the round can start.
+//   ahc_round_args    : up to kArgProblems problems with their workspaces and block ranges IN the kernel arguments: no extra round trip
+//                       (fa_ahc_linkage_batch / fa_offline_cluster_batch with <= 16 recordings).
+template <bool BATCH>
+__global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__restrict__ table, const int2 *__restrict__ blkmap, const int ph) {
+    int blk_ = blockIdx.x;
+    Ws w_ = w_one;
+    if (BATCH) {
+        static_assert(sizeof(Ws) % 8 == 0, "Ws is copied as 64-bit words");
+        typedef const int __attribute__((address_space(4))) *c_i32;
+        typedef const unsigned long long __attribute__((address_space(4))) *c_u64;
+        const int prob = ((c_i32)reinterpret_cast<const int *>(blkmap))[2 * blockIdx.x];
+        blk_ = ((c_i32)reinterpret_cast<const int *>(blkmap))[2 * blockIdx.x + 1];
+        unsigned long long words[sizeof(Ws) / 8];
+        c_u64 src = (c_u64)reinterpret_cast<const unsigned long long *>(table) + static_cast<size_t>(prob) * (sizeof(Ws) / 8);
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(Ws) / 8; ++i) words[i] = src[i];
+        __builtin_memcpy(&w_, words, sizeof(Ws));
+    }
+    ahc_round_body(w_, blk_, ph);
+}
+
+constexpr int kArgProblems = 16;
+struct BatchArgs {
+    Ws w[kArgProblems];
+    int32_t first_block[kArgProblems + 1];   // workgroups [first_block[k], first_block[k + 1]) work on problem k
+    int32_t count, pad;
+};
+static_assert(sizeof(BatchArgs) <= 3584, "kernel arguments are limited to 4 KB");
+
+__global__ __launch_bounds__(kBlk) void ahc_round_args(const BatchArgs a, const int ph) {
+    const int b = blockIdx.x;
+    int prob = 0;
+#pragma unroll
+    for (int k = 1; k < kArgProblems; ++k) prob += (k < a.count && b >= a.first_block[k]) ? 1 : 0;
+    ahc_round_body(a.w[prob], b - a.first_block[prob], ph);
+}
+
 // Exact heights from the stored centroids, the reference's summation order, then sqrt
 // (cluster_result::sqrt, FastClusterWrapper.cpp:128-130).
 __global__ void ahc_heights(Ws w) {
@@ -1330,7 +1356,13 @@ fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *
     RoundGraph *rg = nullptr;
     struct RgGuard { RoundGraph *&p; ~RgGuard() { delete p; } } rgg{rg};
     int grid = 0;
-    auto launch = [&](const int ph) { hipLaunchKernelGGL(ahc_round_t<true>, dim3(grid), dim3(kBlk), lds, ctx->stream, Ws{}, d_table, static_cast<const int2 *>(d_map), ph); };
+    BatchArgs bargs{};
+    bool by_args = false;   // <= kArgProblems running problems: workspaces and block ranges travel in the kernel arguments
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_args), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    auto launch = [&](const int ph) {
+        if (by_args) hipLaunchKernelGGL(ahc_round_args, dim3(grid), dim3(kBlk), lds, ctx->stream, bargs, ph);
+        else hipLaunchKernelGGL(ahc_round_t<true>, dim3(grid), dim3(kBlk), lds, ctx->stream, Ws{}, d_table, static_cast<const int2 *>(d_map), ph);
+    };
     for (long long it = 0; it < max_batches; ++it) {
         int n_active = 0;
         for (const Prob &p : probs) n_active += p.active ? 1 : 0;
@@ -1340,6 +1372,15 @@ fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *
             for (int k = 0; k < count; ++k)
                 if (probs[k].active) for (int b = 0; b < probs[k].w.nblk; ++b) map.push_back(make_int2(k, b));
             grid = static_cast<int>(map.size());
+            by_args = n_active <= kArgProblems;
+            if (by_args) {
+                bargs = BatchArgs{};
+                int slot = 0, first = 0;
+                for (int k = 0; k < count; ++k)
+                    if (probs[k].active) { bargs.w[slot] = probs[k].w; bargs.first_block[slot] = first; first += probs[k].w.nblk; ++slot; }
+                bargs.first_block[slot] = first;
+                bargs.count = slot;
+            }
             FA_HIP_TRY(ctx, hipMemcpyAsync(d_map, map.data(), sizeof(int2) * map.size(), hipMemcpyHostToDevice, ctx->stream));
             FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             delete rg;
