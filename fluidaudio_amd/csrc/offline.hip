@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "fa_common.h"
@@ -315,14 +317,43 @@ fa_status fa_offline_cluster_batch(fa_ctx *ctx, int32_t count, const float *cons
     fa::DeviceGuard guard(ctx->device);
     return guarded(ctx, [&]() -> fa_status {
         std::vector<ClusterJob> jobs;
-        jobs.reserve(static_cast<size_t>(count));
+        jobs.reserve(static_cast<size_t>(count));   // the jobs own device buffers: they must never be copied after prepare()
         std::vector<fa_status> st(static_cast<size_t>(count), FA_SUCCESS);
         for (int32_t r = 0; r < count; ++r) {
             jobs.push_back(ClusterJob{ctx, embeddings[r], n[r], d, rho ? rho[r] : nullptr, rho_dim, chunk_indices ? chunk_indices[r] : nullptr, phi, config, 0,
                                       labels[r], centroids ? centroids[r] : nullptr, max_centroids, &n_centroids[r], infos ? &infos[r] : nullptr});
             st[r] = jobs.back().check_args();
-            if (st[r] == FA_SUCCESS) st[r] = jobs.back().prepare();
         }
+        // Everything except the linkage is, per recording, a chain of small kernels, copies and host decisions: several recordings run
+        // it side by side, each worker thread on its own stream of the same device.
+        const int workers = std::max(1, std::min<int>(count, 8));
+        std::vector<fa_ctx *> wctx(static_cast<size_t>(workers), nullptr);
+        wctx[0] = ctx;
+        for (int t = 1; t < workers; ++t) if (fa_ctx_create(ctx->device, nullptr, &wctx[t]) != FA_SUCCESS) wctx[t] = nullptr;
+        struct Workers { std::vector<fa_ctx *> &w; ~Workers() { for (size_t t = 1; t < w.size(); ++t) if (w[t]) fa_ctx_destroy(w[t]); } } wguard{wctx};
+        std::vector<std::string> werr(static_cast<size_t>(workers));
+        auto on_workers = [&](auto &&phase) {   // phase(job index) -> fa_status, for every recording that is still healthy
+            auto work = [&](const int t, const int stride_from) {
+                fa_ctx *c = wctx[t];
+                fa::DeviceGuard g(c->device);
+                for (int32_t r = stride_from; r < count; r += workers) {
+                    if (st[r] != FA_SUCCESS) continue;
+                    jobs[r].ctx = c;
+                    try { st[r] = phase(r); }
+                    catch (const std::bad_alloc &) { st[r] = FA_ALLOCATION_FAILURE; }
+                    catch (...) { st[r] = FA_UNKNOWN_ERROR; }
+                    if (st[r] != FA_SUCCESS && werr[t].empty()) werr[t] = c->last_error;
+                    jobs[r].ctx = ctx;
+                }
+                (void)hipStreamSynchronize(c->stream);
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < workers; ++t) if (wctx[t]) th.emplace_back(work, t, t);
+            work(0, 0);
+            for (auto &x : th) x.join();
+            for (int t = 1; t < workers; ++t) if (!wctx[t]) work(0, t);   // a worker without a stream of its own: the caller's context takes its share
+        };
+        on_workers([&](const int32_t r) { return jobs[r].prepare(); });
         // the merge chains of all recordings advance together (one launch = one round of every unfinished recording)
         std::vector<int32_t> who;
         std::vector<const double *> din;
@@ -336,9 +367,11 @@ fa_status fa_offline_cluster_batch(fa_ctx *ctx, int32_t count, const float *cons
             (void)fa::ahc_run_device_batch(ctx, static_cast<int>(who.size()), din.data(), rows.data(), static_cast<size_t>(d), dz.data(), config->ahc_mode, ahc_stats.data(), ahc_st.data());
         std::vector<fa_status> per_job_ahc(static_cast<size_t>(count), FA_SUCCESS);
         for (size_t j = 0; j < who.size(); ++j) { per_job_ahc[who[j]] = ahc_st[j]; jobs[who[j]].ahc_stats = ahc_stats[j]; }
+        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        on_workers([&](const int32_t r) { return jobs[r].finish(per_job_ahc[r]); });
+        for (int t = 1; t < workers; ++t) if (!werr[t].empty() && ctx->last_error.empty()) ctx->last_error = werr[t];
         fa_status first = FA_SUCCESS;
         for (int32_t r = 0; r < count; ++r) {
-            if (st[r] == FA_SUCCESS) st[r] = jobs[r].finish(per_job_ahc[r]);
             if (statuses) statuses[r] = st[r];
             if (first == FA_SUCCESS && st[r] != FA_SUCCESS) first = st[r];
         }
