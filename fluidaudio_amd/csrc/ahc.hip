@@ -95,6 +95,7 @@ struct Ws {
     double *C;       // [2N][d]  centroids by node id (rows 0..N-1 = input points)
     double *XT;      // [d][Np]  slot-major transposed coordinates (init; maintained in EXACT mode only)
     RowSt *row;      // [Np]
+    double *e2;      // [Np]   lower bound of the row's entries OTHER than the nearest neighbour's (see the row update of the round)
     int32_t *node;   // [Np]
     double *sizes;   // [2N]     cluster size by node id
     double *Z;       // [(N-1)*4]
@@ -238,6 +239,7 @@ __global__ void ahc_init_rows(Ws w) {
     w.node[i] = i < w.N ? i : kDead;
     RowSt r; r.d1 = dinf(); r.nn = -1; r.nnnode = -1;
     w.row[i] = r;
+    w.e2[i] = dinf();
 }
 
 // Exact pairwise squared distances of the live slots, the reference's summation order
@@ -409,16 +411,21 @@ __global__ __launch_bounds__(256, 2) void ahc_gram_mfma(Ws w, const double *__re
 __global__ __launch_bounds__(kBlk) void ahc_row_minima(Ws w) {
     __shared__ double s_val[kWaves];
     __shared__ int s_idx[kWaves];
+    __shared__ double s_second[kWaves];
+    __shared__ int s_win;
     const int i = blockIdx.x;
-    double v = dinf();
+    double v = dinf(), v2 = dinf();   // the thread's smallest and second smallest entry
     int ix = INT_MAX;
     if (w.node[i] != kDead) {
         const double *row = w.M + static_cast<size_t>(i) * w.Np;
         for (int x = threadIdx.x; x < w.Np; x += kBlk) {
             const double m = row[x];
-            if (m < v) { v = m; ix = x; }  // x ascending per thread => lowest index kept
+            if (m < v) { v2 = v; v = m; ix = x; }  // x ascending per thread => lowest index kept
+            else if (m < v2) v2 = m;
         }
     }
+    const double mine = v;
+    const int mine_ix = ix;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const double ov = __shfl_xor(v, off);
@@ -431,6 +438,18 @@ __global__ __launch_bounds__(kBlk) void ahc_row_minima(Ws w) {
         for (int wv = 1; wv < kWaves; ++wv) if (lt2(s_val[wv], s_idx[wv], v, ix)) { v = s_val[wv]; ix = s_idx[wv]; }
         RowSt r; r.d1 = v; r.nn = ix == INT_MAX ? -1 : ix; r.nnnode = ix == INT_MAX ? -1 : w.node[ix];
         w.row[i] = r;
+        s_win = ix;
+    }
+    __syncthreads();
+    // second smallest entry of the row = the smallest one that is not the winner's (the winner's thread contributes its own second)
+    double c2 = mine_ix == s_win ? v2 : mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(c2, off); if (o < c2) c2 = o; }
+    if ((threadIdx.x & 63) == 0) s_second[threadIdx.x >> 6] = c2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < kWaves; ++wv) if (s_second[wv] < c2) c2 = s_second[wv];
+        w.e2[i] = c2;
     }
 }
 
@@ -637,6 +656,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     AhcState *const nst = w.state + npar;
     int nx = w.node[x];
     RowSt rs = w.row[x];
+    double e2x = w.e2[x];   // lower bound of the entries of row x other than its nearest neighbour's
     const int nanflag = w.flags[0];
 
     // ---- phase 1: every workgroup reduces the same records -> the same decision ------------------------------------
@@ -733,7 +753,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         pd1[k] = dv.pd[k]; pnn[k] = dv.ps[k]; pnnnode[k] = dv.pn[k];
         if (!(pd1[k] < dinf())) { pnn[k] = -1; pnnnode[k] = -1; }
         if (st.pend_row[k] < 0) { pd1[k] = dinf(); pnn[k] = -1; pnnnode[k] = -1; }
-        else if (x == st.pend_row[k]) { rs.d1 = pd1[k]; rs.nn = pnn[k]; rs.nnnode = pnnnode[k]; }
+        else if (x == st.pend_row[k]) { rs.d1 = pd1[k]; rs.nn = pnn[k]; rs.nnnode = pnnnode[k]; e2x = pd1[k]; }   // a scan yields no second minimum: the others are >= d1
     }
     // (b) smallest row minimum (with its row) over all blocks and the finished rows; rows within 2 eps of it
     double g1 = dinf();
@@ -839,7 +859,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
             nst->prev_op = OP_NONE;
             for (int k = 0; k < kPend; ++k) nst->pend_row[k] = -1;
         }
-        if (was_pending) w.row[x] = rs;
+        if (was_pending) { w.row[x] = rs; w.e2[x] = e2x; }
         return;
     }
 
@@ -847,7 +867,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     int pslot[kPend], pnd[kPend];
 #pragma unroll
     for (int k = 0; k < kPend; ++k) { pkey[k] = dinf(); pslot[k] = x; pnd[k] = nx; }
-    bool dirty = was_pending;
+    bool dirty = was_pending, e2_dirty = was_pending;
     bool in_flight = false;  // this row is being (re)produced: it leaves the record until the next round finishes it
 
     if (D.op == OP_MERGE) {
@@ -905,15 +925,28 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         }
         if (act) {
             w.M[static_cast<size_t>(a) * Np + x] = dc;
+            // Row x against its entry for the new cluster.  e2x bounds the entries of the row OTHER than the nearest neighbour's from below
+            // (exact second minimum after the start-up scan, then maintained: an entry that appears lowers it, entries that disappear
+            // leave it a bound).  It decides the case that used to make half of all rows stale on chaining data — the nearest neighbour
+            // WAS one of the merged slots (every point's nearest neighbour is the growing cluster) and the new entry is larger than the
+            // old minimum: if it is still below everything else (dc < e2x) the row simply keeps the cluster as its neighbour.
             const bool vld = rs.nn >= 0;
-            if (dc < rs.d1 || (vld && dc == rs.d1 && a <= rs.nn)) { rs.d1 = dc; rs.nn = a; rs.nnnode = nnew; dirty = true; }
-            else if (vld && (rs.nn == a || rs.nn == b)) { rs.nn = -1; dirty = true; }  // minimum lost: d1 stays as a lower bound
+            const bool hit = vld && (rs.nn == a || rs.nn == b);
+            if (!hit) {
+                if (dc < rs.d1 || (vld && dc == rs.d1 && a <= rs.nn)) {   // new minimum (a stale row: dc below its bound IS its minimum)
+                    e2x = rs.d1; rs.d1 = dc; rs.nn = a; rs.nnnode = nnew; dirty = true; e2_dirty = true;
+                } else if (dc < e2x) { e2x = dc; e2_dirty = true; }
+            } else if (dc < e2x) {                                         // unique minimum again (strict: a tie goes to a re-scan)
+                rs.d1 = dc; rs.nn = a; rs.nnnode = nnew; dirty = true;
+            } else {                                                        // minimum lost: every entry is >= min(e2x, dc) = e2x, a lower bound
+                rs.d1 = e2x; rs.nn = -1; dirty = true;
+            }
             pkey[0] = dc;
 #pragma unroll
             for (int k = 1; k < kPend; ++k)
                 if (x == prow[k]) { pkey[k] = dc; pslot[k] = a; pnd[k] = nnew; in_flight = true; }  // its entry for the new cluster
         } else if (x == a) {
-            nx = nnew; rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; dirty = true; in_flight = true;
+            nx = nnew; rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; e2x = dinf(); dirty = true; e2_dirty = true; in_flight = true;
             w.sizes[nnew] = den;
         } else if (x == b) {
             nx = kDead; rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; dirty = true;
@@ -956,6 +989,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     AHC_STAMP(3);
 
     // own row state back to HBM (only when it changed), then the record of the next round
+    if (e2_dirty) w.e2[x] = e2x;
     if (dirty) {
         w.row[x] = rs;
         if (D.op == OP_MERGE && (x == D.a || x == D.b)) w.node[x] = nx;
@@ -1042,7 +1076,7 @@ __global__ void ahc_heights(Ws w) {
 
 // ------------------------------------------------------------------------------ host driver
 struct Layout {
-    size_t state, cnt, flags, prof, c, xt, row, node, sizes, z, reca, reci, recs, recp, cand, pairs, norms, m, total;
+    size_t state, cnt, flags, prof, c, xt, row, e2, node, sizes, z, reca, reci, recs, recp, cand, pairs, norms, m, total;
 };
 
 Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
@@ -1058,6 +1092,7 @@ Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
     L.recs = take(sizeof(RecS) * 2 * nblk);
     L.recp = take(sizeof(RecP) * 2 * kPend * nblk);
     L.row = take(sizeof(RowSt) * Np);
+    L.e2 = take(sizeof(double) * Np);
     L.node = take(sizeof(int32_t) * Np);
     L.sizes = take(sizeof(double) * 2 * N);
     L.z = take(sizeof(double) * 4 * (N > 1 ? N - 1 : 1));
@@ -1130,6 +1165,7 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
     w.recS = reinterpret_cast<RecS *>(base + L.recs);
     w.recP = reinterpret_cast<RecP *>(base + L.recp);
     w.row = reinterpret_cast<RowSt *>(base + L.row);
+    w.e2 = reinterpret_cast<double *>(base + L.e2);
     w.node = reinterpret_cast<int32_t *>(base + L.node);
     w.sizes = reinterpret_cast<double *>(base + L.sizes);
     w.Z = reinterpret_cast<double *>(base + L.z);
