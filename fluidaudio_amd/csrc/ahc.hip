@@ -59,7 +59,12 @@ constexpr int kDead = INT_MAX;     // node id of an empty slot
 
 enum { OP_NONE = 0, OP_MERGE = 1, OP_RESCAN = 2, OP_COLLECT = 3, OP_PAIRS = 4 };
 
-constexpr int kPiggy = 3;          // stale rows re-scanned on top of every merge / forced re-scan round
+// 1 since the rows keep a bound on their second minimum (e2): stale rows have become rare (0 forced re-scans on both benchmark
+// distributions), and every piggy-backed row costs a reduction chain in both reductions of a round (3 -> 1: 9.1 -> 8.5 us per round)
+#ifndef FA_AHC_PIGGY
+#define FA_AHC_PIGGY 1
+#endif
+constexpr int kPiggy = FA_AHC_PIGGY;   // stale rows re-scanned on top of every merge / forced re-scan round
 constexpr int kPend = 1 + kPiggy;  // rows whose per-block partial minima one round can produce
 
 struct AhcState {  // double buffered by round parity; written by workgroup 0 only
@@ -623,7 +628,7 @@ __device__ void exact_min_pair(const Ws &w, const int np, double *s_sq /*[kWaves
 //   wave 1: the smallest stale bound of each QUARTER of the blocks (candidates for the piggy-backed re-scans)
 //   wave 2: partial minima of the produced rows 1, 2        wave 3: of the produced rows 0, 3
 constexpr int kMaxC = (kMaxBlocks + 63) / 64;  // block records per lane
-static_assert(kPend == 4 && kWaves == 4, "the wave roles of phase 1 are written for 4 waves and 4 produced rows");
+static_assert(kPend >= 2 && kPend <= 4 && kWaves == 4, "the wave roles of phase 1 are written for 4 waves and 2..4 produced rows");
 struct Dec {
     double v1, sv[kWaves], pd[kPend];
     int cnt, r1, q1, nr1, nq1, pad0, pad1, pad2;
@@ -718,7 +723,9 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
             if (lane == 0) { s_dec.sv[q] = m[q]; s_dec.srow[q] = a; s_dec.snode[q] = b; }
         }
     } else {
-        const int k0 = wave == 2 ? 1 : 0, k1 = wave == 2 ? 2 : 3;   // produced rows this wave finishes
+        const int k0 = wave == 2 ? 1 : 0, k1r = wave == 2 ? 2 : 3;   // produced rows this wave finishes
+        const bool has1 = k1r < kPend;
+        const int k1 = has1 ? k1r : k0;
         double keys[2] = {dinf(), dinf()};
         int ps[2] = {-1, -1}, pn[2] = {-1, -1};
 #pragma unroll
@@ -731,14 +738,14 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
             const RecP p1 = w.recP[(static_cast<size_t>(par) * kPend + k1) * nblk + ii];
             if (!ok) continue;
             if (p0.pv < keys[0]) { keys[0] = p0.pv; ps[0] = p0.slot; pn[0] = p0.node; }
-            if (p1.pv < keys[1]) { keys[1] = p1.pv; ps[1] = p1.slot; pn[1] = p1.node; }
+            if (has1 && p1.pv < keys[1]) { keys[1] = p1.pv; ps[1] = p1.slot; pn[1] = p1.node; }
         }
         AHC_STAMP(0);
         double m[2];
         int L[2];
         wave_min_multi<2>(keys, m, L);
         const int a0 = lane_value(ps[0], L[0]), b0 = lane_value(pn[0], L[0]), a1 = lane_value(ps[1], L[1]), b1 = lane_value(pn[1], L[1]);
-        if (lane == 0) { s_dec.pd[k0] = m[0]; s_dec.ps[k0] = a0; s_dec.pn[k0] = b0; s_dec.pd[k1] = m[1]; s_dec.ps[k1] = a1; s_dec.pn[k1] = b1; }
+        if (lane == 0) { s_dec.pd[k0] = m[0]; s_dec.ps[k0] = a0; s_dec.pn[k0] = b0; if (has1) { s_dec.pd[k1] = m[1]; s_dec.ps[k1] = a1; s_dec.pn[k1] = b1; } }
     }
     AHC_STAMP(6);
     __syncthreads();
@@ -886,17 +893,36 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
             if (S >= 0 && act && x != S)
                 pkey[k] = pair_entry(w.M, Np, S, pnode_[k], x, nx, st.sym_limit);
         }
-        // merged centroid (FastClusterWrapper.cpp:89-100), and |ca - cb|^2 summed as a tree (error <= ~10 ulp,
-        // independent of the merge depth).  Every wave evaluates the whole sum: no workgroup barrier.
+        // merged centroid (FastClusterWrapper.cpp:89-100), and |ca - cb|^2 summed as a tree (error <= ~10 ulp, independent of the merge
+        // depth).  Every wave evaluates the whole sum: no workgroup barrier.  The centroid elements are REQUESTED together (an un-unrolled
+        // loop made four dependent round trips of it: 3 800 of a round's 15 600 cycles), and the division runs only in the wave that
+        // stores the centroid.
+        constexpr int kCk = 4;                                   // elements per lane handled without a loop (d <= 256)
+        double xa[kCk], xb[kCk];
+#pragma unroll
+        for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; xa[j] = k < d ? ca[k] : 0.0; xb[j] = k < d ? cb[k] : 0.0; }
+        AHC_STAMP(9);
+        const bool keeps_centroid = wave == 0 && (st.mode == FA_AHC_MODE_EXACT || blk == 0);
         double part = 0.0;
-        for (int k = lane; k < d; k += 64) {
-            const double xa = ca[k], xb = cb[k];
-            const double cc = __ddiv_rn(__dadd_rn(__dmul_rn(xa, ma), __dmul_rn(xb, mb)), den);
-            if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < kCk; ++j) {
+            const int k = lane + 64 * j;
+            if (keeps_centroid && k < d) {
+                const double cc = __ddiv_rn(__dadd_rn(__dmul_rn(xa[j], ma), __dmul_rn(xb[j], mb)), den);
                 if (st.mode == FA_AHC_MODE_EXACT) s_cvec[k] = cc;
                 if (blk == 0) w.C[static_cast<size_t>(nnew) * d + k] = cc;
             }
-            const double diff = xa - xb;
+            const double diff = xa[j] - xb[j];
+            part += diff * diff;
+        }
+        for (int k = lane + 64 * kCk; k < d; k += 64) {      // d > 256
+            const double ya = ca[k], yb = cb[k];
+            if (keeps_centroid) {
+                const double cc = __ddiv_rn(__dadd_rn(__dmul_rn(ya, ma), __dmul_rn(yb, mb)), den);
+                if (st.mode == FA_AHC_MODE_EXACT) s_cvec[k] = cc;
+                if (blk == 0) w.C[static_cast<size_t>(nnew) * d + k] = cc;
+            }
+            const double diff = ya - yb;
             part += diff * diff;
         }
         double dab = wave_sum(part);
@@ -1325,7 +1351,8 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
         (void)hipMemcpy(hp, w.prof, sizeof(hp), hipMemcpyDeviceToHost);
         const double n = hp[15] ? static_cast<double>(hp[15]) : 1.0;
         fprintf(stderr, "ahc profile (cycles/round, block %d of %d, %llu rounds): load+sync %.0f | decide %.0f | merge loads+dab %.0f | row update %.0f | block reduce %.0f | tail %.0f\n",
-                w.nblk / 2, w.nblk, hp[15], hp[0] / n, (hp[1] + hp[6] + hp[7] + hp[8]) / n, hp[2] / n, hp[3] / n, hp[4] / n, hp[5] / n);
+                w.nblk / 2, w.nblk, hp[15], hp[0] / n, (hp[1] + hp[6] + hp[7] + hp[8]) / n, (hp[2] + hp[9]) / n, hp[3] / n, hp[4] / n, hp[5] / n);
+        fprintf(stderr, "  merge loads+dab = operands arrive %.0f | centroid, |ca - cb|^2, wave sum %.0f\n", hp[9] / n, hp[2] / n);
         fprintf(stderr, "  decide = wave reduction %.0f | barrier + result read %.0f | finished rows + global minimum %.0f | state machine + piggy choice %.0f\n", hp[6] / n, hp[7] / n, hp[8] / n, hp[1] / n);
     }
 #endif
