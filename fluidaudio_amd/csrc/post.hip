@@ -25,12 +25,25 @@ __global__ void centroid_kernel(const double *__restrict__ emb, const double *__
     const int c = blockIdx.y;
     if (k >= d || c >= K) return;
     const int s = spk[c];
+    // The sums run in row order (one rounding per operation, like the reference's daxpy), so the ADDITIONS are a dependent chain — but
+    // the loads are not: 16 rows are requested at a time (the one-row loop paid a full memory round trip per row: 21 ms at 43 200 rows).
     double num = 0.0, den = 0.0;
-    for (int64_t t = 0; t < n; ++t) {
-        const double w = gamma[t * S + s];
-        if (!(w > 0)) continue;
-        den = __dadd_rn(den, w);
-        num = __dadd_rn(num, __dmul_rn(w, emb[t * d + k]));
+    constexpr int kAhead = 16;
+    for (int64_t t0 = 0; t0 < n; t0 += kAhead) {
+        double wv[kAhead], ev[kAhead];
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) {
+            const int64_t t = t0 + j;
+            const bool in = t < n;
+            wv[j] = in ? gamma[t * S + s] : 0.0;
+            ev[j] = in ? emb[t * d + k] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) {
+            if (!(wv[j] > 0)) continue;
+            den = __dadd_rn(den, wv[j]);
+            num = __dadd_rn(num, __dmul_rn(wv[j], ev[j]));
+        }
     }
     cent[static_cast<int64_t>(c) * d + k] = den > 0 ? __ddiv_rn(num, den) : 0.0;
 }
