@@ -261,3 +261,16 @@ def test_row_minima_slabs_equal_restatement_and_linkage_first_merge(fa, gpu_ctx,
     st, z = oracle_mod.linkage_ref(y)
     i = int(np.argmin(m))
     assert st == 0 and {int(z[0, 0]), int(z[0, 1])} == {i, int(a[i])} and z[0, 2] == np.sqrt(m[i])
+
+
+def test_batch_of_more_problems_than_fit_the_kernel_arguments(fa, gpu_ctx, oracle_mod):
+    """Up to 16 running problems travel in the kernel arguments (ahc_round_args); more go through the table / block map in HBM and
+    drop to the argument form once enough of them have finished.  20 small problems of different sizes: every dendrogram = the
+    reference build's."""
+    probs = [speaker_mixture(150 + 37 * k, 32, 3 + k % 4, 0.05, 40 + k) for k in range(20)]
+    st, zs = fa.linkage_batch(probs, ctx=gpu_ctx)
+    assert st == [0] * 20
+    for x, z in zip(probs, zs):
+        sr, zr = oracle_mod.linkage_ref(x)
+        assert sr == 0
+        np.testing.assert_array_equal(z, zr)
