@@ -387,6 +387,66 @@ inline OfflineClusteringResult clusterEmbeddings(Context &ctx, const std::vector
     return out;
 }
 
+// Several recordings through the stage in one call (fa_offline_cluster_batch: their merge chains advance together).  One entry per
+// recording; a recording that fails (e.g. no embeddings) yields an empty optional and does not stop the others.
+struct OfflineRecording { std::vector<std::vector<float>> embeddings; Matrix rhoFeatures; std::vector<int> chunkIndices; };
+inline std::vector<std::optional<OfflineClusteringResult>> clusterEmbeddingsBatch(Context &ctx, const std::vector<OfflineRecording> &recordings, const std::vector<double> &phi,
+                                                                                   const OfflineClusteringConfig &config = {}) {
+    const size_t count = recordings.size();
+    std::vector<std::optional<OfflineClusteringResult>> out(count);
+    if (count == 0) return out;
+    size_t d = 0, rd = 0;
+    for (const auto &r : recordings) { if (!r.embeddings.empty()) d = r.embeddings[0].size(); if (!r.rhoFeatures.empty()) rd = r.rhoFeatures[0].size(); }
+    if (d == 0) return out;
+    std::vector<std::vector<float>> e(count);
+    std::vector<std::vector<double>> rho(count), cen(count, std::vector<double>(256 * d));
+    std::vector<std::vector<int32_t>> chunks(count), labels(count);
+    std::vector<const float *> ep(count);
+    std::vector<const double *> rp(count);
+    std::vector<const int32_t *> cp(count);
+    std::vector<int32_t *> lp(count);
+    std::vector<double *> zp(count);
+    std::vector<int64_t> n(count);
+    static const float dummy_f[4] = {0, 0, 0, 0};
+    static const double dummy_d[4] = {0, 0, 0, 0};
+    static const int32_t dummy_i[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < count; ++i) {
+        const auto &r = recordings[i];
+        n[i] = static_cast<int64_t>(r.embeddings.size());
+        e[i].resize(r.embeddings.size() * d);
+        for (size_t t = 0; t < r.embeddings.size(); ++t) std::copy(r.embeddings[t].begin(), r.embeddings[t].end(), e[i].begin() + t * d);
+        size_t rn = 0, rdi = 0;
+        rho[i] = flatten(r.rhoFeatures, rn, rdi);
+        chunks[i].assign(r.chunkIndices.begin(), r.chunkIndices.end());
+        labels[i].assign(std::max<size_t>(r.embeddings.size(), 1), 0);
+        ep[i] = e[i].empty() ? dummy_f : e[i].data();
+        rp[i] = rho[i].empty() ? dummy_d : rho[i].data();
+        cp[i] = chunks[i].empty() ? dummy_i : chunks[i].data();
+        lp[i] = labels[i].data();
+        zp[i] = cen[i].data();
+    }
+    std::vector<double> ph = phi.size() == rd ? phi : std::vector<double>(rd, 1.0);
+    fa_offline_cluster_config c;
+    fa_offline_cluster_default_config(&c);
+    c.clustering_threshold = config.clusteringThreshold; c.warm_start_fa = config.warmStartFa; c.warm_start_fb = config.warmStartFb;
+    c.max_vbx_iterations = config.maxVbxIterations; c.convergence_tolerance = config.convergenceTolerance; c.constrained_assignment = config.constrainedAssignment ? 1 : 0;
+    c.num_speakers = config.numSpeakers.value_or(-1); c.min_speakers = config.minSpeakers.value_or(-1); c.max_speakers = config.maxSpeakers.value_or(-1);
+    std::vector<int32_t> k(count, 0), st(count, 0);
+    std::vector<fa_offline_cluster_info> infos(count);
+    (void)fa_offline_cluster_batch(ctx.handle(), static_cast<int32_t>(count), ep.data(), n.data(), static_cast<int32_t>(d), rd ? rp.data() : nullptr, static_cast<int32_t>(rd), cp.data(),
+                                   rd ? ph.data() : nullptr, &c, lp.data(), zp.data(), 256, k.data(), infos.data(), st.data());
+    for (size_t i = 0; i < count; ++i) {
+        if (st[i] != FA_SUCCESS) continue;
+        OfflineClusteringResult r;
+        r.assignments.assign(labels[i].begin(), labels[i].begin() + n[i]);
+        r.centroids.assign(k[i], std::vector<double>(d));
+        for (int q = 0; q < k[i]; ++q) std::copy(cen[i].begin() + static_cast<size_t>(q) * d, cen[i].begin() + static_cast<size_t>(q + 1) * d, r.centroids[q].begin());
+        r.info = infos[i];
+        out[i] = std::move(r);
+    }
+    return out;
+}
+
 // LuxTtsMelExtractor (Sources/FluidAudio/TTS/LuxTts/LuxTtsMelExtractor.swift:15-132): the torchaudio-flavoured front end, same C ABI
 struct LuxTtsMelExtractor {
     Context &ctx;

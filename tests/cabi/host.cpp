@@ -145,6 +145,11 @@ static void composedStageTests(Context &ctx) {   // OfflineDiarizerManager.clust
     bool threw = false;
     try { clusterEmbeddings(ctx, {}, {}, {}, phi); } catch (const Error &) { threw = true; }
     CHECK(threw);
+    // the same recording twice plus an empty one through the batched call: per recording the single call's result, the empty one fails alone
+    std::vector<OfflineRecording> recs{{emb, rho, chunks}, {{}, {}, {}}, {emb, rho, chunks}};
+    auto many = clusterEmbeddingsBatch(ctx, recs, phi);
+    CHECK(many.size() == 3 && many[0] && !many[1] && many[2] && many[0]->assignments == res.assignments && many[2]->assignments == res.assignments &&
+          many[0]->centroids == res.centroids);
     LuxTtsMelExtractor lux{ctx};
     std::vector<float> a(24000);
     for (size_t i = 0; i < a.size(); ++i) a[i] = 0.2f * std::sin(0.03f * static_cast<float>(i));
