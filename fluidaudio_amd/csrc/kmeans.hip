@@ -104,12 +104,19 @@ __global__ void __launch_bounds__(64) km_members(const int32_t *__restrict__ ass
         base = part;
     }
     int64_t total = 0;
-    for (int64_t i0 = 0; i0 < n; i0 += 64) {
-        const int64_t i = i0 + lane;
-        const bool m = i < n && a[i] == c;
-        const uint64_t mask = __ballot(m);
-        if (PASS == 1 && m) list[static_cast<int64_t>(r) * n + base + total + __popcll(mask & ((1ull << lane) - 1))] = static_cast<int32_t>(i);
-        total += __popcll(mask);
+    constexpr int kRows = 8;   // 8 x 64 assignments requested before the first is looked at (one load per step made every step a memory round trip)
+    for (int64_t i0 = 0; i0 < n; i0 += 64 * kRows) {
+        int32_t av[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) { const int64_t i = i0 + 64 * u + lane; av[u] = i < n ? a[i] : -1; }
+#pragma unroll
+        for (int u = 0; u < kRows; ++u) {
+            const int64_t i = i0 + 64 * u + lane;
+            const bool m = av[u] == c;
+            const uint64_t mask = __ballot(m);
+            if (PASS == 1 && m) list[static_cast<int64_t>(r) * n + base + total + __popcll(mask & ((1ull << lane) - 1))] = static_cast<int32_t>(i);
+            total += __popcll(mask);
+        }
     }
     if (PASS == 0 && lane == 0) counts[static_cast<int64_t>(r) * k + c] = static_cast<int32_t>(total);
 }
