@@ -101,7 +101,9 @@ def test_reference_cases_on_device(fa, gpu_ctx):
 @pytest.mark.parametrize("T,V,W_,K,peaky,use_lm,seed", [(40, 12, 4, 3, 2.0, False, 0), (60, 33, 8, 6, 3.0, True, 1), (25, 9, 16, 8, 1.0, True, 2),
                                                        (120, 70, 10, 40, 4.0, True, 3), (80, 40, 100, 40, 2.5, False, 4), (30, 300, 5, 64, 3.0, True, 5),
                                                        (50, 17, 128, 16, 0.5, True, 6), (90, 6, 3, 5, 0.7, True, 7), (200, 8, 6, 4, 1.0, True, 8),
-                                                       (150, 5, 12, 4, 0.3, False, 9), (64, 1025, 100, 40, 5.0, True, 10)])
+                                                       (150, 5, 12, 4, 0.3, False, 9), (64, 1025, 100, 40, 5.0, True, 10),
+                                                       (20, 2000, 60, 30, 3.0, True, 12),     # 1 280 < V <= 4 160: keys staged in LDS, 17 per thread
+                                                       (12, 5000, 40, 20, 3.0, False, 13)])   # V > 4 160: keys read from HBM, generic selection
 def test_device_matches_restatement(fa, gpu_ctx, oracle_mod, T, V, W_, K, peaky, use_lm, seed):
     rng = np.random.default_rng(seed)
     blank = V - 1 if seed % 2 == 0 else 0
