@@ -32,10 +32,17 @@ static double treesum_rows(const double *c, size_t d, long a, long b) { /* pairw
 
 static int g_piggy = 0;  /* piggy-back re-scans per merge round (0 = the lazy scheme only) */
 void ahc_model_set_piggyback(int k) { g_piggy = k; }
+/* round-2 row bookkeeping of the device (csrc/ahc.hip): e2[x] = lower bound of the entries of row x other than its nearest
+ * neighbour's — exact second minimum after a full scan of the start-up, the row minimum after a later re-scan (no second minimum is
+ * computed there), lowered by new entries.  A row whose nearest neighbour is one of the merged slots keeps the new cluster as its
+ * neighbour when the new entry is STRICTLY below e2; otherwise it goes stale with the bound e2.  Also: pairs of nodes that both
+ * existed at the start-up read the row copy (both triangles were written). */
+static int g_second = 0;
+void ahc_model_set_second_bound(int on) { g_second = on; }
 
 #define DEAD 0x7fffffffL
 /* valid copy of the pair (x, y): the row of the slot holding the younger node */
-#define VAL(x, y) (node[x] > node[y] ? M[(size_t)(x) * np + (y)] : M[(size_t)(y) * np + (x)])
+#define VAL(x, y) ((node[x] > node[y] || (g_second && node[x] < (long)n && node[y] < (long)n)) ? M[(size_t)(x) * np + (y)] : M[(size_t)(y) * np + (x)])
 
 /* mode 0: exact rows (every new-row entry is the reference's sequential fp64 sum)
  * mode 1: Lance-Williams rows; the pair is taken from them only when it is the unique mutual-nearest pair with
@@ -51,10 +58,11 @@ int ahc_model_linkage(const double *data, size_t n, size_t d, double *z, int mod
     double *C = (double *)malloc(sizeof(double) * d * 2 * n);
     double *M = (double *)malloc(sizeof(double) * np * np);
     double *d1 = (double *)malloc(sizeof(double) * np);
+    double *e2 = (double *)malloc(sizeof(double) * np);
     long *nn = (long *)malloc(sizeof(long) * np);
     long *node = (long *)malloc(sizeof(long) * np);
     double *size = (double *)malloc(sizeof(double) * 2 * n);
-    if (!C || !M || !d1 || !nn || !node || !size) return 4;
+    if (!C || !M || !d1 || !e2 || !nn || !node || !size) return 4;
     memcpy(C, data, sizeof(double) * n * d);
     double dmax = 0.0;
     for (size_t i = 0; i < n; ++i) {
@@ -66,9 +74,9 @@ int ahc_model_linkage(const double *data, size_t n, size_t d, double *z, int mod
         }
     }
     for (size_t i = 0; i < n; ++i) {
-        double mv = INFINITY; long mi = -1;
-        for (size_t j = 0; j < n; ++j) if (M[i * np + j] < mv) { mv = M[i * np + j]; mi = (long)j; }
-        d1[i] = mv; nn[i] = mi;
+        double mv = INFINITY, m2 = INFINITY; long mi = -1;
+        for (size_t j = 0; j < n; ++j) { const double v = M[i * np + j]; if (v < mv) { m2 = mv; mv = v; mi = (long)j; } else if (v < m2) m2 = v; }
+        d1[i] = mv; nn[i] = mi; e2[i] = m2;
     }
     const double eps = mode == 1 ? eps_scale * (double)n * 1.1102230246251565e-16 * dmax : 0.0;
     size_t step = 0;
@@ -118,7 +126,7 @@ int ahc_model_linkage(const double *data, size_t n, size_t d, double *z, int mod
                 const double v = VAL(rescan, j);
                 if (v < mv) { mv = v; mi = (long)j; }
             }
-            d1[rescan] = mv; nn[rescan] = mi;
+            d1[rescan] = mv; nn[rescan] = mi; e2[rescan] = mv;
             st->rescans++;
             continue;
         }
@@ -149,11 +157,20 @@ int ahc_model_linkage(const double *data, size_t n, size_t d, double *z, int mod
             M[(size_t)a * np + x] = dc;  /* the only matrix write of the merge */
             if (dc < nmv) { nmv = dc; nmi = (long)x; }
             const int vld = nn[x] >= 0;
-            if (dc < d1[x] || (vld && dc == d1[x] && a <= nn[x])) { d1[x] = dc; nn[x] = a; }
-            else if (vld && (nn[x] == a || nn[x] == b)) nn[x] = -1;
+            if (!g_second) {
+                if (dc < d1[x] || (vld && dc == d1[x] && a <= nn[x])) { d1[x] = dc; nn[x] = a; }
+                else if (vld && (nn[x] == a || nn[x] == b)) nn[x] = -1;
+            } else {
+                const int hit = vld && (nn[x] == a || nn[x] == b);
+                if (!hit) {
+                    if (dc < d1[x] || (vld && dc == d1[x] && a <= nn[x])) { e2[x] = d1[x]; d1[x] = dc; nn[x] = a; }
+                    else if (dc < e2[x]) e2[x] = dc;
+                } else if (dc < e2[x]) { d1[x] = dc; nn[x] = a; }
+                else { d1[x] = e2[x]; nn[x] = -1; }
+            }
         }
         free(newrow);
-        d1[a] = nmv; nn[a] = nmi;
+        d1[a] = nmv; nn[a] = nmi; e2[a] = nmv;
         ++step; st->merges++;
         /* piggy-back: the same round also re-scans the stale row(s) with the smallest lower bound */
         for (int pg = 0; pg < g_piggy; ++pg) {
@@ -166,10 +183,10 @@ int ahc_model_linkage(const double *data, size_t n, size_t d, double *z, int mod
                 const double v = VAL(srow, j);
                 if (v < mv) { mv = v; mi = (long)j; }
             }
-            d1[srow] = mv; nn[srow] = mi;
+            d1[srow] = mv; nn[srow] = mi; e2[srow] = mv;
         }
     }
     for (size_t s = 0; s + 1 < n; ++s) z[4 * s + 2] = sqrt(sqdist_rows(C, d, (long)z[4 * s], (long)z[4 * s + 1]));
-    free(C); free(M); free(d1); free(nn); free(node); free(size);
+    free(C); free(M); free(d1); free(e2); free(nn); free(node); free(size);
     return 0;
 }

@@ -88,6 +88,23 @@ def test_gpu_algorithm_model_equals_reference_build(oracle_mod):
             np.testing.assert_array_equal(z, zr)
             if eps_scale > 1e6:
                 assert st.ambiguous > 100
+        # round-2 row bookkeeping (second-minimum bound e2, row copies of pairs that existed at the start-up): the same dendrogram
+        # with (almost) no forced re-scans — on both distributions every point's nearest neighbour is the growing cluster
+        lib.ahc_model_set_second_bound(0)
+        base = St()
+        z0 = np.zeros_like(zr)
+        lib.ahc_model_linkage(x.ctypes.data_as(C.c_void_p), C.c_size_t(x.shape[0]), C.c_size_t(x.shape[1]), z0.ctypes.data_as(C.c_void_p), 1, C.c_double(16.0), C.byref(base))
+        lib.ahc_model_set_second_bound(1)
+        for mode, eps_scale in ((0, 0.0), (1, 16.0), (1, 1.6e9)):
+            z = np.zeros_like(zr)
+            st = St()
+            rc = lib.ahc_model_linkage(x.ctypes.data_as(C.c_void_p), C.c_size_t(x.shape[0]), C.c_size_t(x.shape[1]),
+                                       z.ctypes.data_as(C.c_void_p), mode, C.c_double(eps_scale), C.byref(st))
+            assert rc == 0 and st.merges == x.shape[0] - 1
+            np.testing.assert_array_equal(z, zr)
+            if (mode, eps_scale) == (1, 16.0):
+                assert st.rescans * 10 <= base.rescans and base.rescans > 50, (st.rescans, base.rescans)
+        lib.ahc_model_set_second_bound(0)
 
 
 def test_cut_is_top_down_not_fcluster(oracle_mod):
