@@ -274,3 +274,18 @@ def test_batch_of_more_problems_than_fit_the_kernel_arguments(fa, gpu_ctx, oracl
         sr, zr = oracle_mod.linkage_ref(x)
         assert sr == 0
         np.testing.assert_array_equal(z, zr)
+
+
+def test_massive_exact_ties_fall_back_to_exact_rows(fa, gpu_ctx):
+    """30 % / 90 % of the rows are exact copies of other rows: the Lance-Williams filter cannot certify anything, the window
+    overflows, the run rebuilds the matrix and continues with exact rows (exact_fallback) — same multiset of heights and the same
+    partition as a run in exact mode from the start, no pathological number of rounds."""
+    for n, dup in ((3000, 0.3), (4000, 0.9)):
+        x = speaker_mixture(n, 64, 12, 0.03, 7).copy()
+        rng = np.random.default_rng(1)
+        x[rng.integers(0, n, int(n * dup))] = x[rng.integers(0, n, int(n * dup))]
+        st0, z0, s0 = fa.linkage(x, mode=fa.AHC_MODE_AUTO, ctx=gpu_ctx, return_stats=True)
+        st1, z1, s1 = fa.linkage(x, mode=fa.AHC_MODE_EXACT, ctx=gpu_ctx, return_stats=True)
+        assert st0 == st1 == 0 and s0["exact_fallback"] == 1 and s0["rounds"] <= 2 * n
+        np.testing.assert_array_equal(np.sort(z0[:, 2]), np.sort(z1[:, 2]))
+        assert same_partition(fa.cut(z0, n, 0.6), fa.cut(z1, n, 0.6))
