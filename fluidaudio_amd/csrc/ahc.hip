@@ -1292,15 +1292,26 @@ fa_status ensure_ahc_workspace(fa_ctx *ctx, size_t bytes) {
     return FA_SUCCESS;
 }
 
-struct RoundGraph {   // kRoundsPerGraph rounds captured once, replayed until every problem reports done
+// rounds per replay for a problem of n points: one replay should finish a small problem (one round per merge + a few re-scans /
+// window rounds) without hundreds of idle rounds behind it — at n = 50 the fixed 512-round graph cost 2.7 ms per call, five times the
+// reference on a host core; large problems use the full length.  Multiple of 4 (counter rotation and parity).
+inline int rounds_for(size_t n) {
+    const size_t want = n + n / 8 + 8;
+    const size_t r = want < static_cast<size_t>(kRoundsPerGraph) ? want : static_cast<size_t>(kRoundsPerGraph);
+    return static_cast<int>((r + 3) & ~static_cast<size_t>(3));
+}
+
+struct RoundGraph {   // `rounds` rounds captured once, replayed until every problem reports done
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool ok = false;
+    int rounds = kRoundsPerGraph;
     ~RoundGraph() { if (exec) (void)hipGraphExecDestroy(exec); if (graph) (void)hipGraphDestroy(graph); }
-    template <class Launch> void capture(fa_ctx *ctx, Launch &&launch) {
+    template <class Launch> void capture(fa_ctx *ctx, Launch &&launch, const int n_rounds) {
         ok = true;
+        rounds = n_rounds;
         if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            for (int i = 0; i < kRoundsPerGraph; ++i) launch(i & 3);
+            for (int i = 0; i < rounds; ++i) launch(i & 3);
             if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess || !graph) ok = false;
             else if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) ok = false;
         } else ok = false;
@@ -1308,7 +1319,7 @@ struct RoundGraph {   // kRoundsPerGraph rounds captured once, replayed until ev
     }
     template <class Launch> fa_status replay(fa_ctx *ctx, Launch &&launch) {
         if (ok) FA_HIP_TRY(ctx, hipGraphLaunch(exec, ctx->stream));
-        else for (int i = 0; i < kRoundsPerGraph; ++i) launch(i & 3);
+        else for (int i = 0; i < rounds; ++i) launch(i & 3);
         return FA_SUCCESS;
     }
 };
@@ -1334,8 +1345,8 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     auto launch = [&](const int ph) { hipLaunchKernelGGL(ahc_round_t<false>, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr), ph); };
     RoundGraph rg;
-    rg.capture(ctx, launch);
-    const long long max_batches = 64 + 8 * static_cast<long long>(N) / kRoundsPerGraph;  // bound on rounds (merges + rescans + windows)
+    rg.capture(ctx, launch, rounds_for(N));
+    const long long max_batches = 64 + 8 * static_cast<long long>(N) / rg.rounds;  // bound on rounds (merges + rescans + windows)
     for (long long it = 0; it < max_batches && p.active; ++it) {
         FA_TRY(rg.replay(ctx, launch));
         FA_HIP_TRY(ctx, hipMemcpyAsync(&p.h, w.state, sizeof(p.h), hipMemcpyDeviceToHost, ctx->stream));
@@ -1413,7 +1424,7 @@ fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *
     const size_t lds = sizeof(double) * d;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     long long max_batches = 64;
-    for (const Prob &p : probs) if (p.active) max_batches = std::max<long long>(max_batches, 64 + 8 * static_cast<long long>(p.N) / kRoundsPerGraph);
+    for (const Prob &p : probs) if (p.active) max_batches = std::max<long long>(max_batches, 64 + 8 * static_cast<long long>(p.N) / rounds_for(p.N));
     std::vector<int2> map;
     int mapped_active = -1;
     RoundGraph *rg = nullptr;
@@ -1448,7 +1459,9 @@ fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *
             FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             delete rg;
             rg = new RoundGraph();
-            rg->capture(ctx, launch);
+            size_t longest = 0;
+            for (const Prob &q : probs) if (q.active && q.N > longest) longest = q.N;
+            rg->capture(ctx, launch, rounds_for(longest));
             mapped_active = n_active;
         }
         FA_TRY(rg->replay(ctx, launch));
