@@ -1068,6 +1068,17 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__
     ahc_round_body(w_, blk_, ph);
 }
 
+// A problem of at most 256 points is ONE block: its rounds need no device-wide barrier at all, a workgroup barrier between them (with
+// the release / acquire that makes the records and row states written by some threads visible to the others) is enough — all rounds
+// of a replay in one launch, no kernel boundary, operands in the local caches (agent-scope fences around the barrier were measured
+// 0.5 us per round slower and are not needed inside one workgroup).
+__global__ __launch_bounds__(kBlk) void ahc_rounds_single_block(const Ws w, const int rounds) {
+    for (int r = 0; r < rounds; ++r) {
+        ahc_round_body(w, 0, r & 3);
+        __syncthreads();   // workgroup-scope release / acquire: the waves of one workgroup share the CU's caches
+    }
+}
+
 constexpr int kArgProblems = 16;
 struct BatchArgs {
     Ws w[kArgProblems];
@@ -1345,10 +1356,15 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     auto launch = [&](const int ph) { hipLaunchKernelGGL(ahc_round_t<false>, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr), ph); };
     RoundGraph rg;
-    rg.capture(ctx, launch, rounds_for(N));
+    const bool single_block = w.nblk == 1 && !getenv("FA_AHC_NO_SINGLE_BLOCK");
+    if (single_block) {
+        rg.rounds = rounds_for(N);
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_rounds_single_block), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    } else rg.capture(ctx, launch, rounds_for(N));
     const long long max_batches = 64 + 8 * static_cast<long long>(N) / rg.rounds;  // bound on rounds (merges + rescans + windows)
     for (long long it = 0; it < max_batches && p.active; ++it) {
-        FA_TRY(rg.replay(ctx, launch));
+        if (single_block) { hipLaunchKernelGGL(ahc_rounds_single_block, dim3(1), dim3(kBlk), lds, ctx->stream, w, rg.rounds); FA_HIP_TRY(ctx, hipGetLastError()); }
+        else FA_TRY(rg.replay(ctx, launch));
         FA_HIP_TRY(ctx, hipMemcpyAsync(&p.h, w.state, sizeof(p.h), hipMemcpyDeviceToHost, ctx->stream));
         FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         FA_TRY(prob_after_replay(ctx, p));
