@@ -30,6 +30,7 @@ AHC_MODE_AUTO, AHC_MODE_EXACT = 0, 1
 # Every symbol include/fluidaudio_hip.h + include/FastClusterWrapper.h declare (checked by tests/test_abi.py).
 EXPORTED_SYMBOLS = [
     "fa_version", "fa_host_alloc", "fa_host_free", "fa_ctx_create", "fa_ctx_destroy", "fa_ctx_synchronize", "fa_ctx_stream", "fa_ctx_last_error",
+    "fa_ctx_set_workspace_limit", "fa_ctx_set_workspace_cap", "fa_ctx_trim", "fa_ctx_workspace_bytes",
     "fa_mel_default_config", "fa_mel_num_frames", "fa_mel_padded_frames", "fa_mel_plan_create", "fa_mel_plan_destroy",
     "fa_mel_plan_utt_stride", "fa_mel_plan_frame_stride", "fa_mel_plan_total_frames", "fa_mel_execute_dev",
     "fa_mel_batch", "fa_mel_hann_window", "fa_mel_filterbank", "fa_mel_normalize_per_feature_dev",
@@ -39,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_linkage_batch", "fa_ahc_row_minima", "fa_ahc_cluster", "fa_ahc_cut",
     "fa_vbx_speaker_count", "fa_vbx_refine",
     "fa_vbx_weighted_centroids", "fa_assign_cosine", "fa_centroid_scores", "fa_constrained_assign",
-    "fa_offline_cluster_default_config", "fa_offline_cluster", "fa_offline_cluster_batch",
+    "fa_offline_cluster_default_config", "fa_offline_cluster", "fa_offline_cluster_ex", "fa_offline_cluster_batch",
     "fa_arpa_parse", "fa_arpa_destroy", "fa_arpa_unigram_count", "fa_arpa_bigram_context_count", "fa_arpa_score",
     "fa_ctc_vocab_create", "fa_ctc_vocab_destroy", "fa_ctc_beam_search_batch_dev", "fa_ctc_beam_search_batch",
     "fa_wav_pcm16_size", "fa_wav_encode_pcm16", "fa_wav_decode", "fa_rttm_parse", "fa_rttm_format", "fa_export_embeddings_json",
@@ -129,6 +130,11 @@ def lib() -> C.CDLL:
     L.fa_ctx_stream.argtypes = [vp]
     L.fa_ctx_stream.restype = vp
     L.fa_ctx_last_error.argtypes = [vp]
+    L.fa_ctx_set_workspace_limit.argtypes = [vp, sz]
+    L.fa_ctx_set_workspace_cap.argtypes = [vp, sz]
+    L.fa_ctx_trim.argtypes = [vp]
+    L.fa_ctx_workspace_bytes.argtypes = [vp]
+    L.fa_ctx_workspace_bytes.restype = sz
     L.fa_ctx_last_error.restype = C.c_char_p
     L.fa_mel_default_config.argtypes = [C.POINTER(MelConfig)]
     L.fa_mel_default_config.restype = None
@@ -184,6 +190,8 @@ def lib() -> C.CDLL:
     L.fa_offline_cluster_default_config.restype = None
     L.fa_offline_cluster.argtypes = [vp, vp, i64, i32, vp, i32, vp, vp, C.POINTER(OfflineClusterConfig), i32, vp, vp, i32,
                                      C.POINTER(i32), C.POINTER(OfflineClusterInfo)]
+    L.fa_offline_cluster_ex.argtypes = [vp, vp, i64, i32, vp, i32, vp, vp, C.POINTER(OfflineClusterConfig), i32, vp, vp, i32,
+                                        C.POINTER(i32), C.POINTER(OfflineClusterInfo), vp, vp, vp]
     u64 = C.c_uint64
     L.fa_arpa_parse.argtypes = [vp, C.c_char_p, i64, C.POINTER(vp)]
     L.fa_arpa_destroy.argtypes = [vp]
@@ -290,6 +298,19 @@ class Context:
 
     def last_error(self) -> str:
         return (lib().fa_ctx_last_error(self._h) or b"").decode()
+
+    # workspace policy (include/fluidaudio_hip.h): what the context may keep cached between calls / may take at all
+    def set_workspace_limit(self, nbytes: int):
+        self.check(lib().fa_ctx_set_workspace_limit(self._h, nbytes), "fa_ctx_set_workspace_limit")
+
+    def set_workspace_cap(self, nbytes: int | None):
+        self.check(lib().fa_ctx_set_workspace_cap(self._h, (1 << 64) - 1 if nbytes is None else nbytes), "fa_ctx_set_workspace_cap")
+
+    def trim(self):
+        self.check(lib().fa_ctx_trim(self._h), "fa_ctx_trim")
+
+    def workspace_bytes(self) -> int:
+        return int(lib().fa_ctx_workspace_bytes(self._h))
 
     def check(self, status: int, where: str):
         if status != SUCCESS:

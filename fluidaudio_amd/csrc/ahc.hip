@@ -1294,15 +1294,6 @@ fa_status prob_finish(fa_ctx *ctx, Prob &p) {   // heights from the stored centr
     return FA_SUCCESS;
 }
 
-fa_status ensure_ahc_workspace(fa_ctx *ctx, size_t bytes) {
-    if (ctx->ahc_ws_bytes >= bytes) return FA_SUCCESS;
-    if (ctx->ahc_ws) { FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ahc_ws); ctx->ahc_ws = nullptr; ctx->ahc_ws_bytes = 0; }
-    const hipError_t e = hipMalloc(&ctx->ahc_ws, bytes);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: cannot allocate %zu bytes of HBM", bytes); }
-    ctx->ahc_ws_bytes = bytes;
-    return FA_SUCCESS;
-}
-
 // rounds per replay for a problem of n points: one replay should finish a small problem (one round per merge + a few re-scans /
 // window rounds) without hundreds of idle rounds behind it — at n = 50 the fixed 512-round graph cost 2.7 ms per call, five times the
 // reference on a host core; large problems use the full length.  Multiple of 4 (counter rotation and parity).
@@ -1342,7 +1333,8 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     Prob p;
     p.N = N; p.d = d; p.Np = (N + kBlk - 1) / kBlk * kBlk; p.d_data = d_data; p.d_Z = d_Z; p.mode = mode;
     p.L = make_layout(N, p.Np, d, p.Np / kBlk);
-    FA_TRY(ensure_ahc_workspace(ctx, p.L.total));
+    fa::WsUse ws_use(ctx);                      // released (and trimmed to the context's limit) when the call returns
+    FA_TRY(fa::ws_acquire(ctx, p.L.total));
     const size_t lds = sizeof(double) * d;
 
     hipEvent_t ev[3];
@@ -1397,8 +1389,10 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
 // Several independent problems (recordings) advanced by the SAME round launches: one launch = one round of every unfinished
 // problem (grid = sum of their blocks), so K serial merge chains share the machine instead of queueing behind each other —
 // a chain alone keeps ~N/256 of the 256 CUs busy at one wavefront per SIMD.  Start-up and finish run per problem.
-fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
-                                   fa_ahc_stats *stats, fa_status *statuses) {
+namespace {
+fa_status ahc_batch_once(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
+                         fa_ahc_stats *stats, fa_status *statuses, bool *completed) {
+    *completed = false;
     std::vector<Prob> probs(static_cast<size_t>(count));
     size_t total = 0, total_blocks = 0;
     std::vector<size_t> at(count, 0);
@@ -1417,7 +1411,8 @@ fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *
     total += (sizeof(Ws) * count + 255) & ~static_cast<size_t>(255);
     const size_t o_map = total;
     total += (sizeof(int2) * std::max<size_t>(total_blocks, 1) + 255) & ~static_cast<size_t>(255);
-    FA_TRY(ensure_ahc_workspace(ctx, total));
+    fa::WsUse ws_use(ctx);
+    FA_TRY(fa::ws_acquire(ctx, total));
     char *base = static_cast<char *>(ctx->ahc_ws);
     hipEvent_t ev[3];
     for (auto &e : ev) FA_HIP_TRY(ctx, hipEventCreate(&e));
@@ -1505,7 +1500,35 @@ fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *
             stats[k].windows = p.h.windows; stats[k].init_ms = t01; stats[k].merge_ms = t12; stats[k].total_ms = t01 + t12;   // times of the whole batch
         }
     }
+    *completed = true;
     return worst;
+}
+}  // namespace
+
+// Status contract: statuses[k] is the outcome of problem k whatever happens.  An early failure of the batch as a whole (workspace
+// allocation, an event, a copy, a graph replay) marks EVERY problem that was to run with that failure — round 2 left them at SUCCESS
+// and the callers went on to cut dendrograms that were never written.  When the combined workspace of the batch (sum of N_k^2 * 8 B)
+// does not fit, the batch is split in halves down to single problems before anything is reported as ALLOCATION_FAILURE.
+fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
+                                   fa_ahc_stats *stats, fa_status *statuses) {
+    if (count <= 0) return FA_SUCCESS;
+    std::vector<fa_status> local(static_cast<size_t>(count), FA_SUCCESS);
+    fa_status *sts = statuses ? statuses : local.data();
+    bool completed = false;
+    const fa_status st = ahc_batch_once(ctx, count, d_data, n, d, d_Z, mode, stats, sts, &completed);
+    if (completed) return st;
+    const fa_status fail = st != FA_SUCCESS ? st : FA_RUNTIME_ERROR;
+    if (fail == FA_ALLOCATION_FAILURE && count > 1) {
+        const int half = count / 2;
+        const fa_status a = fa::ahc_run_device_batch(ctx, half, d_data, n, d, d_Z, mode, stats, sts);
+        const fa_status b = fa::ahc_run_device_batch(ctx, count - half, d_data + half, n + half, d, d_Z + half, mode, stats ? stats + half : nullptr, sts + half);
+        return a != FA_SUCCESS ? a : b;
+    }
+    for (int k = 0; k < count; ++k) {
+        if (n[k] >= 2) sts[k] = fail;
+        if (stats) stats[k] = fa_ahc_stats{};
+    }
+    return fail;
 }
 
 namespace {

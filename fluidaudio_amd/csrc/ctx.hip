@@ -1,7 +1,53 @@
 // ctx.hip — context lifetime for libfluidaudio_hip.so.
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
 #include "fa_common.h"
 
+namespace {
+// every live context, so that an allocation failure in one of them can release the idle caches of the others on the same device
+std::mutex g_registry_mutex;
+std::vector<fa_ctx *> g_registry;
+
+void free_caches_locked(fa_ctx *c, bool scratch_too) {   // registry mutex held, c not in a linkage call
+    fa::DeviceGuard guard(c->device);
+    if (c->ahc_ws) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ahc_ws); c->ahc_ws = nullptr; c->ahc_ws_bytes = 0; }
+    if (scratch_too && c->scratch) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+}
+}  // namespace
+
 namespace fa {
+fa_status ws_acquire(fa_ctx *ctx, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    ctx->ws_busy = true;
+    if (bytes > ctx->ws_cap) return set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: %zu bytes of workspace needed, the context's cap is %zu", bytes, ctx->ws_cap);
+    if (ctx->ahc_ws_bytes >= bytes) return FA_SUCCESS;
+    if (ctx->ahc_ws) { FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ahc_ws); ctx->ahc_ws = nullptr; ctx->ahc_ws_bytes = 0; }
+    hipError_t e = hipMalloc(&ctx->ahc_ws, bytes);
+    if (e != hipSuccess) {   // HBM pressure: idle caches of the other contexts on this device go first
+        (void)hipGetLastError();
+        ctx->ahc_ws = nullptr;
+        for (fa_ctx *c : g_registry)
+            if (c != ctx && c->device == ctx->device && !c->ws_busy && c->ahc_ws) free_caches_locked(c, false);
+        e = hipMalloc(&ctx->ahc_ws, bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->ahc_ws = nullptr;
+        return set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: cannot allocate %zu bytes of HBM", bytes);
+    }
+    ctx->ahc_ws_bytes = bytes;
+    return FA_SUCCESS;
+}
+
+void ws_release(fa_ctx *ctx) {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    ctx->ws_busy = false;
+    if (ctx->ahc_ws && ctx->ahc_ws_bytes > ctx->ws_limit) free_caches_locked(ctx, false);
+}
+
 fa_status ensure_scratch(fa_ctx *ctx, size_t bytes) {
     if (ctx->scratch_bytes >= bytes) return FA_SUCCESS;
     if (ctx->scratch) {
@@ -36,18 +82,59 @@ fa_status fa_ctx_create(int device, void *stream, fa_ctx **out) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return FA_RUNTIME_ERROR; }
         ctx->owns_stream = true;
     }
+    if (const char *lim = getenv("FLUIDAUDIO_HIP_WORKSPACE_LIMIT")) {
+        char *end = nullptr;
+        const unsigned long long v = strtoull(lim, &end, 10);
+        if (end != lim) ctx->ws_limit = static_cast<size_t>(v);
+    }
+    { std::lock_guard<std::mutex> lock(g_registry_mutex); g_registry.push_back(ctx); }
     *out = ctx;
     return FA_SUCCESS;
 }
 
 void fa_ctx_destroy(fa_ctx *ctx) {
     if (!ctx) return;
+    { std::lock_guard<std::mutex> lock(g_registry_mutex); g_registry.erase(std::remove(g_registry.begin(), g_registry.end(), ctx), g_registry.end()); }
     fa::DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ahc_ws) (void)hipFree(ctx->ahc_ws);
+    if (ctx->poly_taps) (void)hipFree(ctx->poly_taps);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+// Workspace policy.  A context keeps its linkage workspace (N^2 * 8 B: 15 GB at 43 200 rows, 20 GB at 50 000) and its scratch
+// buffer between calls.  fa_ctx_set_workspace_limit: a linkage workspace larger than `bytes` is released when the call that used it
+// returns (0 = never keep one; default: keep, or FLUIDAUDIO_HIP_WORKSPACE_LIMIT).  fa_ctx_trim releases everything cached now.
+// fa_ctx_workspace_bytes reports what is cached.  The calling thread must be the one using the context (contexts are not shared).
+fa_status fa_ctx_set_workspace_limit(fa_ctx *ctx, size_t bytes) {
+    if (!ctx) return FA_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    ctx->ws_limit = bytes;
+    if (!ctx->ws_busy && ctx->ahc_ws && ctx->ahc_ws_bytes > bytes) free_caches_locked(ctx, false);
+    return FA_SUCCESS;
+}
+
+fa_status fa_ctx_set_workspace_cap(fa_ctx *ctx, size_t bytes) {
+    if (!ctx) return FA_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    ctx->ws_cap = bytes;
+    return FA_SUCCESS;
+}
+
+fa_status fa_ctx_trim(fa_ctx *ctx) {
+    if (!ctx) return FA_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    if (ctx->ws_busy) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "trim: the context is inside a linkage call");
+    free_caches_locked(ctx, true);
+    return FA_SUCCESS;
+}
+
+size_t fa_ctx_workspace_bytes(const fa_ctx *ctx) {
+    if (!ctx) return 0;
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    return ctx->ahc_ws_bytes + ctx->scratch_bytes;
 }
 
 fa_status fa_ctx_synchronize(fa_ctx *ctx) {

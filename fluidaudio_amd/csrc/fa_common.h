@@ -19,9 +19,18 @@ struct fa_ctx {
     // grow-only device scratch (reused across calls so steady-state calls do not hipMalloc)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
-    // AHC workspace cache (N^2 fp64 matrix etc.)
+    // AHC workspace cache (N^2 fp64 matrix etc.): kept between calls (the first call at a new size pays 0.4 - 2.5 s of hipMalloc),
+    // released when it exceeds ws_limit after a call, by fa_ctx_trim, or — while no call is using it (ws_busy, guarded by the
+    // registry of ctx.hip) — by ANOTHER context of the same device whose own allocation failed.
     void *ahc_ws = nullptr;
     size_t ahc_ws_bytes = 0;
+    size_t ws_limit = static_cast<size_t>(-1);   // bytes a context may keep cached between calls (FLUIDAUDIO_HIP_WORKSPACE_LIMIT)
+    size_t ws_cap = static_cast<size_t>(-1);     // a linkage call needing more workspace than this fails with ALLOCATION_FAILURE
+    bool ws_busy = false;
+    // polyphase resampler taps of the last (up, down) pair, device resident (resample.hip)
+    void *poly_taps = nullptr;
+    size_t poly_taps_bytes = 0;
+    int32_t poly_up = 0, poly_down = 0, poly_half = 0;
 };
 
 namespace fa {
@@ -65,6 +74,17 @@ struct DevBuf {
 };
 
 fa_status ensure_scratch(fa_ctx *ctx, size_t bytes);
+
+// The cached linkage workspace of a context (ctx.hip).  ws_acquire marks it in use and makes it at least `bytes` large: a failed
+// hipMalloc first releases the idle caches (scratch + linkage workspaces) of every OTHER context on the same device and retries, so a
+// pool of contexts on one GPU degrades to re-allocating instead of failing; ws_release ends the use and applies ctx->ws_limit.
+fa_status ws_acquire(fa_ctx *ctx, size_t bytes);
+void ws_release(fa_ctx *ctx);
+struct WsUse {   // scope of one linkage call
+    fa_ctx *ctx;
+    explicit WsUse(fa_ctx *c) : ctx(c) {}
+    ~WsUse() { ws_release(ctx); }
+};
 
 // ---- device-level cores shared by the host-pointer entries and fa_offline_cluster (internal, not part of the C ABI).
 // All pointers prefixed d_ are DEVICE pointers; everything is enqueued on ctx->stream; results stay on the device.

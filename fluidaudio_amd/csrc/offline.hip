@@ -61,6 +61,8 @@ struct ClusterJob {
     const float *embeddings; int64_t n; int32_t d; const double *rho; int32_t rho_dim; const int32_t *chunk_indices; const double *phi;
     const fa_offline_cluster_config *config; int32_t device_pointers;
     int32_t *labels; double *centroids; int32_t max_centroids; int32_t *n_centroids; fa_offline_cluster_info *info;
+    // optional copies of the intermediates (fa_offline_cluster_ex): AHC labels and VBx hard labels of the training rows, ELBO per iteration
+    int32_t *aux_ahc = nullptr; int32_t *aux_hard = nullptr; double *aux_elbos = nullptr;
 
     fa::DevBuf b_emb32, b_rho_in, b_ok, b_emb, b_temb, b_trho, b_train, b_norm, b_z;
     const float *d_emb32 = nullptr;
@@ -153,6 +155,7 @@ struct ClusterJob {
                 FA_TRY(fa_ahc_cut(z.data(), static_cast<size_t>(nt), config->clustering_threshold, initial.data()));
             }
         }
+        if (aux_ahc) memcpy(aux_ahc, initial.data(), sizeof(int32_t) * static_cast<size_t>(nt));
         t_ahc = now_s();
         // ---- VBx (:308-333)
         const int32_t S = nt > 0 ? std::max(1, fa_vbx_speaker_count(initial.data(), nt)) : 0;
@@ -178,7 +181,9 @@ struct ClusterJob {
                 hard.resize(nt);
                 FA_HIP_TRY(ctx, hipMemcpyAsync(hard.data(), vbx.hard.p, sizeof(int32_t) * nt, hipMemcpyDeviceToHost, st));
             }
+            if (aux_hard) FA_HIP_TRY(ctx, hipMemcpyAsync(aux_hard, vbx.hard.p, sizeof(int32_t) * nt, hipMemcpyDeviceToHost, st));
             FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (aux_elbos) memcpy(aux_elbos, elbos.data(), sizeof(double) * static_cast<size_t>(std::max(vbx_iters, 0)));
             have_vbx = true;
             if (has_constraints) {   // refineWithConstraints (VBxClustering.swift:685-733)
                 const int64_t ns = config->num_speakers, mn = config->min_speakers, mx = config->max_speakers;
@@ -251,12 +256,13 @@ struct ClusterJob {
         } else {
             FA_TRY(fa::assign_dev(ctx, b_emb.as<double>(), n, d, b_cent.as<double>(), K, b_cn.as<double>(), b_out.as<int32_t>()));
         }
-        FA_HIP_TRY(ctx, hipMemcpyAsync(labels, b_out.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
         *n_centroids = K;
-        if (centroids && K > 0) {
-            if (K > max_centroids) return fa::set_error(ctx, FA_OUTPUT_TOO_SMALL, "offline cluster: %d centroids, room for %d", K, max_centroids);
-            FA_HIP_TRY(ctx, hipMemcpyAsync(centroids, b_cent.p, sizeof(double) * K * d, hipMemcpyDeviceToHost, st));
+        if (centroids && K > max_centroids) {   // checked BEFORE any output copy is enqueued: on this error the caller's buffers are untouched
+            FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+            return fa::set_error(ctx, FA_OUTPUT_TOO_SMALL, "offline cluster: %d centroids, room for %d", K, max_centroids);
         }
+        FA_HIP_TRY(ctx, hipMemcpyAsync(labels, b_out.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+        if (centroids && K > 0) FA_HIP_TRY(ctx, hipMemcpyAsync(centroids, b_cent.p, sizeof(double) * K * d, hipMemcpyDeviceToHost, st));
         FA_HIP_TRY(ctx, hipStreamSynchronize(st));
         const double t_end = now_s();
         if (info) {
@@ -297,6 +303,27 @@ fa_status fa_offline_cluster(fa_ctx *ctx, const float *embeddings, int64_t n, in
                              fa_offline_cluster_info *info) {
     if (!ctx) return FA_INVALID_ARGUMENT;
     ClusterJob job{ctx, embeddings, n, d, rho, rho_dim, chunk_indices, phi, config, device_pointers, labels, centroids, max_centroids, n_centroids, info};
+    FA_TRY(job.check_args());
+    fa::DeviceGuard guard(ctx->device);
+    return guarded(ctx, [&]() -> fa_status {
+        FA_TRY(job.prepare());
+        fa_status ahc_st = FA_SUCCESS;
+        if (job.nt >= 2)
+            ahc_st = fa::ahc_run_device(ctx, job.b_norm.as<double>(), static_cast<size_t>(job.nt), static_cast<size_t>(d), job.b_z.as<double>(), config->ahc_mode, &job.ahc_stats);
+        return job.finish(ahc_st);
+    });
+}
+
+// fa_offline_cluster + copies of the stage's intermediates for verification at full size (bench.py and the 8 h digest test compare
+// them with the CPU side): ahc_labels [training rows] = AHCClustering.cluster's output, vbx_hard [training rows] = argmax of gamma,
+// elbos [max_vbx_iterations] (info->vbx_iterations of them are written).  Every pointer may be NULL.
+fa_status fa_offline_cluster_ex(fa_ctx *ctx, const float *embeddings, int64_t n, int32_t d, const double *rho, int32_t rho_dim,
+                                const int32_t *chunk_indices, const double *phi, const fa_offline_cluster_config *config,
+                                int32_t device_pointers, int32_t *labels, double *centroids, int32_t max_centroids, int32_t *n_centroids,
+                                fa_offline_cluster_info *info, int32_t *ahc_labels, int32_t *vbx_hard, double *elbos) {
+    if (!ctx) return FA_INVALID_ARGUMENT;
+    ClusterJob job{ctx, embeddings, n, d, rho, rho_dim, chunk_indices, phi, config, device_pointers, labels, centroids, max_centroids, n_centroids, info,
+                   ahc_labels, vbx_hard, elbos};
     FA_TRY(job.check_args());
     fa::DeviceGuard guard(ctx->device);
     return guarded(ctx, [&]() -> fa_status {

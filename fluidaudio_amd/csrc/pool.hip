@@ -27,7 +27,6 @@ struct fa_pool {
     std::vector<char> busy;
     std::mutex m;
     std::condition_variable cv;
-    size_t next = 0;   // round-robin start of the search for a free context
 };
 
 namespace {
@@ -178,16 +177,16 @@ int32_t fa_ctx_device(const fa_ctx *ctx) { return ctx ? ctx->device : -1; }
 fa_status fa_pool_acquire(fa_pool *pool, fa_ctx **ctx) {
     if (!pool || !ctx || pool->ctx.empty()) return FA_INVALID_ARGUMENT;
     std::unique_lock<std::mutex> lock(pool->m);
+    // The LOWEST free context: a serial caller stays on one device (its warm clocks, its cached linkage workspace — round 2 rotated
+    // round-robin, so a serial Swift caller hopped to a cold GPU on every call and every device ended up caching its own N^2 workspace);
+    // other devices are used only while the lower ones are busy, i.e. by concurrent callers.
     size_t found = pool->ctx.size();
     pool->cv.wait(lock, [&] {
-        for (size_t k = 0; k < pool->ctx.size(); ++k) {
-            const size_t i = (pool->next + k) % pool->ctx.size();
+        for (size_t i = 0; i < pool->ctx.size(); ++i)
             if (!pool->busy[i]) { found = i; return true; }
-        }
         return false;
     });
     pool->busy[found] = 1;
-    pool->next = (found + 1) % pool->ctx.size();
     *ctx = pool->ctx[found];
     return FA_SUCCESS;
 }

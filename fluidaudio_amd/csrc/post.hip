@@ -117,6 +117,17 @@ struct HungLds {
     int p[kHungMaxN + 1], way[kHungMaxN + 1];
     unsigned char used[kHungMaxN + 1];
 };
+// the same arrays as pointers: into the wavefront's LDS slice (n <= kHungMaxN), or into a per-wavefront slab of HBM scratch for
+// problems beyond it (more than 256 clusters or rows in a chunk — the reference solves any size, HungarianAssignment.swift:8-62)
+struct HungView {
+    long long *u, *v, *minv;
+    int *p, *way;
+    unsigned char *used;
+};
+__host__ __device__ inline size_t hung_slab_bytes(const int n) {   // per wavefront, 16-byte aligned
+    const size_t e = static_cast<size_t>(n) + 1;
+    return (e * (3 * sizeof(long long) + 2 * sizeof(int) + 1) + 15) & ~static_cast<size_t>(15);
+}
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -124,13 +135,25 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(256) void hungarian_kernel(const double *__restrict__ scores, const int32_t *__restrict__ chunk_start,
-                                                          const int32_t *__restrict__ row_ids, int32_t *__restrict__ out, int n_chunks, int K) {
-    __shared__ HungLds lds[4];
+                                                          const int32_t *__restrict__ row_ids, int32_t *__restrict__ out, int n_chunks, int K,
+                                                          unsigned char *__restrict__ slabs, int slab_n) {
+    __shared__ HungLds lds[BIG ? 1 : 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x * 4 + wave;
     if (chunk >= n_chunks) return;
-    HungLds &h = lds[wave];
+    HungView h;
+    if (BIG) {
+        unsigned char *base = slabs + static_cast<size_t>(chunk) * hung_slab_bytes(slab_n);
+        const size_t e = static_cast<size_t>(slab_n) + 1;
+        h.u = reinterpret_cast<long long *>(base); h.v = h.u + e; h.minv = h.v + e;
+        h.p = reinterpret_cast<int *>(h.minv + e); h.way = h.p + e;
+        h.used = reinterpret_cast<unsigned char *>(h.way + e);
+    } else {
+        HungLds &l = lds[wave];
+        h.u = l.u; h.v = l.v; h.minv = l.minv; h.p = l.p; h.way = l.way; h.used = l.used;
+    }
     const int r0 = chunk_start[chunk], R = chunk_start[chunk + 1] - r0;
     const int32_t *rows = row_ids + r0;
     if (K <= 0) { for (int r = lane; r < R; r += 64) out[rows[r]] = -2; return; }  // no columns: every row unassigned (:71)
@@ -357,9 +380,13 @@ fa_status fa::constrained_assign_dev(fa_ctx *ctx, const double *d_scores, int64_
         starts.push_back(static_cast<int32_t>(n));
         const int n_chunks = static_cast<int>(starts.size()) - 1;
         for (int c = 0; c < n_chunks; ++c) max_rows = std::max(max_rows, starts[c + 1] - starts[c]);
-        if (std::max(max_rows, static_cast<int>(K)) > kHungMaxN)
-            return fa::set_error(ctx, FA_RUNTIME_ERROR, "constrained assign: more than %d rows per chunk or clusters", kHungMaxN);
-        fa::DevBuf d_start, d_rows;
+        const int n_max = std::max(max_rows, static_cast<int>(K));
+        const bool big = n_max > kHungMaxN;   // potentials / matching in HBM slabs instead of LDS (rare: more than 256 clusters survive VBx)
+        fa::DevBuf d_start, d_rows, d_slabs;
+        if (big && d_slabs.alloc(hung_slab_bytes(n_max) * static_cast<size_t>(n_chunks)) != hipSuccess) {
+            (void)hipGetLastError();
+            return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "constrained assign: device allocation failed");
+        }
         if (d_start.alloc(sizeof(int32_t) * starts.size()) != hipSuccess || d_rows.alloc(sizeof(int32_t) * n) != hipSuccess) {
             (void)hipGetLastError();
             return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "constrained assign: device allocation failed");
@@ -367,7 +394,8 @@ fa_status fa::constrained_assign_dev(fa_ctx *ctx, const double *d_scores, int64_
         FA_HIP_TRY(ctx, hipMemcpyAsync(d_start.p, starts.data(), sizeof(int32_t) * starts.size(), hipMemcpyHostToDevice, ctx->stream));
         FA_HIP_TRY(ctx, hipMemcpyAsync(d_rows.p, order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
         FA_HIP_TRY(ctx, hipMemsetAsync(d_out, 0xfe, sizeof(int32_t) * n, ctx->stream));  // placeholder, every row is written
-        hipLaunchKernelGGL(hungarian_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, ctx->stream, d_scores, d_start.as<int32_t>(), d_rows.as<int32_t>(), d_out, n_chunks, K);
+        if (big) hipLaunchKernelGGL(hungarian_kernel<true>, dim3((n_chunks + 3) / 4), dim3(256), 0, ctx->stream, d_scores, d_start.as<int32_t>(), d_rows.as<int32_t>(), d_out, n_chunks, K, d_slabs.as<unsigned char>(), n_max);
+        else hipLaunchKernelGGL(hungarian_kernel<false>, dim3((n_chunks + 3) / 4), dim3(256), 0, ctx->stream, d_scores, d_start.as<int32_t>(), d_rows.as<int32_t>(), d_out, n_chunks, K, static_cast<unsigned char *>(nullptr), 0);
         FA_HIP_TRY(ctx, hipGetLastError());
         FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the tables above are released on return
         return FA_SUCCESS;

@@ -199,13 +199,24 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
     try {
         int64_t n_taps = 0, pre_remove = 0;
         FA_TRY(fa_resample_poly_taps(u, dn, nullptr, 0, &n_taps, &pre_remove));
-        std::vector<float> taps(n_taps);
-        FA_TRY(fa_resample_poly_taps(u, dn, taps.data(), n_taps, &n_taps, &pre_remove));
         fa::DeviceGuard guard(ctx->device);
-        FA_TRY(fa::ensure_scratch(ctx, sizeof(float) * n_taps));
-        float *d_h = static_cast<float *>(ctx->scratch);
-        FA_HIP_TRY(ctx, hipMemcpyAsync(d_h, taps.data(), sizeof(float) * n_taps, hipMemcpyHostToDevice, ctx->stream));
-        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // taps is a host temporary
+        // The Kaiser taps of a rate pair are computed and uploaded ONCE per context (a context-owned buffer, not the shared scratch):
+        // a repeated call with the same (up, down) enqueues its kernel and returns without touching the host or synchronising.
+        if (ctx->poly_up != u || ctx->poly_down != dn || !ctx->poly_taps) {
+            std::vector<float> taps(n_taps);
+            FA_TRY(fa_resample_poly_taps(u, dn, taps.data(), n_taps, &n_taps, &pre_remove));
+            FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // an earlier call may still read the previous pair's taps
+            if (ctx->poly_taps_bytes < sizeof(float) * n_taps) {
+                if (ctx->poly_taps) { (void)hipFree(ctx->poly_taps); ctx->poly_taps = nullptr; ctx->poly_taps_bytes = 0; }
+                FA_HIP_TRY(ctx, hipMalloc(&ctx->poly_taps, sizeof(float) * n_taps));
+                ctx->poly_taps_bytes = sizeof(float) * n_taps;
+            }
+            ctx->poly_up = 0;
+            FA_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_taps, taps.data(), sizeof(float) * n_taps, hipMemcpyHostToDevice, ctx->stream));
+            FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // taps is a host temporary (first call of a rate pair only)
+            ctx->poly_up = u; ctx->poly_down = dn;
+        }
+        float *d_h = static_cast<float *>(ctx->poly_taps);
         const int64_t span = (static_cast<int64_t>(kPolyTile) * dn + u - 1) / u + (n_taps + u - 1) / u + 4;
         const size_t lds = sizeof(float) * (static_cast<size_t>((n_taps + 3) & ~static_cast<int64_t>(3)) + static_cast<size_t>(span));
         if (lds <= 150 * 1024 && getenv("FA_RESAMPLE_SIMPLE") == nullptr) {

@@ -59,9 +59,11 @@ def select_training_embeddings(embedding256) -> list:
 
 
 def cluster_embeddings(embedding256, rho128, chunk_indices, phi, config: OfflineClusteringConfig | None = None,
-                       ctx: L.Context | None = None) -> ClusteringResult:
+                       ctx: L.Context | None = None, intermediates: bool = False) -> ClusteringResult:
     """One device-resident call (fa_offline_cluster).  ``initial_clusters`` / ``vbx`` of the result are not populated (they never
-    leave the device); ``timings`` carries the library's per-stage wall-clock and ``info`` its counters."""
+    leave the device) unless ``intermediates`` asks for copies (fa_offline_cluster_ex: AHC labels in ``initial_clusters``, VBx hard
+    labels and ELBOs in ``info["vbx_hard"]`` / ``info["elbos"]``); ``timings`` carries the library's per-stage wall-clock and
+    ``info`` its counters."""
     import ctypes as C
     cfg = config or OfflineClusteringConfig()
     ctx = ctx or L.default_context()
@@ -87,13 +89,24 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, config: Offline
     cap = 256
     cen = np.zeros((cap, d), np.float64)
     k, info = C.c_int32(), L.OfflineClusterInfo()
-    ctx.check(L.lib().fa_offline_cluster(ctx.handle, emb.ctypes.data, n, d, rho.ctypes.data if rd else None, rd, chunks.ctypes.data,
-                                         ph.ctypes.data if rd else None, C.byref(c), 0, labels.ctypes.data, cen.ctypes.data, cap, C.byref(k),
-                                         C.byref(info)), "fa_offline_cluster")
+    if intermediates:
+        ahc_lab, hard, elbos = np.full(n, -1, np.int32), np.full(n, -1, np.int32), np.zeros(max(cfg.max_vbx_iterations, 1))
+        ctx.check(L.lib().fa_offline_cluster_ex(ctx.handle, emb.ctypes.data, n, d, rho.ctypes.data if rd else None, rd, chunks.ctypes.data,
+                                                ph.ctypes.data if rd else None, C.byref(c), 0, labels.ctypes.data, cen.ctypes.data, cap, C.byref(k),
+                                                C.byref(info), ahc_lab.ctypes.data, hard.ctypes.data, elbos.ctypes.data), "fa_offline_cluster_ex")
+    else:
+        ctx.check(L.lib().fa_offline_cluster(ctx.handle, emb.ctypes.data, n, d, rho.ctypes.data if rd else None, rd, chunks.ctypes.data,
+                                             ph.ctypes.data if rd else None, C.byref(c), 0, labels.ctypes.data, cen.ctypes.data, cap, C.byref(k),
+                                             C.byref(info)), "fa_offline_cluster")
     t = {"inputs_s": info.inputs_s, "ahc_s": info.ahc_s, "vbx_s": info.vbx_s, "assign_s": info.assign_s, "total_s": info.total_s}
-    res = ClusteringResult([int(v) for v in labels], cen[:k.value].copy(), [], None, [], t)
+    res = ClusteringResult(labels if intermediates else [int(v) for v in labels], cen[:k.value].copy(), [], None, [], t)
     res.info = {f: getattr(info, f) for f, _ in info._fields_ if f != "ahc"}
     res.info["ahc"] = info.ahc.as_dict()
+    if intermediates:
+        nt = int(info.training_rows)
+        res.initial_clusters = ahc_lab[:nt]
+        res.info["vbx_hard"] = hard[:nt]
+        res.info["elbos"] = elbos[:int(info.vbx_iterations)].copy()
     return res
 
 

@@ -48,6 +48,21 @@ void *fa_ctx_stream(const fa_ctx *ctx);
  * fa_host_alloc are moved by DMA at the full PCIe rate and let fa_mel_batch overlap its uploads with its downloads. */
 void *fa_host_alloc(size_t bytes);
 void fa_host_free(void *p);
+/* Workspace policy.  A context keeps its linkage workspace (N^2 * 8 B: 15 GB at 43 200 rows, 20 GB at 50 000) and its scratch buffer
+ * between calls, because the first call at a new size pays 0.4 - 2.5 s of hipMalloc.
+ *   fa_ctx_set_workspace_limit : a cached linkage workspace larger than `bytes` is released when the call that used it returns
+ *                                (0 = never keep one).  Default: keep (or the value of FLUIDAUDIO_HIP_WORKSPACE_LIMIT).
+ *   fa_ctx_set_workspace_cap   : a linkage call that would need more than `bytes` of workspace fails with FA_ALLOCATION_FAILURE
+ *                                instead of taking them (the reference's status for std::bad_alloc, FastClusterWrapper.cpp:236-238;
+ *                                AHCClustering degrades to singletons).  Default: no cap — hipMalloc decides.
+ *   fa_ctx_trim                : releases everything cached now.
+ *   fa_ctx_workspace_bytes     : bytes cached right now.
+ * Independently of these, a context whose workspace allocation fails first releases the idle caches of the OTHER contexts on the
+ * same device and retries, so a pool of contexts on one GPU re-allocates under pressure instead of failing. */
+fa_status fa_ctx_set_workspace_limit(fa_ctx *ctx, size_t bytes);
+fa_status fa_ctx_set_workspace_cap(fa_ctx *ctx, size_t bytes);
+fa_status fa_ctx_trim(fa_ctx *ctx);
+size_t fa_ctx_workspace_bytes(const fa_ctx *ctx);
 /* Last error text recorded on this context ("" if none). */
 const char *fa_ctx_last_error(const fa_ctx *ctx);
 /* Library build identification, e.g. "fluidaudio_hip 0.1 gfx950". */
@@ -344,6 +359,15 @@ fa_status fa_offline_cluster(fa_ctx *ctx, const float *embeddings, int64_t n, in
                              const int32_t *chunk_indices, const double *phi, const fa_offline_cluster_config *config,
                              int32_t device_pointers, int32_t *labels, double *centroids, int32_t max_centroids,
                              int32_t *n_centroids, fa_offline_cluster_info *info);
+/* The same call with copies of the stage's intermediates (verification at full size: bench.py and the 8 h digest test compare them
+ * with the CPU side): ahc_labels HOST int32[training rows] = AHCClustering.cluster's labels (AHCClustering.swift:20-67), vbx_hard
+ * HOST int32[training rows] = argmax of the VBx posteriors (VBxClustering.swift:144-146), elbos HOST double[max_vbx_iterations]
+ * (info->vbx_iterations of them are written).  Each may be NULL. */
+fa_status fa_offline_cluster_ex(fa_ctx *ctx, const float *embeddings, int64_t n, int32_t d, const double *rho, int32_t rho_dim,
+                                const int32_t *chunk_indices, const double *phi, const fa_offline_cluster_config *config,
+                                int32_t device_pointers, int32_t *labels, double *centroids, int32_t max_centroids,
+                                int32_t *n_centroids, fa_offline_cluster_info *info, int32_t *ahc_labels, int32_t *vbx_hard,
+                                double *elbos);
 /* `count` recordings through the same stage in ONE call: inputs and training rows of every recording are prepared, the merge
  * chains of all of them advance together (fa_ahc_linkage_batch's round launches: a single chain leaves most of the machine
  * idle), then every recording is cut / refined / assigned.  HOST pointers; all recordings share d, rho_dim, phi and config.

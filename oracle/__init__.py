@@ -406,7 +406,7 @@ def centroid_scores(emb, centroids) -> np.ndarray:
 
 
 def cluster_embeddings(embedding256, rho128, chunk_indices, phi, threshold=0.6, Fa=0.07, Fb=0.8, max_iter=20, tol=1e-4,
-                       constrained=True, num_speakers=None, min_speakers=None, max_speakers=None):
+                       constrained=True, num_speakers=None, min_speakers=None, max_speakers=None, initial=None):
     """CPU restatement of OfflineDiarizerManager.cluster (:270-375) on precomputed embeddings, including the speaker-count
     constraints of VBxClustering.refineWithConstraints (VBxClustering.swift:685-733)."""
     e32 = np.asarray(embedding256, np.float32)
@@ -414,9 +414,10 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, threshold=0.6, 
     ok = np.isfinite(e32).all(axis=1)
     train = np.nonzero(ok)[0] if ok.any() else np.arange(len(e32))
     temb, trho = emb[train], np.ascontiguousarray(rho128, np.float64)[train]
-    initial = ahc_cluster(temb, threshold) if len(train) >= 2 else np.zeros(len(train), np.int32)
+    if initial is None:       # `initial`: AHC labels of the same input computed earlier (the 8 h digest runs two variants on one linkage)
+        initial = ahc_cluster(temb, threshold) if len(train) >= 2 else np.zeros(len(train), np.int32)
     gamma, pi, hard, elbos = vbx_refine(trho, initial, phi, max_iter, tol, Fa, Fb)
-    out = dict(initial=np.asarray(initial), gamma=gamma, pi=pi, was_adjusted=False)
+    out = dict(initial=np.asarray(initial), gamma=gamma, pi=pi, hard=hard, elbos=elbos, was_adjusted=False)
     if num_speakers is not None or min_speakers is not None or max_speakers is not None:
         _, lo, hi = speaker_constraints(len(train), num_speakers, min_speakers, max_speakers)
         detected = len(set(np.argmax(gamma, axis=1).tolist())) if gamma.size else int((np.asarray(pi) > 1e-7).sum())

@@ -1,0 +1,217 @@
+"""Adversarial parity of the centroid linkage (HIP, FA_AHC_MODE_AUTO = Lance-Williams filter + exact certification windows, and
+FA_AHC_MODE_EXACT) against the reference's own C++ build (oracle/_ref; reference: FastClusterWrapper.cpp:45-52,68-75 distances,
+fastcluster_internal.hpp:1625-1800 algorithm).
+
+The AUTO path decides from approximate (Lance-Williams / Gram-form) values only when the decision is certified by a 2 eps window;
+everything inside the window is re-evaluated with the reference's exact sum.  These inputs attack exactly that:
+  * distances a few ulp apart at EVERY level of the hierarchy (a second copy of the point set with permuted coordinates: the same
+    distances in exact arithmetic, different rounding of the sequential sums),
+  * pairs planted 1 / 2 / 8 / 64 ulp apart in squared distance,
+  * fp32-rounded rows widened to fp64 (the real call path, OfflineDiarizerManager.swift:286),
+  * rows quantised to a 1/64 grid (many exact non-zero ties AND near-ties, overlapping candidate pairs),
+  * mirrored copies (exact ties between disjoint pairs at every level).
+Tie-free inputs must reproduce the reference dendrogram bit for bit.  On EXACT ties the reference's order is an artefact of its
+binary heap (fastcluster_internal.hpp:778-890): between disjoint pairs the tree is the same up to row order (heights multiset +
+every partition equal); between OVERLAPPING pairs centroid linkage is not reducible and two valid greedy runs can build different
+trees — there the device's dendrogram is checked to be a valid greedy centroid linkage (every merged pair is a global minimum of
+the reference's distance at its step, heights bit-exact) by an independent numpy replay, and compared with the reference where
+they agree.  `windows` / `exact_fallback` are asserted so that a silent filter failure is visible."""
+import numpy as np
+import pytest
+from conftest import same_partition
+
+pytestmark = pytest.mark.gpu
+THRS = (0.0, 0.05, 0.2, 0.4, 0.6, 0.9, 1.2, 2.0)
+
+
+def seq_sqdist(x, y):
+    """The reference's distance: sequential fp64 sum of squared differences (FastClusterWrapper.cpp:45-52)."""
+    d = np.asarray(x, np.float64) - np.asarray(y, np.float64)
+    return float(np.cumsum(d * d)[-1])
+
+
+def replay_is_valid_greedy(x, z):
+    """Independent numpy replay of a dendrogram: at every step the merged pair must be A global minimum of the reference's
+    distance among the active clusters, the height its square root, the centroid the reference's weighted mean (:89-100)."""
+    n, d = x.shape
+    cent = {i: x[i].copy() for i in range(n)}
+    size = {i: 1.0 for i in range(n)}
+    for s in range(n - 1):
+        a, b, h, m = int(z[s, 0]), int(z[s, 1]), z[s, 2], z[s, 3]
+        ids = sorted(cent)
+        c = np.stack([cent[i] for i in ids])
+        diff = c[:, None, :] - c[None, :, :]
+        dm = np.cumsum(diff * diff, axis=2)[:, :, -1]
+        np.fill_diagonal(dm, np.inf)
+        dab = dm[ids.index(a), ids.index(b)]
+        if dab != dm.min() or h != np.sqrt(dab) or m != size[a] + size[b]:
+            return False, s
+        cent[n + s] = (cent[a] * size[a] + cent[b] * size[b]) / (size[a] + size[b])
+        size[n + s] = size[a] + size[b]
+        del cent[a], cent[b]
+    return True, -1
+
+
+def clustered(n, d, k, sigma, seed):
+    rng = np.random.default_rng(seed)
+    c = rng.standard_normal((k, d))
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    return c[rng.integers(0, k, n)] + sigma * rng.standard_normal((n, d))
+
+
+def check_exact(fa, gpu_ctx, oracle_mod, x, want_windows=False, modes=(0, 1)):
+    sr, zr = oracle_mod.linkage_ref(x)
+    assert sr == 0
+    out = None
+    for mode in modes:
+        st, z, stats = fa.linkage(x, mode=mode, ctx=gpu_ctx, return_stats=True)
+        assert st == 0
+        bad = np.nonzero((z != zr).any(axis=1))[0]
+        assert bad.size == 0, f"mode {mode}: first differing merge {bad[0]} of {len(z)}: device {z[bad[0]]} reference {zr[bad[0]]} stats {stats}"
+        if mode == 0:
+            out = stats
+            if want_windows:
+                assert stats["windows"] > 0 or stats["exact_fallback"] > 0, stats   # the filter saw the near-ties
+    return out
+
+
+@pytest.mark.parametrize("n,d,seed", [(600, 24, 1), (1500, 64, 2), (900, 256, 3)])
+def test_near_ties_at_every_level_permuted_copy(fa, gpu_ctx, oracle_mod, n, d, seed):
+    """Second copy of the set with its coordinates permuted and the first coordinate shifted far away: in exact arithmetic every
+    distance inside copy 2 equals its twin in copy 1; in fp64 the sequential sums round differently — twins a few ulp apart at every
+    level of both sub-trees."""
+    x = clustered(n, d, 9, 0.05, seed)
+    perm = np.random.default_rng(seed + 100).permutation(d)
+    y = x[:, perm].copy()
+    both = np.vstack([x, y])
+    both[n:, 0] += 64.0                                     # the two copies never interact before the last merge
+    stats = check_exact(fa, gpu_ctx, oracle_mod, both, want_windows=True)
+    assert stats["merges"] == 2 * n - 1
+
+
+def plant(p, i, j, want):
+    """Moves the LAST coordinate of point j (equal to point i's there, so the last term of the sequential sum is the only one that
+    changes and the sum can take every fp64 value above its base) until seq_sqdist(p[i], p[j]) == want."""
+    k = p.shape[1] - 1
+    p[j, k] = p[i, k]
+    assert seq_sqdist(p[i], p[j]) <= want
+    lo, hi = 0.0, 1.0
+    for _ in range(400):
+        mid = 0.5 * (lo + hi)
+        p[j, k] = p[i, k] + mid
+        v = seq_sqdist(p[i], p[j])
+        if v == want:
+            return
+        if v < want:
+            lo = mid
+        else:
+            hi = mid
+    raise AssertionError("could not plant the distance")
+
+
+@pytest.mark.parametrize("ulps", [1, 2, 8, 64])
+def test_planted_pairs_ulps_apart(fa, gpu_ctx, oracle_mod, ulps):
+    """Two disjoint closest pairs whose squared distances differ by exactly `ulps` ulp (either one the smaller), inside 2 000 other
+    points: the first merge must be the reference's, and so must everything after it."""
+    rng = np.random.default_rng(50 + ulps)
+    n, d = 2000, 48
+    x = oracle_mod.ahc_normalize(rng.standard_normal((n, d)))
+    for sign in (+1, -1):
+        p = x.copy()
+        p[1] = p[0]; p[1, 3] += 2.0 ** -12                # pair (0, 1) and pair (2, 3): by far the closest pairs, ~2^-24 apart squared
+        p[3] = p[2]; p[3, 5] += 2.0 ** -12
+        base = max(seq_sqdist(p[0], p[1]), seq_sqdist(p[2], p[3]))
+        for _ in range(70):
+            base = np.nextafter(base, np.inf)
+        want = base
+        for _ in range(ulps):
+            want = np.nextafter(want, np.inf)
+        lo_pair, hi_pair = ((0, 1), (2, 3)) if sign > 0 else ((2, 3), (0, 1))   # which of the two ends up `ulps` ulp below the other
+        plant(p, *lo_pair, base)
+        plant(p, *hi_pair, want)
+        da, db = seq_sqdist(p[0], p[1]), seq_sqdist(p[2], p[3])
+        assert abs(da - db) <= ulps * np.spacing(max(da, db)) and (da < db) == (sign > 0) and da != db
+        check_exact(fa, gpu_ctx, oracle_mod, p, want_windows=True)
+
+
+def test_fp32_rows_widened_like_the_swift_caller(fa, gpu_ctx, oracle_mod):
+    """OfflineDiarizerManager.swift:286 widens Float embeddings to Double, AHCClustering normalises in fp64 (:70-105): every
+    coordinate carries at most 24 significant bits before the normalisation."""
+    for seed, (n, d, k, sigma) in enumerate([(4000, 256, 12, 0.03), (2500, 192, 40, 0.02), (3000, 256, 1, 1.0)]):
+        x32 = clustered(n, d, k, sigma, 200 + seed).astype(np.float32)
+        x = oracle_mod.ahc_normalize(x32.astype(np.float64))
+        check_exact(fa, gpu_ctx, oracle_mod, x, modes=(0,))
+        lab = fa.AHCClustering(ctx=gpu_ctx).cluster(x32.astype(np.float64), 0.6)
+        np.testing.assert_array_equal(np.asarray(lab, np.int32), oracle_mod.ahc_cluster(x32.astype(np.float64), 0.6))
+
+
+def test_mirrored_copy_exact_ties_between_disjoint_pairs(fa, gpu_ctx, oracle_mod):
+    """x and -x (shifted apart): bit-identical distances in both halves at every level — ties only between DISJOINT pairs, so the
+    reference's heap order changes the row order of the dendrogram but not the tree: heights multiset and all partitions equal."""
+    x = clustered(700, 32, 7, 0.05, 11)
+    both = np.vstack([x, -x])
+    both[700:, 0] -= 64.0
+    sr, zr = oracle_mod.linkage_ref(both)
+    assert sr == 0
+    for mode in (0, 1):
+        st, z, stats = fa.linkage(both, mode=mode, ctx=gpu_ctx, return_stats=True)
+        assert st == 0
+        np.testing.assert_array_equal(np.sort(z[:, 2]), np.sort(zr[:, 2]))
+        for thr in THRS:
+            assert same_partition(fa.cut(z, len(both), thr), oracle_mod.ahc_cut(zr, len(both), thr)), (thr, mode, stats)
+
+
+@pytest.mark.parametrize("n,d,k", [(240, 8, 5), (300, 12, 3)])
+def test_quantised_rows_overlapping_ties_valid_greedy(fa, gpu_ctx, oracle_mod, n, d, k):
+    """Rows on a 1/64 grid: exact non-zero ties between OVERLAPPING pairs.  Whatever order the ties are taken in, the result must be
+    a valid greedy centroid linkage with bit-exact heights (independent numpy replay) — for the device AND for the reference; where
+    the two trees coincide as multisets of heights the partitions must coincide too."""
+    x = np.round(clustered(n, d, k, 0.08, 31 + n) * 64.0) / 64.0
+    x = x[np.abs(x).sum(axis=1) > 0]
+    sr, zr = oracle_mod.linkage_ref(x)
+    assert sr == 0
+    ok_ref, _ = replay_is_valid_greedy(x, zr)
+    assert ok_ref                                            # the checker accepts the reference's own output
+    for mode in (0, 1):
+        st, z, stats = fa.linkage(x, mode=mode, ctx=gpu_ctx, return_stats=True)
+        assert st == 0
+        ok, step = replay_is_valid_greedy(x, z)
+        assert ok, (mode, step, stats)
+        if np.array_equal(np.sort(z[:, 2]), np.sort(zr[:, 2])):
+            for thr in THRS:
+                assert same_partition(fa.cut(z, len(x), thr), oracle_mod.ahc_cut(zr, len(x), thr)), (thr, mode)
+
+
+def test_quantised_then_normalised_rows_at_size(fa, gpu_ctx, oracle_mod):
+    """The verdict's case (i): rows quantised to a 1/64 grid BEFORE the normalisation (n = 4 000).  After the fp64 normalisation
+    exact ties survive only between identical rows; everything else becomes near-ties a few ulp apart.  Heights multiset and the
+    partitions at 8 thresholds equal the reference's; `windows` shows the filter at work."""
+    x = np.round(clustered(4000, 32, 10, 0.06, 77) * 64.0) / 64.0
+    x = x[np.abs(x).sum(axis=1) > 0]
+    xn = oracle_mod.ahc_normalize(x)
+    sr, zr = oracle_mod.linkage_ref(xn)
+    assert sr == 0
+    st, z, stats = fa.linkage(xn, mode=0, ctx=gpu_ctx, return_stats=True)
+    assert st == 0
+    np.testing.assert_array_equal(np.sort(z[:, 2]), np.sort(zr[:, 2]))
+    for thr in THRS:
+        assert same_partition(fa.cut(z, len(xn), thr), oracle_mod.ahc_cut(zr, len(xn), thr)), (thr, stats)
+    assert stats["windows"] + stats["exact_fallback"] > 0, stats
+
+
+def test_massive_exact_ties_partitions_equal_the_reference(fa, gpu_ctx, oracle_mod):
+    """30 % / 90 % of the rows are exact copies of other rows (round 2 compared the two device modes with each other): duplicates
+    merge at height 0 in any order into the same multi-points, so heights multiset and partitions must equal the REFERENCE's."""
+    from conftest import speaker_mixture
+    for n, dup in ((3000, 0.3), (4000, 0.9)):
+        x = speaker_mixture(n, 64, 12, 0.03, 7).copy()
+        rng = np.random.default_rng(1)
+        x[rng.integers(0, n, int(n * dup))] = x[rng.integers(0, n, int(n * dup))]
+        sr, zr = oracle_mod.linkage_ref(x)
+        assert sr == 0
+        st, z, stats = fa.linkage(x, mode=fa.AHC_MODE_AUTO, ctx=gpu_ctx, return_stats=True)
+        assert st == 0 and stats["exact_fallback"] == 1 and stats["rounds"] <= 2 * n
+        zero = int((zr[:, 2] == 0).sum())
+        assert int((z[:, 2] == 0).sum()) == zero
+        for thr in (0.0, 0.3, 0.6, 1.0):
+            assert same_partition(fa.cut(z, n, thr), oracle_mod.ahc_cut(zr, n, thr)), (thr, stats)

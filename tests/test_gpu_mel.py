@@ -408,3 +408,32 @@ def test_host_pointer_entry_pipelined_slices_equal_one_slice(fa, gpu_ctx, monkey
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     assert outs[0][1].tolist() == [fa.lib().fa_mel_num_frames(C.byref(cfg), n) for n in lens]
+
+
+@pytest.mark.parametrize("n", [16000, 160000, 240000, 1647, 24000, 12345, 8048, 8159])
+def test_device_vs_independent_torch_stft_evaluation(fa, gpu_ctx, oracle_mod, n):
+    """The tuned kernel (mel_kernel_v4: packed radix-16 FFT) against an evaluation that shares NO code with oracle/: torch.stft
+    (float64, center=True, pad_mode="constant", win 400 in n_fft 512) + the librosa-formula Slaney bank (tests/mel_second_opinion.py),
+    i.e. NeMo's AudioToMelSpectrogramPreprocessor, which AudioMelSpectrogram.swift:4-17 names as its spec.  With the reference's fp32
+    tables plugged in (they are part of its definition) the device must be within 1e-4 pure-relative — also on the lengths where the
+    reference emits one more (truncated) frame than torch (L mod 160 >= 48)."""
+    from mel_second_opinion import nemo_logmel_f64
+    a = synth_audio(n, seed=2000 + n)
+    mel = fa.AudioMelSpectrogram(ctx=gpu_ctx)
+    got, ml, nf = mel.compute_flat_transposed(a)
+    assert ml == 1 + (n + 112) // 160
+    ref = nemo_logmel_f64(a, ml, window=oracle_mod.hann(400), bank=oracle_mod.slaney_filterbank())
+    err = oracle_mod.mel_f64_error(got.reshape(nf, 128)[:ml], ref)
+    assert err <= 1e-4, f"n={n}: max rel err vs torch.stft evaluation {err:.3e}"
+    # a batch of 64 such utterances takes the tuned batched kernel (the bench path); row 17 must be the same numbers
+    import torch
+    B = 64
+    d_pcm = torch.from_numpy(a).cuda().repeat(B)
+    plan = mel.plan(np.arange(B + 1, dtype=np.int64) * n, layout="frame_major")
+    d_out = torch.empty(plan.out_shape(), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    plan.execute(d_pcm, d_out)
+    gpu_ctx.synchronize()
+    row = d_out[17].cpu().numpy().reshape(-1, 128)[:ml]
+    assert oracle_mod.mel_f64_error(row, ref) <= 1e-4
+    plan.close()

@@ -1,0 +1,134 @@
+"""Workspace hygiene of the linkage (N^2 * 8 B per context) and the status contract under memory pressure
+(reference: FastClusterWrapper.cpp:203-243 maps std::bad_alloc to ALLOCATION_FAILURE = 4; AHCClustering.swift:52-55 degrades to
+singletons on any non-zero status).  Round 2 kept every context's workspace forever and, in the batched entry, reported SUCCESS
+for problems whose workspace could not be allocated."""
+import numpy as np
+import pytest
+from conftest import speaker_mixture
+
+pytestmark = pytest.mark.gpu
+GB = 1 << 30
+
+
+def ws_need(n):
+    npad = (n + 255) // 256 * 256
+    return npad * npad * 8
+
+
+def test_cap_gives_allocation_failure_and_singletons(fa, oracle_mod):
+    ctx = fa.Context(0)
+    x = speaker_mixture(2000, 32, 5, 0.05, 1)
+    ctx.set_workspace_cap(ws_need(2000) // 2)
+    st, z = fa.linkage(x, ctx=ctx)
+    assert st == fa.ALLOCATION_FAILURE and "cap" in ctx.last_error()
+    ahc = fa.AHCClustering(ctx=ctx)
+    assert ahc.cluster(x, 0.6) == list(range(2000)) and ahc.last_status == fa.ALLOCATION_FAILURE   # degrade, don't crash
+    ctx.set_workspace_cap(None)
+    st, z = fa.linkage(x, ctx=ctx)
+    sr, zr = oracle_mod.linkage_ref(x)
+    assert st == sr == 0
+    np.testing.assert_array_equal(z, zr)
+
+
+def test_n_that_cannot_fit_is_allocation_failure(fa):
+    """N = 196 608 needs 288 GiB for the matrix alone: hipMalloc fails, the status is 4, nothing is written; N beyond the block-record
+    limit is refused before any allocation."""
+    ctx = fa.Context(0)
+    for n in (196608, 250000):
+        x = np.random.default_rng(0).standard_normal((n, 2))
+        z = np.full((n - 1, 4), -7.0)
+        st = fa.lib().fa_ahc_linkage(ctx.handle, x.ctypes.data, n, 2, z.ctypes.data, z.size, 0, 0, None)
+        assert st == fa.ALLOCATION_FAILURE, (n, st, ctx.last_error())
+        assert (z == -7.0).all()
+    assert ctx.workspace_bytes() == 0
+
+
+def test_batch_statuses_under_memory_pressure(fa, oracle_mod):
+    """The combined workspace of a batch exceeds what the context may take: the batch is split until the parts fit (every dendrogram =
+    the reference's); when not even one problem fits, EVERY problem reports ALLOCATION_FAILURE (round 2: SUCCESS + garbage) and the
+    composed stage degrades to singleton initial clusters."""
+    ctx = fa.Context(0)
+    probs = [speaker_mixture(700 + 100 * k, 32, 4, 0.05, 20 + k) for k in range(6)]
+    refs = [oracle_mod.linkage_ref(p)[1] for p in probs]
+    total = sum(ws_need(len(p)) for p in probs)
+    ctx.set_workspace_cap(total // 2)                      # the whole batch does not fit, halves do
+    st, zs = fa.linkage_batch(probs, ctx=ctx)
+    assert st == [0] * 6
+    for z, zr in zip(zs, refs):
+        np.testing.assert_array_equal(z, zr)
+    ctx.set_workspace_cap(ws_need(700) // 4)               # nothing fits
+    st, zs = fa.linkage_batch(probs, ctx=ctx)
+    assert st == [fa.ALLOCATION_FAILURE] * 6
+    assert all(not z.any() for z in zs)                    # output untouched
+    # fa_offline_cluster_batch on the same context: linkage fails -> singletons -> VBx / assignment still produce labels
+    rng = np.random.default_rng(3)
+    recs = []
+    for k in range(3):
+        n = 120 + 30 * k
+        spk = rng.integers(0, 3, n)
+        cen = rng.standard_normal((3, 64))
+        emb = (cen[spk] + 0.05 * rng.standard_normal((n, 64))).astype(np.float32)
+        rho = rng.standard_normal((3, 16))[spk] + 0.3 * rng.standard_normal((n, 16))
+        recs.append((emb, rho, np.arange(n) // 3))
+    phi = np.ones(16)
+    ctx.set_workspace_cap(1024)
+    st, out = fa.cluster_embeddings_batch(recs, phi, ctx=ctx)
+    assert st == [0, 0, 0]
+    for (emb, rho, ch), r in zip(recs, out):
+        assert r.info["initial_clusters"] == len(emb)      # the singleton fallback of AHCClustering.swift:52-55
+        ref = oracle_mod.cluster_embeddings(emb, rho, ch, phi, initial=np.arange(len(emb), dtype=np.int32))
+        np.testing.assert_array_equal(np.asarray(r.assignments), ref["assignments"])
+
+
+def test_limit_and_trim(fa):
+    ctx = fa.Context(0)
+    x = speaker_mixture(3000, 32, 5, 0.05, 2)
+    assert fa.linkage(x, ctx=ctx)[0] == 0
+    kept = ctx.workspace_bytes()
+    assert kept >= ws_need(3000)                           # cached for the next call
+    ctx.trim()
+    assert ctx.workspace_bytes() == 0
+    ctx.set_workspace_limit(ws_need(1000))
+    assert fa.linkage(x, ctx=ctx)[0] == 0
+    assert ctx.workspace_bytes() < ws_need(3000)           # larger than the limit: released when the call returned
+    assert fa.linkage(x[:900], ctx=ctx)[0] == 0
+    assert ctx.workspace_bytes() >= ws_need(900)           # within the limit: kept
+
+
+def test_eight_pooled_contexts_at_20000_and_release_under_pressure(fa, oracle_mod):
+    """8 contexts on one device, N = 20 000 each (8 x 3.2 GB of workspace), concurrently through the drop-in symbol's pool; then HBM
+    is filled up to a few GB and a second context needs more than what is left: the idle workspace of the first one is released and
+    the call succeeds."""
+    import threading
+
+    import torch
+    pool = fa.Pool([0] * 8)
+    x = speaker_mixture(20000, 64, 16, 0.03, 5)
+    out = [None] * 8
+
+    def work(i):
+        with pool.acquire() as (h, _dev):
+            z = np.zeros((len(x) - 1, 4))
+            st = fa.lib().fa_ahc_linkage(h, x.ctypes.data, x.shape[0], x.shape[1], z.ctypes.data, z.size, 0, 0, None)
+            out[i] = (st, z)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert all(o is not None and o[0] == 0 for o in out)
+    for o in out[1:]:
+        np.testing.assert_array_equal(o[1], out[0][1])
+    del pool, out
+    a, b = fa.Context(0), fa.Context(0)
+    n = 24000
+    need = ws_need(n) + n * 64 * 8 * 6
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    filler = torch.empty(int(free - 1.6 * need), dtype=torch.uint8, device="cuda")   # room for ONE workspace of this size, not two
+    y = speaker_mixture(n, 64, 16, 0.03, 6)
+    st_a, z_a = fa.linkage(y, ctx=a)
+    assert st_a == 0 and a.workspace_bytes() >= ws_need(n)
+    st_b, z_b = fa.linkage(y, ctx=b)
+    assert st_b == 0, b.last_error()
+    np.testing.assert_array_equal(z_a, z_b)
+    assert a.workspace_bytes() < ws_need(n)                # released by b's allocation
+    del filler

@@ -173,3 +173,47 @@ def test_float64_evaluation_other_configs(oracle_mod):
     tol = 1e-4 * (np.abs(x64) + np.abs(x64.mean(1, keepdims=True))) / (x64.std(1, ddof=1, keepdims=True) + 1e-5) + 1e-4 * np.abs(z64[:, :v])
     assert np.all(np.abs(z32[:, :v] - z64[:, :v]) <= tol)
     assert not z64[:, v:].any() and not z32[:, v:].any()
+
+
+# ---- an independent second opinion for the NeMo-flavoured configuration (the one the tuned kernel and the bench run) ----------
+SECOND_OPINION_LENGTHS = [16000, 160000, 240000, 1600 + 47, 24001 - 1, 12345, 160 * 50 + 48, 160 * 50 + 159, 513, 400]
+
+
+def test_tables_against_independent_librosa_formulas(oracle_mod):
+    """Hann window and Slaney bank of the restatement (fp32, AudioMelSpectrogram.swift:553-642) against float64 tables built from
+    the published torch / librosa formulas (tests/mel_second_opinion.py): equal to fp32 rounding of the Swift arithmetic."""
+    import torch
+    from mel_second_opinion import slaney_bank_f64
+    w64 = torch.hann_window(400, periodic=False, dtype=torch.float64).numpy()
+    assert np.abs(oracle_mod.hann(400).astype(np.float64) - w64).max() < 5e-7   # fp32 cos of an fp32 argument up to 2 pi (:553-562)
+    fb64 = slaney_bank_f64()
+    fb32 = oracle_mod.slaney_filterbank().astype(np.float64)
+    assert fb32.shape == fb64.shape == (128, 257)
+    assert np.abs(fb32 - fb64).max() < 1e-5 * fb64.max()   # fp32 ramps: ulp(8 kHz) = 4.9e-4 Hz over triangles ~100 Hz wide
+    # same support except where a weight is below fp32 resolution of the ramp arithmetic
+    assert ((fb32 > 0) != (fb64 > 0)).sum() <= 4 and np.abs(fb32 - fb64)[(fb32 > 0) != (fb64 > 0)].max(initial=0.0) < 1e-7   # [127][256]: the Nyquist bin sits ON the last triangle's right edge, 5e-8 in fp32
+
+
+@pytest.mark.parametrize("n", SECOND_OPINION_LENGTHS)
+def test_mel_f64_against_torch_stft_second_opinion(oracle_mod, n):
+    """oracle.mel_f64 (written from the Swift file) against the torch.stft pipeline (written from NeMo's / librosa's published
+    definitions): with the reference's fp32 tables plugged into both, framing, zero padding, pre-emphasis, DFT, power, bank product
+    and log must agree to 1e-9 — including lengths where the reference emits one more (truncated) frame than torch; with the
+    independent float64 tables the difference is the fp32 rounding of the reference's tables only."""
+    from mel_second_opinion import nemo_logmel_f64
+    a = synth_audio(n, seed=1000 + n)
+    ref = oracle_mod.mel_f64(a)
+    T = oracle_mod.mel_frames(oracle_mod.MelConfig(), n)
+    assert ref.shape == (T, 128) and T == 1 + (n + 112) // 160
+    same_tables = nemo_logmel_f64(a, T, window=oracle_mod.hann(400), bank=oracle_mod.slaney_filterbank())
+    assert np.abs(same_tables - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    flat, ml, _ = oracle_mod.mel_flat(a)
+    assert ml == T
+    assert oracle_mod.mel_f64_error(flat[:, :ml].T, same_tables) <= 1e-4     # the fp32 restatement against the INDEPENDENT evaluation: north-star gate
+    # With the independent float64 TABLES the difference is the fp32 rounding of the reference's tables (:553-642): 2.5e-7 on the Hann
+    # window (fp32 cos of an fp32 argument) leaks ~1e-7 of the pre-emphasised high band into every bin — up to 1e-4 in the log domain
+    # in the weakest low mel bands — and 2e-7 on bank weights of 1e-5 .. 4e-2.  A property of the reference's TABLES (part of its
+    # definition), bounded here on a line-free signal; median difference ~2e-6.
+    b = (np.random.default_rng(n).standard_normal(n) * 0.1).astype(np.float32)
+    diff = np.abs(nemo_logmel_f64(b, T) - oracle_mod.mel_f64(b))
+    assert diff.max() <= 5e-4 and np.median(diff) <= 1e-5
