@@ -59,17 +59,63 @@ def clustered(n, d, k, sigma, seed):
     return c[rng.integers(0, k, n)] + sigma * rng.standard_normal((n, d))
 
 
+def replay_sq(x, z):
+    """Squared merge distance of every row of a dendrogram, recomputed on the CPU with the reference's arithmetic (sequential sums
+    :45-52, weighted-mean centroids :89-100) by following the dendrogram's own merges."""
+    n, d = x.shape
+    cent = np.zeros((2 * n - 1, d))
+    cent[:n] = x
+    size = np.ones(2 * n - 1)
+    out = np.zeros(n - 1)
+    for s in range(n - 1):
+        a, b = int(z[s, 0]), int(z[s, 1])
+        diff = cent[a] - cent[b]
+        out[s] = np.cumsum(diff * diff)[-1]
+        cent[n + s] = (cent[a] * size[a] + cent[b] * size[b]) / (size[a] + size[b])
+        size[n + s] = size[a] + size[b]
+    return out
+
+
+def tree_signature(z, n, sq):
+    """The dendrogram as a SET of nodes (leaf set, squared height, size), independent of row order and node numbering: a random
+    64-bit weight per leaf, a node's key = the wrapping sum of its leaves' weights."""
+    w = [int(v) for v in np.random.default_rng(12345).integers(0, 2 ** 63, 2 * n - 1, dtype=np.uint64)]
+    cnt = [1] * (2 * n - 1)
+    for s in range(n - 1):
+        a, b = int(z[s, 0]), int(z[s, 1])
+        w[n + s] = (w[a] + w[b]) & (2 ** 64 - 1)
+        cnt[n + s] = cnt[a] + cnt[b]
+    return sorted(zip(w[n:], sq.tolist(), cnt[n:]))
+
+
 def check_exact(fa, gpu_ctx, oracle_mod, x, want_windows=False, modes=(0, 1)):
+    """Device dendrogram == the reference build's, bit for bit.  The one excuse: rows in a different ORDER where the squared distances
+    are EXACTLY equal (the reference's order among exact ties is its heap layout, fastcluster_internal.hpp:778-890).  That excuse is
+    checked, not assumed: the CPU replay of both dendrograms must give the same squared distance at EVERY step (a pair merged before
+    a closer one — even 1 ulp closer — changes the sequence), the same tree as a set of (leaf set, squared height, size) nodes, and
+    heights that are the square roots of the replayed values."""
     sr, zr = oracle_mod.linkage_ref(x)
     assert sr == 0
+    sq_ref = None
     out = None
     for mode in modes:
         st, z, stats = fa.linkage(x, mode=mode, ctx=gpu_ctx, return_stats=True)
         assert st == 0
         bad = np.nonzero((z != zr).any(axis=1))[0]
-        assert bad.size == 0, f"mode {mode}: first differing merge {bad[0]} of {len(z)}: device {z[bad[0]]} reference {zr[bad[0]]} stats {stats}"
+        if bad.size:
+            if sq_ref is None:
+                sq_ref = replay_sq(x, zr)
+                np.testing.assert_array_equal(np.sqrt(sq_ref), zr[:, 2])
+            sq = replay_sq(x, z)
+            first = bad[0]
+            msg = f"mode {mode}: first differing merge {first} of {len(z)}: device {z[first]} reference {zr[first]} stats {stats}"
+            assert np.array_equal(sq, sq_ref), msg + f"; squared distances differ first at step {int(np.nonzero(sq != sq_ref)[0][0])}"
+            np.testing.assert_array_equal(np.sqrt(sq), z[:, 2])
+            assert tree_signature(z, len(x), sq) == tree_signature(zr, len(x), sq_ref), msg
+            assert len(np.unique(sq_ref)) < len(sq_ref), msg    # exact ties do exist in this input
         if mode == 0:
             out = stats
+            out["rows_out_of_order_on_exact_ties"] = int(bad.size)
             if want_windows:
                 assert stats["windows"] > 0 or stats["exact_fallback"] > 0, stats   # the filter saw the near-ties
     return out
@@ -77,14 +123,15 @@ def check_exact(fa, gpu_ctx, oracle_mod, x, want_windows=False, modes=(0, 1)):
 
 @pytest.mark.parametrize("n,d,seed", [(600, 24, 1), (1500, 64, 2), (900, 256, 3)])
 def test_near_ties_at_every_level_permuted_copy(fa, gpu_ctx, oracle_mod, n, d, seed):
-    """Second copy of the set with its coordinates permuted and the first coordinate shifted far away: in exact arithmetic every
-    distance inside copy 2 equals its twin in copy 1; in fp64 the sequential sums round differently — twins a few ulp apart at every
-    level of both sub-trees."""
+    """Second copy of the set with its coordinates permuted, kept apart by an extra coordinate: in exact arithmetic every distance
+    inside copy 2 equals its twin in copy 1; in fp64 the sequential sums round differently — twins 0 .. a few ulp apart at every level
+    of both sub-trees (where they come out EXACTLY equal the reference's row order is its heap layout: check_exact)."""
     x = clustered(n, d, 9, 0.05, seed)
     perm = np.random.default_rng(seed + 100).permutation(d)
     y = x[:, perm].copy()
-    both = np.vstack([x, y])
-    both[n:, 0] += 64.0                                     # the two copies never interact before the last merge
+    both = np.hstack([np.vstack([x, y]), np.zeros((2 * n, 1))])
+    both[n:, d] = 64.0                                      # an extra LAST coordinate keeps the copies apart (their last merge) and adds
+                                                            # an exact 0 to every within-copy sum: twins differ by summation order only
     stats = check_exact(fa, gpu_ctx, oracle_mod, both, want_windows=True)
     assert stats["merges"] == 2 * n - 1
 
@@ -146,17 +193,17 @@ def test_fp32_rows_widened_like_the_swift_caller(fa, gpu_ctx, oracle_mod):
 
 
 def test_mirrored_copy_exact_ties_between_disjoint_pairs(fa, gpu_ctx, oracle_mod):
-    """x and -x (shifted apart): bit-identical distances in both halves at every level — ties only between DISJOINT pairs, so the
-    reference's heap order changes the row order of the dendrogram but not the tree: heights multiset and all partitions equal."""
+    """x and -x (kept apart by an extra coordinate): bit-identical distances in both halves at every level — exact ties, but only
+    between DISJOINT pairs, so the reference's heap order changes the row order of the dendrogram and nothing else: same tree, same
+    squared distance at every step (check_exact), same partitions."""
     x = clustered(700, 32, 7, 0.05, 11)
-    both = np.vstack([x, -x])
-    both[700:, 0] -= 64.0
+    both = np.hstack([np.vstack([x, -x]), np.zeros((1400, 1))])
+    both[700:, 32] = 64.0
+    stats = check_exact(fa, gpu_ctx, oracle_mod, both)
     sr, zr = oracle_mod.linkage_ref(both)
-    assert sr == 0
     for mode in (0, 1):
-        st, z, stats = fa.linkage(both, mode=mode, ctx=gpu_ctx, return_stats=True)
+        st, z = fa.linkage(both, mode=mode, ctx=gpu_ctx)
         assert st == 0
-        np.testing.assert_array_equal(np.sort(z[:, 2]), np.sort(zr[:, 2]))
         for thr in THRS:
             assert same_partition(fa.cut(z, len(both), thr), oracle_mod.ahc_cut(zr, len(both), thr)), (thr, mode, stats)
 

@@ -88,7 +88,7 @@ def test_limit_and_trim(fa):
     assert kept >= ws_need(3000)                           # cached for the next call
     ctx.trim()
     assert ctx.workspace_bytes() == 0
-    ctx.set_workspace_limit(ws_need(1000))
+    ctx.set_workspace_limit(ws_need(2000))
     assert fa.linkage(x, ctx=ctx)[0] == 0
     assert ctx.workspace_bytes() < ws_need(3000)           # larger than the limit: released when the call returned
     assert fa.linkage(x[:900], ctx=ctx)[0] == 0
