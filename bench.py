@@ -4,21 +4,22 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-A "step" = one pass of the batched STFT->mel featurizer over BASELINE.json configs[1]
-(1024 x 15 s 16 kHz chunks per GPU, synthetic PCM already resident in HBM, output [B,128,1501] fp32).
-`value` = audio hours featurized per second over all ranks (weak scaling: every rank owns its own 1024 chunks,
-no data-path collective).  Rank 0 prints ONE JSON line which also carries
-  roofline      — the mel kernel's measured HBM fraction (algorithmic bytes / HIP-event kernel time / 8 TB/s)
-  cpu_baseline  — the CPU oracle (a restatement of the Swift/Accelerate path, NOT Apple's vDSP) timed on this box: mel on 1 and
-                  8 threads (value = 1 thread), CTC greedy and VBx restatements beside it
-  ctc           — greedy CTC decode on [T=1500, V=1024] matrices (BASELINE configs[3]); at N > 1 the 10 000 matrices are SHARDED
-                  over the ranks (strong scaling) and the token ids are gathered on rank 0 over RCCL
-  ahc_50k       — centroid-linkage AHC on 50 000 x 256 embeddings (the metric's second half; rank 0): the numpy-seeded input whose
-                  reference dendrogram digest is committed (tests/golden/ahc_full_iid_50000.json), bit_exact_vs_reference_digest
-  ahc_batch     — 16 recordings x 5400 x 256 through fa_ahc_linkage_batch vs sequential calls (rank 0)
-  e2e_8h        — BASELINE configs[4]: 8 h audio -> mel -> precomputed embeddings -> AHC + VBx + assignment (fa_offline_cluster);
-                  one 8 h recording per rank (replicas: the merge chain of one recording does not shard), labels gathered on rank 0
-  featurized_plus_clustered_audio_hours_per_s — the metric's first half on the e2e leg (all ranks)
+BASELINE.json metric: "audio hours/sec featurized+clustered per node; AHC wall-clock @ 50k x 256 embeds".
+A "step" = BASELINE configs[4] on one GPU: ONE 8 h recording featurized and clustered — batched STFT->mel over its 1 920 x 15 s
+chunks (synthetic PCM resident in HBM) + the clustering stage on its 43 200 precomputed embeddings (256-d fp32 + 128-d PLDA
+features, resident in HBM): AHC (threshold 0.6) -> VBx -> gamma-weighted centroids -> per-chunk constrained assignment in one
+library call (fa_offline_cluster).  `value` = audio hours featurized + clustered per second over all ranks (weak scaling: every
+rank owns its own recording; the merge chain of one recording does not shard — DESIGN.md §4).  The session of rank 0 is the one
+whose CPU-side results are committed (tests/golden/e2e_8h.json: AHC on the REFERENCE's own linkage build, the rest from the C
+restatements); `e2e_equals_reference_digest` says the timed calls reproduced them.  Rank 0 prints ONE JSON line which also carries
+  roofline      — the dominant kernel of the step (ahc_round_t, one launch per merge): algorithmic bytes per launch / average
+                  launch period measured with HIP events around the merge phase, against 8 TB/s; traffic from the committed PMC pass
+  cpu_baseline  — the same path on this box's host cores: the reference's linkage build (oracle/_ref) + the C restatements, 1 thread
+  mel           — BASELINE configs[1]: 1024 x 15 s chunks per GPU, its own HBM roofline (HIP events per launch)
+  mel_single_10s— configs[0] shape: one 10 s utterance through the host-pointer entry, p50 / p99 latency
+  ctc           — configs[3]: greedy CTC on 10 000 x [1500, 1024] matrices (sharded over the ranks at N > 1), ids verified in-bench
+  ahc_50k       — configs[2]: the metric's second half, dendrogram SHA-256 against the reference build's committed digest
+  ahc_batch, e2e_16x1h, beam_search — serving-shaped legs (rank 0, N = 1)
 """
 import argparse
 import hashlib
@@ -240,10 +241,30 @@ def ctc_leg(fa, ctx, torch, dist, rank, world, total, steps=3):
         t_gather = time.perf_counter() - t0
         gathered = None if got is None else len(got)
     gbs_rank = batch * CTC_BYTES_PER_MATRIX / (ms * 1e-3) / 1e9
+    # ---- verification of what was timed: EVERY frame id against torch.argmax on the device, the collapse of 8 matrices against the oracle
+    fid = torch.empty((batch, T), dtype=torch.int32, device="cuda")
+    fa.ctc_greedy_ids_dev(ctx, x, V - 1, tok, lens, d_frame_ids=fid, order=False)
+    ctx.synchronize()
+    ids_exact = True
+    for b0 in range(0, batch, 1000):
+        ids_exact = ids_exact and bool(torch.equal(fid[b0:b0 + 1000].long(), torch.argmax(x[b0:b0 + 1000], dim=-1)))
+    rows_exact = None
+    if rank == 0:
+        import oracle
+        rows_exact = True
+        for b in list(range(4)) + [batch // 2, batch - 3, batch - 2, batch - 1]:
+            ref = oracle.ctc_greedy(x[b].cpu().numpy(), V - 1)
+            got = tok[b, :int(lens[b])].cpu().numpy()
+            rows_exact = rows_exact and bool(np.array_equal(got, ref))
+    del fid
+    traffic, tsrc = measured_traffic_of("*_ctc_pmc.json", CTC_SOURCES)
+    if traffic is not None:
+        traffic = traffic * batch / 10000.0          # the PMC pass runs the 10 000-matrix launch; per launch of this rank's share
     out = {"matrices": total, "matrices_per_rank": batch, "T": T, "V": V, "dtype": "f32", "ms_per_pass": ms, "wall_ms_per_pass": 1e3 * wall,
            "matrices_per_s": total / wall, "audio_hours_per_s": total * 15.0 / 3600.0 / wall, "scaling": "strong" if world > 1 else "single",
-           "roofline": {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_rank / HBM_PEAK_GBS, "traffic": None,
-                        "note": "per GPU (slowest rank)"},
+           "ids_exact": bool(ids_exact), "ids_checked": f"all {batch} x {T} frame ids == torch.argmax on the device", "collapsed_rows_equal_oracle": rows_exact,
+           "roofline": {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_rank / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                        "algorithmic_bytes_per_launch": batch * CTC_BYTES_PER_MATRIX, "note": "per GPU (slowest rank)"},
            "mean_tokens_per_matrix": float(lens.float().mean()), "gather_token_ids_s": t_gather, "gathered_rows_on_rank0": gathered}
     if world == 1:   # the row kernel next to it (§8f-3): log-softmax with temperature / blank bias, one read + one write of the matrix
         try:
@@ -263,69 +284,6 @@ def ctc_leg(fa, ctx, torch, dist, rank, world, total, steps=3):
                                   "algorithmic_bytes_per_matrix": 2 * CTC_BYTES_PER_MATRIX}
         except Exception as e:  # noqa: BLE001
             out["log_softmax"] = {"error": repr(e)}
-    return out
-
-
-def e2e_leg(fa, ctx, torch, dist, rank, world, hours=8.0, speakers=12):
-    """BASELINE configs[4]: `hours` of synthetic 16 kHz audio per rank -> mel (15 s chunks) -> precomputed embeddings
-    (3 local speaker slots per 2 s step, OfflineDiarizerTypes.swift:46-55) -> AHC + VBx + centroids + constrained
-    assignment in ONE library call (fa_offline_cluster).  One recording per rank (the merge chain of a recording does not
-    shard); the labels gather on rank 0.  Embeddings/PLDA features are synthetic (the reference computes them with CoreML nets)."""
-    n_chunks15 = int(hours * 3600 / 15)
-    d_pcm = synth_pcm(torch, n_chunks15, 99 + rank)
-    mel = fa.AudioMelSpectrogram(ctx=ctx)
-    plan = mel.plan(np.arange(n_chunks15 + 1, dtype=np.int64) * CHUNK_SAMPLES, layout="mel_major")
-    d_out = torch.empty(plan.out_shape(), dtype=torch.float32, device="cuda")
-    d_len = torch.empty(n_chunks15, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    plan.execute(d_pcm, d_out, d_len, order=False)
-    ctx.synchronize()
-    rng = np.random.default_rng(5 + rank)
-    n_win = int(hours * 3600 / 2)
-    n = 3 * n_win
-    centers = rng.standard_normal((speakers, 256))
-    centers /= np.linalg.norm(centers, axis=1, keepdims=True)
-    spk = np.stack([rng.permutation(speakers)[:3] for _ in range(n_win)]).reshape(-1)
-    emb = (centers[spk] + 0.03 * rng.standard_normal((n, 256))).astype(np.float32)
-    phi = np.linspace(2.0, 1.0, 128)
-    rho = (rng.standard_normal((speakers, 128)) * np.sqrt(phi))[spk] + rng.standard_normal((n, 128))
-    chunks = np.repeat(np.arange(n_win), 3)
-    fa.cluster_embeddings(emb, rho, chunks, phi, ctx=ctx)   # warm-up at full size: the context's 15 GB linkage workspace is allocated once (0.4 - 2.5 s of hipMalloc) and kept
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    plan.execute(d_pcm, d_out, d_len, order=False)
-    ctx.synchronize()
-    t_mel = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    res = fa.cluster_embeddings(emb, rho, chunks, phi, ctx=ctx)
-    t_cl = time.perf_counter() - t0
-    del d_out, d_pcm
-    lab = np.asarray(res.assignments)
-    pure = len(set(zip(spk.tolist(), lab.tolist()))) == speakers
-    t_all = t_mel + t_cl
-    gathered = None
-    if dist is not None:
-        tt = torch.tensor([t_all, t_mel, t_cl], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_all, t_mel, t_cl = float(tt[0]), float(tt[1]), float(tt[2])
-        ok = torch.tensor([1.0 if pure else 0.0], device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        pure = bool(ok.item() > 0.5)
-        got = fa.gather_ragged_int32([lab.astype(np.int32)], dist, dst=0)
-        gathered = None if got is None else [int(len(g)) for g in got]
-    out = {"audio_hours_per_rank": hours, "recordings": world, "mel_chunks_per_rank": n_chunks15, "mel_s": t_mel, "embeddings_per_recording": n, "cluster_s": t_cl,
-           "stages_s": res.timings, "speakers_true": speakers, "clusters_found": int(res.centroids.shape[0]),
-           "labels_match_speakers": bool(pure), "audio_hours_per_s": world * hours / t_all, "gathered_label_rows": gathered,
-           "note": "fa_offline_cluster: embeddings and PLDA features go up once (host pointers, PCIe included), intermediates stay in HBM; mel inputs resident in HBM"}
-    if world == 1:
-        # the speaker-count fallback on the same embeddings: best-of-10 K-Means to speakers - 2 (VBxClustering.swift:716-722)
-        emb64 = emb.astype(np.float64)
-        fa.KMeansClustering.cluster_with_centroids_n_init(emb64[:3000], speakers - 2, 100, 10, 0, ctx=ctx)
-        t0 = time.perf_counter()
-        km, _ = fa.KMeansClustering.cluster_with_centroids_n_init(emb64, speakers - 2, 100, 10, 0, ctx=ctx)
-        out["kmeans_fallback_s"] = time.perf_counter() - t0
-        out["kmeans_clusters"] = len(set(km))
     return out
 
 
@@ -402,58 +360,276 @@ def beam_leg(fa, ctx, torch, batch=512, frames=1500, vocab=1025):
             "audio_hours_per_s": batch * frames * 0.01 / 3600 / dt, "us_per_frame_step": dt / frames * 1e6, "mean_tokens": float(lens.float().mean())}
 
 
-def sharded_start_leg(fa, ctx, torch, dist, rank, world, n=50000, d=256):
-    """SURVEY.md §8e, one 50 k problem: all-gather X over RCCL, per-rank row slab of the nearest-neighbour table
-    (fa_ahc_row_minima), all-gather of (min, idx) — next to the same table computed by ONE rank.  The merge chain stays on one GPU."""
-    import ctypes as C
+AHC_SOURCES = ("ahc.hip",)
+CTC_SOURCES = ("ctc.hip",)
+
+
+def sources_sha256(files):
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "fluidaudio_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def measured_traffic_of(pattern, files):
+    """HBM bytes per launch from the newest committed PMC summary matching profiles/<pattern>, refused when the kernel sources changed."""
+    import glob
+    now = sources_sha256(files)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            with open(f) as fh:
+                j = json.load(fh)
+        except Exception:  # noqa: BLE001
+            continue
+        if j.get("kernel_sources_sha256") == now and j.get("hbm_traffic_bytes_per_launch"):
+            return j["hbm_traffic_bytes_per_launch"], {"file": os.path.relpath(f, ROOT), "kernel_sources_sha256": now}
+    return None, {"file": None, "note": "no PMC summary for the present kernel sources (sha256 %s...)" % now[:12]}
+
+
+def e2e_session_for(rank, hours):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    from ahc_full_inputs import ahc_input
-    x = ahc_input("iid", n, d)
-    d_x = torch.from_numpy(x).cuda()
+    from e2e_inputs import e2e_session, input_digest
+    s = e2e_session(hours, 12, seed=5 + rank)
+    gold = aux = None
+    gp = os.path.join(ROOT, "tests", "golden", "e2e_8h.json")
+    if rank == 0 and hours == 8.0 and os.path.exists(gp):
+        with open(gp) as f:
+            gold = json.load(f)
+        if gold["input_sha256"] != input_digest(s):
+            gold = None                                  # another numpy: the digests do not apply
+        else:
+            aux = np.load(gp[:-5] + ".npz")
+    return s, gold, aux
 
-    def slab_dev(_x_all, lo, hi):
-        m = torch.empty(hi - lo, dtype=torch.float64, device="cuda")
-        a = torch.empty(hi - lo, dtype=torch.int32, device="cuda")
-        ctx.check(fa.lib().fa_ahc_row_minima(ctx.handle, C.c_void_p(d_x.data_ptr()), n, d, lo, hi, C.c_void_p(m.data_ptr()), C.c_void_p(a.data_ptr()), 1), "fa_ahc_row_minima")
-        ctx.synchronize()
-        return m.cpu().numpy(), a.cpu().numpy()
 
-    lo, hi = fa.shard_range(n, rank, world)
-    slab_dev(None, lo, min(hi, lo + 256))
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    m, a = fa.sharding.row_minima_sharded(x[lo:hi], lo, n, slab_dev, dist)
-    t_sh = time.perf_counter() - t0
-    out = {"n": n, "d": d, "ranks": world, "sharded_s": t_sh}
-    if rank == 0:
+def mel_single_leg(fa, ctx, calls=200):
+    """BASELINE configs[0] shape (the reference's callers are streaming: one utterance per call, StreamingEouAsrManager.swift:558):
+    one 10 s / 160 000-sample utterance through the HOST-pointer entry (upload, kernel, download, synchronise), latency per call."""
+    import oracle
+    rng = np.random.default_rng(11)
+    t = np.arange(160000) / 16000.0
+    a = (rng.uniform(-1, 1, 160000) * 0.1 + 0.3 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    mel = fa.AudioMelSpectrogram(ctx=ctx)
+    for _ in range(10):
+        got, ml, nf = mel.compute_flat(a)
+    lat = []
+    for _ in range(calls):
         t0 = time.perf_counter()
-        m1, a1 = slab_dev(None, 0, n)
-        out["single_rank_s"] = time.perf_counter() - t0
-        out["tables_equal"] = bool(np.array_equal(m, m1) and np.array_equal(a, a1))
-        out["note"] = ("exact (difference-form) fp64 distances; the production start-up is the Gram-form MFMA kernel (40 ms at 50k on one GPU) and the "
-                       "serial merge chain (570 ms) does not shard: see DESIGN.md §4")
+        got, ml, nf = mel.compute_flat(a)
+        lat.append(time.perf_counter() - t0)
+    lat = np.sort(np.asarray(lat))
+    t0 = time.perf_counter()
+    ref, rml, rnf = oracle.mel_flat(a)
+    t_cpu = time.perf_counter() - t0
+    err = float(np.max(np.abs(got.reshape(128, nf) - ref) / np.maximum(1.0, np.abs(ref))))
+    return {"samples": 160000, "frames": int(ml), "calls": calls, "p50_ms": 1e3 * float(lat[len(lat) // 2]), "p99_ms": 1e3 * float(lat[int(len(lat) * 0.99) - 1]),
+            "min_ms": 1e3 * float(lat[0]), "realtime_factor_p50": 10.0 / float(lat[len(lat) // 2]), "cpu_oracle_1_core_ms": 1e3 * t_cpu,
+            "max_rel_err_vs_oracle": err, "within_1e-4": bool(err <= 1e-4 and (ml, nf) == (rml, rnf)),
+            "note": "host-pointer entry fa_mel_batch incl. PCIe both ways and the Python ctypes call"}
+
+
+def headline_leg(fa, ctx, torch, dist, rank, world, steps, warmup, hours=8.0):
+    """The timed region of the bench: K x (mel over the recording's chunks + fa_offline_cluster on its embeddings), inputs resident."""
+    from e2e_inputs import sha256 as sha
+    s, gold, aux = e2e_session_for(rank, hours)
+    n_chunks15 = int(hours * 3600 / 15)
+    d_pcm = synth_pcm(torch, n_chunks15, 99 + rank)
+    mel = fa.AudioMelSpectrogram(ctx=ctx)
+    plan = mel.plan(np.arange(n_chunks15 + 1, dtype=np.int64) * CHUNK_SAMPLES, layout="mel_major")
+    d_out = torch.empty(plan.out_shape(), dtype=torch.float32, device="cuda")
+    d_len = torch.empty(n_chunks15, dtype=torch.int32, device="cuda")
+    d_emb = torch.from_numpy(s["emb"]).cuda()
+    d_rho = torch.from_numpy(s["rho"]).cuda()
+    torch.cuda.synchronize()
+    n = len(s["emb"])
+    # cold start: the first call of a context at this size allocates the linkage workspace (N^2 * 8 B = 15 GB at 43 200 rows)
+    t0 = time.perf_counter()
+    first = fa.cluster_embeddings(d_emb, d_rho, s["chunks"], s["phi"], ctx=ctx)
+    first_call_s = time.perf_counter() - t0
+    plan.execute(d_pcm, d_out, d_len, order=False)
+    ctx.synchronize()
+
+    def step():
+        plan.execute(d_pcm, d_out, d_len, order=False)
+        return fa.cluster_embeddings(d_emb, d_rho, s["chunks"], s["phi"], ctx=ctx, intermediates=False)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    results = [step() for _ in range(steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
     if dist is not None:
-        dist.barrier()
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    # mel share of a step, timed on its own (not part of the timed region above)
+    t0 = time.perf_counter()
+    plan.execute(d_pcm, d_out, d_len, order=False)
+    ctx.synchronize()
+    t_mel = time.perf_counter() - t0
+    assert int(d_len[0]) == 1501 and bool(torch.isfinite(d_out[n_chunks15 // 2]).all())
+    # ---- verification of what was timed
+    lab = [np.asarray(r.assignments, np.int32) for r in results]
+    same_every_step = all(np.array_equal(lab[0], x) for x in lab[1:])
+    pure = len(set(zip(s["spk"].tolist(), lab[-1].tolist()))) == s["speakers"]
+    digest = None
+    if gold is not None:
+        chk = fa.cluster_embeddings(s["emb"], s["rho"], s["chunks"], s["phi"], ctx=ctx, intermediates=True)   # host pointers + copies of the intermediates
+        digest = {"file": "tests/golden/e2e_8h.json",
+                  "assignments": sha(lab[-1]) == gold["assignments_sha256"],
+                  "centroids_1e-9": bool(results[-1].centroids.shape == aux["centroids"].shape and np.allclose(results[-1].centroids, aux["centroids"], rtol=0, atol=1e-9)),
+                  "ahc_labels": sha(np.asarray(chk.initial_clusters, np.int32)) == gold["ahc_labels_sha256"],
+                  "vbx_hard_labels": sha(np.asarray(chk.info["vbx_hard"], np.int32)) == gold["vbx_hard_sha256"],
+                  "vbx_iterations": int(chk.info["vbx_iterations"]) == gold["vbx_iterations"],
+                  "elbos_1e-9": bool(np.allclose(chk.info["elbos"], gold["vbx_elbos"], rtol=1e-9, atol=0)),
+                  "host_pointer_call_equals_device_pointer_call": bool(np.array_equal(np.asarray(chk.assignments, np.int32), lab[-1])),
+                  "cpu_seconds_1_core_when_generated": gold["cpu_seconds_1_core"]}
+        digest["all"] = all(v for k, v in digest.items() if isinstance(v, bool))
+    ok = torch.tensor([1.0 if (pure and same_every_step and (digest is None or digest["all"])) else 0.0], device="cuda")
+    if dist is not None:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    # ---- the dominant kernel: one ahc_round_t launch per round; period = merge-phase HIP-event time / rounds
+    rounds = sum(r.info["ahc"]["rounds"] for r in results)
+    merge_ms = sum(r.info["ahc"]["merge_ms"] for r in results)
+    init_ms = sum(r.info["ahc"]["init_ms"] for r in results) / len(results)
+    period_us = 1e3 * merge_ms / max(1, rounds)
+    npad = (n + 255) // 256 * 256
+    round_bytes = 3 * npad * 8                      # DESIGN.md §3.3: two operand rows read + one row written, fp64, per merge
+    ach = round_bytes / (period_us * 1e-6) / 1e9
+    traffic, tsrc = measured_traffic_of("*_ahc_round_pmc.json", AHC_SOURCES)
+    gram_flop = 2.0 * npad * npad * s["emb"].shape[1] / 2.0      # tiles on and below the diagonal only
+    stage = {k: float(np.mean([r.timings[k] for r in results])) for k in results[0].timings}
+    out = {"elapsed": elapsed, "hours": hours, "first_call_s": first_call_s, "first_call_note": "fresh context: includes the hipMalloc of the 15 GB linkage workspace",
+           "mel_s": t_mel, "mel_chunks": n_chunks15, "embeddings": n, "stages_s": stage, "clusters_found": int(results[-1].centroids.shape[0]),
+           "speakers_true": s["speakers"], "labels_match_speakers": bool(pure), "identical_every_step": bool(same_every_step),
+           "e2e_equals_reference_digest": None if digest is None else bool(digest["all"]), "digest_checks": digest, "all_ranks_ok": bool(ok.item() > 0.5),
+           "ahc": {"rounds_per_step": rounds / len(results), "us_per_round": period_us, "init_ms": init_ms, "merge_ms": merge_ms / len(results),
+                   "windows": results[-1].info["ahc"]["windows"], "exact_fallback": results[-1].info["ahc"]["exact_fallback"],
+                   "gram": {"bound": "mfma", "achieved": gram_flop / 1e12 / max(init_ms * 1e-3, 1e-9), "peak": 78.6, "unit": "TFLOP/s",
+                            "note": "fp64 matrix-core start-up (ahc_gram_mfma): flops of the half Gram matrix / the WHOLE start-up time (transpose, norms, Gram, row minima, records)"}},
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                        "kernel": "ahc_round_t<false>", "launch_period_us": period_us, "launches_per_step": rounds / len(results),
+                        "algorithmic_bytes_per_launch": round_bytes,
+                        "note": "serial-chain-bound, not bandwidth-bound: N - 1 dependent merges, each = kernel boundary + two dependent memory round trips + "
+                                "two reductions (DESIGN.md §3.3); the period is the HIP-event time of the merge phase / launches, i.e. launch duration + boundary"}}
+    del d_out, d_pcm, d_emb, d_rho
     return out
+
+
+def cpu_e2e_baseline(hours=1.0):
+    """The same path on this box's host cores, 1 thread, on a bounded sample (`hours` of audio): oracle mel on its chunks + the
+    REFERENCE's own linkage build (oracle/_ref) + the C restatements of VBx / centroids / Hungarian.  The clustering cost grows like
+    N^2, so the rate of a shorter recording OVERSTATES what the CPU reaches on 8 h (committed: 607 s for the 8 h linkage alone)."""
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from e2e_inputs import e2e_session
+    s = e2e_session(hours, 12, seed=5)
+    rng = np.random.default_rng(1234)
+    t = np.arange(CHUNK_SAMPLES) / 16000.0
+    chunk = (rng.uniform(-1, 1, CHUNK_SAMPLES) * 0.1 + 0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3000 * t)).astype(np.float32)
+    oracle.mel_flat(chunk[:16000])
+    n_chunks = int(hours * 240)
+    timed = min(n_chunks, 64)
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        oracle.mel_flat(chunk)
+    t_mel = (time.perf_counter() - t0) * n_chunks / timed
+    t0 = time.perf_counter()
+    oracle.cluster_embeddings(s["emb"], s["rho"], s["chunks"], s["phi"])
+    t_cl = time.perf_counter() - t0
+    return {"value": hours / (t_mel + t_cl), "unit": "audio_hours/s", "cores": 1, "kind": "reference",
+            "sample": f"{hours:g} h recording ({len(s['emb'])} embeddings): clustering {t_cl:.1f} s = the reference's FastClusterWrapper build (oracle/_ref) + C "
+                      f"restatements of VBx / centroids / Hungarian; mel {t_mel:.1f} s = oracle computeFlat restatement on {n_chunks} chunks ({timed} timed, scaled); "
+                      f"1 of {os.cpu_count()} host cores; Swift/Accelerate itself cannot run on this box",
+            "mel_s": t_mel, "cluster_s": t_cl,
+            "full_size_note": "8 h (43 200 embeddings) on one core of the build container: linkage 607 s + VBx/assignment 2 s (tests/golden/e2e_8h.json) "
+                              "+ mel ~430 s at this rate => ~0.008 audio-hours/s"}
+
+
+def mel_leg(fa, ctx, torch, dist, rank, world, B, steps, warmup, clock_warm_s):
+    """BASELINE configs[1]: one fa_mel_execute_dev over B x 15 s chunks resident in HBM per step; HIP events per launch on the context's stream."""
+    stream = torch.cuda.ExternalStream(ctx.stream)
+    d_pcm = synth_pcm(torch, B, 1234 + rank)
+    offsets = np.arange(B + 1, dtype=np.int64) * CHUNK_SAMPLES
+    mel = fa.AudioMelSpectrogram(ctx=ctx)           # NeMo config: 128 mels, n_fft 512, hop 160, win 400, preemph 0.97
+    plan = mel.plan(offsets, layout="mel_major")     # computeFlat layout [B, 128, 1501]
+    d_out = torch.empty(plan.out_shape(), dtype=torch.float32, device="cuda")
+    d_len = torch.zeros(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    # inside the timed loops the launches go straight to the context's stream (order=False): inputs are complete (synchronised
+    # above) and nothing on torch's stream touches the buffers until the loop has been synchronised
+    t_warm = time.perf_counter() + max(0.0, clock_warm_s)   # set-up: bring the device to sustained clocks (not timed, not a step)
+    while time.perf_counter() < t_warm:
+        plan.execute(d_pcm, d_out, d_len, order=False)
+        ctx.synchronize()
+    for _ in range(warmup):
+        plan.execute(d_pcm, d_out, d_len, order=False)
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record(stream)
+    for i in range(steps):
+        plan.execute(d_pcm, d_out, d_len, order=False)
+        ev[i + 1].record(stream)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+        dist.barrier()
+    kernel_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    kernel_ms_avg = float(np.mean(kernel_ms))
+    assert int(d_len[0]) == 1501 and bool(torch.isfinite(d_out[B // 2]).all())
+    hours = world * B * 15.0 / 3600.0
+    value = hours * steps / elapsed
+    ach = B * MEL_BYTES_PER_CHUNK / (kernel_ms_avg * 1e-3) / 1e9
+    traffic, traffic_source = measured_traffic()
+    return {"workload": "BASELINE configs[1]: batched STFT->mel, 1024 x 15 s 16 kHz chunks per GPU, NeMo config (n_fft 512, hop 160, win 400, 128 mels, "
+                        "preemph 0.97), output [B,128,1501] fp32, inputs resident in HBM", "chunks_per_gpu": B, "steps": steps, "warmup": warmup,
+            "audio_hours_per_s": value, "realtime_factor": value * 3600.0, "ms_per_step": 1e3 * elapsed / steps, "scaling": "weak",
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "mel_kernel_v4<MEL_MAJOR>", "kernel_ms_avg": kernel_ms_avg, "kernel_ms_min": float(np.min(kernel_ms)),
+                         "algorithmic_bytes_per_launch": B * MEL_BYTES_PER_CHUNK,
+                         "note": "VALU / LDS-issue bound rather than HBM bound (DESIGN.md §3.1)"}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10, help="timed steps; one step = one 8 h recording featurized + clustered (~0.3 s)")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--hours", type=float, default=8.0, help="length of the recording of a step (BASELINE configs[4]: 8)")
+    ap.add_argument("--mel-steps", type=int, default=200, help="launches of the configs[1] mel leg")
+    ap.add_argument("--mel-warmup", type=int, default=20)
     ap.add_argument("--clock-warm-s", type=float, default=0.3,
-                    help="seconds of the same launches before the W warm-up steps: the device leaves idle clocks only after ~30 ms "
+                    help="mel leg: seconds of the same launches before its warm-up steps: the device leaves idle clocks only after ~30 ms "
                          "of sustained load (launch time falls from 0.95 to 0.68 ms over the first ~40 launches, scripts/mel_variance.py)")
-    ap.add_argument("--chunks", type=int, default=CHUNKS_PER_GPU, help="15 s chunks per GPU per step (BASELINE config: 1024)")
+    ap.add_argument("--chunks", type=int, default=CHUNKS_PER_GPU, help="mel leg: 15 s chunks per GPU per launch (BASELINE config: 1024)")
+    ap.add_argument("--skip-mel", action="store_true")
     ap.add_argument("--skip-ahc", action="store_true")
     ap.add_argument("--skip-ctc", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
-    ap.add_argument("--skip-e2e", action="store_true")
+    ap.add_argument("--skip-e2e", action="store_true", help="skip the 16 x 1 h leg (the headline itself cannot be skipped)")
     ap.add_argument("--skip-beam", action="store_true")
-    ap.add_argument("--skip-sharded-start", action="store_true", help="N > 1 only: the sharded nearest-neighbour start-up of one 50k problem")
+    ap.add_argument("--only-mel", action="store_true", help="profiling helper: the configs[1] mel leg alone, printed as a reduced line")
     ap.add_argument("--ctc-matrices", type=int, default=10000)
     args = ap.parse_args()
 
@@ -473,75 +649,51 @@ def main():
         torch.cuda.set_device(local_rank)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
     ctx = fa.default_context(local_rank)
-    stream = torch.cuda.ExternalStream(ctx.stream)
-    B = args.chunks
-    d_pcm = synth_pcm(torch, B, 1234 + rank)
-    offsets = np.arange(B + 1, dtype=np.int64) * CHUNK_SAMPLES
-    mel = fa.AudioMelSpectrogram(ctx=ctx)           # NeMo config: 128 mels, n_fft 512, hop 160, win 400, preemph 0.97
-    plan = mel.plan(offsets, layout="mel_major")     # computeFlat layout [B, 128, 1501]
-    d_out = torch.empty(plan.out_shape(), dtype=torch.float32, device="cuda")
-    d_len = torch.zeros(B, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-
-    def barrier():
+    solo = world == 1
+    if args.only_mel:
+        m = mel_leg(fa, ctx, torch, dist, rank, world, args.chunks, args.mel_steps, args.mel_warmup, args.clock_warm_s)
+        if rank == 0:
+            print(json.dumps({"metric": "mel leg only (profiling helper)", "mel": m}))
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-        ctx.synchronize()
+            dist.destroy_process_group()
+        return
 
-    # inside the timed loops the launches go straight to the context's stream (order=False): inputs are complete (synchronised
-    # above) and nothing on torch's stream touches the buffers until the loop has been synchronised
-    t_warm = time.perf_counter() + max(0.0, args.clock_warm_s)   # set-up: bring the device to sustained clocks (not timed, not a step)
-    while time.perf_counter() < t_warm:
-        plan.execute(d_pcm, d_out, d_len, order=False)
-        ctx.synchronize()
-    for _ in range(args.warmup):
-        plan.execute(d_pcm, d_out, d_len, order=False)
-    barrier()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    ev[0].record(stream)
-    for i in range(args.steps):
-        plan.execute(d_pcm, d_out, d_len, order=False)
-        ev[i + 1].record(stream)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
-        dist.barrier()
-    kernel_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
-    kernel_ms_avg = float(np.mean(kernel_ms))
-    assert int(d_len[0]) == 1501 and bool(torch.isfinite(d_out[B // 2]).all())
-
-    hours = world * B * 15.0 / 3600.0
-    value = hours * args.steps / elapsed
-    ach = B * MEL_BYTES_PER_CHUNK / (kernel_ms_avg * 1e-3) / 1e9
-    traffic, traffic_source = measured_traffic()
+    # ---------------- the timed region: K steps of configs[4]
+    h = headline_leg(fa, ctx, torch, dist, rank, world, args.steps, args.warmup, args.hours)
+    elapsed = h.pop("elapsed")
+    value = world * args.hours * args.steps / elapsed
+    roof = h.pop("roofline")
     line = {
-        "metric": "audio hours/sec featurized (batched STFT->mel, 1024 x 15 s chunks per GPU); featurized+clustered in "
-                  "featurized_plus_clustered_audio_hours_per_s; AHC wall-clock @ 50k x 256 in ahc_50k",
+        "metric": "audio hours/sec featurized+clustered per node; AHC wall-clock @ 50k x 256 embeds (ahc_50k.seconds)",
         "value": value, "unit": "audio_hours/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: batched STFT->mel, 1024 x 15 s 16 kHz chunks per GPU, NeMo config "
-                               "(n_fft 512, hop 160, win 400, 128 mels, preemph 0.97), output [B,128,1501] fp32, inputs resident in HBM",
-                   "chunks_per_gpu": B, "realtime_factor": value * 3600.0, "clock_warm_s": args.clock_warm_s, "parallelism": f"dp{world} (independent utterance shards, no collective)"},
-        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "mel_kernel_v4<MEL_MAJOR>", "kernel_ms_avg": kernel_ms_avg, "kernel_ms_min": float(np.min(kernel_ms)),
-                     "algorithmic_bytes_per_launch": B * MEL_BYTES_PER_CHUNK,
-                     "note": "the kernel is VALU/LDS-issue bound, not HBM bound: 0.33 ms of pure VALU issue at the measured 4 cycles per wave64 instruction "
-                             "(profiles/r02_ubench_peak.txt) vs 0.22 ms of HBM time; see DESIGN.md §3.1"},
+        "dtype": "f64 (clustering; the mel stage computes in f32)", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[4] on {world} GPU(s): per GPU one {args.hours:g} h synthetic 16 kHz recording -> mel ({int(args.hours * 240)} x 15 s chunks) -> "
+                               f"{int(args.hours * 5400)} precomputed 256-d embeddings + 128-d PLDA features -> AHC (thr 0.6) + VBx + centroids + constrained assignment; "
+                               "PCM, embeddings and PLDA features resident in HBM, labels + centroids returned to the host",
+                   "hours_per_step_per_gpu": args.hours, "embeddings_per_recording": h["embeddings"], "realtime_factor": value * 3600.0,
+                   "parallelism": f"dp{world} (one recording per GPU, no data-path collective: the merge chain of a recording does not shard)"},
+        "e2e_equals_reference_digest": h["e2e_equals_reference_digest"],
+        "roofline": roof,
+        "e2e_8h": h,
     }
-    solo = world == 1
-    del d_out, d_pcm
     torch.cuda.empty_cache()
     if solo and not args.skip_cpu and rank == 0:
-        line["cpu_baseline"] = cpu_baselines()
+        try:
+            line["cpu_baseline"] = cpu_e2e_baseline()
+            line["cpu_baseline"]["stages"] = cpu_baselines()
+        except Exception as e:  # noqa: BLE001
+            line["cpu_baseline"] = {"error": repr(e)}
+    if not args.skip_mel:
+        try:
+            line["mel"] = mel_leg(fa, ctx, torch, dist, rank, world, args.chunks, args.mel_steps, args.mel_warmup, args.clock_warm_s)
+        except Exception as e:  # noqa: BLE001
+            line["mel"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
     if not args.skip_ctc:
         try:
             r = ctc_leg(fa, ctx, torch, dist, rank, world, args.ctc_matrices)
@@ -549,25 +701,16 @@ def main():
             r = {"error": repr(e)}
         line["ctc"] = r
         torch.cuda.empty_cache()
-    if not args.skip_e2e:
-        try:
-            r = e2e_leg(fa, ctx, torch, dist, rank, world)
-        except Exception as e:  # noqa: BLE001
-            r = {"error": repr(e)}
-        line["e2e_8h"] = r
-        line["featurized_plus_clustered_audio_hours_per_s"] = r.get("audio_hours_per_s") if isinstance(r, dict) else None
-        torch.cuda.empty_cache()
-    if world > 1 and not args.skip_sharded_start:
-        try:
-            line["ahc_sharded_start"] = sharded_start_leg(fa, ctx, torch, dist, rank, world)
-        except Exception as e:  # noqa: BLE001
-            line["ahc_sharded_start"] = {"error": repr(e)}
-        torch.cuda.empty_cache()
     if rank != 0:
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
+    if solo and not args.skip_mel:
+        try:
+            line["mel_single_10s"] = mel_single_leg(fa, ctx)
+        except Exception as e:  # noqa: BLE001
+            line["mel_single_10s"] = {"error": repr(e)}
     if solo and not args.skip_ahc:
         try:
             line["ahc_50k"] = ahc_leg(fa, ctx, torch)

@@ -67,12 +67,25 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, config: Offline
     import ctypes as C
     cfg = config or OfflineClusteringConfig()
     ctx = ctx or L.default_context()
-    emb = np.ascontiguousarray(embedding256, np.float32)
-    if emb.ndim != 2 or emb.shape[0] == 0:
-        raise ValueError("noSpeechDetected")                                 # :281-283
-    n, d = emb.shape
-    rho = np.ascontiguousarray(rho128, np.float64)
-    rd = rho.shape[1] if rho.ndim == 2 and rho.size else 0
+    on_device = hasattr(embedding256, "data_ptr")          # torch CUDA tensors: device_pointers = 1, nothing is uploaded
+    if on_device:
+        emb, rho = embedding256, rho128
+        assert emb.is_cuda and emb.is_contiguous() and emb.dtype.itemsize == 4 and emb.dim() == 2
+        if emb.shape[0] == 0:
+            raise ValueError("noSpeechDetected")
+        n, d = int(emb.shape[0]), int(emb.shape[1])
+        rd = int(rho.shape[1]) if rho is not None and rho.dim() == 2 and rho.numel() else 0
+        if rd:
+            assert rho.is_cuda and rho.is_contiguous() and rho.dtype.itemsize == 8 and int(rho.shape[0]) == n
+        emb_ptr, rho_ptr = emb.data_ptr(), (rho.data_ptr() if rd else None)
+    else:
+        emb = np.ascontiguousarray(embedding256, np.float32)
+        if emb.ndim != 2 or emb.shape[0] == 0:
+            raise ValueError("noSpeechDetected")                                 # :281-283
+        n, d = emb.shape
+        rho = np.ascontiguousarray(rho128, np.float64)
+        rd = rho.shape[1] if rho.ndim == 2 and rho.size else 0
+        emb_ptr, rho_ptr = emb.ctypes.data, (rho.ctypes.data if rd else None)
     ph = np.ascontiguousarray(phi, np.float64)
     if rd and ph.size != rd:
         ph = np.ones(rd)                                                      # dimension mismatch -> identity (VBxClustering.swift:72-76)
@@ -91,12 +104,12 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, config: Offline
     k, info = C.c_int32(), L.OfflineClusterInfo()
     if intermediates:
         ahc_lab, hard, elbos = np.full(n, -1, np.int32), np.full(n, -1, np.int32), np.zeros(max(cfg.max_vbx_iterations, 1))
-        ctx.check(L.lib().fa_offline_cluster_ex(ctx.handle, emb.ctypes.data, n, d, rho.ctypes.data if rd else None, rd, chunks.ctypes.data,
-                                                ph.ctypes.data if rd else None, C.byref(c), 0, labels.ctypes.data, cen.ctypes.data, cap, C.byref(k),
+        ctx.check(L.lib().fa_offline_cluster_ex(ctx.handle, emb_ptr, n, d, rho_ptr, rd, chunks.ctypes.data,
+                                                ph.ctypes.data if rd else None, C.byref(c), int(on_device), labels.ctypes.data, cen.ctypes.data, cap, C.byref(k),
                                                 C.byref(info), ahc_lab.ctypes.data, hard.ctypes.data, elbos.ctypes.data), "fa_offline_cluster_ex")
     else:
-        ctx.check(L.lib().fa_offline_cluster(ctx.handle, emb.ctypes.data, n, d, rho.ctypes.data if rd else None, rd, chunks.ctypes.data,
-                                             ph.ctypes.data if rd else None, C.byref(c), 0, labels.ctypes.data, cen.ctypes.data, cap, C.byref(k),
+        ctx.check(L.lib().fa_offline_cluster(ctx.handle, emb_ptr, n, d, rho_ptr, rd, chunks.ctypes.data,
+                                             ph.ctypes.data if rd else None, C.byref(c), int(on_device), labels.ctypes.data, cen.ctypes.data, cap, C.byref(k),
                                              C.byref(info)), "fa_offline_cluster")
     t = {"inputs_s": info.inputs_s, "ahc_s": info.ahc_s, "vbx_s": info.vbx_s, "assign_s": info.assign_s, "total_s": info.total_s}
     res = ClusteringResult(labels if intermediates else [int(v) for v in labels], cen[:k.value].copy(), [], None, [], t)

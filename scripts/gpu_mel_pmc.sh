@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --clock-warm-s 0 --skip-ahc --skip-ctc --skip-cpu --skip-e2e --skip-beam"
+CMD="python $GRAFT_REPO_ROOT/bench.py --only-mel --mel-steps 3 --mel-warmup 1 --clock-warm-s 0"
 run() { name=$1; shift; ( cd /tmp && timeout 300 rocprofv3 --pmc "$@" -d "$GRAFT_REPO_ROOT/gpurun_out/pmc/$name" -o $name -- $CMD ) > gpurun_out/pmc/$name.log 2>&1; echo "$name rc=$?"; }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
