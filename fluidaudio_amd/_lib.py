@@ -12,7 +12,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libfluidaudio_hip.so")
+LIB_PATH = os.environ.get("FLUIDAUDIO_HIP_LIBRARY") or os.path.join(CSRC, "libfluidaudio_hip.so")   # the override is for kernel experiments (scripts/)
 
 SUCCESS, INVALID_ARGUMENT, INDEX_OVERFLOW, OUTPUT_TOO_SMALL, ALLOCATION_FAILURE, RUNTIME_ERROR, UNKNOWN_ERROR = 0, 1, 2, 3, 4, 5, 255
 STATUS_NAMES = {0: "SUCCESS", 1: "INVALID_ARGUMENT", 2: "INDEX_OVERFLOW", 3: "OUTPUT_TOO_SMALL",

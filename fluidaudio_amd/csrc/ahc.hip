@@ -43,6 +43,7 @@
 #include <climits>
 #include <cmath>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "fa_common.h"
@@ -59,23 +60,55 @@ constexpr int kDead = INT_MAX;     // node id of an empty slot
 
 enum { OP_NONE = 0, OP_MERGE = 1, OP_RESCAN = 2, OP_COLLECT = 3, OP_PAIRS = 4 };
 
-// 1 since the rows keep a bound on their second minimum (e2): stale rows have become rare (0 forced re-scans on both benchmark
-// distributions), and every piggy-backed row costs a reduction chain in both reductions of a round (3 -> 1: 9.1 -> 8.5 us per round)
+// 0 since round 3.  Round 2 went 3 -> 1 when the rows got a bound on their second minimum (e2): stale rows became rare (0 forced
+// re-scans on the benchmark distributions; 9.1 -> 8.5 us per round).  Measured this round with 1: 8 .. 72 piggy-backed re-scans in
+// 50 000 merges — and every piggy-backed row costs a reduction chain in both reductions of a round plus the stale-bound quantity
+// and the choice logic.  With 0 a stale row is re-scanned when its bound reaches the global minimum (a forced round, still 0 of them
+// on all three benchmark inputs): 7.13 -> 6.32 us per round (8 h session), 7.27 -> 6.41 (50k iid).
 #ifndef FA_AHC_PIGGY
-#define FA_AHC_PIGGY 1
+#define FA_AHC_PIGGY 0
 #endif
+// Rows requested one round ahead (0 = off, the default: MEASURED AND REJECTED in round 3, kept as a switch for the record).
+// The merges of every benchmark input are ONE chain: each merge joins the cluster made by the previous merge with its nearest
+// neighbour, whose matrix row is cold in HBM (a different 350 KB row every round: ~2 100 cycles until the operands arrive).  That
+// neighbour is predictable one round EARLIER: the entries of the new row barely move when the cluster absorbs another point, so the
+// next partner is usually one of the runners-up of the row produced now.  With kPrefetch > 0, wave 3 of phase 1 picks up to kPrefetch
+// runner-up blocks of the produced row from the records it reduces anyway (ballot against an adaptive threshold, no extra
+// reduction) and every workgroup requests its slice of those rows + their centroids next to the operands of the current merge
+// without ever waiting for them.  Result on the device (scripts/gpu_ahc_variants.sh, profiles/r03_ahc_variants.txt): the partner was
+// among 3 requested rows in 72 % (8 h session) / 59 % (50k iid) of the merges, among 1 in 41 % / 30 % — and the round got SLOWER:
+// 6.14 -> 6.31 us (1 row) -> 6.61 us (3 rows); "operands arrive" 2 130 -> 2 860 cycles.  A row requested by the previous kernel is
+// not served any faster by the next one (the L2 does not keep it across the kernel boundary, MALL / TLB warmth buys nothing
+// measurable), while the extra requests queue in front of the operands that ARE waited for.
+#ifndef FA_AHC_PREFETCH
+#define FA_AHC_PREFETCH 0
+#endif
+constexpr int kPrefetch = FA_AHC_PREFETCH;
+constexpr int kPfSlots = kPrefetch > 0 ? kPrefetch : 1;
 constexpr int kPiggy = FA_AHC_PIGGY;   // stale rows re-scanned on top of every merge / forced re-scan round
 constexpr int kPend = 1 + kPiggy;  // rows whose per-block partial minima one round can produce
 
-struct AhcState {  // double buffered by round parity; written by workgroup 0 only
+// Device state, double buffered by round parity; written by workgroup 0 only.  AhcHot is what EVERY thread of every round needs: it
+// is fetched with a handful of 16-byte VECTOR loads issued next to the record loads (round 2 read the whole state through the
+// scalar cache: with ~40 SGPRs of workspace pointers live the compiler spilled and chained the reads into three dependent scalar
+// round trips that had to finish before the first record load could even be issued).  The rest is touched by one thread per round.
+struct AhcHot {
     int32_t step, done, halt, need_exact, error, mode;
     int32_t prev_op;              // what the previous round executed
     int32_t sym_limit;            // nodes below this id existed when the matrix was last built in full: BOTH copies of their pairs are valid
     int32_t pend_row[kPend], pend_node[kPend];  // rows whose block-partial minima the previous round produced (-1: none)
     double eps, lim;              // lim: window limit carried COLLECT -> PAIRS -> evaluation
+    double pf_delta;              // relative threshold of the runner-up pick (adapted every round towards ~kPrefetch + 1 blocks inside it)
+};
+struct alignas(16) AhcState : AhcHot {
     unsigned long long dmax_bits, nmax_bits;  // largest matrix entry / largest squared norm seen by the start-up kernels
     long long rounds, rescans, windows, piggy;
+    int32_t pf_slot[kPfSlots];    // rows requested ahead by the previous round
+    int32_t pf_pad;
+    long long pf_hits, pf_merges; // merges whose partner row had been requested ahead / merges of the chain kind
 };
+static_assert(sizeof(AhcState) % 16 == 0 && sizeof(AhcHot) % 8 == 0, "the state is read in 16-byte pieces");
+constexpr int kHotVec = (sizeof(AhcHot) + 15) / 16;
 
 struct WinCounters {  // 4 copies rotating with the round index: [t&3] written, [(t-1)&3] read, [(t+1)&3] cleared
     unsigned long long stale_key;  // (slot << 32 | node) of the lowest stale row inside the window
@@ -462,7 +495,8 @@ __global__ __launch_bounds__(kBlk) void ahc_row_minima(Ws w) {
 // Per workgroup, for the NEXT round: the smallest row minimum (+ its row), how many rows lie within 2 eps of it, the
 // smallest stale bound, and the block-partial minima of the rows being produced.  Per wave: 2 + kPend interleaved
 // DPP min-reductions (winner lanes by ballot); across the four waves: LDS + ONE __syncthreads; thread 0 writes.
-constexpr int kNQ = 2 + kPend;
+constexpr int kStaleQ = kPiggy > 0 ? 1 : 0;   // the stale-bound quantity only feeds the choice of piggy-backed rows
+constexpr int kNQ = 1 + kStaleQ + kPend;
 struct __attribute__((aligned(8))) QOut { double v; int a, b, c, d; };   // one reduced quantity of one wave: value + payload
 struct WaveOut {                                                          // quantity 0: smallest row minimum (r1, q1, node r1, node q1)
     QOut q[kWaves][kNQ];                                                  //          1: smallest stale bound (row, node)
@@ -476,15 +510,17 @@ __device__ __forceinline__ void block_record(const Ws &w, const int par, const i
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double keys[kNQ], m[kNQ];
     int L[kNQ];
-    keys[0] = key; keys[1] = skey;
+    constexpr int kP0 = 1 + kStaleQ;   // first produced-row quantity
+    keys[0] = key;
+    if (kStaleQ) keys[kStaleQ] = skey;
 #pragma unroll
-    for (int p = 0; p < kPend; ++p) keys[2 + p] = pkey[p];
+    for (int p = 0; p < kPend; ++p) keys[kP0 + p] = pkey[p];
     wave_min_multi<kNQ>(keys, m, L);
     QOut o[kNQ];
     o[0].v = m[0]; o[0].a = lane_value(x, L[0]); o[0].b = lane_value(nnx, L[0]); o[0].c = lane_value(nx, L[0]); o[0].d = lane_value(nnnodex, L[0]);
-    o[1].v = m[1]; o[1].a = lane_value(x, L[1]); o[1].b = lane_value(nx, L[1]); o[1].c = 0; o[1].d = 0;
+    if (kStaleQ) { o[kStaleQ].v = m[kStaleQ]; o[kStaleQ].a = lane_value(x, L[kStaleQ]); o[kStaleQ].b = lane_value(nx, L[kStaleQ]); o[kStaleQ].c = 0; o[kStaleQ].d = 0; }
 #pragma unroll
-    for (int p = 0; p < kPend; ++p) { o[2 + p].v = m[2 + p]; o[2 + p].a = lane_value(pslot[p], L[2 + p]); o[2 + p].b = lane_value(pnode[p], L[2 + p]); o[2 + p].c = 0; o[2 + p].d = 0; }
+    for (int p = 0; p < kPend; ++p) { o[kP0 + p].v = m[kP0 + p]; o[kP0 + p].a = lane_value(pslot[p], L[kP0 + p]); o[kP0 + p].b = lane_value(pnode[p], L[kP0 + p]); o[kP0 + p].c = 0; o[kP0 + p].d = 0; }
     const int cnt = wave_count(key <= m[0] + 2.0 * eps && key < dinf());
     if (lane == 0) {
 #pragma unroll
@@ -512,7 +548,7 @@ __device__ __forceinline__ void block_record(const Ws &w, const int par, const i
         const bool any = best.v < dinf();
         w.recA[o1] = ra;
         w.recI[o1] = any ? make_int4(best.a, best.b, best.c, best.d) : make_int4(-1, -1, -1, -1);
-    } else if (tid == 1) {
+    } else if (kStaleQ && tid == 1) {
         RecS rsv; rsv.sv = best.v;
         const bool any = best.v < dinf();
         rsv.srow = any ? best.a : -1; rsv.snode = any ? best.b : -1;
@@ -521,7 +557,7 @@ __device__ __forceinline__ void block_record(const Ws &w, const int par, const i
         RecP rp; rp.pv = best.v;
         const bool any = best.v < dinf();
         rp.slot = any ? best.a : -1; rp.node = any ? best.b : -1;
-        w.recP[(static_cast<size_t>(par) * kPend + (tid - 2)) * w.nblk + blk] = rp;
+        w.recP[(static_cast<size_t>(par) * kPend + (tid - kP0)) * w.nblk + blk] = rp;
     }
 }
 
@@ -628,10 +664,16 @@ __device__ void exact_min_pair(const Ws &w, const int np, double *s_sq /*[kWaves
 //   wave 1: the smallest stale bound of each QUARTER of the blocks (candidates for the piggy-backed re-scans)
 //   wave 2: partial minima of the produced rows 1, 2        wave 3: of the produced rows 0, 3
 constexpr int kMaxC = (kMaxBlocks + 63) / 64;  // block records per lane
-static_assert(kPend >= 2 && kPend <= 4 && kWaves == 4, "the wave roles of phase 1 are written for 4 waves and 2..4 produced rows");
+// A record is ONE 16-byte load.  (Round 2 read the records as structs inside a `for (j < kMaxC) { if (!(j < c)) continue; ... }` loop: the
+// compiler split every struct into a value load and a payload load that it issued only after comparing the value, and chained the
+// iterations — for 50 000 points 4 (wave 0) to 8 (the produced-row wave) DEPENDENT L2 / MALL round trips at the start of every round
+// instead of one.  Now all records of a lane are requested before the first one is looked at: straight-line code, one case per count.)
+__device__ __forceinline__ int4 rec16(const void *base, const size_t idx) { return reinterpret_cast<const int4 *>(base)[idx]; }
+__device__ __forceinline__ double rec_f64(const int4 r) { return __hiloint2double(r.y, r.x); }
 struct Dec {
     double v1, sv[kWaves], pd[kPend];
-    int cnt, r1, q1, nr1, nq1, pad0, pad1, pad2;
+    int cnt, r1, q1, nr1, nq1, pfn, pad1, pad2;
+    int pfs[kPfSlots], pfnode[kPfSlots];
     int srow[kWaves], snode[kWaves], ps[kPend], pn[kPend];
 };
 
@@ -655,34 +697,74 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     unsigned long long t_seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = clock64();
 #endif
-    // Every load of the round's first memory round trip is issued before anything is branched on: state, own row
-    // state and the block records all have addresses that depend on kernel arguments only.
-    const AhcState st = w.state[par];
+    // Every load of the round's first memory round trip is requested before anything is waited for or branched on: the block records
+    // this wave reduces (their addresses depend on kernel arguments only), the hot part of the state, the own row state.
+    const int c = (nblk + 63) >> 6;
+    const size_t ro = static_cast<size_t>(par) * nblk;
+    const bool row_wave = wave >= 2 && (wave == 2 ? 1 : 0) < kPend;      // waves that finish produced rows: 3 (row 0 [, 3]) and, with piggy-backed rows, 2 (rows 1, 2)
+    const int pk0 = wave == 2 ? 1 : 0, pk1r = wave == 2 ? 2 : 3;
+    const bool phas1 = pk1r < kPend;
+    const int pk1 = phas1 ? pk1r : pk0;
+    constexpr int kC4 = 4;                                              // records per lane held in registers (N <= 65 536); beyond: the generic path
+    int4 q0[kC4], q1[kC4];
+    bool qok[kC4];
+    {
+        const void *b0 = wave == 0 ? static_cast<const void *>(w.recA + ro) : static_cast<const void *>(w.recP + (static_cast<size_t>(par) * kPend + pk0) * nblk);
+        const void *b1 = wave == 0 ? static_cast<const void *>(w.recI + ro) : static_cast<const void *>(w.recP + (static_cast<size_t>(par) * kPend + pk1) * nblk);
+#pragma unroll
+        for (int j = 0; j < kC4; ++j) {
+            const int i = lane * c + j;
+            qok[j] = c <= kC4 && j < c && i < nblk && (wave == 0 || row_wave);
+            const size_t ii = qok[j] ? i : 0;
+            q0[j] = rec16(b0, ii);
+            q1[j] = rec16(b1, ii);
+        }
+    }
+    int vz = 0;
+    asm volatile("" : "+v"(vz));                                        // an opaque 0 in a VGPR: keeps the state on the vector memory path
+    const char *sp = reinterpret_cast<const char *>(w.state + par) + vz;
+    int4 hraw[kHotVec];
+#pragma unroll
+    for (int i = 0; i < kHotVec; ++i) hraw[i] = reinterpret_cast<const int4 *>(sp)[i];
+    // the thread that writes the next state also requests the cold part of the present one now (16-byte pieces; it is looked at in the tail)
+    constexpr int kColdVec = (sizeof(AhcState) - kHotVec * 16 + 15) / 16;
+    int4 craw[kColdVec > 0 ? kColdVec : 1];
+#pragma unroll
+    for (int i = 0; i < kColdVec; ++i) craw[i] = blk == 0 && tid == 0 ? reinterpret_cast<const int4 *>(sp)[kHotVec + i] : make_int4(0, 0, 0, 0);
     AhcState *const nst = w.state + npar;
     int nx = w.node[x];
     RowSt rs = w.row[x];
     double e2x = w.e2[x];   // lower bound of the entries of row x other than its nearest neighbour's
     const int nanflag = w.flags[0];
+    __builtin_amdgcn_sched_barrier(0);
+    AhcHot st;
+    __builtin_memcpy(&st, hraw, sizeof(AhcHot));
+    auto whole_state = [&]() {   // thread (0, 0) only: the present state reassembled from its pieces
+        int4 all[kHotVec + (kColdVec > 0 ? kColdVec : 1)];
+#pragma unroll
+        for (int i = 0; i < kHotVec; ++i) all[i] = hraw[i];
+#pragma unroll
+        for (int i = 0; i < kColdVec; ++i) all[kHotVec + i] = craw[i];
+        AhcState out;
+        __builtin_memcpy(&out, all, sizeof(AhcState));
+        return out;
+    };
 
     // ---- phase 1: every workgroup reduces the same records -> the same decision ------------------------------------
-    const int perw = (nblk + kWaves - 1) / kWaves, c = (nblk + 63) >> 6;
-    const size_t ro = static_cast<size_t>(par) * nblk;
-    if (wave == 0) {
-        double va[kMaxC], key = dinf();
-        int ca[kMaxC];
+    const int perw = (nblk + kWaves - 1) / kWaves;
+    // wave 0: the smallest row minimum over all blocks (+ its row, neighbour, node ids) and the rows within 2 eps of it
+    auto reduce_minimum = [&](auto cc, const int4 *ra, const int4 *ri, const bool *ok) {
+        constexpr int C = decltype(cc)::value;
+        double va[C], key = dinf();
+        int ca[C];
         int4 ids = make_int4(-1, -1, -1, -1);
 #pragma unroll
-        for (int j = 0; j < kMaxC; ++j) {
-            va[j] = dinf(); ca[j] = 0;
-            if (j > 0 && !(j < c)) continue;   // N <= 16 384: one record per lane, straight-line
-            const int i = lane * c + j;
-            const bool ok = j < c && i < nblk;
-            const int ii = ok ? i : 0;
-            const RecA ra = w.recA[ro + ii];
-            const int4 ri = w.recI[ro + ii];
-            if (!ok) continue;
-            va[j] = ra.v1; ca[j] = ra.cnt;
-            if (ra.v1 < key) { key = ra.v1; ids = ri; }
+        for (int j = 0; j < C; ++j) {
+            va[j] = ok[j] ? rec_f64(ra[j]) : dinf();
+            ca[j] = ok[j] ? ra[j].z : 0;
+            const bool better = va[j] < key;
+            key = better ? va[j] : key;
+            ids.x = better ? ri[j].x : ids.x; ids.y = better ? ri[j].y : ids.y; ids.z = better ? ri[j].z : ids.z; ids.w = better ? ri[j].w : ids.w;
         }
         AHC_STAMP(0);
         const double keys[1] = {key};
@@ -692,11 +774,67 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         int cl = 0;
         const double wl = m[0] + 2.0 * st.eps;
 #pragma unroll
-        for (int j = 0; j < kMaxC; ++j) if (va[j] <= wl && va[j] < dinf()) cl += ca[j];
+        for (int j = 0; j < C; ++j) cl += (va[j] <= wl && va[j] < dinf()) ? ca[j] : 0;
         const int cnt = wave_count(cl >= 1) + wave_count(cl >= 2) + wave_count(cl >= 3);  // exact up to 3 per lane; only "== 2" matters
-        const int r1 = lane_value(ids.x, L[0]), q1 = lane_value(ids.y, L[0]), nr1 = lane_value(ids.z, L[0]), nq1 = lane_value(ids.w, L[0]);
-        if (lane == 0) { s_dec.v1 = m[0]; s_dec.cnt = cnt; s_dec.r1 = r1; s_dec.q1 = q1; s_dec.nr1 = nr1; s_dec.nq1 = nq1; }
-    } else if (wave == 1) {
+        const int r1 = lane_value(ids.x, L[0]), q1_ = lane_value(ids.y, L[0]), nr1 = lane_value(ids.z, L[0]), nq1 = lane_value(ids.w, L[0]);
+        if (lane == 0) { s_dec.v1 = m[0]; s_dec.cnt = cnt; s_dec.r1 = r1; s_dec.q1 = q1_; s_dec.nr1 = nr1; s_dec.nq1 = nq1; }
+    };
+    // waves 2 / 3: block-partial minima of the rows the previous round produced -> their minimum and nearest neighbour
+    auto reduce_rows = [&](auto cc, const int4 *r0, const int4 *r1, const bool *ok) {
+        constexpr int C = decltype(cc)::value;
+        double keys[2] = {dinf(), dinf()};
+        int ps[2] = {-1, -1}, pn[2] = {-1, -1};
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const double v0 = ok[j] ? rec_f64(r0[j]) : dinf(), v1 = ok[j] && phas1 ? rec_f64(r1[j]) : dinf();
+            const bool b0 = v0 < keys[0], b1 = v1 < keys[1];
+            keys[0] = b0 ? v0 : keys[0]; ps[0] = b0 ? r0[j].z : ps[0]; pn[0] = b0 ? r0[j].w : pn[0];
+            keys[1] = b1 ? v1 : keys[1]; ps[1] = b1 ? r1[j].z : ps[1]; pn[1] = b1 ? r1[j].w : pn[1];
+        }
+        AHC_STAMP(0);
+        double m[2];
+        int L[2];
+        wave_min_multi<2>(keys, m, L);
+        const int a0 = lane_value(ps[0], L[0]), b0 = lane_value(pn[0], L[0]), a1 = lane_value(ps[1], L[1]), b1 = lane_value(pn[1], L[1]);
+        if (lane == 0) { s_dec.pd[pk0] = m[0]; s_dec.ps[pk0] = a0; s_dec.pn[pk0] = b0; if (phas1) { s_dec.pd[pk1] = m[1]; s_dec.ps[pk1] = a1; s_dec.pn[pk1] = b1; } }
+        if (kPrefetch > 0 && wave == 3) {   // runners-up of the row produced by the previous round: lanes (block groups) within (1 + delta) of its minimum
+            unsigned long long mask = __builtin_amdgcn_ballot_w64(keys[0] <= m[0] * (1.0 + st.pf_delta) && lane != L[0] && ps[0] >= 0 && keys[0] < dinf());
+            const int inside = __popcll(mask);
+            int cs[kPfSlots], cn[kPfSlots];
+#pragma unroll
+            for (int g = 0; g < kPfSlots; ++g) {
+                const int l = mask ? __ffsll(static_cast<long long>(mask)) - 1 : 0;
+                cs[g] = mask ? lane_value(ps[0], l) : -1;
+                cn[g] = mask ? lane_value(pn[0], l) : -1;
+                mask &= mask - 1;
+            }
+            if (lane == 0) {
+                s_dec.pfn = inside;
+#pragma unroll
+                for (int g = 0; g < kPfSlots; ++g) { s_dec.pfs[g] = cs[g]; s_dec.pfnode[g] = cn[g]; }
+            }
+        }
+    };
+    if (c <= kC4) {
+        if (wave == 0) reduce_minimum(std::integral_constant<int, kC4>{}, q0, q1, qok);
+        else if (row_wave) reduce_rows(std::integral_constant<int, kC4>{}, q0, q1, qok);
+    } else if (wave == 0 || row_wave) {   // more than 65 536 points: 5 .. 12 records per lane, requested together, then the same reductions
+        int4 g0[kMaxC], g1[kMaxC];
+        bool gok[kMaxC];
+        const void *b0 = wave == 0 ? static_cast<const void *>(w.recA + ro) : static_cast<const void *>(w.recP + (static_cast<size_t>(par) * kPend + pk0) * nblk);
+        const void *b1 = wave == 0 ? static_cast<const void *>(w.recI + ro) : static_cast<const void *>(w.recP + (static_cast<size_t>(par) * kPend + pk1) * nblk);
+#pragma unroll
+        for (int j = 0; j < kMaxC; ++j) {
+            const int i = lane * c + j;
+            gok[j] = j < c && i < nblk;
+            const size_t ii = gok[j] ? i : 0;
+            g0[j] = rec16(b0, ii);
+            g1[j] = rec16(b1, ii);
+        }
+        if (wave == 0) reduce_minimum(std::integral_constant<int, kMaxC>{}, g0, g1, gok);
+        else reduce_rows(std::integral_constant<int, kMaxC>{}, g0, g1, gok);
+    }
+    if (kPiggy > 0 && wave == 1) {   // the smallest stale bound of each QUARTER of the blocks (candidates for the piggy-backed re-scans)
         double keys[kWaves];
         int srow[kWaves], snode[kWaves];
 #pragma unroll
@@ -722,30 +860,6 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
             const int a = lane_value(srow[q], L[q]), b = lane_value(snode[q], L[q]);
             if (lane == 0) { s_dec.sv[q] = m[q]; s_dec.srow[q] = a; s_dec.snode[q] = b; }
         }
-    } else {
-        const int k0 = wave == 2 ? 1 : 0, k1r = wave == 2 ? 2 : 3;   // produced rows this wave finishes
-        const bool has1 = k1r < kPend;
-        const int k1 = has1 ? k1r : k0;
-        double keys[2] = {dinf(), dinf()};
-        int ps[2] = {-1, -1}, pn[2] = {-1, -1};
-#pragma unroll
-        for (int j = 0; j < kMaxC; ++j) {
-            if (j > 0 && !(j < c)) continue;
-            const int i = lane * c + j;
-            const bool ok = j < c && i < nblk;
-            const int ii = ok ? i : 0;
-            const RecP p0 = w.recP[(static_cast<size_t>(par) * kPend + k0) * nblk + ii];
-            const RecP p1 = w.recP[(static_cast<size_t>(par) * kPend + k1) * nblk + ii];
-            if (!ok) continue;
-            if (p0.pv < keys[0]) { keys[0] = p0.pv; ps[0] = p0.slot; pn[0] = p0.node; }
-            if (has1 && p1.pv < keys[1]) { keys[1] = p1.pv; ps[1] = p1.slot; pn[1] = p1.node; }
-        }
-        AHC_STAMP(0);
-        double m[2];
-        int L[2];
-        wave_min_multi<2>(keys, m, L);
-        const int a0 = lane_value(ps[0], L[0]), b0 = lane_value(pn[0], L[0]), a1 = lane_value(ps[1], L[1]), b1 = lane_value(pn[1], L[1]);
-        if (lane == 0) { s_dec.pd[k0] = m[0]; s_dec.ps[k0] = a0; s_dec.pn[k0] = b0; if (has1) { s_dec.pd[k1] = m[1]; s_dec.ps[k1] = a1; s_dec.pn[k1] = b1; } }
     }
     AHC_STAMP(6);
     __syncthreads();
@@ -781,7 +895,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     AHC_STAMP(8);
     if (st.done || st.halt) {  // finished or waiting for the host: carry the state forward
         if (blk == 0 && tid == 0) {
-            *nst = st; nst->prev_op = OP_NONE;
+            *nst = whole_state(); nst->prev_op = OP_NONE;
             for (int k = 0; k < kPend; ++k) nst->pend_row[k] = -1;
         }
         return;
@@ -861,7 +975,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     for (int k = 0; k < kPend; ++k) was_pending = was_pending || x == st.pend_row[k];
     if (D.done || D.halt) {
         if (blk == 0 && tid == 0) {
-            *nst = st;
+            *nst = whole_state();
             nst->done = D.done; nst->halt = D.halt; nst->need_exact = D.need_exact; nst->error = D.error;
             nst->prev_op = OP_NONE;
             for (int k = 0; k < kPend; ++k) nst->pend_row[k] = -1;
@@ -870,6 +984,9 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         return;
     }
 
+    double pf_row[kPfSlots], pf_cen[kPfSlots][4];   // sinks of the warm-up requests (kPrefetch): consumed by an empty asm at the end of the round
+#pragma unroll
+    for (int g = 0; g < kPfSlots; ++g) { pf_row[g] = 0.0; pf_cen[g][0] = pf_cen[g][1] = pf_cen[g][2] = pf_cen[g][3] = 0.0; }
     double pkey[kPend];  // this column's entry of each row being produced
     int pslot[kPend], pnd[kPend];
 #pragma unroll
@@ -901,6 +1018,22 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         double xa[kCk], xb[kCk];
 #pragma unroll
         for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; xa[j] = k < d ? ca[k] : 0.0; xb[j] = k < d ? cb[k] : 0.0; }
+        if (kPrefetch > 0) {   // warm-up requests for the likely partner rows of the NEXT merge (see kPrefetch); nothing below waits for them
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < kPfSlots; ++g) {
+                const int S = dv.pfs[g], nS = dv.pfnode[g];
+                if (S >= 0 && S != a && S != b) {
+                    if (act && x != S) pf_row[g] = pair_entry(w.M, Np, S, nS, x, nx, st.sym_limit);
+                    if (wave == 0) {   // the candidate's centroid: 2 KB, one request per lane and 512-byte quarter
+                        const double *cp = w.C + static_cast<size_t>(nS) * d;
+#pragma unroll
+                        for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; if (k < d) pf_cen[g][j] = cp[k]; }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         AHC_STAMP(9);
         const bool keeps_centroid = wave == 0 && (st.mode == FA_AHC_MODE_EXACT || blk == 0);
         double part = 0.0;
@@ -1023,15 +1156,40 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     const bool live = nx != kDead && !in_flight;
     block_record(w, npar, blk, st.eps, live ? rs.d1 : dinf(), live && rs.nn < 0 ? rs.d1 : dinf(), pkey, pslot, pnd, x, nx, rs.nn, rs.nnnode, s_out);
     AHC_STAMP(4);
+    if (kPrefetch > 0) {
+#pragma unroll
+        for (int g = 0; g < kPfSlots; ++g) asm volatile("" ::"v"(pf_row[g]), "v"(pf_cen[g][0]), "v"(pf_cen[g][1]), "v"(pf_cen[g][2]), "v"(pf_cen[g][3]));
+    }
     if (blk == 0 && tid == 0) {
-        AhcState n = st;
+        const AhcState full = whole_state();
+        AhcState n = full;
+        if (kPrefetch > 0) {
+            if (D.op == OP_MERGE) {
+                // was the partner of this merge among the rows requested by the previous round?  (statistics only)
+                bool chain = false, hit = false;
+#pragma unroll
+                for (int k = 0; k < kPend; ++k) chain = chain || (st.prev_op == OP_MERGE && (D.a == st.pend_row[0] || D.b == st.pend_row[0]));
+#pragma unroll
+                for (int g = 0; g < kPfSlots; ++g) hit = hit || (full.pf_slot[g] >= 0 && (full.pf_slot[g] == D.a || full.pf_slot[g] == D.b));
+                if (chain) { n.pf_merges = full.pf_merges + 1; if (hit) n.pf_hits = full.pf_hits + 1; }
+#pragma unroll
+                for (int g = 0; g < kPfSlots; ++g) n.pf_slot[g] = dv.pfs[g];
+                // keep about kPrefetch + 1 block groups inside the threshold
+                double dl = st.pf_delta;
+                if (dv.pfn > kPrefetch + 2) dl *= 0.7; else if (dv.pfn < kPrefetch) dl *= 1.3;
+                n.pf_delta = dl < 1e-13 ? 1e-13 : (dl > 1.0 ? 1.0 : dl);
+            } else {
+#pragma unroll
+                for (int g = 0; g < kPfSlots; ++g) n.pf_slot[g] = -1;
+            }
+        }
         n.prev_op = D.op;
         for (int k = 0; k < kPend; ++k) { n.pend_row[k] = prow[k]; n.pend_node[k] = pnode_[k]; if (k > 0 && prow[k] >= 0) n.piggy = n.piggy + 1; }
         n.lim = D.lim;
-        n.rounds = st.rounds + 1;
+        n.rounds = full.rounds + 1;
         if (D.op == OP_MERGE) n.step = st.step + 1;
-        if (D.op == OP_RESCAN) n.rescans = st.rescans + 1;
-        if (D.op == OP_COLLECT) n.windows = st.windows + 1;
+        if (D.op == OP_RESCAN) n.rescans = full.rescans + 1;
+        if (D.op == OP_COLLECT) n.windows = full.windows + 1;
         *nst = n;
     }
     AHC_STAMP(5);
@@ -1217,6 +1375,8 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
     init[0].mode = p.mode == FA_AHC_MODE_EXACT ? FA_AHC_MODE_EXACT : FA_AHC_MODE_AUTO;
     for (int k = 0; k < kPend; ++k) { init[0].pend_row[k] = -1; init[0].pend_node[k] = -1; }
     init[0].prev_op = OP_NONE;
+    init[0].pf_delta = 1e-3;
+    for (int g = 0; g < kPfSlots; ++g) init[0].pf_slot[g] = -1;
     init[0].sym_limit = static_cast<int32_t>(N);          // the start-up writes the full matrix: every pair of points has both copies
     init[1] = init[0];
     WinCounters cinit[4];
@@ -1248,8 +1408,8 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
         memcpy(&nmax, &nbits, sizeof(nmax));
         const double u = 1.1102230246251565e-16;
         const double eps = 16.0 * static_cast<double>(N) * u * dmax + 8.0 * (static_cast<double>(d) + 2.0) * u * nmax;
-        FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state) + offsetof(AhcState, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
-        FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state + 1) + offsetof(AhcState, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state) + offsetof(AhcHot, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state + 1) + offsetof(AhcHot, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(ahc_records, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);  // window counts need eps
         FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // eps is a host temporary
     }
@@ -1375,6 +1535,10 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
         fprintf(stderr, "  decide = wave reduction %.0f | barrier + result read %.0f | finished rows + global minimum %.0f | state machine + piggy choice %.0f\n", hp[6] / n, hp[7] / n, hp[8] / n, hp[1] / n);
     }
 #endif
+    if (getenv("FA_AHC_DEBUG"))
+        fprintf(stderr, "ahc: N %zu rounds %lld merges %d forced re-scans %lld piggy-backed re-scans %lld windows %lld fallback %lld (kPiggy %d); "
+                "rows requested ahead: %d per round, partner was among them in %lld of %lld chain merges, threshold %.3g\n", N, p.h.rounds, p.h.step,
+                p.h.rescans, p.h.piggy, p.h.windows, p.fallback, kPiggy, kPrefetch, p.h.pf_hits, p.h.pf_merges, p.h.pf_delta);
     if (stats) {
         float t01 = 0, t12 = 0;
         (void)hipEventElapsedTime(&t01, ev[0], ev[1]);

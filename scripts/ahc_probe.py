@@ -39,7 +39,14 @@ def main():
 
     for n in ns:
         for kind in kinds:
-            x = oracle.ahc_normalize(np.random.default_rng(0).standard_normal((n, 256))) if kind == "iid" else speaker_mixture(n, 256, 64, 0.02, 0)
+            if kind == "iid":
+                x = oracle.ahc_normalize(np.random.default_rng(0).standard_normal((n, 256)))
+            elif kind == "e2e":      # the bench session (tests/golden/e2e_inputs.py), n = 5400 x hours
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+                from e2e_inputs import e2e_session
+                x = oracle.ahc_normalize(e2e_session(n / 5400.0)["emb"].astype(np.float64))
+            else:
+                x = speaker_mixture(n, 256, 64, 0.02, 0)
             for mode in modes:
                 if mode == 1 and n > 20000:
                     continue
