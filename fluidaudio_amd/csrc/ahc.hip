@@ -226,6 +226,14 @@ __device__ __forceinline__ void wave_min_multi(const double (&key)[NQ], double (
         L[q] = __builtin_amdgcn_readfirstlane(mask ? __ffsll(static_cast<long long>(mask)) - 1 : 0);
     }
 }
+// Workgroup barrier for an exchange through LDS: the LDS writes of this wave are complete (lgkmcnt), nothing is said about global memory.
+// __syncthreads() is a workgroup-scope release + acquire: on gfx950 it also waits (vmcnt(0)) until every global STORE issued so far has
+// been acknowledged — in the round kernel the rewritten matrix row and the row states, i.e. a memory round trip in front of the block record.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 // number of lanes whose predicate holds (uniform)
 __device__ __forceinline__ int wave_count(const bool p) { return __popcll(__builtin_amdgcn_ballot_w64(p)); }
 
@@ -527,7 +535,7 @@ __device__ __forceinline__ void block_record(const Ws &w, const int par, const i
         for (int q = 0; q < kNQ; ++q) s_out->q[wave][q] = o[q];
         s_out->cnt[wave] = cnt;
     }
-    __syncthreads();
+    lds_barrier();   // LDS exchange only: __syncthreads() would also wait for the row / matrix stores of this round to reach memory (a store round trip on the critical path)
     if (tid >= kNQ) return;
     // lane q of wave 0 merges quantity q of the four waves (ties -> lowest wave == lowest rows) and writes its own record:
     // six short chains side by side instead of one thread walking all six
@@ -862,7 +870,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         }
     }
     AHC_STAMP(6);
-    __syncthreads();
+    lds_barrier();
     const Dec dv = s_dec;  // one batch of LDS reads, everything below is register arithmetic on uniform values (moving it to the scalar
                            // unit with readfirstlane was measured 9 % slower: the chain is latency-bound on either unit)
     AHC_STAMP(7);
@@ -1064,7 +1072,9 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         double dc = dinf();
         if (st.mode == FA_AHC_MODE_AUTO) {
             if (act) {  // Lance-Williams centroid update: a filter only, ties/near-ties are re-evaluated exactly
-                const double wa = ma / den, wb = mb / den, wab = (ma * mb) / (den * den);
+                // weights from ONE division (the values are a filter, certified by the 2 eps window: the two extra roundings stay inside the
+                // 16 u per merge level that eps budgets for 8); three IEEE fp64 divisions were ~40 dependent instructions per round
+                const double inv = 1.0 / den, wa = ma * inv, wb = mb * inv, wab = wa * wb;
                 dc = wa * da + wb * db - wab * dab;
                 if (!(dc > 0.0)) dc = 0.0;  // also keeps -0.0 out of the bit-pattern reductions
             }
@@ -1399,9 +1409,10 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
         double dmax;
         const long long bits = static_cast<long long>(p.h.dmax_bits);
         memcpy(&dmax, &bits, sizeof(dmax));
-        // rounding bound of the Lance-Williams recurrence: <= 8 u dmax per merge level (3 products, 2 sums, 3 rounded
-        // weights, the tree-summed d(a,b)), errors of the two parents enter with weights wa + wb = 1, tree depth <= N;
-        // factor 2 of margin.
+        // rounding bound of the Lance-Williams recurrence: <= 9.5 u dmax per merge level — weights from one reciprocal (wa, wb: 2 u each,
+        // wab: 5 u), 3 products, 2 sums: (3 u)(wa da + wb db) + (6 u) wab dab + 2 u dmax <= (3 + 1.5 + 2) u dmax, plus the tree-summed
+        // d(a,b) (~10 ulp of it, weighted by wab <= 1/4: 2.5 u dmax); errors of the two parents enter with weights wa + wb = 1, tree
+        // depth <= N; 16 u per level leaves a margin of 1.7.
         // Start-up matrix in Gram form: |x|^2 + |y|^2 - 2 x.y carries <= (d + 2) u (|x|^2 + |y|^2 + 2 |x||y|) <= 4 (d + 2) u nmax.
         double nmax;
         const long long nbits = static_cast<long long>(p.h.nmax_bits);
