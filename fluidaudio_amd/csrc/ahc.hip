@@ -128,26 +128,28 @@ struct __attribute__((aligned(16))) RowSt {  // per slot, owned by thread (slot 
     int nn, nnnode;          // nearest neighbour slot (lowest on ties; -1: merged away) and its node id
 };
 
-struct Ws {
+struct Ws {   // what a round touches first comes first: with kernel-argument preloading (Makefile: -amdgpu-kernarg-preload-count) the leading
+              // 16 dwords arrive in SGPRs with the wavefront instead of through a scalar load at its start
+    int32_t nblk, Np;
+    AhcState *state;   // [2]
+    RecA *recA;      // [2][nblk]
+    int4 *recI;      // [2][nblk]
+    RecP *recP;      // [2][kPend][nblk]
+    RowSt *row;      // [Np]
+    int32_t *node;   // [Np]
+    double *e2;      // [Np]   lower bound of the row's entries OTHER than the nearest neighbour's (see the row update of the round)
+    int32_t N, d;
+    int32_t *flags;    // [0]: a NaN distance was seen (nan_error, FastClusterWrapper.cpp:60-62)
     double *M;       // [Np][Np]
     double *C;       // [2N][d]  centroids by node id (rows 0..N-1 = input points)
     double *XT;      // [d][Np]  slot-major transposed coordinates (init; maintained in EXACT mode only)
-    RowSt *row;      // [Np]
-    double *e2;      // [Np]   lower bound of the row's entries OTHER than the nearest neighbour's (see the row update of the round)
-    int32_t *node;   // [Np]
     double *sizes;   // [2N]     cluster size by node id
     double *Z;       // [(N-1)*4]
-    RecA *recA;      // [2][nblk]
-    int4 *recI;      // [2][nblk]
     RecS *recS;      // [2][nblk]
-    RecP *recP;      // [2][kPend][nblk]
     int2 *cand;      // [kMaxCand]  slot, node
     int4 *pairs;     // [kMaxPairs] a, b, node a, node b
     WinCounters *cnt;  // [4]
-    int32_t *flags;    // [0]: a NaN distance was seen (nan_error, FastClusterWrapper.cpp:60-62)
     unsigned long long *prof;  // [16] cycle counters (FA_AHC_PROFILE builds only)
-    AhcState *state;   // [2]
-    int32_t N, Np, d, nblk;
 };
 
 __device__ __forceinline__ double dinf() { return __longlong_as_double(0x7ff0000000000000LL); }
@@ -738,7 +740,8 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     constexpr int kColdVec = (sizeof(AhcState) - kHotVec * 16 + 15) / 16;
     int4 craw[kColdVec > 0 ? kColdVec : 1];
 #pragma unroll
-    for (int i = 0; i < kColdVec; ++i) craw[i] = blk == 0 && tid == 0 ? reinterpret_cast<const int4 *>(sp)[kHotVec + i] : make_int4(0, 0, 0, 0);
+    for (int i = 0; i < kColdVec; ++i) craw[i] = reinterpret_cast<const int4 *>(sp)[kHotVec + i];   // every thread (one broadcast line): an exec-masked
+                                                                                                   // version made wave 0 of block 0 wait for the whole batch
     AhcState *const nst = w.state + npar;
     int nx = w.node[x];
     RowSt rs = w.row[x];
@@ -916,7 +919,13 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     Decision D;
     D.op = OP_NONE; D.a = D.b = D.na = D.nb = -1; D.dab = -1.0; D.lim = st.lim; D.halt = D.need_exact = D.error = D.done = 0;
     const WinCounters *cr = w.cnt + ((ph + 3) & 3);
-    if (nanflag) {
+    // The common case as ONE test (every round of a run but a handful): a merge of the certified pair (R1, Q1).  The general chain below
+    // costs eight dependent compare-and-branch steps on uniform values before the operands of the merge can be requested.
+    const bool plain_merge = !nanflag && st.step < N - 1 && st.prev_op != OP_COLLECT && st.prev_op != OP_PAIRS && R1 >= 0 && Q1 >= 0 &&
+                             (st.mode == FA_AHC_MODE_EXACT || nwin == 2);
+    if (plain_merge) {
+        D.op = OP_MERGE;
+    } else if (nanflag) {
         D.halt = 1; D.error = 1;  // NaN distance in an earlier round
     } else if (st.step >= N - 1) {
         D.done = 1;
@@ -939,14 +948,12 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         D.halt = 1; D.error = 2;  // cannot happen with finite data; stop rather than spin
     } else if (Q1 < 0) {
         D.op = OP_RESCAN; D.a = R1; D.na = NR1;  // a lower bound reached the minimum: re-scan that row first
-    } else if (st.mode == FA_AHC_MODE_EXACT) {
-        D.op = OP_MERGE;
     } else {
         // The pair (R1, Q1) is stored once, so row Q1 carries the same value: exactly two row minima inside the
         // window [g1, g1 + 2 eps] means {R1, Q1} is the unique candidate pair (any other entry <= lim of either row
-        // would put a third row inside the window; bounds of stale rows count as row minima).
-        if (nwin == 2) D.op = OP_MERGE;
-        else { D.op = OP_COLLECT; D.lim = glim; }
+        // would put a third row inside the window; bounds of stale rows count as row minima).  nwin == 2 (and exact rows) took the
+        // branch at the top; here the window holds more: collect it.
+        D.op = OP_COLLECT; D.lim = glim;
     }
     if (D.op == OP_MERGE && D.a < 0) {
         const bool lo = R1 < Q1;
@@ -1218,9 +1225,14 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
 //   ahc_round_args    : up to kArgProblems problems with their workspaces and block ranges IN the kernel arguments: no extra round trip
 //                       (fa_ahc_linkage_batch / fa_offline_cluster_batch with <= 16 recordings).
 template <bool BATCH>
-__global__ __launch_bounds__(kBlk) void ahc_round_t(const Ws w_one, const Ws *__restrict__ table, const int2 *__restrict__ blkmap, const int ph) {
+__global__ __launch_bounds__(kBlk) void ahc_round_t(const int ph, const int nblk_, AhcState *const state_, RecA *const recA_, int4 *const recI_, RecP *const recP_,
+                                                    const Ws w_one, const Ws *__restrict__ table, const int2 *__restrict__ blkmap) {
+    // The leading scalar arguments repeat what the first loads of a round need (round parity, block count, state and record arrays):
+    // scalars at the front of the argument list are PRELOADED into SGPRs with the wavefront (Makefile: -amdgpu-kernarg-preload-count;
+    // a by-value struct is not), so the record loads of phase 1 do not wait for a scalar load of the arguments first.
     int blk_ = blockIdx.x;
     Ws w_ = w_one;
+    if (!BATCH) { w_.nblk = nblk_; w_.state = state_; w_.recA = recA_; w_.recI = recI_; w_.recP = recP_; }
     if (BATCH) {
         static_assert(sizeof(Ws) % 8 == 0, "Ws is copied as 64-bit words");
         typedef const int __attribute__((address_space(4))) *c_i32;
@@ -1517,7 +1529,7 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
 
     const Ws w = p.w;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    auto launch = [&](const int ph) { hipLaunchKernelGGL(ahc_round_t<false>, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr), ph); };
+    auto launch = [&](const int ph) { hipLaunchKernelGGL(ahc_round_t<false>, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, ph, w.nblk, w.state, w.recA, w.recI, w.recP, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr)); };
     RoundGraph rg;
     const bool single_block = w.nblk == 1 && !getenv("FA_AHC_NO_SINGLE_BLOCK");
     if (single_block) {
@@ -1621,7 +1633,7 @@ fa_status ahc_batch_once(fa_ctx *ctx, int count, const double *const *d_data, co
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_args), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     auto launch = [&](const int ph) {
         if (by_args) hipLaunchKernelGGL(ahc_round_args, dim3(grid), dim3(kBlk), lds, ctx->stream, bargs, ph);
-        else hipLaunchKernelGGL(ahc_round_t<true>, dim3(grid), dim3(kBlk), lds, ctx->stream, Ws{}, d_table, static_cast<const int2 *>(d_map), ph);
+        else hipLaunchKernelGGL(ahc_round_t<true>, dim3(grid), dim3(kBlk), lds, ctx->stream, ph, 0, static_cast<AhcState *>(nullptr), static_cast<RecA *>(nullptr), static_cast<int4 *>(nullptr), static_cast<RecP *>(nullptr), Ws{}, d_table, static_cast<const int2 *>(d_map));
     };
     for (long long it = 0; it < max_batches; ++it) {
         int n_active = 0;

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "fa_common.h"
@@ -46,6 +47,61 @@ __global__ void centroid_kernel(const double *__restrict__ emb, const double *__
         }
     }
     cent[static_cast<int64_t>(c) * d + k] = den > 0 ? __ddiv_rn(num, den) : 0.0;
+}
+
+// The same sums for long recordings: the additions of one (speaker, dimension) are a dependent chain in row order — that is the
+// reference's daxpy order and what makes the result bit-identical to the CPU restatement — but nothing says the LOADS have to be:
+// centroid_kernel keeps 16 rows in flight per thread and runs on K x d / 64 wavefronts (12 x 4 at the 8 h session: 4.1 ms, every
+// 16 rows cost a full memory round trip).  Here a workgroup of 4 wavefronts owns (speaker, 64 dimensions): all four fetch tiles of
+// 128 rows (32 requests in flight per thread, coalesced 512-byte rows) into a double-buffered LDS tile while wavefront 0 walks
+// the previous tile in row order.  Same operations in the same order: identical bits.
+constexpr int kCenTile = 128;
+__global__ __launch_bounds__(256) void centroid_tiled_kernel(const double *__restrict__ emb, const double *__restrict__ gamma, const int32_t *__restrict__ spk,
+                                                             double *__restrict__ cent, int64_t n, int d, int S, int K) {
+    extern __shared__ double cen_lds[];                      // [2][kCenTile][64] values, then [2][kCenTile] weights
+    double *wbuf = cen_lds + 2 * kCenTile * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane, c = blockIdx.y;
+    const int s = spk[c];
+    const bool kin = k < d;
+    constexpr int kPer = kCenTile / 4;                       // rows per wavefront and tile
+    double ev[kPer], wv = 0.0;
+    auto fetch = [&](const int64_t t0) {                     // rows t0 + wave * kPer + j
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int64_t t = t0 + wave * kPer + j;
+            ev[j] = t < n && kin ? emb[t * d + k] : 0.0;
+        }
+        const int64_t tw = t0 + wave * kPer + lane;          // lane j < kPer carries the weight of row j of this wavefront's share
+        wv = lane < kPer && tw < n ? gamma[tw * S + s] : 0.0;
+    };
+    auto put = [&](const int buf) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) cen_lds[(static_cast<size_t>(buf) * kCenTile + wave * kPer + j) * 64 + lane] = ev[j];
+        if (lane < kPer) wbuf[buf * kCenTile + wave * kPer + lane] = wv;
+    };
+    double num = 0.0, den = 0.0;
+    fetch(0);
+    put(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t t0 = 0; t0 < n; t0 += kCenTile, buf ^= 1) {
+        if (t0 + kCenTile < n) fetch(t0 + kCenTile);         // in flight while wavefront 0 adds
+        if (wave == 0) {
+            const double *tile = cen_lds + static_cast<size_t>(buf) * kCenTile * 64 + lane;
+            const double *wt = wbuf + buf * kCenTile;
+#pragma unroll 16
+            for (int r = 0; r < kCenTile; ++r) {
+                const double w = wt[r], e = tile[r * 64];
+                if (!(w > 0)) continue;                      // rows beyond n carry weight 0
+                den = __dadd_rn(den, w);
+                num = __dadd_rn(num, __dmul_rn(w, e));
+            }
+        }
+        if (t0 + kCenTile < n) put(buf ^ 1);                 // the other buffer: its last readers finished before the previous barrier
+        __syncthreads();
+    }
+    if (wave == 0 && kin) cent[static_cast<int64_t>(c) * d + k] = den > 0 ? __ddiv_rn(num, den) : 0.0;
 }
 
 // unit-normalised copy (normalize :824-859: a vector with sum of squares <= 0 is returned unchanged)
@@ -342,7 +398,12 @@ fa_status fa_constrained_assign(fa_ctx *ctx, const double *scores, int64_t n, in
 fa_status fa::centroids_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_gamma, int32_t S, const int32_t *d_spk, int32_t K,
                             double *d_cent) {
     if (K <= 0) return FA_SUCCESS;
-    hipLaunchKernelGGL(centroid_kernel, dim3((d + 63) / 64, K), dim3(64), 0, ctx->stream, d_emb, d_gamma, d_spk, d_cent, n, d, S, K);
+    if (n >= 4 * kCenTile && getenv("FA_CENTROID_SIMPLE") == nullptr) {
+        const size_t lds = sizeof(double) * (2 * kCenTile * 64 + 2 * kCenTile);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(centroid_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipLaunchKernelGGL(centroid_tiled_kernel, dim3((d + 63) / 64, K), dim3(256), lds, ctx->stream, d_emb, d_gamma, d_spk, d_cent, n, d, S, K);
+    } else
+        hipLaunchKernelGGL(centroid_kernel, dim3((d + 63) / 64, K), dim3(64), 0, ctx->stream, d_emb, d_gamma, d_spk, d_cent, n, d, S, K);
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }

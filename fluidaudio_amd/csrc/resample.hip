@@ -11,7 +11,10 @@
 //     10 * max(up, down), unit DC gain, the output alignment of scipy.signal.resample_poly) so that an independent
 //     second opinion exists on the CPU.  One thread per output sample walks the ~2*10*max(up,down)/up taps of its
 //     phase; consecutive threads read consecutive input samples and taps `up` apart.
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "fa_common.h"
@@ -41,9 +44,9 @@ __global__ void linear_kernel(const float *__restrict__ mono, float *__restrict_
 }
 
 __global__ void poly_kernel(const float *__restrict__ x, const float *__restrict__ h, float *__restrict__ y, int64_t n_in, int64_t n_out,
-                            int64_t h_len, int up, int down, int64_t pre_remove) {
-    const int64_t m = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (m >= n_out) return;
+                            int64_t h_len, int up, int down, int64_t pre_remove, int64_t m_lo, int64_t m_hi) {
+    const int64_t m = m_lo + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (m >= m_hi || m >= n_out) return;
     const int64_t p = (m + pre_remove) * down;  // position in the zero-stuffed stream
     int64_t k_hi = p / up;                      // largest k with p - k*up >= 0
     int64_t k_lo = (p - (h_len - 1) + up - 1) / up;  // smallest k with p - k*up <= h_len - 1
@@ -91,6 +94,47 @@ __global__ __launch_bounds__(kThreads) void poly_lds_kernel(const float *__restr
             y[m] = acc;
         }
     }
+}
+
+// Integer decimation (up == 1, down 2 .. 5: 32 / 48 / 64 / 80 kHz -> 16 kHz), register-tiled: every output has the SAME taps, so they are read
+// once per wavefront through the scalar cache (constant address space -> SGPRs, folded into the fused multiply-adds as scalar
+// operands), and R consecutive outputs of a thread share their inputs: NT + (R - 1) DOWN samples fetched with 16-byte loads straight
+// into registers — no LDS at all.  The LDS-staged kernel above spends two LDS operand reads per multiply-add (11.8 % of the HBM
+// roofline for 48 -> 16 kHz, LDS-issue bound); here a multiply-add costs one v_fmac with a scalar operand.  Per output the terms are
+// added in ascending input order with fmaf, INCLUDING the leading zero taps: bit-identical to poly_kernel.
+// Geometry for up == 1 (fa_resample_poly_taps): half = 10 DOWN, NT = 21 DOWN + 1 taps of which the first DOWN are zeros,
+// pre_remove = 11: output m reads inputs (m - 10) DOWN ... (m + 11) DOWN with tap (m + 11) DOWN - k.  The launch covers outputs
+// [m_begin, m_begin + count R) whose inputs all exist; m_begin = 10 (mod 4) and R DOWN = 0 (mod 4) make every thread's first input a
+// multiple of 4 samples: aligned 16-byte loads with a compile-time lane layout.  The edges go to poly_kernel.
+constexpr int kDecimR = 8;
+template <int DOWN>
+__global__ __launch_bounds__(kThreads) void poly_decim_kernel(const float *__restrict__ x, const float *__restrict__ h, float *__restrict__ y, int64_t m_begin,
+                                                              int64_t groups) {
+    constexpr int R = kDecimR, NT = 21 * DOWN + 1, NIN = NT + (R - 1) * DOWN, NV = (NIN + 3) / 4;
+    static_assert((R * DOWN) % 4 == 0, "aligned 16-byte loads need R * DOWN = 0 (mod 4)");
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    if (g >= groups) return;
+    const int64_t m0 = m_begin + g * R;
+    const float4 *src = reinterpret_cast<const float4 *>(x + (m0 - 10) * DOWN);
+    float xin[4 * NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { const float4 q = src[v]; xin[4 * v] = q.x; xin[4 * v + 1] = q.y; xin[4 * v + 2] = q.z; xin[4 * v + 3] = q.w; }
+    typedef const float __attribute__((address_space(4))) *c_f32;
+    const c_f32 taps = (c_f32)h;
+    float acc[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) acc[j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)          // ascending input index; output j meets it with tap NT - 1 + j DOWN - i
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int ti = NT - 1 + j * DOWN - i;
+            if (ti >= 0 && ti < NT) acc[j] = fmaf(taps[ti], xin[i], acc[j]);
+        }
+    float4 *dst = reinterpret_cast<float4 *>(y + m0);   // m0 = 10 (mod 4) + multiple of 8: 8-byte aligned only -> two-float stores
+    (void)dst;
+#pragma unroll
+    for (int j = 0; j < R; j += 2) *reinterpret_cast<float2 *>(y + m0 + j) = make_float2(acc[j], acc[j + 1]);
 }
 
 double bessel_i0(double x) {  // power series, converges fast for the beta used here
@@ -217,9 +261,39 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
             ctx->poly_up = u; ctx->poly_down = dn;
         }
         float *d_h = static_cast<float *>(ctx->poly_taps);
+        const bool simple = getenv("FA_RESAMPLE_SIMPLE") != nullptr;
+        auto edges = [&](const int64_t m_lo, const int64_t m_hi) {   // outputs [m_lo, m_hi) by the one-thread-per-output kernel (clamps at the signal's ends)
+            if (m_hi <= m_lo) return;
+            hipLaunchKernelGGL(poly_kernel, dim3(static_cast<unsigned>((m_hi - m_lo + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, frames, n_out,
+                               n_taps, u, dn, pre_remove, m_lo, m_hi);
+        };
+        // integer decimation: register-tiled kernel on the outputs whose inputs all exist, poly_kernel on the two edges
+        bool decim = false;
+        if (!simple && u == 1 && (dn == 2 || dn == 3 || dn == 4 || dn == 5) && getenv("FA_RESAMPLE_NO_DECIM") == nullptr &&
+            (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_y) & 7) == 0 && n_taps == 21 * dn + 1 && pre_remove == 11) {
+            const int64_t m_begin = 10;                                                  // inputs start at (m - 10) dn >= 0; 10 = 10 (mod 4)
+            const int64_t m_last = (frames - 1) / dn - 11;                               // (m + 11) dn <= frames - 1
+            const int64_t groups = m_last >= m_begin ? (std::min(m_last + 1, n_out) - m_begin) / kDecimR : 0;
+            // the 16-byte loads of the last group may run up to 3 samples past its last input: keep them inside the signal
+            int64_t gr = groups;
+            while (gr > 0 && ((m_begin + gr * kDecimR - 1) + 11) * dn + 3 > frames - 1) --gr;
+            if (gr > 0) {
+                const unsigned grid = static_cast<unsigned>((gr + kThreads - 1) / kThreads);
+                switch (dn) {
+                    case 2: hipLaunchKernelGGL(poly_decim_kernel<2>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;
+                    case 3: hipLaunchKernelGGL(poly_decim_kernel<3>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;
+                    case 4: hipLaunchKernelGGL(poly_decim_kernel<4>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;
+                    default: hipLaunchKernelGGL(poly_decim_kernel<5>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;   // (6: 127 taps + 169 inputs spill)
+                }
+                edges(0, m_begin);
+                edges(m_begin + gr * kDecimR, n_out);
+                decim = true;
+            }
+        }
         const int64_t span = (static_cast<int64_t>(kPolyTile) * dn + u - 1) / u + (n_taps + u - 1) / u + 4;
         const size_t lds = sizeof(float) * (static_cast<size_t>((n_taps + 3) & ~static_cast<int64_t>(3)) + static_cast<size_t>(span));
-        if (lds <= 150 * 1024 && getenv("FA_RESAMPLE_SIMPLE") == nullptr) {
+        if (decim) {
+        } else if (lds <= 150 * 1024 && !simple) {
             if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(poly_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
             const int64_t tiles = (n_out + kPolyTile - 1) / kPolyTile;
             const int per_cu = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : 3);
@@ -227,8 +301,7 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
             hipLaunchKernelGGL(poly_lds_kernel, dim3(grid), dim3(kThreads), lds, ctx->stream, d_x, d_h, d_y, frames, n_out, static_cast<int>(n_taps), u, dn, pre_remove,
                                static_cast<int>(span));
         } else {   // very long filters (extreme rate ratios): one thread per output straight from global memory
-            hipLaunchKernelGGL(poly_kernel, dim3(static_cast<unsigned>((n_out + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, frames, n_out,
-                               n_taps, u, dn, pre_remove);
+            edges(0, n_out);
         }
         FA_HIP_TRY(ctx, hipGetLastError());
         return FA_SUCCESS;

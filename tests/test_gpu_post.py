@@ -5,7 +5,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,d,S,seed", [(500, 256, 7, 0), (1, 16, 3, 1), (3000, 128, 40, 2), (257, 33, 5, 3)])
+@pytest.mark.parametrize("n,d,S,seed", [(500, 256, 7, 0), (1, 16, 3, 1), (3000, 128, 40, 2), (257, 33, 5, 3),
+                                        (512, 100, 4, 4), (641, 64, 3, 5), (5000, 256, 12, 6), (1153, 70, 9, 7)])   # n >= 512: the tiled kernel
 def test_centroids_and_assignment_match_oracle(fa, gpu_ctx, oracle_mod, n, d, S, seed):
     rng = np.random.default_rng(seed)
     emb = rng.standard_normal((n, d))
@@ -59,3 +60,15 @@ def test_scores_and_constrained_assignment_match_oracle(fa, gpu_ctx, oracle_mod,
     assert got == want
     if K >= 3:
         assert min(got) >= 0
+
+
+def test_constrained_assignment_beyond_256_clusters(fa, gpu_ctx, oracle_mod):
+    """More than 256 clusters (or rows in a chunk): potentials / matching live in HBM slabs instead of LDS (round 2 returned
+    RUNTIME_ERROR; the reference solves any size, HungarianAssignment.swift:8-62).  Same integers -> same assignment."""
+    rng = np.random.default_rng(9)
+    for n, K, per in ((300, 300, 3), (640, 40, 320), (700, 257, 7)):
+        scores = rng.standard_normal((n, K))
+        chunks = (np.arange(n) // per).astype(np.int32)
+        want = oracle_mod.constrained_assign(scores, chunks)
+        got = fa.ConstrainedClusterAssignment.assign(scores, chunks, ctx=gpu_ctx)
+        np.testing.assert_array_equal(np.asarray(got), want)

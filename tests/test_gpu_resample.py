@@ -36,10 +36,13 @@ def test_polyphase_extension_vs_scipy(fa, gpu_ctx, up, down, n):
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("up,down,n", [(1, 3, 250001), (160, 441, 132300), (2, 1, 40000), (640, 441, 33075), (1, 6, 96000), (1, 1, 5000), (3, 2, 5), (160, 147, 14700)])
+@pytest.mark.parametrize("up,down,n", [(1, 3, 250001), (160, 441, 132300), (2, 1, 40000), (640, 441, 33075), (1, 6, 96000), (1, 1, 5000), (3, 2, 5), (160, 147, 14700),
+                                       (1, 2, 100003), (1, 4, 64000), (1, 5, 80007), (1, 3, 62), (1, 3, 63), (1, 3, 64), (1, 3, 130), (1, 3, 1000), (1, 2, 45), (1, 5, 200)])
 def test_lds_kernel_equals_simple_kernel(fa, gpu_ctx, monkeypatch, up, down, n):
-    """The LDS-staged persistent polyphase kernel keeps the summation order of the one-thread-per-output kernel: identical bits
-    on several rate pairs (48k / 44.1k / 8k / 11.025k / 96k -> 16k, 44.1k -> 48k), multi-tile signals and tiny ones."""
+    """The LDS-staged persistent polyphase kernel and the register-tiled decimation kernel (up = 1, down 2 .. 5: interior outputs, the
+    edges by the simple kernel) keep the summation order of the one-thread-per-output kernel: identical bits on several rate pairs
+    (48k / 44.1k / 8k / 11.025k / 32k / 64k / 80k / 96k -> 16k, 44.1k -> 48k), multi-tile signals, tiny ones, and lengths around the
+    point where the first interior group appears."""
     rng = np.random.default_rng(n)
     x = (0.4 * np.sin(2 * np.pi * 440 * np.arange(n) / 16000.0) + 0.1 * rng.standard_normal(n)).astype(np.float32)
     got = fa.resample_poly(x, up, down, ctx=gpu_ctx)
