@@ -601,10 +601,33 @@ def mel_leg(fa, ctx, torch, dist, rank, world, B, steps, warmup, clock_warm_s):
     hours = world * B * 15.0 / 3600.0
     value = hours * steps / elapsed
     ach = B * MEL_BYTES_PER_CHUNK / (kernel_ms_avg * 1e-3) / 1e9
-    traffic, traffic_source = measured_traffic()
+    # what the unaligned output rows cost: the same launch with frame_stride 1504 (rows of 6 016 bytes = 47 x 128-byte lines) instead
+    # of the reference's 1501 (6 004 bytes: every row starts inside a line its neighbour also writes)
+    aligned = None
+    try:
+        plan_a = mel.plan(offsets, layout="mel_major", frame_stride=1504)
+        d_out_a = torch.empty(plan_a.out_shape(), dtype=torch.float32, device="cuda")
+        for _ in range(10):
+            plan_a.execute(d_pcm, d_out_a, d_len, order=False)
+        ctx.synchronize()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        na = max(20, steps // 4)
+        ea.record(stream)
+        for _ in range(na):
+            plan_a.execute(d_pcm, d_out_a, d_len, order=False)
+        eb.record(stream)
+        ctx.synchronize()
+        ms_a = ea.elapsed_time(eb) / na
+        same = bool(torch.equal(d_out_a[:, :, :1501], d_out))
+        aligned = {"frame_stride": 1504, "kernel_ms_avg": ms_a, "speedup_vs_1501": kernel_ms_avg / ms_a, "same_values": same,
+                   "note": "row stride of 47 whole 128-byte lines: measures the cost of the 1.2x write amplification of the reference's [128, 1501] layout"}
+        del d_out_a
+        plan_a.close()
+    except Exception as e:  # noqa: BLE001
+        aligned = {"error": repr(e)}
     return {"workload": "BASELINE configs[1]: batched STFT->mel, 1024 x 15 s 16 kHz chunks per GPU, NeMo config (n_fft 512, hop 160, win 400, 128 mels, "
                         "preemph 0.97), output [B,128,1501] fp32, inputs resident in HBM", "chunks_per_gpu": B, "steps": steps, "warmup": warmup,
-            "audio_hours_per_s": value, "realtime_factor": value * 3600.0, "ms_per_step": 1e3 * elapsed / steps, "scaling": "weak",
+            "audio_hours_per_s": value, "realtime_factor": value * 3600.0, "ms_per_step": 1e3 * elapsed / steps, "scaling": "weak", "aligned_rows": aligned,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "mel_kernel_v4<MEL_MAJOR>", "kernel_ms_avg": kernel_ms_avg, "kernel_ms_min": float(np.min(kernel_ms)),
                          "algorithmic_bytes_per_launch": B * MEL_BYTES_PER_CHUNK,

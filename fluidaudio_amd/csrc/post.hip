@@ -90,12 +90,17 @@ __global__ __launch_bounds__(256) void centroid_tiled_kernel(const double *__res
         if (wave == 0) {
             const double *tile = cen_lds + static_cast<size_t>(buf) * kCenTile * 64 + lane;
             const double *wt = wbuf + buf * kCenTile;
-#pragma unroll 16
-            for (int r = 0; r < kCenTile; ++r) {
-                const double w = wt[r], e = tile[r * 64];
-                if (!(w > 0)) continue;                      // rows beyond n carry weight 0
-                den = __dadd_rn(den, w);
-                num = __dadd_rn(num, __dmul_rn(w, e));
+            for (int r0 = 0; r0 < kCenTile; r0 += 16) {   // 32 LDS reads requested together, then 16 branch-free steps of the chain: a skipped
+                double ww[16], ee[16];                    // row (weight <= 0, :655) keeps the old sums through a select — no 0 * e is ever added
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { ww[j] = wt[r0 + j]; ee[j] = tile[(r0 + j) * 64]; }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const bool on = ww[j] > 0;
+                    const double d2 = __dadd_rn(den, ww[j]), n2 = __dadd_rn(num, __dmul_rn(ww[j], ee[j]));
+                    den = on ? d2 : den;
+                    num = on ? n2 : num;
+                }
             }
         }
         if (t0 + kCenTile < n) put(buf ^ 1);                 // the other buffer: its last readers finished before the previous barrier
