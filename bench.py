@@ -555,7 +555,7 @@ def cpu_e2e_baseline(hours=1.0):
                               "+ mel ~430 s at this rate => ~0.008 audio-hours/s"}
 
 
-def mel_leg(fa, ctx, torch, dist, rank, world, B, steps, warmup, clock_warm_s):
+def mel_leg(fa, ctx, torch, dist, rank, world, B, steps, warmup, clock_warm_s, measure_aligned=True):
     """BASELINE configs[1]: one fa_mel_execute_dev over B x 15 s chunks resident in HBM per step; HIP events per launch on the context's stream."""
     stream = torch.cuda.ExternalStream(ctx.stream)
     d_pcm = synth_pcm(torch, B, 1234 + rank)
@@ -601,10 +601,13 @@ def mel_leg(fa, ctx, torch, dist, rank, world, B, steps, warmup, clock_warm_s):
     hours = world * B * 15.0 / 3600.0
     value = hours * steps / elapsed
     ach = B * MEL_BYTES_PER_CHUNK / (kernel_ms_avg * 1e-3) / 1e9
+    traffic, traffic_source = measured_traffic()
     # what the unaligned output rows cost: the same launch with frame_stride 1504 (rows of 6 016 bytes = 47 x 128-byte lines) instead
     # of the reference's 1501 (6 004 bytes: every row starts inside a line its neighbour also writes)
     aligned = None
     try:
+        if not measure_aligned:
+            raise RuntimeError("skipped (profiling run)")
         plan_a = mel.plan(offsets, layout="mel_major", frame_stride=1504)
         d_out_a = torch.empty(plan_a.out_shape(), dtype=torch.float32, device="cuda")
         for _ in range(10):
@@ -677,7 +680,7 @@ def main():
     ctx = fa.default_context(local_rank)
     solo = world == 1
     if args.only_mel:
-        m = mel_leg(fa, ctx, torch, dist, rank, world, args.chunks, args.mel_steps, args.mel_warmup, args.clock_warm_s)
+        m = mel_leg(fa, ctx, torch, dist, rank, world, args.chunks, args.mel_steps, args.mel_warmup, args.clock_warm_s, measure_aligned=False)
         if rank == 0:
             print(json.dumps({"metric": "mel leg only (profiling helper)", "mel": m}))
         if dist is not None:
