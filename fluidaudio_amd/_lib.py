@@ -25,7 +25,7 @@ MEL_CENTER_ZERO, MEL_CENTER_REFLECT = 0, 1
 MEL_SCALE_SLANEY, MEL_SCALE_HTK_NONORM = 0, 1
 MEL_TAIL_ZERO, MEL_TAIL_REPLICATE = 0, 1
 DTYPE_F32, DTYPE_F16 = 0, 1
-AHC_MODE_AUTO, AHC_MODE_EXACT = 0, 1
+AHC_MODE_AUTO, AHC_MODE_EXACT, AHC_MODE_REFERENCE_ORDER = 0, 1, 2
 
 # Every symbol include/fluidaudio_hip.h + include/FastClusterWrapper.h declare (checked by tests/test_abi.py).
 EXPORTED_SYMBOLS = [
@@ -72,7 +72,7 @@ class TdtConfig(C.Structure):
 
 class AhcStats(C.Structure):
     _fields_ = [("merges", C.c_int64), ("rounds", C.c_int64), ("rescans", C.c_int64), ("exact_fallback", C.c_int64),
-                ("init_ms", C.c_double), ("merge_ms", C.c_double), ("total_ms", C.c_double), ("windows", C.c_int64)]
+                ("init_ms", C.c_double), ("merge_ms", C.c_double), ("total_ms", C.c_double), ("windows", C.c_int64), ("reference_order", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -47,6 +47,7 @@
 #include <vector>
 
 #include "fa_common.h"
+#include "ahc_reforder.h"
 
 namespace {
 
@@ -598,12 +599,12 @@ struct Decision {
 // operation; FastClusterWrapper.cpp:68-75).  One wavefront per pair: 64 lanes square the differences of a 64-wide
 // slice, lane 0 adds them in index order.  Minimum by (value, a, b); returned in every thread.
 __device__ void exact_min_pair(const Ws &w, const int np, double *s_sq /*[kWaves*64]*/, double *s_val, int *s_idx,
-                               double &best, int &best_p) {
+                               double &best, int &best_p, bool &tie) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = w.d;
     best = dinf();
     best_p = INT_MAX;
-    bool nan_seen = false;
+    bool nan_seen = false, tie_w = false;   // tie: two DIFFERENT pairs share the exact minimum (the same pair may be listed twice, once from each of its rows)
     for (int p0 = 0; p0 < np; p0 += kWaves) {
         const int p = p0 + wave;
         const bool live = p < np;
@@ -627,16 +628,18 @@ __device__ void exact_min_pair(const Ws &w, const int np, double *s_sq /*[kWaves
         }
         if (lane == 0 && live) {
             if (sum != sum) nan_seen = true;
-            else if (best_p == INT_MAX || sum < best) { best = sum; best_p = p; }
+            else if (best_p == INT_MAX || sum < best) { best = sum; best_p = p; tie_w = false; }
             else if (sum == best) {
                 const int4 bp = w.pairs[best_p];
+                if (pr.x != bp.x || pr.y != bp.y) tie_w = true;
                 if (pr.x < bp.x || (pr.x == bp.x && pr.y < bp.y)) best_p = p;
             }
         }
     }
-    if (lane == 0) { s_val[wave] = nan_seen ? -1.0 : best; s_idx[wave] = best_p; }
+    if (lane == 0) { s_val[wave] = nan_seen ? -1.0 : best; s_idx[wave] = best_p; s_idx[kWaves + wave] = tie_w ? 1 : 0; }
     __syncthreads();
     best = dinf(); best_p = INT_MAX;
+    tie = false;
     bool bad = false;
     for (int wv = 0; wv < kWaves; ++wv) {
         const double v = s_val[wv];
@@ -644,8 +647,10 @@ __device__ void exact_min_pair(const Ws &w, const int np, double *s_sq /*[kWaves
         if (v < 0.0) bad = true;
         if (p == INT_MAX) continue;
         bool take = best_p == INT_MAX || v < best;
-        if (!take && v == best) {
+        if (take) tie = s_idx[kWaves + wv] != 0;
+        else if (v == best) {
             const int4 q = w.pairs[p], bq = w.pairs[best_p];
+            if (q.x != bq.x || q.y != bq.y || s_idx[kWaves + wv] != 0) tie = true;
             take = q.x < bq.x || (q.x == bq.x && q.y < bq.y);
         }
         if (take) { best = v; best_p = p; }
@@ -697,7 +702,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     __shared__ Dec s_dec;
     __shared__ double s_sq[kBlk];
     __shared__ double s_val[kWaves];
-    __shared__ int s_idx[kWaves];
+    __shared__ int s_idx[2 * kWaves];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = blk * kBlk + tid;
     const int par = ph & 1, npar = par ^ 1;
@@ -939,9 +944,10 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         const int np = cr->npairs;
         if (np > kMaxPairs || np < 1) { D.halt = 1; D.need_exact = 1; }
         else {
-            double best; int bp;
-            exact_min_pair(w, np, s_sq, s_val, s_idx, best, bp);
+            double best; int bp; bool tie;
+            exact_min_pair(w, np, s_sq, s_val, s_idx, best, bp, tie);
             if (bp < 0 || bp == INT_MAX) { D.halt = 1; D.error = 1; }
+            else if (tie) { D.halt = 1; D.need_exact = 2; }   // an EXACT tie at the minimum: which pair the reference takes is its heap's business -> reference order
             else { const int4 e = w.pairs[bp]; D.op = OP_MERGE; D.a = e.x; D.b = e.y; D.na = e.z; D.nb = e.w; D.dab = best; }
         }
     } else if (R1 < 0) {
@@ -1291,6 +1297,161 @@ __global__ void ahc_heights(Ws w) {
     z[2] = __dsqrt_rn(sum);
 }
 
+// ------------------------------------------------------------------------------ reference order (ahc_reforder.h)
+// The run that reproduces the reference's choice among EXACTLY tied distances: every distance the reference evaluates is evaluated
+// here (its sequential fp64 sums), in parallel over the active clusters, and ONE thread replays its selection (binary heap, active
+// list, fa_ro::Sel).  Per dendrogram row: ro_scan (all workgroups: the new node against every active node, or the re-scan of a heap
+// top whose neighbour is gone; block minima by (value, node id)) + ro_select (one workgroup: the minimum of the block minima, then
+// the heap / list updates and the next pair).  O(N d) per merge and two dependent launches: ~40 us per merge instead of 6 — the price
+// of the reference's order, paid only by inputs that contain exact ties at the minimum.
+struct RoPart { double v; int32_t node, pad; };
+struct RoDev {                       // scalars of fa_ro::Sel between launches + flags
+    int32_t heap_size, list_first, merges, op, a, b, n, done, nan_seen, pad;
+    long long scans;
+};
+struct RoWs {
+    double *C, *XT, *M, *sizes, *key, *pair_a, *pair_b, *height_sq, *Z;
+    int32_t *node, *slot_of, *at, *pos, *nghbr, *next, *prev, *flags;
+    RoPart *part;
+    RoDev *dev;
+    int32_t N, Np, d, nblk;
+};
+
+__global__ void ro_init(RoWs w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * w.N) { w.sizes[i] = 1.0; w.slot_of[i] = i < w.N ? i : -1; }
+    if (i < w.Np) w.node[i] = i < w.N ? i : kDead;
+}
+
+// start-up of the reference (fastcluster_internal.hpp:1653-1678): nearest LOWER-indexed point of every point from the exact matrix,
+// lowest index on ties
+__global__ __launch_bounds__(kBlk) void ro_lower_minima(RoWs w) {
+    __shared__ double s_val[kWaves];
+    __shared__ int s_idx[kWaves];
+    const int i = blockIdx.x + 1;
+    double v = dinf();
+    int ix = INT_MAX;
+    const double *row = w.M + static_cast<size_t>(i) * w.Np;
+    for (int x = threadIdx.x; x < i; x += kBlk) { const double m = row[x]; if (m < v) { v = m; ix = x; } }   // x ascending per thread
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(ix, off);
+        if (lt2(ov, oi, v, ix)) { v = ov; ix = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = v; s_idx[threadIdx.x >> 6] = ix; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < kWaves; ++wv) if (lt2(s_val[wv], s_idx[wv], v, ix)) { v = s_val[wv]; ix = s_idx[wv]; }
+        w.key[i] = v;
+        w.nghbr[i] = ix;
+    }
+}
+
+__global__ __launch_bounds__(kBlk) void ro_scan(RoWs w) {
+    extern __shared__ double s_c[];            // [d] coordinates of the scanned node
+    __shared__ double s_val[kWaves];
+    __shared__ int s_idx[kWaves];
+    const RoDev st = *w.dev;
+    if (st.done || st.op == fa_ro::RO_DONE) return;
+    const int tid = threadIdx.x, x = blockIdx.x * kBlk + tid, d = w.d, Np = w.Np;
+    const bool fresh = st.op == fa_ro::RO_NEW_ROW;
+    const int sa = w.slot_of[st.a], sb = fresh ? w.slot_of[st.b] : -1;
+    const int created = st.n + st.merges - 1, limit = fresh ? created : st.a;
+    if (fresh) {   // merged centroid (FastClusterWrapper.cpp:89-100); every workgroup evaluates it, workgroup 0 stores it by node id
+        const double ma = w.sizes[st.a], mb = w.sizes[st.b], den = ma + mb;
+        const double *ca = w.C + static_cast<size_t>(st.a) * d, *cb = w.C + static_cast<size_t>(st.b) * d;
+        for (int k = tid; k < d; k += kBlk) {
+            const double cc = __ddiv_rn(__dadd_rn(__dmul_rn(ca[k], ma), __dmul_rn(cb[k], mb)), den);
+            s_c[k] = cc;
+            if (blockIdx.x == 0) w.C[static_cast<size_t>(created) * d + k] = cc;
+        }
+        if (blockIdx.x == 0 && tid == 0) w.sizes[created] = den;
+    } else {
+        const double *ca = w.C + static_cast<size_t>(st.a) * d;
+        for (int k = tid; k < d; k += kBlk) s_c[k] = ca[k];
+    }
+    __syncthreads();
+    const int nx = w.node[x];
+    const bool act = nx != kDead && x != sa && x != sb && nx < limit;
+    double sum = dinf();
+    if (act) {
+        const double *col = w.XT + x;
+        sum = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < d; ++k) {
+            const double diff = __dsub_rn(col[static_cast<size_t>(k) * Np], s_c[k]);   // sqeuclidean_extended(j, scanned) (:68-75)
+            sum = __dadd_rn(sum, __dmul_rn(diff, diff));
+        }
+        if (sum != sum) w.flags[0] = 1;
+    }
+    __syncthreads();                           // every column of this block has been read before slot sa is overwritten
+    if (fresh && sa / kBlk == static_cast<int>(blockIdx.x)) {
+        for (int k = tid; k < d; k += kBlk) w.XT[static_cast<size_t>(k) * Np + sa] = s_c[k];
+        if (tid == 0) { w.node[sa] = created; w.slot_of[created] = sa; }
+    }
+    if (fresh && x == sb) w.node[sb] = kDead;
+    double v = act ? sum : dinf();
+    int id = act ? nx : INT_MAX;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(id, off);
+        if (lt2(ov, oi, v, id)) { v = ov; id = oi; }
+    }
+    if ((tid & 63) == 0) { s_val[tid >> 6] = v; s_idx[tid >> 6] = id; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int wv = 1; wv < kWaves; ++wv) if (lt2(s_val[wv], s_idx[wv], v, id)) { v = s_val[wv]; id = s_idx[wv]; }
+        RoPart pt; pt.v = v; pt.node = id; pt.pad = 0;
+        w.part[blockIdx.x] = pt;
+    }
+}
+
+__global__ __launch_bounds__(kBlk) void ro_select(RoWs w) {
+    __shared__ double s_val[kWaves];
+    __shared__ int s_idx[kWaves];
+    RoDev st = *w.dev;
+    if (st.done || st.op == fa_ro::RO_DONE) return;
+    const int tid = threadIdx.x;
+    double v = dinf();
+    int id = INT_MAX;
+    for (int b = tid; b < w.nblk; b += kBlk) { const RoPart pt = w.part[b]; if (lt2(pt.v, pt.node, v, id)) { v = pt.v; id = pt.node; } }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(id, off);
+        if (lt2(ov, oi, v, id)) { v = ov; id = oi; }
+    }
+    if ((tid & 63) == 0) { s_val[tid >> 6] = v; s_idx[tid >> 6] = id; }
+    __syncthreads();
+    if (tid != 0) return;
+    for (int wv = 1; wv < kWaves; ++wv) if (lt2(s_val[wv], s_idx[wv], v, id)) { v = s_val[wv]; id = s_idx[wv]; }
+    if (w.flags[0] || id == INT_MAX) { st.done = 1; st.nan_seen = w.flags[0] ? 1 : 2; *w.dev = st; return; }   // NaN distance (nan_error) / nothing to scan
+    fa_ro::Sel sel;
+    sel.heap.key = w.key; sel.heap.at = w.at; sel.heap.pos = w.pos; sel.heap.size = st.heap_size;
+    sel.list.next = w.next; sel.list.prev = w.prev; sel.list.first = st.list_first;
+    sel.nghbr = w.nghbr; sel.n = st.n; sel.merges = st.merges; sel.op = st.op; sel.a = st.a; sel.b = st.b;
+    sel.pair_a = w.pair_a; sel.pair_b = w.pair_b; sel.height_sq = w.height_sq;
+    sel.scan_result(v, id);
+    st.heap_size = sel.heap.size; st.list_first = sel.list.first; st.merges = sel.merges; st.op = sel.op; st.a = sel.a; st.b = sel.b;
+    st.scans = st.scans + 1;
+    if (sel.op == fa_ro::RO_DONE) st.done = 1;
+    *w.dev = st;
+}
+
+// dendrogram rows as LinkageOutput::append writes them (FastClusterWrapper.cpp:150-160), heights square-rooted (:128-130)
+__global__ void ro_finish(RoWs w) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= w.N - 1) return;
+    const double a = w.pair_a[r], b = w.pair_b[r];
+    double *z = w.Z + static_cast<size_t>(r) * 4;
+    z[0] = a < b ? a : b;
+    z[1] = a < b ? b : a;
+    z[2] = __dsqrt_rn(w.height_sq[r]);
+    z[3] = __dadd_rn(w.sizes[static_cast<int>(a)], w.sizes[static_cast<int>(b)]);
+}
+
 // ------------------------------------------------------------------------------ host driver
 struct Layout {
     size_t state, cnt, flags, prof, c, xt, row, e2, node, sizes, z, reca, reci, recs, recp, cand, pairs, norms, m, total;
@@ -1355,6 +1516,7 @@ struct Prob {   // one linkage problem: its workspace, its copy of the device st
     long long fallback = 0;
     fa_status st = FA_SUCCESS;
     bool active = true;
+    bool needs_ro = false;   // an exact tie at the minimum (or a window overflowing with near-ties): to be recomputed in reference order
 };
 
 void window_counter_init(WinCounters (&c)[4]) { for (auto &x : c) { x.stale_key = ~0ULL; x.ncand = 0; x.npairs = 0; } }
@@ -1445,28 +1607,22 @@ fa_status prob_after_replay(fa_ctx *ctx, Prob &p) {
     if (h.error == 1) { p.active = false; return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance"); }
     if (h.error) { p.active = false; return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: internal selection failure (%d)", h.error); }
     if (h.done) { p.active = false; return FA_SUCCESS; }
-    if (h.halt && h.need_exact) {  // ambiguity window overflow under the Lance-Williams filter: exact rows from here on
+    if (h.halt && h.need_exact) {
+        // An exact tie at the minimum (need_exact 2) or a window overflowing with near-ties (1: duplicated / quantised inputs).  Which of
+        // several exactly tied pairs the reference merges is decided by its heap (ahc_reforder.h), so the problem is recomputed in
+        // reference order by the caller.  (Round 2 continued with exact rows and its own tie order here: same heights and partitions on
+        // duplicates, but a different row order — and, where tied pairs overlap, possibly a different tree.)
         ++p.fallback;
-        AhcState patch[2];
-        patch[0] = h;
-        patch[0].halt = 0; patch[0].need_exact = 0; patch[0].mode = FA_AHC_MODE_EXACT; patch[0].eps = 0.0;
-        patch[0].prev_op = OP_NONE;
-        patch[0].sym_limit = static_cast<int32_t>(p.N) + h.step;   // the rebuild below writes both copies of every pair of the nodes made so far
-        for (int k = 0; k < kPend; ++k) { patch[0].pend_row[k] = -1; patch[0].pend_node[k] = -1; }
-        patch[1] = patch[0];
-        WinCounters cinit[4];
-        window_counter_init(cinit);
-        FA_HIP_TRY(ctx, hipMemcpyAsync(p.w.state, patch, sizeof(patch), hipMemcpyHostToDevice, ctx->stream));
-        FA_HIP_TRY(ctx, hipMemcpyAsync(p.w.cnt, cinit, sizeof(cinit), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(ahc_gather_xt, dim3((p.Np + 255) / 256), dim3(256), 0, ctx->stream, p.w);
-        FA_TRY(exact_rebuild(ctx, p.w));
-        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // patch / cinit are host temporaries
+        p.needs_ro = true;
+        p.active = false;
+        return FA_SUCCESS;
     } else if (h.halt) { p.active = false; return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: halted without a reason"); }
     return FA_SUCCESS;
 }
 
 fa_status prob_finish(fa_ctx *ctx, Prob &p) {   // heights from the stored centroids, dendrogram to the caller's device buffer
     if (p.st != FA_SUCCESS) return p.st;
+    if (p.needs_ro) return FA_SUCCESS;   // recomputed by ro_run_device
     if (!p.h.done) return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: round budget exhausted at step %d", p.h.step);
     int32_t hflag = 0;
     hipLaunchKernelGGL(ahc_heights, dim3((p.N + 255) / 256), dim3(256), 0, ctx->stream, p.w);
@@ -1511,8 +1667,118 @@ struct RoundGraph {   // `rounds` rounds captured once, replayed until every pro
 
 }  // namespace
 
+namespace {
+
+// The whole problem in the reference's selection order (see the kernels above).  d_data / d_Z: device pointers.
+fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats) {
+    FA_TRY(prob_check_shape(ctx, N, d));
+    const size_t Np = (N + kBlk - 1) / kBlk * kBlk, nblk = Np / kBlk;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~static_cast<size_t>(255); return at; };
+    const size_t o_dev = take(sizeof(RoDev)), o_dummy = take(sizeof(AhcState) * 2), o_flags = take(16), o_part = take(sizeof(RoPart) * nblk);
+    const size_t o_node = take(4 * Np), o_slot = take(4 * 2 * N), o_sizes = take(8 * 2 * N), o_key = take(8 * 2 * N), o_at = take(4 * N), o_pos = take(4 * 2 * N);
+    const size_t o_ngh = take(4 * 2 * N), o_next = take(4 * (2 * N + 1)), o_prev = take(4 * (2 * N + 1));
+    const size_t o_pa = take(8 * N), o_pb = take(8 * N), o_hs = take(8 * N), o_z = take(8 * 4 * N);
+    const size_t o_c = take(8 * d * 2 * N), o_xt = take(8 * d * Np), o_m = take(8 * Np * Np);
+    FA_TRY(fa::ws_acquire(ctx, o));
+    char *base = static_cast<char *>(ctx->ahc_ws);
+    RoWs w{};
+    w.dev = reinterpret_cast<RoDev *>(base + o_dev); w.flags = reinterpret_cast<int32_t *>(base + o_flags); w.part = reinterpret_cast<RoPart *>(base + o_part);
+    w.node = reinterpret_cast<int32_t *>(base + o_node); w.slot_of = reinterpret_cast<int32_t *>(base + o_slot); w.sizes = reinterpret_cast<double *>(base + o_sizes);
+    w.key = reinterpret_cast<double *>(base + o_key); w.at = reinterpret_cast<int32_t *>(base + o_at); w.pos = reinterpret_cast<int32_t *>(base + o_pos);
+    w.nghbr = reinterpret_cast<int32_t *>(base + o_ngh); w.next = reinterpret_cast<int32_t *>(base + o_next); w.prev = reinterpret_cast<int32_t *>(base + o_prev);
+    w.pair_a = reinterpret_cast<double *>(base + o_pa); w.pair_b = reinterpret_cast<double *>(base + o_pb); w.height_sq = reinterpret_cast<double *>(base + o_hs);
+    w.Z = reinterpret_cast<double *>(base + o_z); w.C = reinterpret_cast<double *>(base + o_c); w.XT = reinterpret_cast<double *>(base + o_xt);
+    w.M = reinterpret_cast<double *>(base + o_m);
+    w.N = static_cast<int32_t>(N); w.Np = static_cast<int32_t>(Np); w.d = static_cast<int32_t>(d); w.nblk = static_cast<int32_t>(nblk);
+    hipStream_t st = ctx->stream;
+    hipEvent_t ev[3];
+    for (auto &e : ev) FA_HIP_TRY(ctx, hipEventCreate(&e));
+    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
+    FA_HIP_TRY(ctx, hipEventRecord(ev[0], st));
+    // ---- start-up: exact matrix (the reference's sums), nearest lower-indexed neighbours
+    FA_HIP_TRY(ctx, hipMemsetAsync(base + o_dev, 0, o_part - o_dev, st));            // RoDev, the dummy state of ahc_pairwise, flags
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(ro_init, dim3(static_cast<unsigned>((std::max(Np, 2 * N) + 255) / 256)), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, st, d_data, w.XT, w.N, w.Np, w.d);
+    Ws pw{};
+    pw.M = w.M; pw.XT = w.XT; pw.node = w.node; pw.flags = w.flags; pw.state = reinterpret_cast<AhcState *>(base + o_dummy); pw.Np = w.Np; pw.d = w.d; pw.N = w.N;
+    pw.nblk = w.nblk;
+    hipLaunchKernelGGL(ahc_pairwise, dim3(w.Np / PT, w.Np / PT), dim3(256), 0, st, pw);
+    if (N > 1) hipLaunchKernelGGL(ro_lower_minima, dim3(static_cast<unsigned>(N - 1)), dim3(kBlk), 0, st, w);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    // ---- the heap over points 1 .. N-1, the list, the first pair: host (the selection logic is the same header on both sides)
+    std::vector<double> key(2 * N, 0.0), pa(N, 0.0), pb(N, 0.0), hs(N, 0.0);
+    std::vector<int32_t> at(N, 0), pos(2 * N, 0), ngh(2 * N, 0), next(2 * N + 1, 0), prev(2 * N + 1, 0);
+    int32_t hflag = 0;
+    FA_HIP_TRY(ctx, hipMemcpyAsync(key.data(), w.key, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(ngh.data(), w.nghbr, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(&hflag, w.flags, sizeof(hflag), hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (hflag) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
+    fa_ro::Sel sel{};
+    sel.heap.key = key.data(); sel.heap.at = at.data(); sel.heap.pos = pos.data();
+    sel.heap.init_identity(static_cast<int32_t>(N) - 1, 1);
+    sel.heap.heapify();
+    sel.list.next = next.data(); sel.list.prev = prev.data();
+    sel.list.init(2 * static_cast<int32_t>(N) - 1);
+    sel.nghbr = ngh.data(); sel.n = static_cast<int32_t>(N); sel.merges = 0; sel.pair_a = pa.data(); sel.pair_b = pb.data(); sel.height_sq = hs.data();
+    sel.advance();
+    RoDev hd{};
+    hd.heap_size = sel.heap.size; hd.list_first = sel.list.first; hd.merges = sel.merges; hd.op = sel.op; hd.a = sel.a; hd.b = sel.b; hd.n = sel.n;
+    hd.done = sel.op == fa_ro::RO_DONE ? 1 : 0;
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.key, key.data(), sizeof(double) * 2 * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.at, at.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.pos, pos.data(), sizeof(int32_t) * 2 * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.nghbr, ngh.data(), sizeof(int32_t) * 2 * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.next, next.data(), sizeof(int32_t) * (2 * N + 1), hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.prev, prev.data(), sizeof(int32_t) * (2 * N + 1), hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.pair_a, pa.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.pair_b, pb.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.height_sq, hs.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.dev, &hd, sizeof(hd), hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(st));   // the vectors above are host temporaries
+    FA_HIP_TRY(ctx, hipEventRecord(ev[1], st));
+    // ---- one (scan, select) pair per dendrogram row or re-scan, replayed from a graph until the device reports the end
+    const size_t lds = sizeof(double) * d;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ro_scan), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    auto launch = [&](const int) {
+        hipLaunchKernelGGL(ro_scan, dim3(w.nblk), dim3(kBlk), lds, st, w);
+        hipLaunchKernelGGL(ro_select, dim3(1), dim3(kBlk), 0, st, w);
+    };
+    RoundGraph rg;
+    rg.capture(ctx, launch, static_cast<int>(std::min<size_t>(256, (N + 3) & ~static_cast<size_t>(3))));
+    const long long max_replays = 16 + 8 * static_cast<long long>(N) / rg.rounds;   // rows + re-scans (a node is re-scanned only when it tops the heap with a merged neighbour)
+    for (long long it = 0; it < max_replays && !hd.done; ++it) {
+        FA_TRY(rg.replay(ctx, launch));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(&hd, w.dev, sizeof(hd), hipMemcpyDeviceToHost, st));
+        FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    if (hd.nan_seen == 1) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
+    if (!hd.done || hd.nan_seen || hd.merges != static_cast<int32_t>(N) - 1) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: reference-order run stopped at row %d", hd.merges);
+    hipLaunchKernelGGL(ro_finish, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, st, w);
+    FA_HIP_TRY(ctx, hipMemcpyAsync(d_Z, w.Z, sizeof(double) * 4 * (N - 1), hipMemcpyDeviceToDevice, st));
+    FA_HIP_TRY(ctx, hipEventRecord(ev[2], st));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (stats) {
+        float t01 = 0, t12 = 0;
+        (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+        stats->merges = hd.merges; stats->rounds += hd.scans; stats->reference_order = 1;
+        stats->init_ms += t01; stats->merge_ms += t12; stats->total_ms += t01 + t12;
+    }
+    return FA_SUCCESS;
+}
+
+}  // namespace
+
 fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, int mode, fa_ahc_stats *stats) {
     FA_TRY(prob_check_shape(ctx, N, d));
+    if (mode == FA_AHC_MODE_REFERENCE_ORDER) {
+        fa::WsUse ws_use(ctx);
+        if (stats) *stats = fa_ahc_stats{};
+        return ro_run_device(ctx, d_data, N, d, d_Z, stats);
+    }
     Prob p;
     p.N = N; p.d = d; p.Np = (N + kBlk - 1) / kBlk * kBlk; p.d_data = d_data; p.d_Z = d_Z; p.mode = mode;
     p.L = make_layout(N, p.Np, d, p.Np / kBlk);
@@ -1547,6 +1813,17 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     FA_TRY(prob_finish(ctx, p));
     FA_HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
     FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (p.needs_ro) {   // exact ties at the minimum: the whole problem again, in the reference's selection order
+        if (stats) {
+            float t01 = 0, t12 = 0;
+            (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+            (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+            *stats = fa_ahc_stats{};
+            stats->rounds = p.h.rounds; stats->rescans = p.h.rescans; stats->exact_fallback = p.fallback; stats->windows = p.h.windows;
+            stats->init_ms = t01; stats->merge_ms = t12; stats->total_ms = t01 + t12;
+        }
+        return ro_run_device(ctx, d_data, N, d, d_Z, stats);
+    }
 #ifdef FA_AHC_PROFILE
     {
         unsigned long long hp[16];
@@ -1580,6 +1857,19 @@ namespace {
 fa_status ahc_batch_once(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
                          fa_ahc_stats *stats, fa_status *statuses, bool *completed) {
     *completed = false;
+    if (mode == FA_AHC_MODE_REFERENCE_ORDER) {   // no batching in this mode: the selection is a serial replay per problem
+        fa::WsUse ws_use(ctx);
+        fa_status worst = FA_SUCCESS;
+        for (int k = 0; k < count; ++k) {
+            fa_status st = FA_SUCCESS;
+            if (stats) stats[k] = fa_ahc_stats{};
+            if (n[k] >= 2) st = ro_run_device(ctx, d_data[k], n[k], d, d_Z[k], stats ? &stats[k] : nullptr);
+            if (statuses) statuses[k] = st;
+            if (st != FA_SUCCESS && worst == FA_SUCCESS) worst = st;
+        }
+        *completed = true;
+        return worst;
+    }
     std::vector<Prob> probs(static_cast<size_t>(count));
     size_t total = 0, total_blocks = 0;
     std::vector<size_t> at(count, 0);
@@ -1686,6 +1976,14 @@ fa_status ahc_batch_once(fa_ctx *ctx, int count, const double *const *d_data, co
             stats[k].merges = p.h.step; stats[k].rounds = p.h.rounds; stats[k].rescans = p.h.rescans; stats[k].exact_fallback = p.fallback;
             stats[k].windows = p.h.windows; stats[k].init_ms = t01; stats[k].merge_ms = t12; stats[k].total_ms = t01 + t12;   // times of the whole batch
         }
+    }
+    // problems that met an exact tie at the minimum: one after the other in reference order (every other problem has delivered its dendrogram)
+    for (int k = 0; k < count; ++k) {
+        Prob &p = probs[k];
+        if (!p.needs_ro || p.st != FA_SUCCESS) continue;
+        p.st = ro_run_device(ctx, p.d_data, p.N, p.d, p.d_Z, stats ? &stats[k] : nullptr);
+        if (statuses) statuses[k] = p.st;
+        if (p.st != FA_SUCCESS && worst == FA_SUCCESS) worst = p.st;
     }
     *completed = true;
     return worst;

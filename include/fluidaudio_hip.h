@@ -253,10 +253,15 @@ typedef struct {
     int64_t exact_fallback;/* 1 if the Lance-Williams filter hit an ambiguity and the run switched to exact rows */
     double init_ms, merge_ms, total_ms; /* device time (hipEvent) */
     int64_t windows;       /* rounds in which several pairs fell inside the rounding bound and were re-evaluated exactly */
+    int64_t reference_order; /* 1 if the run met an EXACT tie at the minimum (or was asked to) and was computed in the reference's own
+                              * selection order (binary heap + index-ordered scans, fastcluster_internal.hpp:778-935,1625-1800):
+                              * row for row the reference's output on tied input; `rounds` then counts its scans */
 } fa_ahc_stats;
 
-enum { FA_AHC_MODE_AUTO = 0,   /* Lance-Williams filter + exact re-verification, exact rows on ambiguity */
-       FA_AHC_MODE_EXACT = 1 };/* every matrix entry is the reference's sequential fp64 sum */
+enum { FA_AHC_MODE_AUTO = 0,   /* Lance-Williams filter + exact re-verification; an exact tie at the minimum (or a window overflowing
+                                * with near-ties) re-runs the problem in reference order: the dendrogram is the reference's row for row */
+       FA_AHC_MODE_EXACT = 1,  /* every matrix entry is the reference's sequential fp64 sum; ties in (value, row, column) order */
+       FA_AHC_MODE_REFERENCE_ORDER = 2 };/* the reference's selection order from the start (slow: ~40 us per merge; what AUTO falls back to) */
 
 /* Same computation with an explicit context; data/dendrogram are HOST pointers unless
  * device_pointers != 0.  stats may be NULL. */

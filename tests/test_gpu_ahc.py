@@ -88,9 +88,12 @@ def test_exact_ties_same_heights_and_partitions(fa, gpu_ctx, oracle_mod):
     for x in cases:
         xn = oracle_mod.ahc_normalize(x)
         _, zr = oracle_mod.linkage_ref(xn)
-        for mode in (fa.AHC_MODE_AUTO, fa.AHC_MODE_EXACT):
+        for mode in (fa.AHC_MODE_AUTO, fa.AHC_MODE_REFERENCE_ORDER, fa.AHC_MODE_EXACT):
             st, z, stats = fa.linkage(xn, mode=mode, ctx=gpu_ctx, return_stats=True)
             assert st == 0
+            if mode != fa.AHC_MODE_EXACT:      # round 3: the reference's own order among the ties (csrc/ahc_reforder.h)
+                np.testing.assert_array_equal(z, zr)
+                assert stats["reference_order"] == 1 or mode == fa.AHC_MODE_AUTO   # AUTO takes that route only when it meets a tie at the minimum
             np.testing.assert_allclose(np.sort(z[:, 2]), np.sort(zr[:, 2]), rtol=0, atol=1e-15)
             for thr in (0.0, 1e-9, 0.3, 0.6, 1.0, 1.3, 1.5, 2.0):
                 assert same_partition(fa.cut(z, len(xn), thr), oracle_mod.ahc_cut(zr, len(xn), thr)), (thr, mode)
@@ -276,16 +279,16 @@ def test_batch_of_more_problems_than_fit_the_kernel_arguments(fa, gpu_ctx, oracl
         np.testing.assert_array_equal(z, zr)
 
 
-def test_massive_exact_ties_fall_back_to_exact_rows(fa, gpu_ctx):
+def test_massive_exact_ties_reference_order_vs_exact_mode(fa, gpu_ctx):
     """30 % / 90 % of the rows are exact copies of other rows: the Lance-Williams filter cannot certify anything, the window
-    overflows, the run rebuilds the matrix and continues with exact rows (exact_fallback) — same multiset of heights and the same
-    partition as a run in exact mode from the start, no pathological number of rounds."""
+    overflows and the problem is recomputed in the reference's selection order (reference_order) — same multiset of heights and the
+    same partition as a run in exact mode (its own tie order) from the start."""
     for n, dup in ((3000, 0.3), (4000, 0.9)):
         x = speaker_mixture(n, 64, 12, 0.03, 7).copy()
         rng = np.random.default_rng(1)
         x[rng.integers(0, n, int(n * dup))] = x[rng.integers(0, n, int(n * dup))]
         st0, z0, s0 = fa.linkage(x, mode=fa.AHC_MODE_AUTO, ctx=gpu_ctx, return_stats=True)
         st1, z1, s1 = fa.linkage(x, mode=fa.AHC_MODE_EXACT, ctx=gpu_ctx, return_stats=True)
-        assert st0 == st1 == 0 and s0["exact_fallback"] == 1 and s0["rounds"] <= 2 * n
+        assert st0 == st1 == 0 and s0["exact_fallback"] == 1 and s0["reference_order"] == 1 and s0["rounds"] <= 8 * n
         np.testing.assert_array_equal(np.sort(z0[:, 2]), np.sort(z1[:, 2]))
         assert same_partition(fa.cut(z0, n, 0.6), fa.cut(z1, n, 0.6))

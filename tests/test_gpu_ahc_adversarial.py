@@ -139,9 +139,11 @@ def tree_signature(z, n, sq):
 
 
 def check_exact(fa, gpu_ctx, oracle_mod, x, want_windows=False, modes=(0, 1)):
-    """Device dendrogram == the reference build's, bit for bit.  The one excuse: rows in a different ORDER because squared distances
-    were EXACTLY equal (the reference's order among exact ties is its heap layout, fastcluster_internal.hpp:778-890).  That excuse is
-    checked, not assumed: the reference run must contain exact ties, the device's dendrogram must be a VALID greedy run under the
+    """Device dendrogram == the reference build's, bit for bit — in FA_AHC_MODE_AUTO (what the drop-in symbol runs) and
+    FA_AHC_MODE_REFERENCE_ORDER without exception: an exact tie at the minimum re-runs the problem in the reference's selection order
+    (csrc/ahc_reforder.h).  FA_AHC_MODE_EXACT keeps its own documented tie order (value, row, column) and has ONE excuse: rows in a
+    different ORDER because squared distances were EXACTLY equal (the reference's order among exact ties is its heap layout,
+    fastcluster_internal.hpp:778-890).  That excuse is checked, not assumed: the reference run must contain exact ties, the device's dendrogram must be a VALID greedy run under the
     reference's exact arithmetic (valid_greedy_fast: at every step the merged pair is a global minimum, bitwise — a pair merged
     before one that is 1 ulp closer fails), and both must be the same tree as a set of (leaf set, squared height, size) nodes."""
     sr, zr = oracle_mod.linkage_ref(x)
@@ -152,6 +154,8 @@ def check_exact(fa, gpu_ctx, oracle_mod, x, want_windows=False, modes=(0, 1)):
         st, z, stats = fa.linkage(x, mode=mode, ctx=gpu_ctx, return_stats=True)
         assert st == 0
         bad = np.nonzero((z != zr).any(axis=1))[0]
+        if mode != 1:    # AUTO (re-runs in the reference's selection order on an exact tie) and REFERENCE_ORDER: row for row, no excuse
+            assert bad.size == 0, f"mode {mode}: first differing merge {bad[0]} of {len(z)}: device {z[bad[0]]} reference {zr[bad[0]]} stats {stats}"
         if bad.size:
             if sq_ref is None:
                 sq_ref = replay_sq(x, zr)
@@ -269,9 +273,12 @@ def test_quantised_rows_overlapping_ties_valid_greedy(fa, gpu_ctx, oracle_mod, n
     assert sr == 0
     ok_ref, _ = replay_is_valid_greedy(x, zr)
     assert ok_ref                                            # the checker accepts the reference's own output
-    for mode in (0, 1):
+    for mode in (0, 2, 1):
         st, z, stats = fa.linkage(x, mode=mode, ctx=gpu_ctx, return_stats=True)
         assert st == 0
+        if mode != 1:   # the reference's own choice among the tied pairs, row for row
+            np.testing.assert_array_equal(z, zr)
+            assert stats["reference_order"] == 1 or mode == 0
         ok, step = replay_is_valid_greedy(x, z)
         assert ok, (mode, step, stats)
         if np.array_equal(np.sort(z[:, 2]), np.sort(zr[:, 2])):
@@ -290,15 +297,17 @@ def test_quantised_then_normalised_rows_at_size(fa, gpu_ctx, oracle_mod):
     assert sr == 0
     st, z, stats = fa.linkage(xn, mode=0, ctx=gpu_ctx, return_stats=True)
     assert st == 0
+    np.testing.assert_array_equal(z, zr)
     np.testing.assert_array_equal(np.sort(z[:, 2]), np.sort(zr[:, 2]))
     for thr in THRS:
         assert same_partition(fa.cut(z, len(xn), thr), oracle_mod.ahc_cut(zr, len(xn), thr)), (thr, stats)
     assert stats["merges"] == len(xn) - 1
 
 
-def test_massive_exact_ties_partitions_equal_the_reference(fa, gpu_ctx, oracle_mod):
-    """30 % / 90 % of the rows are exact copies of other rows (round 2 compared the two device modes with each other): duplicates
-    merge at height 0 in any order into the same multi-points, so heights multiset and partitions must equal the REFERENCE's."""
+def test_massive_exact_ties_equal_the_reference(fa, gpu_ctx, oracle_mod):
+    """30 % / 90 % of the rows are exact copies of other rows (round 2 compared the two device modes with each other): the window of
+    the Lance-Williams filter overflows, the problem is recomputed in the reference's selection order and equals the reference build's
+    dendrogram row for row."""
     from conftest import speaker_mixture
     for n, dup in ((3000, 0.3), (4000, 0.9)):
         x = speaker_mixture(n, 64, 12, 0.03, 7).copy()
@@ -307,8 +316,42 @@ def test_massive_exact_ties_partitions_equal_the_reference(fa, gpu_ctx, oracle_m
         sr, zr = oracle_mod.linkage_ref(x)
         assert sr == 0
         st, z, stats = fa.linkage(x, mode=fa.AHC_MODE_AUTO, ctx=gpu_ctx, return_stats=True)
-        assert st == 0 and stats["exact_fallback"] == 1 and stats["rounds"] <= 2 * n
+        assert st == 0 and stats["exact_fallback"] == 1 and stats["reference_order"] == 1
+        np.testing.assert_array_equal(z, zr)              # row for row, the duplicates merged in the reference's order
         zero = int((zr[:, 2] == 0).sum())
         assert int((z[:, 2] == 0).sum()) == zero
         for thr in (1e-9, 0.3, 0.6, 1.0):   # not 0.0: three mutual copies merge as (2x + x) / 3, off x by an ulp — WHICH copy ends up 1e-17 away is tie order
             assert same_partition(fa.cut(z, n, thr), oracle_mod.ahc_cut(zr, n, thr)), (thr, stats)
+
+
+@pytest.mark.parametrize("n,d,kind", [(2, 3, "iid"), (3, 2, "iid"), (257, 5, "grid"), (1000, 16, "iid"), (1500, 8, "grid"), (700, 4, "dup")])
+def test_reference_order_mode_equals_the_reference(fa, gpu_ctx, oracle_mod, n, d, kind):
+    """FA_AHC_MODE_REFERENCE_ORDER on its own (what AUTO falls back to): tie-free, grid-quantised and duplicated inputs, tiny and
+    multi-block sizes — the reference build's dendrogram row for row; `rounds` counts the scans (one per row + the re-scans)."""
+    rng = np.random.default_rng(n + d)
+    x = rng.standard_normal((n, d))
+    if kind == "grid":
+        x = np.round(x * 3) / 3
+    if kind == "dup":
+        x[rng.integers(0, n, n // 2)] = x[rng.integers(0, n, n // 2)]
+    sr, zr = oracle_mod.linkage_ref(x)
+    st, z, stats = fa.linkage(x, mode=fa.AHC_MODE_REFERENCE_ORDER, ctx=gpu_ctx, return_stats=True)
+    assert st == sr == 0
+    np.testing.assert_array_equal(z, zr)
+    assert stats["reference_order"] == 1 and stats["merges"] == n - 1
+    # the drop-in symbol (AUTO) on the same input
+    st2, z2 = fa.fastcluster_compute_centroid_linkage(x)
+    assert st2 == 0
+    np.testing.assert_array_equal(z2, zr)
+
+
+def test_batch_with_tied_and_tie_free_problems(fa, gpu_ctx, oracle_mod):
+    """fa_ahc_linkage_batch: the tied problems of a batch are recomputed in reference order after the others have finished; every
+    dendrogram is the reference's."""
+    rng = np.random.default_rng(5)
+    probs = [rng.standard_normal((300, 8)), np.round(rng.standard_normal((400, 8)) * 2) / 2, rng.standard_normal((500, 8)), np.repeat(rng.standard_normal((100, 8)), 3, axis=0)]
+    st, zs, stats = fa.linkage_batch(probs, ctx=gpu_ctx, return_stats=True)
+    assert st == [0, 0, 0, 0]
+    for x, z in zip(probs, zs):
+        np.testing.assert_array_equal(z, oracle_mod.linkage_ref(x)[1])
+    assert stats[1]["reference_order"] == 1 and stats[3]["reference_order"] == 1 and stats[0]["reference_order"] == 0
