@@ -32,13 +32,15 @@
 //     the pair to merge is taken from those values only when it is the unique mutual-nearest pair
 //     with every other row minimum farther than 2*eps (eps = rounding bound of the recurrence);
 //     otherwise all matrix entries inside the window are re-evaluated with the reference's exact
-//     sum (COLLECT -> PAIRS -> evaluate rounds), and if the window overflows (massive ties,
-//     duplicated inputs) the run switches to FA_AHC_MODE_EXACT rows.  Heights are always
+//     sum (COLLECT -> PAIRS -> evaluate rounds); an exact tie there, or a window that overflows
+//     (massive ties, duplicated inputs), sends the problem to the reference-order run.  Heights are always
 //     recomputed after the loop from the stored centroids with the reference's sequential sum, so
 //     the merge order never depends on the approximation and the output rows are bit-identical;
 //   * FA_AHC_MODE_EXACT: every new-row entry is the reference's sequential fp64 sum (O(N d) per merge).
-// Exactly tied distances are merged in (value, row, column) order; the reference's tie order is an
-// artefact of its binary heap layout.  Heights and the partition at any threshold are the same.
+// Exactly tied distances: the round kernel's order is (value, row, column); the reference's is decided by its binary heap.  A run in
+// FA_AHC_MODE_AUTO that meets an exact tie at the minimum (or a window overflowing with near-ties) is therefore recomputed in the
+// reference's selection order (ahc_reforder.h, the ro_* kernels below): the output equals the reference row for row on tied input too.
+// FA_AHC_MODE_EXACT keeps (value, row, column): same heights and partitions on duplicates, possibly other rows.
 #include <algorithm>
 #include <climits>
 #include <cmath>
