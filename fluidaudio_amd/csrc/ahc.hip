@@ -274,15 +274,6 @@ __global__ void ahc_transpose(const double *__restrict__ data, double *__restric
     }
 }
 
-// slot-major coordinates of the clusters currently alive (switch to EXACT rows mid-run)
-__global__ void ahc_gather_xt(Ws w) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= w.Np) return;
-    const int nx = w.node[x];
-    for (int k = 0; k < w.d; ++k)
-        w.XT[static_cast<size_t>(k) * w.Np + x] = nx != kDead ? w.C[static_cast<size_t>(nx) * w.d + k] : 0.0;
-}
-
 __global__ void ahc_init_rows(Ws w) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 2 * w.N) w.sizes[i] = 1.0;
@@ -291,6 +282,42 @@ __global__ void ahc_init_rows(Ws w) {
     RowSt r; r.d1 = dinf(); r.nn = -1; r.nnnode = -1;
     w.row[i] = r;
     w.e2[i] = dinf();
+}
+
+// Initial state, window counters and flags written ON the device, and eps from the maxima the start-up kernels found: the set-up of a
+// problem needs no host round trip (round 2 read dmax / nmax back, computed eps on the host and uploaded it: two stream synchronisations
+// per call — most of the fixed cost of a short recording).  A NaN met by the start-up kernels sets flags[0]; the first round halts on it.
+__global__ void ahc_init_state(Ws w, int mode) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    AhcState s{};
+    s.mode = mode;
+    for (int k = 0; k < kPend; ++k) { s.pend_row[k] = -1; s.pend_node[k] = -1; }
+    s.prev_op = OP_NONE;
+    s.pf_delta = 1e-3;
+    for (int g = 0; g < kPfSlots; ++g) s.pf_slot[g] = -1;
+    s.sym_limit = w.N;                                     // the start-up writes the full matrix: every pair of points has both copies
+    w.state[0] = s; w.state[1] = s;
+    for (int i = 0; i < 4; ++i) { w.cnt[i].stale_key = ~0ULL; w.cnt[i].ncand = 0; w.cnt[i].npairs = 0; }
+    for (int i = 0; i < 4; ++i) w.flags[i] = 0;
+    for (int i = 0; i < 16; ++i) w.prof[i] = 0;
+}
+
+__global__ void ahc_set_eps(Ws w) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const AhcState s = w.state[0];
+    double eps = 0.0;
+    if (s.mode == FA_AHC_MODE_AUTO) {
+        // rounding bound of the Lance-Williams recurrence: <= 9.5 u dmax per merge level — weights from one reciprocal (wa, wb: 2 u each,
+        // wab: 5 u), 3 products, 2 sums: (3 u)(wa da + wb db) + (6 u) wab dab + 2 u dmax <= (3 + 1.5 + 2) u dmax, plus the tree-summed
+        // d(a,b) (~10 ulp of it, weighted by wab <= 1/4: 2.5 u dmax); errors of the two parents enter with weights wa + wb = 1, tree
+        // depth <= N; 16 u per level leaves a margin of 1.7.
+        // Start-up matrix in Gram form: |x|^2 + |y|^2 - 2 x.y carries <= (d + 2) u (|x|^2 + |y|^2 + 2 |x||y|) <= 4 (d + 2) u nmax.
+        const double dmax = __longlong_as_double(static_cast<long long>(s.dmax_bits)), nmax = __longlong_as_double(static_cast<long long>(s.nmax_bits));
+        const double u = 1.1102230246251565e-16;
+        eps = 16.0 * static_cast<double>(w.N) * u * dmax + 8.0 * (static_cast<double>(w.d) + 2.0) * u * nmax;
+    }
+    w.state[0].eps = eps; w.state[1].eps = eps;
+    w.state[1].dmax_bits = s.dmax_bits; w.state[1].nmax_bits = s.nmax_bits;
 }
 
 // Exact pairwise squared distances of the live slots, the reference's summation order
@@ -1486,21 +1513,6 @@ Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
     return L;
 }
 
-// exact matrix, row minima and parity-0 records of the clusters currently alive (XT must hold their coordinates)
-fa_status exact_rebuild(fa_ctx *ctx, const Ws &w, double *gram_norms = nullptr) {
-    if (gram_norms) {  // AUTO start: Gram form on the fp64 matrix cores (approximate entries, see ahc_gram_mfma)
-        hipLaunchKernelGGL(ahc_sqnorms, dim3((w.Np + 255) / 256), dim3(256), 0, ctx->stream, w, gram_norms);
-        hipLaunchKernelGGL(ahc_gram_mfma, dim3(w.Np / GT, w.Np / GT), dim3(256), 0, ctx->stream, w, gram_norms);
-    } else {
-        const int tiles = w.Np / PT;
-        hipLaunchKernelGGL(ahc_pairwise, dim3(tiles, tiles), dim3(256), 0, ctx->stream, w);
-    }
-    hipLaunchKernelGGL(ahc_row_minima, dim3(w.Np), dim3(kBlk), 0, ctx->stream, w);
-    hipLaunchKernelGGL(ahc_records, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);
-    FA_HIP_TRY(ctx, hipGetLastError());
-    return FA_SUCCESS;
-}
-
 // d_data: device [N][d]; d_Z: device [(N-1)*4] (heights already square-rooted on return).
 }  // namespace (reopened below: the next function is one of the device-level cores declared in fa_common.h)
 
@@ -1518,6 +1530,7 @@ struct Prob {   // one linkage problem: its workspace, its copy of the device st
     long long fallback = 0;
     fa_status st = FA_SUCCESS;
     bool active = true;
+    bool z_on_host = false;  // d_Z is the caller's host buffer
     bool needs_ro = false;   // an exact tie at the minimum (or a window overflowing with near-ties): to be recomputed in reference order
 };
 
@@ -1557,49 +1570,23 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
     w.M = reinterpret_cast<double *>(base + L.m);
     w.N = static_cast<int32_t>(N); w.Np = static_cast<int32_t>(Np); w.d = static_cast<int32_t>(d); w.nblk = static_cast<int32_t>(Np / kBlk);
 
-    AhcState init[2]{};
-    init[0].mode = p.mode == FA_AHC_MODE_EXACT ? FA_AHC_MODE_EXACT : FA_AHC_MODE_AUTO;
-    for (int k = 0; k < kPend; ++k) { init[0].pend_row[k] = -1; init[0].pend_node[k] = -1; }
-    init[0].prev_op = OP_NONE;
-    init[0].pf_delta = 1e-3;
-    for (int g = 0; g < kPfSlots; ++g) init[0].pf_slot[g] = -1;
-    init[0].sym_limit = static_cast<int32_t>(N);          // the start-up writes the full matrix: every pair of points has both copies
-    init[1] = init[0];
-    WinCounters cinit[4];
-    window_counter_init(cinit);
-    FA_HIP_TRY(ctx, hipMemcpyAsync(w.state, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    FA_HIP_TRY(ctx, hipMemcpyAsync(w.cnt, cinit, sizeof(cinit), hipMemcpyHostToDevice, ctx->stream));
-    FA_HIP_TRY(ctx, hipMemsetAsync(w.flags, 0, sizeof(int32_t) * 4, ctx->stream));
-    FA_HIP_TRY(ctx, hipMemsetAsync(w.prof, 0, sizeof(unsigned long long) * 16, ctx->stream));
+    const int dev_mode = p.mode == FA_AHC_MODE_EXACT ? FA_AHC_MODE_EXACT : FA_AHC_MODE_AUTO;
+    hipLaunchKernelGGL(ahc_init_state, dim3(1), dim3(64), 0, ctx->stream, w, dev_mode);
     FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, p.d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(ahc_init_rows, dim3((std::max(Np, 2 * N) + 255) / 256), dim3(256), 0, ctx->stream, w);
     hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, ctx->stream, p.d_data, w.XT, w.N, w.Np, w.d);
-    double *d_norms = reinterpret_cast<double *>(base + L.norms);
-    FA_TRY(exact_rebuild(ctx, w, init[0].mode == FA_AHC_MODE_AUTO ? d_norms : nullptr));
-    int32_t hflag = 0;
-    FA_HIP_TRY(ctx, hipMemcpyAsync(&p.h, w.state, sizeof(p.h), hipMemcpyDeviceToHost, ctx->stream));
-    FA_HIP_TRY(ctx, hipMemcpyAsync(&hflag, w.flags, sizeof(hflag), hipMemcpyDeviceToHost, ctx->stream));
-    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // init / cinit are host temporaries; the state feeds eps below
-    if (hflag) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
-    if (init[0].mode == FA_AHC_MODE_AUTO) {
-        double dmax;
-        const long long bits = static_cast<long long>(p.h.dmax_bits);
-        memcpy(&dmax, &bits, sizeof(dmax));
-        // rounding bound of the Lance-Williams recurrence: <= 9.5 u dmax per merge level — weights from one reciprocal (wa, wb: 2 u each,
-        // wab: 5 u), 3 products, 2 sums: (3 u)(wa da + wb db) + (6 u) wab dab + 2 u dmax <= (3 + 1.5 + 2) u dmax, plus the tree-summed
-        // d(a,b) (~10 ulp of it, weighted by wab <= 1/4: 2.5 u dmax); errors of the two parents enter with weights wa + wb = 1, tree
-        // depth <= N; 16 u per level leaves a margin of 1.7.
-        // Start-up matrix in Gram form: |x|^2 + |y|^2 - 2 x.y carries <= (d + 2) u (|x|^2 + |y|^2 + 2 |x||y|) <= 4 (d + 2) u nmax.
-        double nmax;
-        const long long nbits = static_cast<long long>(p.h.nmax_bits);
-        memcpy(&nmax, &nbits, sizeof(nmax));
-        const double u = 1.1102230246251565e-16;
-        const double eps = 16.0 * static_cast<double>(N) * u * dmax + 8.0 * (static_cast<double>(d) + 2.0) * u * nmax;
-        FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state) + offsetof(AhcHot, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
-        FA_HIP_TRY(ctx, hipMemcpyAsync(reinterpret_cast<char *>(w.state + 1) + offsetof(AhcHot, eps), &eps, sizeof(eps), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(ahc_records, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);  // window counts need eps
-        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // eps is a host temporary
+    if (dev_mode == FA_AHC_MODE_AUTO) {  // Gram form on the fp64 matrix cores (approximate entries, see ahc_gram_mfma)
+        double *d_norms = reinterpret_cast<double *>(base + L.norms);
+        hipLaunchKernelGGL(ahc_sqnorms, dim3((w.Np + 255) / 256), dim3(256), 0, ctx->stream, w, d_norms);
+        hipLaunchKernelGGL(ahc_gram_mfma, dim3(w.Np / GT, w.Np / GT), dim3(256), 0, ctx->stream, w, d_norms);
+    } else {
+        const int tiles = w.Np / PT;
+        hipLaunchKernelGGL(ahc_pairwise, dim3(tiles, tiles), dim3(256), 0, ctx->stream, w);
     }
+    hipLaunchKernelGGL(ahc_row_minima, dim3(w.Np), dim3(kBlk), 0, ctx->stream, w);
+    hipLaunchKernelGGL(ahc_set_eps, dim3(1), dim3(64), 0, ctx->stream, w);
+    hipLaunchKernelGGL(ahc_records, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);  // window counts need eps
+    FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }
 
@@ -1628,7 +1615,7 @@ fa_status prob_finish(fa_ctx *ctx, Prob &p) {   // heights from the stored centr
     if (!p.h.done) return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: round budget exhausted at step %d", p.h.step);
     int32_t hflag = 0;
     hipLaunchKernelGGL(ahc_heights, dim3((p.N + 255) / 256), dim3(256), 0, ctx->stream, p.w);
-    FA_HIP_TRY(ctx, hipMemcpyAsync(p.d_Z, p.w.Z, sizeof(double) * 4 * (p.N - 1), hipMemcpyDeviceToDevice, ctx->stream));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(p.d_Z, p.w.Z, sizeof(double) * 4 * (p.N - 1), p.z_on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
     FA_HIP_TRY(ctx, hipMemcpyAsync(&hflag, p.w.flags, sizeof(hflag), hipMemcpyDeviceToHost, ctx->stream));
     FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (hflag) return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
@@ -1672,7 +1659,7 @@ struct RoundGraph {   // `rounds` rounds captured once, replayed until every pro
 namespace {
 
 // The whole problem in the reference's selection order (see the kernels above).  d_data / d_Z: device pointers.
-fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats) {
+fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host = false) {
     FA_TRY(prob_check_shape(ctx, N, d));
     const size_t Np = (N + kBlk - 1) / kBlk * kBlk, nblk = Np / kBlk;
     size_t o = 0;
@@ -1759,7 +1746,7 @@ fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, d
     if (hd.nan_seen == 1) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
     if (!hd.done || hd.nan_seen || hd.merges != static_cast<int32_t>(N) - 1) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: reference-order run stopped at row %d", hd.merges);
     hipLaunchKernelGGL(ro_finish, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, st, w);
-    FA_HIP_TRY(ctx, hipMemcpyAsync(d_Z, w.Z, sizeof(double) * 4 * (N - 1), hipMemcpyDeviceToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(d_Z, w.Z, sizeof(double) * 4 * (N - 1), z_on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
     FA_HIP_TRY(ctx, hipEventRecord(ev[2], st));
     FA_HIP_TRY(ctx, hipStreamSynchronize(st));
     if (stats) {
@@ -1774,14 +1761,31 @@ fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, d
 
 }  // namespace
 
-fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, int mode, fa_ahc_stats *stats) {
+namespace {
+struct CachedGraph {   // the round launches of one problem shape, kept in the context between calls
+    RoundGraph rg;
+    const void *base = nullptr;
+    size_t N = 0, d = 0;
+};
+void cached_graph_free(void *p) { delete static_cast<CachedGraph *>(p); }
+fa_status ctx_events(fa_ctx *ctx, hipEvent_t (&ev)[3]) {
+    for (int i = 0; i < 3; ++i) {
+        if (!ctx->ahc_ev[i]) FA_HIP_TRY(ctx, hipEventCreate(&ctx->ahc_ev[i]));
+        ev[i] = ctx->ahc_ev[i];
+    }
+    return FA_SUCCESS;
+}
+}  // namespace
+
+fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, int mode, fa_ahc_stats *stats, bool z_on_host) {
     FA_TRY(prob_check_shape(ctx, N, d));
     if (mode == FA_AHC_MODE_REFERENCE_ORDER) {
         fa::WsUse ws_use(ctx);
         if (stats) *stats = fa_ahc_stats{};
-        return ro_run_device(ctx, d_data, N, d, d_Z, stats);
+        return ro_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host);
     }
     Prob p;
+    p.z_on_host = z_on_host;
     p.N = N; p.d = d; p.Np = (N + kBlk - 1) / kBlk * kBlk; p.d_data = d_data; p.d_Z = d_Z; p.mode = mode;
     p.L = make_layout(N, p.Np, d, p.Np / kBlk);
     fa::WsUse ws_use(ctx);                      // released (and trimmed to the context's limit) when the call returns
@@ -1789,8 +1793,7 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     const size_t lds = sizeof(double) * d;
 
     hipEvent_t ev[3];
-    for (auto &e : ev) FA_HIP_TRY(ctx, hipEventCreate(&e));
-    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
+    FA_TRY(ctx_events(ctx, ev));                // created once per context
     FA_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
     FA_TRY(prob_setup(ctx, p, static_cast<char *>(ctx->ahc_ws)));
     FA_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
@@ -1798,12 +1801,27 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     const Ws w = p.w;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     auto launch = [&](const int ph) { hipLaunchKernelGGL(ahc_round_t<false>, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, ph, w.nblk, w.state, w.recA, w.recI, w.recP, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr)); };
-    RoundGraph rg;
+    // The captured graph only holds launch parameters (workspace pointers, block count): it is reused as long as the workspace sits at
+    // the same address and the shape is the same — repeated calls on recordings of one length skip capture + instantiation.
+    RoundGraph single_rg;
+    RoundGraph *rgp = &single_rg;
     const bool single_block = w.nblk == 1 && !getenv("FA_AHC_NO_SINGLE_BLOCK");
     if (single_block) {
-        rg.rounds = rounds_for(N);
+        single_rg.rounds = rounds_for(N);
         if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_rounds_single_block), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    } else rg.capture(ctx, launch, rounds_for(N));
+    } else {
+        CachedGraph *cg = static_cast<CachedGraph *>(ctx->ahc_graph);
+        if (!cg || cg->base != ctx->ahc_ws || cg->N != N || cg->d != d || !cg->rg.ok) {
+            delete cg;
+            cg = new CachedGraph();
+            ctx->ahc_graph = cg;
+            ctx->ahc_graph_free = cached_graph_free;
+            cg->base = ctx->ahc_ws; cg->N = N; cg->d = d;
+            cg->rg.capture(ctx, launch, rounds_for(N));
+        }
+        rgp = &cg->rg;
+    }
+    RoundGraph &rg = *rgp;
     const long long max_batches = 64 + 8 * static_cast<long long>(N) / rg.rounds;  // bound on rounds (merges + rescans + windows)
     for (long long it = 0; it < max_batches && p.active; ++it) {
         if (single_block) { hipLaunchKernelGGL(ahc_rounds_single_block, dim3(1), dim3(kBlk), lds, ctx->stream, w, rg.rounds); FA_HIP_TRY(ctx, hipGetLastError()); }
@@ -1824,7 +1842,7 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
             stats->rounds = p.h.rounds; stats->rescans = p.h.rescans; stats->exact_fallback = p.fallback; stats->windows = p.h.windows;
             stats->init_ms = t01; stats->merge_ms = t12; stats->total_ms = t01 + t12;
         }
-        return ro_run_device(ctx, d_data, N, d, d_Z, stats);
+        return ro_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host);
     }
 #ifdef FA_AHC_PROFILE
     {
@@ -2071,16 +2089,10 @@ fa_status fa_ahc_linkage(fa_ctx *ctx, const double *data, size_t n, size_t d, do
     try {
         fa::DeviceGuard guard(ctx->device);
         if (device_pointers) return fa::ahc_run_device(ctx, data, n, d, dendrogram, mode, stats);
-        fa::DevBuf d_in, d_z;
-        if (d_in.alloc(sizeof(double) * n * d) != hipSuccess || d_z.alloc(sizeof(double) * 4 * (n - 1)) != hipSuccess) {
-            (void)hipGetLastError();
-            return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: input staging allocation failed");
-        }
-        FA_HIP_TRY(ctx, hipMemcpyAsync(d_in.p, data, sizeof(double) * n * d, hipMemcpyHostToDevice, ctx->stream));
-        FA_TRY(fa::ahc_run_device(ctx, d_in.as<double>(), n, d, d_z.as<double>(), mode, stats));
-        FA_HIP_TRY(ctx, hipMemcpyAsync(dendrogram, d_z.p, sizeof(double) * 4 * (n - 1), hipMemcpyDeviceToHost, ctx->stream));
-        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        return FA_SUCCESS;
+        // input staged in the context's grow-only scratch (no hipMalloc / hipFree per call), dendrogram copied straight from the workspace
+        FA_TRY(fa::ensure_scratch(ctx, sizeof(double) * n * d));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch, data, sizeof(double) * n * d, hipMemcpyHostToDevice, ctx->stream));
+        return fa::ahc_run_device(ctx, static_cast<const double *>(ctx->scratch), n, d, dendrogram, mode, stats, /*z_on_host*/ true);
     } catch (const std::bad_alloc &) {
         return FA_ALLOCATION_FAILURE;
     } catch (const std::exception &) {

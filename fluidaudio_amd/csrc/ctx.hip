@@ -100,6 +100,8 @@ void fa_ctx_destroy(fa_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ahc_ws) (void)hipFree(ctx->ahc_ws);
     if (ctx->poly_taps) (void)hipFree(ctx->poly_taps);
+    if (ctx->ahc_graph && ctx->ahc_graph_free) ctx->ahc_graph_free(ctx->ahc_graph);
+    for (auto &e : ctx->ahc_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -27,6 +27,11 @@ struct fa_ctx {
     size_t ws_limit = static_cast<size_t>(-1);   // bytes a context may keep cached between calls (FLUIDAUDIO_HIP_WORKSPACE_LIMIT)
     size_t ws_cap = static_cast<size_t>(-1);     // a linkage call needing more workspace than this fails with ALLOCATION_FAILURE
     bool ws_busy = false;
+    // linkage: per-call set-up that does not depend on the data is kept (events; the captured graph of round launches, valid as long as
+    // the workspace address and the problem shape are the same) — a short recording is dominated by such fixed costs
+    hipEvent_t ahc_ev[3] = {nullptr, nullptr, nullptr};
+    void *ahc_graph = nullptr;                 // owned by ahc.hip (ahc_graph_free releases it)
+    void (*ahc_graph_free)(void *) = nullptr;
     // polyphase resampler taps of the last (up, down) pair, device resident (resample.hip)
     void *poly_taps = nullptr;
     size_t poly_taps_bytes = 0;
@@ -88,7 +93,8 @@ struct WsUse {   // scope of one linkage call
 
 // ---- device-level cores shared by the host-pointer entries and fa_offline_cluster (internal, not part of the C ABI).
 // All pointers prefixed d_ are DEVICE pointers; everything is enqueued on ctx->stream; results stay on the device.
-fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, int mode, fa_ahc_stats *stats);   // ahc.hip
+// d_Z: device pointer, or (z_on_host) the caller's host buffer the dendrogram is copied to directly
+fa_status ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, int mode, fa_ahc_stats *stats, bool z_on_host = false);   // ahc.hip
 fa_status ahc_normalize_dev(fa_ctx *ctx, const double *d_x, double *d_out, int64_t n, int32_t d);                              // ahc.hip (:70-105)
 // count independent problems advanced by the same round launches; d_data / d_Z: HOST arrays of device pointers; statuses, stats: per problem (nullable)
 fa_status ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,

@@ -40,7 +40,7 @@ def test_n_that_cannot_fit_is_allocation_failure(fa):
         st = fa.lib().fa_ahc_linkage(ctx.handle, x.ctypes.data, n, 2, z.ctypes.data, z.size, 0, 0, None)
         assert st == fa.ALLOCATION_FAILURE, (n, st, ctx.last_error())
         assert (z == -7.0).all()
-    assert ctx.workspace_bytes() == 0
+    assert ctx.workspace_bytes() < (1 << 26)              # nothing but the input staging (scratch) is cached
 
 
 def test_batch_statuses_under_memory_pressure(fa, oracle_mod):
@@ -132,3 +132,4 @@ def test_eight_pooled_contexts_at_20000_and_release_under_pressure(fa, oracle_mo
     np.testing.assert_array_equal(z_a, z_b)
     assert a.workspace_bytes() < ws_need(n)                # released by b's allocation
     del filler
+    torch.cuda.empty_cache()                               # hand the filler back to the driver: later tests allocate through hipMalloc
