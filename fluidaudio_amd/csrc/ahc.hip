@@ -945,11 +945,6 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         }
         return;
     }
-    if (blk == 0 && tid == 0) {  // clear the window counters of the next round
-        WinCounters *z = w.cnt + ((ph + 1) & 3);
-        z->stale_key = ~0ULL; z->ncand = 0; z->npairs = 0;
-    }
-
     Decision D;
     D.op = OP_NONE; D.a = D.b = D.na = D.nb = -1; D.dab = -1.0; D.lim = st.lim; D.halt = D.need_exact = D.error = D.done = 0;
     const WinCounters *cr = w.cnt + ((ph + 3) & 3);
@@ -1208,6 +1203,10 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     const bool live = nx != kDead && !in_flight;
     block_record(w, npar, blk, st.eps, live ? rs.d1 : dinf(), live && rs.nn < 0 ? rs.d1 : dinf(), pkey, pslot, pnd, x, nx, rs.nn, rs.nnnode, s_out);
     AHC_STAMP(4);
+    if (blk == 0 && tid == 0) {  // clear the window counters of the next round (here, in the tail: in front of the decision the store's round
+        WinCounters *z = w.cnt + ((ph + 1) & 3);   // trip sat on the critical path of workgroup 0 — the next wait for a load also waits for it)
+        z->stale_key = ~0ULL; z->ncand = 0; z->npairs = 0;
+    }
     if (kPrefetch > 0) {
 #pragma unroll
         for (int g = 0; g < kPfSlots; ++g) asm volatile("" ::"v"(pf_row[g]), "v"(pf_cen[g][0]), "v"(pf_cen[g][1]), "v"(pf_cen[g][2]), "v"(pf_cen[g][3]));
