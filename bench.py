@@ -429,6 +429,72 @@ def mel_single_leg(fa, ctx, calls=200):
             "note": "host-pointer entry fa_mel_batch incl. PCIe both ways and the Python ctypes call"}
 
 
+def vbx_sharded_leg(fa, ctx, torch, dist, rank, world, hours=64.0):
+    """the VBx iteration loop sharded over the frame axis (VBxClustering.swift:301-661): every rank holds 64 / world
+    slices of the frames, ONE all-gather (RCCL) of the 64 slice records per iteration.  Strong scaling on a fixed problem (default: the
+    embeddings of 64 h = 345 600 frames x 128, 24 speakers); rank 0 also runs the whole problem alone (fa_vbx_refine) and the ELBO
+    histories must be equal bit for bit — the sharded run computes the same slice records."""
+    from fluidaudio_amd.sharding import VbxShard, all_gather_records, vbx_refine_sharded, vbx_shard_frames
+    if 64 % world:
+        return {"skipped": f"world size {world} does not divide the 64 slices"}
+    T, D, K = int(hours * 5400), 128, 24
+    per = -(-T // 64)
+
+    def frames(z):                       # slice z of the problem, the same bytes on whichever rank generates it
+        rng = np.random.default_rng(1000 + z)
+        n = max(0, min((z + 1) * per, T) - z * per)
+        means = np.random.default_rng(999).standard_normal((K, D)) * 30.0 * 0.3
+        spk = rng.integers(0, K, n)
+        x = means[spk] + 30.0 * 0.1 * rng.standard_normal((n, D))
+        init = spk.copy()
+        flip = rng.random(n) < 0.1
+        init[flip] = rng.integers(0, K, int(flip.sum()))
+        return x, init.astype(np.int32)
+    phi = np.random.default_rng(998).uniform(0.5, 4.0, D)
+    lo, hi = vbx_shard_frames(T, rank, world)
+    zn = 64 // world
+    parts = [frames(z) for z in range(rank * zn, (rank + 1) * zn)]
+    x = np.concatenate([p[0] for p in parts]); init = np.concatenate([p[1] for p in parts])
+    assert x.shape[0] == hi - lo
+    shard = VbxShard(x, init, T, K, phi, rank, world, ctx=ctx)
+    gather = all_gather_records(dist) if dist is not None else (lambda c: c)
+    vbx_refine_sharded(shard, gather, 2, 0.0)            # warm-up (RCCL set-up, first launches)
+    shard.close()
+    shard = VbxShard(x, init, T, K, phi, rank, world, ctx=ctx)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, pi, hard, elbos = vbx_refine_sharded(shard, gather, 20, 1e-4)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    shard.close()
+    tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    same = torch.tensor([1.0], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        e = torch.tensor(elbos + [0.0] * (20 - len(elbos)), dtype=torch.float64, device="cuda")
+        emin, emax = e.clone(), e.clone()
+        dist.all_reduce(emin, op=dist.ReduceOp.MIN); dist.all_reduce(emax, op=dist.ReduceOp.MAX)
+        same[0] = float(bool((emin == emax).all()))
+    out = {"workload": f"VBx over {T} frames x {D}, {K} speakers, sharded over the frame axis on {world} GPU(s)", "world": world, "iterations": len(elbos),
+           "sharded_s": float(tt.item()), "all_ranks_same_elbos": bool(same.item() == 1.0), "scaling": "strong",
+           "all_gather_bytes_per_iteration": 64 * (K * (D + 1) + 1) * 8}
+    if rank == 0:
+        allp = [frames(z) for z in range(64)]
+        X = np.concatenate([p[0] for p in allp]); I = np.concatenate([p[1] for p in allp])
+        v = fa.VBxClustering(phi, ctx=ctx)
+        v.refine(X, I)
+        t0 = time.perf_counter()
+        one = v.refine(X, I)
+        out["single_device_s_incl_host_copies"] = time.perf_counter() - t0
+        out["elbos_equal_single_device"] = one.elbos == elbos
+        out["hard_labels_equal_single_device"] = bool(np.array_equal(np.asarray(one.hard_clusters[0][lo:hi], np.int32), hard))
+    return out
+
+
 def headline_leg(fa, ctx, torch, dist, rank, world, steps, warmup, hours=8.0):
     """The timed region of the bench: K x (mel over the recording's chunks + fa_offline_cluster on its embeddings), inputs resident."""
     from e2e_inputs import sha256 as sha
@@ -655,6 +721,7 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-e2e", action="store_true", help="skip the 16 x 1 h leg (the headline itself cannot be skipped)")
     ap.add_argument("--skip-beam", action="store_true")
+    ap.add_argument("--vbx-sharded", action="store_true", help="run the sharded-VBx leg at N = 1 too (it always runs at N > 1)")
     ap.add_argument("--only-mel", action="store_true", help="profiling helper: the configs[1] mel leg alone, printed as a reduced line")
     ap.add_argument("--ctc-matrices", type=int, default=10000)
     args = ap.parse_args()
@@ -726,6 +793,13 @@ def main():
         except Exception as e:  # noqa: BLE001
             r = {"error": repr(e)}
         line["ctc"] = r
+        torch.cuda.empty_cache()
+    if not solo or args.vbx_sharded:   # the one leg with a data-path collective (§8e row 4); at N = 1 only on request
+        try:
+            r = vbx_sharded_leg(fa, ctx, torch, dist, rank, world)
+        except Exception as e:  # noqa: BLE001
+            r = {"error": repr(e)}
+        line["vbx_sharded"] = r
         torch.cuda.empty_cache()
     if rank != 0:
         if dist is not None:

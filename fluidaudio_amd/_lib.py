@@ -39,6 +39,8 @@ EXPORTED_SYMBOLS = [
     "fa_tdt_map_duration_bin", "fa_tdt_clamp_probability", "fa_tdt_greedy_tables_dev", "fa_tdt_greedy_logits_dev",
     "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_linkage_batch", "fa_ahc_row_minima", "fa_ahc_cluster", "fa_ahc_cut",
     "fa_vbx_speaker_count", "fa_vbx_refine",
+    "fa_vbx_shard_slices", "fa_vbx_shard_range", "fa_vbx_shard_chunk_doubles", "fa_vbx_shard_create", "fa_vbx_shard_destroy",
+    "fa_vbx_shard_frames", "fa_vbx_shard_begin", "fa_vbx_shard_iterate", "fa_vbx_shard_finish_iteration", "fa_vbx_shard_result",
     "fa_vbx_weighted_centroids", "fa_assign_cosine", "fa_centroid_scores", "fa_constrained_assign",
     "fa_offline_cluster_default_config", "fa_offline_cluster", "fa_offline_cluster_ex", "fa_offline_cluster_batch",
     "fa_arpa_parse", "fa_arpa_destroy", "fa_arpa_unigram_count", "fa_arpa_bigram_context_count", "fa_arpa_score",
@@ -182,6 +184,21 @@ def lib() -> C.CDLL:
     L.fa_vbx_speaker_count.argtypes = [vp, i64]
     L.fa_vbx_speaker_count.restype = i32
     L.fa_vbx_refine.argtypes = [vp, vp, i64, i32, vp, vp, f64, f64, i32, f64, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
+    L.fa_vbx_shard_slices.argtypes = []
+    L.fa_vbx_shard_slices.restype = i32
+    L.fa_vbx_shard_range.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.fa_vbx_shard_range.restype = None
+    L.fa_vbx_shard_chunk_doubles.argtypes = [i32, i32, i32]
+    L.fa_vbx_shard_chunk_doubles.restype = i64
+    L.fa_vbx_shard_create.argtypes = [vp, vp, i64, i32, vp, i32, vp, f64, f64, i32, i32, C.POINTER(vp)]
+    L.fa_vbx_shard_destroy.argtypes = [vp]
+    L.fa_vbx_shard_destroy.restype = None
+    L.fa_vbx_shard_frames.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.fa_vbx_shard_frames.restype = None
+    L.fa_vbx_shard_begin.argtypes = [vp, vp]
+    L.fa_vbx_shard_iterate.argtypes = [vp, vp, vp]
+    L.fa_vbx_shard_finish_iteration.argtypes = [vp, vp, C.POINTER(f64)]
+    L.fa_vbx_shard_result.argtypes = [vp, vp, vp, vp]
     L.fa_vbx_weighted_centroids.argtypes = [vp, vp, i64, i32, vp, vp, i32, vp, vp, C.POINTER(i32)]
     L.fa_assign_cosine.argtypes = [vp, vp, i64, i32, vp, i32, vp]
     L.fa_centroid_scores.argtypes = [vp, vp, i64, i32, vp, i32, vp]

@@ -6,6 +6,13 @@
 // row soft-max are small and skinny (T ~ 4e4, D = 128, S = #AHC clusters); they are evaluated
 // here with deterministic reductions (fixed split of T, partials summed in a fixed order) so
 // that repeated runs are bit-identical.  fp64 throughout, like the reference (cblas_d*, vvexp).
+//
+// Everything that crosses frames goes through ONE record per slice of the frame axis (kSplit = 64 slices): the slice's
+// sum_t gamma[t][s] (rho[t][:], 1) and its sum of the per-frame log-likelihoods.  An iteration reads the 64 records in slice
+// order (speaker statistics, pi, ELBO) and writes the 64 records of the new posteriors — so the same kernels run the whole
+// problem on one device (vbx_run_dev) or a contiguous range of slices per device with one all-gather of the records per
+// iteration in between (fa_vbx_shard_*: SURVEY §8(e) row 4, the iteration loop of VBxClustering.swift:301-661 sharded over
+// T).  Both give the same bits: a shard computes exactly the records the single device computes for those slices.
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -25,14 +32,18 @@ struct VbxWs {
     double *gamma;     // [T][S]
     double *pi;        // [S]
     double *logpi;     // [S]
-    double *part;      // [kSplit][S][D+1]  (column D carries sum_t gamma)
+    const double *rec_in;  // [kSplit][stride] complete slice records: [S][D+1] (column D carries sum_t gamma), then the slice's sum of llrow
+    double *rec_out;       // [z_n][stride] records of the slices z_lo .. z_lo + z_n - 1 that this device owns
     double *alpha;     // [S][D]
     double *invL;      // [S][D]
     double *phiT;      // [S]
     double *llrow;     // [T]
     double *scal;      // [8]: 0 elbo, 1 ll
-    int64_t T;
+    int64_t T;         // frames held here: the global frames t0g .. t0g + T - 1
+    int64_t Tg, t0g;   // frames of the whole problem; global index of local frame 0
+    int64_t stride;    // doubles per slice record = S (D + 1) + 1
     int32_t D, S;
+    int32_t z_lo, z_n; // slices owned
     double Fa, Fb;
 };
 
@@ -89,19 +100,36 @@ __global__ void vbx_fill(double *p, int n, double v) {
     if (i < n) p[i] = v;
 }
 
-// part[z][s][0..D] = sum over the z-th slice of frames of gamma[t][s] * (rho[t][:], 1)   (:312-325, :342-357)
-// grid: (ceil((D+1)/64), ceil(S/4), kSplit), block 256 = 64 columns x 4 speakers.
-__global__ __launch_bounds__(kThreads) void vbx_gt_rho(VbxWs w, int first_col_tile) {
-    const int col = (blockIdx.x + first_col_tile) * 64 + (threadIdx.x & 63);
+// record[z][s][0..D] = sum over the z-th slice of frames of gamma[t][s] * (rho[t][:], 1)   (:312-325, :342-357)
+// grid: (ceil((D+1)/64), ceil(S/4), slices owned), block 256 = 64 columns x 4 speakers.
+__global__ __launch_bounds__(kThreads) void vbx_gt_rho(VbxWs w) {
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int s = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int z = blockIdx.z;
-    const int64_t per = (w.T + kSplit - 1) / kSplit;
-    const int64_t t0 = z * per, t1 = t0 + per < w.T ? t0 + per : w.T;
+    const int z = w.z_lo + blockIdx.z;
+    const int64_t per = (w.Tg + kSplit - 1) / kSplit;
+    int64_t t0 = z * per, t1 = t0 + per < w.Tg ? t0 + per : w.Tg;   // global frames of the slice ...
+    t0 -= w.t0g; t1 -= w.t0g;                                       // ... as local rows
     if (s >= w.S || col > w.D) return;
     double acc = 0.0;
     if (col < w.D) for (int64_t t = t0; t < t1; ++t) acc += w.gamma[t * w.S + s] * w.rho[t * w.D + col];
     else for (int64_t t = t0; t < t1; ++t) acc += w.gamma[t * w.S + s];
-    w.part[(static_cast<int64_t>(z) * w.S + s) * (w.D + 1) + col] = acc;
+    w.rec_out[blockIdx.z * w.stride + static_cast<int64_t>(s) * (w.D + 1) + col] = acc;
+}
+
+// last double of a slice record: the sum of the per-frame log-likelihoods of the slice (:623-630), fixed order.  One workgroup per slice.
+__global__ __launch_bounds__(kThreads) void vbx_llpart(VbxWs w) {
+    __shared__ double red[kThreads];
+    const int tid = threadIdx.x;
+    const int z = w.z_lo + blockIdx.x;
+    const int64_t per = (w.Tg + kSplit - 1) / kSplit;
+    int64_t t0 = z * per, t1 = t0 + per < w.Tg ? t0 + per : w.Tg;
+    t0 -= w.t0g; t1 -= w.t0g;
+    double a = 0.0;
+    for (int64_t t = t0 + tid; t < t1; t += kThreads) a += w.llrow[t];
+    red[tid] = a;
+    __syncthreads();
+    for (int off = kThreads / 2; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
+    if (tid == 0) w.rec_out[blockIdx.x * w.stride + w.stride - 1] = red[0];
 }
 
 // Per speaker: N_s, invL, alpha, phi term (:330-337, :370-387, :402-432).  One workgroup per speaker.
@@ -113,18 +141,18 @@ __global__ __launch_bounds__(kThreads) void vbx_speaker(VbxWs w, int mode) {
     if (mode == 1) {
         if (tid == 0) {
             double ns = 0.0;
-            for (int z = 0; z < kSplit; ++z) ns += w.part[(static_cast<int64_t>(z) * w.S + s) * (D + 1) + D];
+            for (int z = 0; z < kSplit; ++z) ns += w.rec_in[z * w.stride + static_cast<int64_t>(s) * (D + 1) + D];
             w.pi[s] = ns;
         }
         return;
     }
     double ns = 0.0;
-    for (int z = 0; z < kSplit; ++z) ns += w.part[(static_cast<int64_t>(z) * w.S + s) * (D + 1) + D];
+    for (int z = 0; z < kSplit; ++z) ns += w.rec_in[z * w.stride + static_cast<int64_t>(s) * (D + 1) + D];
     const double weight = (w.Fa / w.Fb) * ns;
     double acc = 0.0;
     for (int d = tid; d < D; d += kThreads) {
         double tmp = 0.0;
-        for (int z = 0; z < kSplit; ++z) tmp += w.part[(static_cast<int64_t>(z) * w.S + s) * (D + 1) + d];
+        for (int z = 0; z < kSplit; ++z) tmp += w.rec_in[z * w.stride + static_cast<int64_t>(s) * (D + 1) + d];
         const double den = 1.0 + weight * w.phi[d];
         const double il = 1.0 / (den > 1e-12 ? den : 1e-12);
         const double al = (tmp * il) * (w.Fa / w.Fb);
@@ -180,18 +208,13 @@ __global__ __launch_bounds__(kThreads) void vbx_estep(VbxWs w) {
     }
 }
 
-// Scalars of one iteration: normalise pi (:605-621), log-likelihood (sum of llrow in frame order) and
+// Scalars of one iteration: normalise pi (:605-621), log-likelihood (the slice sums in slice order) and
 // ELBO = ll + Fb/2 * sum(log invL - invL - alpha^2 + 1) (:623-647).  One workgroup, fixed order.
 __global__ __launch_bounds__(kThreads) void vbx_scalars(VbxWs w) {
     __shared__ double red[kThreads];
     const int tid = threadIdx.x;
-    double a = 0.0;
-    for (int64_t t = tid; t < w.T; t += kThreads) a += w.llrow[t];
-    red[tid] = a;
-    __syncthreads();
-    for (int off = kThreads / 2; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
-    const double ll = red[0];
-    __syncthreads();
+    double ll = 0.0;
+    for (int z = 0; z < kSplit; ++z) ll += w.rec_in[z * w.stride + w.stride - 1];
     double b = 0.0;
     const int64_t n = static_cast<int64_t>(w.S) * w.D;
     for (int64_t i = tid; i < n; i += kThreads) { const double il = w.invL[i], al = w.alpha[i]; b += log(il) - il - al * al + 1.0; }
@@ -268,60 +291,232 @@ fa_status fa_vbx_refine(fa_ctx *ctx, const double *rho, int64_t T, int32_t D, co
 
 }  // extern "C"
 
+// ---- host side -------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// buffers + kernel arguments for the frames [t0g, t0g + T) of a problem of Tg frames; the device owns the slices z_lo .. z_lo + z_n - 1
+fa_status vbx_setup(fa_ctx *ctx, const double *d_X, int64_t T, int64_t Tg, int64_t t0g, int32_t D, const int32_t *d_labels, int32_t S, const double *phi_host,
+                    double Fa, double Fb, int32_t z_lo, int32_t z_n, fa::VbxDevice &o, VbxWs &w) {
+    std::vector<double> phic(D);
+    for (int d = 0; d < D; ++d) phic[d] = phi_host[d] > 1e-12 ? phi_host[d] : 1e-12;  // :241
+    const size_t Tn = static_cast<size_t>(T > 0 ? T : 1);
+    const size_t TD = Tn * D, TS = Tn * S, SD = static_cast<size_t>(S) * D;
+    const int64_t stride = static_cast<int64_t>(S) * (D + 1) + 1;
+    hipError_t e = hipSuccess;
+    auto A = [&](fa::DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.alloc(bytes); };
+    A(o.phi, 8 * D); A(o.rho, 8 * TD); A(o.G, 8 * Tn); A(o.gamma, 8 * TS); A(o.pi, 8 * S); A(o.logpi, 8 * S);
+    A(o.part, 8 * static_cast<size_t>(kSplit) * stride); A(o.alpha, 8 * SD); A(o.invL, 8 * SD); A(o.phiT, 8 * S);
+    A(o.ll, 8 * Tn); A(o.scal, 64); A(o.hard, 4 * Tn);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "vbx: device allocation failed"); }
+    o.T = T; o.D = D; o.S = S;
+    hipStream_t st = ctx->stream;
+    FA_HIP_TRY(ctx, hipMemcpyAsync(o.phi.p, phic.data(), 8 * D, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemsetAsync(o.ll.p, 0, 8 * Tn, st));   // the records written before the first E-step carry a zero log-likelihood
+    w = VbxWs{};
+    w.X = d_X; w.phi = o.phi.as<double>(); w.rho = o.rho.as<double>(); w.G = o.G.as<double>();
+    w.gamma = o.gamma.as<double>(); w.pi = o.pi.as<double>(); w.logpi = o.logpi.as<double>();
+    w.rec_in = o.part.as<double>(); w.rec_out = o.part.as<double>() + static_cast<int64_t>(z_lo) * stride;
+    w.alpha = o.alpha.as<double>(); w.invL = o.invL.as<double>(); w.phiT = o.phiT.as<double>(); w.llrow = o.ll.as<double>();
+    w.scal = o.scal.as<double>(); w.T = T; w.Tg = Tg; w.t0g = t0g; w.stride = stride; w.D = D; w.S = S; w.z_lo = z_lo; w.z_n = z_n; w.Fa = Fa; w.Fb = Fb;
+    if (static_cast<size_t>(8) * 4 * D > 64 * 1024) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "vbx: feature dimension too large");
+    if (T > 0) {
+        const int wave_blocks = static_cast<int>((T + 3) / 4);
+        hipLaunchKernelGGL(vbx_prepare, dim3(wave_blocks), dim3(kThreads), 0, st, w);
+        hipLaunchKernelGGL(vbx_init_gamma, dim3(wave_blocks), dim3(kThreads), 0, st, w, d_labels, 7.0);
+    }
+    hipLaunchKernelGGL(vbx_fill, dim3((S + 255) / 256), dim3(256), 0, st, w.pi, S, 1.0 / static_cast<double>(S));  // :239
+    FA_HIP_TRY(ctx, hipGetLastError());
+    FA_HIP_TRY(ctx, hipStreamSynchronize(st));   // phic (a host temporary) has been consumed
+    return FA_SUCCESS;
+}
+
+// the records of the owned slices from the present posteriors (and the present per-frame log-likelihoods)
+fa_status vbx_records(fa_ctx *ctx, const VbxWs &w) {
+    if (w.z_n <= 0) return FA_SUCCESS;
+    hipLaunchKernelGGL(vbx_gt_rho, dim3((w.D + 1 + 63) / 64, (w.S + 3) / 4, w.z_n), dim3(kThreads), 0, ctx->stream, w);
+    hipLaunchKernelGGL(vbx_llpart, dim3(w.z_n), dim3(kThreads), 0, ctx->stream, w);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+// speaker statistics from the complete records, then the E-step of the frames held here (:330-572)
+fa_status vbx_estep_phase(fa_ctx *ctx, const VbxWs &w) {
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(vbx_speaker, dim3(w.S), dim3(kThreads), 0, st, w, 0);
+    hipLaunchKernelGGL(vbx_logpi, dim3((w.S + 255) / 256), dim3(256), 0, st, w);
+    if (w.T > 0) hipLaunchKernelGGL(vbx_estep, dim3(static_cast<int>((w.T + 3) / 4)), dim3(kThreads), sizeof(double) * 4 * static_cast<size_t>(w.D), st, w);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+// pi of the new posteriors (column D of the complete records, :586-621) and the ELBO (:623-647)
+fa_status vbx_finish_phase(fa_ctx *ctx, const VbxWs &w, double *elbo) {
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(vbx_speaker, dim3(w.S), dim3(kThreads), 0, st, w, 1);
+    hipLaunchKernelGGL(vbx_scalars, dim3(1), dim3(kThreads), 0, st, w);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    FA_HIP_TRY(ctx, hipMemcpyAsync(elbo, w.scal, sizeof(double), hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return FA_SUCCESS;
+}
+fa_status vbx_hard_phase(fa_ctx *ctx, const VbxWs &w, int32_t *d_hard) {
+    if (w.T > 0) hipLaunchKernelGGL(vbx_hard, dim3(static_cast<int>((w.T + 255) / 256)), dim3(256), 0, ctx->stream, w, d_hard);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+
+}  // namespace
+
 // The EM loop on device-resident inputs (d_X: [T][D] rho features, d_labels: [T] AHC labels with S distinct values); gamma, pi and
 // the hard assignment stay on the device in `out`.  The ELBO of every iteration crosses to the host (8 bytes) for the
 // convergence test of the reference (:653-659).
 fa_status fa::vbx_run_dev(fa_ctx *ctx, const double *d_X, int64_t T, int32_t D, const int32_t *d_labels, int32_t S, const double *phi_host,
                           double Fa, double Fb, int32_t max_iter, double epsilon, double *elbos, int32_t *n_iters, fa::VbxDevice &o) {
     if (n_iters) *n_iters = 0;
-    std::vector<double> phic(D);
-    for (int d = 0; d < D; ++d) phic[d] = phi_host[d] > 1e-12 ? phi_host[d] : 1e-12;  // :241
-    const size_t TD = static_cast<size_t>(T) * D, TS = static_cast<size_t>(T) * S, SD = static_cast<size_t>(S) * D;
-    hipError_t e = hipSuccess;
-    auto A = [&](fa::DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.alloc(bytes); };
-    A(o.phi, 8 * D); A(o.rho, 8 * TD); A(o.G, 8 * T); A(o.gamma, 8 * TS); A(o.pi, 8 * S); A(o.logpi, 8 * S);
-    A(o.part, 8 * static_cast<size_t>(kSplit) * S * (D + 1)); A(o.alpha, 8 * SD); A(o.invL, 8 * SD); A(o.phiT, 8 * S);
-    A(o.ll, 8 * T); A(o.scal, 64); A(o.hard, 4 * T);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "vbx: device allocation failed"); }
-    o.T = T; o.D = D; o.S = S;
-    hipStream_t st = ctx->stream;
-    FA_HIP_TRY(ctx, hipMemcpyAsync(o.phi.p, phic.data(), 8 * D, hipMemcpyHostToDevice, st));
-    VbxWs w{};
-    w.X = d_X; w.phi = o.phi.as<double>(); w.rho = o.rho.as<double>(); w.G = o.G.as<double>();
-    w.gamma = o.gamma.as<double>(); w.pi = o.pi.as<double>(); w.logpi = o.logpi.as<double>(); w.part = o.part.as<double>();
-    w.alpha = o.alpha.as<double>(); w.invL = o.invL.as<double>(); w.phiT = o.phiT.as<double>(); w.llrow = o.ll.as<double>();
-    w.scal = o.scal.as<double>(); w.T = T; w.D = D; w.S = S; w.Fa = Fa; w.Fb = Fb;
-    const int wave_blocks = static_cast<int>((T + 3) / 4);
-    hipLaunchKernelGGL(vbx_prepare, dim3(wave_blocks), dim3(kThreads), 0, st, w);
-    hipLaunchKernelGGL(vbx_init_gamma, dim3(wave_blocks), dim3(kThreads), 0, st, w, d_labels, 7.0);
-    hipLaunchKernelGGL(vbx_fill, dim3((S + 255) / 256), dim3(256), 0, st, w.pi, S, 1.0 / static_cast<double>(S));  // :239
-    FA_HIP_TRY(ctx, hipGetLastError());
-    FA_HIP_TRY(ctx, hipStreamSynchronize(st));   // phic (a host temporary) has been consumed
-    const dim3 ggrid((D + 1 + 63) / 64, (S + 3) / 4, kSplit);
-    const size_t estep_lds = sizeof(double) * 4 * static_cast<size_t>(D);
-    if (estep_lds > 64 * 1024) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "vbx: feature dimension too large");
+    VbxWs w;
+    FA_TRY(vbx_setup(ctx, d_X, T, T, 0, D, d_labels, S, phi_host, Fa, Fb, 0, kSplit, o, w));
+    FA_TRY(vbx_records(ctx, w));
     double prev = -1.7976931348623157e308;
     int iters = 0;
     for (int it = 0; it < max_iter; ++it) {
         iters = it + 1;
-        hipLaunchKernelGGL(vbx_gt_rho, ggrid, dim3(kThreads), 0, st, w, 0);
-        hipLaunchKernelGGL(vbx_speaker, dim3(S), dim3(kThreads), 0, st, w, 0);
-        hipLaunchKernelGGL(vbx_logpi, dim3((S + 255) / 256), dim3(256), 0, st, w);
-        hipLaunchKernelGGL(vbx_estep, dim3(wave_blocks), dim3(kThreads), estep_lds, st, w);
-        // only the column tile that holds column D of the partials: sum_t gamma of the NEW gamma (pi, :586-603)
-        hipLaunchKernelGGL(vbx_gt_rho, dim3(1, ggrid.y, kSplit), dim3(kThreads), 0, st, w, D / 64);
-        hipLaunchKernelGGL(vbx_speaker, dim3(S), dim3(kThreads), 0, st, w, 1);
-        hipLaunchKernelGGL(vbx_scalars, dim3(1), dim3(kThreads), 0, st, w);
-        FA_HIP_TRY(ctx, hipGetLastError());
+        FA_TRY(vbx_estep_phase(ctx, w));
+        FA_TRY(vbx_records(ctx, w));      // of the NEW posteriors: pi and the log-likelihood of this iteration, the statistics of the next
         double elbo = 0.0;
-        FA_HIP_TRY(ctx, hipMemcpyAsync(&elbo, w.scal, sizeof(double), hipMemcpyDeviceToHost, st));
-        FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+        FA_TRY(vbx_finish_phase(ctx, w, &elbo));
         if (elbos) elbos[it] = elbo;
         if (it > 0 && std::fabs(elbo - prev) < epsilon) { prev = elbo; break; }  // :653-659
         prev = elbo;
     }
-    hipLaunchKernelGGL(vbx_hard, dim3(static_cast<int>((T + 255) / 256)), dim3(256), 0, st, w, o.hard.as<int32_t>());
-    FA_HIP_TRY(ctx, hipGetLastError());
+    FA_TRY(vbx_hard_phase(ctx, w, o.hard.as<int32_t>()));
     if (n_iters) *n_iters = iters;
     return FA_SUCCESS;
 }
+
+// ---- sharded over the frame axis -------------------------------------------------------------------------------
+// One fa_vbx_shard per device holds a contiguous range of the 64 slices (world sizes that divide 64).  The caller moves the records:
+//   begin(chunk) -> all-gather chunks -> repeat { iterate(full, chunk) -> all-gather -> finish_iteration(full, &elbo) } -> result.
+// Every device evaluates the speaker statistics, pi and the ELBO from the same complete records, so all of them take the same
+// convergence decision without a broadcast; the only collective is the all-gather of 64 (S (D + 1) + 1) doubles per iteration.
+struct fa_vbx_shard {
+    fa_ctx *ctx = nullptr;
+    fa::VbxDevice dev;
+    fa::DevBuf X, labels;
+    VbxWs w{};
+    int32_t rank = 0, world = 1;
+    int64_t t_lo = 0, t_hi = 0;
+};
+
+extern "C" {
+
+int32_t fa_vbx_shard_slices(void) { return kSplit; }
+
+void fa_vbx_shard_range(int64_t T_total, int32_t rank, int32_t world, int64_t *t_lo, int64_t *t_hi) {
+    int64_t lo = 0, hi = 0;
+    if (T_total > 0 && world > 0 && kSplit % world == 0 && rank >= 0 && rank < world) {
+        const int64_t per = (T_total + kSplit - 1) / kSplit, zn = kSplit / world;
+        lo = rank * zn * per; hi = (rank + 1) * zn * per;
+        lo = lo < T_total ? lo : T_total; hi = hi < T_total ? hi : T_total;
+    }
+    if (t_lo) *t_lo = lo;
+    if (t_hi) *t_hi = hi;
+}
+
+int64_t fa_vbx_shard_chunk_doubles(int32_t S, int32_t D, int32_t world) {
+    if (S < 1 || D < 1 || world < 1 || kSplit % world != 0) return 0;
+    return (kSplit / world) * (static_cast<int64_t>(S) * (D + 1) + 1);
+}
+
+fa_status fa_vbx_shard_create(fa_ctx *ctx, const double *rho_local, int64_t T_total, int32_t D, const int32_t *labels_local, int32_t S,
+                              const double *phi, double Fa, double Fb, int32_t rank, int32_t world, fa_vbx_shard **out) {
+    if (!ctx || !out) return FA_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (T_total <= 0 || D <= 0 || S < 1 || !phi || world < 1 || kSplit % world != 0 || rank < 0 || rank >= world)
+        return fa::set_error(ctx, FA_INVALID_ARGUMENT, "vbx shard: bad shape (the world size must divide 64)");
+    fa::DeviceGuard guard(ctx->device);
+    try {
+        fa_vbx_shard *h = new fa_vbx_shard;
+        h->ctx = ctx; h->rank = rank; h->world = world;
+        fa_vbx_shard_range(T_total, rank, world, &h->t_lo, &h->t_hi);
+        const int64_t T = h->t_hi - h->t_lo;
+        if (T > 0 && (!rho_local || !labels_local)) { delete h; return FA_INVALID_ARGUMENT; }
+        const size_t Tn = static_cast<size_t>(T > 0 ? T : 1);
+        if (h->X.alloc(8 * Tn * D) != hipSuccess || h->labels.alloc(4 * Tn) != hipSuccess) {
+            (void)hipGetLastError(); delete h;
+            return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "vbx shard: device allocation failed");
+        }
+        fa_status st = FA_SUCCESS;
+        if (T > 0) {
+            hipError_t e = hipMemcpyAsync(h->X.p, rho_local, 8 * static_cast<size_t>(T) * D, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(h->labels.p, labels_local, 4 * static_cast<size_t>(T), hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) st = fa::hip_status(ctx, e, "vbx shard upload");
+        }
+        const int32_t zn = kSplit / world;
+        if (st == FA_SUCCESS) st = vbx_setup(ctx, h->X.as<double>(), T, T_total, h->t_lo, D, h->labels.as<int32_t>(), S, phi, Fa, Fb, rank * zn, zn, h->dev, h->w);
+        if (st != FA_SUCCESS) { delete h; return st; }
+        *out = h;
+        return FA_SUCCESS;
+    } catch (const std::bad_alloc &) {
+        return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "vbx shard: host allocation failed");
+    } catch (...) {
+        return fa::set_error(ctx, FA_UNKNOWN_ERROR, "vbx shard: unexpected failure");
+    }
+}
+
+void fa_vbx_shard_destroy(fa_vbx_shard *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    delete h;
+}
+
+void fa_vbx_shard_frames(const fa_vbx_shard *h, int64_t *t_lo, int64_t *t_hi) {
+    if (t_lo) *t_lo = h ? h->t_lo : 0;
+    if (t_hi) *t_hi = h ? h->t_hi : 0;
+}
+
+// d_chunk: DEVICE double[fa_vbx_shard_chunk_doubles]: the records of the slices held here, from the initial posteriors.  Complete on return.
+fa_status fa_vbx_shard_begin(fa_vbx_shard *h, double *d_chunk) {
+    if (!h || !d_chunk) return FA_INVALID_ARGUMENT;
+    fa::DeviceGuard guard(h->ctx->device);
+    VbxWs w = h->w;
+    w.rec_out = d_chunk;
+    FA_TRY(vbx_records(h->ctx, w));
+    FA_HIP_TRY(h->ctx, hipStreamSynchronize(h->ctx->stream));
+    return FA_SUCCESS;
+}
+
+// d_full: DEVICE double[64 x record]: the gathered records of the present posteriors; d_chunk: the records of the new ones.  Complete on return.
+fa_status fa_vbx_shard_iterate(fa_vbx_shard *h, const double *d_full, double *d_chunk) {
+    if (!h || !d_full || !d_chunk) return FA_INVALID_ARGUMENT;
+    fa::DeviceGuard guard(h->ctx->device);
+    VbxWs w = h->w;
+    w.rec_in = d_full; w.rec_out = d_chunk;
+    FA_TRY(vbx_estep_phase(h->ctx, w));
+    FA_TRY(vbx_records(h->ctx, w));
+    FA_HIP_TRY(h->ctx, hipStreamSynchronize(h->ctx->stream));
+    return FA_SUCCESS;
+}
+
+// d_full: the gathered records of the posteriors fa_vbx_shard_iterate just wrote; *elbo: the ELBO of the iteration (:623-647)
+fa_status fa_vbx_shard_finish_iteration(fa_vbx_shard *h, const double *d_full, double *elbo) {
+    if (!h || !d_full || !elbo) return FA_INVALID_ARGUMENT;
+    fa::DeviceGuard guard(h->ctx->device);
+    VbxWs w = h->w;
+    w.rec_in = d_full;
+    return vbx_finish_phase(h->ctx, w, elbo);
+}
+
+// HOST outputs: gamma_local [frames held][S], pi [S], hard_local [frames held] (each may be NULL)
+fa_status fa_vbx_shard_result(fa_vbx_shard *h, double *gamma_local, double *pi, int32_t *hard_local) {
+    if (!h) return FA_INVALID_ARGUMENT;
+    fa_ctx *ctx = h->ctx;
+    fa::DeviceGuard guard(ctx->device);
+    const int64_t T = h->t_hi - h->t_lo;
+    FA_TRY(vbx_hard_phase(ctx, h->w, h->dev.hard.as<int32_t>()));
+    if (gamma_local && T > 0) FA_HIP_TRY(ctx, hipMemcpyAsync(gamma_local, h->dev.gamma.p, 8 * static_cast<size_t>(T) * h->w.S, hipMemcpyDeviceToHost, ctx->stream));
+    if (pi) FA_HIP_TRY(ctx, hipMemcpyAsync(pi, h->dev.pi.p, 8 * static_cast<size_t>(h->w.S), hipMemcpyDeviceToHost, ctx->stream));
+    if (hard_local && T > 0) FA_HIP_TRY(ctx, hipMemcpyAsync(hard_local, h->dev.hard.p, 4 * static_cast<size_t>(T), hipMemcpyDeviceToHost, ctx->stream));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FA_SUCCESS;
+}
+
+}  // extern "C"

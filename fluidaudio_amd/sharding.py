@@ -125,3 +125,107 @@ def row_minima_numpy(x_all, lo: int, hi: int):
         j = int(np.argmin(dist))                                 # first minimum = lowest index
         mins[i - lo], args[i - lo] = dist[j], j
     return mins, args
+
+
+# ---- VBx sharded over the frame axis (reference loop: VBxClustering.swift:301-661) ------------------------------
+VBX_SLICES = 64   # == fa_vbx_shard_slices(): everything that crosses frames is one record per slice
+
+
+def vbx_shard_frames(T_total: int, rank: int, world_size: int) -> tuple[int, int]:
+    """Frames [lo, hi) a rank holds (== fa_vbx_shard_range): 64 / world consecutive slices of ceil(T / 64) frames."""
+    if world_size < 1 or VBX_SLICES % world_size or not (0 <= rank < world_size):
+        raise ValueError("the world size must divide 64")
+    per = -(-T_total // VBX_SLICES)
+    zn = VBX_SLICES // world_size
+    return min(rank * zn * per, T_total), min((rank + 1) * zn * per, T_total)
+
+
+class VbxShard:
+    """One rank's part of a sharded VBx run on its GPU (fa_vbx_shard_* of the C ABI).  `rho_local` / `labels_local` are the frames
+    vbx_shard_frames() names, `n_speakers` the number of distinct labels of the WHOLE problem.  Records travel as torch CUDA tensors
+    (the collective library moves them); begin() / iterate() return this rank's chunk, finish() the ELBO of the iteration."""
+
+    def __init__(self, rho_local, labels_local, T_total: int, n_speakers: int, phi, rank: int, world_size: int,
+                 warm_start_fa: float = 0.07, warm_start_fb: float = 0.8, ctx=None):
+        import ctypes as C
+        import torch
+        from . import _lib as L
+        self._L, self._C, self._torch = L, C, torch
+        self.ctx = ctx or L.default_context()
+        rho = np.ascontiguousarray(rho_local, np.float64)
+        lab = np.ascontiguousarray(labels_local, np.int32)
+        lo, hi = vbx_shard_frames(T_total, rank, world_size)
+        D = rho.shape[1]
+        if rho.shape[0] != hi - lo or lab.size != hi - lo:
+            raise ValueError(f"rank {rank} of {world_size} holds the frames [{lo}, {hi}) of {T_total}")
+        phi = np.ascontiguousarray(phi, np.float64)
+        if phi.size != D:
+            phi = np.ones(D)                                   # dimension mismatch -> identity (:72-76)
+        self.frames, self.S, self.D, self.world = (lo, hi), int(n_speakers), D, world_size
+        h = C.c_void_p()
+        self.ctx.check(L.lib().fa_vbx_shard_create(self.ctx.handle, rho.ctypes.data, T_total, D, lab.ctypes.data, self.S, phi.ctypes.data,
+                                                   warm_start_fa, warm_start_fb, rank, world_size, C.byref(h)), "fa_vbx_shard_create")
+        self._h = h
+        dev = torch.device("cuda", self.ctx.device)
+        self._chunk = torch.empty(L.lib().fa_vbx_shard_chunk_doubles(self.S, D, world_size), dtype=torch.float64, device=dev)
+
+    def begin(self):
+        self.ctx.check(self._L.lib().fa_vbx_shard_begin(self._h, self._chunk.data_ptr()), "fa_vbx_shard_begin")
+        return self._chunk
+
+    def iterate(self, full):
+        assert full.is_cuda and full.dtype == self._torch.float64 and full.numel() == self._chunk.numel() * self.world
+        self._torch.cuda.current_stream(full.device).synchronize()   # the gather ran on torch's stream, the kernels run on the context's
+        self.ctx.check(self._L.lib().fa_vbx_shard_iterate(self._h, full.data_ptr(), self._chunk.data_ptr()), "fa_vbx_shard_iterate")
+        return self._chunk
+
+    def finish(self, full) -> float:
+        self._torch.cuda.current_stream(full.device).synchronize()
+        e = self._C.c_double()
+        self.ctx.check(self._L.lib().fa_vbx_shard_finish_iteration(self._h, full.data_ptr(), self._C.byref(e)), "fa_vbx_shard_finish_iteration")
+        return e.value
+
+    def result(self):
+        n = self.frames[1] - self.frames[0]
+        gamma, pi, hard = np.zeros((n, self.S)), np.zeros(self.S), np.zeros(n, np.int32)
+        self.ctx.check(self._L.lib().fa_vbx_shard_result(self._h, gamma.ctypes.data, pi.ctypes.data, hard.ctypes.data), "fa_vbx_shard_result")
+        return gamma, pi, hard
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lib().fa_vbx_shard_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def all_gather_records(dist=None):
+    """gather(chunk) -> the chunks of all ranks in rank order, as one tensor (torch.distributed: "nccl" = RCCL on the GPU box)."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist  # noqa: F811
+
+    def gather(chunk):
+        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+            return chunk
+        parts = [torch.empty_like(chunk) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, chunk)
+        return torch.cat(parts)
+    return gather
+
+
+def vbx_refine_sharded(shard, gather, max_iterations: int = 20, convergence_tolerance: float = 1e-4):
+    """The iteration loop of VBxClustering.runVBx (:301-661) over a sharded frame axis: ONE all-gather of the slice records per
+    iteration; every rank evaluates the ELBO from the same records and stops in the same iteration (:653-659).
+    `shard`: begin() / iterate(full) / finish(full) / result() (VbxShard on a GPU); returns (gamma_local, pi, hard_local, elbos)."""
+    full = gather(shard.begin())
+    prev, elbos = -np.inf, []
+    for it in range(max_iterations):
+        full = gather(shard.iterate(full))
+        elbo = shard.finish(full)
+        elbos.append(elbo)
+        if it > 0 and abs(elbo - prev) < convergence_tolerance:
+            break
+        prev = elbo
+    gamma, pi, hard = shard.result()
+    return gamma, pi, hard, elbos

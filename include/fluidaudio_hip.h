@@ -307,6 +307,32 @@ fa_status fa_vbx_refine(fa_ctx *ctx, const double *rho, int64_t T, int32_t D, co
                         double *gamma, double *pi, int32_t *hard, double *elbos, int32_t *n_iters,
                         int32_t *n_speakers);
 
+/* The same iteration loop (VBxClustering.swift:301-661) sharded over the frame axis, one fa_vbx_shard per device.
+ * Everything that crosses frames is one record per slice of the frame axis (fa_vbx_shard_slices() = 64 slices of ceil(T / 64) frames:
+ * [S][D + 1] doubles = sum_t gamma[t][s] (rho[t][:], 1), then the slice's sum of the per-frame log-likelihoods); a device holds
+ * 64 / world consecutive slices = the frames fa_vbx_shard_range() names (world must divide 64).  Protocol, identical on every rank:
+ *     begin(chunk)  ->  all-gather the chunks in rank order into `full`
+ *     repeat up to max_iter times { iterate(full, chunk) -> all-gather -> finish_iteration(full, &elbo); stop when |elbo - previous| < epsilon (:653-659) }
+ *     result(...)
+ * Every rank evaluates speaker statistics, pi and the ELBO from the same gathered records: same decisions everywhere, no other
+ * collective.  The records of a slice are computed exactly as fa_vbx_refine computes them on one device, so the sharded run equals
+ * fa_vbx_refine bit for bit at every world size.  rho_local / labels_local: HOST, the frames of fa_vbx_shard_range(); phi HOST [D];
+ * chunk / full: DEVICE double[fa_vbx_shard_chunk_doubles(S, D, world)] / [... (S, D, 1)] (the caller's collective library moves them;
+ * both calls that write a chunk return with it complete); S = number of distinct labels of the WHOLE problem. */
+typedef struct fa_vbx_shard fa_vbx_shard;
+int32_t fa_vbx_shard_slices(void);
+void fa_vbx_shard_range(int64_t T_total, int32_t rank, int32_t world, int64_t *t_lo, int64_t *t_hi);
+int64_t fa_vbx_shard_chunk_doubles(int32_t S, int32_t D, int32_t world);
+fa_status fa_vbx_shard_create(fa_ctx *ctx, const double *rho_local, int64_t T_total, int32_t D, const int32_t *labels_local, int32_t S,
+                              const double *phi, double Fa, double Fb, int32_t rank, int32_t world, fa_vbx_shard **out);
+void fa_vbx_shard_destroy(fa_vbx_shard *shard);
+void fa_vbx_shard_frames(const fa_vbx_shard *shard, int64_t *t_lo, int64_t *t_hi);
+fa_status fa_vbx_shard_begin(fa_vbx_shard *shard, double *d_chunk);
+fa_status fa_vbx_shard_iterate(fa_vbx_shard *shard, const double *d_full, double *d_chunk);
+fa_status fa_vbx_shard_finish_iteration(fa_vbx_shard *shard, const double *d_full, double *elbo);
+/* HOST outputs (each may be NULL): gamma_local double[frames held * S], pi double[S], hard_local int32[frames held]. */
+fa_status fa_vbx_shard_result(fa_vbx_shard *shard, double *gamma_local, double *pi, int32_t *hard_local);
+
 /* ------------------------------------------------------------------ post-VBx -------- */
 /* OfflineDiarizerManager.computeCentroids (FluidAudio/Diarizer/Offline/Core/OfflineDiarizerManager.swift:613-691) and
  * assignEmbeddings (:789-822).  HOST pointers, fp64.

@@ -35,3 +35,50 @@ def test_vbx_edge_cases(fa, gpu_ctx, oracle_mod):
     a = fa.VBxClustering(phi, ctx=gpu_ctx).refine(x, init)
     b = fa.VBxClustering(phi, ctx=gpu_ctx).refine(x, init)
     assert np.array_equal(a.gamma, b.gamma) and a.elbos == b.elbos
+
+
+@pytest.mark.parametrize("T,D,K,seed,world", [(2500, 128, 7, 1, 2), (2500, 128, 7, 1, 8), (1000, 128, 70, 3, 4), (50, 16, 3, 4, 8), (43200, 128, 12, 6, 8)])
+def test_vbx_sharded_over_frames_equals_single_device_bit_for_bit(fa, gpu_ctx, oracle_mod, T, D, K, seed, world):
+    """SURVEY §8(e) row 4 (VBxClustering.swift:301-661 sharded over T): `world` shards of 64 / world slices each — here all on one GPU,
+    the all-gather being a torch.cat — reproduce fa_vbx_refine bit for bit: gamma, pi, hard labels, every ELBO, the iteration count.
+    (T = 50 < 64 slices: most shards hold no frame at all.)  The N > 1 transport (torch.distributed all_gather) is covered by the gloo test."""
+    import torch
+    from fluidaudio_amd.sharding import VbxShard, vbx_refine_sharded, vbx_shard_frames
+    x, init, phi = make_problem(T, D, K, seed)
+    one = fa.VBxClustering(phi, ctx=gpu_ctx).refine(x, init)
+    S = one.num_clusters
+    shards = []
+    for r in range(world):
+        lo, hi = vbx_shard_frames(T, r, world)
+        shards.append(VbxShard(x[lo:hi], init[lo:hi], T, S, phi, r, world, ctx=gpu_ctx))
+
+    class Lockstep:     # all ranks of the job in one process: every call runs on each shard, the "collective" is a concatenation
+        def begin(self): return [s.begin().clone() for s in shards]
+        def iterate(self, full): return [s.iterate(full).clone() for s in shards]
+        def finish(self, full):
+            e = [s.finish(full) for s in shards]
+            assert all(v == e[0] for v in e)        # every rank computes the same ELBO from the same records
+            return e[0]
+        def result(self):
+            parts = [s.result() for s in shards]
+            assert all(np.array_equal(p[1], parts[0][1]) for p in parts)
+            return np.concatenate([p[0] for p in parts]), parts[0][1], np.concatenate([p[2] for p in parts])
+
+    gamma, pi, hard, elbos = vbx_refine_sharded(Lockstep(), lambda chunks: torch.cat(chunks), 20, 1e-4)
+    for s in shards:
+        s.close()
+    assert elbos == one.elbos
+    assert np.array_equal(gamma, one.gamma) and np.array_equal(pi, one.pi) and hard.tolist() == one.hard_clusters[0]
+    if T <= 2500:
+        og, op, oh, oe = oracle_mod.vbx_refine(x, init, phi)
+        assert len(oe) == len(elbos) and np.array_equal(oh, hard)
+        np.testing.assert_allclose(gamma, og, atol=1e-9)
+
+
+def test_vbx_shard_argument_checks(fa, gpu_ctx):
+    from fluidaudio_amd.sharding import VbxShard, vbx_shard_frames
+    with pytest.raises(ValueError):
+        vbx_shard_frames(100, 0, 3)                     # 3 does not divide 64
+    x, init, phi = make_problem(200, 8, 3, 5)
+    with pytest.raises(ValueError):
+        VbxShard(x[:10], init[:10], 200, 3, phi, 0, 2, ctx=gpu_ctx)   # not the frames this rank holds
