@@ -53,7 +53,10 @@
 
 namespace {
 
-constexpr int kBlk = 256;          // rows per block record == threads per round workgroup
+#ifndef FA_AHC_BLK
+#define FA_AHC_BLK 256
+#endif
+constexpr int kBlk = FA_AHC_BLK;   // rows per block record == threads per round workgroup (512 measured: see profiles/r03_ahc_variants.txt)
 constexpr int kWaves = kBlk / 64;
 constexpr int kMaxBlocks = 768;    // N <= 196 608 (N^2 * 8 B = 288 GB is reached at N ~ 190 000)
 constexpr int kRoundsPerGraph = 512;  // multiple of 4 (counter rotation) and of 2 (parity)
@@ -475,7 +478,105 @@ __global__ __launch_bounds__(256, 2) void ahc_gram_mfma(Ws w, const double *__re
                 if (!(v > 0.0)) v = 0.0;  // duplicates can come out slightly negative; keeps -0.0 out of the bit-pattern reductions
                 if (ok && v > lmax) lmax = v;
                 w.M[static_cast<size_t>(i) * Np + j] = ok ? v : dinf();
+#ifndef FA_GRAM_NO_MIRROR
                 if (mirror) w.M[static_cast<size_t>(j) * Np + i] = ok ? v : dinf();   // 4 consecutive doubles per row and store; the four e complete the lines in L2
+#endif
+            }
+    }
+    if (bad) w.flags[0] = 1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(lmax, off); if (o > lmax) lmax = o; }
+    if (lane == 0 && lmax > 0.0)
+        atomicMax(&w.state[0].dmax_bits, static_cast<unsigned long long>(__double_as_longlong(lmax)));
+}
+
+// The same contraction for d % 16 == 0 (every embedding size on the path), re-plumbed around what scripts/ubench/mfma64.hip measured
+// (profiles/r03_ubench_mfma64.txt): a stream of independent v_mfma_f64_16x16x4_f64 runs at 65 TFLOP/s, with eight ds_read_b64 in front of
+// every 16 of them at 45, with four ds_read_b128 at 57 — every instruction that WRITES VGPRs while the matrix core runs costs 40-70 of its
+// clocks, wherever it is placed and however many wavefronts share the SIMD.  So: operand tiles travel global -> LDS without touching
+// registers (global_load_lds_dwordx4: one instruction = one 1 KB k-row of a 128-wide tile; the kernel above needs 8 loads + 8 ds_write per
+// thread and chunk for it), two LDS stages and ONE barrier per k-chunk, operands read as 16-byte pairs (rows 2 m, 2 m + 1 of a 32-row
+// group -> two MFMA tiles per read: the tile index of the rows is interleaved, which the epilogue undoes), and the results leave as
+// 16-byte stores in both the direct and the mirrored direction.
+typedef double d2f64 __attribute__((ext_vector_type(2)));
+constexpr int G2K = 16, G2S = 144;
+constexpr size_t kGram2LdsBytes = sizeof(double) * 2 * 2 * G2K * G2S;   // [stage][operand][k][144]: 73 728 B, two workgroups per CU
+
+__global__ __launch_bounds__(256, 2) void ahc_gram_mfma2(Ws w, const double *__restrict__ norms) {
+    extern __shared__ __attribute__((aligned(16))) double sg[];
+    if (blockIdx.x > blockIdx.y) return;   // symmetric: tiles on and below the diagonal, off-diagonal tiles are written twice
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;   // wave: in an SGPR, so the row addresses below are scalar
+    const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+    const bool mirror = i0 != j0;
+    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int Np = w.Np, nchunk = w.d / G2K;
+    v4f64 acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = v4f64{0.0, 0.0, 0.0, 0.0};
+    // wavefront `wave` moves the k rows 4 wave .. 4 wave + 3 of both operands of a chunk: 8 instructions, 1 KB each
+    auto issue = [&](const int k0, const int st) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kk = wave * 4 + q;
+            const double *row = w.XT + static_cast<size_t>(k0 + kk) * Np;   // wave-uniform
+            __builtin_amdgcn_global_load_lds(row + i0 + 2 * lane, sg + ((st * 2 + 0) * G2K + kk) * G2S, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(row + j0 + 2 * lane, sg + ((st * 2 + 1) * G2K + kk) * G2S, 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    for (int c = 0; c < nchunk; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's rows of chunk c are in LDS ...
+        __syncthreads();                                    // ... everybody's are, and nobody reads the other stage any more
+        if (c + 1 < nchunk) issue((c + 1) * G2K, (c + 1) & 1);
+        const double *A = sg + ((c & 1) * 2 + 0) * G2K * G2S + wr + 2 * l15, *B = sg + ((c & 1) * 2 + 1) * G2K * G2S + wc + 2 * l15;
+#pragma unroll
+        for (int ks = 0; ks < G2K / 4; ++ks) {
+            const int kr = 4 * ks + lq;
+            d2f64 a2[2], b2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { a2[t] = *reinterpret_cast<const d2f64 *>(A + kr * G2S + 32 * t); b2[t] = *reinterpret_cast<const d2f64 *>(B + kr * G2S + 32 * t); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                    acc[r][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64((r & 1) ? a2[r >> 1].y : a2[r >> 1].x, (cc & 1) ? b2[cc >> 1].y : b2[cc >> 1].x, acc[r][cc], 0, 0, 0);
+        }
+    }
+    // tile (r, cc), register e, lane: row i = i0 + wr + 32 (r >> 1) + 2 (lq + 4 e) + (r & 1), column j = j0 + wc + 32 (cc >> 1) + 2 l15 + (cc & 1)
+    double lmax = 0.0;
+    bool bad = false;
+    auto entry = [&](const double dot, const double ni, const double nj, const bool ok) {
+        double v = ni + nj - 2.0 * dot;
+        if (ok && v != v) bad = true;
+        if (!(v > 0.0)) v = 0.0;  // duplicates can come out slightly negative; keeps -0.0 out of the bit-pattern reductions
+        if (ok && v > lmax) lmax = v;
+        return ok ? v : dinf();
+    };
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {   // column pair group: columns jb, jb + 1
+        __builtin_amdgcn_sched_barrier(0);   // one strip at a time (register pressure)
+        const int jb = j0 + wc + 32 * cp + 2 * l15;
+        const bool lj0 = w.node[jb] != kDead, lj1 = w.node[jb + 1] != kDead;
+        const double nj0 = norms[jb], nj1 = norms[jb + 1];
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ib = i0 + wr + 32 * rp + 2 * (lq + 4 * e);   // rows ib (tiles 2 rp) and ib + 1 (tiles 2 rp + 1)
+                const bool li0 = w.node[ib] != kDead, li1 = w.node[ib + 1] != kDead;
+                const double ni0 = norms[ib], ni1 = norms[ib + 1];
+                const double v00 = entry(acc[2 * rp][2 * cp][e], ni0, nj0, li0 && lj0 && ib != jb);
+                const double v01 = entry(acc[2 * rp][2 * cp + 1][e], ni0, nj1, li0 && lj1 && ib != jb + 1);
+                const double v10 = entry(acc[2 * rp + 1][2 * cp][e], ni1, nj0, li1 && lj0 && ib + 1 != jb);
+                const double v11 = entry(acc[2 * rp + 1][2 * cp + 1][e], ni1, nj1, li1 && lj1 && ib + 1 != jb + 1);
+                *reinterpret_cast<d2f64 *>(w.M + static_cast<size_t>(ib) * Np + jb) = d2f64{v00, v01};
+                *reinterpret_cast<d2f64 *>(w.M + static_cast<size_t>(ib + 1) * Np + jb) = d2f64{v10, v11};
+                if (mirror) {
+                    *reinterpret_cast<d2f64 *>(w.M + static_cast<size_t>(jb) * Np + ib) = d2f64{v00, v10};
+                    *reinterpret_cast<d2f64 *>(w.M + static_cast<size_t>(jb + 1) * Np + ib) = d2f64{v01, v11};
+                }
             }
     }
     if (bad) w.flags[0] = 1;
@@ -1577,7 +1678,12 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
     if (dev_mode == FA_AHC_MODE_AUTO) {  // Gram form on the fp64 matrix cores (approximate entries, see ahc_gram_mfma)
         double *d_norms = reinterpret_cast<double *>(base + L.norms);
         hipLaunchKernelGGL(ahc_sqnorms, dim3((w.Np + 255) / 256), dim3(256), 0, ctx->stream, w, d_norms);
-        hipLaunchKernelGGL(ahc_gram_mfma, dim3(w.Np / GT, w.Np / GT), dim3(256), 0, ctx->stream, w, d_norms);
+        if (w.d % G2K == 0 && getenv("FA_AHC_GRAM_V1") == nullptr) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_gram_mfma2), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGram2LdsBytes));
+            FA_HIP_TRY(ctx, attr);
+            hipLaunchKernelGGL(ahc_gram_mfma2, dim3(w.Np / GT, w.Np / GT), dim3(256), kGram2LdsBytes, ctx->stream, w, d_norms);
+        } else
+            hipLaunchKernelGGL(ahc_gram_mfma, dim3(w.Np / GT, w.Np / GT), dim3(256), 0, ctx->stream, w, d_norms);
     } else {
         const int tiles = w.Np / PT;
         hipLaunchKernelGGL(ahc_pairwise, dim3(tiles, tiles), dim3(256), 0, ctx->stream, w);
