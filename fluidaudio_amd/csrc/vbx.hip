@@ -111,8 +111,14 @@ __global__ __launch_bounds__(kThreads) void vbx_gt_rho(VbxWs w) {
     t0 -= w.t0g; t1 -= w.t0g;                                       // ... as local rows
     if (s >= w.S || col > w.D) return;
     double acc = 0.0;
-    if (col < w.D) for (int64_t t = t0; t < t1; ++t) acc += w.gamma[t * w.S + s] * w.rho[t * w.D + col];
-    else for (int64_t t = t0; t < t1; ++t) acc += w.gamma[t * w.S + s];
+    // (unrolled: 16 independent loads in flight per thread; the additions keep their order — t ascending — so the sums keep their bits)
+    if (col < w.D) {
+#pragma unroll 8
+        for (int64_t t = t0; t < t1; ++t) acc += w.gamma[t * w.S + s] * w.rho[t * w.D + col];
+    } else {
+#pragma unroll 8
+        for (int64_t t = t0; t < t1; ++t) acc += w.gamma[t * w.S + s];
+    }
     w.rec_out[blockIdx.z * w.stride + static_cast<int64_t>(s) * (w.D + 1) + col] = acc;
 }
 
