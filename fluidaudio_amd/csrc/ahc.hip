@@ -53,6 +53,9 @@
 
 namespace {
 
+#ifndef FA_AHC_SPECULATE
+#define FA_AHC_SPECULATE 1   // the operands of the presumptive merge are requested before the decision is complete (0: after it, as in round 2)
+#endif
 #ifndef FA_AHC_BLK
 #define FA_AHC_BLK 256
 #endif
@@ -789,10 +792,10 @@ __device__ void exact_min_pair(const Ws &w, const int np, double *s_sq /*[kWaves
     if (bad) best_p = -1;  // NaN distance -> nan_error in the reference
 }
 
-#ifdef FA_AHC_PROFILE
+#ifdef FA_AHC_PROFILE   // 1: every stamp waits for all outstanding memory operations (phase costs in isolation); 2: stamps only (the overlapped timeline)
 #define AHC_STAMP(i)                                                                  \
     do {                                                                              \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                   \
+        if (FA_AHC_PROFILE == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
         const unsigned long long t_now = clock64();                                   \
         t_seg[i] = t_now - t_prev;                                                    \
         t_prev = t_now;                                                               \
@@ -883,6 +886,13 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     double e2x = w.e2[x];   // lower bound of the entries of row x other than its nearest neighbour's
     const int nanflag = w.flags[0];
     __builtin_amdgcn_sched_barrier(0);
+#ifndef FA_AHC_LATE_KERNARGS
+    // Kernel arguments that are first used in the MIDDLE of the dependent chain (N: the step test and the node id of the merged cluster, Np:
+    // the row addresses of the operands, cnt / pairs / cand: the rare window paths, which the compiler loads together with N): left to the
+    // scheduler they are scalar loads right where they are used, i.e. two scalar-cache round trips inside the chain.  Naming them here puts
+    // the loads next to the round's first memory round trip.
+    asm volatile("" :: "s"(N), "s"(Np), "s"(d), "s"(w.cnt), "s"(w.pairs), "s"(w.cand));
+#endif
     AhcHot st;
     __builtin_memcpy(&st, hraw, sizeof(AhcHot));
     auto whole_state = [&]() {   // thread (0, 0) only: the present state reassembled from its pieces
@@ -1032,6 +1042,29 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         if (P >= 0 && lt2(pd1[k], P, g1, R1 < 0 ? INT_MAX : R1)) { g1 = pd1[k]; R1 = P; Q1 = pnn[k]; NR1 = st.pend_node[k]; NQ1 = pnnnode[k]; }
     }
     if (!(g1 < dinf())) R1 = -1;
+    // The operands of the merge of (R1, Q1) are requested HERE: in all but a handful of rounds that pair is what the round merges, and the
+    // window count, the state tests and the dispatch below (~900 cycles of branches on uniform values) only decide whether the values are
+    // used.  The second memory round trip of the round starts that much earlier; a round that does something else drops them.
+    constexpr int kCk = 4;                                   // centroid elements per lane handled without a loop (d <= 256)
+    const bool spec = FA_AHC_SPECULATE && R1 >= 0 && Q1 >= 0;
+    const bool spec_lo = R1 < Q1;
+    const int sp_a = spec_lo ? R1 : Q1, sp_b = spec_lo ? Q1 : R1, sp_na = spec_lo ? NR1 : NQ1, sp_nb = spec_lo ? NQ1 : NR1;
+    double sp_ma = 0.0, sp_mb = 0.0, sp_da = 0.0, sp_db = 0.0, sp_xa[kCk], sp_xb[kCk];
+#pragma unroll
+    for (int j = 0; j < kCk; ++j) { sp_xa[j] = 0.0; sp_xb[j] = 0.0; }
+    // (the youngest load of the round's first batch is consumed here: the load counter completes in order, so everything older has arrived and
+    // nothing in the decision below has to wait on the counter — a wait there would also wait for the requests that follow)
+    asm volatile("" :: "v"(nanflag), "v"(e2x), "v"(rs.d1), "v"(nx));
+    if (spec) {
+        sp_ma = w.sizes[sp_na]; sp_mb = w.sizes[sp_nb];
+        if (nx != kDead && x != sp_a && x != sp_b && st.mode == FA_AHC_MODE_AUTO) {
+            sp_da = pair_entry(w.M, Np, sp_a, sp_na, x, nx, st.sym_limit);
+            sp_db = pair_entry(w.M, Np, sp_b, sp_nb, x, nx, st.sym_limit);
+        }
+        const double *ca = w.C + static_cast<size_t>(sp_na) * d, *cb = w.C + static_cast<size_t>(sp_nb) * d;
+#pragma unroll
+        for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; sp_xa[j] = k < d ? ca[k] : 0.0; sp_xb[j] = k < d ? cb[k] : 0.0; }
+    }
     const double glim = g1 + 2.0 * st.eps;
     int nwin = 0;  // conservative (never too small): nested counts were taken against local minima
     if (dv.v1 <= glim) nwin += dv.cnt;
@@ -1142,14 +1175,19 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
 
     if (D.op == OP_MERGE) {
         const int a = D.a, b = D.b, na = D.na, nb = D.nb, nnew = N + st.step;
-        const double ma = w.sizes[na], mb = w.sizes[nb], den = ma + mb;
+        const bool sp_hit = spec && a == sp_a && b == sp_b && na == sp_na && nb == sp_nb;   // uniform; false only for the pair an exact window picked
         const double *ca = w.C + static_cast<size_t>(na) * d, *cb = w.C + static_cast<size_t>(nb) * d;
         const bool act = nx != kDead && x != a && x != b;
-        double da = 0.0, db = 0.0;
-        if (act && st.mode == FA_AHC_MODE_AUTO) {  // valid copy of a pair lives in the row of the younger node
-            da = pair_entry(w.M, Np, a, na, x, nx, st.sym_limit);
-            db = pair_entry(w.M, Np, b, nb, x, nx, st.sym_limit);
+        double ma = sp_ma, mb = sp_mb, da = sp_da, db = sp_db;
+        if (!sp_hit) {
+            ma = w.sizes[na]; mb = w.sizes[nb];
+            da = 0.0; db = 0.0;
+            if (act && st.mode == FA_AHC_MODE_AUTO) {  // valid copy of a pair lives in the row of the younger node
+                da = pair_entry(w.M, Np, a, na, x, nx, st.sym_limit);
+                db = pair_entry(w.M, Np, b, nb, x, nx, st.sym_limit);
+            }
         }
+        const double den = ma + mb;
 #pragma unroll
         for (int k = 1; k < kPend; ++k) {  // piggy-backed re-scans: pairs not touched by this merge
             const int S = prow[k];
@@ -1160,10 +1198,13 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         // depth).  Every wave evaluates the whole sum: no workgroup barrier.  The centroid elements are REQUESTED together (an un-unrolled
         // loop made four dependent round trips of it: 3 800 of a round's 15 600 cycles), and the division runs only in the wave that
         // stores the centroid.
-        constexpr int kCk = 4;                                   // elements per lane handled without a loop (d <= 256)
         double xa[kCk], xb[kCk];
 #pragma unroll
-        for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; xa[j] = k < d ? ca[k] : 0.0; xb[j] = k < d ? cb[k] : 0.0; }
+        for (int j = 0; j < kCk; ++j) { xa[j] = sp_xa[j]; xb[j] = sp_xb[j]; }
+        if (!sp_hit) {
+#pragma unroll
+            for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; xa[j] = k < d ? ca[k] : 0.0; xb[j] = k < d ? cb[k] : 0.0; }
+        }
         if (kPrefetch > 0) {   // warm-up requests for the likely partner rows of the NEXT merge (see kPrefetch); nothing below waits for them
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
