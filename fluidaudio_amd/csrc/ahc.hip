@@ -1402,13 +1402,20 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
 //                       (fa_ahc_linkage_batch / fa_offline_cluster_batch with <= 16 recordings).
 template <bool BATCH>
 __global__ __launch_bounds__(kBlk) void ahc_round_t(const int ph, const int nblk_, AhcState *const state_, RecA *const recA_, int4 *const recI_, RecP *const recP_,
+                                                    const unsigned off_row, const unsigned off_node, const unsigned off_e2, const unsigned off_flags,
                                                     const Ws w_one, const Ws *__restrict__ table, const int2 *__restrict__ blkmap) {
-    // The leading scalar arguments repeat what the first loads of a round need (round parity, block count, state and record arrays):
-    // scalars at the front of the argument list are PRELOADED into SGPRs with the wavefront (Makefile: -amdgpu-kernarg-preload-count;
-    // a by-value struct is not), so the record loads of phase 1 do not wait for a scalar load of the arguments first.
+    // The leading scalar arguments repeat what the FIRST loads of a round need (round parity, block count, state and record arrays, and the
+    // row-state arrays as byte offsets from the state): scalars at the front of the argument list are PRELOADED into SGPRs with the
+    // wavefront (Makefile: -amdgpu-kernarg-preload-count; a by-value struct is not), so nothing of the round's first memory round trip
+    // waits for a scalar load of the argument segment (the compiler had put that wait in front of the record requests).
     int blk_ = blockIdx.x;
     Ws w_ = w_one;
-    if (!BATCH) { w_.nblk = nblk_; w_.state = state_; w_.recA = recA_; w_.recI = recI_; w_.recP = recP_; }
+    if (!BATCH) {
+        w_.nblk = nblk_; w_.Np = nblk_ * kBlk; w_.state = state_; w_.recA = recA_; w_.recI = recI_; w_.recP = recP_;
+        char *base = reinterpret_cast<char *>(state_);
+        w_.row = reinterpret_cast<RowSt *>(base + off_row); w_.node = reinterpret_cast<int *>(base + off_node);
+        w_.e2 = reinterpret_cast<double *>(base + off_e2); w_.flags = reinterpret_cast<int *>(base + off_flags);
+    }
     if (BATCH) {
         static_assert(sizeof(Ws) % 8 == 0, "Ws is copied as 64-bit words");
         typedef const int __attribute__((address_space(4))) *c_i32;
@@ -1946,7 +1953,9 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
 
     const Ws w = p.w;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    auto launch = [&](const int ph) { hipLaunchKernelGGL(ahc_round_t<false>, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, ph, w.nblk, w.state, w.recA, w.recI, w.recP, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr)); };
+    auto off_of = [&](const void *p) { return static_cast<unsigned>(static_cast<const char *>(p) - reinterpret_cast<const char *>(w.state)); };   // small arrays: within 4 GB of the state (make_layout puts the matrix last)
+    const unsigned o_row = off_of(w.row), o_node = off_of(w.node), o_e2 = off_of(w.e2), o_flags = off_of(w.flags);
+    auto launch = [&](const int ph) { hipLaunchKernelGGL(ahc_round_t<false>, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, ph, w.nblk, w.state, w.recA, w.recI, w.recP, o_row, o_node, o_e2, o_flags, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr)); };
     // The captured graph only holds launch parameters (workspace pointers, block count): it is reused as long as the workspace sits at
     // the same address and the shape is the same — repeated calls on recordings of one length skip capture + instantiation.
     RoundGraph single_rg;
@@ -2089,7 +2098,7 @@ fa_status ahc_batch_once(fa_ctx *ctx, int count, const double *const *d_data, co
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_args), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     auto launch = [&](const int ph) {
         if (by_args) hipLaunchKernelGGL(ahc_round_args, dim3(grid), dim3(kBlk), lds, ctx->stream, bargs, ph);
-        else hipLaunchKernelGGL(ahc_round_t<true>, dim3(grid), dim3(kBlk), lds, ctx->stream, ph, 0, static_cast<AhcState *>(nullptr), static_cast<RecA *>(nullptr), static_cast<int4 *>(nullptr), static_cast<RecP *>(nullptr), Ws{}, d_table, static_cast<const int2 *>(d_map));
+        else hipLaunchKernelGGL(ahc_round_t<true>, dim3(grid), dim3(kBlk), lds, ctx->stream, ph, 0, static_cast<AhcState *>(nullptr), static_cast<RecA *>(nullptr), static_cast<int4 *>(nullptr), static_cast<RecP *>(nullptr), 0u, 0u, 0u, 0u, Ws{}, d_table, static_cast<const int2 *>(d_map));
     };
     for (long long it = 0; it < max_batches; ++it) {
         int n_active = 0;
