@@ -1315,6 +1315,11 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
                 pkey[k] = pair_entry(w.M, Np, S, pnode_[k], x, nx, st.sym_limit);
             if (x == S) in_flight = true;
         }
+        // consumed inside the branch: a load still pending where the branches join makes the compiler wait on the in-order memory counter at
+        // the join's first use of pkey — and on the MERGE path that wait finds only this round's STORES outstanding: a store round trip in
+        // front of the block record of every merge round
+#pragma unroll
+        for (int k = 0; k < kPend; ++k) asm volatile("" :: "v"(pkey[k]));
     } else if (D.op == OP_COLLECT) {
         WinCounters *cw = w.cnt + (ph & 3);
         if (nx != kDead && rs.d1 <= D.lim) {
