@@ -1056,14 +1056,18 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     // nothing in the decision below has to wait on the counter — a wait there would also wait for the requests that follow)
     asm volatile("" :: "v"(nanflag), "v"(e2x), "v"(rs.d1), "v"(nx));
     if (spec) {
+        // sizes and centroids first, the two matrix entries (a cold row each) last: loads complete in order.  (Requesting the entries from
+        // every thread, so that the wait for the centroids need not cover them, was measured: dead columns then read cold column copies
+        // nobody needs — 5.8 instead of 5.3 us per round at 43 200 points.)
         sp_ma = w.sizes[sp_na]; sp_mb = w.sizes[sp_nb];
+        const double *ca = w.C + static_cast<size_t>(sp_na) * d, *cb = w.C + static_cast<size_t>(sp_nb) * d;
+#pragma unroll
+        for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; sp_xa[j] = k < d ? ca[k] : 0.0; sp_xb[j] = k < d ? cb[k] : 0.0; }
+        __builtin_amdgcn_sched_barrier(0);
         if (nx != kDead && x != sp_a && x != sp_b && st.mode == FA_AHC_MODE_AUTO) {
             sp_da = pair_entry(w.M, Np, sp_a, sp_na, x, nx, st.sym_limit);
             sp_db = pair_entry(w.M, Np, sp_b, sp_nb, x, nx, st.sym_limit);
         }
-        const double *ca = w.C + static_cast<size_t>(sp_na) * d, *cb = w.C + static_cast<size_t>(sp_nb) * d;
-#pragma unroll
-        for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; sp_xa[j] = k < d ? ca[k] : 0.0; sp_xb[j] = k < d ? cb[k] : 0.0; }
     }
     const double glim = g1 + 2.0 * st.eps;
     int nwin = 0;  // conservative (never too small): nested counts were taken against local minima
