@@ -292,3 +292,20 @@ def test_massive_exact_ties_reference_order_vs_exact_mode(fa, gpu_ctx):
         assert st0 == st1 == 0 and s0["exact_fallback"] == 1 and s0["reference_order"] == 1 and s0["rounds"] <= 8 * n
         np.testing.assert_array_equal(np.sort(z0[:, 2]), np.sort(z1[:, 2]))
         assert same_partition(fa.cut(z0, n, 0.6), fa.cut(z1, n, 0.6))
+
+
+def test_more_than_65536_points_takes_the_many_record_path(fa, gpu_ctx):
+    """N > 65 536: more than four block records per lane in the round's first reduction (the generic path of ahc_round_body; every
+    other test stays below it).  66 000 x 4: the filter-based rounds (AUTO) against the reference-order scans (a different set of
+    kernels that evaluates every distance exactly, checked against the reference build elsewhere) — row for row.  35 GB of workspace."""
+    import torch
+    n, d = 66_000, 4
+    x = np.random.default_rng(66).standard_normal((n, d))
+    st, z, stats = fa.linkage(x, mode=fa.AHC_MODE_AUTO, ctx=gpu_ctx, return_stats=True)
+    assert st == 0 and stats["merges"] == n - 1 and stats["reference_order"] == 0, stats
+    st2, z2, stats2 = fa.linkage(x, mode=fa.AHC_MODE_REFERENCE_ORDER, ctx=gpu_ctx, return_stats=True)
+    assert st2 == 0 and stats2["reference_order"] == 1
+    bad = np.nonzero((z != z2).any(axis=1))[0]
+    assert bad.size == 0, f"first differing row {bad[:3]}: {z[bad[:1]]} vs {z2[bad[:1]]}; stats {stats}"
+    gpu_ctx.trim()
+    torch.cuda.empty_cache()
