@@ -101,6 +101,7 @@ void fa_ctx_destroy(fa_ctx *ctx) {
     if (ctx->ahc_ws) (void)hipFree(ctx->ahc_ws);
     if (ctx->poly_taps) (void)hipFree(ctx->poly_taps);
     if (ctx->ahc_graph && ctx->ahc_graph_free) ctx->ahc_graph_free(ctx->ahc_graph);
+    if (ctx->mel_cache && ctx->mel_cache_free) ctx->mel_cache_free(ctx->mel_cache);
     for (auto &e : ctx->ahc_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -130,6 +131,7 @@ fa_status fa_ctx_trim(fa_ctx *ctx) {
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     if (ctx->ws_busy) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "trim: the context is inside a linkage call");
     free_caches_locked(ctx, true);
+    if (ctx->mel_cache && ctx->mel_cache_free) { ctx->mel_cache_free(ctx->mel_cache); ctx->mel_cache = nullptr; }
     return FA_SUCCESS;
 }
 

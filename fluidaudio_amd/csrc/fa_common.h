@@ -32,6 +32,9 @@ struct fa_ctx {
     hipEvent_t ahc_ev[3] = {nullptr, nullptr, nullptr};
     void *ahc_graph = nullptr;                 // owned by ahc.hip (ahc_graph_free releases it)
     void (*ahc_graph_free)(void *) = nullptr;
+    // mel: plans of small host-pointer calls (tables + geometry on the device) are kept (mel.hip) — a streaming caller repeats one shape
+    void *mel_cache = nullptr;
+    void (*mel_cache_free)(void *) = nullptr;
     // polyphase resampler taps of the last (up, down) pair, device resident (resample.hip)
     void *poly_taps = nullptr;
     size_t poly_taps_bytes = 0;

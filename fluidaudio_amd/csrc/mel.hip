@@ -1099,6 +1099,60 @@ fa_status fa_mel_normalize_per_feature_dev(fa_ctx *ctx, float *d_mel, int32_t ba
     return FA_SUCCESS;
 }
 
+// Plans of small host-pointer calls, kept per context (see fa_mel_batch).  Key = everything fa_mel_plan_create looks at.
+}  // extern "C"
+namespace {
+constexpr int32_t kMelCacheMaxBatch = 8;
+constexpr size_t kMelCacheEntries = 8;
+constexpr size_t kMelCfgKeyBytes = offsetof(fa_mel_config, tail_mode) + sizeof(int32_t);   // every field in front of the filterbank pointer, no padding
+struct MelPlanCache {
+    struct Entry {
+        fa_mel_config cfg;
+        int32_t batch, frame_stride;
+        bool has_expected;
+        std::vector<int64_t> offsets;
+        std::vector<int32_t> expected;
+        fa_mel_plan *plan;
+    };
+    std::vector<Entry> entries;
+};
+void mel_cache_free(void *p) {
+    MelPlanCache *c = static_cast<MelPlanCache *>(p);
+    if (!c) return;
+    for (auto &en : c->entries) fa_mel_plan_destroy(en.plan);
+    delete c;
+}
+fa_status mel_cached_plan(fa_ctx *ctx, const fa_mel_config *cfg, const int64_t *offsets, int32_t batch, const int32_t *expected_frames,
+                          int32_t frame_stride, fa_mel_plan **out) {
+    try {
+        if (!ctx->mel_cache) { ctx->mel_cache = new MelPlanCache; ctx->mel_cache_free = mel_cache_free; }
+        MelPlanCache *c = static_cast<MelPlanCache *>(ctx->mel_cache);
+        for (auto &en : c->entries) {
+            if (en.batch != batch || en.frame_stride != frame_stride || en.has_expected != (expected_frames != nullptr)) continue;
+            if (memcmp(&en.cfg, cfg, kMelCfgKeyBytes) != 0) continue;
+            if (memcmp(en.offsets.data(), offsets, sizeof(int64_t) * (batch + 1)) != 0) continue;
+            if (expected_frames && memcmp(en.expected.data(), expected_frames, sizeof(int32_t) * batch) != 0) continue;
+            *out = en.plan;
+            return FA_SUCCESS;
+        }
+        fa_mel_plan *p = nullptr;
+        FA_TRY(fa_mel_plan_create(ctx, cfg, offsets, batch, expected_frames, frame_stride, &p));
+        if (c->entries.size() >= kMelCacheEntries) { fa_mel_plan_destroy(c->entries.front().plan); c->entries.erase(c->entries.begin()); }
+        MelPlanCache::Entry en;
+        en.cfg = *cfg; en.batch = batch; en.frame_stride = frame_stride; en.has_expected = expected_frames != nullptr;
+        en.offsets.assign(offsets, offsets + batch + 1);
+        if (expected_frames) en.expected.assign(expected_frames, expected_frames + batch);
+        en.plan = p;
+        c->entries.push_back(std::move(en));
+        *out = p;
+        return FA_SUCCESS;
+    } catch (const std::bad_alloc &) {
+        return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "mel plan cache: host allocation failed");
+    }
+}
+}  // namespace
+extern "C" {
+
 // Host-pointer entry.  Pageable host buffers: copy in, kernel, copy out on the context's stream (each copy is a staged copy inside
 // the runtime at ~55 GB/s; measured: slicing + a second host thread does not overlap the two directions, the staging serialises).
 // PINNED host buffers (fa_host_alloc, or memory the caller registered with the HIP runtime): the batch is cut into slices of
@@ -1110,9 +1164,15 @@ fa_status fa_mel_batch(fa_ctx *ctx, const fa_mel_config *cfg, const float *pcm, 
     if (!ctx || !mel || !offsets || batch < 1) return FA_INVALID_ARGUMENT;
     fa::DeviceGuard guard(ctx->device);
     fa_mel_plan *whole = nullptr;   // geometry of the whole batch (frame stride, utterance stride) + validation
-    FA_TRY(fa_mel_plan_create(ctx, cfg, offsets, batch, expected_frames, frame_stride, &whole));
+    // Small calls (the reference's streaming callers: one chunk of a fixed length per call, StreamingEouAsrManager.swift:558) keep their
+    // plan in the context: building the tables on the host, one hipMalloc / upload / hipFree for them and three more for the I/O buffers
+    // were 110 of the 194 us such a call took (scripts/mel_latency_probe.py).
+    const bool cached = batch <= kMelCacheMaxBatch && cfg && cfg->filterbank == nullptr;
+    if (cached) FA_TRY(mel_cached_plan(ctx, cfg, offsets, batch, expected_frames, frame_stride, &whole));
+    else FA_TRY(fa_mel_plan_create(ctx, cfg, offsets, batch, expected_frames, frame_stride, &whole));
+    struct PlanOwner { fa_mel_plan *&p; bool own; ~PlanOwner() { if (own && p) fa_mel_plan_destroy(p); } } owner{whole, !cached};
     const int64_t ns = offsets[batch];
-    if (ns > 0 && !pcm) { fa_mel_plan_destroy(whole); return FA_INVALID_ARGUMENT; }
+    if (ns > 0 && !pcm) return FA_INVALID_ARGUMENT;
     const int32_t fstride = whole->frame_stride;
     const int64_t ustride = whole->utt_stride;
     auto pinned = [](const void *p) {
@@ -1132,28 +1192,35 @@ fa_status fa_mel_batch(fa_ctx *ctx, const fa_mel_config *cfg, const float *pcm, 
     first.push_back(batch);
     const int n_slices = static_cast<int>(first.size()) - 1;
     const size_t out_floats = static_cast<size_t>(ustride) * batch;
-    fa::DevBuf d_pcm, d_last, d_out, d_len;
-    hipError_t e = d_pcm.alloc(sizeof(float) * static_cast<size_t>(ns));
-    if (e == hipSuccess) e = d_out.alloc(sizeof(float) * out_floats);
-    if (e == hipSuccess) e = d_len.alloc(sizeof(int32_t) * batch);
-    if (e == hipSuccess && last_samples) e = d_last.alloc(sizeof(float) * batch);
-    if (e != hipSuccess) { (void)hipGetLastError(); fa_mel_plan_destroy(whole); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "fa_mel_batch: device allocation failed"); }
-    if (n_slices <= 1) {
+    hipError_t e = hipSuccess;
+    if (n_slices <= 1) {   // one slice: samples, output and lengths in the context's scratch buffer (grow-only, kept between calls)
+        auto al = [](size_t b) { return (b + 255) & ~static_cast<size_t>(255); };
+        const size_t o_pcm = 0, o_out = al(sizeof(float) * static_cast<size_t>(ns)), o_len = o_out + al(sizeof(float) * out_floats),
+                     o_last = o_len + al(sizeof(int32_t) * batch), total = o_last + al(sizeof(float) * batch);
+        if (fa::ensure_scratch(ctx, total) != FA_SUCCESS) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "fa_mel_batch: device allocation failed"); }
+        char *base = static_cast<char *>(ctx->scratch);
+        float *d_pcm = reinterpret_cast<float *>(base + o_pcm), *d_out = reinterpret_cast<float *>(base + o_out), *d_last = reinterpret_cast<float *>(base + o_last);
+        int32_t *d_len = reinterpret_cast<int32_t *>(base + o_len);
         fa_status st = FA_SUCCESS;
         do {
-            if (ns > 0 && (e = hipMemcpyAsync(d_pcm.p, pcm, sizeof(float) * ns, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-            if (last_samples && (e = hipMemcpyAsync(d_last.p, last_samples, sizeof(float) * batch, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-            st = fa_mel_execute_dev(whole, d_pcm.as<float>(), last_samples ? d_last.as<float>() : nullptr, d_out.as<float>(), d_len.as<int32_t>());
+            if (ns > 0 && (e = hipMemcpyAsync(d_pcm, pcm, sizeof(float) * ns, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+            if (last_samples && (e = hipMemcpyAsync(d_last, last_samples, sizeof(float) * batch, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+            st = fa_mel_execute_dev(whole, d_pcm, last_samples ? d_last : nullptr, d_out, d_len);
             if (st != FA_SUCCESS) break;
-            if ((e = hipMemcpyAsync(mel, d_out.p, sizeof(float) * out_floats, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
-            if (mel_lengths && (e = hipMemcpyAsync(mel_lengths, d_len.p, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(mel, d_out, sizeof(float) * out_floats, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+            if (mel_lengths && (e = hipMemcpyAsync(mel_lengths, d_len, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
             e = hipStreamSynchronize(ctx->stream);
         } while (0);
-        fa_mel_plan_destroy(whole);
         if (st != FA_SUCCESS) return st;
         return fa::hip_status(ctx, e, "fa_mel_batch");
     }
-    fa_mel_plan_destroy(whole);
+    fa::DevBuf d_pcm, d_last, d_out, d_len;
+    e = d_pcm.alloc(sizeof(float) * static_cast<size_t>(ns));
+    if (e == hipSuccess) e = d_out.alloc(sizeof(float) * out_floats);
+    if (e == hipSuccess) e = d_len.alloc(sizeof(int32_t) * batch);
+    if (e == hipSuccess && last_samples) e = d_last.alloc(sizeof(float) * batch);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "fa_mel_batch: device allocation failed"); }
+    if (owner.own) { fa_mel_plan_destroy(whole); whole = nullptr; }   // only its geometry was needed: every slice gets its own plan
     try {
         hipStream_t down = nullptr;
         FA_HIP_TRY(ctx, hipStreamCreateWithFlags(&down, hipStreamNonBlocking));

@@ -437,3 +437,26 @@ def test_device_vs_independent_torch_stft_evaluation(fa, gpu_ctx, oracle_mod, n)
     row = d_out[17].cpu().numpy().reshape(-1, 128)[:ml]
     assert oracle_mod.mel_f64_error(row, ref) <= 1e-4
     plan.close()
+
+
+def test_host_pointer_plan_cache_is_transparent(fa, gpu_ctx, oracle_mod):
+    """fa_mel_batch keeps the plans of small calls in the context (a streaming caller repeats one shape: AudioMelSpectrogram callers in
+    StreamingEouAsrManager.swift:558): interleaved lengths and layouts (more distinct shapes than the cache holds, so entries are evicted
+    and rebuilt), a configuration change and fa_ctx_trim in between must never change a result."""
+    mel = fa.AudioMelSpectrogram(ctx=gpu_ctx)
+    lens = [4000 + 1777 * k for k in range(11)]
+    audio = {n: synth_audio(n, 100 + n % 97) for n in lens}
+    ref = {n: oracle_mod.mel_flat(audio[n]) for n in lens}
+    for rep in range(3):
+        for n in (lens if rep != 1 else lens[::-1]):
+            got, ml, nf = mel.compute_flat(audio[n])
+            r, rml, rnf = ref[n]
+            assert (ml, nf) == (rml, rnf)
+            assert np.max(np.abs(got.reshape(128, nf) - r) / np.maximum(1.0, np.abs(r))) <= 1e-4
+            tr, tml, tnf = mel.compute_flat_transposed(audio[n])           # same audio, other layout: another cache entry
+            np.testing.assert_array_equal(tr.reshape(tnf, 128).T[:, :ml], got.reshape(128, nf)[:, :ml])
+        if rep == 0:
+            gpu_ctx.trim()                                                  # drops the cached plans
+    first, _, nf = mel.compute_flat(audio[lens[0]])
+    again, _, _ = mel.compute_flat(audio[lens[0]])
+    np.testing.assert_array_equal(first, again)
