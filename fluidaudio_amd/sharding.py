@@ -192,11 +192,15 @@ class VbxShard:
         return gamma, pi, hard
 
     def close(self):
-        if getattr(self, "_h", None):
-            self._L.lib().fa_vbx_shard_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.lib().fa_vbx_shard_destroy(h)
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown: the library may already be gone)
+            pass
 
 
 def all_gather_records(dist=None):
