@@ -212,6 +212,11 @@ def all_gather_records(dist=None):
     def gather(chunk):
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
             return chunk
+        if chunk.is_cuda and dist.get_backend() != "nccl":      # a CPU transport (gloo in the tests): staged through the host
+            host = chunk.cpu()
+            parts = [torch.empty_like(host) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, host)
+            return torch.cat(parts).to(chunk.device)
         parts = [torch.empty_like(chunk) for _ in range(dist.get_world_size())]
         dist.all_gather(parts, chunk)
         return torch.cat(parts)

@@ -82,3 +82,53 @@ def test_vbx_shard_argument_checks(fa, gpu_ctx):
     x, init, phi = make_problem(200, 8, 3, 5)
     with pytest.raises(ValueError):
         VbxShard(x[:10], init[:10], 200, 3, phi, 0, 2, ctx=gpu_ctx)   # not the frames this rank holds
+
+
+def _vbx_rank(rank, world, port, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+    import fluidaudio_amd as fa
+    from fluidaudio_amd.sharding import VbxShard, all_gather_records, vbx_refine_sharded, vbx_shard_frames
+    from test_oracle_vbx import make_problem
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, init, phi = make_problem(3000, 64, 6, 8)
+    lo, hi = vbx_shard_frames(len(x), rank, world)
+    shard = VbxShard(x[lo:hi], init[lo:hi], len(x), 6, phi, rank, world, ctx=fa.default_context())
+    gamma, pi, hard, elbos = vbx_refine_sharded(shard, all_gather_records(dist), 20, 1e-4)
+    shard.close()
+    q.put((rank, gamma, pi, hard, elbos))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_vbx_sharded_two_processes_one_gpu(fa, gpu_ctx):
+    """The N > 1 path end to end with real processes: two ranks (both on this box's one GPU, each with its own context), the device
+    kernels of fa_vbx_shard_*, torch.distributed.all_gather for the records (gloo here, staged through the host; "nccl" = RCCL on a
+    multi-GPU node) — gamma, pi, hard labels and every ELBO equal the single-device fa_vbx_refine bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    from test_oracle_vbx import make_problem
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_vbx_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    x, init, phi = make_problem(3000, 64, 6, 8)
+    one = fa.VBxClustering(phi, ctx=gpu_ctx).refine(x, init)
+    assert got[0][4] == got[1][4] == one.elbos
+    assert np.array_equal(np.concatenate([got[0][1], got[1][1]]), one.gamma)
+    assert np.array_equal(got[0][2], one.pi) and np.array_equal(got[1][2], one.pi)
+    assert np.concatenate([got[0][3], got[1][3]]).tolist() == one.hard_clusters[0]
