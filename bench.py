@@ -456,7 +456,20 @@ def vbx_sharded_leg(fa, ctx, torch, dist, rank, world, hours=64.0):
     parts = [frames(z) for z in range(rank * zn, (rank + 1) * zn)]
     x = np.concatenate([p[0] for p in parts]); init = np.concatenate([p[1] for p in parts])
     assert x.shape[0] == hi - lo
-    shard = VbxShard(x, init, T, K, phi, rank, world, ctx=ctx)
+    err = None
+    try:                                                  # local set-up: a rank that fails here must not leave the others inside a collective
+        shard = VbxShard(x, init, T, K, phi, rank, world, ctx=ctx)
+    except Exception as e:  # noqa: BLE001
+        err, shard = repr(e), None
+    if dist is not None:
+        okf = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if okf.item() != 1.0:
+            if shard is not None:
+                shard.close()
+            return {"error": err or "another rank failed to set its shard up"}
+    elif err:
+        return {"error": err}
     gather = all_gather_records(dist) if dist is not None else (lambda c: c)
     vbx_refine_sharded(shard, gather, 2, 0.0)            # warm-up (RCCL set-up, first launches)
     shard.close()
