@@ -749,8 +749,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("FA_BENCH_BACKEND", "nccl")      # "gloo": a rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
+        if backend != "nccl":
+            local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
     if args.gpus != world and rank == 0 and world > 1:
