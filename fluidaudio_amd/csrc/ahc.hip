@@ -48,6 +48,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <thread>
+
 #include "fa_common.h"
 #include "ahc_reforder.h"
 
@@ -2178,11 +2180,59 @@ fa_status ahc_batch_once(fa_ctx *ctx, int count, const double *const *d_data, co
 // allocation, an event, a copy, a graph replay) marks EVERY problem that was to run with that failure — round 2 left them at SUCCESS
 // and the callers went on to cut dendrograms that were never written.  When the combined workspace of the batch (sum of N_k^2 * 8 B)
 // does not fit, the batch is split in halves down to single problems before anything is reported as ALLOCATION_FAILURE.
+namespace {
+// A few LARGE problems: their merge chains run CONCURRENTLY, problem 0 on the caller's context and every other one on a helper context
+// (own stream, own workspace, a host thread each) — not as one batched chain.  The chain of a large problem is latency-bound (N - 1
+// dependent launches on ~N/256 of the 256 CUs, one wavefront per SIMD), so independent chains overlap almost freely: two recordings of
+// 43 200 embeddings take 0.29 s this way against 0.36 s as one batched chain and 0.50 s one after the other; four take 0.37 s (one
+// hardware queue each: GPU_MAX_HW_QUEUES >= 8 in the process environment helps, profiles/r03_e2e_in_flight.json).  Many SMALL problems
+// are the opposite case (a chain of a 5 400-point problem occupies 22 CUs): those stay batched.
+constexpr int kInFlightMax = 4;
+constexpr size_t kInFlightMinN = 16384;
+fa_status ahc_batch_in_flight(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
+                              fa_ahc_stats *stats, fa_status *sts) {
+    for (int k = 1; k < count; ++k) {
+        fa_ctx *&h = ctx->helpers[k - 1];
+        if (!h) {
+            const fa_status st = fa_ctx_create(ctx->device, nullptr, &h);
+            if (st != FA_SUCCESS) { h = nullptr; return fa::set_error(ctx, st, "ahc: cannot create a helper context"); }
+            h->ws_limit = ctx->ws_limit;
+            h->ws_cap = ctx->ws_cap;
+        }
+    }
+    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the inputs were produced on the caller's stream
+    std::vector<std::thread> threads;
+    for (int k = 1; k < count; ++k)
+        threads.emplace_back([&, k]() {
+            fa_ctx *h = ctx->helpers[k - 1];
+            fa::DeviceGuard guard(h->device);
+            sts[k] = fa::ahc_run_device(h, d_data[k], n[k], d, d_Z[k], mode, stats ? &stats[k] : nullptr, false);
+        });
+    sts[0] = fa::ahc_run_device(ctx, d_data[0], n[0], d, d_Z[0], mode, stats ? &stats[0] : nullptr, false);
+    for (auto &t : threads) t.join();
+    fa_status first = sts[0];
+    for (int k = 1; k < count; ++k) {
+        if (sts[k] == FA_ALLOCATION_FAILURE) {   // HBM pressure: this one runs alone on the caller's context (whose workspace is free again)
+            (void)fa_ctx_trim(ctx->helpers[k - 1]);
+            sts[k] = fa::ahc_run_device(ctx, d_data[k], n[k], d, d_Z[k], mode, stats ? &stats[k] : nullptr, false);
+        }
+        if (sts[k] != FA_SUCCESS && ctx->last_error.empty()) ctx->last_error = ctx->helpers[k - 1]->last_error;
+        if (first == FA_SUCCESS) first = sts[k];
+    }
+    return first;
+}
+}  // namespace
+
 fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
                                    fa_ahc_stats *stats, fa_status *statuses) {
     if (count <= 0) return FA_SUCCESS;
     std::vector<fa_status> local(static_cast<size_t>(count), FA_SUCCESS);
     fa_status *sts = statuses ? statuses : local.data();
+    {
+        bool large = count >= 2 && count <= kInFlightMax && getenv("FA_AHC_NO_IN_FLIGHT") == nullptr;
+        for (int k = 0; k < count && large; ++k) large = n[k] >= kInFlightMinN;
+        if (large) return ahc_batch_in_flight(ctx, count, d_data, n, d, d_Z, mode, stats, sts);
+    }
     bool completed = false;
     const fa_status st = ahc_batch_once(ctx, count, d_data, n, d, d_Z, mode, stats, sts, &completed);
     if (completed) return st;

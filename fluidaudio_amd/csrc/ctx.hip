@@ -94,6 +94,7 @@ fa_status fa_ctx_create(int device, void *stream, fa_ctx **out) {
 
 void fa_ctx_destroy(fa_ctx *ctx) {
     if (!ctx) return;
+    for (auto &h : ctx->helpers) { if (h) fa_ctx_destroy(h); h = nullptr; }
     { std::lock_guard<std::mutex> lock(g_registry_mutex); g_registry.erase(std::remove(g_registry.begin(), g_registry.end(), ctx), g_registry.end()); }
     fa::DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -113,6 +114,7 @@ void fa_ctx_destroy(fa_ctx *ctx) {
 // fa_ctx_workspace_bytes reports what is cached.  The calling thread must be the one using the context (contexts are not shared).
 fa_status fa_ctx_set_workspace_limit(fa_ctx *ctx, size_t bytes) {
     if (!ctx) return FA_INVALID_ARGUMENT;
+    for (fa_ctx *h : ctx->helpers) if (h) (void)fa_ctx_set_workspace_limit(h, bytes);
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     ctx->ws_limit = bytes;
     if (!ctx->ws_busy && ctx->ahc_ws && ctx->ahc_ws_bytes > bytes) free_caches_locked(ctx, false);
@@ -121,6 +123,7 @@ fa_status fa_ctx_set_workspace_limit(fa_ctx *ctx, size_t bytes) {
 
 fa_status fa_ctx_set_workspace_cap(fa_ctx *ctx, size_t bytes) {
     if (!ctx) return FA_INVALID_ARGUMENT;
+    for (fa_ctx *h : ctx->helpers) if (h) (void)fa_ctx_set_workspace_cap(h, bytes);
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     ctx->ws_cap = bytes;
     return FA_SUCCESS;
@@ -128,6 +131,7 @@ fa_status fa_ctx_set_workspace_cap(fa_ctx *ctx, size_t bytes) {
 
 fa_status fa_ctx_trim(fa_ctx *ctx) {
     if (!ctx) return FA_INVALID_ARGUMENT;
+    for (fa_ctx *h : ctx->helpers) if (h) (void)fa_ctx_trim(h);
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     if (ctx->ws_busy) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "trim: the context is inside a linkage call");
     free_caches_locked(ctx, true);
@@ -138,7 +142,9 @@ fa_status fa_ctx_trim(fa_ctx *ctx) {
 size_t fa_ctx_workspace_bytes(const fa_ctx *ctx) {
     if (!ctx) return 0;
     std::lock_guard<std::mutex> lock(g_registry_mutex);
-    return ctx->ahc_ws_bytes + ctx->scratch_bytes;
+    size_t total = ctx->ahc_ws_bytes + ctx->scratch_bytes;
+    for (const fa_ctx *h : ctx->helpers) if (h) total += h->ahc_ws_bytes + h->scratch_bytes;
+    return total;
 }
 
 fa_status fa_ctx_synchronize(fa_ctx *ctx) {

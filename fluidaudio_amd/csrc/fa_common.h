@@ -32,6 +32,9 @@ struct fa_ctx {
     hipEvent_t ahc_ev[3] = {nullptr, nullptr, nullptr};
     void *ahc_graph = nullptr;                 // owned by ahc.hip (ahc_graph_free releases it)
     void (*ahc_graph_free)(void *) = nullptr;
+    // linkage batches of a few LARGE problems run their merge chains concurrently, one per helper context (own stream, own workspace): see
+    // ahc_run_device_batch.  Created on first use, trimmed and destroyed with this context.
+    fa_ctx *helpers[3] = {nullptr, nullptr, nullptr};
     // mel: plans of small host-pointer calls (tables + geometry on the device) are kept (mel.hip) — a streaming caller repeats one shape
     void *mel_cache = nullptr;
     void (*mel_cache_free)(void *) = nullptr;

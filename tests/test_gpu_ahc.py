@@ -309,3 +309,28 @@ def test_more_than_65536_points_takes_the_many_record_path(fa, gpu_ctx):
     assert bad.size == 0, f"first differing row {bad[:3]}: {z[bad[:1]]} vs {z2[bad[:1]]}; stats {stats}"
     gpu_ctx.trim()
     torch.cuda.empty_cache()
+
+
+def test_batch_of_large_problems_runs_chains_in_flight(fa, gpu_ctx, monkeypatch):
+    """fa_ahc_linkage_batch with 2 .. 4 problems of >= 16 384 points: each merge chain runs on its own helper context concurrently (not as one
+    batched chain).  Every dendrogram equals the single-problem call bit for bit; the helper workspaces count towards
+    fa_ctx_workspace_bytes and go with fa_ctx_trim."""
+    import torch
+    rng = np.random.default_rng(77)
+    probs = [rng.standard_normal((n, 16)) for n in (17000, 16500, 18000)]
+    singles = [fa.linkage(x, ctx=gpu_ctx)[1] for x in probs]
+    gpu_ctx.trim()
+    st, zs, stats = fa.linkage_batch(probs, ctx=gpu_ctx, return_stats=True)
+    assert list(st) == [0, 0, 0]
+    for z, zr, s in zip(zs, singles, stats):
+        np.testing.assert_array_equal(z, zr)
+        assert s["merges"] == len(zr)
+    one = 17000 * 17000 * 8
+    assert gpu_ctx.workspace_bytes() > 2.5 * one          # three workspaces are cached: the context's and two helpers'
+    monkeypatch.setenv("FA_AHC_NO_IN_FLIGHT", "1")         # the batched chain gives the same dendrograms
+    st2, zs2 = fa.linkage_batch(probs, ctx=gpu_ctx)
+    for z, zr in zip(zs2, singles):
+        np.testing.assert_array_equal(z, zr)
+    gpu_ctx.trim()
+    assert gpu_ctx.workspace_bytes() < (1 << 26)
+    torch.cuda.empty_cache()
