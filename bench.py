@@ -363,10 +363,11 @@ def e2e_many_leg(fa, ctx, torch, recordings=16, hours_each=1.0, speakers=8):
     st, out = fa.cluster_embeddings_batch(recs, phi, ctx=ctx)
     t_cl = time.perf_counter() - t0
     t0 = time.perf_counter()
-    seq = [fa.cluster_embeddings(e, r, c, phi, ctx=ctx) for e, r, c in recs[:4]]
-    t_seq4 = time.perf_counter() - t0
+    n_seq = min(4, recordings)
+    seq = [fa.cluster_embeddings(e, r, c, phi, ctx=ctx) for e, r, c in recs[:n_seq]]
+    t_seq4 = (time.perf_counter() - t0) * 4 / n_seq
     pure = all(s == 0 and len(set(zip(t.tolist(), o.assignments))) == speakers for s, t, o in zip(st, truth, out))
-    same = all(a.assignments == b.assignments for a, b in zip(seq, out[:4]))
+    same = all(a.assignments == b.assignments for a, b in zip(seq, out[:n_seq]))
     hours = recordings * hours_each
     return {"recordings": recordings, "hours_each": hours_each, "embeddings_per_recording": len(truth[0]), "mel_s": t_mel, "cluster_batch_s": t_cl,
             "cluster_sequential_s_extrapolated": t_seq4 * recordings / 4, "labels_match_speakers": bool(pure), "equals_single_calls": bool(same),
