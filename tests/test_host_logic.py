@@ -141,3 +141,30 @@ def test_htk_filterbank_and_config_validation(fa):
     cfg.filterbank = None
     for n in (1, 255, 256, 103936):
         assert fa.lib().fa_mel_num_frames(C.byref(cfg), n) == 1 + n // 256
+
+
+def test_vbx_shard_geometry_needs_no_gpu(fa):
+    """fa_vbx_shard_range / _chunk_doubles / _slices (host arithmetic of the sharded VBx protocol) and their Python mirror: the ranks of a
+    world cover [0, T) without gaps in rank order, own whole slices of ceil(T / 64) frames, and a world size that does not divide 64 owns
+    nothing (create refuses it)."""
+    from fluidaudio_amd import _lib as L
+    from fluidaudio_amd.sharding import VBX_SLICES, vbx_shard_frames
+    lib = L.lib()
+    assert lib.fa_vbx_shard_slices() == VBX_SLICES == 64
+    for T in (1, 63, 64, 65, 1000, 43200, 345600):
+        per = -(-T // 64)
+        for world in (1, 2, 4, 8, 16, 32, 64):
+            end = 0
+            for rank in range(world):
+                lo, hi = C.c_int64(), C.c_int64()
+                lib.fa_vbx_shard_range(T, rank, world, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == vbx_shard_frames(T, rank, world)
+                assert lo.value == end and (lo.value % per == 0 or lo.value == T)
+                end = hi.value
+            assert end == T
+    lo, hi = C.c_int64(7), C.c_int64(7)
+    lib.fa_vbx_shard_range(1000, 0, 3, C.byref(lo), C.byref(hi))
+    assert (lo.value, hi.value) == (0, 0)
+    assert lib.fa_vbx_shard_chunk_doubles(24, 128, 8) == 8 * (24 * 129 + 1)
+    assert lib.fa_vbx_shard_chunk_doubles(24, 128, 3) == 0
+    assert lib.fa_vbx_shard_chunk_doubles(24, 128, 1) * 8 == 64 * (24 * 129 + 1) * 8   # the all-gather of one iteration, in bytes
