@@ -36,6 +36,13 @@ public:
     Context &operator=(const Context &) = delete;
     fa_ctx *handle() const { return h_; }
     void check(fa_status st, const char *where) const { if (st != FA_SUCCESS) throw Error(st, where, fa_ctx_last_error(h_)); }
+    // Memory policy of the cached linkage workspace (N^2 * 8 bytes: 15 GB at 43 200 embeddings): keep at most `bytes` between calls /
+    // refuse calls that need more than `bytes` (ALLOCATION_FAILURE = the reference's status 4: AHCClustering degrades to singletons) /
+    // release everything cached now / what is cached (helper contexts of in-flight batches included).
+    void setWorkspaceLimit(size_t bytes) { check(fa_ctx_set_workspace_limit(h_, bytes), "fa_ctx_set_workspace_limit"); }
+    void setWorkspaceCap(size_t bytes) { check(fa_ctx_set_workspace_cap(h_, bytes), "fa_ctx_set_workspace_cap"); }
+    void trim() { check(fa_ctx_trim(h_), "fa_ctx_trim"); }
+    size_t workspaceBytes() const { return fa_ctx_workspace_bytes(h_); }
 private:
     fa_ctx *h_ = nullptr;
 };
