@@ -894,6 +894,8 @@ def main():
         torch.cuda.empty_cache()
         try:
             line["e2e_8h_x4_in_flight"] = e2e_in_flight_leg(fa, torch)
+            line["config"]["recordings_in_flight"] = ("1 (value = one 8 h recording per step: the latency view); with 4 such recordings in flight on the same GPU: "
+                                                      f"{line['e2e_8h_x4_in_flight']['audio_hours_per_s']:.1f} audio-hours/s (e2e_8h_x4_in_flight, every result digest-checked)")
         except Exception as e:  # noqa: BLE001
             line["e2e_8h_x4_in_flight"] = {"error": repr(e)}
         torch.cuda.empty_cache()
