@@ -53,3 +53,26 @@ def test_selection_logic_reproduces_the_reference_row_for_row(oracle_mod, emul, 
     z = emul(x)
     bad = np.nonzero((z != zr).any(axis=1))[0]
     assert bad.size == 0, f"{name}: first differing row {bad[0]} of {len(z)}: emulation {z[bad[0]]} reference {zr[bad[0]]}"
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_selection_logic_on_random_tie_heavy_inputs(oracle_mod, emul, seed):
+    """Randomised: size, dimension, grid step, duplication rate and a mirror are drawn per seed — low-entropy inputs whose distance
+    multisets are full of exact ties (often overlapping ones).  Row for row against the reference build."""
+    if not oracle_mod.ref_available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(1000 + seed)
+    n, d = int(rng.integers(3, 260)), int(rng.integers(1, 7))
+    step = float(rng.choice([1.0, 0.5, 0.25, 1 / 3, 1 / 64]))
+    x = np.round(rng.standard_normal((n, d)) * rng.choice([1.0, 2.0, 4.0]) / step) * step
+    if rng.random() < 0.5:                                   # duplicated rows
+        k = max(1, n // 3)
+        x[rng.integers(0, n, k)] = x[rng.integers(0, n, k)]
+    if rng.random() < 0.3:                                   # a mirrored copy far away: every intra-copy distance occurs twice
+        x = np.vstack([x, -x + 50.0])
+    x = np.ascontiguousarray(x[rng.permutation(len(x))], np.float64)
+    st, zr = oracle_mod.linkage_ref(x)
+    assert st == 0
+    z = emul(x)
+    bad = np.nonzero((z != zr).any(axis=1))[0]
+    assert bad.size == 0, f"seed {seed} (n {len(x)}, d {d}, step {step}): first differing row {bad[0]}: emulation {z[bad[0]]} reference {zr[bad[0]]}"
