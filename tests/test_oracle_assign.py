@@ -42,3 +42,20 @@ def test_assignment_is_optimal_on_random_chunks(oracle_mod):
             best = max(best, tot)
         tot = sum(sc[r, c] for r, c in enumerate(got) if c >= 0)
         assert abs(tot - best) < 1e-5 and len({c for c in got if c >= 0}) == sum(c >= 0 for c in got)
+
+
+def test_assignment_total_equals_scipy_optimum_on_larger_matrices(oracle_mod):
+    """An independent solver (scipy.optimize.linear_sum_assignment, maximising) reaches the same TOTAL on matrices too large for the
+    permutation check above — rectangular both ways, up to the 3-local-speaker x many-centroid shape of a diarization chunk
+    (HungarianAssignment.swift:12-60; which of several optimal assignments is returned is the restatement's business, the total is not)."""
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(7)
+    for rows, cols in ((12, 12), (3, 40), (40, 3), (30, 30), (7, 19), (25, 8), (1, 9), (64, 64)):
+        for _ in range(3):
+            sc = rng.random((rows, cols))
+            got = oracle_mod.max_score_assignment(sc)
+            used = [c for c in got if c >= 0]
+            assert len(set(used)) == len(used) == min(rows, cols)
+            tot = sum(sc[r, c] for r, c in enumerate(got) if c >= 0)
+            ri, ci = linear_sum_assignment(sc, maximize=True)
+            assert abs(tot - sc[ri, ci].sum()) < 1e-4 * min(rows, cols), (rows, cols, tot, sc[ri, ci].sum())
