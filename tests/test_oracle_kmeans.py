@@ -100,3 +100,26 @@ def test_empty_cluster_reseed_keeps_k():
 ])
 def test_speaker_constraints_resolve(args, expect):
     assert oracle.speaker_constraints(*args) == expect
+
+
+def test_result_is_a_lloyd_fixed_point_and_matches_sklearn_on_separated_data(oracle_mod):
+    """An independent implementation (scikit-learn): (1) started from the restatement's final centroids, one more Lloyd step of sklearn
+    on the L2-normalised rows (KMeansClustering.swift:65, 109 normalise first; centroids and inertia live in that space) moves nothing —
+    labels and centroids are a fixed point of the algorithm KMeansClustering.swift:133-238 runs; (2) on well separated
+    clusters best-of-10 finds the same partition and inertia as sklearn's own best-of-10 (the draws of the two differ by construction: the
+    reference's are pinned nowhere, §2)."""
+    from sklearn.cluster import KMeans
+    rng = np.random.default_rng(4)
+    k, d = 6, 32
+    cen = rng.standard_normal((k, d)) * 6.0
+    x = cen[rng.integers(0, k, 900)] + rng.standard_normal((900, d))
+    lab, c, best, inert = oracle_mod.kmeans_ninit(x, k, 100, 10, 0)
+    assert c.shape == (k, d) and len(set(lab.tolist())) == k
+    xn = x / np.linalg.norm(x, axis=1, keepdims=True)
+    step = KMeans(n_clusters=k, init=c, n_init=1, max_iter=1, algorithm="lloyd", tol=0.0).fit(xn)
+    assert np.array_equal(step.labels_, lab)
+    np.testing.assert_allclose(step.cluster_centers_, c, rtol=0, atol=1e-9)
+    own = KMeans(n_clusters=k, n_init=10, random_state=0, algorithm="lloyd").fit(xn)
+    pairs = set(zip(lab.tolist(), own.labels_.tolist()))
+    assert len(pairs) == k                                            # same partition up to the names of the clusters
+    assert abs(float(np.nanmin(inert)) - own.inertia_) <= 1e-6 * own.inertia_
