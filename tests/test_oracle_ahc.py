@@ -122,3 +122,34 @@ def test_committed_golden_matches_reference_build(oracle_mod):
         np.testing.assert_array_equal(zz, z)
         assert same_partition(oracle_mod.ahc_cut(zz, x.shape[0], thr), lab)
     assert len(set(g["labels_m"].tolist())) == 12  # the mixture recovers its 12 speakers at thr 0.6
+
+
+def _merge_sets(z, n):
+    """{frozenset(leaves of the merged cluster): height} of a SciPy-style linkage matrix — independent of the order of its rows."""
+    mem = [frozenset([i]) for i in range(n)]
+    out = {}
+    for a, b, h, s in z:
+        m = mem[int(a)] | mem[int(b)]
+        assert len(m) == int(s)
+        mem.append(m)
+        out[m] = float(h)
+    return out
+
+
+def test_scipy_centroid_linkage_is_the_same_tree(oracle_mod):
+    """Second opinion: scipy.cluster.hierarchy.linkage(method="centroid") is another implementation of greedy centroid
+    linkage (Lance-Williams updates on the condensed distance matrix, rows SORTED by height afterwards; the reference keeps centroids and
+    emits rows in merge order, FastClusterWrapper.cpp:169-192).  On tie-free input both describe the same tree: the same clusters are
+    formed, at the same heights up to the rounding of the two formulations.  SciPy relabels clusters after sorting, so the comparison is
+    over the SETS of leaves each merge creates, not over row contents."""
+    from scipy.cluster.hierarchy import linkage
+    rng = np.random.default_rng(11)
+    for n, d, mix in ((60, 8, False), (250, 32, False), (400, 64, True)):
+        x = speaker_mixture(n, d, 9, 0.05, seed=n) if mix else rng.standard_normal((n, d))
+        x = oracle_mod.ahc_normalize(x)
+        st, z = oracle_mod.linkage_ref(x)
+        assert st == 0
+        a, b = _merge_sets(z, n), _merge_sets(linkage(x, method="centroid", metric="euclidean"), n)
+        assert a.keys() == b.keys()
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, a[k]), (len(k), a[k], b[k])
