@@ -26,6 +26,14 @@ def test_header_and_library_agree(fa):
     assert b"gfx950" in lib.fa_version()
 
 
+def test_integration_lists_every_symbol():
+    """INTEGRATION.md section 5 names every declared entry next to the reference seam it serves."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    index = text[text.index("## 5. Symbol index"):]
+    missing = sorted(n for n in declared_symbols() if f"`{n}`" not in index)
+    assert not missing, missing
+
+
 def test_status_enum_matches_reference_numbering():
     text = open(os.path.join(ROOT, "include", "FastClusterWrapper.h")).read()
     pairs = dict(re.findall(r"FASTCLUSTER_WRAPPER_(\w+)\s*=\s*(\d+)", text))
