@@ -26,6 +26,16 @@ def kernel_body(text, pattern):
     return name, text[i:j]
 
 
+def strip_preload_header(body):
+    """With -amdgpu-kernarg-preload-count the kernel starts with a compatibility header (s_load of the preloaded arguments, a wait, s_branch,
+    .p2align 8) for firmware without preloading; hardware that preloads enters 256 bytes further on and never runs it."""
+    m = re.search(r"\n\s*s_branch\s+\S+\s*\n\s*\.p2align\s+8\s*\n", body)
+    if m and m.start() < 2000 and "s_load" in body[:m.start()] and "v_" not in body[:m.start()].split(":", 1)[-1]:
+        head = body[:body.index("\n") + 1]
+        return head + body[m.end():], True
+    return body, False
+
+
 def listing(body):
     out, k = [], 0
     for line in body.split("\n"):
@@ -74,6 +84,7 @@ def main():
     a = ap.parse_args()
     text = open(a.asm).read()
     name, body = kernel_body(text, a.kernel)
+    body, preload = strip_preload_header(body)
     lst = listing(body)
     if a.listing:
         with open(a.listing, "w") as f:
@@ -81,6 +92,8 @@ def main():
                 f.write(t + "\n" if k is None else f"{k:6d}  {t}\n")
     meta = {m.group(1): m.group(2) for m in re.finditer(r"; (NumVgprs|NumAgprs|ScratchSize|Occupancy|NumSgprs): (\d+)", text[text.index(name + ":"):text.index(name + ":") + len(body) + 4000])}
     print(f"kernel {name[:100]}\n  {sum(1 for k, _ in lst if k is not None)} instructions; {meta}")
+    if preload:
+        print("  (kernel-argument preload header skipped: the listing starts at the entry point the hardware uses)")
     # 1. vmcnt drains
     print("\nvector-memory counter (static program order; L = loads, S = stores / atomics issued since the last vmcnt(0)):")
     loads = stores = 0
