@@ -168,3 +168,24 @@ def test_vbx_shard_geometry_needs_no_gpu(fa):
     assert lib.fa_vbx_shard_chunk_doubles(24, 128, 8) == 8 * (24 * 129 + 1)
     assert lib.fa_vbx_shard_chunk_doubles(24, 128, 3) == 0
     assert lib.fa_vbx_shard_chunk_doubles(24, 128, 1) * 8 == 64 * (24 * 129 + 1) * 8   # the all-gather of one iteration, in bytes
+
+
+def test_default_configs_equal_the_reference_defaults(fa):
+    """The *_default_config entries are pure host functions; their values are the reference's defaults: AudioMelSpectrogram.init
+    (Shared/AudioMelSpectrogram.swift:59-70), TdtConfig (TdtConfig.swift:13-26) and OfflineDiarizerConfig.default as its own test pins it
+    (OfflineModuleTests.swift:10-21: threshold 0.6, Fa 0.07, Fb 0.8, 20 iterations)."""
+    L = fa._lib
+    m = L.MelConfig()
+    fa.lib().fa_mel_default_config(C.byref(m))
+    assert (m.sample_rate, m.n_mels, m.n_fft, m.hop, m.win, m.pad_to) == (16000, 128, 512, 160, 400, 0)
+    assert m.preemph == np.float32(0.97) and m.log_floor == np.float32(2.0 ** -24)
+    assert (m.floor_mode, m.window_periodic, m.padding_mode, m.layout) == (L.MEL_FLOOR_ADDITIVE, 0, L.MEL_PAD_CENTER, 0)
+    t = L.TdtConfig()
+    fa.lib().fa_tdt_default_config(C.byref(t))
+    assert (t.blank_id, t.max_symbols_per_step, t.max_tokens_per_chunk, t.consecutive_blank_limit) == (8192, 10, 150, 5)
+    assert t.n_duration_bins == 5 and list(t.duration_bins)[:5] == [0, 1, 2, 3, 4]
+    o = L.OfflineClusterConfig()
+    fa.lib().fa_offline_cluster_default_config(C.byref(o))
+    assert (o.clustering_threshold, o.warm_start_fa, o.warm_start_fb, o.max_vbx_iterations) == (0.6, 0.07, 0.8, 20)
+    assert o.convergence_tolerance == 1e-4 and o.constrained_assignment == 1                       # VBxClustering.swift:653-659
+    assert (o.num_speakers, o.min_speakers, o.max_speakers) == (-1, -1, -1)                           # nil: no speaker-count constraint
