@@ -38,6 +38,19 @@ class OfflineClusteringConfig:  # OfflineDiarizerTypes.swift:155-163,189-192
     min_speakers: int | None = None
     max_speakers: int | None = None
 
+    def validate(self) -> None:
+        """The clustering / VBx guards of OfflineDiarizerConfig.validate (OfflineDiarizerTypes.swift:357-408; the reference throws
+        OfflineDiarizationError.invalidConfiguration with these messages before any audio is touched)."""
+        t = self.clustering_threshold
+        if not (t > 0 and t <= 2.0):                         # distances between unit rows live in [0, 2] (:358-364); NaN fails too
+            raise ValueError(f"invalidConfiguration: clustering.threshold must be within (0, 2], got {t}")
+        if not (self.warm_start_fa > 0 and self.warm_start_fb > 0):
+            raise ValueError(f"invalidConfiguration: clustering warm-start Fa/Fb must be positive (Fa={self.warm_start_fa}, Fb={self.warm_start_fb})")
+        if not self.max_vbx_iterations > 0:
+            raise ValueError(f"invalidConfiguration: maxVBxIterations must be > 0, got {self.max_vbx_iterations}")
+        if not self.convergence_tolerance > 0:
+            raise ValueError("invalidConfiguration: convergenceTolerance must be positive")
+
 
 @dataclass
 class ClusteringResult:
@@ -66,6 +79,7 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, config: Offline
     ``info`` its counters."""
     import ctypes as C
     cfg = config or OfflineClusteringConfig()
+    cfg.validate()
     ctx = ctx or L.default_context()
     on_device = hasattr(embedding256, "data_ptr")          # torch CUDA tensors: device_pointers = 1, nothing is uploaded
     if on_device:
@@ -142,6 +156,7 @@ def cluster_embeddings_batch(recordings, phi, config: OfflineClusteringConfig | 
     Returns (statuses, [ClusteringResult | None]) — per recording identical to cluster_embeddings()."""
     import ctypes as C
     cfg = config or OfflineClusteringConfig()
+    cfg.validate()
     ctx = ctx or L.default_context()
     recs = [(np.ascontiguousarray(e, np.float32), np.ascontiguousarray(r, np.float64), np.ascontiguousarray(c, np.int32)) for e, r, c in recordings]
     k = len(recs)
@@ -186,6 +201,7 @@ def cluster_embeddings_stagewise(embedding256, rho128, chunk_indices, phi, confi
                                  ctx: L.Context | None = None) -> ClusteringResult:
     import time
     cfg = config or OfflineClusteringConfig()
+    cfg.validate()
     ctx = ctx or L.default_context()
     t = {}
     emb = np.asarray(embedding256, np.float32).astype(np.float64)          # Float -> Double widening (:286)

@@ -362,6 +362,13 @@ struct OfflineClusteringConfig {   // OfflineDiarizerTypes.swift:155-163,189-192
     int maxVbxIterations = 20;
     bool constrainedAssignment = true;
     std::optional<int> numSpeakers, minSpeakers, maxSpeakers;
+    // the clustering / VBx guards of OfflineDiarizerConfig.validate (OfflineDiarizerTypes.swift:357-408: invalidConfiguration)
+    void validate() const {
+        if (!(clusteringThreshold > 0 && clusteringThreshold <= 2.0)) throw Error(FA_INVALID_ARGUMENT, "invalidConfiguration: clustering.threshold must be within (0, 2]");
+        if (!(warmStartFa > 0 && warmStartFb > 0)) throw Error(FA_INVALID_ARGUMENT, "invalidConfiguration: clustering warm-start Fa/Fb must be positive");
+        if (!(maxVbxIterations > 0)) throw Error(FA_INVALID_ARGUMENT, "invalidConfiguration: maxVBxIterations must be > 0");
+        if (!(convergenceTolerance > 0)) throw Error(FA_INVALID_ARGUMENT, "invalidConfiguration: convergenceTolerance must be positive");
+    }
 };
 struct OfflineClusteringResult {
     std::vector<int> assignments;   // -2: slot dropped by the constrained assignment
@@ -370,6 +377,7 @@ struct OfflineClusteringResult {
 };
 inline OfflineClusteringResult clusterEmbeddings(Context &ctx, const std::vector<std::vector<float>> &embeddings, const Matrix &rhoFeatures, const std::vector<int> &chunkIndices,
                                                  const std::vector<double> &phi, const OfflineClusteringConfig &config = {}) {
+    config.validate();
     if (embeddings.empty()) throw Error(FA_INVALID_ARGUMENT, "noSpeechDetected");   // :281-283
     const size_t n = embeddings.size(), d = embeddings[0].size();
     std::vector<float> e(n * d);
@@ -399,6 +407,7 @@ inline OfflineClusteringResult clusterEmbeddings(Context &ctx, const std::vector
 struct OfflineRecording { std::vector<std::vector<float>> embeddings; Matrix rhoFeatures; std::vector<int> chunkIndices; };
 inline std::vector<std::optional<OfflineClusteringResult>> clusterEmbeddingsBatch(Context &ctx, const std::vector<OfflineRecording> &recordings, const std::vector<double> &phi,
                                                                                    const OfflineClusteringConfig &config = {}) {
+    config.validate();
     const size_t count = recordings.size();
     std::vector<std::optional<OfflineClusteringResult>> out(count);
     if (count == 0) return out;

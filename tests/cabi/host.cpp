@@ -213,6 +213,13 @@ int main(int argc, char **argv) {
         CHECK(lm.unigramCount() == 1);
         CHECK(SpeakerCountConstraints::resolve(100, 0, std::nullopt, std::nullopt).maxSpeakers == 1);
         CHECK(decodeCtcTokenIds({0, 1}, {{0, std::string(W) + "a"}, {1, std::string(W) + "b"}}) == "a b");
+        // OfflineModuleTests.swift:10-33: the default configuration validates, threshold 2.5 is an invalidConfiguration naming clustering.threshold
+        OfflineClusteringConfig().validate();
+        OfflineClusteringConfig bad;
+        bad.clusteringThreshold = 2.5;
+        bool invalid = false;
+        try { bad.validate(); } catch (const Error &e) { invalid = e.status == FA_INVALID_ARGUMENT && std::string(e.what()).find("clustering.threshold") != std::string::npos; }
+        CHECK(invalid);
         bool threw = false;
         try { Context c(0); } catch (const Error &e) { threw = e.status == FA_RUNTIME_ERROR; }
         std::printf("context without a GPU throws RUNTIME_ERROR: %s\n", threw ? "yes" : "no (a GPU is present)");

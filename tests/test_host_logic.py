@@ -189,3 +189,24 @@ def test_default_configs_equal_the_reference_defaults(fa):
     assert (o.clustering_threshold, o.warm_start_fa, o.warm_start_fb, o.max_vbx_iterations) == (0.6, 0.07, 0.8, 20)
     assert o.convergence_tolerance == 1e-4 and o.constrained_assignment == 1                       # VBxClustering.swift:653-659
     assert (o.num_speakers, o.min_speakers, o.max_speakers) == (-1, -1, -1)                           # nil: no speaker-count constraint
+
+
+def test_clustering_config_guards_of_the_reference(fa):
+    """OfflineDiarizerConfig.validate (OfflineDiarizerTypes.swift:357-408), the clustering / VBx part, as its tests exercise it
+    (OfflineModuleTests.swift:10-33: the default passes, threshold 2.5 throws naming clustering.threshold); the guards fire before
+    any device is touched, so this runs without a GPU."""
+    import pytest
+    fa.OfflineClusteringConfig().validate()
+    x = np.zeros((4, 256), np.float32)
+    for kw, word in ((dict(clustering_threshold=2.5), "clustering.threshold"), (dict(clustering_threshold=0.0), "clustering.threshold"),
+                     (dict(clustering_threshold=float("nan")), "clustering.threshold"), (dict(warm_start_fa=0.0), "Fa/Fb"),
+                     (dict(warm_start_fb=-1.0), "Fa/Fb"), (dict(max_vbx_iterations=0), "maxVBxIterations"),
+                     (dict(convergence_tolerance=0.0), "convergenceTolerance")):
+        cfg = fa.OfflineClusteringConfig(**kw)
+        for call in (lambda: fa.cluster_embeddings(x, np.zeros((4, 128)), np.zeros(4, np.int32), np.ones(128), cfg),
+                     lambda: fa.cluster_embeddings_stagewise(x, np.zeros((4, 128)), np.zeros(4, np.int32), np.ones(128), cfg),
+                     lambda: fa.cluster_embeddings_batch([(x, np.zeros((4, 128)), np.zeros(4, np.int32))], np.ones(128), cfg)):
+            with pytest.raises(ValueError, match="invalidConfiguration") as e:
+                call()
+            assert word in str(e.value)
+    fa.OfflineClusteringConfig(clustering_threshold=2.0).validate()          # the closed end of (0, 2]
