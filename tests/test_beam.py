@@ -58,6 +58,123 @@ def test_arpa_oracle_and_library_agree(fa, oracle_mod):
             assert l2.score(w, p) == float(r2.score(w, p)), (w, p)
 
 
+# ---- CtcDecoderDemoTests.swift: the reference's three demo cases (greedy vs beam vs beam + LM) ---------------------------------------
+DEMO1_VOCAB = {0: W + "patient", 1: W + "has", 2: W + "diabetes", 3: W + "die", 4: W + "beetus", 5: W + "high", 6: W + "blood", 7: W + "pressure"}
+
+
+def _demo_rows(n, *hot):
+    """frames of CtcDecoderDemoTests.swift:27-53 / :99-113: -10 everywhere except the listed (index, value) pairs"""
+    r = [-10.0] * n
+    for i, v in hot:
+        r[i] = v
+    return r
+
+
+DEMO1_LP = ([_demo_rows(9, (0, -1.0))] * 2 + [_demo_rows(9, (8, -1.0))] + [_demo_rows(9, (1, -1.0))] * 2 + [_demo_rows(9, (8, -1.0))] +
+            [_demo_rows(9, (2, -1.5), (3, -1.4))] * 2 + [_demo_rows(9, (8, -1.0))] + [_demo_rows(9, (4, -1.2))] * 2)
+DEMO2_VOCAB = {0: W + "the", 1: W + "cat", 2: W + "sat", 3: W + "dog"}
+DEMO2_LP = ([_demo_rows(5, (0, -1.0))] * 2 + [_demo_rows(5, (4, -1.0))] + [_demo_rows(5, (1, -1.5), (3, -1.4))] * 2 + [_demo_rows(5, (4, -1.0))] +
+            [_demo_rows(5, (2, -1.0))] * 2)
+# the demo models are built in code from NATURAL-log entries (ARPALanguageModel.Entry(logProb:backoff:), :80-87, :163-196)
+MEDICAL_UNI = {"patient": (-1.5, -0.3), "has": (-1.8, -0.2), "diabetes": (-2.2, -0.1), "hypertension": (-2.5, -0.1), "die": (-4.0, -0.5),
+               "beetus": (-5.0, -0.5), "hyper": (-4.5, -0.4), "tension": (-4.3, -0.4)}
+MEDICAL_BI = {"patient": {"has": (-0.3, 0.0)}, "has": {"diabetes": (-0.5, 0.0), "hypertension": (-0.6, 0.0)}}
+CATDOG_UNI = {"the": (-1.0, -0.3), "cat": (-1.5, 0.0), "dog": (-1.5, 0.0), "sat": (-1.5, 0.0)}
+CATDOG_BI = {"the": {"cat": (-0.3, 0.0), "dog": (-2.0, 0.0)}}
+
+
+def oracle_lm(oracle_mod, uni, bi):
+    lm = oracle_mod.ARPALanguageModel()
+    lm.unigrams = {w: (np.float32(p), np.float32(b)) for w, (p, b) in uni.items()}
+    lm.bigrams = {c: {w: (np.float32(p), np.float32(b)) for w, (p, b) in d.items()} for c, d in bi.items()}
+    return lm
+
+
+def _log10_text(v):
+    """a decimal log10 value whose float32 parse times float32(ln 10) rounds to float32(v) — the library takes models as ARPA text
+    (log10), the demo tests hand over natural-log entries"""
+    want, k = np.float32(v), np.float32(np.log(10.0))
+    c = np.float32(want / k)
+    for cand in (c, np.nextafter(c, np.float32(np.inf)), np.nextafter(c, np.float32(-np.inf))):
+        if np.float32(cand * k) == want:
+            return repr(float(cand))
+    return None
+
+
+def arpa_text(uni, bi):
+    """ARPA text of a model given in natural-log entries; (text, exact): exact = every entry reproduces its float32 value bit for bit"""
+    exact, lines = True, ["\\data\\", "", "\\1-grams:"]
+    def field(v):
+        nonlocal exact
+        t = _log10_text(v)
+        if t is None:
+            exact, t = False, repr(float(np.float32(v) / np.float32(np.log(10.0))))
+        return t
+    for w, (p, b) in uni.items():
+        lines.append(f"{field(p)}\t{w}\t{field(b)}")
+    lines += ["", "\\2-grams:"]
+    for c, d in bi.items():
+        for w, (p, b) in d.items():
+            lines.append(f"{field(p)}\t{c}\t{w}")
+    lines += ["", "\\end\\", ""]
+    return "\n".join(lines), exact
+
+
+def test_oracle_reference_demo_cases(oracle_mod):
+    """CtcDecoderDemoTests.swift:11-76 and :80-135: greedy and beam search without a model follow the acoustics ("die beetus", "dog"),
+    the word-level model turns the search to the real words."""
+    o = oracle_mod
+    ids = o.ctc_greedy(np.asarray(DEMO1_LP, np.float32), 8)
+    assert o.decode_ctc_token_ids(ids, DEMO1_VOCAB) == "patient has die beetus"                                     # :56-58
+    assert o.decode_ctc_token_ids(o.ctc_beam_search(DEMO1_LP, DEMO1_VOCAB, None, 10, 0.3, 0.0, 8)[0], DEMO1_VOCAB) == "patient has die beetus"   # :61-66
+    lm = oracle_lm(o, MEDICAL_UNI, MEDICAL_BI)
+    assert o.decode_ctc_token_ids(o.ctc_beam_search(DEMO1_LP, DEMO1_VOCAB, lm, 10, 5.0, 0.0, 8)[0], DEMO1_VOCAB) == "patient has diabetes"       # :69-76
+    assert o.decode_ctc_token_ids(o.ctc_greedy(np.asarray(DEMO2_LP, np.float32), 4), DEMO2_VOCAB) == "the dog sat"    # :115-118
+    lm2 = oracle_lm(o, CATDOG_UNI, CATDOG_BI)
+    assert o.decode_ctc_token_ids(o.ctc_beam_search(DEMO2_LP, DEMO2_VOCAB, lm2, 10, 2.0, 0.0, 4)[0], DEMO2_VOCAB) == "the cat sat"               # :131-137
+
+
+def test_demo_models_as_arpa_text_and_windows_line_endings(fa, oracle_mod):
+    """The library takes a model as ARPA text: the demo models written as log10 text reproduce the natural-log entries (host code, no
+    GPU), and a file with \\r\\n line endings parses like the reference's reader, which trims every line (CtcDecoderDemoTests.swift:139-159)."""
+    for uni, bi in ((MEDICAL_UNI, MEDICAL_BI), (CATDOG_UNI, CATDOG_BI)):
+        text, exact = arpa_text(uni, bi)
+        ref, lib, parsed = oracle_lm(oracle_mod, uni, bi), fa.ARPALanguageModel(text), oracle_mod.ARPALanguageModel.parse(text)
+        assert lib.unigram_count == len(uni) and lib.bigram_context_count == len(bi)
+        words = list(uni) + ["xyzzy"]
+        for w in words:
+            for p in words + [None]:
+                assert lib.score(w, p) == float(parsed.score(w, p))
+                if exact:
+                    assert lib.score(w, p) == float(ref.score(w, p)), (w, p)
+                else:
+                    assert lib.score(w, p) == pytest.approx(float(ref.score(w, p)), rel=3e-7)
+    crlf = "\\data\\\r\nngram 1=2\r\n\r\n\\1-grams:\r\n-1.0\thello\t0.0\r\n-1.0\tworld\t0.0\r\n\r\n\\end\\\r\n"
+    ref, lib = oracle_mod.ARPALanguageModel.parse(crlf), fa.ARPALanguageModel(crlf)
+    assert len(ref.unigrams) == 2 and lib.unigram_count == 2 and {"hello", "world"} == set(ref.unigrams)
+    assert lib.score("hello", None) == float(ref.score("hello", None)) == pytest.approx(-LOG10, rel=1e-6)
+    assert lib.score("world", "hello") == float(ref.score("world", "hello"))
+
+
+def test_reference_arpa_fixture_parses_identically(fa, oracle_mod):
+    """Tests/.../CTC/sample_medical.arpa, the reference's ARPA fixture (read where it lies; not copied): 15 unigrams, 12 bigrams in 5
+    contexts; library and restatement give the same float for every (word, context) pair."""
+    import os
+    path = "/root/reference/Tests/FluidAudioTests/ASR/Parakeet/SlidingWindow/CTC/sample_medical.arpa"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    text = open(path, encoding="utf-8").read()
+    ref, lib = oracle_mod.ARPALanguageModel.parse(text), fa.ARPALanguageModel.load(path)
+    assert len(ref.unigrams) == lib.unigram_count == 15
+    assert len(ref.bigrams) == lib.bigram_context_count == 5 and sum(len(d) for d in ref.bigrams.values()) == 12
+    words = list(ref.unigrams) + ["beetus"]
+    for w in words:
+        for p in words + [None]:
+            assert lib.score(w, p) == float(ref.score(w, p)), (w, p)
+    assert lib.score("pressure", "blood") == pytest.approx(-0.1 * LOG10, rel=1e-6)
+    assert lib.score("diabetes", "doctor") == pytest.approx((-0.2 - 2.2) * LOG10, rel=1e-6)      # backoff of "doctor" + unigram
+
+
 def random_case(rng, T, V, peaky):
     x = rng.standard_normal((T, V)).astype(np.float32) * peaky
     x = x - np.log(np.exp(x.astype(np.float64)).sum(1, keepdims=True)).astype(np.float32)
@@ -95,6 +212,27 @@ def test_reference_cases_on_device(fa, gpu_ctx):
     lp = [[0.0, -100.0, -100.0, -100.0], [-100.0, -1.0, -0.9, -100.0]]
     assert fa.ctc_beam_search(lp, v, None, 10, 0.0, 0.0, 3, ctx=gpu_ctx) == "the dog"
     assert fa.ctc_beam_search(lp, v, lm, 10, 5.0, 0.0, 3, ctx=gpu_ctx) == "the cat"
+
+
+@pytest.mark.gpu
+def test_reference_demo_cases_on_device(fa, gpu_ctx, oracle_mod):
+    """CtcDecoderDemoTests.swift:11-76, :80-135 on the device: the reference's expected strings, and token ids + scores of the restatement."""
+    assert fa.ctc_greedy_decode(DEMO1_LP, DEMO1_VOCAB, blank_id=8, ctx=gpu_ctx) == "patient has die beetus"
+    assert fa.ctc_beam_search(DEMO1_LP, DEMO1_VOCAB, None, 10, 0.3, 0.0, 8, ctx=gpu_ctx) == "patient has die beetus"
+    text, exact = arpa_text(MEDICAL_UNI, MEDICAL_BI)
+    assert exact
+    lm = fa.ARPALanguageModel(text, ctx=gpu_ctx)
+    assert fa.ctc_beam_search(DEMO1_LP, DEMO1_VOCAB, lm, 10, 5.0, 0.0, 8, ctx=gpu_ctx) == "patient has diabetes"
+    assert fa.ctc_greedy_decode(DEMO2_LP, DEMO2_VOCAB, blank_id=4, ctx=gpu_ctx) == "the dog sat"
+    text2, exact2 = arpa_text(CATDOG_UNI, CATDOG_BI)
+    assert exact2
+    lm2 = fa.ARPALanguageModel(text2, ctx=gpu_ctx)
+    assert fa.ctc_beam_search(DEMO2_LP, DEMO2_VOCAB, lm2, 10, 2.0, 0.0, 4, ctx=gpu_ctx) == "the cat sat"
+    for lp, voc, dev_lm, uni, bi, w, blank in ((DEMO1_LP, DEMO1_VOCAB, lm, MEDICAL_UNI, MEDICAL_BI, 5.0, 8), (DEMO2_LP, DEMO2_VOCAB, lm2, CATDOG_UNI, CATDOG_BI, 2.0, 4)):
+        x = np.asarray(lp, np.float32)
+        ids, scores = fa.ctc_beam_search_ids_batch(x[None], voc, dev_lm, 10, w, 0.0, blank, ctx=gpu_ctx)
+        want, total = oracle_mod.ctc_beam_search(x, voc, oracle_lm(oracle_mod, uni, bi), 10, w, 0.0, blank)
+        assert ids[0] == want and scores[0] == pytest.approx(total, rel=2e-6, abs=2e-5)
 
 
 @pytest.mark.gpu
