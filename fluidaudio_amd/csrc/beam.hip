@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "fa_common.h"
+#include "text_util.h"
 
 namespace {
 
@@ -586,14 +587,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
 
 inline uint32_t pow2_at_least(size_t n) { uint32_t c = 16; while (c < n) c <<= 1; return c; }
 
-bool parse_float_full(const std::string &s, float &out) {   // Swift's Float(String)
-    if (s.empty()) return false;
-    char *end = nullptr;
-    const float v = strtof(s.c_str(), &end);
-    if (end != s.c_str() + s.size() || s[0] == ' ') return false;
-    out = v;
-    return true;
-}
+bool parse_float_full(const std::string &s, float &out) { return fa_text::parse_float(s, out); }   // Swift's Float(String)
 
 }  // namespace
 
@@ -629,14 +623,13 @@ fa_status fa_arpa_parse(fa_ctx *ctx, const char *text, int64_t len, fa_arpa_lm *
         std::vector<B2> bs;
         std::unordered_map<std::string, int> contexts;
         std::string section;
-        const std::string ws = " \t\r\n\f\v";
         for (int64_t pos = 0; pos <= len;) {
             int64_t e = pos;
-            while (e < len && text[e] != '\n') ++e;
-            std::string line(text + pos, text + e);
+            while (e < len && text[e] != '\n') ++e;                                              // the reader cuts at the byte \n only (:126)
+            const char *la = text + pos, *lb = text + e;
             pos = e + 1;
-            const size_t a0 = line.find_first_not_of(ws), a1 = line.find_last_not_of(ws);
-            line = a0 == std::string::npos ? std::string() : line.substr(a0, a1 - a0 + 1);   // trimmingCharacters (:131)
+            fa_text::trim(la, lb, fa_text::ws_or_nl_len);                                        // trimmingCharacters(in: .whitespacesAndNewlines) (:131)
+            const std::string line(la, lb);
             if (line.empty() || line.rfind("\\data\\", 0) == 0) continue;                       // :54
             if (line == "\\end\\") break;                                                       // :55
             if (line[0] == '\\') { section = line; continue; }                                  // :56-59

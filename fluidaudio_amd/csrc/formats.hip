@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "fa_common.h"
+#include "text_util.h"
 
 namespace {
 
@@ -52,17 +53,7 @@ void put_u16(uint8_t *p, uint16_t v) { p[0] = v & 255; p[1] = (v >> 8) & 255; }
 uint32_t get_u32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24); }
 uint16_t get_u16(const uint8_t *p) { return static_cast<uint16_t>(p[0] | (p[1] << 8)); }
 
-bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\f' || c == '\v'; }
-
-// Swift's Float(String): the whole field must be a number
-bool parse_float(const std::string &s, float &out) {
-    if (s.empty()) return false;
-    char *end = nullptr;
-    const float v = strtof(s.c_str(), &end);
-    if (end != s.c_str() + s.size()) return false;
-    out = v;
-    return true;
-}
+using fa_text::parse_float;   // Swift's Float(String): the whole field must be a number (text_util.h)
 
 template <class T>
 void append_number(std::string &o, T v) {
@@ -148,21 +139,24 @@ fa_status fa_rttm_parse(const char *text, int64_t len, int32_t strict, fa_rttm_s
     if (!text || len < 0 || !count) return FA_INVALID_ARGUMENT;
     std::vector<fa_rttm_segment> segs;
     int64_t pos = 0;
+    const char *const text_end = text + len;
     while (pos <= len) {
+        // lines: components(separatedBy: .newlines) (RTTMParser.swift:30, SortformerBenchmark.swift:699) — \n, \r, \v, \f, U+0085, U+2028, U+2029
         int64_t e = pos;
-        while (e < len && text[e] != '\n') ++e;
-        int64_t a = pos, b = e;
-        while (a < b && is_space(text[a])) ++a;
-        while (b > a && is_space(text[b - 1])) --b;
-        const std::string line(text + a, text + b);
-        pos = e + 1;
+        int nl = 0;
+        while (e < len && (nl = fa_text::nl_len(text + e, text_end)) == 0) ++e;
+        const char *a = text + pos, *b = text + e;
+        fa_text::trim(a, b, fa_text::ws_len);                  // trimmingCharacters(in: .whitespaces) (:31): Zs + tab
+        const std::string line(a, b);
+        pos = e + (nl > 0 ? nl : 1);
         if (line.empty() || (strict && line[0] == '#')) continue;
+        // fields: split(whereSeparator: \.isWhitespace) (:36) / components(separatedBy: .whitespaces) without the empty ones (:703-705)
         std::vector<std::string> f;
-        for (size_t i = 0; i < line.size();) {
-            while (i < line.size() && is_space(line[i])) ++i;
-            size_t j = i;
-            while (j < line.size() && !is_space(line[j])) ++j;
-            if (j > i) f.emplace_back(line.substr(i, j - i));
+        for (const char *i = line.data(), *le = line.data() + line.size(); i < le;) {
+            for (int k; i < le && (k = fa_text::ws_or_nl_len(i, le)) > 0;) i += k;
+            const char *j = i;
+            while (j < le && fa_text::ws_or_nl_len(j, le) == 0) ++j;
+            if (j > i) f.emplace_back(i, j);
             i = j;
         }
         float start = 0, dur = 0;

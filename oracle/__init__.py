@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import re
 import subprocess
 from dataclasses import dataclass
 
@@ -548,19 +549,29 @@ def wav_pcm16(samples, sample_rate: float, normalize: bool = True) -> bytes:
     return hdr + b"data" + struct.pack("<I", 2 * pcm.size) + pcm.tobytes()
 
 
+# Character classes of the reference's text readers (Foundation / Swift standard library):
+#   CharacterSet.whitespaces = Unicode category Zs + tab; CharacterSet.newlines = U+000A ... U+000D, U+0085, U+2028, U+2029;
+#   Character.isWhitespace (the Unicode White_Space property) = CharacterSet.whitespacesAndNewlines = their union.
+_WS = "\t \u00a0\u1680\u2000\u2001\u2002\u2003\u2004\u2005\u2006\u2007\u2008\u2009\u200a\u202f\u205f\u3000"
+_NL = "\n\x0b\x0c\r\u0085\u2028\u2029"
+_RE_NL = re.compile("[" + _NL + "]")
+_RE_WSNL = re.compile("[" + _WS + _NL + "]+")
+
+
 def rttm_parse(text: str, strict: bool = True):
     """RTTMParser.loadSegments (RTTMParser.swift:22-63) / SortformerBenchmark.loadRTTMGroundTruth (:681-731) -> list of
-    (speaker, start float32, end float32); raises ValueError(line) in strict mode."""
+    (speaker, start float32, end float32); raises ValueError(line) in strict mode.  Lines = components(separatedBy: .newlines),
+    trimmed with .whitespaces; fields split at white space (:36 / :703-705, empty fields dropped); numbers = Float(String)."""
     out = []
-    for raw in text.split("\n"):
-        line = raw.strip(" \t\r\f\v")
+    for raw in _RE_NL.split(text):
+        line = raw.strip(_WS)
         if not line or (strict and line.startswith("#")):
             continue
-        f = line.split()
+        f = [x for x in _RE_WSNL.split(line) if x]
         ok = len(f) >= 8 and f[0] == "SPEAKER"
         if ok:
             try:
-                start, dur = np.float32(f[3]), np.float32(f[4])
+                start, dur = _swift_float(f[3]), _swift_float(f[4])
             except ValueError:
                 ok = False
         if not ok:
@@ -578,11 +589,25 @@ def rttm_parse(text: str, strict: bool = True):
 WORD_BOUNDARY = "▁"          # ASRConstants.sentencePieceWordBoundary
 
 
+_RE_NAN_PAYLOAD = re.compile(r"[+-]?nan\([0-9a-z]*\)\Z", re.I)
+
+
 def _swift_float(s: str):
-    """Float(String) of the Swift standard library: the whole string must be a number, no surrounding whitespace."""
-    if not s or s != s.strip() or "_" in s:
+    """Float(String) of the Swift standard library: the whole string is one number — decimal or hexadecimal ("0x1.8p3"), "inf" /
+    "infinity" / "nan" in any case, optional sign; no surrounding white space, no digit separators, ASCII only.  (Python's float()
+    also takes "1_0", Arabic-Indic digits and surrounding blanks, and no hexadecimal: hence the checks.)"""
+    if not s or not s.isascii() or "_" in s or any(ord(c) <= 32 or ord(c) == 127 for c in s):
         raise ValueError(s)
-    return np.float32(s)
+    body = s.lstrip("+-").lower()
+    with np.errstate(over="ignore"):
+        if body.startswith("0x"):
+            try:
+                return np.float32(float.fromhex(s))
+            except OverflowError:
+                return np.float32(-np.inf if s.startswith("-") else np.inf)
+        if _RE_NAN_PAYLOAD.match(s):
+            return np.float32(np.nan)
+        return np.float32(s)
 
 
 class ARPALanguageModel:
@@ -597,8 +622,8 @@ class ARPALanguageModel:
     @classmethod
     def parse(cls, text: str):
         lm, section = cls(), ""
-        for raw in text.split("\n"):
-            line = raw.strip()
+        for raw in text.split("\n"):                                                    # the reader cuts at the byte \\n only (:126)
+            line = raw.strip(_WS + _NL)                                                  # .whitespacesAndNewlines (:131)
             if not line or line.startswith("\\data\\"):
                 continue
             if line == "\\end\\":

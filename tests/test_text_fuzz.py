@@ -1,0 +1,138 @@
+"""Differential fuzzing of the two text readers on the path's edges (host code of the library, no GPU): the C++ parsers against the
+Python restatements on thousands of generated inputs built from the syntax the reference's readers actually distinguish —
+CharacterSet.whitespaces / .newlines / Character.isWhitespace (Unicode Zs, U+0085, U+2028, U+2029 ...), Float(String) (hexadecimal
+floats, inf / nan spellings, no digit separators, no surrounding blanks, ASCII only), CR-only and CRLF files, malformed lines.
+RTTMParser.swift:22-63, SortformerBenchmark.swift:681-731, ARPALanguageModel.swift:46-104,118-141."""
+import numpy as np
+import pytest
+
+ARABIC_THREE = "\u0663"      # a digit for Python's float(), not for Float(String)
+NUMS = ["0", "1.5", "-2.25", "+3.0", ".5", "5.", "1e3", "1E-2", "inf", "-inf", "nan", "NaN", "Infinity", "0x1p3", "-0X1.8P1", "1_0", "1.0f", "--1",
+        "1..2", "1e", "1e+", ARABIC_THREE, "1,5", "0.1e400", "1e-400", "00012.5", "+.5e+1", "nan(7)", "0x", "1e5x"]
+WS = [" ", "\t", "  ", " \t ", "\u00a0", "\u3000 ", "\u2009", "\u202f\u205f", "\u1680"]
+NL = ["\n", "\r\n", "\r", "\x0b", "\x0c", "\u0085", "\u2028", "\u2029", "\n", ""]
+
+
+def _pick(rng, a):
+    return a[rng.integers(len(a))]
+
+
+def _same(a, b):
+    return a == b or (a != a and b != b)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_rttm_reader_equals_restatement_on_generated_text(fa, oracle_mod, seed):
+    rng = np.random.default_rng(seed)
+    toks = ["SPEAKER", "speaker", "LEXEME", "a", "meet1", "1", "<NA>", "spk", "#", "s p", "é", "\u00a0x", "sp\u2003k"]
+
+    def line():
+        k = rng.integers(0, 7)
+        if k == 0:
+            return ""
+        if k == 1:
+            return "# " + _pick(rng, toks)
+        f = [_pick(rng, toks) for _ in range(rng.integers(5, 12))]
+        if rng.random() < 0.85:
+            f[0] = "SPEAKER"
+        f[3], f[4] = (_pick(rng, NUMS[:14]), _pick(rng, NUMS[:14])) if rng.random() < 0.6 else (_pick(rng, NUMS), _pick(rng, NUMS))
+        s = _pick(rng, WS).join(f)
+        return "  " + s + " \t" if rng.random() < 0.2 else s
+
+    compared = errors = 0
+    with np.errstate(invalid="ignore", over="ignore"):
+        for _ in range(1200):
+            text = "".join(line() + _pick(rng, NL) for _ in range(rng.integers(1, 6)))
+            for strict in (True, False):
+                try:
+                    want, bad = oracle_mod.rttm_parse(text, strict), None
+                except ValueError as e:
+                    want, bad = None, str(e)
+                try:
+                    got = [(s.speaker_id, s.start_time_seconds, s.end_time_seconds) for s in fa.RTTMParser.parse(text, strict=strict)]
+                except fa.RTTMParserError as e:
+                    got = None
+                    assert bad is not None and bad in str(e), (text, strict)           # the same line is reported (RTTMParser.swift:37-46)
+                    errors += 1
+                assert (want is None) == (got is None), (text, strict, want, got)
+                if want is None:
+                    continue
+                if strict and any(s[1] != s[1] for s in want):
+                    # a NaN start time makes `sorted { $0.start < $1.start }` (:62) depend on the sort algorithm itself: same segments, order unpinned
+                    want, got = sorted(want, key=repr), sorted(got, key=repr)
+                assert len(want) == len(got) and all(a[0] == b[0] and _same(a[1], b[1]) and _same(a[2], b[2]) for a, b in zip(want, got)), (text, strict, want, got)
+                compared += len(want)
+    assert compared > 500 and errors > 100
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_arpa_reader_equals_restatement_on_generated_text(fa, oracle_mod, seed):
+    rng = np.random.default_rng(seed)
+    nums = ["0", "-1.5", "-2.25", "+3.0", "-.5", "-5.", "-1e1", "-1E-2", "-inf", "nan", "0x1p-3", "-1_0", "-1.0f", "--1", "-1e", ARABIC_THREE, "-1,5",
+            "-00012.5", " -1.0", "-1.0 ", "\u00a0-1.0", "", "-99"]
+    words = ["the", "cat", "sat", "<unk>", "déjà", "a b", "", " x", "x ", "\u00a0y", "THE"]
+    heads = ["\\data\\", "\\data\\ extra", "ngram 1=3", "ngram 2=1", "\\1-grams:", "\\2-grams:", "\\3-grams:", "\\end\\", "\\1-grams: ", "\\foo", "ngram", "# c", ""]
+    pre = ["", "", "", " ", "\t", "\u00a0", "\u3000", "\r", "\x0b", "\u2028"]
+    post = ["", "", "", " ", "\t", "\r", "\u2009", " \u00a0", "\x0c", "\u0085"]
+
+    def line():
+        if rng.integers(0, 10) < 3:
+            return _pick(rng, pre) + _pick(rng, heads) + _pick(rng, post)
+        n = rng.integers(1, 6)
+        f = [_pick(rng, nums)] + [_pick(rng, words) for _ in range(n - 1)]
+        if n >= 3 and rng.random() < 0.5:
+            f[-1] = _pick(rng, nums)                                                   # a back-off field (:69, :74), possibly malformed -> 0
+        return _pick(rng, pre) + "\t".join(f) + _pick(rng, post)
+
+    entries = 0
+    for _ in range(700):
+        lines = ["\\data\\", "ngram 1=3", "", "\\1-grams:"] + [line() for _ in range(rng.integers(0, 6))] + ["\\2-grams:"] + [line() for _ in range(rng.integers(0, 6))]
+        if rng.random() < 0.5:
+            lines.insert(rng.integers(0, len(lines)), line())
+        if rng.random() < 0.7:
+            lines += ["\\end\\", line()]                                               # nothing after \end\ counts (:55)
+        text = _pick(rng, ["\n", "\r\n"]).join(lines)
+        ref, lib = oracle_mod.ARPALanguageModel.parse(text), fa.ARPALanguageModel(text)
+        assert lib.unigram_count == len(ref.unigrams) and lib.bigram_context_count == len(ref.bigrams), text
+        ws = sorted(set(list(ref.unigrams) + [w for d in ref.bigrams.values() for w in d] + list(ref.bigrams) + ["zz"]))
+        for w in ws:
+            for p in ws + [None]:
+                assert _same(lib.score(w, p), float(ref.score(w, p))), (text, w, p)
+        entries += len(ref.unigrams) + sum(len(d) for d in ref.bigrams.values())
+    assert entries > 500
+
+
+def test_float_of_string_rules(oracle_mod, fa):
+    """Float(String) as both readers must see it, through one RTTM line per candidate."""
+    good = {"1.5": 1.5, "+3.0": 3.0, ".5": 0.5, "5.": 5.0, "1e3": 1000.0, "1E-2": float(np.float32(0.01)), "inf": np.inf, "-Infinity": -np.inf,
+            "0x1p3": 8.0, "-0X1.8P1": -3.0, "00012.5": 12.5, "1e-400": 0.0, "0.1e400": np.inf}
+    bad = ["1_0", "1.0f", "--1", "1..2", "1e", "1e+", ARABIC_THREE, "1,5", "0x", "1e5x"]
+    with np.errstate(over="ignore"):
+        for s, v in good.items():
+            assert float(oracle_mod._swift_float(s)) == v
+            line = f"SPEAKER f 1 {s} 0 <NA> <NA> spk"
+            assert fa.RTTMParser.parse(line)[0].start_time_seconds == v == oracle_mod.rttm_parse(line)[0][1]
+    assert np.isnan(oracle_mod._swift_float("nan")) and np.isnan(oracle_mod._swift_float("NaN(12)"))
+    for s in bad + ["", "1.5 ", " 1.5"]:
+        with pytest.raises(ValueError):
+            oracle_mod._swift_float(s)
+    for s in bad:
+        line = f"SPEAKER f 1 0 1 <NA> <NA> spk\nSPEAKER f 1 {s} 0 <NA> <NA> spk"
+        with pytest.raises(fa.RTTMParserError):
+            fa.RTTMParser.parse(line)
+        with pytest.raises(ValueError):
+            oracle_mod.rttm_parse(line)
+        assert len(fa.RTTMParser.parse(line, strict=False)) == 1 == len(oracle_mod.rttm_parse(line, strict=False))
+
+
+def test_line_and_field_separators_of_the_reference(fa, oracle_mod):
+    """A CR-only file is several lines (components(separatedBy: .newlines), RTTMParser.swift:30), a no-break space separates fields
+    (Character.isWhitespace, :36), and U+2028 ends a line; ARPA lines end at \\n only and are trimmed of all of these (:126-131)."""
+    cr = "SPEAKER f 1 2.0 1.0 <NA> <NA> B\rSPEAKER f 1 0.5 1.0 <NA> <NA> A\r"
+    for text in (cr, cr.replace("\r", "\u2028"), cr.replace(" ", "\u00a0"), cr.replace(" ", "\u3000\t")):
+        got = [(s.speaker_id, s.start_time_seconds, s.end_time_seconds) for s in fa.RTTMParser.parse(text)]
+        assert got == oracle_mod.rttm_parse(text) == [("A", 0.5, 1.5), ("B", 2.0, 3.0)]
+    arpa = "\\data\\\u00a0\r\n\u2003\\1-grams:\u0085\r\n-1.0\tcat\t-0.5\u2029\r\n\\end\\\x0c\r\n-2.0\tdog\n"
+    ref, lib = oracle_mod.ARPALanguageModel.parse(arpa), fa.ARPALanguageModel(arpa)
+    assert list(ref.unigrams) == ["cat"] and lib.unigram_count == 1
+    assert lib.score("cat", None) == float(ref.score("cat", None)) and lib.score("dog", "cat") == float(ref.score("dog", "cat"))
