@@ -114,7 +114,7 @@ fa_status fa_wav_decode(const uint8_t *data, int64_t len, float *out, int64_t ou
         } else if (memcmp(data + pos, "data", 4) == 0) {
             if (!ch || !((fmt == 1 && bits == 16) || (fmt == 3 && bits == 32))) return FA_INVALID_ARGUMENT;
             const int64_t avail = std::min<int64_t>(sz, len - pos - 8);
-            const int64_t n = avail / (bits / 8);
+            const int64_t n = avail / (bits / 8) / ch * ch;     // whole frames only (a truncated file may end inside one)
             if (frames) *frames = n / ch;
             if (channels) *channels = ch;
             if (sample_rate) *sample_rate = rate;

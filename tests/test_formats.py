@@ -78,6 +78,40 @@ def test_wav_reader_pcm16_and_float(fa, oracle_mod):
         fa.AudioWAV.read(b"RIFFxxxxWAVE")
 
 
+def test_wav_reader_survives_damaged_files(fa):
+    """The reader is a C function fed with file bytes: truncations, bit flips and random chunk sizes must end in a result or in
+    ValueError, never in a crash or an out-of-bounds read (the copies below are exact-length numpy buffers).  A file that ends inside a
+    frame yields its whole frames."""
+    rng = np.random.default_rng(0)
+    f = (rng.standard_normal((50, 2)) * 0.1).astype(np.float32)
+    pcm = (rng.standard_normal(101) * 8000).astype("<i2")
+    files = [b"RIFF" + struct.pack("<I", 36 + f.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 3, 2, 22050, 22050 * 8, 8, 32) + b"data" + struct.pack("<I", f.nbytes) + f.tobytes(),
+             b"RIFF" + struct.pack("<I", 36 + pcm.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16) + b"data" + struct.pack("<I", pcm.nbytes) + pcm.tobytes()]
+    y, _ = fa.AudioWAV.read(files[0][:-5])                      # 3 bytes short of the last frame + 2 more: 49 whole frames
+    assert y.shape == (49, 2) and np.array_equal(y, f[:49])
+    ok = bad = 0
+    for it in range(3000):
+        b = bytearray(files[it % 2])
+        k = rng.integers(0, 4)
+        if k == 0:
+            b = b[:rng.integers(0, len(b))]
+        elif k == 1:
+            for _ in range(rng.integers(1, 6)):
+                b[rng.integers(0, min(len(b), 48))] ^= 1 << rng.integers(0, 8)
+        elif k == 2:
+            pos = int(rng.choice([4, 16, 40]))
+            b[pos:pos + 4] = struct.pack("<I", int(rng.choice([0, 1, 7, 2 ** 31 - 1, 2 ** 32 - 1, len(b), len(b) - 43])))
+        else:
+            b = b[:36] + bytes(rng.integers(0, 256, rng.integers(0, 40), dtype=np.uint8)) + b[36:]
+        try:
+            y, sr = fa.AudioWAV.read(bytes(b))
+            assert y.ndim == 2 and y.shape[1] >= 1 and y.size * (4 if b[20] == 3 else 2) <= len(b)
+            ok += 1
+        except ValueError:
+            bad += 1
+    assert ok > 200 and bad > 200
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,scale,normalize", [(1, 0.3, True), (1000, 0.2, True), (48000, 3.0, True), (48000, 3.0, False), (777, 0.0, True),
                                                (100003, 1e-3, True)])
