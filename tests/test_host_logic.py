@@ -210,3 +210,22 @@ def test_clustering_config_guards_of_the_reference(fa):
                 call()
             assert word in str(e.value)
     fa.OfflineClusteringConfig(clustering_threshold=2.0).validate()          # the closed end of (0, 2]
+
+
+def test_tables_bit_identical_to_oracle_over_the_configurations_callers_use(fa, oracle_mod):
+    """Hann window and Slaney bank for the other front ends of the reference (LS-EEND: nFFT = nextPow2(winLength) at 8 kHz,
+    LSEENDTypes.swift:55-57; 80-mel Parakeet variants; 24 kHz TTS front ends): fp32 formulas of AudioMelSpectrogram.swift:553-642."""
+    L = fa._lib
+    for sr, n_fft, win, n_mels in ((16000, 512, 400, 128), (16000, 512, 400, 80), (8000, 256, 200, 23), (8000, 256, 256, 40), (16000, 1024, 1024, 64),
+                                   (24000, 1024, 1024, 100), (22050, 2048, 1024, 128), (16000, 64, 64, 8), (48000, 2048, 2048, 256)):
+        for periodic in (0, 1):
+            cfg = L.MelConfig()
+            fa.lib().fa_mel_default_config(C.byref(cfg))
+            cfg.sample_rate, cfg.n_fft, cfg.win, cfg.n_mels, cfg.window_periodic = sr, n_fft, win, n_mels, periodic
+            w = np.zeros(win, np.float32)
+            fb = np.zeros((n_mels, n_fft // 2 + 1), np.float32)
+            assert fa.lib().fa_mel_hann_window(C.byref(cfg), w.ctypes.data) == 0
+            assert fa.lib().fa_mel_filterbank(C.byref(cfg), fb.ctypes.data) == 0
+            np.testing.assert_array_equal(w, oracle_mod.hann(win, bool(periodic)))
+            np.testing.assert_array_equal(fb, oracle_mod.slaney_filterbank(n_fft, n_mels, sr))
+            assert fb.min() >= 0 and (fb.sum(axis=1) > 0).sum() >= n_mels - 2            # AudioMelSpectrogramTests.swift:93-105
