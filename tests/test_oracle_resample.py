@@ -65,3 +65,19 @@ def test_poly_taps_follow_scipy_specification(fa):
         assert taps.size == h.size + pre_pad and pre == (half + pre_pad) // down
         assert np.all(taps[:pre_pad] == 0)
         np.testing.assert_allclose(taps[pre_pad:], h.astype(np.float32), rtol=0, atol=2e-7 * up)
+
+
+def test_output_lengths_need_no_gpu(fa, oracle_mod):
+    """The frame-count entries are host arithmetic: linear = the restatement's count (AudioConverter.swift:396-400: Int(Double(frames) *
+    ratio) with ratio = target / source as Double), polyphase = ceil(n * up / down) as scipy.signal.resample_poly defines it."""
+    from scipy.signal import resample_poly
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        frames = int(rng.integers(0, 200000))
+        sr = float(rng.choice([8000, 11025, 16000, 22050, 32000, 44100, 48000, 96000, 12345.6]))
+        tr = float(rng.choice([16000, 8000, 24000, 44100]))
+        assert fa.lib().fa_resample_linear_frames(frames, sr, tr) == oracle_mod.lib().fa_oracle_resample_linear_frames(frames, sr, tr), (frames, sr, tr)
+    for n in (0, 1, 2, 7, 160, 161, 44100, 48000, 100003):
+        for up, down in ((1, 3), (1, 2), (160, 441), (2, 3), (3, 1), (1, 1), (1, 5), (320, 441)):
+            want = len(resample_poly(np.zeros(n), up, down)) if n else 0
+            assert fa.lib().fa_resample_poly_frames(n, up, down) == want, (n, up, down)
