@@ -350,6 +350,7 @@ bool degenerate(const double *emb, int64_t n, int32_t d, int32_t num_clusters, i
 extern "C" {
 
 uint64_t fa_seeded_rng_next(uint64_t *state) {
+    if (!state) return 0;
     Rng r{*state};
     const uint64_t v = r.next();
     *state = r.s;
@@ -357,7 +358,7 @@ uint64_t fa_seeded_rng_next(uint64_t *state) {
 }
 
 uint64_t fa_seeded_rng_below(uint64_t *state, uint64_t upper_bound) {
-    if (upper_bound == 0) return 0;
+    if (upper_bound == 0 || !state) return 0;
     Rng r{*state};
     const uint64_t v = r.below(upper_bound);
     *state = r.s;
@@ -399,6 +400,7 @@ fa_status fa_kmeans_cluster_ninit(fa_ctx *ctx, const double *emb, int64_t n, int
 
 void fa_speaker_constraints_resolve(int64_t num_embeddings, const int64_t *num_speakers, const int64_t *min_speakers, const int64_t *max_speakers,
                                     int64_t out[3]) {
+    if (!out) return;
     int64_t rmin = num_speakers ? *num_speakers : (min_speakers ? *min_speakers : 1);
     rmin = std::max<int64_t>(1, std::min(num_embeddings, rmin));
     int64_t rmax = num_speakers ? *num_speakers : (max_speakers ? *max_speakers : num_embeddings);

@@ -79,3 +79,34 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "fa_oracle" not in text and "oracle/" not in text.replace("oracle/ is test", ""), f
+
+
+def test_every_entry_survives_null_and_zero_arguments(fa):
+    """No entry may crash on NULL pointers / zero sizes — the reference's wrapper answers them with a status
+    (FastClusterWrapper.cpp:203-226) and nothing else may cross the ABI.  Runs in a child process so that a crash is a test failure
+    naming the entry, not the end of the test run."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import fluidaudio_amd as fa
+lib = fa.lib()
+for name in sorted(fa._lib.EXPORTED_SYMBOLS):
+    f = getattr(lib, name)
+    args = []
+    for t in (f.argtypes or []):
+        if t in (C.c_float, C.c_double):
+            args.append(0.0)
+        elif t in (C.c_void_p, C.c_char_p) or isinstance(t, type) and issubclass(t, C._Pointer):
+            args.append(None)
+        else:
+            args.append(0)
+    print(name, flush=True)
+    f(*args)
+print("done", flush=True)
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    lines = r.stdout.strip().splitlines()
+    assert r.returncode == 0 and lines[-1] == "done", f"crashed in {lines[-1] if lines else '?'}: rc {r.returncode} {r.stderr[-300:]}"
+    assert len(lines) == len(fa._lib.EXPORTED_SYMBOLS) + 1
