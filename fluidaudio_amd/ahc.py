@@ -57,9 +57,30 @@ def fastcluster_compute_centroid_linkage(data) -> tuple[int, np.ndarray]:
     return st, z
 
 
+def check_dendrogram(z, n: int) -> None:
+    """A linkage matrix the cut can walk: (n - 1) rows; the children of row r are two different nodes that exist when it is formed
+    (leaves 0 .. n-1, merges n .. n+r-1) and no node is merged twice.  The reference only ever cuts what its own wrapper wrote
+    (AHCClustering.swift:40-58) and has no such check; a C caller can hand over anything, and a child index >= its own row's node
+    would send the walk out of bounds or around a cycle."""
+    z = np.asarray(z, np.float64)
+    if n <= 1:
+        return
+    if z.shape != (n - 1, 4):
+        raise ValueError(f"dendrogram of {n} points needs {n - 1} rows of 4 values, got shape {z.shape}")
+    kids = z[:, :2]
+    if not np.isfinite(kids).all() or (kids != np.floor(kids)).any():
+        raise ValueError("dendrogram: child indices must be whole numbers")
+    limit = (n + np.arange(n - 1))[:, None]
+    if (kids < 0).any() or (kids >= limit).any() or (kids[:, 0] == kids[:, 1]).any():
+        raise ValueError("dendrogram: a row merges a node that does not exist yet, or a node with itself")
+    if len(np.unique(kids)) != kids.size:
+        raise ValueError("dendrogram: a node is merged twice")
+
+
 def cut(z, n: int, threshold: float) -> np.ndarray:
     """assignmentsFromDendrogram + remapClusterIds (:124-210) with the threshold clamp (:112-121)."""
     z = np.ascontiguousarray(z, np.float64)
+    check_dendrogram(z.reshape(-1, 4) if z.size else z, n)
     labels = np.zeros(max(n, 1), np.int32)
     st = L.lib().fa_ahc_cut(z.ctypes.data if z.size else None, n, float(threshold), labels.ctypes.data)
     if st != L.SUCCESS:

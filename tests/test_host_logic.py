@@ -229,3 +229,27 @@ def test_tables_bit_identical_to_oracle_over_the_configurations_callers_use(fa, 
             np.testing.assert_array_equal(w, oracle_mod.hann(win, bool(periodic)))
             np.testing.assert_array_equal(fb, oracle_mod.slaney_filterbank(n_fft, n_mels, sr))
             assert fb.min() >= 0 and (fb.sum(axis=1) > 0).sum() >= n_mels - 2            # AudioMelSpectrogramTests.swift:93-105
+
+
+def test_cut_refuses_dendrograms_it_cannot_walk(fa):
+    """fa.cut validates before it calls the C entry: a child index at or beyond its own row's node is an out-of-bounds read or a cycle for
+    the walk of AHCClustering.swift:124-197 (which only ever sees its own wrapper's output)."""
+    import pytest
+    rng = np.random.default_rng(1)
+    good = random_dendrogram(9, rng)
+    fa.check_dendrogram(good, 9)
+    for mutate in (lambda z: z.__setitem__((3, 0), 9 + 3),          # its own node: a cycle
+                   lambda z: z.__setitem__((2, 1), 9 + 5),          # a later node
+                   lambda z: z.__setitem__((0, 0), -1),
+                   lambda z: z.__setitem__((4, 1), 1e12),
+                   lambda z: z.__setitem__((1, 0), np.nan),
+                   lambda z: z.__setitem__((5, 0), z[5, 0] + 0.5),
+                   lambda z: z.__setitem__((6, 0), z[6, 1]),        # a node merged with itself
+                   lambda z: z.__setitem__((7, 0), z[0, 0])):       # a node merged twice
+        z = good.copy()
+        mutate(z)
+        with pytest.raises(ValueError):
+            fa.cut(z, 9, 0.5)
+    with pytest.raises(ValueError):
+        fa.cut(good[:-1], 9, 0.5)
+    assert fa.cut(good, 9, 5.0).tolist() == [0] * 9
