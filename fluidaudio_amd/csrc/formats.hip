@@ -187,10 +187,14 @@ fa_status fa_rttm_parse(const char *text, int64_t len, int32_t strict, fa_rttm_s
 // extension: "SPEAKER <file> 1 <start> <duration> <NA> <NA> <speaker> <NA> <NA>\n" per segment, 3 decimals
 int64_t fa_rttm_format(const fa_rttm_segment *segs, int64_t n, const char *file_id, char *out, int64_t out_capacity) {
     std::string o;
+    if (!segs) n = 0;
     char buf[256];
     for (int64_t i = 0; i < n; ++i) {
-        snprintf(buf, sizeof(buf), "SPEAKER %s 1 %.3f %.3f <NA> <NA> %s <NA> <NA>\n", file_id ? file_id : "audio", static_cast<double>(segs[i].start_seconds),
+        // the speaker id is a fixed 64-byte field that a caller may have filled to the last byte; a long file id must not truncate the line
+        snprintf(buf, sizeof(buf), " 1 %.3f %.3f <NA> <NA> %.64s <NA> <NA>\n", static_cast<double>(segs[i].start_seconds),
                  static_cast<double>(segs[i].end_seconds - segs[i].start_seconds), segs[i].speaker_id);
+        o += "SPEAKER ";
+        o += file_id ? file_id : "audio";
         o += buf;
     }
     if (out && out_capacity > static_cast<int64_t>(o.size())) memcpy(out, o.c_str(), o.size() + 1);

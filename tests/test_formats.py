@@ -46,6 +46,17 @@ def test_rttm_empty_and_roundtrip(fa):
     assert [(s.speaker_id, s.start_time_seconds, s.end_time_seconds) for s in fa.RTTMParser.parse(text)] == [("A", 0.0, 1.5), ("B", 1.25, 4.0)]
 
 
+def test_rttm_format_long_names(fa):
+    """Extension entry: a file id longer than any line buffer and a speaker id that fills its 64-byte field neither truncate the line
+    nor read past the field."""
+    segs = [fa.TimedSpeakerSegment("A" * 80, 0.0, 1.5), fa.TimedSpeakerSegment("B", 1.25, 4.0)]
+    text = fa.RTTMParser.format(segs, "rec" * 200)
+    lines = text.splitlines()
+    assert len(lines) == 2 and all(ln.startswith("SPEAKER " + "rec" * 200 + " 1 ") and ln.endswith(" <NA> <NA>") for ln in lines)
+    back = fa.RTTMParser.parse(text)
+    assert [(s.speaker_id, s.start_time_seconds, s.end_time_seconds) for s in back] == [("A" * 63, 0.0, 1.5), ("B", 1.25, 4.0)]
+
+
 def test_export_embeddings_json(fa):
     rng = np.random.default_rng(0)
     items = [(0, 1, 0, 99, 0.0, 1.98), (3, 0, 300, 431, 6.0, 8.625), (7, 2, 700, 800, 14.0, 16.1)]
