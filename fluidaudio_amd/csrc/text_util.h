@@ -47,7 +47,7 @@ inline void trim(const char *&a, const char *&b, Len len) {
     for (;;) {
         // the last character starts 1 ... 3 bytes before b
         int cut = 0;
-        for (int back = 1; back <= 3 && b - back >= a; ++back) { const int k = len(b - back, b); if (k == back) { cut = back; break; } }
+        for (int back = 1; back <= 3 && back <= b - a; ++back) { const int k = len(b - back, b); if (k == back) { cut = back; break; } }
         if (!cut) break;
         b -= cut;
     }

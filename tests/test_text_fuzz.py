@@ -136,3 +136,17 @@ def test_line_and_field_separators_of_the_reference(fa, oracle_mod):
     ref, lib = oracle_mod.ARPALanguageModel.parse(arpa), fa.ARPALanguageModel(arpa)
     assert list(ref.unigrams) == ["cat"] and lib.unigram_count == 1
     assert lib.score("cat", None) == float(ref.score("cat", None)) and lib.score("dog", "cat") == float(ref.score("dog", "cat"))
+
+
+def test_text_entries_under_address_and_ub_sanitizers(tmp_path):
+    """scripts/asan_text_fuzz.sh: the host side of formats.hip / beam.hip built with -fsanitize=address,undefined and driven by
+    tests/cabi/asan_text.cpp (300 000 generated RTTM / ARPA / WAV inputs in exact-size heap buffers + the JSON writer): a read past a
+    caller's buffer, a leak or undefined behaviour in the C++ readers is a failure here.  Skipped where the sanitizer build is impossible."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "scripts", "asan_text_fuzz.sh"), str(tmp_path)], capture_output=True, text=True, timeout=900)
+    if r.returncode == 77:
+        pytest.skip("sanitizer build not possible here: " + r.stdout[-200:])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-500:])
+    assert "done:" in r.stdout
