@@ -253,3 +253,28 @@ def test_cut_refuses_dendrograms_it_cannot_walk(fa):
     with pytest.raises(ValueError):
         fa.cut(good[:-1], 9, 0.5)
     assert fa.cut(good, 9, 5.0).tolist() == [0] * 9
+
+
+def test_bench_line_contract_on_the_committed_line():
+    """The driver parses ONE JSON line of bench.py: the committed line of the round (profiles/r03_bench_v7.json, written on an MI355X)
+    carries every field of the contract with the right types, and bench.py still spells each of them."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r03_bench_v7.json")) as f:
+        line = json.loads(f.read().strip().splitlines()[-1])
+    need = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float, "higher_is_better": bool,
+            "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict, "cpu_baseline": dict}
+    for k, t in need.items():
+        assert isinstance(line[k], t), (k, type(line[k]))
+    assert "vs_baseline" in line and line["vs_baseline"] is None          # BASELINE.md publishes no number for this metric
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["data"] == "synthetic" and "workload" in line["config"]
+    assert abs(line["value"] - line["n_gpus"] * line["config"]["hours_per_step_per_gpu"] * line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) < 1e-6 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 0
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert line["e2e_equals_reference_digest"] is True
+    src = open(os.path.join(root, "bench.py")).read()
+    for k in list(need) + ["vs_baseline", "bound", "achieved", "peak", "frac", "traffic", "cores", "kind", "sample"]:
+        assert f'"{k}"' in src, k
