@@ -64,6 +64,19 @@ inline fa_status hip_status(fa_ctx *ctx, hipError_t e, const char *what) {
     return set_error(ctx, st, "%s: %s", what, hipGetErrorString(e));
 }
 
+// No exception crosses the C ABI (the reference's wrapper: std::bad_alloc -> ALLOCATION_FAILURE, anything else -> UNKNOWN_ERROR,
+// FastClusterWrapper.cpp:236-243).  For entry points whose host side allocates (std::vector / std::string).
+template <class F>
+inline fa_status no_throw(fa_ctx *ctx, const char *what, F &&f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        try { return set_error(ctx, FA_ALLOCATION_FAILURE, "%s: host allocation failed", what); } catch (...) { return FA_ALLOCATION_FAILURE; }
+    } catch (...) {
+        try { return set_error(ctx, FA_UNKNOWN_ERROR, "%s: unexpected failure", what); } catch (...) { return FA_UNKNOWN_ERROR; }
+    }
+}
+
 #define FA_HIP_TRY(ctx, expr)                                              \
     do {                                                                   \
         const hipError_t fa_e_ = (expr);                                   \

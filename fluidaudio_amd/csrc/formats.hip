@@ -137,6 +137,7 @@ fa_status fa_wav_decode(const uint8_t *data, int64_t len, float *out, int64_t ou
 fa_status fa_rttm_parse(const char *text, int64_t len, int32_t strict, fa_rttm_segment *out, int64_t out_capacity, int64_t *count,
                         char *bad_line, int64_t bad_line_capacity) {
     if (!text || len < 0 || !count) return FA_INVALID_ARGUMENT;
+    return fa::no_throw(nullptr, "rttm parse", [&]() -> fa_status {
     std::vector<fa_rttm_segment> segs;
     int64_t pos = 0;
     const char *const text_end = text + len;
@@ -182,10 +183,13 @@ fa_status fa_rttm_parse(const char *text, int64_t len, int32_t strict, fa_rttm_s
         std::copy(segs.begin(), segs.end(), out);
     }
     return FA_SUCCESS;
+    });
 }
 
 // extension: "SPEAKER <file> 1 <start> <duration> <NA> <NA> <speaker> <NA> <NA>\n" per segment, 3 decimals
 int64_t fa_rttm_format(const fa_rttm_segment *segs, int64_t n, const char *file_id, char *out, int64_t out_capacity) {
+    int64_t length = -1;                                         // -1: the text could not be built (host allocation failed)
+    (void)fa::no_throw(nullptr, "rttm format", [&]() -> fa_status {
     std::string o;
     if (!segs) n = 0;
     char buf[256];
@@ -198,12 +202,17 @@ int64_t fa_rttm_format(const fa_rttm_segment *segs, int64_t n, const char *file_
         o += buf;
     }
     if (out && out_capacity > static_cast<int64_t>(o.size())) memcpy(out, o.c_str(), o.size() + 1);
-    return static_cast<int64_t>(o.size());
+    length = static_cast<int64_t>(o.size());
+    return FA_SUCCESS;
+    });
+    return length;
 }
 
 // exportEmbeddings payload (:918-947) as JSON text.  Returns the length; writes when the buffer is large enough.
 int64_t fa_export_embeddings_json(const fa_export_embedding *items, int64_t n, const float *embedding256, int32_t emb_dim, const double *rho128,
                                   int32_t rho_dim, const int32_t *assignments, int64_t n_assignments, char *out, int64_t out_capacity) {
+    int64_t length = -1;                                         // -1: the text could not be built (host allocation failed)
+    (void)fa::no_throw(nullptr, "embedding export", [&]() -> fa_status {
     std::string o = "[";
     for (int64_t i = 0; i < n; ++i) {
         if (i) o += ',';
@@ -222,7 +231,10 @@ int64_t fa_export_embeddings_json(const fa_export_embedding *items, int64_t n, c
     }
     o += ']';
     if (out && out_capacity > static_cast<int64_t>(o.size())) memcpy(out, o.c_str(), o.size() + 1);
-    return static_cast<int64_t>(o.size());
+    length = static_cast<int64_t>(o.size());
+    return FA_SUCCESS;
+    });
+    return length;
 }
 
 }  // extern "C"

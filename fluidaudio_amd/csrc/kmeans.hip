@@ -371,11 +371,13 @@ fa_status fa_kmeans_cluster(fa_ctx *ctx, const double *emb, int64_t n, int32_t d
     if (out_iterations) *out_iterations = 0;
     if (n < 0 || (n > 0 && (!labels || (d > 0 && !emb)))) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "kmeans: bad arguments");
     if (n > INT32_MAX) return fa::set_error(ctx, FA_INDEX_OVERFLOW, "kmeans: n exceeds int32");
-    if (degenerate(emb, n, d, num_clusters, labels, centroids, out_k)) return FA_SUCCESS;
-    const int k = static_cast<int>(std::min<int64_t>(num_clusters, n));
-    FA_TRY(kmeans_device(ctx, emb, n, d, k, max_iterations, &seed, 1, false, labels, centroids, nullptr, nullptr, out_iterations));
-    if (out_k) *out_k = k;
-    return FA_SUCCESS;
+    return fa::no_throw(ctx, "kmeans", [&]() -> fa_status {
+        if (degenerate(emb, n, d, num_clusters, labels, centroids, out_k)) return FA_SUCCESS;
+        const int k = static_cast<int>(std::min<int64_t>(num_clusters, n));
+        FA_TRY(kmeans_device(ctx, emb, n, d, k, max_iterations, &seed, 1, false, labels, centroids, nullptr, nullptr, out_iterations));
+        if (out_k) *out_k = k;
+        return FA_SUCCESS;
+    });
 }
 
 fa_status fa_kmeans_cluster_ninit(fa_ctx *ctx, const double *emb, int64_t n, int32_t d, int32_t num_clusters, int32_t max_iterations, int32_t n_init,
@@ -386,16 +388,18 @@ fa_status fa_kmeans_cluster_ninit(fa_ctx *ctx, const double *emb, int64_t n, int
         return fa_kmeans_cluster(ctx, emb, n, d, num_clusters, max_iterations, base_seed, labels, centroids, out_k, nullptr);
     if (n < 0 || !labels || (d > 0 && !emb)) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "kmeans: bad arguments");
     if (n > INT32_MAX) return fa::set_error(ctx, FA_INDEX_OVERFLOW, "kmeans: n exceeds int32");
-    if (degenerate(emb, n, d, num_clusters, labels, centroids, out_k)) {  // d == 0 or k <= 0: every run returns the same labels
-        if (inertias) std::fill(inertias, inertias + n_init, 0.0);
+    return fa::no_throw(ctx, "kmeans", [&]() -> fa_status {
+        if (degenerate(emb, n, d, num_clusters, labels, centroids, out_k)) {  // d == 0 or k <= 0: every run returns the same labels
+            if (inertias) std::fill(inertias, inertias + n_init, 0.0);
+            return FA_SUCCESS;
+        }
+        const int k = static_cast<int>(std::min<int64_t>(num_clusters, n));
+        std::vector<uint64_t> seeds(n_init);
+        for (int i = 0; i < n_init; ++i) seeds[i] = base_seed + static_cast<uint64_t>(i);
+        FA_TRY(kmeans_device(ctx, emb, n, d, k, max_iterations, seeds.data(), n_init, true, labels, centroids, best_run, inertias, nullptr));
+        if (out_k) *out_k = k;
         return FA_SUCCESS;
-    }
-    const int k = static_cast<int>(std::min<int64_t>(num_clusters, n));
-    std::vector<uint64_t> seeds(n_init);
-    for (int i = 0; i < n_init; ++i) seeds[i] = base_seed + static_cast<uint64_t>(i);
-    FA_TRY(kmeans_device(ctx, emb, n, d, k, max_iterations, seeds.data(), n_init, true, labels, centroids, best_run, inertias, nullptr));
-    if (out_k) *out_k = k;
-    return FA_SUCCESS;
+    });
 }
 
 void fa_speaker_constraints_resolve(int64_t num_embeddings, const int64_t *num_speakers, const int64_t *min_speakers, const int64_t *max_speakers,

@@ -137,6 +137,7 @@ fa_status fa_device_count(int32_t *count) {
 fa_status fa_pool_create(const int32_t *devices, int32_t n_devices, fa_pool **out) {
     if (!out || n_devices < 0 || (n_devices > 0 && !devices)) return FA_INVALID_ARGUMENT;
     *out = nullptr;
+    return fa::no_throw(nullptr, "pool create", [&]() -> fa_status {
     std::vector<int> devs;
     if (n_devices == 0) {
         int32_t c = 0;
@@ -157,6 +158,7 @@ fa_status fa_pool_create(const int32_t *devices, int32_t n_devices, fa_pool **ou
     pool->busy.assign(pool->ctx.size(), 0);
     *out = pool;
     return FA_SUCCESS;
+    });
 }
 
 void fa_pool_destroy(fa_pool *pool) {

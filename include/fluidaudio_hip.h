@@ -492,7 +492,7 @@ typedef struct fa_rttm_segment {   /* TimedSpeakerSegment as the RTTM loaders fi
 fa_status fa_rttm_parse(const char *text, int64_t len, int32_t strict, fa_rttm_segment *out, int64_t out_capacity, int64_t *count,
                         char *bad_line, int64_t bad_line_capacity);
 /* Extension: one "SPEAKER <file> 1 <start> <duration> <NA> <NA> <speaker> <NA> <NA>" line per segment; returns the text
- * length and writes it (NUL-terminated) when out_capacity is larger. */
+ * length and writes it (NUL-terminated) when out_capacity is larger; -1 when the text could not be built (host allocation failed). */
 int64_t fa_rttm_format(const fa_rttm_segment *segs, int64_t n, const char *file_id, char *out, int64_t out_capacity);
 
 typedef struct fa_export_embedding {   /* TimedEmbedding fields of the export payload */
@@ -501,7 +501,7 @@ typedef struct fa_export_embedding {   /* TimedEmbedding fields of the export pa
 } fa_export_embedding;
 /* OfflineDiarizerManager.exportEmbeddings (FluidAudio/Diarizer/Offline/Core/OfflineDiarizerManager.swift:913-955): JSON
  * array of {chunkIndex, speakerIndex, startFrame, endFrame, startTime, endTime, embedding256, rho128, cluster}; cluster = -1
- * past the end of assignments.  Numbers are printed in their shortest round-trip form.  Returns the text length. */
+ * past the end of assignments.  Numbers are printed in their shortest round-trip form.  Returns the text length (-1: host allocation failed). */
 int64_t fa_export_embeddings_json(const fa_export_embedding *items, int64_t n, const float *embedding256, int32_t emb_dim,
                                   const double *rho128, int32_t rho_dim, const int32_t *assignments, int64_t n_assignments,
                                   char *out, int64_t out_capacity);
