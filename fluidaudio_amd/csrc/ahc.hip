@@ -2202,17 +2202,24 @@ fa_status ahc_batch_in_flight(fa_ctx *ctx, int count, const double *const *d_dat
     }
     FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the inputs were produced on the caller's stream
     std::vector<std::thread> threads;
-    for (int k = 1; k < count; ++k)
-        threads.emplace_back([&, k]() {
-            fa_ctx *h = ctx->helpers[k - 1];
-            fa::DeviceGuard guard(h->device);
-            sts[k] = fa::ahc_run_device(h, d_data[k], n[k], d, d_Z[k], mode, stats ? &stats[k] : nullptr, false);
-        });
+    std::vector<char> started(static_cast<size_t>(count), 0);
+    for (int k = 1; k < count; ++k) {
+        try {
+            threads.emplace_back([&, k]() {
+                fa_ctx *h = ctx->helpers[k - 1];
+                fa::DeviceGuard guard(h->device);
+                sts[k] = fa::ahc_run_device(h, d_data[k], n[k], d, d_Z[k], mode, stats ? &stats[k] : nullptr, false);
+            });
+            started[static_cast<size_t>(k)] = 1;
+        } catch (...) {                          // no thread to be had (std::system_error): that problem runs on the caller's context below
+            sts[k] = FA_ALLOCATION_FAILURE;
+        }
+    }
     sts[0] = fa::ahc_run_device(ctx, d_data[0], n[0], d, d_Z[0], mode, stats ? &stats[0] : nullptr, false);
     for (auto &t : threads) t.join();
     fa_status first = sts[0];
     for (int k = 1; k < count; ++k) {
-        if (sts[k] == FA_ALLOCATION_FAILURE) {   // HBM pressure: this one runs alone on the caller's context (whose workspace is free again)
+        if (sts[k] == FA_ALLOCATION_FAILURE) {   // HBM pressure (or no thread): this one runs alone on the caller's context (whose workspace is free again)
             (void)fa_ctx_trim(ctx->helpers[k - 1]);
             sts[k] = fa::ahc_run_device(ctx, d_data[k], n[k], d, d_Z[k], mode, stats ? &stats[k] : nullptr, false);
         }
@@ -2403,9 +2410,18 @@ fa_status fa_ahc_cut(const double *z, size_t n, double threshold, int32_t *label
         const size_t total = 2 * n - 1;
         std::vector<int64_t> left(total, -1), right(total, -1), assign(n, -1);
         std::vector<double> height(total, 0.0);
+        std::vector<char> merged(total, 0);
         for (size_t r = 0; r + 1 < n; ++r) {
-            left[n + r] = static_cast<int64_t>(z[4 * r]);
-            right[n + r] = static_cast<int64_t>(z[4 * r + 1]);
+            // The reference only ever cuts what its own wrapper wrote (AHCClustering.swift:40-58); a C caller can hand over anything.  The
+            // children of row r must be two different nodes that exist when it is formed (leaves, or rows < r) and were not merged before:
+            // anything else is an out-of-bounds read or an endless walk below.
+            const double a = z[4 * r], b = z[4 * r + 1], limit = static_cast<double>(n + r);
+            if (!(a >= 0.0 && a < limit && b >= 0.0 && b < limit) || a != std::floor(a) || b != std::floor(b) || a == b) return FA_INVALID_ARGUMENT;
+            const size_t ia = static_cast<size_t>(a), ib = static_cast<size_t>(b);
+            if (merged[ia] || merged[ib]) return FA_INVALID_ARGUMENT;
+            merged[ia] = merged[ib] = 1;
+            left[n + r] = static_cast<int64_t>(ia);
+            right[n + r] = static_cast<int64_t>(ib);
             height[n + r] = z[4 * r + 2];
         }
         std::vector<int64_t> stack{static_cast<int64_t>(total - 1)}, queue;

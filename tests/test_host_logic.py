@@ -255,6 +255,57 @@ def test_cut_refuses_dendrograms_it_cannot_walk(fa):
     assert fa.cut(good, 9, 5.0).tolist() == [0] * 9
 
 
+def test_c_entry_fa_ahc_cut_refuses_dendrograms_it_cannot_walk(fa):
+    """The C entry itself (what a Swift / C host binds, not the Python guard): every damaged matrix comes back INVALID_ARGUMENT without
+    an out-of-bounds access or an endless walk, valid ones keep the labels of the walk in AHCClustering.swift:124-197.  Includes the
+    shapes the round-3 fuzz run found (a child at or beyond its own row's node, cycles through later rows)."""
+    L = fa._lib
+    rng = np.random.default_rng(7)
+
+    def raw_cut(z, n, thr=0.5):
+        z = np.ascontiguousarray(z, np.float64)
+        labels = np.full(max(n, 1), -7, np.int32)
+        return fa.lib().fa_ahc_cut(z.ctypes.data, n, float(thr), labels.ctypes.data), labels
+
+    for n in (2, 3, 9, 64, 257):
+        good = random_dendrogram(n, rng)
+        st, lab = raw_cut(good, n)
+        assert st == L.SUCCESS and lab.min() >= 0
+        # the labels of the guarded Python path are the labels of the raw entry
+        assert lab[:n].tolist() == fa.cut(good, n, 0.5).tolist()
+        for trial in range(60):
+            z = good.copy()
+            r = int(rng.integers(0, n - 1))
+            c = int(rng.integers(0, 2))
+            kind = trial % 8
+            if kind == 0:
+                z[r, c] = n + r                                   # its own node
+            elif kind == 1:
+                z[r, c] = n + r + int(rng.integers(0, n))         # a later (or non-existent) node
+            elif kind == 2:
+                z[r, c] = -1 - int(rng.integers(0, 5))
+            elif kind == 3:
+                z[r, c] = [np.nan, np.inf, -np.inf, 1e300][trial // 8 % 4]
+            elif kind == 4:
+                z[r, c] += 0.25
+            elif kind == 5:
+                z[r, 0] = z[r, 1]                                 # a node merged with itself
+            elif kind == 6:
+                if n == 2:
+                    continue
+                other = (r + 1 + int(rng.integers(0, n - 2))) % (n - 1)
+                z[r, c] = z[other, int(rng.integers(0, 2))]       # a node merged twice
+                if z[r, 0] == z[r, 1] or z[r, c] >= n + r:
+                    pass                                          # still damaged, another way
+            else:
+                z[r, c] = 2.0 ** 53 + 2 * trial                   # whole number far beyond any node
+            st, lab = raw_cut(z, n)
+            assert st == L.INVALID_ARGUMENT, (n, trial, kind, st)
+    # a two-row cycle: row 0 names node n+1, row 1 names node n (the endless walk of the fuzz run)
+    z = np.array([[0, 5, 0.1, 2], [1, 4, 0.2, 3], [2, 3, 0.3, 4]], np.float64)
+    assert raw_cut(z, 4)[0] == L.INVALID_ARGUMENT
+
+
 def test_bench_line_contract_on_the_committed_line():
     """The driver parses ONE JSON line of bench.py: the committed line of the round (profiles/r03_bench_v7.json, written on an MI355X)
     carries every field of the contract with the right types, and bench.py still spells each of them."""
