@@ -760,6 +760,28 @@ def mel_leg(fa, ctx, torch, dist, rank, world, B, steps, warmup, clock_warm_s, m
                          "note": "VALU / LDS-issue bound rather than HBM bound (DESIGN.md §3.1)"}}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks of this script, one per GPU, under torch.distributed.run
+    (the form the driver uses for N > 1) and hand its exit code back.  Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")             # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def ranks_seen(torch, dist, device):
+    """How many ranks the process group really joined: the sum of a one from every rank."""
+    one = torch.ones(1, dtype=torch.int64, device=device) if device is not None else torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(one)
+    return int(one.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -781,30 +803,58 @@ def main():
     ap.add_argument("--vbx-sharded", action="store_true", help="run the sharded-VBx leg at N = 1 too (it always runs at N > 1)")
     ap.add_argument("--only-mel", action="store_true", help="profiling helper: the configs[1] mel leg alone, printed as a reduced line")
     ap.add_argument("--ctc-matrices", type=int, default=10000)
+    ap.add_argument("--launch-check", action="store_true", help="start the ranks, form the process group, all-reduce a one per rank, print what was seen; no device work")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))                          # `python bench.py --gpus N` starts its own N ranks
     import torch
-    import fluidaudio_amd as fa
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # one rank per GPU is the contract: a launcher that started a different number of ranks than --gpus says is a mistake, not a warning
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
+    backend = os.environ.get("FA_BENCH_BACKEND", "nccl")          # "gloo": a rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("FA_BENCH_BACKEND", "nccl")      # "gloo": a rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
+        if args.launch_check:                                      # control flow only (runs without a GPU): rendezvous + one all-reduce
+            dist.init_process_group("gloo" if not torch.cuda.is_available() else backend, rank=rank, world_size=world)
+            seen = ranks_seen(torch, dist, torch.device("cuda", local_rank % torch.cuda.device_count()) if torch.cuda.is_available() and backend == "nccl" else None)
+            if rank == 0:
+                print(json.dumps({"launch_check": True, "n_gpus": seen, "world_size_env": world, "backend": dist.get_backend()}))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+        have = torch.cuda.device_count()
+        if backend == "nccl" and have < world:
+            if rank == 0:
+                print(f"bench.py: --gpus {world} needs {world} visible GPUs, this box has {have} (FA_BENCH_BACKEND=gloo rehearses the control flow "
+                      "with several ranks per GPU)", file=sys.stderr)
+            sys.exit(2)
         if backend != "nccl":
-            local_rank %= max(torch.cuda.device_count(), 1)
+            local_rank %= max(have, 1)
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        seen = ranks_seen(torch, dist, torch.device("cuda", local_rank) if backend == "nccl" else None)
+        if seen != world:
+            raise RuntimeError(f"the process group saw {seen} ranks, WORLD_SIZE says {world}")
     else:
+        if args.launch_check:
+            print(json.dumps({"launch_check": True, "n_gpus": 1, "world_size_env": 1, "backend": None}))
+            return
         torch.cuda.set_device(local_rank)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    import fluidaudio_amd as fa
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
     ctx = fa.default_context(local_rank)
@@ -905,6 +955,22 @@ def main():
             line["beam_search"] = beam_leg(fa, ctx, torch)
         except Exception as e:  # noqa: BLE001
             line["beam_search"] = {"error": repr(e)}
+    # The driver keeps `config` whole and drops / truncates the extra keys: the second half of the metric and the fractions of the other
+    # north-star kernels ride in it (each from the leg of the same name, where the inputs of the number are).
+    def pick(leg, *path):
+        v = line.get(leg)
+        for k in path:
+            v = v.get(k) if isinstance(v, dict) else None
+        return v
+    line["config"].update({
+        "ahc_50k_seconds": pick("ahc_50k", "seconds"), "ahc_50k_bit_exact_vs_reference_digest": pick("ahc_50k", "bit_exact_vs_reference_digest"),
+        "mel_roofline_frac": pick("mel", "roofline", "frac"), "mel_realtime_factor": pick("mel", "realtime_factor"),
+        "ctc_roofline_frac": pick("ctc", "roofline", "frac"), "ctc_ids_exact": pick("ctc", "ids_exact"),
+        "ctc_fp16_roofline_frac": pick("ctc_fp16", "roofline", "frac"),
+        "resample_44k1_roofline_frac": pick("resample", "44100->16000", "roofline", "frac"),
+        "tdt_roofline_frac": pick("tdt", "roofline", "frac"),
+        "vbx_sharded_all_ranks_same_elbos": pick("vbx_sharded", "all_ranks_same_elbos"),
+    })
     print(json.dumps(line))
     if dist is not None:
         dist.barrier()
