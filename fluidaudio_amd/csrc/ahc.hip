@@ -79,23 +79,9 @@ enum { OP_NONE = 0, OP_MERGE = 1, OP_RESCAN = 2, OP_COLLECT = 3, OP_PAIRS = 4 };
 #ifndef FA_AHC_PIGGY
 #define FA_AHC_PIGGY 0
 #endif
-// Rows requested one round ahead (0 = off, the default: MEASURED AND REJECTED in round 3, kept as a switch for the record).
-// The merges of every benchmark input are ONE chain: each merge joins the cluster made by the previous merge with its nearest
-// neighbour, whose matrix row is cold in HBM (a different 350 KB row every round: ~2 100 cycles until the operands arrive).  That
-// neighbour is predictable one round EARLIER: the entries of the new row barely move when the cluster absorbs another point, so the
-// next partner is usually one of the runners-up of the row produced now.  With kPrefetch > 0, wave 3 of phase 1 picks up to kPrefetch
-// runner-up blocks of the produced row from the records it reduces anyway (ballot against an adaptive threshold, no extra
-// reduction) and every workgroup requests its slice of those rows + their centroids next to the operands of the current merge
-// without ever waiting for them.  Result on the device (scripts/gpu_ahc_variants.sh, profiles/r03_ahc_variants.txt): the partner was
-// among 3 requested rows in 72 % (8 h session) / 59 % (50k iid) of the merges, among 1 in 41 % / 30 % — and the round got SLOWER:
-// 6.14 -> 6.31 us (1 row) -> 6.61 us (3 rows); "operands arrive" 2 130 -> 2 860 cycles.  A row requested by the previous kernel is
-// not served any faster by the next one (the L2 does not keep it across the kernel boundary, MALL / TLB warmth buys nothing
-// measurable), while the extra requests queue in front of the operands that ARE waited for.
-#ifndef FA_AHC_PREFETCH
-#define FA_AHC_PREFETCH 0
-#endif
-constexpr int kPrefetch = FA_AHC_PREFETCH;
-constexpr int kPfSlots = kPrefetch > 0 ? kPrefetch : 1;
+// (Round 3 measured and rejected requesting the likely partner rows of the NEXT merge one round ahead — the partner was among 3 requested
+// rows in 72 % / 59 % of the merges, yet the round got slower, 6.14 -> 6.61 us: DESIGN.md 3.3.1b, profiles/r03_ahc_variants.txt.  The
+// switch FA_AHC_PREFETCH and its code left the tree in round 4.)
 constexpr int kPiggy = FA_AHC_PIGGY;   // stale rows re-scanned on top of every merge / forced re-scan round
 constexpr int kPend = 1 + kPiggy;  // rows whose per-block partial minima one round can produce
 
@@ -109,14 +95,11 @@ struct AhcHot {
     int32_t sym_limit;            // nodes below this id existed when the matrix was last built in full: BOTH copies of their pairs are valid
     int32_t pend_row[kPend], pend_node[kPend];  // rows whose block-partial minima the previous round produced (-1: none)
     double eps, lim;              // lim: window limit carried COLLECT -> PAIRS -> evaluation
-    double pf_delta;              // relative threshold of the runner-up pick (adapted every round towards ~kPrefetch + 1 blocks inside it)
+    int32_t n_points, hot_pad;    // N of THIS problem: the uniform-layout batch (ahc_round_uni) shares every other shape constant between its problems
 };
 struct alignas(16) AhcState : AhcHot {
     unsigned long long dmax_bits, nmax_bits;  // largest matrix entry / largest squared norm seen by the start-up kernels
     long long rounds, rescans, windows, piggy;
-    int32_t pf_slot[kPfSlots];    // rows requested ahead by the previous round
-    int32_t pf_pad;
-    long long pf_hits, pf_merges; // merges whose partner row had been requested ahead / merges of the chain kind
 };
 static_assert(sizeof(AhcState) % 16 == 0 && sizeof(AhcHot) % 8 == 0, "the state is read in 16-byte pieces");
 constexpr int kHotVec = (sizeof(AhcHot) + 15) / 16;
@@ -301,8 +284,7 @@ __global__ void ahc_init_state(Ws w, int mode) {
     s.mode = mode;
     for (int k = 0; k < kPend; ++k) { s.pend_row[k] = -1; s.pend_node[k] = -1; }
     s.prev_op = OP_NONE;
-    s.pf_delta = 1e-3;
-    for (int g = 0; g < kPfSlots; ++g) s.pf_slot[g] = -1;
+    s.n_points = w.N; s.hot_pad = 0;
     s.sym_limit = w.N;                                     // the start-up writes the full matrix: every pair of points has both copies
     w.state[0] = s; w.state[1] = s;
     for (int i = 0; i < 4; ++i) { w.cnt[i].stale_key = ~0ULL; w.cnt[i].ncand = 0; w.cnt[i].npairs = 0; }
@@ -822,8 +804,7 @@ __device__ __forceinline__ int4 rec16(const void *base, const size_t idx) { retu
 __device__ __forceinline__ double rec_f64(const int4 r) { return __hiloint2double(r.y, r.x); }
 struct Dec {
     double v1, sv[kWaves], pd[kPend];
-    int cnt, r1, q1, nr1, nq1, pfn, pad1, pad2;
-    int pfs[kPfSlots], pfnode[kPfSlots];
+    int cnt, r1, q1, nr1, nq1, pad0, pad1, pad2;
     int srow[kWaves], snode[kWaves], ps[kPend], pn[kPend];
 };
 
@@ -831,7 +812,13 @@ struct Dec {
 // blkmap[b].x as its block blkmap[b].y; the problem's workspace descriptor comes from a table in HBM (written before the
 // first launch, constant afterwards: read through the constant address space, i.e. with scalar loads, like a kernel argument).
 // the round itself; `w` = the problem's workspace, `blk` = this workgroup's block of 256 slots (see the three entry kernels below)
-__device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const int ph /* round index & 3 */) {
+// N_IN_STATE: the point count comes from the problem's state (uniform-layout batch: every other shape constant is shared by its problems).
+// Its arrays that are first touched AFTER the round's first batch of requests (matrix, centroids, sizes, dendrogram, window buffers) arrive
+// as problem 0's and are moved by `late_shift` bytes behind that batch: their pointers come out of scalar loads of the argument segment, and an
+// addition in front of the first request would put the wait for those loads there.
+template <bool N_IN_STATE = false>
+__device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, const int ph /* round index & 3 */, const size_t late_shift = 0) {
+    Ws w = w_in;
     extern __shared__ double s_cvec[];  // [d] merged centroid (EXACT rows)
     __shared__ WaveOut s_out[1];
     __shared__ Dec s_dec;
@@ -841,7 +828,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = blk * kBlk + tid;
     const int par = ph & 1, npar = par ^ 1;
-    const int Np = w.Np, nblk = w.nblk, d = w.d, N = w.N;
+    const int Np = w.Np, nblk = w.nblk, d = w.d, N_arg = w.N;
 #ifdef FA_AHC_PROFILE
     const int prof_blk = nblk / 2;
     unsigned long long t_seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -893,10 +880,16 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
     // the row addresses of the operands, cnt / pairs / cand: the rare window paths, which the compiler loads together with N): left to the
     // scheduler they are scalar loads right where they are used, i.e. two scalar-cache round trips inside the chain.  Naming them here puts
     // the loads next to the round's first memory round trip.
-    asm volatile("" :: "s"(N), "s"(Np), "s"(d), "s"(w.cnt), "s"(w.pairs), "s"(w.cand));
+    asm volatile("" :: "s"(N_arg), "s"(Np), "s"(d), "s"(w.cnt), "s"(w.pairs), "s"(w.cand));
 #endif
     AhcHot st;
     __builtin_memcpy(&st, hraw, sizeof(AhcHot));
+    const int N = N_IN_STATE ? st.n_points : N_arg;
+    if (N_IN_STATE) {
+        auto at = [late_shift](auto *q) { return reinterpret_cast<decltype(q)>(reinterpret_cast<char *>(q) + late_shift); };
+        w.M = at(w.M); w.C = at(w.C); w.XT = at(w.XT); w.sizes = at(w.sizes); w.Z = at(w.Z); w.recS = at(w.recS);
+        w.cand = at(w.cand); w.pairs = at(w.pairs); w.cnt = at(w.cnt); w.prof = at(w.prof);
+    }
     auto whole_state = [&]() {   // thread (0, 0) only: the present state reassembled from its pieces
         int4 all[kHotVec + (kColdVec > 0 ? kColdVec : 1)];
 #pragma unroll
@@ -955,23 +948,6 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         wave_min_multi<2>(keys, m, L);
         const int a0 = lane_value(ps[0], L[0]), b0 = lane_value(pn[0], L[0]), a1 = lane_value(ps[1], L[1]), b1 = lane_value(pn[1], L[1]);
         if (lane == 0) { s_dec.pd[pk0] = m[0]; s_dec.ps[pk0] = a0; s_dec.pn[pk0] = b0; if (phas1) { s_dec.pd[pk1] = m[1]; s_dec.ps[pk1] = a1; s_dec.pn[pk1] = b1; } }
-        if (kPrefetch > 0 && wave == 3) {   // runners-up of the row produced by the previous round: lanes (block groups) within (1 + delta) of its minimum
-            unsigned long long mask = __builtin_amdgcn_ballot_w64(keys[0] <= m[0] * (1.0 + st.pf_delta) && lane != L[0] && ps[0] >= 0 && keys[0] < dinf());
-            const int inside = __popcll(mask);
-            int cs[kPfSlots], cn[kPfSlots];
-#pragma unroll
-            for (int g = 0; g < kPfSlots; ++g) {
-                const int l = mask ? __ffsll(static_cast<long long>(mask)) - 1 : 0;
-                cs[g] = mask ? lane_value(ps[0], l) : -1;
-                cn[g] = mask ? lane_value(pn[0], l) : -1;
-                mask &= mask - 1;
-            }
-            if (lane == 0) {
-                s_dec.pfn = inside;
-#pragma unroll
-                for (int g = 0; g < kPfSlots; ++g) { s_dec.pfs[g] = cs[g]; s_dec.pfnode[g] = cn[g]; }
-            }
-        }
     };
     if (c <= kC4) {
         if (wave == 0) reduce_minimum(std::integral_constant<int, kC4>{}, q0, q1, qok);
@@ -1169,9 +1145,6 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         return;
     }
 
-    double pf_row[kPfSlots], pf_cen[kPfSlots][4];   // sinks of the warm-up requests (kPrefetch): consumed by an empty asm at the end of the round
-#pragma unroll
-    for (int g = 0; g < kPfSlots; ++g) { pf_row[g] = 0.0; pf_cen[g][0] = pf_cen[g][1] = pf_cen[g][2] = pf_cen[g][3] = 0.0; }
     double pkey[kPend];  // this column's entry of each row being produced
     int pslot[kPend], pnd[kPend];
 #pragma unroll
@@ -1210,22 +1183,6 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         if (!sp_hit) {
 #pragma unroll
             for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; xa[j] = k < d ? ca[k] : 0.0; xb[j] = k < d ? cb[k] : 0.0; }
-        }
-        if (kPrefetch > 0) {   // warm-up requests for the likely partner rows of the NEXT merge (see kPrefetch); nothing below waits for them
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < kPfSlots; ++g) {
-                const int S = dv.pfs[g], nS = dv.pfnode[g];
-                if (S >= 0 && S != a && S != b) {
-                    if (act && x != S) pf_row[g] = pair_entry(w.M, Np, S, nS, x, nx, st.sym_limit);
-                    if (wave == 0) {   // the candidate's centroid: 2 KB, one request per lane and 512-byte quarter
-                        const double *cp = w.C + static_cast<size_t>(nS) * d;
-#pragma unroll
-                        for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; if (k < d) pf_cen[g][j] = cp[k]; }
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
         AHC_STAMP(9);
         const bool keeps_centroid = wave == 0 && (st.mode == FA_AHC_MODE_EXACT || blk == 0);
@@ -1360,33 +1317,9 @@ __device__ __forceinline__ void ahc_round_body(const Ws w, const int blk, const 
         WinCounters *z = w.cnt + ((ph + 1) & 3);   // trip sat on the critical path of workgroup 0 — the next wait for a load also waits for it)
         z->stale_key = ~0ULL; z->ncand = 0; z->npairs = 0;
     }
-    if (kPrefetch > 0) {
-#pragma unroll
-        for (int g = 0; g < kPfSlots; ++g) asm volatile("" ::"v"(pf_row[g]), "v"(pf_cen[g][0]), "v"(pf_cen[g][1]), "v"(pf_cen[g][2]), "v"(pf_cen[g][3]));
-    }
     if (blk == 0 && tid == 0) {
         const AhcState full = whole_state();
         AhcState n = full;
-        if (kPrefetch > 0) {
-            if (D.op == OP_MERGE) {
-                // was the partner of this merge among the rows requested by the previous round?  (statistics only)
-                bool chain = false, hit = false;
-#pragma unroll
-                for (int k = 0; k < kPend; ++k) chain = chain || (st.prev_op == OP_MERGE && (D.a == st.pend_row[0] || D.b == st.pend_row[0]));
-#pragma unroll
-                for (int g = 0; g < kPfSlots; ++g) hit = hit || (full.pf_slot[g] >= 0 && (full.pf_slot[g] == D.a || full.pf_slot[g] == D.b));
-                if (chain) { n.pf_merges = full.pf_merges + 1; if (hit) n.pf_hits = full.pf_hits + 1; }
-#pragma unroll
-                for (int g = 0; g < kPfSlots; ++g) n.pf_slot[g] = dv.pfs[g];
-                // keep about kPrefetch + 1 block groups inside the threshold
-                double dl = st.pf_delta;
-                if (dv.pfn > kPrefetch + 2) dl *= 0.7; else if (dv.pfn < kPrefetch) dl *= 1.3;
-                n.pf_delta = dl < 1e-13 ? 1e-13 : (dl > 1.0 ? 1.0 : dl);
-            } else {
-#pragma unroll
-                for (int g = 0; g < kPfSlots; ++g) n.pf_slot[g] = -1;
-            }
-        }
         n.prev_op = D.op;
         for (int k = 0; k < kPend; ++k) { n.pend_row[k] = prow[k]; n.pend_node[k] = pnode_[k]; if (k > 0 && prow[k] >= 0) n.piggy = n.piggy + 1; }
         n.lim = D.lim;
@@ -1452,6 +1385,39 @@ __global__ __launch_bounds__(kBlk) void ahc_rounds_single_block(const Ws w, cons
         __syncthreads();   // workgroup-scope release / acquire: the waves of one workgroup share the CU's caches
     }
 }
+
+// ahc_round_uni: K problems in ONE launch without any look-up in front of the round (round 4).  The host lays the K workspaces out with the
+// SAME layout (that of the largest problem; a smaller one simply has more dead padding slots) at a constant stride, so every array of
+// problem k is the array of problem 0 + k * stride: the grid is (blocks, problems), the problem index is the workgroup id in y (an SGPR the
+// hardware hands over), and the addresses of the round's first memory round trip are arithmetic on PRELOADED kernel arguments — the same
+// zero scalar round trips as the single-problem kernel.  (ahc_round_args, the round-2 form: 154 scalar instructions and three dependent
+// scalar-cache round trips — block -> problem search over 16 block ranges, then two batches of workspace fields out of a by-value array
+// indexed by the problem — in front of its first request: 11 us per round of 16 problems against 5.3 us for one.)  Only N differs per
+// problem: it comes from the hot part of the problem's state, with the first batch of loads.
+// arg 0 = (blocks << 2) | (round & 3), stride in 4 KB pages: 14 preloaded dwords like ahc_round_t.
+#define FA_AHC_UNI_KERNEL(NAME, ATTR)                                                                                                                   \
+    __global__ __launch_bounds__(kBlk) ATTR void NAME(const unsigned nblk_ph, const unsigned stride_pages, AhcState *const state_, RecA *const recA_,  \
+                                                      int4 *const recI_, RecP *const recP_, const unsigned off_row, const unsigned off_node,           \
+                                                      const unsigned off_e2, const unsigned off_flags, const Ws w_one) {                              \
+        ahc_round_uni_body(nblk_ph, stride_pages, state_, recA_, recI_, recP_, off_row, off_node, off_e2, off_flags, w_one);                           \
+    }
+__device__ __forceinline__ void ahc_round_uni_body(const unsigned nblk_ph, const unsigned stride_pages, AhcState *const state_, RecA *const recA_, int4 *const recI_,
+                                                   RecP *const recP_, const unsigned off_row, const unsigned off_node, const unsigned off_e2, const unsigned off_flags,
+                                                   const Ws &w_one) {
+    const size_t sh = (static_cast<size_t>(blockIdx.y) * stride_pages) << 12;
+    auto at = [sh](auto *p) { return reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + sh); };
+    Ws w_ = w_one;
+    const int nblk_ = static_cast<int>(nblk_ph >> 2);
+    w_.nblk = nblk_; w_.Np = nblk_ * kBlk; w_.state = at(state_); w_.recA = at(recA_); w_.recI = at(recI_); w_.recP = at(recP_);
+    char *base = reinterpret_cast<char *>(w_.state);
+    w_.row = reinterpret_cast<RowSt *>(base + off_row); w_.node = reinterpret_cast<int *>(base + off_node);
+    w_.e2 = reinterpret_cast<double *>(base + off_e2); w_.flags = reinterpret_cast<int *>(base + off_flags);
+    ahc_round_body<true>(w_, blockIdx.x, static_cast<int>(nblk_ph & 3u), sh);
+}
+// the same kernel at three register budgets: more co-resident workgroups per CU against spills (which one serves a batch: ahc_batch_uniform)
+FA_AHC_UNI_KERNEL(ahc_round_uni, )
+FA_AHC_UNI_KERNEL(ahc_round_uni_w3, __attribute__((amdgpu_waves_per_eu(3, 3))))
+FA_AHC_UNI_KERNEL(ahc_round_uni_w4, __attribute__((amdgpu_waves_per_eu(4, 4))))
 
 constexpr int kArgProblems = 16;
 struct BatchArgs {
@@ -2022,9 +1988,8 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     }
 #endif
     if (getenv("FA_AHC_DEBUG"))
-        fprintf(stderr, "ahc: N %zu rounds %lld merges %d forced re-scans %lld piggy-backed re-scans %lld windows %lld fallback %lld (kPiggy %d); "
-                "rows requested ahead: %d per round, partner was among them in %lld of %lld chain merges, threshold %.3g\n", N, p.h.rounds, p.h.step,
-                p.h.rescans, p.h.piggy, p.h.windows, p.fallback, kPiggy, kPrefetch, p.h.pf_hits, p.h.pf_merges, p.h.pf_delta);
+        fprintf(stderr, "ahc: N %zu rounds %lld merges %d forced re-scans %lld piggy-backed re-scans %lld windows %lld fallback %lld (kPiggy %d)\n", N, p.h.rounds,
+                p.h.step, p.h.rescans, p.h.piggy, p.h.windows, p.fallback, kPiggy);
     if (stats) {
         float t01 = 0, t12 = 0;
         (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
@@ -2176,6 +2141,134 @@ fa_status ahc_batch_once(fa_ctx *ctx, int count, const double *const *d_data, co
 }
 }  // namespace
 
+namespace {
+// The same, with the uniform layout of ahc_round_uni: every problem's workspace has the layout of the LARGEST problem and sits at a constant
+// stride, the grid is (blocks of that layout, problems).  Eligible batches (the caller checks): >= 2 problems of >= 2 points, no reference-
+// order mode, the smallest padded size at least half the largest (a smaller problem only pays dead padding slots: start-up and HBM of
+// the larger layout).  Problems are placed by size, largest first: the running set stays a prefix of the placement, so the grid shrinks in y
+// as the short ones finish.  Per problem the result is the single-problem entry's bit for bit (test_uniform_batch_*).
+int uniform_kernel_choice(size_t blocks_total) {
+    // co-residency: 256 CUs x 4 SIMDs x (waves per SIMD) / 4 waves per workgroup.  The default build of the round holds 2 waves per SIMD
+    // (186 VGPRs): 512 workgroups; capped at 168 / 128 VGPRs: 768 / 1024.  FA_AHC_UNI_WAVES = 2 | 3 | 4 overrides (measurements).
+    if (const char *e = getenv("FA_AHC_UNI_WAVES")) { const int v = atoi(e); if (v >= 2 && v <= 4) return v; }
+    return blocks_total <= 512 ? 2 : (blocks_total <= 768 ? 3 : 4);
+}
+
+fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
+                            fa_ahc_stats *stats, fa_status *statuses, bool *completed) {
+    *completed = false;
+    std::vector<int> ord(static_cast<size_t>(count));
+    for (int k = 0; k < count; ++k) ord[k] = k;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return n[a] > n[b]; });
+    const size_t Nmax = n[ord[0]], Npmax = (Nmax + kBlk - 1) / kBlk * kBlk, nblk = Npmax / kBlk;
+    FA_TRY(prob_check_shape(ctx, Nmax, d));
+    const Layout L = make_layout(Nmax, Npmax, d, nblk);
+    const size_t stride = (L.total + 4095) & ~static_cast<size_t>(4095);
+    if ((stride >> 12) > 0xffffffffull) return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: workspace stride too large");
+    fa::WsUse ws_use(ctx);
+    FA_TRY(fa::ws_acquire(ctx, stride * static_cast<size_t>(count)));
+    char *base = static_cast<char *>(ctx->ahc_ws);
+    std::vector<Prob> probs(static_cast<size_t>(count));     // in placement order
+    hipEvent_t ev[3];
+    for (auto &e : ev) FA_HIP_TRY(ctx, hipEventCreate(&e));
+    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
+    FA_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+    for (int j = 0; j < count; ++j) {
+        Prob &p = probs[j];
+        const int k = ord[j];
+        p.N = n[k]; p.d = d; p.Np = Npmax; p.d_data = d_data[k]; p.d_Z = d_Z[k]; p.mode = mode; p.L = L;
+        if (statuses) statuses[k] = FA_SUCCESS;
+        const fa_status st = prob_setup(ctx, p, base + stride * static_cast<size_t>(j));
+        if (st != FA_SUCCESS) { p.st = st; p.active = false; }
+    }
+    FA_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
+    const size_t lds = sizeof(double) * d;
+    const Ws w0 = probs[0].w;
+    auto off_of = [&](const void *q) { return static_cast<unsigned>(static_cast<const char *>(q) - reinterpret_cast<const char *>(w0.state)); };
+    const unsigned o_row = off_of(w0.row), o_node = off_of(w0.node), o_e2 = off_of(w0.e2), o_flags = off_of(w0.flags);
+    const unsigned stride_pages = static_cast<unsigned>(stride >> 12);
+    int grid_y = count;
+    int kernel = 2;
+    auto launch = [&](const int ph) {
+        const unsigned a0 = (static_cast<unsigned>(w0.nblk) << 2) | static_cast<unsigned>(ph & 3);
+        const dim3 grid(static_cast<unsigned>(w0.nblk), static_cast<unsigned>(grid_y));
+        if (kernel == 4) hipLaunchKernelGGL(ahc_round_uni_w4, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
+        else if (kernel == 3) hipLaunchKernelGGL(ahc_round_uni_w3, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
+        else hipLaunchKernelGGL(ahc_round_uni, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
+    };
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_w3), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_w4), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    }
+    const long long max_batches = 64 + 8 * static_cast<long long>(Nmax) / rounds_for(Nmax);
+    RoundGraph *rg = nullptr;
+    struct RgGuard { RoundGraph *&p; ~RgGuard() { delete p; } } rgg{rg};
+    int captured_y = -1;
+    for (long long it = 0; it < max_batches; ++it) {
+        int last_active = -1;
+        for (int j = 0; j < count; ++j) if (probs[j].active) last_active = j;
+        if (last_active < 0) break;
+        // the running set is (nearly) a prefix: shrink the grid when at most half of the captured problems still run
+        if (captured_y < 0 || (last_active + 1) * 2 <= captured_y) {
+            grid_y = last_active + 1;
+            kernel = uniform_kernel_choice(static_cast<size_t>(grid_y) * w0.nblk);
+            size_t longest = 0;
+            for (int j = 0; j <= last_active; ++j) if (probs[j].active && probs[j].N > longest) longest = probs[j].N;
+            delete rg;
+            rg = new RoundGraph();
+            rg->capture(ctx, launch, rounds_for(longest));
+            captured_y = grid_y;
+        }
+        FA_TRY(rg->replay(ctx, launch));
+        for (int j = 0; j < grid_y; ++j) if (probs[j].active) FA_HIP_TRY(ctx, hipMemcpyAsync(&probs[j].h, probs[j].w.state, sizeof(AhcState), hipMemcpyDeviceToHost, ctx->stream));
+        FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int j = 0; j < grid_y; ++j) if (probs[j].active) (void)prob_after_replay(ctx, probs[j]);
+    }
+    fa_status worst = FA_SUCCESS;
+    for (int j = 0; j < count; ++j) {
+        Prob &p = probs[j];
+        if (p.st == FA_SUCCESS) (void)prob_finish(ctx, p);
+        if (statuses) statuses[ord[j]] = p.st;
+        if (p.st != FA_SUCCESS && worst == FA_SUCCESS) worst = p.st;
+    }
+    FA_HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        float t01 = 0, t12 = 0;
+        (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+        for (int j = 0; j < count; ++j) {
+            const Prob &p = probs[j];
+            fa_ahc_stats &o = stats[ord[j]];
+            o = fa_ahc_stats{};
+            o.merges = p.h.step; o.rounds = p.h.rounds; o.rescans = p.h.rescans; o.exact_fallback = p.fallback;
+            o.windows = p.h.windows; o.init_ms = t01; o.merge_ms = t12; o.total_ms = t01 + t12;   // times of the whole batch
+        }
+    }
+    for (int j = 0; j < count; ++j) {   // exact ties at the minimum: those problems again, one after the other, in reference order
+        Prob &p = probs[j];
+        if (!p.needs_ro || p.st != FA_SUCCESS) continue;
+        p.st = ro_run_device(ctx, p.d_data, p.N, p.d, p.d_Z, stats ? &stats[ord[j]] : nullptr);
+        if (statuses) statuses[ord[j]] = p.st;
+        if (p.st != FA_SUCCESS && worst == FA_SUCCESS) worst = p.st;
+    }
+    *completed = true;
+    return worst;
+}
+
+bool uniform_eligible(int count, const size_t *n, int mode) {
+    if (count < 2 || mode == FA_AHC_MODE_REFERENCE_ORDER || getenv("FA_AHC_NO_UNIFORM")) return false;
+    size_t lo = SIZE_MAX, hi = 0;
+    for (int k = 0; k < count; ++k) {
+        if (n[k] < 2) return false;
+        const size_t np = (n[k] + kBlk - 1) / kBlk * kBlk;
+        lo = std::min(lo, np); hi = std::max(hi, np);
+    }
+    return hi / kBlk >= 2 && lo * 2 >= hi && hi / kBlk <= static_cast<size_t>(kMaxBlocks);   // one-block problems keep their single-launch form
+}
+}  // namespace
+
 // Status contract: statuses[k] is the outcome of problem k whatever happens.  An early failure of the batch as a whole (workspace
 // allocation, an event, a copy, a graph replay) marks EVERY problem that was to run with that failure — round 2 left them at SUCCESS
 // and the callers went on to cut dendrograms that were never written.  When the combined workspace of the batch (sum of N_k^2 * 8 B)
@@ -2236,12 +2329,15 @@ fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *
     std::vector<fa_status> local(static_cast<size_t>(count), FA_SUCCESS);
     fa_status *sts = statuses ? statuses : local.data();
     {
-        bool large = count >= 2 && count <= kInFlightMax && getenv("FA_AHC_NO_IN_FLIGHT") == nullptr;
+        // chains in flight on helper contexts (round 3) only on request since round 4: the uniform-layout batch advances the same problems by
+        // ONE launch per round, on one stream — its rate does not depend on which hardware queues the process's streams landed on
+        bool large = count >= 2 && count <= kInFlightMax && getenv("FA_AHC_IN_FLIGHT") != nullptr;
         for (int k = 0; k < count && large; ++k) large = n[k] >= kInFlightMinN;
         if (large) return ahc_batch_in_flight(ctx, count, d_data, n, d, d_Z, mode, stats, sts);
     }
     bool completed = false;
-    const fa_status st = ahc_batch_once(ctx, count, d_data, n, d, d_Z, mode, stats, sts, &completed);
+    const fa_status st = uniform_eligible(count, n, mode) ? ahc_batch_uniform(ctx, count, d_data, n, d, d_Z, mode, stats, sts, &completed)
+                                                          : ahc_batch_once(ctx, count, d_data, n, d, d_Z, mode, stats, sts, &completed);
     if (completed) return st;
     const fa_status fail = st != FA_SUCCESS ? st : FA_RUNTIME_ERROR;
     if (fail == FA_ALLOCATION_FAILURE && count > 1) {

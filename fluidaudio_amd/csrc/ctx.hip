@@ -101,6 +101,7 @@ void fa_ctx_destroy(fa_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ahc_ws) (void)hipFree(ctx->ahc_ws);
     if (ctx->poly_taps) (void)hipFree(ctx->poly_taps);
+    if (ctx->poly_rows && ctx->poly_rows_free) ctx->poly_rows_free(ctx->poly_rows);
     if (ctx->ahc_graph && ctx->ahc_graph_free) ctx->ahc_graph_free(ctx->ahc_graph);
     if (ctx->mel_cache && ctx->mel_cache_free) ctx->mel_cache_free(ctx->mel_cache);
     for (auto &e : ctx->ahc_ev) if (e) (void)hipEventDestroy(e);

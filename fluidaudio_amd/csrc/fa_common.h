@@ -42,6 +42,8 @@ struct fa_ctx {
     void *poly_taps = nullptr;
     size_t poly_taps_bytes = 0;
     int32_t poly_up = 0, poly_down = 0, poly_half = 0;
+    void *poly_rows = nullptr;                 // per-phase tables of the same pair for poly_rows_kernel (owned by resample.hip)
+    void (*poly_rows_free)(void *) = nullptr;
 };
 
 namespace fa {

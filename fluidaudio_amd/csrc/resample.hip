@@ -137,6 +137,164 @@ __global__ __launch_bounds__(kThreads) void poly_decim_kernel(const float *__res
     for (int j = 0; j < R; j += 2) *reinterpret_cast<float2 *>(y + m0 + j) = make_float2(acc[j], acc[j + 1]);
 }
 
+// ------------------------------------------------------------------------------ non-integer ratios (44.1 / 22.05 / 11.025 / 88.2 kHz -> 16 kHz)
+// poly_rows_kernel (round 4).  Output m uses the taps h[p - k up] of its PHASE p mod up, p = (m + pre_remove) down; outputs m and m + up
+// share a phase and their input windows lie exactly `down` samples apart.  So lane l of a wavefront takes the outputs m0 + phase + up l:
+//   * the taps of a phase are the same in all 64 lanes -> they arrive through the scalar cache (a per-phase table, contiguous) and enter the
+//     fused multiply-adds as SGPR operands: no LDS read, no vector register per tap;
+//   * the input window of lane l is row l of an LDS tile whose rows are `down` samples apart in the signal and `sld` floats apart in LDS,
+//     sld = 4 x odd: every lane's 16-byte reads are aligned and the 64 lanes of a read fall on distinct bank groups.  A window starts at
+//     (off & ~3) in its row, the misalignment a = off & 3 is the same in all lanes and selects one of four unrolled bodies whose register
+//     indices are compile-time constants: NV ds_read_b128 per phase and wavefront instead of ~4 NV x 2 scalar-width LDS operands
+//     (poly_lds_kernel: two ds_read_b32 per multiply-add, 6.9 % of the HBM roofline at 44.1 -> 16 kHz, LDS-issue bound);
+//   * a workgroup = one tile (64 up consecutive outputs) x one group of phases (the phases are split so that the rows of a group fit ~72 KB:
+//     two workgroups per CU, one staging while the other computes).  Results leave straight from the accumulator: lane l writes
+//     y[m0 + phase + up l] — scattered 4-byte stores whose lines fill up in L2 as the other phases of the tile arrive.
+// Summation order per output: ascending input index over exactly the k range of poly_kernel (leading zero taps included) -> identical bits.
+// The tile geometry (first output, first input, per-phase window offsets and counts) is computed once per rate pair on the host
+// (PolyRows below); outputs whose windows touch the ends of the signal go to poly_kernel.
+struct PolyRowsGeom {
+    int64_t m_begin, k_begin;       // first output / first staged input of tile 0
+    int32_t up, down, ntp;          // ntp: floats per phase in the tap table (max taps of a phase rounded up to 4)
+    int32_t groups, ppg;            // phase groups per tile, phases per group
+    int32_t sld;                    // LDS row stride in floats (4 x odd)
+    int32_t smax;                   // last staged offset + 1 within a row over all phases (for the tile-count bound)
+};
+constexpr int kRowsThreads = 512, kRowsWaves = kRowsThreads / 64;
+
+template <int NV>
+__global__ __launch_bounds__(kRowsThreads) void poly_rows_kernel(const float *__restrict__ x, const float *__restrict__ tt, const int2 *__restrict__ ptab,
+                                                                float *__restrict__ y, const PolyRowsGeom g, const int64_t tiles, const int64_t m_end) {
+    extern __shared__ float xs[];
+    typedef const float __attribute__((address_space(4))) *c_f32;
+    typedef const int __attribute__((address_space(4))) *c_i32;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tile = blockIdx.x / g.groups;
+    const int grp = static_cast<int>(blockIdx.x - tile * g.groups);
+    const int ph0 = grp * g.ppg, ph1 = ph0 + g.ppg < g.up ? ph0 + g.ppg : g.up;
+    const c_i32 pt = (c_i32) reinterpret_cast<const int *>(ptab);
+    const int smin = pt[2 * ph0] & ~3;
+    const int span = pt[2 * (ph1 - 1)] + 4 * NV - smin;                 // offsets grow with the phase
+    const int64_t kt = g.k_begin + tile * 64 * g.down + smin;
+    for (int r = 0; r < 64 / kRowsWaves; ++r) {                         // wavefront w stages rows 8 w .. 8 w + 7: coalesced 256-byte requests
+        const int l = wave * (64 / kRowsWaves) + r;
+        const float *src = x + kt + static_cast<int64_t>(l) * g.down;
+        float *dst = xs + l * g.sld;
+        for (int sidx = lane; sidx < span; sidx += 64) dst[sidx] = src[sidx];
+    }
+    __syncthreads();
+    const float *rowp = xs + lane * g.sld - smin;
+    const int64_t m0 = g.m_begin + tile * 64 * g.up + static_cast<int64_t>(lane) * g.up;
+    for (int ph = ph0 + wave; ph < ph1; ph += kRowsWaves) {
+        const int off = pt[2 * ph], cnt = pt[2 * ph + 1];
+        const int a = off & 3;
+        const float4 *wp = reinterpret_cast<const float4 *>(rowp + (off - a));
+        float xr[4 * NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { const float4 q = wp[v]; xr[4 * v] = q.x; xr[4 * v + 1] = q.y; xr[4 * v + 2] = q.z; xr[4 * v + 3] = q.w; }
+        // all taps of the phase in one batch of scalar loads (the table is padded to ntp floats per phase; pinned in SGPRs here so that the
+        // loads are not sunk into the per-chunk branches below: one scalar round trip per phase, not one per chunk)
+        const c_f32 tsrc = (c_f32)(tt + static_cast<size_t>(ph) * g.ntp);
+        float tp[4 * (NV - 1)];
+#pragma unroll
+        for (int j = 0; j < 4 * (NV - 1); ++j) tp[j] = tsrc[j];
+#pragma unroll
+        for (int j = 0; j < 4 * (NV - 1); j += 4) asm volatile("" :: "s"(tp[j]), "s"(tp[j + 1]), "s"(tp[j + 2]), "s"(tp[j + 3]));
+        float acc = 0.0f;
+        auto body = [&](auto av) {
+            constexpr int A = decltype(av)::value;
+#pragma unroll
+            for (int c = 0; c < NV - 1; ++c) {                          // taps 4c .. 4c + 3 meet xr[A + 4c ..]; A + 4 (NV - 1) - 1 + 3 < 4 NV
+                if (4 * c + 4 <= cnt) {
+#pragma unroll
+                    for (int j = 4 * c; j < 4 * c + 4; ++j) acc = fmaf(tp[j], xr[A + j], acc);
+                } else {
+#pragma unroll
+                    for (int j = 4 * c; j < 4 * c + 4; ++j) if (j < cnt) acc = fmaf(tp[j], xr[A + j], acc);
+                }
+            }
+        };
+        if (a == 0) body(std::integral_constant<int, 0>{});
+        else if (a == 1) body(std::integral_constant<int, 1>{});
+        else if (a == 2) body(std::integral_constant<int, 2>{});
+        else body(std::integral_constant<int, 3>{});
+        const int64_t m = m0 + ph;
+        if (m < m_end) y[m] = acc;
+    }
+}
+
+// host side of poly_rows_kernel: the tables of one rate pair, resident on the device with the context
+struct PolyRows {
+    PolyRowsGeom g{};
+    int nv = 0;                     // 16-byte reads per phase window
+    size_t lds = 0;
+    void *d_tables = nullptr;       // [ptab int2 x up][tt float x up x ntp]
+    int up = 0, down = 0;
+    ~PolyRows() { if (d_tables) (void)hipFree(d_tables); }
+};
+void poly_rows_free(void *p) { delete static_cast<PolyRows *>(p); }
+
+// Geometry + tables; false when the pair does not suit the kernel (then poly_lds_kernel serves it).
+bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &ptab, std::vector<float> &tt) {
+    const int64_t h_len = static_cast<int64_t>(h.size());
+    if (up < 8 || up > 1024 || down > 4096) return false;               // few phases: the register-tiled kernels; huge ones: tables too large
+    const int q1 = static_cast<int>((h_len + up - 1) / up);             // a window holds floor(h_len / up) or that + 1 taps
+    int nv = (q1 + 3) / 4 + 1;                                          // 4 (nv - 1) >= q1 taps; the extra read covers a misalignment of up to 3
+    {   // instantiated sizes (poly_rows_launch); a larger one only reads a little further into the row
+        static const int sizes[] = {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 24, 31};
+        int pick = 0;
+        for (int v : sizes) if (v >= nv) { pick = v; break; }
+        if (!pick) return false;
+        nv = pick;
+    }
+    // first output whose window lies inside the signal: p - (h_len - 1) >= 0
+    int64_t m_begin = (h_len - 1 + down - 1) / down - pre_remove;
+    if (m_begin < 0) m_begin = 0;
+    const int64_t p0 = (m_begin + pre_remove) * down;
+    const int64_t k_begin = (p0 - (h_len - 1) + up - 1) / up;           // k_lo of the first output
+    ptab.assign(2 * static_cast<size_t>(up), 0);
+    const int ntp = 4 * (nv - 1);
+    tt.assign(static_cast<size_t>(up) * ntp, 0.0f);
+    int smax = 0;
+    for (int ph = 0; ph < up; ++ph) {
+        const int64_t p = p0 + static_cast<int64_t>(ph) * down;
+        const int64_t k_hi = p / up, k_lo = (p - (h_len - 1) + up - 1) / up;   // p - (h_len - 1) >= 0 here
+        const int cnt = static_cast<int>(k_hi - k_lo + 1);
+        if (cnt > ntp || cnt < 1) return false;
+        ptab[2 * ph] = static_cast<int>(k_lo - k_begin);
+        ptab[2 * ph + 1] = cnt;
+        for (int j = 0; j < cnt; ++j) tt[static_cast<size_t>(ph) * ntp + j] = h[static_cast<size_t>(p - (k_lo + j) * up)];
+        smax = std::max(smax, ptab[2 * ph] + 4 * nv);
+    }
+    // phase groups: the rows of a group within ~72 KB of LDS (two workgroups per CU); rows are `sld` floats apart, sld = 4 x odd >= span
+    int groups = 1, ppg = up, sld = 0;
+    for (;; ++groups) {
+        ppg = (up + groups - 1) / groups;
+        int span = 0;
+        for (int gq = 0; gq < groups; ++gq) {
+            const int a0 = gq * ppg, a1 = std::min(up, a0 + ppg);
+            if (a0 >= a1) continue;
+            span = std::max(span, ptab[2 * (a1 - 1)] + 4 * nv - (ptab[2 * a0] & ~3));
+        }
+        sld = (span + 3) / 4;
+        if (sld % 2 == 0) ++sld;
+        sld *= 4;
+        if (static_cast<size_t>(sld) * 64 * sizeof(float) <= 74 * 1024 || ppg <= kRowsWaves) break;
+    }
+    if (static_cast<size_t>(sld) * 64 * sizeof(float) > 150 * 1024) return false;
+    R.g.m_begin = m_begin; R.g.k_begin = k_begin; R.g.up = up; R.g.down = down; R.g.ntp = ntp; R.g.groups = groups; R.g.ppg = ppg; R.g.sld = sld; R.g.smax = smax;
+    R.nv = nv; R.lds = static_cast<size_t>(sld) * 64 * sizeof(float); R.up = up; R.down = down;
+    return true;
+}
+
+template <int NV>
+void poly_rows_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end) {
+    const int2 *ptab = static_cast<const int2 *>(R.d_tables);
+    const float *tt = reinterpret_cast<const float *>(static_cast<const char *>(R.d_tables) + sizeof(int2) * R.up);
+    if (R.lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(poly_rows_kernel<NV>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(R.lds));
+    hipLaunchKernelGGL(poly_rows_kernel<NV>, dim3(static_cast<unsigned>(tiles * R.g.groups)), dim3(kRowsThreads), R.lds, ctx->stream, d_x, tt, ptab, d_y, R.g, tiles, m_end);
+}
+
 double bessel_i0(double x) {  // power series, converges fast for the beta used here
     double sum = 1.0, term = 1.0;
     const double q = x * x / 4.0;
@@ -259,6 +417,24 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
             FA_HIP_TRY(ctx, hipMemcpyAsync(ctx->poly_taps, taps.data(), sizeof(float) * n_taps, hipMemcpyHostToDevice, ctx->stream));
             FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // taps is a host temporary (first call of a rate pair only)
             ctx->poly_up = u; ctx->poly_down = dn;
+            // per-phase tables of the pair for poly_rows_kernel (non-integer ratios), built and uploaded with the taps
+            if (ctx->poly_rows && ctx->poly_rows_free) { ctx->poly_rows_free(ctx->poly_rows); ctx->poly_rows = nullptr; }
+            {
+                PolyRows *R = new PolyRows();
+                std::vector<int> ptab;
+                std::vector<float> tt;
+                bool ok = poly_rows_build(*R, taps, u, dn, pre_remove, ptab, tt);
+                if (ok) {
+                    const size_t b0 = sizeof(int) * ptab.size(), b1 = sizeof(float) * tt.size();
+                    ok = hipMalloc(&R->d_tables, b0 + b1) == hipSuccess &&
+                         hipMemcpyAsync(R->d_tables, ptab.data(), b0, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                         hipMemcpyAsync(static_cast<char *>(R->d_tables) + b0, tt.data(), b1, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                         hipStreamSynchronize(ctx->stream) == hipSuccess;
+                    if (!ok) (void)hipGetLastError();
+                }
+                if (ok) { ctx->poly_rows = R; ctx->poly_rows_free = poly_rows_free; }
+                else delete R;                                            // the LDS-staged kernel serves the pair
+            }
         }
         float *d_h = static_cast<float *>(ctx->poly_taps);
         const bool simple = getenv("FA_RESAMPLE_SIMPLE") != nullptr;
@@ -290,9 +466,37 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
                 decim = true;
             }
         }
+        // non-integer ratios: row-tiled kernel on the tiles whose staged inputs all exist, poly_kernel on the two ends
+        bool rows = false;
+        if (!decim && !simple && ctx->poly_rows && getenv("FA_RESAMPLE_NO_ROWS") == nullptr) {
+            const PolyRows &R = *static_cast<const PolyRows *>(ctx->poly_rows);
+            const PolyRowsGeom &G = R.g;
+            // tile t stages x[k_begin + 64 down t ... + 63 down + smax): all of it inside the signal
+            const int64_t last_need = G.k_begin + 63LL * G.down + G.smax;     // exclusive end of tile 0's staged range
+            int64_t tiles = frames >= last_need ? (frames - last_need) / (64LL * G.down) + 1 : 0;
+            const int64_t per_tile = 64LL * G.up;
+            if (G.m_begin < n_out) tiles = std::min(tiles, (n_out - G.m_begin + per_tile - 1) / per_tile); else tiles = 0;
+            // every output of the tiles must have its whole window (k_hi <= frames - 1): true when the staged range is inside the signal and
+            // the window of the tile's last output ends inside its row — guaranteed by smax covering off + 4 nv of every phase
+            if (tiles > 0 && tiles * G.groups < (1LL << 31)) {
+                const int64_t m_stop = std::min(n_out, G.m_begin + tiles * per_tile);
+                switch (R.nv) {
+#define FA_ROWS_CASE(V) case V: poly_rows_launch<V>(ctx, R, d_x, d_y, tiles, m_stop); break;
+                    FA_ROWS_CASE(4) FA_ROWS_CASE(5) FA_ROWS_CASE(6) FA_ROWS_CASE(7) FA_ROWS_CASE(8) FA_ROWS_CASE(9) FA_ROWS_CASE(10) FA_ROWS_CASE(11) FA_ROWS_CASE(12)
+                    FA_ROWS_CASE(13) FA_ROWS_CASE(14) FA_ROWS_CASE(15) FA_ROWS_CASE(16) FA_ROWS_CASE(17) FA_ROWS_CASE(18) FA_ROWS_CASE(20) FA_ROWS_CASE(24) FA_ROWS_CASE(31)
+#undef FA_ROWS_CASE
+                    default: tiles = 0; break;
+                }
+                if (tiles > 0) {
+                    edges(0, G.m_begin);
+                    edges(m_stop, n_out);
+                    rows = true;
+                }
+            }
+        }
         const int64_t span = (static_cast<int64_t>(kPolyTile) * dn + u - 1) / u + (n_taps + u - 1) / u + 4;
         const size_t lds = sizeof(float) * (static_cast<size_t>((n_taps + 3) & ~static_cast<int64_t>(3)) + static_cast<size_t>(span));
-        if (decim) {
+        if (decim || rows) {
         } else if (lds <= 150 * 1024 && !simple) {
             if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(poly_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
             const int64_t tiles = (n_out + kPolyTile - 1) / kPolyTile;

@@ -311,9 +311,10 @@ def test_more_than_65536_points_takes_the_many_record_path(fa, gpu_ctx):
     torch.cuda.empty_cache()
 
 
-def test_batch_of_large_problems_runs_chains_in_flight(fa, gpu_ctx, monkeypatch):
-    """fa_ahc_linkage_batch with 2 .. 4 problems of >= 16 384 points: each merge chain runs on its own helper context concurrently (not as one
-    batched chain).  Every dendrogram equals the single-problem call bit for bit; the helper workspaces count towards
+def test_batch_of_large_problems_three_ways(fa, gpu_ctx, monkeypatch):
+    """fa_ahc_linkage_batch with 2 .. 4 problems of >= 16 384 points: by default ONE launch per round advances all of them (uniform layout,
+    ahc_round_uni; round 4); FA_AHC_IN_FLIGHT=1 runs each merge chain on its own helper context concurrently (round 3), FA_AHC_NO_UNIFORM=1 the
+    round-2 batched chain.  Every dendrogram of every form equals the single-problem call bit for bit; helper workspaces count towards
     fa_ctx_workspace_bytes and go with fa_ctx_trim."""
     import torch
     rng = np.random.default_rng(77)
@@ -325,12 +326,57 @@ def test_batch_of_large_problems_runs_chains_in_flight(fa, gpu_ctx, monkeypatch)
     for z, zr, s in zip(zs, singles, stats):
         np.testing.assert_array_equal(z, zr)
         assert s["merges"] == len(zr)
-    one = 17000 * 17000 * 8
-    assert gpu_ctx.workspace_bytes() > 2.5 * one          # three workspaces are cached: the context's and two helpers'
-    monkeypatch.setenv("FA_AHC_NO_IN_FLIGHT", "1")         # the batched chain gives the same dendrograms
+    one = 18176 * 18176 * 8
+    assert gpu_ctx.workspace_bytes() > 3 * one             # three workspaces of the largest problem's layout, one allocation
+    gpu_ctx.trim()
+    monkeypatch.setenv("FA_AHC_IN_FLIGHT", "1")
+    st1, zs1 = fa.linkage_batch(probs, ctx=gpu_ctx)
+    assert list(st1) == [0, 0, 0]
+    for z, zr in zip(zs1, singles):
+        np.testing.assert_array_equal(z, zr)
+    assert gpu_ctx.workspace_bytes() > 2.5 * 17000 * 17000 * 8   # the context's and two helpers'
+    monkeypatch.delenv("FA_AHC_IN_FLIGHT")
+    monkeypatch.setenv("FA_AHC_NO_UNIFORM", "1")
     st2, zs2 = fa.linkage_batch(probs, ctx=gpu_ctx)
     for z, zr in zip(zs2, singles):
         np.testing.assert_array_equal(z, zr)
     gpu_ctx.trim()
     assert gpu_ctx.workspace_bytes() < (1 << 26)
     torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waves", ["", "2", "3", "4"])
+def test_uniform_batch_equals_reference_build(fa, gpu_ctx, oracle_mod, monkeypatch, waves):
+    """The uniform-layout batch (every problem in the layout of the largest, one launch per round, problem = workgroup id y): ragged sizes
+    within a factor of two, both distributions, a NaN problem that fails alone, a problem with exact ties at the minimum that is recomputed in
+    reference order — per problem the reference build's dendrogram bit for bit, at each of the kernel's three register budgets."""
+    if waves:
+        monkeypatch.setenv("FA_AHC_UNI_WAVES", waves)
+    rng = np.random.default_rng(11)
+    tied = speaker_mixture(1400, 64, 6, 0.05, 21).copy()
+    tied[700:1400] = tied[0:700]                            # every row twice: exact ties at every minimum
+    probs = [speaker_mixture(2100, 64, 20, 0.03, 4), oracle_mod.ahc_normalize(rng.standard_normal((1300, 64))), speaker_mixture(2047, 64, 9, 0.04, 1),
+             speaker_mixture(1537, 64, 5, 0.05, 2), tied]
+    bad = speaker_mixture(1500, 64, 4, 0.05, 5).copy()
+    bad[17, 3] = np.nan
+    probs.append(bad)
+    for mode in (0, 1):
+        st, zs, stats = fa.linkage_batch(probs, mode=mode, ctx=gpu_ctx, return_stats=True)
+        assert st[:-1] == [0] * (len(probs) - 1) and st[-1] == 5, st
+        for k, (x, z) in enumerate(zip(probs[:-1], zs[:-1])):
+            sr, zr = oracle_mod.linkage_ref(x)
+            assert sr == 0
+            if k == 4 and mode == 1:                        # exact mode keeps its own order among exact ties: heights and partition
+                np.testing.assert_array_equal(np.sort(z[:, 2]), np.sort(zr[:, 2]))
+                continue
+            np.testing.assert_array_equal(z, zr)
+        assert stats[0]["merges"] == 2099 and stats[3]["merges"] == 1536
+        if mode == 0:
+            assert stats[4]["reference_order"] == 1 and stats[0]["reference_order"] == 0
+    # two equal problems next to a different one: no cross-talk between the workspaces
+    st, zs = fa.linkage_batch([probs[0], probs[2], probs[0]], ctx=gpu_ctx)
+    assert st == [0, 0, 0]
+    np.testing.assert_array_equal(zs[0], zs[2])
+    st1, z1 = fa.linkage(probs[2], ctx=gpu_ctx)
+    np.testing.assert_array_equal(zs[1], z1)

@@ -37,7 +37,10 @@ def test_polyphase_extension_vs_scipy(fa, gpu_ctx, up, down, n):
 
 
 @pytest.mark.parametrize("up,down,n", [(1, 3, 250001), (160, 441, 132300), (2, 1, 40000), (640, 441, 33075), (1, 6, 96000), (1, 1, 5000), (3, 2, 5), (160, 147, 14700),
-                                       (1, 2, 100003), (1, 4, 64000), (1, 5, 80007), (1, 3, 62), (1, 3, 63), (1, 3, 64), (1, 3, 130), (1, 3, 1000), (1, 2, 45), (1, 5, 200)])
+                                       (1, 2, 100003), (1, 4, 64000), (1, 5, 80007), (1, 3, 62), (1, 3, 63), (1, 3, 64), (1, 3, 130), (1, 3, 1000), (1, 2, 45), (1, 5, 200),
+                                       # the row-tiled kernel of non-integer ratios (round 4): several tiles, the last one partial, signals too short for a tile
+                                       (160, 441, 1000003), (160, 441, 40000), (160, 441, 37000), (320, 441, 300007), (640, 441, 150000), (80, 441, 500000),
+                                       (160, 147, 200000), (16, 15, 90000), (8, 7, 50000), (147, 160, 120000)])
 def test_lds_kernel_equals_simple_kernel(fa, gpu_ctx, monkeypatch, up, down, n):
     """The LDS-staged persistent polyphase kernel and the register-tiled decimation kernel (up = 1, down 2 .. 5: interior outputs, the
     edges by the simple kernel) keep the summation order of the one-thread-per-output kernel: identical bits on several rate pairs
@@ -50,3 +53,38 @@ def test_lds_kernel_equals_simple_kernel(fa, gpu_ctx, monkeypatch, up, down, n):
     ref = fa.resample_poly(x, up, down, ctx=gpu_ctx)
     monkeypatch.delenv("FA_RESAMPLE_SIMPLE")
     np.testing.assert_array_equal(got, ref)
+
+
+def test_rows_kernel_actually_serves_the_common_non_integer_pairs(fa, gpu_ctx, monkeypatch):
+    """44.1 / 22.05 kHz -> 16 kHz go through poly_rows_kernel (not silently through the fallback): with FA_RESAMPLE_NO_ROWS the LDS-staged kernel
+    produces the same bits, and on a device-resident hour of audio the row-tiled kernel is the faster of the two by a wide margin."""
+    import ctypes as C
+    import torch
+    for up, down, rate in ((160, 441, 44100), (320, 441, 22050)):
+        n = rate * 600
+        x = torch.randn(n, device="cuda", dtype=torch.float32) * 0.1
+        n_out = fa.lib().fa_resample_poly_frames(n, up, down)
+        y = torch.empty(n_out, device="cuda", dtype=torch.float32)
+        y2 = torch.empty_like(y)
+        got = C.c_int64()
+        stream = torch.cuda.ExternalStream(gpu_ctx.stream)
+
+        def run(dst):
+            gpu_ctx.check(fa.lib().fa_resample_poly_dev(gpu_ctx.handle, C.c_void_p(x.data_ptr()), n, up, down, C.c_void_p(dst.data_ptr()), n_out, C.byref(got)), "resample")
+
+        def timed(dst):
+            torch.cuda.synchronize()
+            run(dst); gpu_ctx.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(3):
+                run(dst)
+            e1.record(stream)
+            gpu_ctx.synchronize()
+            return e0.elapsed_time(e1) / 3
+        t_rows = timed(y)
+        monkeypatch.setenv("FA_RESAMPLE_NO_ROWS", "1")
+        t_lds = timed(y2)
+        monkeypatch.delenv("FA_RESAMPLE_NO_ROWS")
+        assert torch.equal(y, y2)
+        assert t_rows < 0.7 * t_lds, (up, down, t_rows, t_lds)
