@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
         L.fa_oracle_tdt_initial_time_index.argtypes = [C.c_int, C.c_int, C.c_int]
         L.fa_oracle_tdt_clamp_probability.argtypes = [C.c_float]
         L.fa_oracle_tdt_clamp_probability.restype = C.c_float
+        L.fa_oracle_tdt_last_joint_calls.restype = C.c_long
         L.fa_oracle_tdt_greedy.argtypes = [_i32p, _i32p, _f32p] + [C.c_int] * 12 + [_i32p, C.c_int, C.c_int, _i32p, _i32p, _i32p, _f32p,
                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.fa_oracle_hungarian_solve.argtypes = [np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS"), C.c_int, _i32p]
@@ -522,7 +523,8 @@ def tdt_greedy(tok, dur_bin, prob, enc_len, audio_frames=None, t0=0, is_last=Fal
                                     ot, oti, od, oc, C.byref(cnt), C.byref(ft), C.byref(fu))
     n = min(cnt.value, max_out)
     return dict(status=st, tokens=ot[:n].copy(), timestamps=oti[:n].copy(), durations=od[:n].copy(), confidences=oc[:n].copy(),
-                count=cnt.value, final_time=None if ft.value == -2 ** 31 else ft.value, final_u=fu.value)
+                count=cnt.value, final_time=None if ft.value == -2 ** 31 else ft.value, final_u=fu.value,
+                joint_calls=int(lib().fa_oracle_tdt_last_joint_calls()))
 
 
 def ctc_log_probs(logits, temperature: float = 1.0, blank_bias: float = 0.0, blank_id: int = -1) -> np.ndarray:

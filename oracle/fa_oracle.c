@@ -861,8 +861,12 @@ typedef struct {
     int token, duration, err; float score;
 } tdt_joint;
 
+static __thread long tdt_joint_calls; /* joint evaluations of the calling thread's last fa_oracle_tdt_greedy (what a walk on logits reads: one row each) */
+long fa_oracle_tdt_last_joint_calls(void) { return tdt_joint_calls; }
+
 static int tdt_run_joint(tdt_joint *j, int frame) { /* TdtModelInference.runJointPrepared, served from the decision tables */
     if (j->u >= j->U || frame < 0 || frame >= j->T) { j->err = 3; return 0; }
+    tdt_joint_calls += 1;
     const long i = (long)j->u * j->T + frame;
     j->token = j->tok[i];
     j->score = fa_oracle_tdt_clamp_probability(j->prob[i]);
@@ -880,6 +884,7 @@ int fa_oracle_tdt_greedy(const int32_t *tok, const int32_t *bin, const float *pr
                          int32_t *out_dur, float *out_conf, int *out_count, int *final_time, int *final_u) {
     tdt_joint j = {tok, bin, prob, U, T, 0, bins, nbins, blank_id, 0, 0, 0.0f};
     int count = 0, status = 0;
+    tdt_joint_calls = 0;
     *out_count = 0; *final_u = 0; *final_time = INT32_MIN;
     if (enc_len <= 1) return 0;                                         /* :110-112 */
     int time_indices = t0;

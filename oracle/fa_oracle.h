@@ -163,6 +163,7 @@ void fa_oracle_centroid_scores(const double *emb, long n, long d, const double *
  * TdtFrameNavigation.swift:20-105, TdtDurationMapping.swift:17-31); joint decisions served from [U][T] tables */
 int fa_oracle_tdt_initial_time_index(int has_time_jump, int time_jump, int context_frame_adjustment);
 float fa_oracle_tdt_clamp_probability(float v);
+long fa_oracle_tdt_last_joint_calls(void);   /* joint evaluations of this thread's last fa_oracle_tdt_greedy call */
 int fa_oracle_tdt_greedy(const int32_t *tok, const int32_t *bin, const float *prob, int U, int T, int enc_len, int audio_frames,
                          int t0, int is_last, int global_offset, int emit_after, int blank_id, int max_symbols, int max_tokens,
                          int blank_limit, const int *bins, int nbins, int max_out, int32_t *out_tok, int32_t *out_time,
