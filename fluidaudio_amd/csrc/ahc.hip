@@ -307,7 +307,6 @@ __global__ void ahc_set_eps(Ws w) {
         eps = 16.0 * static_cast<double>(w.N) * u * dmax + 8.0 * (static_cast<double>(w.d) + 2.0) * u * nmax;
     }
     w.state[0].eps = eps; w.state[1].eps = eps;
-    w.state[1].dmax_bits = s.dmax_bits; w.state[1].nmax_bits = s.nmax_bits;
 }
 
 // Exact pairwise squared distances of the live slots, the reference's summation order
@@ -816,7 +815,10 @@ struct Dec {
 // Its arrays that are first touched AFTER the round's first batch of requests (matrix, centroids, sizes, dendrogram, window buffers) arrive
 // as problem 0's and are moved by `late_shift` bytes behind that batch: their pointers come out of scalar loads of the argument segment, and an
 // addition in front of the first request would put the wait for those loads there.
-template <bool N_IN_STATE = false>
+// BIG: more than 65 536 points, i.e. more than four block records per lane in the first reduction.  That path holds 2 x 12 records in registers
+// and alone raised the whole kernel from 106 to 180 VGPRs (2 instead of 4 wavefronts per SIMD): it is compiled only into the kernels that
+// serve such problems, so that four times as many workgroups of the common sizes are resident — what a launch over several problems needs.
+template <bool N_IN_STATE = false, bool BIG = true>
 __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, const int ph /* round index & 3 */, const size_t late_shift = 0) {
     Ws w = w_in;
     extern __shared__ double s_cvec[];  // [d] merged centroid (EXACT rows)
@@ -863,12 +865,9 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     int4 hraw[kHotVec];
 #pragma unroll
     for (int i = 0; i < kHotVec; ++i) hraw[i] = reinterpret_cast<const int4 *>(sp)[i];
-    // the thread that writes the next state also requests the cold part of the present one now (16-byte pieces; it is looked at in the tail)
-    constexpr int kColdVec = (sizeof(AhcState) - kHotVec * 16 + 15) / 16;
-    int4 craw[kColdVec > 0 ? kColdVec : 1];
-#pragma unroll
-    for (int i = 0; i < kColdVec; ++i) craw[i] = reinterpret_cast<const int4 *>(sp)[kHotVec + i];   // every thread (one broadcast line): an exec-masked
-                                                                                                   // version made wave 0 of block 0 wait for the whole batch
+    // The cold part of the state (run counters; the start-up maxima) is NOT read by the rounds (round 4): the counters live in state[0] only and
+    // thread (0, 0) bumps them with atomic adds that nobody waits for.  Round 3 fetched it in every thread next to the hot part (a broadcast
+    // line, but 12 VGPRs per thread for the whole round and three more requests in the first batch).
     AhcState *const nst = w.state + npar;
     int nx = w.node[x];
     RowSt rs = w.row[x];
@@ -890,16 +889,8 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
         w.M = at(w.M); w.C = at(w.C); w.XT = at(w.XT); w.sizes = at(w.sizes); w.Z = at(w.Z); w.recS = at(w.recS);
         w.cand = at(w.cand); w.pairs = at(w.pairs); w.cnt = at(w.cnt); w.prof = at(w.prof);
     }
-    auto whole_state = [&]() {   // thread (0, 0) only: the present state reassembled from its pieces
-        int4 all[kHotVec + (kColdVec > 0 ? kColdVec : 1)];
-#pragma unroll
-        for (int i = 0; i < kHotVec; ++i) all[i] = hraw[i];
-#pragma unroll
-        for (int i = 0; i < kColdVec; ++i) all[kHotVec + i] = craw[i];
-        AhcState out;
-        __builtin_memcpy(&out, all, sizeof(AhcState));
-        return out;
-    };
+    AhcHot *const nhot = nst;                                          // the next round's state: the hot 64 bytes only (the cold part stays in state[0])
+    auto bump = [&](long long *counter) { atomicAdd(reinterpret_cast<unsigned long long *>(counter), 1ULL); };
 
     // ---- phase 1: every workgroup reduces the same records -> the same decision ------------------------------------
     const int perw = (nblk + kWaves - 1) / kWaves;
@@ -952,7 +943,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     if (c <= kC4) {
         if (wave == 0) reduce_minimum(std::integral_constant<int, kC4>{}, q0, q1, qok);
         else if (row_wave) reduce_rows(std::integral_constant<int, kC4>{}, q0, q1, qok);
-    } else if (wave == 0 || row_wave) {   // more than 65 536 points: 5 .. 12 records per lane, requested together, then the same reductions
+    } else if (BIG && (wave == 0 || row_wave)) {   // more than 65 536 points: 5 .. 12 records per lane, requested together, then the same reductions
         int4 g0[kMaxC], g1[kMaxC];
         bool gok[kMaxC];
         const void *b0 = wave == 0 ? static_cast<const void *>(w.recA + ro) : static_cast<const void *>(w.recP + (static_cast<size_t>(par) * kPend + pk0) * nblk);
@@ -1056,8 +1047,10 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     AHC_STAMP(8);
     if (st.done || st.halt) {  // finished or waiting for the host: carry the state forward
         if (blk == 0 && tid == 0) {
-            *nst = whole_state(); nst->prev_op = OP_NONE;
-            for (int k = 0; k < kPend; ++k) nst->pend_row[k] = -1;
+            AhcHot n = st;
+            n.prev_op = OP_NONE;
+            for (int k = 0; k < kPend; ++k) n.pend_row[k] = -1;
+            *nhot = n;
         }
         return;
     }
@@ -1136,10 +1129,11 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     for (int k = 0; k < kPend; ++k) was_pending = was_pending || x == st.pend_row[k];
     if (D.done || D.halt) {
         if (blk == 0 && tid == 0) {
-            *nst = whole_state();
-            nst->done = D.done; nst->halt = D.halt; nst->need_exact = D.need_exact; nst->error = D.error;
-            nst->prev_op = OP_NONE;
-            for (int k = 0; k < kPend; ++k) nst->pend_row[k] = -1;
+            AhcHot n = st;
+            n.done = D.done; n.halt = D.halt; n.need_exact = D.need_exact; n.error = D.error;
+            n.prev_op = OP_NONE;
+            for (int k = 0; k < kPend; ++k) n.pend_row[k] = -1;
+            *nhot = n;
         }
         if (was_pending) { w.row[x] = rs; w.e2[x] = e2x; }
         return;
@@ -1318,16 +1312,15 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
         z->stale_key = ~0ULL; z->ncand = 0; z->npairs = 0;
     }
     if (blk == 0 && tid == 0) {
-        const AhcState full = whole_state();
-        AhcState n = full;
+        AhcHot n = st;
         n.prev_op = D.op;
-        for (int k = 0; k < kPend; ++k) { n.pend_row[k] = prow[k]; n.pend_node[k] = pnode_[k]; if (k > 0 && prow[k] >= 0) n.piggy = n.piggy + 1; }
+        for (int k = 0; k < kPend; ++k) { n.pend_row[k] = prow[k]; n.pend_node[k] = pnode_[k]; if (k > 0 && prow[k] >= 0) bump(&w.state[0].piggy); }
         n.lim = D.lim;
-        n.rounds = full.rounds + 1;
         if (D.op == OP_MERGE) n.step = st.step + 1;
-        if (D.op == OP_RESCAN) n.rescans = full.rescans + 1;
-        if (D.op == OP_COLLECT) n.windows = full.windows + 1;
-        *nst = n;
+        *nhot = n;
+        bump(&w.state[0].rounds);
+        if (D.op == OP_RESCAN) bump(&w.state[0].rescans);
+        if (D.op == OP_COLLECT) bump(&w.state[0].windows);
     }
     AHC_STAMP(5);
 #ifdef FA_AHC_PROFILE
@@ -1344,7 +1337,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
 //                       (constant address space = scalar loads): two dependent memory round trips before the round can start.
 //   ahc_round_args    : up to kArgProblems problems with their workspaces and block ranges IN the kernel arguments: no extra round trip
 //                       (fa_ahc_linkage_batch / fa_offline_cluster_batch with <= 16 recordings).
-template <bool BATCH>
+template <bool BATCH, bool BIG>
 __global__ __launch_bounds__(kBlk) void ahc_round_t(const int ph, const int nblk_, AhcState *const state_, RecA *const recA_, int4 *const recI_, RecP *const recP_,
                                                     const unsigned off_row, const unsigned off_node, const unsigned off_e2, const unsigned off_flags,
                                                     const Ws w_one, const Ws *__restrict__ table, const int2 *__restrict__ blkmap) {
@@ -1372,7 +1365,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const int ph, const int nblk
         for (unsigned i = 0; i < sizeof(Ws) / 8; ++i) words[i] = src[i];
         __builtin_memcpy(&w_, words, sizeof(Ws));
     }
-    ahc_round_body(w_, blk_, ph);
+    ahc_round_body<false, BIG>(w_, blk_, ph);
 }
 
 // A problem of at most 256 points is ONE block: its rounds need no device-wide barrier at all, a workgroup barrier between them (with
@@ -1381,7 +1374,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const int ph, const int nblk
 // 0.5 us per round slower and are not needed inside one workgroup).
 __global__ __launch_bounds__(kBlk) void ahc_rounds_single_block(const Ws w, const int rounds) {
     for (int r = 0; r < rounds; ++r) {
-        ahc_round_body(w, 0, r & 3);
+        ahc_round_body<false, false>(w, 0, r & 3);
         __syncthreads();   // workgroup-scope release / acquire: the waves of one workgroup share the CU's caches
     }
 }
@@ -1412,12 +1405,12 @@ __device__ __forceinline__ void ahc_round_uni_body(const unsigned nblk_ph, const
     char *base = reinterpret_cast<char *>(w_.state);
     w_.row = reinterpret_cast<RowSt *>(base + off_row); w_.node = reinterpret_cast<int *>(base + off_node);
     w_.e2 = reinterpret_cast<double *>(base + off_e2); w_.flags = reinterpret_cast<int *>(base + off_flags);
-    ahc_round_body<true>(w_, blockIdx.x, static_cast<int>(nblk_ph & 3u), sh);
+    ahc_round_body<true, false>(w_, blockIdx.x, static_cast<int>(nblk_ph & 3u), sh);   // the host sends problems of more than 65 536 points elsewhere
 }
 // the same kernel at three register budgets: more co-resident workgroups per CU against spills (which one serves a batch: ahc_batch_uniform)
 FA_AHC_UNI_KERNEL(ahc_round_uni, )
-FA_AHC_UNI_KERNEL(ahc_round_uni_w3, __attribute__((amdgpu_waves_per_eu(3, 3))))
-FA_AHC_UNI_KERNEL(ahc_round_uni_w4, __attribute__((amdgpu_waves_per_eu(4, 4))))
+FA_AHC_UNI_KERNEL(ahc_round_uni_w3, __attribute__((amdgpu_waves_per_eu(6, 6))))   // "w3" / "w4": the second and third budget
+FA_AHC_UNI_KERNEL(ahc_round_uni_w4, __attribute__((amdgpu_waves_per_eu(8, 8))))
 
 constexpr int kArgProblems = 16;
 struct BatchArgs {
@@ -1427,12 +1420,13 @@ struct BatchArgs {
 };
 static_assert(sizeof(BatchArgs) <= 3584, "kernel arguments are limited to 4 KB");
 
+template <bool BIG>
 __global__ __launch_bounds__(kBlk) void ahc_round_args(const BatchArgs a, const int ph) {
     const int b = blockIdx.x;
     int prob = 0;
 #pragma unroll
     for (int k = 1; k < kArgProblems; ++k) prob += (k < a.count && b >= a.first_block[k]) ? 1 : 0;
-    ahc_round_body(a.w[prob], b - a.first_block[prob], ph);
+    ahc_round_body<false, BIG>(a.w[prob], b - a.first_block[prob], ph);
 }
 
 // Exact heights from the stored centroids, the reference's summation order, then sqrt
@@ -1464,7 +1458,7 @@ struct RoDev {                       // scalars of fa_ro::Sel between launches +
     long long scans;
 };
 struct RoWs {
-    double *C, *XT, *M, *sizes, *key, *pair_a, *pair_b, *height_sq, *Z;
+    double *C, *XT, *sizes, *key, *pair_a, *pair_b, *height_sq, *Z;
     int32_t *node, *slot_of, *at, *pos, *nghbr, *next, *prev, *flags;
     RoPart *part;
     RoDev *dev;
@@ -1477,28 +1471,76 @@ __global__ void ro_init(RoWs w) {
     if (i < w.Np) w.node[i] = i < w.N ? i : kDead;
 }
 
-// start-up of the reference (fastcluster_internal.hpp:1653-1678): nearest LOWER-indexed point of every point from the exact matrix,
-// lowest index on ties
-__global__ __launch_bounds__(kBlk) void ro_lower_minima(RoWs w) {
-    __shared__ double s_val[kWaves];
-    __shared__ int s_idx[kWaves];
-    const int i = blockIdx.x + 1;
-    double v = dinf();
-    int ix = INT_MAX;
-    const double *row = w.M + static_cast<size_t>(i) * w.Np;
-    for (int x = threadIdx.x; x < i; x += kBlk) { const double m = row[x]; if (m < v) { v = m; ix = x; } }   // x ascending per thread
+// start-up of the reference (fastcluster_internal.hpp:1653-1678): nearest LOWER-indexed point of every point, lowest index on ties — straight from
+// the points, no matrix (round 4): the reference itself keeps centroids + nearest-neighbour arrays only (:1625-1800), so this mode runs in O(N d)
+// memory like it does, for any N.  Tiles of 64 x 64 pairs on and below the diagonal, 4 x 4 per thread, operands k-major in LDS, every distance =
+// the reference's sequential sum (k ascending, one rounding per operation: FastClusterWrapper.cpp:45-52) — the bits ahc_pairwise writes.
+constexpr int kRoT = 64, kRoK = 16;
+__global__ __launch_bounds__(256) void ro_lower_minima_direct(RoWs w) {
+    __shared__ double sa[kRoK][kRoT + 1], sb[kRoK][kRoT + 1];
+    const double *__restrict__ x = w.C;          // rows 0 .. N-1 of the centroid store = the input points, row-major
+    const int n = w.N, d = w.d;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;   // tx: column quad, ty: row quad
+    const int i0 = blockIdx.x * kRoT;
+    double best[4];
+    int arg[4];
+    bool bad = false;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off);
-        const int oi = __shfl_xor(ix, off);
-        if (lt2(ov, oi, v, ix)) { v = ov; ix = oi; }
+    for (int r = 0; r < 4; ++r) { best[r] = dinf(); arg[r] = INT_MAX; }
+    for (int j0 = 0; j0 <= i0 && j0 < n; j0 += kRoT) {
+        double acc[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+        for (int k0 = 0; k0 < d; k0 += kRoK) {
+            for (int e = tid; e < kRoT * kRoK; e += 256) {
+                const int rr = e / kRoK, kk = e % kRoK;
+                const int gi = i0 + rr, gj = j0 + rr, gk = k0 + kk;
+                sa[kk][rr] = gi < n && gk < d ? x[static_cast<size_t>(gi) * d + gk] : 0.0;
+                sb[kk][rr] = gj < n && gk < d ? x[static_cast<size_t>(gj) * d + gk] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < kRoK; ++kk) {
+                double av[4], bv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { av[r] = sa[kk][4 * ty + r]; bv[r] = sb[kk][4 * tx + r]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double diff = __dsub_rn(av[r], bv[c]);
+                        acc[r][c] = __dadd_rn(acc[r][c], __dmul_rn(diff, diff));
+                    }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int gi = i0 + 4 * ty + r, gj = j0 + 4 * tx + c;
+                if (gi < n && gj < gi) {
+                    const double v = acc[r][c];
+                    if (v != v) bad = true;
+                    else if (lt2(v, gj, best[r], arg[r])) { best[r] = v; arg[r] = gj; }
+                }
+            }
     }
-    if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = v; s_idx[threadIdx.x >> 6] = ix; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int wv = 1; wv < kWaves; ++wv) if (lt2(s_val[wv], s_idx[wv], v, ix)) { v = s_val[wv]; ix = s_idx[wv]; }
-        w.key[i] = v;
-        w.nghbr[i] = ix;
+    if (bad) w.flags[0] = 1;                     // NaN distance (nan_error, FastClusterWrapper.cpp:60-62)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                // the 16 threads of a row quad (consecutive lanes): lowest value, then lowest index
+        double v = best[r];
+        int a = arg[r];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(v, off, 16);
+            const int oa = __shfl_xor(a, off, 16);
+            if (lt2(ov, oa, v, a)) { v = ov; a = oa; }
+        }
+        const int gi = i0 + 4 * ty + r;
+        if (tx == 0 && gi >= 1 && gi < n) { w.key[gi] = v; w.nghbr[gi] = a; }
     }
 }
 
@@ -1790,15 +1832,18 @@ namespace {
 
 // The whole problem in the reference's selection order (see the kernels above).  d_data / d_Z: device pointers.
 fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host = false) {
-    FA_TRY(prob_check_shape(ctx, N, d));
+    // O(N d) memory: points / centroids, their slot-major transpose, the reference's heap and list arrays — no distance matrix, so neither the
+    // block-record limit of the filter-based rounds nor HBM bounds N here (the start-up computes the nearest lower neighbours tile-wise)
+    if (d * sizeof(double) > 60 * 1024) return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: dimension too large for the LDS centroid buffer");
+    if (N > static_cast<size_t>(INT32_MAX) / 2 - kBlk) return fa::set_error(ctx, FA_INDEX_OVERFLOW, "ahc: N too large for 32-bit node ids");
     const size_t Np = (N + kBlk - 1) / kBlk * kBlk, nblk = Np / kBlk;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~static_cast<size_t>(255); return at; };
-    const size_t o_dev = take(sizeof(RoDev)), o_dummy = take(sizeof(AhcState) * 2), o_flags = take(16), o_part = take(sizeof(RoPart) * nblk);
+    const size_t o_dev = take(sizeof(RoDev)), o_flags = take(16), o_part = take(sizeof(RoPart) * nblk);
     const size_t o_node = take(4 * Np), o_slot = take(4 * 2 * N), o_sizes = take(8 * 2 * N), o_key = take(8 * 2 * N), o_at = take(4 * N), o_pos = take(4 * 2 * N);
     const size_t o_ngh = take(4 * 2 * N), o_next = take(4 * (2 * N + 1)), o_prev = take(4 * (2 * N + 1));
     const size_t o_pa = take(8 * N), o_pb = take(8 * N), o_hs = take(8 * N), o_z = take(8 * 4 * N);
-    const size_t o_c = take(8 * d * 2 * N), o_xt = take(8 * d * Np), o_m = take(8 * Np * Np);
+    const size_t o_c = take(8 * d * 2 * N), o_xt = take(8 * d * Np);
     FA_TRY(fa::ws_acquire(ctx, o));
     char *base = static_cast<char *>(ctx->ahc_ws);
     RoWs w{};
@@ -1808,23 +1853,18 @@ fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, d
     w.nghbr = reinterpret_cast<int32_t *>(base + o_ngh); w.next = reinterpret_cast<int32_t *>(base + o_next); w.prev = reinterpret_cast<int32_t *>(base + o_prev);
     w.pair_a = reinterpret_cast<double *>(base + o_pa); w.pair_b = reinterpret_cast<double *>(base + o_pb); w.height_sq = reinterpret_cast<double *>(base + o_hs);
     w.Z = reinterpret_cast<double *>(base + o_z); w.C = reinterpret_cast<double *>(base + o_c); w.XT = reinterpret_cast<double *>(base + o_xt);
-    w.M = reinterpret_cast<double *>(base + o_m);
     w.N = static_cast<int32_t>(N); w.Np = static_cast<int32_t>(Np); w.d = static_cast<int32_t>(d); w.nblk = static_cast<int32_t>(nblk);
     hipStream_t st = ctx->stream;
     hipEvent_t ev[3];
     for (auto &e : ev) FA_HIP_TRY(ctx, hipEventCreate(&e));
     struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
     FA_HIP_TRY(ctx, hipEventRecord(ev[0], st));
-    // ---- start-up: exact matrix (the reference's sums), nearest lower-indexed neighbours
-    FA_HIP_TRY(ctx, hipMemsetAsync(base + o_dev, 0, o_part - o_dev, st));            // RoDev, the dummy state of ahc_pairwise, flags
+    // ---- start-up: nearest lower-indexed neighbours (the reference's sums), no matrix
+    FA_HIP_TRY(ctx, hipMemsetAsync(base + o_dev, 0, o_part - o_dev, st));            // RoDev, flags
     FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(ro_init, dim3(static_cast<unsigned>((std::max(Np, 2 * N) + 255) / 256)), dim3(256), 0, st, w);
     hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, st, d_data, w.XT, w.N, w.Np, w.d);
-    Ws pw{};
-    pw.M = w.M; pw.XT = w.XT; pw.node = w.node; pw.flags = w.flags; pw.state = reinterpret_cast<AhcState *>(base + o_dummy); pw.Np = w.Np; pw.d = w.d; pw.N = w.N;
-    pw.nblk = w.nblk;
-    hipLaunchKernelGGL(ahc_pairwise, dim3(w.Np / PT, w.Np / PT), dim3(256), 0, st, pw);
-    if (N > 1) hipLaunchKernelGGL(ro_lower_minima, dim3(static_cast<unsigned>(N - 1)), dim3(kBlk), 0, st, w);
+    if (N > 1) hipLaunchKernelGGL(ro_lower_minima_direct, dim3(static_cast<unsigned>((N + kRoT - 1) / kRoT)), dim3(256), 0, st, w);
     FA_HIP_TRY(ctx, hipGetLastError());
     // ---- the heap over points 1 .. N-1, the list, the first pair: host (the selection logic is the same header on both sides)
     std::vector<double> key(2 * N, 0.0), pa(N, 0.0), pb(N, 0.0), hs(N, 0.0);
@@ -1883,7 +1923,7 @@ fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, d
         float t01 = 0, t12 = 0;
         (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
         (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
-        stats->merges = hd.merges; stats->rounds += hd.scans; stats->reference_order = 1;
+        stats->merges = hd.merges; stats->rounds += hd.scans; if (!stats->reference_order) stats->reference_order = 1;
         stats->init_ms += t01; stats->merge_ms += t12; stats->total_ms += t01 + t12;
     }
     return FA_SUCCESS;
@@ -1908,18 +1948,36 @@ fa_status ctx_events(fa_ctx *ctx, hipEvent_t (&ev)[3]) {
 }  // namespace
 
 fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, int mode, fa_ahc_stats *stats, bool z_on_host) {
-    FA_TRY(prob_check_shape(ctx, N, d));
+    // The filter-based rounds keep an N x N matrix resident (N^2 * 8 B); the reference needs O(N d) (fastcluster_internal.hpp:1625-1800).  When the
+    // matrix cannot be had — more points than block records (N > 196 608), not enough HBM, or the context's cap — the problem runs in the
+    // reference-order mode instead, which has no matrix: slower per merge (every new row is O(N d) exact sums) but the same dendrogram, where
+    // round 3 returned ALLOCATION_FAILURE and AHCClustering degraded to singletons (a >= 36 h recording lost its clustering).
+    // stats->reference_order == 2 marks that route.
+    fa::WsUse ws_use(ctx);                      // released (and trimmed to the context's limit) when the call returns
+    auto without_matrix = [&]() {
+        if (stats) { *stats = fa_ahc_stats{}; stats->reference_order = 2; }
+        const fa_status st = ro_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host);
+        if (st == FA_SUCCESS) ctx->last_error.clear();
+        return st;
+    };
     if (mode == FA_AHC_MODE_REFERENCE_ORDER) {
-        fa::WsUse ws_use(ctx);
         if (stats) *stats = fa_ahc_stats{};
         return ro_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host);
+    }
+    const bool may_fall_back = getenv("FA_AHC_NO_MATRIX_FREE") == nullptr;
+    if (prob_check_shape(ctx, N, d) != FA_SUCCESS) {   // too many points for the block records (a too large d fails in ro_run_device as well)
+        if (may_fall_back) return without_matrix();
+        return FA_ALLOCATION_FAILURE;
     }
     Prob p;
     p.z_on_host = z_on_host;
     p.N = N; p.d = d; p.Np = (N + kBlk - 1) / kBlk * kBlk; p.d_data = d_data; p.d_Z = d_Z; p.mode = mode;
     p.L = make_layout(N, p.Np, d, p.Np / kBlk);
-    fa::WsUse ws_use(ctx);                      // released (and trimmed to the context's limit) when the call returns
-    FA_TRY(fa::ws_acquire(ctx, p.L.total));
+    {
+        const fa_status ws = fa::ws_acquire(ctx, p.L.total);
+        if (ws == FA_ALLOCATION_FAILURE && may_fall_back) return without_matrix();
+        FA_TRY(ws);
+    }
     const size_t lds = sizeof(double) * d;
 
     hipEvent_t ev[3];
@@ -1929,10 +1987,17 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     FA_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
 
     const Ws w = p.w;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    const bool big = w.nblk > 4 * 64 || getenv("FA_AHC_ROUND_BIG") != nullptr;   // more than four block records per lane: the kernel with the many-record reduction
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    }
     auto off_of = [&](const void *p) { return static_cast<unsigned>(static_cast<const char *>(p) - reinterpret_cast<const char *>(w.state)); };   // small arrays: within 4 GB of the state (make_layout puts the matrix last)
     const unsigned o_row = off_of(w.row), o_node = off_of(w.node), o_e2 = off_of(w.e2), o_flags = off_of(w.flags);
-    auto launch = [&](const int ph) { hipLaunchKernelGGL(ahc_round_t<false>, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, ph, w.nblk, w.state, w.recA, w.recI, w.recP, o_row, o_node, o_e2, o_flags, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr)); };
+    auto launch = [&](const int ph) {
+        if (big) hipLaunchKernelGGL((ahc_round_t<false, true>), dim3(w.nblk), dim3(kBlk), lds, ctx->stream, ph, w.nblk, w.state, w.recA, w.recI, w.recP, o_row, o_node, o_e2, o_flags, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr));
+        else hipLaunchKernelGGL((ahc_round_t<false, false>), dim3(w.nblk), dim3(kBlk), lds, ctx->stream, ph, w.nblk, w.state, w.recA, w.recI, w.recP, o_row, o_node, o_e2, o_flags, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr));
+    };
     // The captured graph only holds launch parameters (workspace pointers, block count): it is reused as long as the workspace sits at
     // the same address and the shape is the same — repeated calls on recordings of one length skip capture + instantiation.
     RoundGraph single_rg;
@@ -2061,7 +2126,12 @@ fa_status ahc_batch_once(fa_ctx *ctx, int count, const double *const *d_data, co
     int2 *d_map = reinterpret_cast<int2 *>(base + o_map);
     FA_HIP_TRY(ctx, hipMemcpyAsync(const_cast<Ws *>(d_table), table.data(), sizeof(Ws) * count, hipMemcpyHostToDevice, ctx->stream));
     const size_t lds = sizeof(double) * d;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    bool big = getenv("FA_AHC_ROUND_BIG") != nullptr;
+    for (const Prob &p : probs) if (p.active && p.Np / kBlk > 4 * 64) big = true;
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    }
     long long max_batches = 64;
     for (const Prob &p : probs) if (p.active) max_batches = std::max<long long>(max_batches, 64 + 8 * static_cast<long long>(p.N) / rounds_for(p.N));
     std::vector<int2> map;
@@ -2071,10 +2141,18 @@ fa_status ahc_batch_once(fa_ctx *ctx, int count, const double *const *d_data, co
     int grid = 0;
     BatchArgs bargs{};
     bool by_args = false;   // <= kArgProblems running problems: workspaces and block ranges travel in the kernel arguments
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_args), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_args<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_args<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    }
     auto launch = [&](const int ph) {
-        if (by_args) hipLaunchKernelGGL(ahc_round_args, dim3(grid), dim3(kBlk), lds, ctx->stream, bargs, ph);
-        else hipLaunchKernelGGL(ahc_round_t<true>, dim3(grid), dim3(kBlk), lds, ctx->stream, ph, 0, static_cast<AhcState *>(nullptr), static_cast<RecA *>(nullptr), static_cast<int4 *>(nullptr), static_cast<RecP *>(nullptr), 0u, 0u, 0u, 0u, Ws{}, d_table, static_cast<const int2 *>(d_map));
+        if (by_args) {
+            if (big) hipLaunchKernelGGL(ahc_round_args<true>, dim3(grid), dim3(kBlk), lds, ctx->stream, bargs, ph);
+            else hipLaunchKernelGGL(ahc_round_args<false>, dim3(grid), dim3(kBlk), lds, ctx->stream, bargs, ph);
+        } else if (big)
+            hipLaunchKernelGGL((ahc_round_t<true, true>), dim3(grid), dim3(kBlk), lds, ctx->stream, ph, 0, static_cast<AhcState *>(nullptr), static_cast<RecA *>(nullptr), static_cast<int4 *>(nullptr), static_cast<RecP *>(nullptr), 0u, 0u, 0u, 0u, Ws{}, d_table, static_cast<const int2 *>(d_map));
+        else
+            hipLaunchKernelGGL((ahc_round_t<true, false>), dim3(grid), dim3(kBlk), lds, ctx->stream, ph, 0, static_cast<AhcState *>(nullptr), static_cast<RecA *>(nullptr), static_cast<int4 *>(nullptr), static_cast<RecP *>(nullptr), 0u, 0u, 0u, 0u, Ws{}, d_table, static_cast<const int2 *>(d_map));
     };
     for (long long it = 0; it < max_batches; ++it) {
         int n_active = 0;
@@ -2148,10 +2226,12 @@ namespace {
 // the larger layout).  Problems are placed by size, largest first: the running set stays a prefix of the placement, so the grid shrinks in y
 // as the short ones finish.  Per problem the result is the single-problem entry's bit for bit (test_uniform_batch_*).
 int uniform_kernel_choice(size_t blocks_total) {
-    // co-residency: 256 CUs x 4 SIMDs x (waves per SIMD) / 4 waves per workgroup.  The default build of the round holds 2 waves per SIMD
-    // (186 VGPRs): 512 workgroups; capped at 168 / 128 VGPRs: 768 / 1024.  FA_AHC_UNI_WAVES = 2 | 3 | 4 overrides (measurements).
-    if (const char *e = getenv("FA_AHC_UNI_WAVES")) { const int v = atoi(e); if (v >= 2 && v <= 4) return v; }
-    return blocks_total <= 512 ? 2 : (blocks_total <= 768 ? 3 : 4);
+    // co-residency: 256 CUs x 4 SIMDs x (waves per SIMD) / 4 waves per workgroup.  The round without the many-record path needs 94 VGPRs:
+    // 5 waves per SIMD = 1 280 resident workgroups (7 recordings of 8 h).  Capped at 80 / 64 VGPRs (52 / 120 bytes of scratch): 1 536 / 2 048.
+    // FA_AHC_UNI_WAVES = 5 | 6 | 8 picks one (measurements: profiles/r04_uni_probe.json).
+    (void)blocks_total;
+    if (const char *e = getenv("FA_AHC_UNI_WAVES")) { const int v = atoi(e); if (v == 6) return 3; if (v == 8) return 4; }
+    return 2;
 }
 
 fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
@@ -2265,7 +2345,7 @@ bool uniform_eligible(int count, const size_t *n, int mode) {
         const size_t np = (n[k] + kBlk - 1) / kBlk * kBlk;
         lo = std::min(lo, np); hi = std::max(hi, np);
     }
-    return hi / kBlk >= 2 && lo * 2 >= hi && hi / kBlk <= static_cast<size_t>(kMaxBlocks);   // one-block problems keep their single-launch form
+    return hi / kBlk >= 2 && lo * 2 >= hi && hi / kBlk <= 4 * 64;   // one-block problems keep their single-launch form; > 65 536 points: the many-record kernels
 }
 }  // namespace
 
@@ -2346,6 +2426,8 @@ fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *
         const fa_status b = fa::ahc_run_device_batch(ctx, count - half, d_data + half, n + half, d, d_Z + half, mode, stats ? stats + half : nullptr, sts + half);
         return a != FA_SUCCESS ? a : b;
     }
+    if (fail == FA_ALLOCATION_FAILURE && count == 1 && n[0] >= 2)   // not even one matrix fits: the single-problem entry knows the matrix-free route
+        return sts[0] = fa::ahc_run_device(ctx, d_data[0], n[0], d, d_Z[0], mode, stats ? &stats[0] : nullptr, false);
     for (int k = 0; k < count; ++k) {
         if (n[k] >= 2) sts[k] = fail;
         if (stats) stats[k] = fa_ahc_stats{};

@@ -162,7 +162,7 @@ struct PolyRowsGeom {
 };
 constexpr int kRowsThreads = 512, kRowsWaves = kRowsThreads / 64;
 
-template <int NV>
+template <int NV, int IT>   // NV: 16-byte reads per window; IT: 64-float pieces per staged row (sld <= 64 IT)
 __global__ __launch_bounds__(kRowsThreads) void poly_rows_kernel(const float *__restrict__ x, const float *__restrict__ tt, const int2 *__restrict__ ptab,
                                                                 float *__restrict__ y, const PolyRowsGeom g, const int64_t tiles, const int64_t m_end) {
     extern __shared__ float xs[];
@@ -176,11 +176,23 @@ __global__ __launch_bounds__(kRowsThreads) void poly_rows_kernel(const float *__
     const int smin = pt[2 * ph0] & ~3;
     const int span = pt[2 * (ph1 - 1)] + 4 * NV - smin;                 // offsets grow with the phase
     const int64_t kt = g.k_begin + tile * 64 * g.down + smin;
-    for (int r = 0; r < 64 / kRowsWaves; ++r) {                         // wavefront w stages rows 8 w .. 8 w + 7: coalesced 256-byte requests
-        const int l = wave * (64 / kRowsWaves) + r;
-        const float *src = x + kt + static_cast<int64_t>(l) * g.down;
-        float *dst = xs + l * g.sld;
-        for (int sidx = lane; sidx < span; sidx += 64) dst[sidx] = src[sidx];
+    {   // wavefront w stages rows 8 w .. 8 w + 7 with coalesced 256-byte requests — ALL of them requested before the first is written to LDS
+        // (the first version wrote each element as it arrived: 40 dependent HBM round trips per thread, 26 us per workgroup where the arithmetic
+        // takes 7: 18.8 % of the HBM roofline at 44.1 -> 16 kHz)
+        constexpr int kRowsPerWave = 64 / kRowsWaves;
+        float v[kRowsPerWave][IT];
+#pragma unroll
+        for (int r = 0; r < kRowsPerWave; ++r) {
+            const float *src = x + kt + static_cast<int64_t>(wave * kRowsPerWave + r) * g.down;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) { const int sidx = lane + 64 * it; v[r][it] = sidx < span ? src[sidx] : 0.0f; }
+        }
+#pragma unroll
+        for (int r = 0; r < kRowsPerWave; ++r) {
+            float *dst = xs + (wave * kRowsPerWave + r) * g.sld;
+#pragma unroll
+            for (int it = 0; it < IT; ++it) { const int sidx = lane + 64 * it; if (sidx < span) dst[sidx] = v[r][it]; }
+        }
     }
     __syncthreads();
     const float *rowp = xs + lane * g.sld - smin;
@@ -281,18 +293,23 @@ bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down,
         sld *= 4;
         if (static_cast<size_t>(sld) * 64 * sizeof(float) <= 74 * 1024 || ppg <= kRowsWaves) break;
     }
-    if (static_cast<size_t>(sld) * 64 * sizeof(float) > 150 * 1024) return false;
+    if (static_cast<size_t>(sld) * 64 * sizeof(float) > 150 * 1024 || sld > 64 * 10) return false;
     R.g.m_begin = m_begin; R.g.k_begin = k_begin; R.g.up = up; R.g.down = down; R.g.ntp = ntp; R.g.groups = groups; R.g.ppg = ppg; R.g.sld = sld; R.g.smax = smax;
     R.nv = nv; R.lds = static_cast<size_t>(sld) * 64 * sizeof(float); R.up = up; R.down = down;
     return true;
 }
 
-template <int NV>
-void poly_rows_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end) {
+template <int NV, int IT>
+void poly_rows_launch_it(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end) {
     const int2 *ptab = static_cast<const int2 *>(R.d_tables);
     const float *tt = reinterpret_cast<const float *>(static_cast<const char *>(R.d_tables) + sizeof(int2) * R.up);
-    if (R.lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(poly_rows_kernel<NV>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(R.lds));
-    hipLaunchKernelGGL(poly_rows_kernel<NV>, dim3(static_cast<unsigned>(tiles * R.g.groups)), dim3(kRowsThreads), R.lds, ctx->stream, d_x, tt, ptab, d_y, R.g, tiles, m_end);
+    if (R.lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(poly_rows_kernel<NV, IT>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(R.lds));
+    hipLaunchKernelGGL((poly_rows_kernel<NV, IT>), dim3(static_cast<unsigned>(tiles * R.g.groups)), dim3(kRowsThreads), R.lds, ctx->stream, d_x, tt, ptab, d_y, R.g, tiles, m_end);
+}
+template <int NV>
+void poly_rows_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end) {
+    if (R.g.sld <= 64 * 5) poly_rows_launch_it<NV, 5>(ctx, R, d_x, d_y, tiles, m_end);       // rows of a group within 74 KB (the common case)
+    else poly_rows_launch_it<NV, 10>(ctx, R, d_x, d_y, tiles, m_end);                       // few phases with long windows: one group per tile
 }
 
 double bessel_i0(double x) {  // power series, converges fast for the beta used here

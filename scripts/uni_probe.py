@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round time of the uniform-layout batched AHC round (ahc_round_uni) against the number of problems per launch and the kernel's register
-budget (FA_AHC_UNI_WAVES = waves per SIMD the build allows: 2 = 180 VGPRs, 3 = 168, 4 = 128 + 308 B scratch), next to the round-2 batched
+budget (FA_AHC_UNI_WAVES = waves per SIMD the build allows: default 5 = 94 VGPRs, 6 = 80 + 52 B scratch, 8 = 64 + 120 B scratch), next to the round-2 batched
 kernel (FA_AHC_NO_UNIFORM) and the round-3 chains in flight (FA_AHC_IN_FLIGHT).  Problems: the 8 h session (43 200 x 256) and 1 h (5 400 x 256)."""
 import json
 import os
@@ -36,17 +36,19 @@ def run(probs, env):
 
 
 out = []
-big = [unit_rows(8.0, 5 + k) for k in range(8)]
+big = [unit_rows(8.0, 5 + k) for k in range(12)]
 ref = {}
-for k in range(8):
+for k in range(12):
     st, z = fa.linkage(big[k], ctx=ctx)
     assert st == 0
     ref[k] = z
-for K in (2, 3, 4, 6, 8):
-    for env in ({}, {"FA_AHC_UNI_WAVES": "2"}, {"FA_AHC_UNI_WAVES": "3"}, {"FA_AHC_UNI_WAVES": "4"}, {"FA_AHC_NO_UNIFORM": "1"}, {"FA_AHC_IN_FLIGHT": "1"}):
+for K in (1, 2, 4, 6, 7, 8, 12):
+    for env in ({}, {"FA_AHC_UNI_WAVES": "6"}, {"FA_AHC_UNI_WAVES": "8"}, {"FA_AHC_NO_UNIFORM": "1"}, {"FA_AHC_IN_FLIGHT": "1"}):
         if env.get("FA_AHC_IN_FLIGHT") and K > 4:
             continue
         if env.get("FA_AHC_NO_UNIFORM") and K not in (2, 4, 8):
+            continue
+        if K == 1 and env:
             continue
         st, zs, stats, wall = run(big[:K], env)
         same = all(s == 0 and np.array_equal(z, ref[i]) for i, (s, z) in enumerate(zip(st, zs)))

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--dist", choices=["iid", "mix"], required=True)
     ap.add_argument("--n", type=int, required=True)
     ap.add_argument("--d", type=int, default=256)
+    ap.add_argument("--stem", default=None, help="file stem under tests/golden (default ahc_full_<dist>_<n>); the matrix-free case: ahc_mf_iid_200000x4 with --d 4")
     a = ap.parse_args()
     oracle.build()
     assert oracle.ref_available(), "oracle/_ref is not built (needs /root/reference)"
@@ -43,7 +44,7 @@ def main():
     for thr in THRESHOLDS:
         lab = oracle.ahc_cut(z, a.n, thr)
         out["cuts"][repr(thr)] = {"labels_sha256": sha256(lab.astype(np.int32)), "clusters": int(lab.max()) + 1}
-    stem = os.path.join(HERE, f"ahc_full_{a.dist}_{a.n}")
+    stem = os.path.join(HERE, a.stem or f"ahc_full_{a.dist}_{a.n}")
     with open(stem + ".json", "w") as f:
         json.dump(out, f, indent=1)
     np.savez_compressed(stem + "_pairs.npz", pairs=z[:, :2].astype(np.int32))

@@ -87,4 +87,4 @@ def test_rows_kernel_actually_serves_the_common_non_integer_pairs(fa, gpu_ctx, m
         t_lds = timed(y2)
         monkeypatch.delenv("FA_RESAMPLE_NO_ROWS")
         assert torch.equal(y, y2)
-        assert t_rows < 0.7 * t_lds, (up, down, t_rows, t_lds)
+        assert t_rows < 0.85 * t_lds, (up, down, t_rows, t_lds)

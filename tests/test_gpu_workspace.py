@@ -15,32 +15,56 @@ def ws_need(n):
     return npad * npad * 8
 
 
-def test_cap_gives_allocation_failure_and_singletons(fa, oracle_mod):
+def test_cap_below_the_matrix_runs_without_a_matrix_and_a_tiny_cap_gives_singletons(fa, oracle_mod):
+    """A cap below N^2 * 8 B no longer fails the call (round 4): the problem runs in the matrix-free reference-order mode — O(N d) memory like the
+    reference (fastcluster_internal.hpp:1625-1800) — and returns the reference build's dendrogram (stats: reference_order == 2).  A cap below even
+    that is ALLOCATION_FAILURE, and AHCClustering degrades to singletons (AHCClustering.swift:52-55)."""
     ctx = fa.Context(0)
     x = speaker_mixture(2000, 32, 5, 0.05, 1)
+    sr, zr = oracle_mod.linkage_ref(x)
     ctx.set_workspace_cap(ws_need(2000) // 2)
+    st, z, stats = fa.linkage(x, ctx=ctx, return_stats=True)
+    assert st == sr == 0 and stats["reference_order"] == 2, (st, stats, ctx.last_error())
+    np.testing.assert_array_equal(z, zr)
+    assert fa.AHCClustering(ctx=ctx).cluster(x, 0.6) == oracle_mod.ahc_cluster(x, 0.6).tolist()
+    ctx.set_workspace_cap(1024)
     st, z = fa.linkage(x, ctx=ctx)
     assert st == fa.ALLOCATION_FAILURE and "cap" in ctx.last_error()
     ahc = fa.AHCClustering(ctx=ctx)
     assert ahc.cluster(x, 0.6) == list(range(2000)) and ahc.last_status == fa.ALLOCATION_FAILURE   # degrade, don't crash
     ctx.set_workspace_cap(None)
-    st, z = fa.linkage(x, ctx=ctx)
-    sr, zr = oracle_mod.linkage_ref(x)
-    assert st == sr == 0
+    st, z, stats = fa.linkage(x, ctx=ctx, return_stats=True)
+    assert st == 0 and stats["reference_order"] == 0
     np.testing.assert_array_equal(z, zr)
 
 
-def test_n_that_cannot_fit_is_allocation_failure(fa):
-    """N = 196 608 needs 288 GiB for the matrix alone: hipMalloc fails, the status is 4, nothing is written; N beyond the block-record
-    limit is refused before any allocation."""
+def test_n_beyond_any_matrix_equals_the_reference_digest(fa):
+    """N = 200 000 x 4: the matrix would take 320 GB and N exceeds the block records of the filter-based rounds, where round 3 returned
+    ALLOCATION_FAILURE.  Now: reference-order scans without a matrix, the dendrogram of the REFERENCE build by digest
+    (tests/golden/ahc_mf_iid_200000x4.json, generated on the CPU by make_ahc_full_digest.py --d 4 --stem ...); merge pairs located on a mismatch."""
+    import json
+    import os
+    import sys
+    gold_dir = os.path.join(os.path.dirname(__file__), "golden")
+    sys.path.insert(0, gold_dir)
+    from ahc_full_inputs import ahc_input, dendrogram_digest, sha256
+    jp = os.path.join(gold_dir, "ahc_mf_iid_200000x4.json")
+    if not os.path.exists(jp):
+        pytest.skip("ahc_mf_iid_200000x4.json not committed")
+    with open(jp) as f:
+        gold = json.load(f)
+    x = ahc_input("iid", gold["n"], gold["d"])
+    assert sha256(x) == gold["input_sha256"]
     ctx = fa.Context(0)
-    for n in (196608, 250000):
-        x = np.random.default_rng(0).standard_normal((n, 2))
-        z = np.full((n - 1, 4), -7.0)
-        st = fa.lib().fa_ahc_linkage(ctx.handle, x.ctypes.data, n, 2, z.ctypes.data, z.size, 0, 0, None)
-        assert st == fa.ALLOCATION_FAILURE, (n, st, ctx.last_error())
-        assert (z == -7.0).all()
-    assert ctx.workspace_bytes() < (1 << 26)              # nothing but the input staging (scratch) is cached
+    st, z, stats = fa.linkage(x, ctx=ctx, return_stats=True)
+    assert st == 0 and stats["reference_order"] == 2 and stats["merges"] == gold["n"] - 1, (st, stats, ctx.last_error())
+    dig = dendrogram_digest(z)
+    if dig["dendrogram_sha256"] != gold["dendrogram_sha256"]:
+        pairs = np.load(jp[:-5] + "_pairs.npz")["pairs"]
+        bad = np.nonzero((z[:, :2].astype(np.int32) != pairs).any(axis=1))[0]
+        raise AssertionError(f"dendrogram differs from the reference build's; first differing merge rows {bad[:5]} of {bad.size}; heights equal: "
+                             f"{dig['heights_sha256'] == gold['heights_sha256']}")
+    assert ctx.workspace_bytes() < (1 << 28)              # O(N d): 2 N x 4 centroids, the transpose, heap and list arrays
 
 
 def test_batch_statuses_under_memory_pressure(fa, oracle_mod):
@@ -56,7 +80,12 @@ def test_batch_statuses_under_memory_pressure(fa, oracle_mod):
     assert st == [0] * 6
     for z, zr in zip(zs, refs):
         np.testing.assert_array_equal(z, zr)
-    ctx.set_workspace_cap(ws_need(700) // 4)               # nothing fits
+    ctx.set_workspace_cap(ws_need(700) // 4)               # no matrix fits: every problem ends up alone and runs without one (round 4)
+    st, zs, stats = fa.linkage_batch(probs, ctx=ctx, return_stats=True)
+    assert st == [0] * 6 and all(s["reference_order"] == 2 for s in stats)
+    for z, zr in zip(zs, refs):
+        np.testing.assert_array_equal(z, zr)
+    ctx.set_workspace_cap(1024)                            # nothing at all fits
     st, zs = fa.linkage_batch(probs, ctx=ctx)
     assert st == [fa.ALLOCATION_FAILURE] * 6
     assert all(not z.any() for z in zs)                    # output untouched
