@@ -30,7 +30,7 @@ AHC_MODE_AUTO, AHC_MODE_EXACT, AHC_MODE_REFERENCE_ORDER = 0, 1, 2
 # Every symbol include/fluidaudio_hip.h + include/FastClusterWrapper.h declare (checked by tests/test_abi.py).
 EXPORTED_SYMBOLS = [
     "fa_version", "fa_host_alloc", "fa_host_free", "fa_ctx_create", "fa_ctx_destroy", "fa_ctx_synchronize", "fa_ctx_stream", "fa_ctx_last_error",
-    "fa_ctx_set_workspace_limit", "fa_ctx_set_workspace_cap", "fa_ctx_trim", "fa_ctx_workspace_bytes",
+    "fa_ctx_set_workspace_limit", "fa_ctx_set_workspace_cap", "fa_ctx_trim", "fa_ctx_workspace_bytes", "fa_ctx_reserve",
     "fa_mel_default_config", "fa_mel_num_frames", "fa_mel_padded_frames", "fa_mel_plan_create", "fa_mel_plan_destroy",
     "fa_mel_plan_utt_stride", "fa_mel_plan_frame_stride", "fa_mel_plan_total_frames", "fa_mel_execute_dev",
     "fa_mel_batch", "fa_mel_hann_window", "fa_mel_filterbank", "fa_mel_normalize_per_feature_dev",
@@ -137,6 +137,7 @@ def lib() -> C.CDLL:
     L.fa_ctx_trim.argtypes = [vp]
     L.fa_ctx_workspace_bytes.argtypes = [vp]
     L.fa_ctx_workspace_bytes.restype = sz
+    L.fa_ctx_reserve.argtypes = [vp, sz, sz, i32]
     L.fa_ctx_last_error.restype = C.c_char_p
     L.fa_mel_default_config.argtypes = [C.POINTER(MelConfig)]
     L.fa_mel_default_config.restype = None
@@ -328,6 +329,10 @@ class Context:
 
     def workspace_bytes(self) -> int:
         return int(lib().fa_ctx_workspace_bytes(self._h))
+
+    def reserve(self, n_max: int, d: int, recordings: int = 1):
+        """Take the linkage workspace of `recordings` problems of up to n_max x d now (server start-up), not inside the first request."""
+        self.check(lib().fa_ctx_reserve(self._h, int(n_max), int(d), int(recordings)), "fa_ctx_reserve")
 
     def check(self, status: int, where: str):
         if status != SUCCESS:

@@ -95,7 +95,8 @@ struct AhcHot {
     int32_t sym_limit;            // nodes below this id existed when the matrix was last built in full: BOTH copies of their pairs are valid
     int32_t pend_row[kPend], pend_node[kPend];  // rows whose block-partial minima the previous round produced (-1: none)
     double eps, lim;              // lim: window limit carried COLLECT -> PAIRS -> evaluation
-    int32_t n_points, hot_pad;    // N of THIS problem: the uniform-layout batch (ahc_round_uni) shares every other shape constant between its problems
+    int32_t n_points;             // N of THIS problem: the uniform-layout batch (ahc_round_uni) shares every other shape constant between its problems
+    int32_t rounds32;             // rounds executed: carried in the hot state (the rare counters — re-scans, windows — are atomics on state[0])
 };
 struct alignas(16) AhcState : AhcHot {
     unsigned long long dmax_bits, nmax_bits;  // largest matrix entry / largest squared norm seen by the start-up kernels
@@ -284,7 +285,7 @@ __global__ void ahc_init_state(Ws w, int mode) {
     s.mode = mode;
     for (int k = 0; k < kPend; ++k) { s.pend_row[k] = -1; s.pend_node[k] = -1; }
     s.prev_op = OP_NONE;
-    s.n_points = w.N; s.hot_pad = 0;
+    s.n_points = w.N; s.rounds32 = 0;
     s.sym_limit = w.N;                                     // the start-up writes the full matrix: every pair of points has both copies
     w.state[0] = s; w.state[1] = s;
     for (int i = 0; i < 4; ++i) { w.cnt[i].stale_key = ~0ULL; w.cnt[i].ncand = 0; w.cnt[i].npairs = 0; }
@@ -865,9 +866,10 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     int4 hraw[kHotVec];
 #pragma unroll
     for (int i = 0; i < kHotVec; ++i) hraw[i] = reinterpret_cast<const int4 *>(sp)[i];
-    // The cold part of the state (run counters; the start-up maxima) is NOT read by the rounds (round 4): the counters live in state[0] only and
-    // thread (0, 0) bumps them with atomic adds that nobody waits for.  Round 3 fetched it in every thread next to the hot part (a broadcast
-    // line, but 12 VGPRs per thread for the whole round and three more requests in the first batch).
+    // The cold part of the state (counters of rare events; the start-up maxima) is NOT read by the rounds (round 4): those counters live in
+    // state[0] only and thread (0, 0) bumps them with atomic adds that nobody waits for — in the rounds where the event happens; the round
+    // counter itself travels in the hot state.  Round 3 fetched the cold part in every thread next to the hot part (a broadcast line, but
+    // 12 VGPRs per thread for the whole round and three more requests in the first batch).
     AhcState *const nst = w.state + npar;
     int nx = w.node[x];
     RowSt rs = w.row[x];
@@ -1317,8 +1319,8 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
         for (int k = 0; k < kPend; ++k) { n.pend_row[k] = prow[k]; n.pend_node[k] = pnode_[k]; if (k > 0 && prow[k] >= 0) bump(&w.state[0].piggy); }
         n.lim = D.lim;
         if (D.op == OP_MERGE) n.step = st.step + 1;
+        n.rounds32 = st.rounds32 + 1;
         *nhot = n;
-        bump(&w.state[0].rounds);
         if (D.op == OP_RESCAN) bump(&w.state[0].rescans);
         if (D.op == OP_COLLECT) bump(&w.state[0].windows);
     }
@@ -1764,6 +1766,7 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
 
 // p.h holds the state after a replay of the round graph: finished, failed, or to be switched to exact rows
 fa_status prob_after_replay(fa_ctx *ctx, Prob &p) {
+    p.h.rounds = p.h.rounds32;   // the round counter travels in the hot state
     const AhcState &h = p.h;
     if (h.error == 1) { p.active = false; return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance"); }
     if (h.error) { p.active = false; return p.st = fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: internal selection failure (%d)", h.error); }
@@ -2574,6 +2577,20 @@ fastcluster_wrapper_status fastcluster_compute_centroid_linkage(const double *da
     } catch (...) {
         return FASTCLUSTER_WRAPPER_UNKNOWN_ERROR;
     }
+}
+
+fa_status fa_ctx_reserve(fa_ctx *ctx, size_t n_max, size_t d, int32_t recordings) {
+    if (!ctx || d == 0 || recordings < 1) return FA_INVALID_ARGUMENT;
+    if (n_max < 2) return FA_SUCCESS;
+    return fa::no_throw(ctx, "fa_ctx_reserve", [&]() -> fa_status {
+        fa::DeviceGuard guard(ctx->device);
+        FA_TRY(prob_check_shape(ctx, n_max, d));
+        const size_t Np = (n_max + kBlk - 1) / kBlk * kBlk;
+        const Layout L = make_layout(n_max, Np, d, Np / kBlk);
+        const size_t stride = (L.total + 4095) & ~static_cast<size_t>(4095);
+        fa::WsUse use(ctx);
+        return fa::ws_acquire(ctx, recordings > 1 ? stride * static_cast<size_t>(recordings) : L.total);
+    });
 }
 
 fa_status fa_ahc_cut(const double *z, size_t n, double threshold, int32_t *labels) {

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "fa_common.h"
@@ -137,48 +138,72 @@ __global__ __launch_bounds__(kThreads) void poly_decim_kernel(const float *__res
     for (int j = 0; j < R; j += 2) *reinterpret_cast<float2 *>(y + m0 + j) = make_float2(acc[j], acc[j + 1]);
 }
 
-// ------------------------------------------------------------------------------ non-integer ratios (44.1 / 22.05 / 11.025 / 88.2 kHz -> 16 kHz)
+// ------------------------------------------------------------------------------ non-integer ratios (44.1 / 22.05 / 11.025 kHz -> 16 kHz)
 // poly_rows_kernel (round 4).  Output m uses the taps h[p - k up] of its PHASE p mod up, p = (m + pre_remove) down; outputs m and m + up
 // share a phase and their input windows lie exactly `down` samples apart.  So lane l of a wavefront takes the outputs m0 + phase + up l:
-//   * the taps of a phase are the same in all 64 lanes -> they arrive through the scalar cache (a per-phase table, contiguous) and enter the
-//     fused multiply-adds as SGPR operands: no LDS read, no vector register per tap;
+//   * the taps of a phase are the same in all 64 lanes.  They sit in ONE vector register — lane j holds tap j, lanes 62 / 63 the window offset
+//     and the tap count of the phase — fetched by one coalesced 256-byte load a whole chunk of phases ahead, and enter the fused multiply-adds
+//     as scalar operands through v_readlane: no LDS read and no memory wait per tap.  (First version: the taps of a phase through the scalar
+//     cache, five s_load + a wait in front of every phase — the 37 KB table does not fit the 16 KB scalar cache: 24 % of the HBM roofline.)
 //   * the input window of lane l is row l of an LDS tile whose rows are `down` samples apart in the signal and `sld` floats apart in LDS,
-//     sld = 4 x odd: every lane's 16-byte reads are aligned and the 64 lanes of a read fall on distinct bank groups.  A window starts at
-//     (off & ~3) in its row, the misalignment a = off & 3 is the same in all lanes and selects one of four unrolled bodies whose register
-//     indices are compile-time constants: NV ds_read_b128 per phase and wavefront instead of ~4 NV x 2 scalar-width LDS operands
-//     (poly_lds_kernel: two ds_read_b32 per multiply-add, 6.9 % of the HBM roofline at 44.1 -> 16 kHz, LDS-issue bound);
+//     sld = 4 x odd: every lane's 16-byte reads are aligned and the 64 lanes of a read fall on distinct bank groups.  A window is read from the
+//     16-byte boundary below its start; its misalignment (the same in all lanes) is absorbed by the table row, whose taps are shifted by it:
+//     NV ds_read_b128 per phase and wavefront instead of two scalar-width LDS operands per multiply-add (poly_lds_kernel: 6.9 % of the HBM
+//     roofline at 44.1 -> 16 kHz, LDS-issue bound);
 //   * a workgroup = one tile (64 up consecutive outputs) x one group of phases (the phases are split so that the rows of a group fit ~72 KB:
-//     two workgroups per CU, one staging while the other computes).  Results leave straight from the accumulator: lane l writes
-//     y[m0 + phase + up l] — scattered 4-byte stores whose lines fill up in L2 as the other phases of the tile arrive.
-// Summation order per output: ascending input index over exactly the k range of poly_kernel (leading zero taps included) -> identical bits.
+//     two workgroups per CU, one staging while the other computes); a wavefront takes CHUNKS of four consecutive phases, so a lane ends a
+//     chunk with four consecutive outputs and stores them as one 16-byte piece (the first version stored 4 bytes per lane and phase: one L2
+//     transaction per output sample, 128 G transactions per second).
+// Summation order per output: ascending input index over the k range of poly_kernel, zero taps in front and behind -> identical bits on finite input.
 // The tile geometry (first output, first input, per-phase window offsets and counts) is computed once per rate pair on the host
 // (PolyRows below); outputs whose windows touch the ends of the signal go to poly_kernel.
 struct PolyRowsGeom {
-    int64_t m_begin, k_begin;       // first output / first staged input of tile 0
-    int32_t up, down, ntp;          // ntp: floats per phase in the tap table (max taps of a phase rounded up to 4)
-    int32_t groups, ppg;            // phase groups per tile, phases per group
+    int64_t m_begin, k_begin;       // first output (a multiple of 4) / first staged input of tile 0
+    int32_t up, down;
+    int32_t groups, ppg;            // phase groups per tile, phases per group (a multiple of 4)
     int32_t sld;                    // LDS row stride in floats (4 x odd)
     int32_t smax;                   // last staged offset + 1 within a row over all phases (for the tile-count bound)
 };
 constexpr int kRowsThreads = 512, kRowsWaves = kRowsThreads / 64;
+constexpr int kRowsOffLane = 62;   // lane of a phase's table row that carries its (aligned) window offset; taps: lanes 0 .. 61
 
-template <int NV, int IT>   // NV: 16-byte reads per window; IT: 64-float pieces per staged row (sld <= 64 IT)
-__global__ __launch_bounds__(kRowsThreads) void poly_rows_kernel(const float *__restrict__ x, const float *__restrict__ tt, const int2 *__restrict__ ptab,
-                                                                float *__restrict__ y, const PolyRowsGeom g, const int64_t tiles, const int64_t m_end) {
+// one phase: `trow` = its table row (one value per lane), rowp = this lane's LDS row (shifted by the group's first staged offset).
+// The table row holds the phase's taps SHIFTED by the misalignment of its window (zeros in front and behind), so the window is read from the
+// 16-byte boundary below it and every multiply-add has compile-time register indices — no per-alignment code paths.  The padding taps are
+// zeros: on finite inputs x * 0 adds +-0 and the sum keeps the bits of poly_kernel's (scipy's upfirdn pads its phases with zeros the same way).
+template <int NV>
+__device__ __forceinline__ float rows_phase(const float trow, const float *rowp) {
+    const int tb = __float_as_int(trow);
+    const int off4 = __builtin_amdgcn_readlane(tb, kRowsOffLane);      // window offset rounded down to a multiple of 4
+    const float4 *wp = reinterpret_cast<const float4 *>(rowp + off4);
+    float xr[4 * NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { const float4 q = wp[v]; xr[4 * v] = q.x; xr[4 * v + 1] = q.y; xr[4 * v + 2] = q.z; xr[4 * v + 3] = q.w; }
+    float acc = 0.0f;
+    constexpr int NT = 4 * NV < kRowsOffLane ? 4 * NV : kRowsOffLane;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(tb, j)), xr[j], acc);
+    return acc;
+}
+
+template <int NV, int IT>   // NV: 16-byte reads per window (4 (NV - 1) taps at most); IT: 64-float pieces per staged row (sld <= 64 IT)
+__global__ __launch_bounds__(kRowsThreads) void poly_rows_kernel(const float *__restrict__ x, const float *__restrict__ tt, const int2 *__restrict__ gtab,
+                                                                float *__restrict__ y, const PolyRowsGeom g, const int64_t m_end, const int vec_ok) {
     extern __shared__ float xs[];
-    typedef const float __attribute__((address_space(4))) *c_f32;
     typedef const int __attribute__((address_space(4))) *c_i32;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t tile = blockIdx.x / g.groups;
     const int grp = static_cast<int>(blockIdx.x - tile * g.groups);
     const int ph0 = grp * g.ppg, ph1 = ph0 + g.ppg < g.up ? ph0 + g.ppg : g.up;
-    const c_i32 pt = (c_i32) reinterpret_cast<const int *>(ptab);
-    const int smin = pt[2 * ph0] & ~3;
-    const int span = pt[2 * (ph1 - 1)] + 4 * NV - smin;                 // offsets grow with the phase
+    const int nchunks = (ph1 - ph0 + 3) >> 2;
+    auto row = [&](const int ph) -> float { return ph < ph1 ? tt[static_cast<size_t>(ph) * 64 + lane] : 0.0f; };   // ph is wave-uniform
+    int c = wave;
+    float t0 = row(ph0 + 4 * c), t1 = row(ph0 + 4 * c + 1), t2 = row(ph0 + 4 * c + 2), t3 = row(ph0 + 4 * c + 3);   // requested before the staging
+    const c_i32 gt = (c_i32) reinterpret_cast<const int *>(gtab);
+    const int smin = gt[2 * grp], span = gt[2 * grp + 1];
     const int64_t kt = g.k_begin + tile * 64 * g.down + smin;
     {   // wavefront w stages rows 8 w .. 8 w + 7 with coalesced 256-byte requests — ALL of them requested before the first is written to LDS
-        // (the first version wrote each element as it arrived: 40 dependent HBM round trips per thread, 26 us per workgroup where the arithmetic
-        // takes 7: 18.8 % of the HBM roofline at 44.1 -> 16 kHz)
+        // (writing each element as it arrived made 40 dependent HBM round trips per thread: 18.8 % of the HBM roofline at 44.1 -> 16 kHz)
         constexpr int kRowsPerWave = 64 / kRowsWaves;
         float v[kRowsPerWave][IT];
 #pragma unroll
@@ -196,42 +221,23 @@ __global__ __launch_bounds__(kRowsThreads) void poly_rows_kernel(const float *__
     }
     __syncthreads();
     const float *rowp = xs + lane * g.sld - smin;
-    const int64_t m0 = g.m_begin + tile * 64 * g.up + static_cast<int64_t>(lane) * g.up;
-    for (int ph = ph0 + wave; ph < ph1; ph += kRowsWaves) {
-        const int off = pt[2 * ph], cnt = pt[2 * ph + 1];
-        const int a = off & 3;
-        const float4 *wp = reinterpret_cast<const float4 *>(rowp + (off - a));
-        float xr[4 * NV];
+    const int64_t mlane = g.m_begin + tile * 64 * g.up + static_cast<int64_t>(lane) * g.up;
+    for (; c < nchunks; c += kRowsWaves) {
+        const int p = ph0 + 4 * c, pn = p + 4 * kRowsWaves;
+        const float n0 = row(pn), n1 = row(pn + 1), n2 = row(pn + 2), n3 = row(pn + 3);   // the next chunk's table rows travel under this chunk's arithmetic
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        acc[0] = rows_phase<NV>(t0, rowp);                                                   // p < ph1 by construction of nchunks
+        if (p + 1 < ph1) acc[1] = rows_phase<NV>(t1, rowp);
+        if (p + 2 < ph1) acc[2] = rows_phase<NV>(t2, rowp);
+        if (p + 3 < ph1) acc[3] = rows_phase<NV>(t3, rowp);
+        const int64_t m = mlane + p;
+        if (vec_ok && p + 3 < ph1 && m + 3 < m_end) {
+            *reinterpret_cast<float4 *>(y + m) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) { const float4 q = wp[v]; xr[4 * v] = q.x; xr[4 * v + 1] = q.y; xr[4 * v + 2] = q.z; xr[4 * v + 3] = q.w; }
-        // all taps of the phase in one batch of scalar loads (the table is padded to ntp floats per phase; pinned in SGPRs here so that the
-        // loads are not sunk into the per-chunk branches below: one scalar round trip per phase, not one per chunk)
-        const c_f32 tsrc = (c_f32)(tt + static_cast<size_t>(ph) * g.ntp);
-        float tp[4 * (NV - 1)];
-#pragma unroll
-        for (int j = 0; j < 4 * (NV - 1); ++j) tp[j] = tsrc[j];
-#pragma unroll
-        for (int j = 0; j < 4 * (NV - 1); j += 4) asm volatile("" :: "s"(tp[j]), "s"(tp[j + 1]), "s"(tp[j + 2]), "s"(tp[j + 3]));
-        float acc = 0.0f;
-        auto body = [&](auto av) {
-            constexpr int A = decltype(av)::value;
-#pragma unroll
-            for (int c = 0; c < NV - 1; ++c) {                          // taps 4c .. 4c + 3 meet xr[A + 4c ..]; A + 4 (NV - 1) - 1 + 3 < 4 NV
-                if (4 * c + 4 <= cnt) {
-#pragma unroll
-                    for (int j = 4 * c; j < 4 * c + 4; ++j) acc = fmaf(tp[j], xr[A + j], acc);
-                } else {
-#pragma unroll
-                    for (int j = 4 * c; j < 4 * c + 4; ++j) if (j < cnt) acc = fmaf(tp[j], xr[A + j], acc);
-                }
-            }
-        };
-        if (a == 0) body(std::integral_constant<int, 0>{});
-        else if (a == 1) body(std::integral_constant<int, 1>{});
-        else if (a == 2) body(std::integral_constant<int, 2>{});
-        else body(std::integral_constant<int, 3>{});
-        const int64_t m = m0 + ph;
-        if (m < m_end) y[m] = acc;
+            for (int u = 0; u < 4; ++u) if (p + u < ph1 && m + u < m_end) y[m + u] = acc[u];
+        }
+        t0 = n0; t1 = n1; t2 = n2; t3 = n3;
     }
 }
 
@@ -240,71 +246,83 @@ struct PolyRows {
     PolyRowsGeom g{};
     int nv = 0;                     // 16-byte reads per phase window
     size_t lds = 0;
-    void *d_tables = nullptr;       // [ptab int2 x up][tt float x up x ntp]
+    void *d_tables = nullptr;       // [gtab int2 x groups, padded to 256 B][table rows: 64 floats per phase]
+    size_t tt_offset = 0;
     int up = 0, down = 0;
     ~PolyRows() { if (d_tables) (void)hipFree(d_tables); }
 };
 void poly_rows_free(void *p) { delete static_cast<PolyRows *>(p); }
 
 // Geometry + tables; false when the pair does not suit the kernel (then poly_lds_kernel serves it).
-bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &ptab, std::vector<float> &tt) {
+bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt) {
     const int64_t h_len = static_cast<int64_t>(h.size());
-    if (up < 8 || up > 1024 || down > 4096) return false;               // few phases: the register-tiled kernels; huge ones: tables too large
+    if (up < 8 || up > 4096 || down > 8192) return false;               // few phases: the register-tiled kernels; huge ones: tables too large
     const int q1 = static_cast<int>((h_len + up - 1) / up);             // a window holds floor(h_len / up) or that + 1 taps
-    int nv = (q1 + 3) / 4 + 1;                                          // 4 (nv - 1) >= q1 taps; the extra read covers a misalignment of up to 3
+    if (q1 + 3 > kRowsOffLane) return false;                            // shifted taps of a phase + its offset share one 64-lane table row
+    int nv = (q1 + 3 + 3) / 4;                                          // 4 nv >= misalignment (<= 3) + taps
     {   // instantiated sizes (poly_rows_launch); a larger one only reads a little further into the row
-        static const int sizes[] = {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 24, 31};
+        static const int sizes[] = {4, 6, 8, 10, 12, 14, 16};
         int pick = 0;
         for (int v : sizes) if (v >= nv) { pick = v; break; }
         if (!pick) return false;
         nv = pick;
     }
-    // first output whose window lies inside the signal: p - (h_len - 1) >= 0
+    // first output whose window lies inside the signal: p - (h_len - 1) >= 0; rounded up to a multiple of 4 (16-byte output pieces)
     int64_t m_begin = (h_len - 1 + down - 1) / down - pre_remove;
     if (m_begin < 0) m_begin = 0;
+    m_begin = (m_begin + 3) & ~static_cast<int64_t>(3);
     const int64_t p0 = (m_begin + pre_remove) * down;
     const int64_t k_begin = (p0 - (h_len - 1) + up - 1) / up;           // k_lo of the first output
-    ptab.assign(2 * static_cast<size_t>(up), 0);
-    const int ntp = 4 * (nv - 1);
-    tt.assign(static_cast<size_t>(up) * ntp, 0.0f);
+    std::vector<int> off(up), cnt(up);
+    tt.assign(static_cast<size_t>(up) * 64, 0.0f);
     int smax = 0;
     for (int ph = 0; ph < up; ++ph) {
         const int64_t p = p0 + static_cast<int64_t>(ph) * down;
         const int64_t k_hi = p / up, k_lo = (p - (h_len - 1) + up - 1) / up;   // p - (h_len - 1) >= 0 here
-        const int cnt = static_cast<int>(k_hi - k_lo + 1);
-        if (cnt > ntp || cnt < 1) return false;
-        ptab[2 * ph] = static_cast<int>(k_lo - k_begin);
-        ptab[2 * ph + 1] = cnt;
-        for (int j = 0; j < cnt; ++j) tt[static_cast<size_t>(ph) * ntp + j] = h[static_cast<size_t>(p - (k_lo + j) * up)];
-        smax = std::max(smax, ptab[2 * ph] + 4 * nv);
+        cnt[ph] = static_cast<int>(k_hi - k_lo + 1);
+        off[ph] = static_cast<int>(k_lo - k_begin);
+        const int a = off[ph] & 3, off4 = off[ph] - a;
+        if (cnt[ph] < 1 || a + cnt[ph] > std::min(4 * nv, kRowsOffLane)) return false;
+        float *rowp = tt.data() + static_cast<size_t>(ph) * 64;
+        for (int j = 0; j < cnt[ph]; ++j) rowp[a + j] = h[static_cast<size_t>(p - (k_lo + j) * up)];
+        memcpy(rowp + kRowsOffLane, &off4, sizeof(int));
+        smax = std::max(smax, off4 + 4 * nv);
     }
-    // phase groups: the rows of a group within ~72 KB of LDS (two workgroups per CU); rows are `sld` floats apart, sld = 4 x odd >= span
+    // phase groups (a multiple of 4 phases each): the rows of a group within ~72 KB of LDS (two workgroups per CU); rows are `sld` floats apart,
+    // sld = 4 x odd >= the longest staged span of a group
     int groups = 1, ppg = up, sld = 0;
     for (;; ++groups) {
-        ppg = (up + groups - 1) / groups;
+        ppg = ((up + groups - 1) / groups + 3) & ~3;
         int span = 0;
-        for (int gq = 0; gq < groups; ++gq) {
-            const int a0 = gq * ppg, a1 = std::min(up, a0 + ppg);
-            if (a0 >= a1) continue;
-            span = std::max(span, ptab[2 * (a1 - 1)] + 4 * nv - (ptab[2 * a0] & ~3));
+        for (int a0 = 0; a0 < up; a0 += ppg) {
+            const int a1 = std::min(up, a0 + ppg);
+            span = std::max(span, (off[a1 - 1] & ~3) + 4 * nv - (off[a0] & ~3));
         }
         sld = (span + 3) / 4;
         if (sld % 2 == 0) ++sld;
         sld *= 4;
-        if (static_cast<size_t>(sld) * 64 * sizeof(float) <= 74 * 1024 || ppg <= kRowsWaves) break;
+        if (static_cast<size_t>(sld) * 64 * sizeof(float) <= 74 * 1024 || ppg <= 4 * kRowsWaves) break;
     }
+    groups = (up + ppg - 1) / ppg;
     if (static_cast<size_t>(sld) * 64 * sizeof(float) > 150 * 1024 || sld > 64 * 10) return false;
-    R.g.m_begin = m_begin; R.g.k_begin = k_begin; R.g.up = up; R.g.down = down; R.g.ntp = ntp; R.g.groups = groups; R.g.ppg = ppg; R.g.sld = sld; R.g.smax = smax;
+    gtab.assign(2 * static_cast<size_t>(groups), 0);
+    for (int gq = 0; gq < groups; ++gq) {
+        const int a0 = gq * ppg, a1 = std::min(up, a0 + ppg);
+        gtab[2 * gq] = off[a0] & ~3;
+        gtab[2 * gq + 1] = (off[a1 - 1] & ~3) + 4 * nv - (off[a0] & ~3);
+    }
+    R.g.m_begin = m_begin; R.g.k_begin = k_begin; R.g.up = up; R.g.down = down; R.g.groups = groups; R.g.ppg = ppg; R.g.sld = sld; R.g.smax = smax;
     R.nv = nv; R.lds = static_cast<size_t>(sld) * 64 * sizeof(float); R.up = up; R.down = down;
     return true;
 }
 
 template <int NV, int IT>
 void poly_rows_launch_it(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end) {
-    const int2 *ptab = static_cast<const int2 *>(R.d_tables);
-    const float *tt = reinterpret_cast<const float *>(static_cast<const char *>(R.d_tables) + sizeof(int2) * R.up);
+    const int2 *gtab = static_cast<const int2 *>(R.d_tables);
+    const float *tt = reinterpret_cast<const float *>(static_cast<const char *>(R.d_tables) + R.tt_offset);
+    const int vec_ok = R.up % 4 == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0 ? 1 : 0;   // m_begin and the chunk starts are multiples of 4
     if (R.lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(poly_rows_kernel<NV, IT>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(R.lds));
-    hipLaunchKernelGGL((poly_rows_kernel<NV, IT>), dim3(static_cast<unsigned>(tiles * R.g.groups)), dim3(kRowsThreads), R.lds, ctx->stream, d_x, tt, ptab, d_y, R.g, tiles, m_end);
+    hipLaunchKernelGGL((poly_rows_kernel<NV, IT>), dim3(static_cast<unsigned>(tiles * R.g.groups)), dim3(kRowsThreads), R.lds, ctx->stream, d_x, tt, gtab, d_y, R.g, m_end, vec_ok);
 }
 template <int NV>
 void poly_rows_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end) {
@@ -438,13 +456,14 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
             if (ctx->poly_rows && ctx->poly_rows_free) { ctx->poly_rows_free(ctx->poly_rows); ctx->poly_rows = nullptr; }
             {
                 PolyRows *R = new PolyRows();
-                std::vector<int> ptab;
+                std::vector<int> gtab;
                 std::vector<float> tt;
-                bool ok = poly_rows_build(*R, taps, u, dn, pre_remove, ptab, tt);
+                bool ok = poly_rows_build(*R, taps, u, dn, pre_remove, gtab, tt);
                 if (ok) {
-                    const size_t b0 = sizeof(int) * ptab.size(), b1 = sizeof(float) * tt.size();
+                    const size_t b0 = (sizeof(int) * gtab.size() + 255) & ~static_cast<size_t>(255), b1 = sizeof(float) * tt.size();
+                    R->tt_offset = b0;
                     ok = hipMalloc(&R->d_tables, b0 + b1) == hipSuccess &&
-                         hipMemcpyAsync(R->d_tables, ptab.data(), b0, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                         hipMemcpyAsync(R->d_tables, gtab.data(), sizeof(int) * gtab.size(), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
                          hipMemcpyAsync(static_cast<char *>(R->d_tables) + b0, tt.data(), b1, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
                          hipStreamSynchronize(ctx->stream) == hipSuccess;
                     if (!ok) (void)hipGetLastError();
@@ -499,8 +518,7 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
                 const int64_t m_stop = std::min(n_out, G.m_begin + tiles * per_tile);
                 switch (R.nv) {
 #define FA_ROWS_CASE(V) case V: poly_rows_launch<V>(ctx, R, d_x, d_y, tiles, m_stop); break;
-                    FA_ROWS_CASE(4) FA_ROWS_CASE(5) FA_ROWS_CASE(6) FA_ROWS_CASE(7) FA_ROWS_CASE(8) FA_ROWS_CASE(9) FA_ROWS_CASE(10) FA_ROWS_CASE(11) FA_ROWS_CASE(12)
-                    FA_ROWS_CASE(13) FA_ROWS_CASE(14) FA_ROWS_CASE(15) FA_ROWS_CASE(16) FA_ROWS_CASE(17) FA_ROWS_CASE(18) FA_ROWS_CASE(20) FA_ROWS_CASE(24) FA_ROWS_CASE(31)
+                    FA_ROWS_CASE(4) FA_ROWS_CASE(6) FA_ROWS_CASE(8) FA_ROWS_CASE(10) FA_ROWS_CASE(12) FA_ROWS_CASE(14) FA_ROWS_CASE(16)
 #undef FA_ROWS_CASE
                     default: tiles = 0; break;
                 }

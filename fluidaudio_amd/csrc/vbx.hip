@@ -15,6 +15,7 @@
 // T).  Both give the same bits: a shard computes exactly the records the single device computes for those slices.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "fa_common.h"
@@ -177,6 +178,8 @@ __global__ void vbx_logpi(VbxWs w) {  // log(max(pi, 1e-8)) (:498-514)
     if (s < w.S) { const double p = w.pi[s]; w.logpi[s] = log(p >= 1e-8 ? p : 1e-8); }
 }
 
+__device__ __forceinline__ void vbx_softmax_row(const VbxWs &w, int64_t t, double *g, double mx, int lane);
+
 // E-step for one frame per wave: logP[s] = Fa (rho_t . alpha_s - phiT_s/2 + G_t) (:441-492),
 // gamma = softmax(logP + log pi), llrow = logsumexp (:516-572).  S is processed in chunks of 64.
 __global__ __launch_bounds__(kThreads) void vbx_estep(VbxWs w) {
@@ -201,6 +204,11 @@ __global__ __launch_bounds__(kThreads) void vbx_estep(VbxWs w) {
         mx = lp > mx ? lp : mx;
     }
     mx = wave_max(mx);
+    vbx_softmax_row(w, t, g, mx, lane);
+}
+
+// gamma = softmax of the staged row, llrow = its logsumexp (:516-572); `mx` = the row maximum, known to every lane.
+__device__ __forceinline__ void vbx_softmax_row(const VbxWs &w, const int64_t t, double *g, const double mx, const int lane) {
     double sum = 0.0;
     for (int s = lane; s < w.S; s += 64) { const double e = exp(g[s] - mx); g[s] = e; sum += e; }
     sum = wave_sum(sum);
@@ -212,6 +220,119 @@ __global__ __launch_bounds__(kThreads) void vbx_estep(VbxWs w) {
         for (int s = lane; s < w.S; s += 64) g[s] *= inv;
         if (lane == 0) w.llrow[t] = mx + log(sum);
     }
+}
+
+// ---- many speakers (the hard sessions: AHC leaves hundreds of clusters, e.g. 597 at sigma = 0.041) ------------------------------------------
+// Both contractions of an iteration are then real matrix products — gamma^T (rho, 1): [S x T_slice] x [T_slice x (D + 1)] per slice, and
+// rho alpha^T: [T x D] x [D x S] — and the kernels above (one speaker per wavefront column / one frame per wavefront, every multiply-add fed by
+// two global loads, the alpha rows of 64 lanes in 64 different lines) take 7.6 ms per iteration at S = 597, T = 43 200: 46 ms of the 300 ms
+// of that recording.  Tiled form: 64 x 64 outputs per workgroup, 4 x 4 per thread, both operands k-major in LDS (16 k per stage), operands read
+// as 16-byte pairs.  Every output is ONE accumulator fed in ascending k by fused multiply-adds with the same operands as the kernels above —
+// the same bits, so single-device and sharded runs, and small-S and large-S code paths, agree on every record.  (fp64 vector FMA runs at the
+// rate of the fp64 matrix core on this part; the MFMA form would have to keep this summation order to keep the records' bits and does not.)
+constexpr int kVT = 64, kVK = 16, kVPad = 2;
+constexpr int kVbxTiledMinS = 48;
+
+// record[z][s][0..D] for the slices owned; grid (ceil((D + 1) / 64), ceil(S / 64), z_n)
+__global__ __launch_bounds__(kThreads) void vbx_gt_rho_tiled(VbxWs w) {
+    __shared__ __attribute__((aligned(16))) double sa[kVK][kVT + kVPad], sb[kVK][kVT + kVPad];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;   // tx: column quad, ty: speaker quad
+    const int c0 = blockIdx.x * kVT, s0 = blockIdx.y * kVT;
+    const int z = w.z_lo + blockIdx.z;
+    const int64_t per = (w.Tg + kSplit - 1) / kSplit;
+    int64_t t0 = z * per, t1 = t0 + per < w.Tg ? t0 + per : w.Tg;
+    t0 -= w.t0g; t1 -= w.t0g;
+    const int D = w.D, S = w.S;
+    double acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+    for (int64_t k0 = t0; k0 < t1; k0 += kVK) {
+        for (int e = tid; e < kVK * kVT; e += kThreads) {
+            const int kk = e / kVT, i = e % kVT;
+            const int64_t t = k0 + kk;
+            const bool in = t < t1;
+            sa[kk][i] = in && s0 + i < S ? w.gamma[t * S + s0 + i] : 0.0;
+            const int col = c0 + i;
+            sb[kk][i] = !in ? 0.0 : (col < D ? w.rho[t * D + col] : (col == D ? 1.0 : 0.0));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kVK; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = sa[kk][4 * ty + r]; b[r] = sb[kk][4 * tx + r]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fma(a[r], b[c], acc[r][c]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int sp = s0 + 4 * ty + r, col = c0 + 4 * tx + c;
+            if (sp < S && col <= D) w.rec_out[blockIdx.z * w.stride + static_cast<int64_t>(sp) * (D + 1) + col] = acc[r][c];
+        }
+}
+
+// logP staged in gamma: gamma[t][s] = Fa (rho_t . alpha_s - phiT_s / 2 + G_t) + log pi_s; grid (ceil(S / 64), ceil(T / 64))
+__global__ __launch_bounds__(kThreads) void vbx_logits_tiled(VbxWs w) {
+    __shared__ __attribute__((aligned(16))) double sa[kVK][kVT + kVPad], sb[kVK][kVT + kVPad];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;   // tx: speaker quad, ty: frame quad
+    const int s0 = blockIdx.x * kVT;
+    const int64_t f0 = static_cast<int64_t>(blockIdx.y) * kVT;
+    const int D = w.D, S = w.S;
+    double acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+    for (int k0 = 0; k0 < D; k0 += kVK) {
+        for (int e = tid; e < kVK * kVT; e += kThreads) {
+            const int i = e / kVK, kk = e % kVK, d = k0 + kk;       // 16 consecutive d of one row: 128-byte segments
+            sa[kk][i] = f0 + i < w.T && d < D ? w.rho[(f0 + i) * D + d] : 0.0;
+            sb[kk][i] = s0 + i < S && d < D ? w.alpha[static_cast<int64_t>(s0 + i) * D + d] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < kVK; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = sa[kk][4 * ty + r]; b[r] = sb[kk][4 * tx + r]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fma(a[r], b[c], acc[r][c]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t t = f0 + 4 * ty + r;
+        if (t >= w.T) continue;
+        const double gt = w.G[t];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int sp = s0 + 4 * tx + c;
+            if (sp < S) w.gamma[t * S + sp] = fma(fma(w.phiT[sp], -0.5, acc[r][c]) + gt, w.Fa, w.logpi[sp]);
+        }
+    }
+}
+
+// the row soft-max over the staged logits; one wavefront per frame
+__global__ __launch_bounds__(kThreads) void vbx_softmax_rows(VbxWs w) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    if (t >= w.T) return;
+    double *g = w.gamma + t * w.S;
+    double mx = -1.7976931348623157e308;
+    for (int s = lane; s < w.S; s += 64) { const double lp = g[s]; mx = lp > mx ? lp : mx; }
+    mx = wave_max(mx);
+    vbx_softmax_row(w, t, g, mx, lane);
 }
 
 // Scalars of one iteration: normalise pi (:605-621), log-likelihood (the slice sums in slice order) and
@@ -339,7 +460,10 @@ fa_status vbx_setup(fa_ctx *ctx, const double *d_X, int64_t T, int64_t Tg, int64
 // the records of the owned slices from the present posteriors (and the present per-frame log-likelihoods)
 fa_status vbx_records(fa_ctx *ctx, const VbxWs &w) {
     if (w.z_n <= 0) return FA_SUCCESS;
-    hipLaunchKernelGGL(vbx_gt_rho, dim3((w.D + 1 + 63) / 64, (w.S + 3) / 4, w.z_n), dim3(kThreads), 0, ctx->stream, w);
+    if (w.S >= kVbxTiledMinS && getenv("FA_VBX_NO_TILED") == nullptr)
+        hipLaunchKernelGGL(vbx_gt_rho_tiled, dim3((w.D + 1 + kVT - 1) / kVT, (w.S + kVT - 1) / kVT, w.z_n), dim3(kThreads), 0, ctx->stream, w);
+    else
+        hipLaunchKernelGGL(vbx_gt_rho, dim3((w.D + 1 + 63) / 64, (w.S + 3) / 4, w.z_n), dim3(kThreads), 0, ctx->stream, w);
     hipLaunchKernelGGL(vbx_llpart, dim3(w.z_n), dim3(kThreads), 0, ctx->stream, w);
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
@@ -349,7 +473,11 @@ fa_status vbx_estep_phase(fa_ctx *ctx, const VbxWs &w) {
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(vbx_speaker, dim3(w.S), dim3(kThreads), 0, st, w, 0);
     hipLaunchKernelGGL(vbx_logpi, dim3((w.S + 255) / 256), dim3(256), 0, st, w);
-    if (w.T > 0) hipLaunchKernelGGL(vbx_estep, dim3(static_cast<int>((w.T + 3) / 4)), dim3(kThreads), sizeof(double) * 4 * static_cast<size_t>(w.D), st, w);
+    if (w.T > 0 && w.S >= kVbxTiledMinS && getenv("FA_VBX_NO_TILED") == nullptr) {
+        hipLaunchKernelGGL(vbx_logits_tiled, dim3((w.S + kVT - 1) / kVT, static_cast<unsigned>((w.T + kVT - 1) / kVT)), dim3(kThreads), 0, st, w);
+        hipLaunchKernelGGL(vbx_softmax_rows, dim3(static_cast<int>((w.T + 3) / 4)), dim3(kThreads), 0, st, w);
+    } else if (w.T > 0)
+        hipLaunchKernelGGL(vbx_estep, dim3(static_cast<int>((w.T + 3) / 4)), dim3(kThreads), sizeof(double) * 4 * static_cast<size_t>(w.D), st, w);
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }

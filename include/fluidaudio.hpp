@@ -43,6 +43,8 @@ public:
     void setWorkspaceCap(size_t bytes) { check(fa_ctx_set_workspace_cap(h_, bytes), "fa_ctx_set_workspace_cap"); }
     void trim() { check(fa_ctx_trim(h_), "fa_ctx_trim"); }
     size_t workspaceBytes() const { return fa_ctx_workspace_bytes(h_); }
+    // server start-up: the workspace of `recordings` linkage problems of up to nMax embeddings now, not inside the first request
+    void reserve(size_t nMax, size_t d, int32_t recordings = 1) { check(fa_ctx_reserve(h_, nMax, d, recordings), "fa_ctx_reserve"); }
 private:
     fa_ctx *h_ = nullptr;
 };

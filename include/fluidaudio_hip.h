@@ -57,12 +57,17 @@ void fa_host_free(void *p);
  *                                AHCClustering degrades to singletons).  Default: no cap — hipMalloc decides.
  *   fa_ctx_trim                : releases everything cached now.
  *   fa_ctx_workspace_bytes     : bytes cached right now.
+ *   fa_ctx_reserve             : takes the workspace of `recordings` linkage problems of up to n_max points x d dimensions NOW (one
+ *                                recording: fa_ahc_linkage / fa_offline_cluster; several: the batched entries, whose problems share one
+ *                                allocation), so that a server pays the hipMalloc (0.3 - 6 s for 15 GB, depending on the box) at start-up
+ *                                and not inside its first request.  Subject to the cap; kept between calls like any workspace within the limit.
  * Independently of these, a context whose workspace allocation fails first releases the idle caches of the OTHER contexts on the
  * same device and retries, so a pool of contexts on one GPU re-allocates under pressure instead of failing. */
 fa_status fa_ctx_set_workspace_limit(fa_ctx *ctx, size_t bytes);
 fa_status fa_ctx_set_workspace_cap(fa_ctx *ctx, size_t bytes);
 fa_status fa_ctx_trim(fa_ctx *ctx);
 size_t fa_ctx_workspace_bytes(const fa_ctx *ctx);
+fa_status fa_ctx_reserve(fa_ctx *ctx, size_t n_max, size_t d, int32_t recordings);
 /* Last error text recorded on this context ("" if none). */
 const char *fa_ctx_last_error(const fa_ctx *ctx);
 /* Library build identification, e.g. "fluidaudio_hip 0.1 gfx950". */

@@ -132,3 +132,26 @@ def test_vbx_sharded_two_processes_one_gpu(fa, gpu_ctx):
     assert np.array_equal(np.concatenate([got[0][1], got[1][1]]), one.gamma)
     assert np.array_equal(got[0][2], one.pi) and np.array_equal(got[1][2], one.pi)
     assert np.concatenate([got[0][3], got[1][3]]).tolist() == one.hard_clusters[0]
+
+
+@pytest.mark.parametrize("T,D,K,seed", [(3000, 128, 70, 3), (5000, 128, 300, 4), (700, 40, 49, 5), (4097, 96, 129, 6)])
+def test_tiled_kernels_of_many_speakers_keep_the_bits(fa, gpu_ctx, oracle_mod, monkeypatch, T, D, K, seed):
+    """S >= 48 speakers (hard sessions: hundreds of AHC clusters): the two contractions of an iteration run as 64 x 64 tiled products
+    (vbx_gt_rho_tiled, vbx_logits_tiled + vbx_softmax_rows).  Every output is one accumulator fed in ascending k by the same fused
+    multiply-adds as the one-speaker-per-wavefront kernels: gamma, pi, ELBOs and labels are identical bit for bit (FA_VBX_NO_TILED=1 runs
+    the old kernels), and equal to the CPU restatement at its tolerance."""
+    x, init, phi = make_problem(T, D, K, seed)
+    tiled = fa.VBxClustering(phi, ctx=gpu_ctx).refine(x, init)
+    monkeypatch.setenv("FA_VBX_NO_TILED", "1")
+    plain = fa.VBxClustering(phi, ctx=gpu_ctx).refine(x, init)
+    monkeypatch.delenv("FA_VBX_NO_TILED")
+    assert tiled.num_clusters == plain.num_clusters == K
+    assert tiled.elbos == plain.elbos
+    np.testing.assert_array_equal(tiled.gamma, plain.gamma)
+    np.testing.assert_array_equal(tiled.pi, plain.pi)
+    assert tiled.hard_clusters == plain.hard_clusters
+    if T * K <= 400_000:
+        gamma, pi, hard, elbos = oracle_mod.vbx_refine(x, init, phi)
+        np.testing.assert_allclose(tiled.elbos, elbos, rtol=1e-9)
+        np.testing.assert_allclose(tiled.gamma, gamma, atol=1e-9)
+        assert tiled.hard_clusters[0] == hard.tolist()
