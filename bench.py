@@ -495,7 +495,7 @@ def resample_leg(fa, ctx, torch, seconds=3600):
     return out
 
 
-def tdt_leg(fa, ctx, torch, B=256, U=64, T=188, V1=1025, nd=5, dtype="float32"):
+def tdt_leg(fa, ctx, torch, B=1024, U=64, T=188, V1=1025, nd=5, dtype="float32"):
     """The TDT greedy walk (TdtDecoderV3.swift:230-467) on joint LOGITS resident in HBM: B chunks of 15 s (T = 188 encoder frames), the joint
     evaluated on a (u, t) grid of U x T cells of W = V1 + nd logits each (the networks themselves are not in the reference tree: synthetic
     logits, ~75 % blanks).  The walk visits ~T + tokens cells per chunk and reads only those rows: algorithmic bytes = visited cells x W x 4.

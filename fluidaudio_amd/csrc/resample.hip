@@ -138,6 +138,62 @@ __global__ __launch_bounds__(kThreads) void poly_decim_kernel(const float *__res
     for (int j = 0; j < R; j += 2) *reinterpret_cast<float2 *>(y + m0 + j) = make_float2(acc[j], acc[j + 1]);
 }
 
+// ------------------------------------------------------------------------------ small interpolation factors (8 / 12 / 24 kHz -> 16 kHz)
+// poly_interp_kernel<UP, DOWN, NT>: the register-tiled form of poly_decim_kernel for UP = 2 .. 4.  A thread produces R UP consecutive outputs
+// whose first one starts a phase cycle ((m0 + pre_remove) DOWN = 0 mod UP: the host picks the first output accordingly), so the tap index of
+// every (output, input) pair is a compile-time constant: taps through the scalar cache as scalar operands of the fused multiply-adds, the
+// R DOWN + NT / UP inputs of the thread in registers, no LDS.  (The LDS-staged kernel reads two LDS operands per multiply-add: 11 % of the HBM
+// roofline at 8 -> 16 kHz.)  Per output the terms are added in ascending input order over exactly the k range of poly_kernel: identical bits.
+// Loads and stores are 16-byte accesses of 4-byte alignment (neither the first input nor the first output of a thread is 16-byte aligned in
+// general; the hardware's unaligned access mode serves them).
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+template <int UP, int DOWN, int NT>
+__global__ __launch_bounds__(kThreads) void poly_interp_kernel(const float *__restrict__ x, const float *__restrict__ h, float *__restrict__ y, const int64_t m_begin,
+                                                               const int64_t q_begin, const int64_t groups) {
+    constexpr int R = 4, NO = R * UP, KB = (NT - 1) / UP, NIN = ((NO - 1) * DOWN) / UP + KB + 1, NV = (NIN + 3) / 4;
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    if (g >= groups) return;
+    const f4u *src = reinterpret_cast<const f4u *>(x + (q_begin - KB + g * (R * DOWN)));
+    float xin[4 * NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { const f4u q = src[v]; xin[4 * v] = q.x; xin[4 * v + 1] = q.y; xin[4 * v + 2] = q.z; xin[4 * v + 3] = q.w; }
+    typedef const float __attribute__((address_space(4))) *c_f32;
+    const c_f32 taps = (c_f32)h;
+    float acc[NO];
+#pragma unroll
+    for (int r = 0; r < NO; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)          // ascending input index; output r meets input i with tap r DOWN + (KB - i) UP
+#pragma unroll
+        for (int r = 0; r < NO; ++r) {
+            const int ti = r * DOWN + (KB - i) * UP;
+            if (ti >= 0 && ti < NT) acc[r] = fmaf(taps[ti], xin[i], acc[r]);
+        }
+    f4u *dst = reinterpret_cast<f4u *>(y + m_begin + g * NO);
+#pragma unroll
+    for (int v = 0; v < NO / 4; ++v) { f4u o; o.x = acc[4 * v]; o.y = acc[4 * v + 1]; o.z = acc[4 * v + 2]; o.w = acc[4 * v + 3]; dst[v] = o; }
+}
+
+// launches poly_interp_kernel on the outputs whose inputs all exist; returns the covered range [m_lo, m_hi) (empty when the pair has no instance)
+template <int UP, int DOWN, int NT>
+void poly_interp_launch(fa_ctx *ctx, const float *d_x, const float *d_h, float *d_y, int64_t frames, int64_t n_out, int64_t pre_remove, int64_t &m_lo, int64_t &m_hi) {
+    constexpr int R = 4, NO = R * UP, KB = (NT - 1) / UP, NIN = ((NO - 1) * DOWN) / UP + KB + 1, NV = (NIN + 3) / 4;
+    // first output: (m + pre_remove) = j UP with j DOWN >= KB (the first input of the thread exists)
+    int64_t j = (KB + DOWN - 1) / DOWN;
+    while (j * UP < pre_remove) ++j;
+    const int64_t m_begin = j * UP - pre_remove, q_begin = j * DOWN;
+    // group g reads x[q_begin - KB + g R DOWN ... + 4 NV): inside the signal; its outputs below n_out
+    int64_t groups = 0;
+    const int64_t first = q_begin - KB;
+    if (frames >= first + 4 * NV) groups = (frames - first - 4 * NV) / (R * DOWN) + 1;
+    if (m_begin < n_out) groups = std::min(groups, (n_out - m_begin) / NO); else groups = 0;
+    m_lo = m_hi = 0;
+    if (groups <= 0) return;
+    hipLaunchKernelGGL((poly_interp_kernel<UP, DOWN, NT>), dim3(static_cast<unsigned>((groups + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin,
+                       q_begin, groups);
+    m_lo = m_begin; m_hi = m_begin + groups * NO;
+}
+
 // ------------------------------------------------------------------------------ non-integer ratios (44.1 / 22.05 / 11.025 kHz -> 16 kHz)
 // poly_rows_kernel (round 4).  Output m uses the taps h[p - k up] of its PHASE p mod up, p = (m + pre_remove) down; outputs m and m + up
 // share a phase and their input windows lie exactly `down` samples apart.  So lane l of a wavefront takes the outputs m0 + phase + up l:
@@ -500,6 +556,21 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
                 edges(0, m_begin);
                 edges(m_begin + gr * kDecimR, n_out);
                 decim = true;
+            }
+        }
+        // small interpolation factors: register-tiled kernel on the outputs whose inputs all exist, poly_kernel on the two ends
+        if (!decim && !simple && u >= 2 && u <= 4 && getenv("FA_RESAMPLE_NO_INTERP") == nullptr) {
+            int64_t lo = 0, hi = 0;
+            if (u == 2 && dn == 1 && n_taps == 42) poly_interp_launch<2, 1, 42>(ctx, d_x, d_h, d_y, frames, n_out, pre_remove, lo, hi);
+            else if (u == 2 && dn == 3 && n_taps == 64) poly_interp_launch<2, 3, 64>(ctx, d_x, d_h, d_y, frames, n_out, pre_remove, lo, hi);
+            else if (u == 4 && dn == 3 && n_taps == 83) poly_interp_launch<4, 3, 83>(ctx, d_x, d_h, d_y, frames, n_out, pre_remove, lo, hi);
+            else if (u == 4 && dn == 1 && n_taps == 82) poly_interp_launch<4, 1, 82>(ctx, d_x, d_h, d_y, frames, n_out, pre_remove, lo, hi);
+            else if (u == 3 && dn == 1 && n_taps == 62) poly_interp_launch<3, 1, 62>(ctx, d_x, d_h, d_y, frames, n_out, pre_remove, lo, hi);
+            else if (u == 3 && dn == 2 && n_taps == 63) poly_interp_launch<3, 2, 63>(ctx, d_x, d_h, d_y, frames, n_out, pre_remove, lo, hi);
+            if (hi > lo) {
+                edges(0, lo);
+                edges(hi, n_out);
+                decim = true;   // served: the kernels below have nothing left to do
             }
         }
         // non-integer ratios: row-tiled kernel on the tiles whose staged inputs all exist, poly_kernel on the two ends

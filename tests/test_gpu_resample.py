@@ -40,7 +40,10 @@ def test_polyphase_extension_vs_scipy(fa, gpu_ctx, up, down, n):
                                        (1, 2, 100003), (1, 4, 64000), (1, 5, 80007), (1, 3, 62), (1, 3, 63), (1, 3, 64), (1, 3, 130), (1, 3, 1000), (1, 2, 45), (1, 5, 200),
                                        # the row-tiled kernel of non-integer ratios (round 4): several tiles, the last one partial, signals too short for a tile
                                        (160, 441, 1000003), (160, 441, 40000), (160, 441, 37000), (320, 441, 300007), (640, 441, 150000), (80, 441, 500000),
-                                       (160, 147, 200000), (16, 15, 90000), (8, 7, 50000), (147, 160, 120000)])
+                                       (160, 147, 200000), (16, 15, 90000), (8, 7, 50000), (147, 160, 120000),
+                                       # the register-tiled kernel of small interpolation factors (8 / 12 / 24 / 4 / 5.33 / 10.67 kHz -> 16 kHz)
+                                       (2, 1, 1000003), (2, 1, 100), (2, 1, 57), (2, 3, 240000), (2, 3, 130), (4, 3, 120001), (4, 1, 40000), (3, 1, 53333), (3, 2, 106667),
+                                       (4, 3, 64), (3, 2, 40)])
 def test_lds_kernel_equals_simple_kernel(fa, gpu_ctx, monkeypatch, up, down, n):
     """The LDS-staged persistent polyphase kernel and the register-tiled decimation kernel (up = 1, down 2 .. 5: interior outputs, the
     edges by the simple kernel) keep the summation order of the one-thread-per-output kernel: identical bits on several rate pairs

@@ -162,3 +162,33 @@ def test_eight_pooled_contexts_at_20000_and_release_under_pressure(fa, oracle_mo
     assert a.workspace_bytes() < ws_need(n)                # released by b's allocation
     del filler
     torch.cuda.empty_cache()                               # hand the filler back to the driver: later tests allocate through hipMalloc
+
+
+def test_reserve_takes_the_workspace_before_the_first_request(fa, oracle_mod):
+    """fa_ctx_reserve (server start-up): the linkage workspace of `recordings` problems of up to n_max x d is allocated now; the calls that follow
+    find it (no growth of what the context holds) and give the reference's dendrograms; the cap applies; bad arguments are refused."""
+    import ctypes as C
+    ctx = fa.Context(0)
+    assert ctx.workspace_bytes() == 0
+    ctx.reserve(3000, 64)
+    held = ctx.workspace_bytes()
+    assert held >= ws_need(3000)
+    x = speaker_mixture(3000, 64, 7, 0.04, 3)
+    st, z = fa.linkage(x, ctx=ctx)
+    sr, zr = oracle_mod.linkage_ref(x)
+    assert st == sr == 0 and ctx.workspace_bytes() == held
+    np.testing.assert_array_equal(z, zr)
+    ctx.reserve(3000, 64, recordings=3)                    # a batch of three shares one allocation
+    held3 = ctx.workspace_bytes()
+    assert held3 >= 3 * ws_need(3000)
+    st, zs = fa.linkage_batch([x, x[:2900], x[:2800]], ctx=ctx)
+    assert st == [0, 0, 0] and ctx.workspace_bytes() == held3
+    np.testing.assert_array_equal(zs[0], zr)
+    ctx.trim()
+    ctx.set_workspace_cap(ws_need(3000) // 2)
+    with pytest.raises(fa.FluidAudioHipError):
+        ctx.reserve(3000, 64)
+    assert fa.lib().fa_ctx_reserve(ctx.handle, 3000, 0, 1) == fa.INVALID_ARGUMENT
+    assert fa.lib().fa_ctx_reserve(ctx.handle, 3000, 64, 0) == fa.INVALID_ARGUMENT
+    assert fa.lib().fa_ctx_reserve(None, 3000, 64, 1) == fa.INVALID_ARGUMENT
+    assert fa.lib().fa_ctx_reserve(ctx.handle, 1, 64, 1) == 0
