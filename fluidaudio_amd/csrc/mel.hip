@@ -60,7 +60,6 @@ struct MelArgs {
     unsigned long long queue_base;   // ... and the first value that belongs to this launch
     unsigned long long *prof;  // FA_MEL_PROF env (diagnostics): per-phase cycle sums of one workgroup's wave 0
     int32_t prio_lo, prio_hi, prio_pw, prio_rd;  // wave priorities: FFT / filterbank..store / power / sample reads (FA_MEL_PRIO=a,b,c,d)
-    int32_t interior_fast;     // mel_kernel_v4: interior tiles request their samples without clamp arithmetic (FA_MEL_V4_INTERIOR=0: the one general path)
 };
 
 // lane l <- lane (16 - l) & 15 inside every row of 16 lanes: row_mirror (l <- 15 - l), then row_ror:1 (l <- l - 1)
@@ -1006,7 +1005,6 @@ fa_status fa_mel_execute_dev(fa_mel_plan *p, const float *d_pcm, const float *d_
     }
     MelArgs a = p->args;
     a.pcm = d_pcm; a.last = d_last; a.out = d_mel; a.lengths = d_lengths;
-    { static const int s_interior = [] { const char *e = getenv("FA_MEL_V4_INTERIOR"); return e ? atoi(e) : 1; }(); a.interior_fast = s_interior; }
     static unsigned long long *s_prof = nullptr;
     static int s_prof_calls = 0;
     static unsigned long long s_last_span[4] = {0, 0, 0, 0};

@@ -171,11 +171,17 @@ __global__ __launch_bounds__(64) void tdt_logits_kernel(const TdtArgs a, const T
         // per-lane: first maximum over k = lane, lane + 64, ... (ascending, strict '>': NaN never wins) and the online soft-max denominator
         float bv = -INFINITY, m = -INFINITY, ssum = 0.0f;
         int bi = 0x7fffffff;
-        constexpr int kBatch = 8;
-        for (int k0 = lane; k0 < g.V1; k0 += 64 * kBatch) {
-            float v[kBatch];
+        // the row is requested sixteen 256-byte pieces at a time, and the NEXT sixteen before the present ones are looked at: a row of 1 030 logits
+        // is one memory round trip, a row of 8 198 (Parakeet-TDT v3) four overlapped ones
+        constexpr int kBatch = 16;
+        float v[kBatch], vn[kBatch];
+        auto request = [&](float (&dst)[kBatch], const int k0) {
 #pragma unroll
-            for (int j = 0; j < kBatch; ++j) { const int k = k0 + 64 * j; v[j] = k < g.V1 ? at(row, k) : -INFINITY; }
+            for (int j = 0; j < kBatch; ++j) { const int k = k0 + 64 * j; dst[j] = k < g.V1 ? at(row, k) : -INFINITY; }
+        };
+        request(v, lane);
+        for (int k0 = lane; k0 < g.V1; k0 += 64 * kBatch) {
+            request(vn, k0 + 64 * kBatch);                                          // (beyond the row: no loads, -inf)
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
                 const int k = k0 + 64 * j;
@@ -184,6 +190,8 @@ __global__ __launch_bounds__(64) void tdt_logits_kernel(const TdtArgs a, const T
                 if (v[j] > m) { ssum = m == -INFINITY ? 0.0f : ssum * __expf(m - v[j]); m = v[j]; }
                 if (!(v[j] == -INFINITY && m == -INFINITY)) ssum += __expf(v[j] - m);      // NaN logits poison the sum (probability 0 after the clamp), like the two-pass form
             }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) v[j] = vn[j];
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
