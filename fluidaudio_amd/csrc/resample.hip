@@ -19,9 +19,14 @@
 #include <vector>
 
 #include "fa_common.h"
+#include "resample_geom.h"
 
 namespace {
 
+using fa::PolyRowsGeom;
+using fa::kRowsThreads;
+using fa::kRowsWaves;
+using fa::kRowsOffLane;
 constexpr int kThreads = 256;
 
 __global__ void mixdown_kernel(const float *__restrict__ planar, float *__restrict__ mono, int channels, int64_t frames) {
@@ -178,15 +183,9 @@ __global__ __launch_bounds__(kThreads) void poly_interp_kernel(const float *__re
 template <int UP, int DOWN, int NT>
 void poly_interp_launch(fa_ctx *ctx, const float *d_x, const float *d_h, float *d_y, int64_t frames, int64_t n_out, int64_t pre_remove, int64_t &m_lo, int64_t &m_hi) {
     constexpr int R = 4, NO = R * UP, KB = (NT - 1) / UP, NIN = ((NO - 1) * DOWN) / UP + KB + 1, NV = (NIN + 3) / 4;
-    // first output: (m + pre_remove) = j UP with j DOWN >= KB (the first input of the thread exists)
-    int64_t j = (KB + DOWN - 1) / DOWN;
-    while (j * UP < pre_remove) ++j;
-    const int64_t m_begin = j * UP - pre_remove, q_begin = j * DOWN;
-    // group g reads x[q_begin - KB + g R DOWN ... + 4 NV): inside the signal; its outputs below n_out
-    int64_t groups = 0;
-    const int64_t first = q_begin - KB;
-    if (frames >= first + 4 * NV) groups = (frames - first - 4 * NV) / (R * DOWN) + 1;
-    if (m_begin < n_out) groups = std::min(groups, (n_out - m_begin) / NO); else groups = 0;
+    int64_t m_begin = 0, q_begin = 0, groups = 0;
+    fa::interp_geometry(UP, DOWN, NT, R, frames, n_out, pre_remove, m_begin, q_begin, groups);   // resample_geom.h
+    (void)KB; (void)NIN; (void)NV; (void)NO;
     m_lo = m_hi = 0;
     if (groups <= 0) return;
     hipLaunchKernelGGL((poly_interp_kernel<UP, DOWN, NT>), dim3(static_cast<unsigned>((groups + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin,
@@ -213,16 +212,7 @@ void poly_interp_launch(fa_ctx *ctx, const float *d_x, const float *d_h, float *
 // Summation order per output: ascending input index over the k range of poly_kernel, zero taps in front and behind -> identical bits on finite input.
 // The tile geometry (first output, first input, per-phase window offsets and counts) is computed once per rate pair on the host
 // (PolyRows below); outputs whose windows touch the ends of the signal go to poly_kernel.
-struct PolyRowsGeom {
-    int64_t m_begin, k_begin;       // first output (a multiple of 4) / first staged input of tile 0
-    int32_t up, down;
-    int32_t groups, ppg;            // phase groups per tile, phases per group (a multiple of 4)
-    int32_t sld;                    // LDS row stride in floats (4 x odd)
-    int32_t smax;                   // last staged offset + 1 within a row over all phases (for the tile-count bound)
-};
-constexpr int kRowsThreads = 512, kRowsWaves = kRowsThreads / 64;
-constexpr int kRowsOffLane = 62;   // lane of a phase's table row that carries its (aligned) window offset; taps: lanes 0 .. 61
-
+// (PolyRowsGeom, kRowsThreads / kRowsWaves / kRowsOffLane and the host-side geometry: resample_geom.h — shared with the CPU emulation of the tests)
 // one phase: `trow` = its table row (one value per lane), rowp = this lane's LDS row (shifted by the group's first staged offset).
 // The table row holds the phase's taps SHIFTED by the misalignment of its window (zeros in front and behind), so the window is read from the
 // 16-byte boundary below it and every multiply-add has compile-time register indices — no per-alignment code paths.  The padding taps are
@@ -309,66 +299,10 @@ struct PolyRows {
 };
 void poly_rows_free(void *p) { delete static_cast<PolyRows *>(p); }
 
-// Geometry + tables; false when the pair does not suit the kernel (then poly_lds_kernel serves it).
+// Geometry + tables (resample_geom.h); false when the pair does not suit the kernel (then poly_lds_kernel serves it).
 bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt) {
-    const int64_t h_len = static_cast<int64_t>(h.size());
-    if (up < 8 || up > 4096 || down > 8192) return false;               // few phases: the register-tiled kernels; huge ones: tables too large
-    const int q1 = static_cast<int>((h_len + up - 1) / up);             // a window holds floor(h_len / up) or that + 1 taps
-    if (q1 + 3 > kRowsOffLane) return false;                            // shifted taps of a phase + its offset share one 64-lane table row
-    int nv = (q1 + 3 + 3) / 4;                                          // 4 nv >= misalignment (<= 3) + taps
-    {   // instantiated sizes (poly_rows_launch); a larger one only reads a little further into the row
-        static const int sizes[] = {4, 6, 8, 10, 12, 14, 16};
-        int pick = 0;
-        for (int v : sizes) if (v >= nv) { pick = v; break; }
-        if (!pick) return false;
-        nv = pick;
-    }
-    // first output whose window lies inside the signal: p - (h_len - 1) >= 0; rounded up to a multiple of 4 (16-byte output pieces)
-    int64_t m_begin = (h_len - 1 + down - 1) / down - pre_remove;
-    if (m_begin < 0) m_begin = 0;
-    m_begin = (m_begin + 3) & ~static_cast<int64_t>(3);
-    const int64_t p0 = (m_begin + pre_remove) * down;
-    const int64_t k_begin = (p0 - (h_len - 1) + up - 1) / up;           // k_lo of the first output
-    std::vector<int> off(up), cnt(up);
-    tt.assign(static_cast<size_t>(up) * 64, 0.0f);
-    int smax = 0;
-    for (int ph = 0; ph < up; ++ph) {
-        const int64_t p = p0 + static_cast<int64_t>(ph) * down;
-        const int64_t k_hi = p / up, k_lo = (p - (h_len - 1) + up - 1) / up;   // p - (h_len - 1) >= 0 here
-        cnt[ph] = static_cast<int>(k_hi - k_lo + 1);
-        off[ph] = static_cast<int>(k_lo - k_begin);
-        const int a = off[ph] & 3, off4 = off[ph] - a;
-        if (cnt[ph] < 1 || a + cnt[ph] > std::min(4 * nv, kRowsOffLane)) return false;
-        float *rowp = tt.data() + static_cast<size_t>(ph) * 64;
-        for (int j = 0; j < cnt[ph]; ++j) rowp[a + j] = h[static_cast<size_t>(p - (k_lo + j) * up)];
-        memcpy(rowp + kRowsOffLane, &off4, sizeof(int));
-        smax = std::max(smax, off4 + 4 * nv);
-    }
-    // phase groups (a multiple of 4 phases each): the rows of a group within ~72 KB of LDS (two workgroups per CU); rows are `sld` floats apart,
-    // sld = 4 x odd >= the longest staged span of a group
-    int groups = 1, ppg = up, sld = 0;
-    for (;; ++groups) {
-        ppg = ((up + groups - 1) / groups + 3) & ~3;
-        int span = 0;
-        for (int a0 = 0; a0 < up; a0 += ppg) {
-            const int a1 = std::min(up, a0 + ppg);
-            span = std::max(span, (off[a1 - 1] & ~3) + 4 * nv - (off[a0] & ~3));
-        }
-        sld = (span + 3) / 4;
-        if (sld % 2 == 0) ++sld;
-        sld *= 4;
-        if (static_cast<size_t>(sld) * 64 * sizeof(float) <= 74 * 1024 || ppg <= 4 * kRowsWaves) break;
-    }
-    groups = (up + ppg - 1) / ppg;
-    if (static_cast<size_t>(sld) * 64 * sizeof(float) > 150 * 1024 || sld > 64 * 10) return false;
-    gtab.assign(2 * static_cast<size_t>(groups), 0);
-    for (int gq = 0; gq < groups; ++gq) {
-        const int a0 = gq * ppg, a1 = std::min(up, a0 + ppg);
-        gtab[2 * gq] = off[a0] & ~3;
-        gtab[2 * gq + 1] = (off[a1 - 1] & ~3) + 4 * nv - (off[a0] & ~3);
-    }
-    R.g.m_begin = m_begin; R.g.k_begin = k_begin; R.g.up = up; R.g.down = down; R.g.groups = groups; R.g.ppg = ppg; R.g.sld = sld; R.g.smax = smax;
-    R.nv = nv; R.lds = static_cast<size_t>(sld) * 64 * sizeof(float); R.up = up; R.down = down;
+    if (!fa::rows_geometry(R.g, R.nv, h, up, down, pre_remove, gtab, tt)) return false;
+    R.lds = static_cast<size_t>(R.g.sld) * 64 * sizeof(float); R.up = up; R.down = down;
     return true;
 }
 
@@ -578,13 +512,8 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
         if (!decim && !simple && ctx->poly_rows && getenv("FA_RESAMPLE_NO_ROWS") == nullptr) {
             const PolyRows &R = *static_cast<const PolyRows *>(ctx->poly_rows);
             const PolyRowsGeom &G = R.g;
-            // tile t stages x[k_begin + 64 down t ... + 63 down + smax): all of it inside the signal
-            const int64_t last_need = G.k_begin + 63LL * G.down + G.smax;     // exclusive end of tile 0's staged range
-            int64_t tiles = frames >= last_need ? (frames - last_need) / (64LL * G.down) + 1 : 0;
+            int64_t tiles = fa::rows_tiles(G, frames, n_out);                  // tiles whose staged inputs all exist (resample_geom.h)
             const int64_t per_tile = 64LL * G.up;
-            if (G.m_begin < n_out) tiles = std::min(tiles, (n_out - G.m_begin + per_tile - 1) / per_tile); else tiles = 0;
-            // every output of the tiles must have its whole window (k_hi <= frames - 1): true when the staged range is inside the signal and
-            // the window of the tile's last output ends inside its row — guaranteed by smax covering off + 4 nv of every phase
             if (tiles > 0 && tiles * G.groups < (1LL << 31)) {
                 const int64_t m_stop = std::min(n_out, G.m_begin + tiles * per_tile);
                 switch (R.nv) {

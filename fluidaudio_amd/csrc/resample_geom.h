@@ -1,0 +1,109 @@
+// resample_geom.h — host-side geometry of the polyphase kernels of resample.hip, in plain C++ so that the CPU tests can run it
+// (tests/cpu/resample_geom_emul.cpp emulates the kernels' indexing with it and checks every staged / read / written index).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace fa {
+
+struct PolyRowsGeom {
+    int64_t m_begin, k_begin;       // first output (a multiple of 4) / first staged input of tile 0
+    int32_t up, down;
+    int32_t groups, ppg;            // phase groups per tile, phases per group (a multiple of 4)
+    int32_t sld;                    // LDS row stride in floats (4 x odd)
+    int32_t smax;                   // last staged offset + 1 within a row over all phases (for the tile-count bound)
+};
+constexpr int kRowsThreads = 512, kRowsWaves = kRowsThreads / 64;
+constexpr int kRowsOffLane = 62;   // lane of a phase's table row that carries its (aligned) window offset; taps: lanes 0 .. 61
+
+// poly_rows_kernel: tables of one rate pair.  h = the FIR of fa_resample_poly_taps (leading zero taps included), gtab = {first staged offset,
+// staged span} per phase group, tt = 64 floats per phase (taps shifted by the window's misalignment, zeros around them; lane 62: the aligned
+// window offset).  nv = 16-byte reads per window.  false: the pair does not suit the kernel.
+inline bool rows_geometry(PolyRowsGeom &g, int &nv_out, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt) {
+    const int64_t h_len = static_cast<int64_t>(h.size());
+    if (up < 8 || up > 4096 || down > 8192) return false;               // few phases: the register-tiled kernels; huge ones: tables too large
+    const int q1 = static_cast<int>((h_len + up - 1) / up);             // a window holds floor(h_len / up) or that + 1 taps
+    if (q1 + 3 > kRowsOffLane) return false;                            // shifted taps of a phase + its offset share one 64-lane table row
+    int nv = (q1 + 3 + 3) / 4;                                          // 4 nv >= misalignment (<= 3) + taps
+    {   // instantiated sizes (poly_rows_launch); a larger one only reads a little further into the row
+        static const int sizes[] = {4, 6, 8, 10, 12, 14, 16};
+        int pick = 0;
+        for (int v : sizes) if (v >= nv) { pick = v; break; }
+        if (!pick) return false;
+        nv = pick;
+    }
+    // first output whose window lies inside the signal: p - (h_len - 1) >= 0; rounded up to a multiple of 4 (16-byte output pieces)
+    int64_t m_begin = (h_len - 1 + down - 1) / down - pre_remove;
+    if (m_begin < 0) m_begin = 0;
+    m_begin = (m_begin + 3) & ~static_cast<int64_t>(3);
+    const int64_t p0 = (m_begin + pre_remove) * down;
+    const int64_t k_begin = (p0 - (h_len - 1) + up - 1) / up;           // k_lo of the first output
+    std::vector<int> off(up), cnt(up);
+    tt.assign(static_cast<size_t>(up) * 64, 0.0f);
+    int smax = 0;
+    for (int ph = 0; ph < up; ++ph) {
+        const int64_t p = p0 + static_cast<int64_t>(ph) * down;
+        const int64_t k_hi = p / up, k_lo = (p - (h_len - 1) + up - 1) / up;   // p - (h_len - 1) >= 0 here
+        cnt[ph] = static_cast<int>(k_hi - k_lo + 1);
+        off[ph] = static_cast<int>(k_lo - k_begin);
+        const int a = off[ph] & 3, off4 = off[ph] - a;
+        if (cnt[ph] < 1 || a + cnt[ph] > std::min(4 * nv, kRowsOffLane)) return false;
+        float *rowp = tt.data() + static_cast<size_t>(ph) * 64;
+        for (int j = 0; j < cnt[ph]; ++j) rowp[a + j] = h[static_cast<size_t>(p - (k_lo + j) * up)];
+        memcpy(rowp + kRowsOffLane, &off4, sizeof(int));
+        smax = std::max(smax, off4 + 4 * nv);
+    }
+    // phase groups (a multiple of 4 phases each): the rows of a group within ~72 KB of LDS (two workgroups per CU); rows are `sld` floats apart,
+    // sld = 4 x odd >= the longest staged span of a group
+    int groups = 1, ppg = up, sld = 0;
+    for (;; ++groups) {
+        ppg = ((up + groups - 1) / groups + 3) & ~3;
+        int span = 0;
+        for (int a0 = 0; a0 < up; a0 += ppg) {
+            const int a1 = std::min(up, a0 + ppg);
+            span = std::max(span, (off[a1 - 1] & ~3) + 4 * nv - (off[a0] & ~3));
+        }
+        sld = (span + 3) / 4;
+        if (sld % 2 == 0) ++sld;
+        sld *= 4;
+        if (static_cast<size_t>(sld) * 64 * sizeof(float) <= 74 * 1024 || ppg <= 4 * kRowsWaves) break;
+    }
+    groups = (up + ppg - 1) / ppg;
+    if (static_cast<size_t>(sld) * 64 * sizeof(float) > 150 * 1024 || sld > 64 * 10) return false;
+    gtab.assign(2 * static_cast<size_t>(groups), 0);
+    for (int gq = 0; gq < groups; ++gq) {
+        const int a0 = gq * ppg, a1 = std::min(up, a0 + ppg);
+        gtab[2 * gq] = off[a0] & ~3;
+        gtab[2 * gq + 1] = (off[a1 - 1] & ~3) + 4 * nv - (off[a0] & ~3);
+    }
+    g.m_begin = m_begin; g.k_begin = k_begin; g.up = up; g.down = down; g.groups = groups; g.ppg = ppg; g.sld = sld; g.smax = smax;
+    nv_out = nv;
+    return true;
+}
+
+// tiles of 64 up outputs whose staged inputs all exist: tile t stages x[k_begin + 64 down t ... + 63 down + smax)
+inline int64_t rows_tiles(const PolyRowsGeom &G, int64_t frames, int64_t n_out) {
+    const int64_t last_need = G.k_begin + 63LL * G.down + G.smax;      // exclusive end of tile 0's staged range
+    int64_t tiles = frames >= last_need ? (frames - last_need) / (64LL * G.down) + 1 : 0;
+    const int64_t per_tile = 64LL * G.up;
+    if (G.m_begin < n_out) tiles = std::min(tiles, (n_out - G.m_begin + per_tile - 1) / per_tile); else tiles = 0;
+    return tiles;
+}
+
+// poly_interp_kernel<UP, DOWN, NT> with R outputs-per-phase-cycle groups per thread: first output, first phase cycle, number of threads' groups
+inline void interp_geometry(int up, int down, int nt, int r, int64_t frames, int64_t n_out, int64_t pre_remove, int64_t &m_begin, int64_t &q_begin, int64_t &groups) {
+    const int no = r * up, kb = (nt - 1) / up, nin = ((no - 1) * down) / up + kb + 1, nv = (nin + 3) / 4;
+    // first output: (m + pre_remove) = j UP with j DOWN >= KB (the first input of the thread exists)
+    int64_t j = (kb + down - 1) / down;
+    while (j * up < pre_remove) ++j;
+    m_begin = j * up - pre_remove; q_begin = j * down;
+    // group g reads x[q_begin - KB + g R DOWN ... + 4 NV): inside the signal; its outputs below n_out
+    groups = 0;
+    const int64_t first = q_begin - kb;
+    if (frames >= first + 4 * nv) groups = (frames - first - 4 * nv) / (static_cast<int64_t>(r) * down) + 1;
+    if (m_begin < n_out) groups = std::min(groups, (n_out - m_begin) / no); else groups = 0;
+}
+
+}  // namespace fa

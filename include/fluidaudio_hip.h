@@ -52,9 +52,11 @@ void fa_host_free(void *p);
  * between calls, because the first call at a new size pays 0.4 - 2.5 s of hipMalloc.
  *   fa_ctx_set_workspace_limit : a cached linkage workspace larger than `bytes` is released when the call that used it returns
  *                                (0 = never keep one).  Default: keep (or the value of FLUIDAUDIO_HIP_WORKSPACE_LIMIT).
- *   fa_ctx_set_workspace_cap   : a linkage call that would need more than `bytes` of workspace fails with FA_ALLOCATION_FAILURE
- *                                instead of taking them (the reference's status for std::bad_alloc, FastClusterWrapper.cpp:236-238;
- *                                AHCClustering degrades to singletons).  Default: no cap — hipMalloc decides.
+ *   fa_ctx_set_workspace_cap   : a linkage call never takes more than `bytes` of workspace.  A problem whose N x N matrix exceeds the cap
+ *                                (or HBM, or 196 608 points) runs in the matrix-free mode — O(N d) memory like the reference, the same
+ *                                dendrogram, ~5x slower per merge; when even that exceeds the cap the call fails with FA_ALLOCATION_FAILURE
+ *                                (the reference's status for std::bad_alloc, FastClusterWrapper.cpp:236-238; AHCClustering degrades to
+ *                                singletons).  Default: no cap — hipMalloc decides.
  *   fa_ctx_trim                : releases everything cached now.
  *   fa_ctx_workspace_bytes     : bytes cached right now.
  *   fa_ctx_reserve             : takes the workspace of `recordings` linkage problems of up to n_max points x d dimensions NOW (one
