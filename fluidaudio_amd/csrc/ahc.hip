@@ -2406,11 +2406,74 @@ fa_status ahc_batch_in_flight(fa_ctx *ctx, int count, const double *const *d_dat
 }
 }  // namespace
 
-fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
-                                   fa_ahc_stats *stats, fa_status *statuses) {
+namespace {
+// Many LARGE recordings: G uniform batches side by side (round 4).  A uniform batch costs a fixed ~5.3 us per round (kernel boundary + two dependent
+// memory round trips: latency) plus ~0.75 us of instruction issue per problem; two batches of K / 2 problems on two streams fill each other's
+// latency: 8 recordings of 8 h advance in ~7.5 us per round of both instead of 11 us as one batch.  Group 0 runs on the caller's context, the
+// others on its helper contexts (own stream, own workspace, a host thread each — the round-3 in-flight machinery, but with 2 streams instead of
+// one per recording, so that two free hardware queues suffice).  A group that cannot get its workspace (or its thread) is run afterwards on the
+// caller's context.  FA_AHC_UNI_GROUPS = 1 .. 4 overrides the choice (1: one batch).
+fa_status run_device_batch_impl(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode, fa_ahc_stats *stats,
+                                fa_status *statuses, bool allow_groups);
+
+int uniform_groups(int count, const size_t *n) {
+    if (const char *e = getenv("FA_AHC_UNI_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= 4) return std::min(v, count / 2 > 0 ? count / 2 : 1); }
+    size_t lo = SIZE_MAX;
+    for (int k = 0; k < count; ++k) lo = std::min(lo, n[k]);
+    return count >= 6 && lo >= kInFlightMinN ? 2 : 1;
+}
+
+fa_status ahc_batch_uniform_groups(fa_ctx *ctx, int groups, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
+                                   fa_ahc_stats *stats, fa_status *sts) {
+    for (int g = 1; g < groups; ++g) {
+        fa_ctx *&h = ctx->helpers[g - 1];
+        if (!h) {
+            if (fa_ctx_create(ctx->device, nullptr, &h) != FA_SUCCESS) { h = nullptr; groups = g; break; }
+            h->ws_limit = ctx->ws_limit;
+            h->ws_cap = ctx->ws_cap;
+        }
+    }
+    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the inputs were produced on the caller's stream
+    std::vector<int> first(static_cast<size_t>(groups) + 1, 0);
+    for (int g = 0; g <= groups; ++g) first[g] = static_cast<int>(static_cast<long long>(count) * g / groups);
+    std::vector<char> done(static_cast<size_t>(groups), 0);
+    auto run_group = [&](fa_ctx *c, const int g) {
+        const int a = first[g], m = first[g + 1] - first[g];
+        bool completed = false;
+        fa::DeviceGuard guard(c->device);
+        (void)ahc_batch_uniform(c, m, d_data + a, n + a, d, d_Z + a, mode, stats ? stats + a : nullptr, sts + a, &completed);
+        done[static_cast<size_t>(g)] = completed ? 1 : 0;
+    };
+    std::vector<std::thread> threads;
+    for (int g = 1; g < groups; ++g) {
+        try { threads.emplace_back(run_group, ctx->helpers[g - 1], g); }
+        catch (...) { done[static_cast<size_t>(g)] = 0; }   // no thread to be had: that group runs on the caller's context below
+    }
+    run_group(ctx, 0);
+    for (auto &t : threads) t.join();
+    fa_status worst = FA_SUCCESS;
+    for (int g = 0; g < groups; ++g) {
+        const int a = first[g], m = first[g + 1] - first[g];
+        if (!done[static_cast<size_t>(g)]) {               // workspace / thread trouble: alone on the caller's context, through the general dispatcher (it splits further)
+            if (g > 0 && ctx->helpers[g - 1]) (void)fa_ctx_trim(ctx->helpers[g - 1]);
+            (void)run_device_batch_impl(ctx, m, d_data + a, n + a, d, d_Z + a, mode, stats ? stats + a : nullptr, sts + a, false);
+        } else if (g > 0 && ctx->last_error.empty()) {
+            for (int k = a; k < a + m; ++k) if (sts[k] != FA_SUCCESS) { ctx->last_error = ctx->helpers[g - 1]->last_error; break; }
+        }
+        for (int k = a; k < a + m; ++k) if (sts[k] != FA_SUCCESS && worst == FA_SUCCESS) worst = sts[k];
+    }
+    return worst;
+}
+
+fa_status run_device_batch_impl(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode, fa_ahc_stats *stats,
+                                fa_status *statuses, const bool allow_groups) {
     if (count <= 0) return FA_SUCCESS;
     std::vector<fa_status> local(static_cast<size_t>(count), FA_SUCCESS);
     fa_status *sts = statuses ? statuses : local.data();
+    if (allow_groups && uniform_eligible(count, n, mode)) {
+        const int groups = uniform_groups(count, n);
+        if (groups > 1) return ahc_batch_uniform_groups(ctx, groups, count, d_data, n, d, d_Z, mode, stats, sts);
+    }
     {
         // chains in flight on helper contexts (round 3) only on request since round 4: the uniform-layout batch advances the same problems by
         // ONE launch per round, on one stream — its rate does not depend on which hardware queues the process's streams landed on
@@ -2425,8 +2488,8 @@ fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *
     const fa_status fail = st != FA_SUCCESS ? st : FA_RUNTIME_ERROR;
     if (fail == FA_ALLOCATION_FAILURE && count > 1) {
         const int half = count / 2;
-        const fa_status a = fa::ahc_run_device_batch(ctx, half, d_data, n, d, d_Z, mode, stats, sts);
-        const fa_status b = fa::ahc_run_device_batch(ctx, count - half, d_data + half, n + half, d, d_Z + half, mode, stats ? stats + half : nullptr, sts + half);
+        const fa_status a = run_device_batch_impl(ctx, half, d_data, n, d, d_Z, mode, stats, sts, allow_groups);
+        const fa_status b = run_device_batch_impl(ctx, count - half, d_data + half, n + half, d, d_Z + half, mode, stats ? stats + half : nullptr, sts + half, allow_groups);
         return a != FA_SUCCESS ? a : b;
     }
     if (fail == FA_ALLOCATION_FAILURE && count == 1 && n[0] >= 2)   // not even one matrix fits: the single-problem entry knows the matrix-free route
@@ -2436,6 +2499,12 @@ fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *
         if (stats) stats[k] = fa_ahc_stats{};
     }
     return fail;
+}
+}  // namespace
+
+fa_status fa::ahc_run_device_batch(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
+                                   fa_ahc_stats *stats, fa_status *statuses) {
+    return run_device_batch_impl(ctx, count, d_data, n, d, d_Z, mode, stats, statuses, true);
 }
 
 namespace {

@@ -5,6 +5,13 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r4 gpurun_out/summary
 export TMPDIR=/tmp
 ( time timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider ) > gpurun_out/r4/pytest_call7.log 2>&1; echo "pytest rc=$?"
+( time timeout 900 python scripts/uni_probe.py ) > gpurun_out/r4/uni_probe.log 2>&1; echo "uni probe rc=$?"; grep "^{" gpurun_out/r4/uni_probe.log | python -c "
+import sys, json
+for l in sys.stdin:
+    r = json.loads(l)
+    print(r['n'], r['K'], r['env'], 'us/round %.2f' % r['us_per_round'], 'wall %.3f' % r['wall_s'], 'h/s %.1f' % r.get('audio_hours_per_s_linkage_only', 0), r['equal_single'])
+"; tail -3 gpurun_out/r4/uni_probe.log | cut -c1-300
+bash scripts/gpu_pmc_kernel.sh ahc_round ahc_round_t "ahc.hip" python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --skip-mel --skip-ahc --skip-ctc --skip-cpu --skip-e2e --skip-beam --skip-resample
 tail -12 gpurun_out/r4/pytest_call7.log | cut -c1-700
 name=r4k
 mkdir -p gpurun_out/pmc_$name

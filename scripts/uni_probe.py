@@ -24,10 +24,17 @@ def unit_rows(hours, seed):
     return x / np.sqrt((x * x).sum(axis=1, keepdims=True))
 
 
+_last_shape = [None]
+
+
 def run(probs, env):
-    for k in ("FA_AHC_UNI_WAVES", "FA_AHC_NO_UNIFORM", "FA_AHC_IN_FLIGHT"):
+    for k in ("FA_AHC_UNI_WAVES", "FA_AHC_UNI_GROUPS", "FA_AHC_NO_UNIFORM", "FA_AHC_IN_FLIGHT"):
         os.environ.pop(k, None)
     os.environ.update(env)
+    shape = (len(probs), env.get("FA_AHC_UNI_GROUPS"), env.get("FA_AHC_IN_FLIGHT"))
+    if shape != _last_shape[0]:
+        ctx.trim()                      # the workspaces of another split must not add up to more than HBM holds
+        _last_shape[0] = shape
     fa.linkage_batch(probs, ctx=ctx)
     t0 = time.perf_counter()
     st, zs, stats = fa.linkage_batch(probs, ctx=ctx, return_stats=True)
@@ -42,13 +49,16 @@ for k in range(12):
     st, z = fa.linkage(big[k], ctx=ctx)
     assert st == 0
     ref[k] = z
-for K in (1, 2, 4, 6, 7, 8, 12):
-    for env in ({}, {"FA_AHC_UNI_WAVES": "6"}, {"FA_AHC_UNI_WAVES": "8"}, {"FA_AHC_NO_UNIFORM": "1"}, {"FA_AHC_IN_FLIGHT": "1"}):
+for K in (1, 2, 4, 6, 8, 12):
+    for env in ({"FA_AHC_UNI_GROUPS": "1"}, {"FA_AHC_UNI_GROUPS": "2"}, {"FA_AHC_UNI_GROUPS": "3"}, {"FA_AHC_UNI_GROUPS": "4"}, {}, {"FA_AHC_NO_UNIFORM": "1"}, {"FA_AHC_IN_FLIGHT": "1"}):
         if env.get("FA_AHC_IN_FLIGHT") and K > 4:
             continue
         if env.get("FA_AHC_NO_UNIFORM") and K not in (2, 4, 8):
             continue
         if K == 1 and env:
+            continue
+        g = int(env.get("FA_AHC_UNI_GROUPS", "1"))
+        if g > 1 and K < 2 * g:
             continue
         st, zs, stats, wall = run(big[:K], env)
         same = all(s == 0 and np.array_equal(z, ref[i]) for i, (s, z) in enumerate(zip(st, zs)))

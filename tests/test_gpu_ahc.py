@@ -380,3 +380,33 @@ def test_uniform_batch_equals_reference_build(fa, gpu_ctx, oracle_mod, monkeypat
     np.testing.assert_array_equal(zs[0], zs[2])
     st1, z1 = fa.linkage(probs[2], ctx=gpu_ctx)
     np.testing.assert_array_equal(zs[1], z1)
+
+
+def test_uniform_batches_side_by_side_equal_single_calls(fa, gpu_ctx, monkeypatch):
+    """Six or more large recordings: two uniform batches on two streams (the caller's context and a helper context) fill each other's latency
+    (ahc_batch_uniform_groups; FA_AHC_UNI_GROUPS picks 1 .. 4 groups).  Every dendrogram equals the single call at every group count, the statistics
+    are those of the problem's own group, and a cap that leaves no room for the groups' workspaces still ends in the right dendrograms."""
+    import torch
+    rng = np.random.default_rng(78)
+    probs = [rng.standard_normal((n, 16)) for n in (17000, 16500, 18000, 16400, 17500, 16900)]
+    singles = [fa.linkage(x, ctx=gpu_ctx)[1] for x in probs]
+    gpu_ctx.trim()
+    for groups in (None, "1", "2", "3"):
+        if groups is None:
+            monkeypatch.delenv("FA_AHC_UNI_GROUPS", raising=False)
+        else:
+            monkeypatch.setenv("FA_AHC_UNI_GROUPS", groups)
+        st, zs, stats = fa.linkage_batch(probs, ctx=gpu_ctx, return_stats=True)
+        assert list(st) == [0] * 6, (groups, st)
+        for z, zr, s in zip(zs, singles, stats):
+            np.testing.assert_array_equal(z, zr)
+            assert s["merges"] == len(zr) and s["reference_order"] == 0
+    monkeypatch.setenv("FA_AHC_UNI_GROUPS", "2")
+    ctx = fa.Context(0)
+    ctx.set_workspace_cap(int(2.5 * 18176 * 18176 * 8))    # a group of three does not fit: split further, still the reference's rows
+    st, zs = fa.linkage_batch(probs, ctx=ctx)
+    assert list(st) == [0] * 6
+    for z, zr in zip(zs, singles):
+        np.testing.assert_array_equal(z, zr)
+    gpu_ctx.trim()
+    torch.cuda.empty_cache()
