@@ -19,7 +19,8 @@ restatements); `e2e_equals_reference_digest` says the timed calls reproduced the
   mel_single_10s— configs[0] shape: one 10 s utterance through the host-pointer entry, p50 / p99 latency
   ctc           — configs[3]: greedy CTC on 10 000 x [1500, 1024] matrices (sharded over the ranks at N > 1), ids verified in-bench
   ahc_50k       — configs[2]: the metric's second half, dendrogram SHA-256 against the reference build's committed digest
-  ahc_batch, e2e_16x1h, beam_search — serving-shaped legs (rank 0, N = 1)
+  ahc_batch, e2e_16x1h, e2e_8h_batch, e2e_8h_hard, beam_search — serving-shaped legs (rank 0, N = 1)
+  resample, tdt, ctc_fp16 — the other north-star kernels, each with its own roofline and an in-bench check
 """
 import argparse
 import hashlib
@@ -30,10 +31,11 @@ import time
 
 import numpy as np
 
-# Hardware queues of the HIP runtime for this process (read when the runtime starts): the in-flight leg runs four independent chains of
-# dependent launches; with the default of four queues and the streams the other legs created before it, two chains shared a queue
-# (58 instead of 87 audio-hours/s).  A deployment that keeps several recordings in flight wants the same setting.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Hardware queues of the HIP runtime for this process (read when the runtime starts).  Only the optional round-3 leg (--in-flight: four independent chains
+# of dependent launches) wants more than the default four: with the streams the other legs created before it, two chains shared a queue (58 instead of
+# 87 audio-hours/s).  The serving path of round 4 (uniform batches, at most two streams) runs on the runtime's defaults: nothing is set for it.
+if "--in-flight" in sys.argv:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -999,6 +1001,7 @@ def main():
     ap.add_argument("--skip-e2e", action="store_true", help="skip the 16 x 1 h leg (the headline itself cannot be skipped)")
     ap.add_argument("--skip-beam", action="store_true")
     ap.add_argument("--skip-resample", action="store_true")
+    ap.add_argument("--in-flight", action="store_true", help="also run round 3's four-chains-in-flight leg (queue-dependent; superseded by e2e_8h_batch)")
     ap.add_argument("--vbx-sharded", action="store_true", help="run the sharded-VBx leg at N = 1 too (it always runs at N > 1)")
     ap.add_argument("--only-mel", action="store_true", help="profiling helper: the configs[1] mel leg alone, printed as a reduced line")
     ap.add_argument("--ctc-matrices", type=int, default=10000)
@@ -1171,13 +1174,15 @@ def main():
             line["e2e_8h_hard"] = {"error": repr(e)}
         ctx.trim()
         torch.cuda.empty_cache()
-        try:
-            line["e2e_8h_x4_in_flight"] = e2e_in_flight_leg(fa, torch)
-            line["config"]["recordings_in_flight"] = ("1 (value = one 8 h recording per step: the latency view); with 4 such recordings in flight on the same GPU: "
-                                                      f"{line['e2e_8h_x4_in_flight']['audio_hours_per_s']:.1f} audio-hours/s (e2e_8h_x4_in_flight, every result digest-checked)")
-        except Exception as e:  # noqa: BLE001
-            line["e2e_8h_x4_in_flight"] = {"error": repr(e)}
-        torch.cuda.empty_cache()
+        if args.in_flight:
+            # round 3's throughput form (four host threads, a context and a chain each).  Its rate depends on which hardware queues the process's
+            # streams landed on (89 audio-hours/s in a fresh leg order, 32 after the batch leg above has created a helper stream: profiles/
+            # r04_bench_v5.json / _v6.json), which is why the uniform batches (e2e_8h_batch) replaced it as the serving path; kept on request.
+            try:
+                line["e2e_8h_x4_in_flight"] = e2e_in_flight_leg(fa, torch)
+            except Exception as e:  # noqa: BLE001
+                line["e2e_8h_x4_in_flight"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
     if solo and not args.skip_beam:
         torch.cuda.empty_cache()
         try:

@@ -234,12 +234,18 @@ __device__ __forceinline__ float rows_phase(const float trow, const float *rowp)
 
 template <int NV, int IT>   // NV: 16-byte reads per window (4 (NV - 1) taps at most); IT: 64-float pieces per staged row (sld <= 64 IT)
 __global__ __launch_bounds__(kRowsThreads) void poly_rows_kernel(const float *__restrict__ x, const float *__restrict__ tt, const int2 *__restrict__ gtab,
-                                                                float *__restrict__ y, const PolyRowsGeom g, const int64_t m_end, const int vec_ok) {
+                                                                float *__restrict__ y, const PolyRowsGeom g, const int64_t tiles, const int64_t m_end, const int vec_ok) {
     extern __shared__ float xs[];
     typedef const int __attribute__((address_space(4))) *c_i32;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t tile = blockIdx.x / g.groups;
-    const int grp = static_cast<int>(blockIdx.x - tile * g.groups);
+    // Workgroups are dealt to the 8 XCDs round-robin by their index, and each XCD has its own L2.  The phase groups of ONE tile stage overlapping
+    // input spans (a window reaches ~60 samples into the neighbouring group's span: 27 % of the input at 44.1 -> 16 kHz), so they are given indices
+    // that differ by a multiple of 8 — the same XCD, dispatched back to back — and the second group finds the overlap in that L2.  (First
+    // version: consecutive indices = different XCDs: 896 MB fetched for 635 MB of input, profiles/r04_resample_44100_pmc.json of call 7.)
+    const int64_t q = blockIdx.x >> 3;
+    const int grp = static_cast<int>(q % g.groups);
+    const int64_t tile = (q / g.groups) * 8 + (blockIdx.x & 7);
+    if (tile >= tiles) return;
     const int ph0 = grp * g.ppg, ph1 = ph0 + g.ppg < g.up ? ph0 + g.ppg : g.up;
     const int nchunks = (ph1 - ph0 + 3) >> 2;
     auto row = [&](const int ph) -> float { return ph < ph1 ? tt[static_cast<size_t>(ph) * 64 + lane] : 0.0f; };   // ph is wave-uniform
@@ -312,7 +318,8 @@ void poly_rows_launch_it(fa_ctx *ctx, const PolyRows &R, const float *d_x, float
     const float *tt = reinterpret_cast<const float *>(static_cast<const char *>(R.d_tables) + R.tt_offset);
     const int vec_ok = R.up % 4 == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0 ? 1 : 0;   // m_begin and the chunk starts are multiples of 4
     if (R.lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(poly_rows_kernel<NV, IT>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(R.lds));
-    hipLaunchKernelGGL((poly_rows_kernel<NV, IT>), dim3(static_cast<unsigned>(tiles * R.g.groups)), dim3(kRowsThreads), R.lds, ctx->stream, d_x, tt, gtab, d_y, R.g, m_end, vec_ok);
+    const int64_t tiles8 = (tiles + 7) / 8 * 8;   // whole rounds of the 8 XCDs: the index -> (tile, group) map of the kernel
+    hipLaunchKernelGGL((poly_rows_kernel<NV, IT>), dim3(static_cast<unsigned>(tiles8 * R.g.groups)), dim3(kRowsThreads), R.lds, ctx->stream, d_x, tt, gtab, d_y, R.g, tiles, m_end, vec_ok);
 }
 template <int NV>
 void poly_rows_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end) {
@@ -514,7 +521,7 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
             const PolyRowsGeom &G = R.g;
             int64_t tiles = fa::rows_tiles(G, frames, n_out);                  // tiles whose staged inputs all exist (resample_geom.h)
             const int64_t per_tile = 64LL * G.up;
-            if (tiles > 0 && tiles * G.groups < (1LL << 31)) {
+            if (tiles > 0 && (tiles + 8) * G.groups < (1LL << 31)) {
                 const int64_t m_stop = std::min(n_out, G.m_begin + tiles * per_tile);
                 switch (R.nv) {
 #define FA_ROWS_CASE(V) case V: poly_rows_launch<V>(ctx, R, d_x, d_y, tiles, m_stop); break;
