@@ -307,12 +307,12 @@ def test_c_entry_fa_ahc_cut_refuses_dendrograms_it_cannot_walk(fa):
 
 
 def test_bench_line_contract_on_the_committed_line():
-    """The driver parses ONE JSON line of bench.py: the committed line of the round (profiles/r03_bench_v7.json, written on an MI355X)
+    """The driver parses ONE JSON line of bench.py: the committed line of the round (profiles/r04_bench_v7.json, written on an MI355X)
     carries every field of the contract with the right types, and bench.py still spells each of them."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r03_bench_v7.json")) as f:
+    with open(os.path.join(root, "profiles", "r04_bench_v7.json")) as f:
         line = json.loads(f.read().strip().splitlines()[-1])
     need = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float, "higher_is_better": bool,
             "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict, "cpu_baseline": dict}
@@ -326,6 +326,15 @@ def test_bench_line_contract_on_the_committed_line():
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert line["e2e_equals_reference_digest"] is True
+    # round 4: the second half of the metric and the other north-star kernels ride in `config` (the driver keeps it whole), every one with its check
+    cfg = line["config"]
+    assert 0 < cfg["ahc_50k_seconds"] < 1.0 and cfg["ahc_50k_bit_exact_vs_reference_digest"] is True and cfg["ctc_ids_exact"] is True
+    for k in ("mel_roofline_frac", "ctc_roofline_frac", "ctc_fp16_roofline_frac", "resample_44k1_roofline_frac", "tdt_roofline_frac"):
+        assert 0 < cfg[k] < 1, k
+    assert line["tdt"]["ids_equal_cpu_restatement_all_chunks"] is True and line["tdt"]["ids_equal_table_walk_all_chunks"] is True
+    assert all(v["within_2e-5"] for v in line["resample"].values() if isinstance(v, dict))
+    assert all(v["equal_single_calls"] and v["recording_0_equals_reference_digest"] for k, v in line["e2e_8h_batch"].items() if k.startswith("x"))
+    assert line["e2e_8h_hard"]["equals_reference_digest"] is True
     src = open(os.path.join(root, "bench.py")).read()
     for k in list(need) + ["vs_baseline", "bound", "achieved", "peak", "frac", "traffic", "cores", "kind", "sample"]:
         assert f'"{k}"' in src, k
