@@ -1081,7 +1081,8 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
         else {
             double best; int bp; bool tie;
             exact_min_pair(w, np, s_sq, s_val, s_idx, best, bp, tie);
-            if (bp < 0 || bp == INT_MAX) { D.halt = 1; D.error = 1; }
+            if (bp < 0) { D.halt = 1; D.error = 1; }               // a NaN distance among the window's pairs (nan_error of the reference)
+            else if (bp == INT_MAX) { D.halt = 1; D.error = 3; }   // no pair at all: an internal selection failure, reported as such
             else if (tie) { D.halt = 1; D.need_exact = 2; }   // an EXACT tie at the minimum: which pair the reference takes is its heap's business -> reference order
             else { const int4 e = w.pairs[bp]; D.op = OP_MERGE; D.a = e.x; D.b = e.y; D.na = e.z; D.nb = e.w; D.dab = best; }
         }

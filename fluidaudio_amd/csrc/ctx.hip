@@ -20,17 +20,26 @@ void free_caches_locked(fa_ctx *c, bool scratch_too) {   // registry mutex held,
 
 namespace fa {
 fa_status ws_acquire(fa_ctx *ctx, size_t bytes) {
-    std::lock_guard<std::mutex> lock(g_registry_mutex);
-    ctx->ws_busy = true;
-    if (bytes > ctx->ws_cap) return set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: %zu bytes of workspace needed, the context's cap is %zu", bytes, ctx->ws_cap);
-    if (ctx->ahc_ws_bytes >= bytes) return FA_SUCCESS;
+    // The registry mutex guards the bookkeeping (who is busy, whose idle cache may be taken) — not the allocation itself: a hipMalloc of tens
+    // of gigabytes takes 0.3 - 6 s, and since round 4 several host threads of one call allocate at the same time (the groups of
+    // ahc_batch_uniform_groups, pooled contexts on other GPUs).  The context is marked busy first, so nobody touches its workspace while it is
+    // (re)allocated outside the lock.
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        ctx->ws_busy = true;
+        if (bytes > ctx->ws_cap) return set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: %zu bytes of workspace needed, the context's cap is %zu", bytes, ctx->ws_cap);
+        if (ctx->ahc_ws_bytes >= bytes) return FA_SUCCESS;
+    }
     if (ctx->ahc_ws) { FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ahc_ws); ctx->ahc_ws = nullptr; ctx->ahc_ws_bytes = 0; }
     hipError_t e = hipMalloc(&ctx->ahc_ws, bytes);
-    if (e != hipSuccess) {   // HBM pressure: idle caches of the other contexts on this device go first
+    if (e != hipSuccess) {   // HBM pressure: the idle linkage workspaces of the other contexts on this device go first (their scratch stays)
         (void)hipGetLastError();
         ctx->ahc_ws = nullptr;
-        for (fa_ctx *c : g_registry)
-            if (c != ctx && c->device == ctx->device && !c->ws_busy && c->ahc_ws) free_caches_locked(c, false);
+        {
+            std::lock_guard<std::mutex> lock(g_registry_mutex);
+            for (fa_ctx *c : g_registry)
+                if (c != ctx && c->device == ctx->device && !c->ws_busy && c->ahc_ws) free_caches_locked(c, false);
+        }
         e = hipMalloc(&ctx->ahc_ws, bytes);
     }
     if (e != hipSuccess) {

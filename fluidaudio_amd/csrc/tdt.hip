@@ -153,9 +153,42 @@ struct TdtLogitArgs {
 
 // Round 4: ONE WAVEFRONT per chunk (round 3: a 256-thread workgroup per chunk, three workgroup barriers and two passes over the row per
 // decision — 4.2 us per decision, 3 % of the HBM roofline on 256 chunks).  A decision is latency, not work: ~4 KB of logits, an argmax and a
-// soft-max denominator.  Within a wavefront both reductions are register butterflies (no LDS, no barrier), the row is read ONCE (the
-// denominator is accumulated online against the running maximum and rescaled when the maximum moves), its loads are requested eight at a
-// time, and four times as many chunks fit a CU — the batch of chunks is the parallel axis of this kernel.
+// soft-max denominator.  Within a wavefront both reductions stay in the VALU (DPP row shifts + row broadcasts; the first version used
+// __shfl_xor: 36 LDS round trips per decision), the row is read ONCE (the denominator is accumulated against the running maximum, one
+// rescale per batch of sixteen values), its loads are requested sixteen 256-byte pieces at a time and one batch ahead, and four times as
+// many chunks fit a CU — the batch of chunks is the parallel axis of this kernel.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float tdt_dpp(const float old, const float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROWMASK, 0xf, false));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int tdt_dpp(const int old, const int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, ROWMASK, 0xf, false); }
+// first maximum of (value, index) over the 64 lanes: lower index on equal values, NaN never present (callers keep it out); every lane gets the result
+__device__ __forceinline__ void tdt_wave_argmax(float &v, int &i) {
+#define FA_TDT_STEP(CTRL, MASK)                                                                   \
+    { const float ov = tdt_dpp<CTRL, MASK>(-INFINITY, v); const int oi = tdt_dpp<CTRL, MASK>(0x7fffffff, i); \
+      if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; } }
+    FA_TDT_STEP(0x111, 0xf) FA_TDT_STEP(0x112, 0xf) FA_TDT_STEP(0x114, 0xf) FA_TDT_STEP(0x118, 0xf)   // row_shr 1, 2, 4, 8: lane 15 of every row holds the row's result
+    FA_TDT_STEP(0x142, 0xa) FA_TDT_STEP(0x143, 0xc)                                                   // row_bcast15 into rows 1, 3; row_bcast31 into rows 2, 3: lane 63 holds it all
+#undef FA_TDT_STEP
+    v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    i = __builtin_amdgcn_readlane(i, 63);
+}
+// soft-max partials (m = maximum, s = sum of exp(x - m)) of the 64 lanes -> the wavefront's, in every lane
+__device__ __forceinline__ void tdt_wave_softmax(float &m, float &s) {
+#define FA_TDT_STEP(CTRL, MASK)                                                                   \
+    { const float om = tdt_dpp<CTRL, MASK>(-INFINITY, m), os = tdt_dpp<CTRL, MASK>(0.0f, s);     \
+      const float nm = om > m ? om : m;                                                           \
+      const float sa = m == -INFINITY ? (nm == -INFINITY ? s : 0.0f) : s * __expf(m - nm);       \
+      const float sb = om == -INFINITY ? (nm == -INFINITY ? os : 0.0f) : os * __expf(om - nm);   \
+      s = sa + sb; m = nm; }
+    FA_TDT_STEP(0x111, 0xf) FA_TDT_STEP(0x112, 0xf) FA_TDT_STEP(0x114, 0xf) FA_TDT_STEP(0x118, 0xf)
+    FA_TDT_STEP(0x142, 0xa) FA_TDT_STEP(0x143, 0xc)
+#undef FA_TDT_STEP
+    m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+    s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
+}
+
 template <bool F16>
 __global__ __launch_bounds__(64) void tdt_logits_kernel(const TdtArgs a, const TdtLogitArgs g) {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -168,9 +201,10 @@ __global__ __launch_bounds__(64) void tdt_logits_kernel(const TdtArgs a, const T
         const int64_t row = tb + static_cast<int64_t>(u) * a.T + frame;
         float dvl = lane < g.nd ? at(row, g.V1 + lane) : -INFINITY;            // the duration logits travel with the first batch of the row
         if (dvl != dvl) dvl = -INFINITY;                                       // NaN never wins the first-maximum scan
-        // per-lane: first maximum over k = lane, lane + 64, ... (ascending, strict '>': NaN never wins) and the online soft-max denominator
+        // per-lane: first maximum over k = lane, lane + 64, ... (ascending, strict '>': NaN never wins) and the soft-max partials (m, ssum)
         float bv = -INFINITY, m = -INFINITY, ssum = 0.0f;
         int bi = 0x7fffffff;
+        bool nan_seen = false;                     // a NaN logit anywhere in the row: probability 0 after the clamp (what the two-pass sum of round 3 gave)
         // the row is requested sixteen 256-byte pieces at a time, and the NEXT sixteen before the present ones are looked at: a row of 1 030 logits
         // is one memory round trip, a row of 8 198 (Parakeet-TDT v3) four overlapped ones
         constexpr int kBatch = 16;
@@ -182,37 +216,29 @@ __global__ __launch_bounds__(64) void tdt_logits_kernel(const TdtArgs a, const T
         request(v, lane);
         for (int k0 = lane; k0 < g.V1; k0 += 64 * kBatch) {
             request(vn, k0 + 64 * kBatch);                                          // (beyond the row: no loads, -inf)
+            float bm = -INFINITY;                                                    // maximum of the batch first: one exp per value, one rescale per batch
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
-                const int k = k0 + 64 * j;
-                if (k >= g.V1) continue;
-                if (v[j] > bv) { bv = v[j]; bi = k; }
-                if (v[j] > m) { ssum = m == -INFINITY ? 0.0f : ssum * __expf(m - v[j]); m = v[j]; }
-                if (!(v[j] == -INFINITY && m == -INFINITY)) ssum += __expf(v[j] - m);      // NaN logits poison the sum (probability 0 after the clamp), like the two-pass form
+                if (v[j] > bv) { bv = v[j]; bi = k0 + 64 * j; }                      // (slots beyond the row hold -inf and never win)
+                bm = v[j] > bm ? v[j] : bm;
+            }
+            if (bm > m) { ssum = m == -INFINITY ? 0.0f : ssum * __expf(m - bm); m = bm; }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const bool in_row = k0 + 64 * j < g.V1;
+                nan_seen = nan_seen || (in_row && v[j] != v[j]);
+                if (in_row && m > -INFINITY) ssum += __expf(v[j] - m);
             }
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) v[j] = vn[j];
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(bv, off), om = __shfl_xor(m, off), os = __shfl_xor(ssum, off);
-            const int oi = __shfl_xor(bi, off);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            const float nm = om > m ? om : m;                                   // both -inf: the sums are 0 (or NaN), no rescaling
-            const float sa = m == -INFINITY ? (nm == -INFINITY ? ssum : 0.0f) : ssum * __expf(m - nm);
-            const float sb = om == -INFINITY ? (nm == -INFINITY ? os : 0.0f) : os * __expf(om - nm);
-            ssum = sa + sb; m = nm;
-        }
+        tdt_wave_argmax(bv, bi);
+        tdt_wave_softmax(m, ssum);
         tok = bi == 0x7fffffff ? 0 : bi;           // all NaN / -inf: index 0 (LogitsArgmax semantics)
-        prob = 1.0f / ssum;
+        prob = __builtin_amdgcn_ballot_w64(nan_seen) ? NAN : 1.0f / ssum;
         float dv = dvl;
         int di = lane < g.nd ? lane : 0x7fffffff;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(dv, off);
-            const int oi = __shfl_xor(di, off);
-            if (ov > dv || (ov == dv && oi < di)) { dv = ov; di = oi; }
-        }
+        tdt_wave_argmax(dv, di);
         bin = (di == 0x7fffffff || !(dv > -INFINITY)) ? 0 : di;                 // first maximum; nothing above -inf: bin 0 (the scan's initial value)
     });
 }

@@ -401,7 +401,16 @@ def test_uniform_batches_side_by_side_equal_single_calls(fa, gpu_ctx, monkeypatc
         for z, zr, s in zip(zs, singles, stats):
             np.testing.assert_array_equal(z, zr)
             assert s["merges"] == len(zr) and s["reference_order"] == 0
+    # a recording with exact ties inside the SECOND group (it runs on the helper context): recomputed there in reference order, the others untouched
+    tied = probs[4].copy()
+    tied[8000:16000] = tied[0:8000]
     monkeypatch.setenv("FA_AHC_UNI_GROUPS", "2")
+    st, zs, stats = fa.linkage_batch(probs[:4] + [tied] + probs[5:], ctx=gpu_ctx, return_stats=True)
+    assert list(st) == [0] * 6 and stats[4]["reference_order"] == 1 and stats[3]["reference_order"] == 0
+    st1, z1 = fa.linkage(tied, ctx=gpu_ctx)
+    np.testing.assert_array_equal(zs[4], z1)
+    np.testing.assert_array_equal(zs[5], singles[5])
+    gpu_ctx.trim()
     ctx = fa.Context(0)
     ctx.set_workspace_cap(int(2.5 * 18176 * 18176 * 8))    # a group of three does not fit: split further, still the reference's rows
     st, zs = fa.linkage_batch(probs, ctx=ctx)

@@ -51,6 +51,9 @@ def test_walk_on_joint_logits_equals_walk_on_tables(fa, gpu_ctx, oracle_mod, dty
     lg[..., blank] += 3.2                                  # ~75 % blanks
     lg[3, 0, 0, 5] = lg[3, 0, 0, 9] = 9.0                  # exact tie -> lowest index
     lg[4, 0, 1, :V1] = np.nan                              # NaN never wins: an all-NaN row decodes to token 0, probability 0
+    lg[5, 0, :4, 7] = np.nan                              # one NaN among finite logits: the token is the finite argmax, the probability 0 after the clamp
+    lg[6, 0, :4, :V1] = -np.inf                          # nothing above -inf: token 0, probability 0
+    lg[7, 0, :4, 3:90] = -np.inf                          # -inf entries contribute nothing to the denominator
     lg = lg.astype(dtype)
     x = lg.astype(np.float32)
     tok = np.argmax(np.where(np.isnan(x[..., :V1]), -np.inf, x[..., :V1]), axis=-1).astype(np.int32)
