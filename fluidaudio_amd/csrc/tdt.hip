@@ -216,15 +216,18 @@ __global__ __launch_bounds__(64) void tdt_logits_kernel(const TdtArgs a, const T
         request(v, lane);
         for (int k0 = lane; k0 < g.V1; k0 += 64 * kBatch) {
             request(vn, k0 + 64 * kBatch);                                          // (beyond the row: no loads, -inf)
+            const int kbase = k0 - lane;                                             // wave-uniform: pieces at or beyond the row's end are skipped by a scalar branch
             float bm = -INFINITY;                                                    // maximum of the batch first: one exp per value, one rescale per batch
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
+                if (kbase + 64 * j >= g.V1) break;                                   // (a row of 1 025 logits: the second batch holds ONE piece)
                 if (v[j] > bv) { bv = v[j]; bi = k0 + 64 * j; }                      // (slots beyond the row hold -inf and never win)
                 bm = v[j] > bm ? v[j] : bm;
             }
             if (bm > m) { ssum = m == -INFINITY ? 0.0f : ssum * __expf(m - bm); m = bm; }
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
+                if (kbase + 64 * j >= g.V1) break;
                 const bool in_row = k0 + 64 * j < g.V1;
                 nan_seen = nan_seen || (in_row && v[j] != v[j]);
                 if (in_row && m > -INFINITY) ssum += __expf(v[j] - m);
