@@ -2262,8 +2262,9 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
         const int k = ord[j];
         p.N = n[k]; p.d = d; p.Np = Npmax; p.d_data = d_data[k]; p.d_Z = d_Z[k]; p.mode = mode; p.L = L;
         if (statuses) statuses[k] = FA_SUCCESS;
-        const fa_status st = prob_setup(ctx, p, base + stride * static_cast<size_t>(j));
-        if (st != FA_SUCCESS) { p.st = st; p.active = false; }
+        // every problem of the grid gets workgroups, so every state must be initialised: a set-up that fails (a failing launch or copy: the device
+        // is in trouble) fails the batch, the caller's splitting logic takes over
+        FA_TRY(prob_setup(ctx, p, base + stride * static_cast<size_t>(j)));
     }
     FA_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
     const size_t lds = sizeof(double) * d;
@@ -2471,7 +2472,7 @@ fa_status run_device_batch_impl(fa_ctx *ctx, int count, const double *const *d_d
     if (count <= 0) return FA_SUCCESS;
     std::vector<fa_status> local(static_cast<size_t>(count), FA_SUCCESS);
     fa_status *sts = statuses ? statuses : local.data();
-    if (allow_groups && uniform_eligible(count, n, mode)) {
+    if (allow_groups && uniform_eligible(count, n, mode) && ctx->ws_cap == static_cast<size_t>(-1)) {   // a capped context keeps its promise: ONE workspace within the cap
         const int groups = uniform_groups(count, n);
         if (groups > 1) return ahc_batch_uniform_groups(ctx, groups, count, d_data, n, d, d_Z, mode, stats, sts);
     }

@@ -412,10 +412,41 @@ def test_uniform_batches_side_by_side_equal_single_calls(fa, gpu_ctx, monkeypatc
     np.testing.assert_array_equal(zs[5], singles[5])
     gpu_ctx.trim()
     ctx = fa.Context(0)
-    ctx.set_workspace_cap(int(2.5 * 18176 * 18176 * 8))    # a group of three does not fit: split further, still the reference's rows
+    ctx.set_workspace_cap(int(2.5 * 18176 * 18176 * 8))    # a capped context runs ONE batch at a time within the cap (no second workspace on a helper): split
+                                                           # down to what fits, still the reference's rows, and never more than the cap held
     st, zs = fa.linkage_batch(probs, ctx=ctx)
     assert list(st) == [0] * 6
     for z, zr in zip(zs, singles):
         np.testing.assert_array_equal(z, zr)
+    assert ctx.workspace_bytes() <= int(2.5 * 18176 * 18176 * 8) + 6 * probs[2].nbytes + (1 << 20)
     gpu_ctx.trim()
     torch.cuda.empty_cache()
+
+
+def test_random_batches_through_whichever_path_serves_them(fa, gpu_ctx, oracle_mod):
+    """Seeded random batches — 2 .. 6 problems, 2 .. 2 400 points each, both distributions, duplicated rows now and then: whichever path the
+    dispatcher picks (uniform layout when the padded sizes lie within a factor of two, the block-map / kernel-argument kernels otherwise, the
+    single-launch kernel for one-block problems, reference order on exact ties), every dendrogram is the reference build's, row for row."""
+    rng = np.random.default_rng(2024)
+    for trial in range(8):
+        k = int(rng.integers(2, 7))
+        base = int(rng.integers(2, 2400))
+        probs = []
+        for j in range(k):
+            n = max(2, int(base * rng.uniform(0.45, 1.0))) if trial % 2 == 0 else int(rng.integers(2, 2400))
+            d = 48
+            if rng.random() < 0.5:
+                x = speaker_mixture(n, d, int(rng.integers(2, 12)), float(rng.uniform(0.02, 0.08)), int(rng.integers(1 << 30)))
+            else:
+                x = oracle_mod.ahc_normalize(rng.standard_normal((n, d)))
+            if rng.random() < 0.2 and n > 10:
+                x = x.copy()
+                x[n // 2] = x[0]                                   # one exact tie (distance 0): the reference's heap order decides
+            probs.append(x)
+        mode = fa.AHC_MODE_AUTO
+        st, zs = fa.linkage_batch(probs, mode=mode, ctx=gpu_ctx)
+        assert list(st) == [0] * k, (trial, st, [len(p) for p in probs])
+        for x, z in zip(probs, zs):
+            sr, zr = oracle_mod.linkage_ref(x)
+            assert sr == 0
+            np.testing.assert_array_equal(z, zr, err_msg=f"trial {trial}, sizes {[len(p) for p in probs]}")
