@@ -57,6 +57,50 @@ void ws_release(fa_ctx *ctx) {
     if (ctx->ahc_ws && ctx->ahc_ws_bytes > ctx->ws_limit) free_caches_locked(ctx, false);
 }
 
+// ---- buffer cache of a context (see fa_ctx::buf_free)
+constexpr size_t kBufCacheLimit = static_cast<size_t>(3) << 30;   // bytes a context keeps; beyond that a returned buffer is released
+void buf_cache_flush(fa_ctx *ctx) {                               // caller holds ctx->buf_mutex
+    for (auto &b : ctx->buf_free) (void)hipFree(b.first);
+    ctx->buf_free.clear();
+    ctx->buf_cached_bytes = 0;
+}
+hipError_t devbuf_take(fa_ctx *ctx, size_t bytes, void **p, size_t *cap) {
+    {
+        std::lock_guard<std::mutex> lock(ctx->buf_mutex);
+        int best = -1;
+        for (int i = 0; i < static_cast<int>(ctx->buf_free.size()); ++i) {
+            const size_t c = ctx->buf_free[i].second;
+            if (c >= bytes && c <= 2 * bytes + (static_cast<size_t>(1) << 20) && (best < 0 || c < ctx->buf_free[best].second)) best = i;
+        }
+        if (best >= 0) {
+            *p = ctx->buf_free[best].first; *cap = ctx->buf_free[best].second;
+            ctx->buf_cached_bytes -= *cap;
+            ctx->buf_free.erase(ctx->buf_free.begin() + best);
+            return hipSuccess;
+        }
+    }
+    const size_t want = (bytes + 255) & ~static_cast<size_t>(255);
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {   // HBM pressure: this context's own cache goes first
+        (void)hipGetLastError();
+        { std::lock_guard<std::mutex> lock(ctx->buf_mutex); buf_cache_flush(ctx); }
+        e = hipMalloc(p, want);
+    }
+    *cap = want;
+    return e;
+}
+void devbuf_give(fa_ctx *ctx, void *p, size_t cap) {
+    {
+        std::lock_guard<std::mutex> lock(ctx->buf_mutex);
+        if (ctx->buf_cached_bytes + cap <= kBufCacheLimit && ctx->buf_free.size() < 256) {
+            ctx->buf_free.emplace_back(p, cap);
+            ctx->buf_cached_bytes += cap;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
 fa_status ensure_scratch(fa_ctx *ctx, size_t bytes) {
     if (ctx->scratch_bytes >= bytes) return FA_SUCCESS;
     if (ctx->scratch) {
@@ -104,10 +148,12 @@ fa_status fa_ctx_create(int device, void *stream, fa_ctx **out) {
 void fa_ctx_destroy(fa_ctx *ctx) {
     if (!ctx) return;
     for (auto &h : ctx->helpers) { if (h) fa_ctx_destroy(h); h = nullptr; }
+    for (auto &h : ctx->workers) { if (h) fa_ctx_destroy(h); h = nullptr; }
     { std::lock_guard<std::mutex> lock(g_registry_mutex); g_registry.erase(std::remove(g_registry.begin(), g_registry.end(), ctx), g_registry.end()); }
     fa::DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    { std::lock_guard<std::mutex> lock(ctx->buf_mutex); fa::buf_cache_flush(ctx); }
     if (ctx->ahc_ws) (void)hipFree(ctx->ahc_ws);
     if (ctx->poly_taps) (void)hipFree(ctx->poly_taps);
     if (ctx->poly_rows && ctx->poly_rows_free) ctx->poly_rows_free(ctx->poly_rows);
@@ -125,6 +171,7 @@ void fa_ctx_destroy(fa_ctx *ctx) {
 fa_status fa_ctx_set_workspace_limit(fa_ctx *ctx, size_t bytes) {
     if (!ctx) return FA_INVALID_ARGUMENT;
     for (fa_ctx *h : ctx->helpers) if (h) (void)fa_ctx_set_workspace_limit(h, bytes);
+    for (fa_ctx *h : ctx->workers) if (h) (void)fa_ctx_set_workspace_limit(h, bytes);
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     ctx->ws_limit = bytes;
     if (!ctx->ws_busy && ctx->ahc_ws && ctx->ahc_ws_bytes > bytes) free_caches_locked(ctx, false);
@@ -134,6 +181,7 @@ fa_status fa_ctx_set_workspace_limit(fa_ctx *ctx, size_t bytes) {
 fa_status fa_ctx_set_workspace_cap(fa_ctx *ctx, size_t bytes) {
     if (!ctx) return FA_INVALID_ARGUMENT;
     for (fa_ctx *h : ctx->helpers) if (h) (void)fa_ctx_set_workspace_cap(h, bytes);
+    for (fa_ctx *h : ctx->workers) if (h) (void)fa_ctx_set_workspace_cap(h, bytes);
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     ctx->ws_cap = bytes;
     return FA_SUCCESS;
@@ -142,9 +190,11 @@ fa_status fa_ctx_set_workspace_cap(fa_ctx *ctx, size_t bytes) {
 fa_status fa_ctx_trim(fa_ctx *ctx) {
     if (!ctx) return FA_INVALID_ARGUMENT;
     for (fa_ctx *h : ctx->helpers) if (h) (void)fa_ctx_trim(h);
+    for (fa_ctx *h : ctx->workers) if (h) (void)fa_ctx_trim(h);
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     if (ctx->ws_busy) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "trim: the context is inside a linkage call");
     free_caches_locked(ctx, true);
+    { fa::DeviceGuard guard(ctx->device); (void)hipStreamSynchronize(ctx->stream); std::lock_guard<std::mutex> bl(ctx->buf_mutex); fa::buf_cache_flush(ctx); }
     if (ctx->mel_cache && ctx->mel_cache_free) { ctx->mel_cache_free(ctx->mel_cache); ctx->mel_cache = nullptr; }
     return FA_SUCCESS;
 }
@@ -152,8 +202,9 @@ fa_status fa_ctx_trim(fa_ctx *ctx) {
 size_t fa_ctx_workspace_bytes(const fa_ctx *ctx) {
     if (!ctx) return 0;
     std::lock_guard<std::mutex> lock(g_registry_mutex);
-    size_t total = ctx->ahc_ws_bytes + ctx->scratch_bytes;
-    for (const fa_ctx *h : ctx->helpers) if (h) total += h->ahc_ws_bytes + h->scratch_bytes;
+    size_t total = ctx->ahc_ws_bytes + ctx->scratch_bytes + ctx->buf_cached_bytes;
+    for (const fa_ctx *h : ctx->helpers) if (h) total += h->ahc_ws_bytes + h->scratch_bytes + h->buf_cached_bytes;
+    for (const fa_ctx *h : ctx->workers) if (h) total += h->ahc_ws_bytes + h->scratch_bytes + h->buf_cached_bytes;
     return total;
 }
 

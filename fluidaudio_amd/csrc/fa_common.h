@@ -6,8 +6,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/fluidaudio_hip.h"
 
@@ -44,6 +47,14 @@ struct fa_ctx {
     int32_t poly_up = 0, poly_down = 0, poly_half = 0;
     void *poly_rows = nullptr;                 // per-phase tables of the same pair for poly_rows_kernel (owned by resample.hip)
     void (*poly_rows_free)(void *) = nullptr;
+    // Device buffers of the clustering stage (inputs, VBx state, centroids, scores: ~30 per recording) are kept by the context that allocated
+    // them and handed out again (fa::DevBuf::alloc(ctx, bytes), ctx.hip): a context is ONE stream, so reuse is ordered by the stream, and neither
+    // the hipMalloc nor the hipFree — which waits for EVERY stream of the device, i.e. for the other recordings' kernels — is paid per call.
+    std::mutex buf_mutex;                      // buffers may come back from another thread than the one using the context
+    std::vector<std::pair<void *, size_t>> buf_free;
+    size_t buf_cached_bytes = 0;
+    // fa_offline_cluster_batch prepares / finishes its recordings on worker contexts (own stream each); kept between calls since round 4
+    fa_ctx *workers[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace fa {
@@ -91,11 +102,21 @@ inline fa_status no_throw(fa_ctx *ctx, const char *what, F &&f) noexcept {
         if (fa_s_ != FA_SUCCESS) return fa_s_;  \
     } while (0)
 
-// RAII device buffer for one-call temporaries on the host-pointer entry points.
+// RAII device buffer.  alloc(bytes): a one-call temporary of the host-pointer entry points (hipMalloc / hipFree).  alloc(ctx, bytes): taken
+// from / returned to the context's buffer cache (ctx.hip) — for buffers used on that context's stream only.
+hipError_t devbuf_take(fa_ctx *ctx, size_t bytes, void **p, size_t *cap);
+void devbuf_give(fa_ctx *ctx, void *p, size_t cap);
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    size_t cap = 0;
+    fa_ctx *owner = nullptr;
+    ~DevBuf() { if (p) { if (owner) devbuf_give(owner, p, cap); else (void)hipFree(p); } }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    hipError_t alloc(fa_ctx *ctx, size_t bytes) {
+        const hipError_t e = devbuf_take(ctx, bytes ? bytes : 1, &p, &cap);
+        if (e == hipSuccess) owner = ctx;
+        return e;
+    }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 

@@ -88,7 +88,7 @@ struct ClusterJob {
         d_emb32 = embeddings;
         d_rho_all = rho;
         if (!device_pointers) {
-            if (b_emb32.alloc(sizeof(float) * n * d) != hipSuccess || (rho_dim > 0 && b_rho_in.alloc(sizeof(double) * n * rho_dim) != hipSuccess)) {
+            if (b_emb32.alloc(ctx, sizeof(float) * n * d) != hipSuccess || (rho_dim > 0 && b_rho_in.alloc(ctx, sizeof(double) * n * rho_dim) != hipSuccess)) {
                 (void)hipGetLastError();
                 return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: input allocation failed");
             }
@@ -98,7 +98,7 @@ struct ClusterJob {
             d_rho_all = b_rho_in.as<double>();
         }
         // ---- selectTrainingEmbeddings (:591-611): rows without NaN / Inf; all rows if none qualifies
-        if (b_ok.alloc(n) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
+        if (b_ok.alloc(ctx, n) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
         hipLaunchKernelGGL(finite_rows, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, st, d_emb32, b_ok.as<uint8_t>(), n, d);
         FA_HIP_TRY(ctx, hipGetLastError());
         std::vector<uint8_t> ok(static_cast<size_t>(n));
@@ -109,14 +109,14 @@ struct ClusterJob {
         const bool all_rows = train.empty() || static_cast<int64_t>(train.size()) == n;
         if (train.empty()) { train.resize(n); for (int64_t i = 0; i < n; ++i) train[i] = static_cast<int32_t>(i); }
         nt = static_cast<int64_t>(train.size());
-        if (b_emb.alloc(sizeof(double) * n * d) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
+        if (b_emb.alloc(ctx, sizeof(double) * n * d) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
         const unsigned g_all = static_cast<unsigned>((n * d + 255) / 256);
         hipLaunchKernelGGL(widen_rows, dim3(g_all), dim3(256), 0, st, d_emb32, static_cast<const int32_t *>(nullptr), b_emb.as<double>(), n, d);   // Float -> Double (:286)
         d_temb = b_emb.as<double>();
         d_trho = d_rho_all;
         if (!all_rows) {
-            if (b_train.alloc(sizeof(int32_t) * nt) != hipSuccess || b_temb.alloc(sizeof(double) * nt * d) != hipSuccess ||
-                (rho_dim > 0 && b_trho.alloc(sizeof(double) * nt * rho_dim) != hipSuccess)) {
+            if (b_train.alloc(ctx, sizeof(int32_t) * nt) != hipSuccess || b_temb.alloc(ctx, sizeof(double) * nt * d) != hipSuccess ||
+                (rho_dim > 0 && b_trho.alloc(ctx, sizeof(double) * nt * rho_dim) != hipSuccess)) {
                 (void)hipGetLastError();
                 return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed");
             }
@@ -130,7 +130,7 @@ struct ClusterJob {
         FA_HIP_TRY(ctx, hipGetLastError());
         FA_HIP_TRY(ctx, hipStreamSynchronize(st));   // `train` is a host temporary
         if (nt >= 2) {   // AHC input (:301-306): unit rows
-            if (b_norm.alloc(sizeof(double) * nt * d) != hipSuccess || b_z.alloc(sizeof(double) * 4 * (nt - 1)) != hipSuccess) {
+            if (b_norm.alloc(ctx, sizeof(double) * nt * d) != hipSuccess || b_z.alloc(ctx, sizeof(double) * 4 * (nt - 1)) != hipSuccess) {
                 (void)hipGetLastError();
                 return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed");
             }
@@ -169,7 +169,7 @@ struct ClusterJob {
         std::vector<int32_t> km_labels;
         int32_t km_k = 0;
         if (rho_dim > 0 && nt > 0) {
-            if (b_lab.alloc(sizeof(int32_t) * nt) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
+            if (b_lab.alloc(ctx, sizeof(int32_t) * nt) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
             FA_HIP_TRY(ctx, hipMemcpyAsync(b_lab.p, initial.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice, st));
             std::vector<double> elbos(static_cast<size_t>(std::max(config->max_vbx_iterations, 1)));
             FA_TRY(fa::vbx_run_dev(ctx, d_trho, nt, rho_dim, b_lab.as<int32_t>(), S, phi, config->warm_start_fa, config->warm_start_fb,
@@ -212,14 +212,14 @@ struct ClusterJob {
         int32_t K = 0;
         if (adjusted && km_k > 0) {
             K = km_k;
-            if (b_cent.alloc(sizeof(double) * K * d) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
+            if (b_cent.alloc(ctx, sizeof(double) * K * d) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
             FA_HIP_TRY(ctx, hipMemcpyAsync(b_cent.p, km_centroids.data(), sizeof(double) * K * d, hipMemcpyHostToDevice, st));
         } else if (have_vbx) {
             std::vector<int32_t> spk;
             for (int s = 0; s < S; ++s) if (pi[s] > 1e-7) spk.push_back(s);
             K = static_cast<int32_t>(spk.size());
             if (K > 0) {
-                if (b_cent.alloc(sizeof(double) * K * d) != hipSuccess || b_spk.alloc(sizeof(int32_t) * K) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
+                if (b_cent.alloc(ctx, sizeof(double) * K * d) != hipSuccess || b_spk.alloc(ctx, sizeof(int32_t) * K) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
                 FA_HIP_TRY(ctx, hipMemcpyAsync(b_spk.p, spk.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice, st));
                 FA_TRY(fa::centroids_dev(ctx, d_temb, nt, d, vbx.gamma.as<double>(), S, b_spk.as<int32_t>(), K, b_cent.as<double>()));
                 FA_HIP_TRY(ctx, hipStreamSynchronize(st));   // spk is a host temporary
@@ -240,17 +240,17 @@ struct ClusterJob {
             std::vector<double> cen;
             for (int c = 0; c < kmax; ++c) if (cnt[c] > 0) for (int k = 0; k < d; ++k) cen.push_back(sum[static_cast<size_t>(c) * d + k] / static_cast<double>(cnt[c]));
             K = static_cast<int32_t>(cen.size() / d);
-            if (b_cent.alloc(sizeof(double) * std::max(K, 1) * d) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
+            if (b_cent.alloc(ctx, sizeof(double) * std::max(K, 1) * d) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
             FA_HIP_TRY(ctx, hipMemcpyAsync(b_cent.p, cen.data(), sizeof(double) * cen.size(), hipMemcpyHostToDevice, st));
             FA_HIP_TRY(ctx, hipStreamSynchronize(st));
         }
 
         // ---- assignment of ALL embeddings (:345-375): constrained per chunk unless the count was forced or there is a single centroid
         fa::DevBuf b_cn, b_scores, b_out;
-        if (b_cn.alloc(sizeof(double) * std::max(K, 1) * d) != hipSuccess || b_out.alloc(sizeof(int32_t) * n) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
+        if (b_cn.alloc(ctx, sizeof(double) * std::max(K, 1) * d) != hipSuccess || b_out.alloc(ctx, sizeof(int32_t) * n) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
         const bool constrained = config->constrained_assignment && !adjusted && K > 1;   // :355-358
         if (constrained) {
-            if (b_scores.alloc(sizeof(double) * n * K) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
+            if (b_scores.alloc(ctx, sizeof(double) * n * K) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
             FA_TRY(fa::scores_dev(ctx, b_emb.as<double>(), n, d, b_cent.as<double>(), K, b_cn.as<double>(), b_scores.as<double>()));
             FA_TRY(fa::constrained_assign_dev(ctx, b_scores.as<double>(), n, K, chunk_indices, b_out.as<int32_t>()));
         } else {
@@ -356,8 +356,12 @@ fa_status fa_offline_cluster_batch(fa_ctx *ctx, int32_t count, const float *cons
         const int workers = std::max(1, std::min<int>(count, 8));
         std::vector<fa_ctx *> wctx(static_cast<size_t>(workers), nullptr);
         wctx[0] = ctx;
-        for (int t = 1; t < workers; ++t) if (fa_ctx_create(ctx->device, nullptr, &wctx[t]) != FA_SUCCESS) wctx[t] = nullptr;
-        struct Workers { std::vector<fa_ctx *> &w; ~Workers() { for (size_t t = 1; t < w.size(); ++t) if (w[t]) fa_ctx_destroy(w[t]); } } wguard{wctx};
+        for (int t = 1; t < workers; ++t) {   // worker contexts live with the caller's context (round 4): their streams and buffer caches are reused by the next call
+            fa_ctx *&wk = ctx->workers[t - 1];
+            if (!wk && fa_ctx_create(ctx->device, nullptr, &wk) != FA_SUCCESS) wk = nullptr;
+            if (wk) { wk->ws_limit = ctx->ws_limit; wk->ws_cap = ctx->ws_cap; wk->last_error.clear(); }
+            wctx[t] = wk;
+        }
         std::vector<std::string> werr(static_cast<size_t>(workers));
         auto on_workers = [&](auto &&phase) {   // phase(job index) -> fa_status, for every recording that is still healthy
             auto work = [&](const int t, const int stride_from) {

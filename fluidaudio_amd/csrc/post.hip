@@ -449,11 +449,11 @@ fa_status fa::constrained_assign_dev(fa_ctx *ctx, const double *d_scores, int64_
         const int n_max = std::max(max_rows, static_cast<int>(K));
         const bool big = n_max > kHungMaxN;   // potentials / matching in HBM slabs instead of LDS (rare: more than 256 clusters survive VBx)
         fa::DevBuf d_start, d_rows, d_slabs;
-        if (big && d_slabs.alloc(hung_slab_bytes(n_max) * static_cast<size_t>(n_chunks)) != hipSuccess) {
+        if (big && d_slabs.alloc(ctx, hung_slab_bytes(n_max) * static_cast<size_t>(n_chunks)) != hipSuccess) {
             (void)hipGetLastError();
             return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "constrained assign: device allocation failed");
         }
-        if (d_start.alloc(sizeof(int32_t) * starts.size()) != hipSuccess || d_rows.alloc(sizeof(int32_t) * n) != hipSuccess) {
+        if (d_start.alloc(ctx, sizeof(int32_t) * starts.size()) != hipSuccess || d_rows.alloc(ctx, sizeof(int32_t) * n) != hipSuccess) {
             (void)hipGetLastError();
             return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "constrained assign: device allocation failed");
         }

@@ -430,7 +430,7 @@ fa_status vbx_setup(fa_ctx *ctx, const double *d_X, int64_t T, int64_t Tg, int64
     const size_t TD = Tn * D, TS = Tn * S, SD = static_cast<size_t>(S) * D;
     const int64_t stride = static_cast<int64_t>(S) * (D + 1) + 1;
     hipError_t e = hipSuccess;
-    auto A = [&](fa::DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.alloc(bytes); };
+    auto A = [&](fa::DevBuf &b, size_t bytes) { if (e == hipSuccess) e = b.alloc(ctx, bytes); };   // from the context's buffer cache: 13 buffers per refinement
     A(o.phi, 8 * D); A(o.rho, 8 * TD); A(o.G, 8 * Tn); A(o.gamma, 8 * TS); A(o.pi, 8 * S); A(o.logpi, 8 * S);
     A(o.part, 8 * static_cast<size_t>(kSplit) * stride); A(o.alpha, 8 * SD); A(o.invL, 8 * SD); A(o.phiT, 8 * S);
     A(o.ll, 8 * Tn); A(o.scal, 64); A(o.hard, 4 * Tn);
