@@ -2418,11 +2418,13 @@ namespace {
 fa_status run_device_batch_impl(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode, fa_ahc_stats *stats,
                                 fa_status *statuses, bool allow_groups);
 
+constexpr size_t kUniGroupsMinN = 4096;
 int uniform_groups(int count, const size_t *n) {
     if (const char *e = getenv("FA_AHC_UNI_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= 4) return std::min(v, count / 2 > 0 ? count / 2 : 1); }
     size_t lo = SIZE_MAX;
     for (int k = 0; k < count; ++k) lo = std::min(lo, n[k]);
-    return count >= 6 && lo >= kInFlightMinN ? 2 : 1;
+    // six long recordings, or eight medium ones (chains of >= 4 096 rounds: the second stream's thread + graph capture, ~2 ms, must be worth it)
+    return (count >= 6 && lo >= kInFlightMinN) || (count >= 8 && lo >= kUniGroupsMinN) ? 2 : 1;
 }
 
 fa_status ahc_batch_uniform_groups(fa_ctx *ctx, int groups, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
