@@ -2385,8 +2385,10 @@ fa_status ahc_batch_in_flight(fa_ctx *ctx, int count, const double *const *d_dat
         try {
             threads.emplace_back([&, k]() {
                 fa_ctx *h = ctx->helpers[k - 1];
-                fa::DeviceGuard guard(h->device);
-                sts[k] = fa::ahc_run_device(h, d_data[k], n[k], d, d_Z[k], mode, stats ? &stats[k] : nullptr, false);
+                try {                            // nothing may leave a host thread; ALLOCATION_FAILURE sends the problem to the caller's context below
+                    fa::DeviceGuard guard(h->device);
+                    sts[k] = fa::ahc_run_device(h, d_data[k], n[k], d, d_Z[k], mode, stats ? &stats[k] : nullptr, false);
+                } catch (...) { sts[k] = FA_ALLOCATION_FAILURE; }
             });
             started[static_cast<size_t>(k)] = 1;
         } catch (...) {                          // no thread to be had (std::system_error): that problem runs on the caller's context below
@@ -2444,8 +2446,10 @@ fa_status ahc_batch_uniform_groups(fa_ctx *ctx, int groups, int count, const dou
     auto run_group = [&](fa_ctx *c, const int g) {
         const int a = first[g], m = first[g + 1] - first[g];
         bool completed = false;
-        fa::DeviceGuard guard(c->device);
-        (void)ahc_batch_uniform(c, m, d_data + a, n + a, d, d_Z + a, mode, stats ? stats + a : nullptr, sts + a, &completed);
+        try {                                    // nothing may leave a host thread: an exception there would end the process
+            fa::DeviceGuard guard(c->device);
+            (void)ahc_batch_uniform(c, m, d_data + a, n + a, d, d_Z + a, mode, stats ? stats + a : nullptr, sts + a, &completed);
+        } catch (...) { completed = false; }
         done[static_cast<size_t>(g)] = completed ? 1 : 0;
     };
     std::vector<std::thread> threads;
