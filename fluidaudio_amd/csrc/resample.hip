@@ -130,12 +130,19 @@ __global__ __launch_bounds__(kThreads) void poly_decim_kernel(const float *__res
     float acc[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) acc[j] = 0.0f;
+    // One v_fmac_f32 per multiply-add, the tap as its scalar operand — written as inline assembly since round 4: left to the compiler, the SLP
+    // vectoriser paired the outputs into v_pk_fma_f32, whose operands must be consecutive register PAIRS; the inputs of two outputs lie DOWN
+    // registers apart, so every packed instruction came with ~1.3 register moves (DOWN = 3: 256 v_pk_fma + 361 moves = 774 instructions for 8
+    // outputs; now 512 v_fmac + the loads and stores).  The same fused multiply-add, the same order: identical bits.
 #pragma unroll
     for (int i = 0; i < NIN; ++i)          // ascending input index; output j meets it with tap NT - 1 + j DOWN - i
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int ti = NT - 1 + j * DOWN - i;
-            if (ti >= 0 && ti < NT) acc[j] = fmaf(taps[ti], xin[i], acc[j]);
+            if (ti >= 0 && ti < NT) {
+                if (DOWN <= 3) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[j]) : "s"(taps[ti]), "v"(xin[i]));   // <= 64 taps: they all fit the scalar registers
+                else acc[j] = fmaf(taps[ti], xin[i], acc[j]);        // 85 / 106 taps: left to the compiler (the constraint would spill scalar registers)
+            }
         }
     float4 *dst = reinterpret_cast<float4 *>(y + m0);   // m0 = 10 (mod 4) + multiple of 8: 8-byte aligned only -> two-float stores
     (void)dst;
