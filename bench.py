@@ -573,7 +573,7 @@ def tdt_leg(fa, ctx, torch, B=1024, U=64, T=188, V1=1025, nd=5, dtype="float32")
 
 AHC_SOURCES = ("ahc.hip",)
 CTC_SOURCES = ("ctc.hip",)
-RESAMPLE_SOURCES = ("resample.hip",)
+RESAMPLE_SOURCES = ("resample.hip", "resample_geom.h")
 TDT_SOURCES = ("tdt.hip",)
 
 

@@ -314,7 +314,9 @@ void poly_rows_free(void *p) { delete static_cast<PolyRows *>(p); }
 
 // Geometry + tables (resample_geom.h); false when the pair does not suit the kernel (then poly_lds_kernel serves it).
 bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt) {
-    if (!fa::rows_geometry(R.g, R.nv, h, up, down, pre_remove, gtab, tt)) return false;
+    size_t budget = 74 * 1024;                                          // rows of a phase group: two workgroups per CU (FA_RESAMPLE_ROWS_LDS_KB: measurements)
+    if (const char *e = getenv("FA_RESAMPLE_ROWS_LDS_KB")) { const int v = atoi(e); if (v >= 16 && v <= 150) budget = static_cast<size_t>(v) * 1024; }
+    if (!fa::rows_geometry(R.g, R.nv, h, up, down, pre_remove, gtab, tt, budget)) return false;
     R.lds = static_cast<size_t>(R.g.sld) * 64 * sizeof(float); R.up = up; R.down = down;
     return true;
 }

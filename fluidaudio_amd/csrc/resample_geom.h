@@ -21,7 +21,8 @@ constexpr int kRowsOffLane = 62;   // lane of a phase's table row that carries i
 // poly_rows_kernel: tables of one rate pair.  h = the FIR of fa_resample_poly_taps (leading zero taps included), gtab = {first staged offset,
 // staged span} per phase group, tt = 64 floats per phase (taps shifted by the window's misalignment, zeros around them; lane 62: the aligned
 // window offset).  nv = 16-byte reads per window.  false: the pair does not suit the kernel.
-inline bool rows_geometry(PolyRowsGeom &g, int &nv_out, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt) {
+inline bool rows_geometry(PolyRowsGeom &g, int &nv_out, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt,
+                          size_t lds_budget = 74 * 1024) {
     const int64_t h_len = static_cast<int64_t>(h.size());
     if (up < 8 || up > 4096 || down > 8192) return false;               // few phases: the register-tiled kernels; huge ones: tables too large
     const int q1 = static_cast<int>((h_len + up - 1) / up);             // a window holds floor(h_len / up) or that + 1 taps
@@ -68,7 +69,7 @@ inline bool rows_geometry(PolyRowsGeom &g, int &nv_out, const std::vector<float>
         sld = (span + 3) / 4;
         if (sld % 2 == 0) ++sld;
         sld *= 4;
-        if (static_cast<size_t>(sld) * 64 * sizeof(float) <= 74 * 1024 || ppg <= 4 * kRowsWaves) break;
+        if (static_cast<size_t>(sld) * 64 * sizeof(float) <= lds_budget || ppg <= 4 * kRowsWaves) break;
     }
     groups = (up + ppg - 1) / ppg;
     if (static_cast<size_t>(sld) * 64 * sizeof(float) > 150 * 1024 || sld > 64 * 10) return false;
