@@ -212,8 +212,8 @@ void poly_interp_launch(fa_ctx *ctx, const float *d_x, const float *d_h, float *
 //     16-byte boundary below its start; its misalignment (the same in all lanes) is absorbed by the table row, whose taps are shifted by it:
 //     NV ds_read_b128 per phase and wavefront instead of two scalar-width LDS operands per multiply-add (poly_lds_kernel: 6.9 % of the HBM
 //     roofline at 44.1 -> 16 kHz, LDS-issue bound);
-//   * a workgroup = one tile (64 up consecutive outputs) x one group of phases (the phases are split so that the rows of a group fit 38 KB:
-//     three to four workgroups per CU, some staging while the others compute; 74 KB = two per CU was 8 % slower); a wavefront takes CHUNKS of four consecutive phases, so a lane ends a
+//   * a workgroup = one tile (64 up consecutive outputs) x one group of phases (the phases are split so that the rows of a group fit 74 KB = two
+//     workgroups per CU, or 38 KB = three to four for the short windows of many-phase pairs: one stages while the others compute); a wavefront takes CHUNKS of four consecutive phases, so a lane ends a
 //     chunk with four consecutive outputs and stores them as one 16-byte piece (the first version stored 4 bytes per lane and phase: one L2
 //     transaction per output sample, 128 G transactions per second).
 // Summation order per output: ascending input index over the k range of poly_kernel, zero taps in front and behind -> identical bits on finite input.
@@ -314,7 +314,7 @@ void poly_rows_free(void *p) { delete static_cast<PolyRows *>(p); }
 
 // Geometry + tables (resample_geom.h); false when the pair does not suit the kernel (then poly_lds_kernel serves it).
 bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt) {
-    size_t budget = 38 * 1024;                                          // rows of a phase group: 3 - 4 workgroups per CU (FA_RESAMPLE_ROWS_LDS_KB: measurements, r04_rows_lds_probe.json)
+    size_t budget = 0;                                                  // automatic (resample_geom.h); FA_RESAMPLE_ROWS_LDS_KB: measurements (r04_rows_lds_probe.json)
     if (const char *e = getenv("FA_RESAMPLE_ROWS_LDS_KB")) { const int v = atoi(e); if (v >= 16 && v <= 150) budget = static_cast<size_t>(v) * 1024; }
     if (!fa::rows_geometry(R.g, R.nv, h, up, down, pre_remove, gtab, tt, budget)) return false;
     R.lds = static_cast<size_t>(R.g.sld) * 64 * sizeof(float); R.up = up; R.down = down;

@@ -22,7 +22,7 @@ constexpr int kRowsOffLane = 62;   // lane of a phase's table row that carries i
 // staged span} per phase group, tt = 64 floats per phase (taps shifted by the window's misalignment, zeros around them; lane 62: the aligned
 // window offset).  nv = 16-byte reads per window.  false: the pair does not suit the kernel.
 inline bool rows_geometry(PolyRowsGeom &g, int &nv_out, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt,
-                          size_t lds_budget = 38 * 1024) {
+                          size_t lds_budget = 0) {
     const int64_t h_len = static_cast<int64_t>(h.size());
     if (up < 8 || up > 4096 || down > 8192) return false;               // few phases: the register-tiled kernels; huge ones: tables too large
     const int q1 = static_cast<int>((h_len + up - 1) / up);             // a window holds floor(h_len / up) or that + 1 taps
@@ -56,9 +56,11 @@ inline bool rows_geometry(PolyRowsGeom &g, int &nv_out, const std::vector<float>
         memcpy(rowp + kRowsOffLane, &off4, sizeof(int));
         smax = std::max(smax, off4 + 4 * nv);
     }
-    // phase groups (a multiple of 4 phases each): the rows of a group within the LDS budget — 38 KB: three to four workgroups per CU stage and compute
-    // side by side (measured against 74 / 60 / 50 / 30 KB: profiles/r04_rows_lds_probe.json); rows are `sld` floats apart, sld = 4 x odd >= the longest
-    // staged span of a group
+    // phase groups (a multiple of 4 phases each): the rows of a group within the LDS budget; rows are `sld` floats apart, sld = 4 x odd >= the longest
+    // staged span of a group.  Budget (0 = automatic): short windows (<= 8 reads per window: the kernel needs 56 VGPRs, 8 wavefronts per SIMD fit) get
+    // 38 KB = three to four workgroups per CU staging and computing side by side (22.05 kHz: -4 %); long windows (16 reads: 84 VGPRs, 5 wavefronts per
+    // SIMD) gain nothing from more, smaller workgroups and keep 74 KB = two per CU (profiles/r04_rows_lds_probe.json, r04_rows_lds_ab.json)
+    if (lds_budget == 0) lds_budget = nv <= 8 ? 38 * 1024 : 74 * 1024;
     int groups = 1, ppg = up, sld = 0;
     for (;; ++groups) {
         ppg = ((up + groups - 1) / groups + 3) & ~3;

@@ -11,7 +11,7 @@ mkdir -p gpurun_out/pmc_$name
 runp() { n=$1; shift; ( cd /tmp && FA_PROBE=resample timeout 600 rocprofv3 --pmc "$@" -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$name/$n" -o $n -- python $GRAFT_REPO_ROOT/scripts/r4_kernels_probe.py ) > gpurun_out/pmc_$name/$n.log 2>&1; echo "$name/$n rc=$?"; }
 runp tcc1 FETCH_SIZE GRBM_GUI_ACTIVE
 runp tcc2 WRITE_SIZE GRBM_GUI_ACTIVE
-summ() {
+summ() {  # SHA over bench.RESAMPLE_SOURCES
   python scripts/pmc_summary.py "$2" $(find gpurun_out/pmc_$name -name "*.db") > gpurun_out/summary/$1_pmc.json
   python - "$1" "$3" <<'PY'
 import json, sys
@@ -19,8 +19,8 @@ sys.path.insert(0, '.')
 import bench
 p = f'gpurun_out/summary/{sys.argv[1]}_pmc.json'
 j = json.load(open(p))
-j['kernel_sources_sha256'] = bench.sources_sha256((sys.argv[2],))
-j['kernel_sources'] = [sys.argv[2]]
+j['kernel_sources_sha256'] = bench.sources_sha256(bench.RESAMPLE_SOURCES)
+j['kernel_sources'] = list(bench.RESAMPLE_SOURCES)
 json.dump(j, open(p, 'w'), indent=1)
 print(sys.argv[1], {k: v for k, v in j.items() if k not in ('counters', 'kernel_sources_sha256')})
 PY
