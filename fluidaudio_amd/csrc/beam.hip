@@ -4,14 +4,15 @@
 // ARPALanguageModel (…/CTC/ARPALanguageModel.swift:16-104).  One workgroup per utterance walks the frames; inside a frame
 // everything is data-parallel over the <= beamWidth x (tokenCandidates + 1) candidate hypotheses:
 //
-//   1. top-K tokens of the frame: most-significant-digit radix select on (log-prob descending, index ascending) keys;
+//   1. top-K tokens of the frame, (log-prob descending, index ascending): computed for ALL frames ahead of the walk by ctc_topk_kernel
+//      (one wavefront per frame, the whole chip busy) — the walk reads K (token, log-prob) pairs per frame;
 //   2. candidate totals.  The reference merges hypotheses through a dictionary keyed by the whole token prefix; here a prefix
 //      is a node of a trie kept in HBM — an open-addressing hash table over (parent node, token), so that a prefix which is
 //      pruned and later re-created gets the SAME node — and two observations replace the dictionary: an extension
 //      (beam i, token v) can only collide with the ONE live beam whose (parent node, last token) is (node i, v), and never
 //      with another extension.  Two 256-slot LDS hash maps (node -> beam, (parent, token) -> beam) answer both questions;
-//   3. pruning to the beam width: the same radix select on (total descending, candidate order ascending) keys, then a
-//      bitonic sort of the <= 128 survivors;
+//   3. pruning to the beam width: most-significant-digit radix select on (total descending, candidate order ascending) keys, then a
+//      rank sort of the <= 128 survivors;
 //   4. survivors become the new beams; new prefixes get trie nodes, and — when a language model is attached — their
 //      running word (a polynomial hash of its bytes, built from per-token (multiplier, addend) pairs) is scored once
 //      against the unigram / bigram hash tables in HBM, so a frame costs at most beamWidth table probes.
@@ -119,6 +120,7 @@ struct BeamArgs {
     int32_t frames, vocab, blank, beam_width, top_k, use_lm, first;
     float lm_weight, word_bonus;
     unsigned long long *prof;   // FA_BEAM_PROF (diagnostics): cycles per step of workgroup 0, thread 0
+    const struct TopEntry *top; const float *blank_lp;   // the pre-pass' tables (ctc_topk_kernel): [workgroup][frame][top_k], [workgroup][frame]
 };
 
 struct Shared {
@@ -134,7 +136,6 @@ struct Shared {
     int32_t map_pl_parent[kMapSlots], map_pl_tok[kMapSlots], map_pl_val[kMapSlots];
     unsigned long long thr, all_and, all_or;
     int32_t sel_count, bin, remaining, done, n_beams;
-    float blank_lp;
 };
 
 // OR over the wavefront of a 32-bit word (DPP row shifts + row broadcasts; lane 63 holds the result)
@@ -143,73 +144,6 @@ __device__ __forceinline__ unsigned wave_or(unsigned v) {
     FA_BEAM_OR(0x111, 0xf) FA_BEAM_OR(0x112, 0xf) FA_BEAM_OR(0x114, 0xf) FA_BEAM_OR(0x118, 0xf) FA_BEAM_OR(0x142, 0xa) FA_BEAM_OR(0x143, 0xc)
 #undef FA_BEAM_OR
     return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
-}
-
-// K smallest of `n` distinct 64-bit keys: returns (through s.thr) a threshold such that the keys <= thr are the K smallest plus at most
-// `room - K` more (the caller sorts what it gathers and keeps the first K).  key(i) may be ~0ull for "absent".
-// Most-significant-digit radix select, 8 bits per pass, with two shortcuts that matter here:
-//   * the digits every present key agrees on are skipped (AND / OR of all keys): log-probabilities of one frame share sign and most
-//     of the exponent, so the first pass or two would send EVERY key to one histogram bin — 64 lanes on one LDS address, the
-//     slowest thing the LDS does;
-//   * the passes stop as soon as the keys below the threshold bin plus the bin itself fit into `room` (the gather buffer).
-template <class KeyFn>
-__device__ void radix_select(Shared &s, const int n, int k, const int room, KeyFn key) {
-    const int tid = threadIdx.x;
-    unsigned long long prefix = 0;
-    if (k <= 0) {   // nothing to select: no key is <= 0
-        if (tid == 0) s.thr = 0;
-        __syncthreads();
-        return;
-    }
-    if (tid == 0) { s.done = 0; s.remaining = k; s.all_and = ~0ull; s.all_or = 0; }
-    __syncthreads();
-    {
-        unsigned long long kand = ~0ull, kor = 0;
-        for (int i = tid; i < n; i += kThreads) { const unsigned long long kk = key(i); if (kk != ~0ull) { kand &= kk; kor |= kk; } }
-        const unsigned ah = ~wave_or(~static_cast<unsigned>(kand >> 32)), al = ~wave_or(~static_cast<unsigned>(kand));
-        const unsigned oh = wave_or(static_cast<unsigned>(kor >> 32)), ol = wave_or(static_cast<unsigned>(kor));
-        if ((tid & 63) == 0) { atomicAnd(&s.all_and, (static_cast<unsigned long long>(ah) << 32) | al); atomicOr(&s.all_or, (static_cast<unsigned long long>(oh) << 32) | ol); }
-    }
-    __syncthreads();
-    const unsigned long long differ = s.all_and ^ s.all_or;           // 0: at most one distinct key present
-    const int first_pass = differ ? __clzll(static_cast<long long>(differ)) >> 3 : 7;
-    if (first_pass > 0) prefix = s.all_or >> (64 - 8 * first_pass);   // the digits all present keys share
-    for (int pass = first_pass; pass < 8; ++pass) {
-        const int shift = 56 - 8 * pass;
-        s.hist2[0][tid] = 0;
-        __syncthreads();
-        if (s.done) break;
-        for (int i = tid; i < n; i += kThreads) {   // plain LDS atomics: wave-aggregating the increments was measured slower
-            const unsigned long long kk = key(i);
-            if (kk != ~0ull && (pass == 0 || (kk >> (shift + 8)) == prefix)) atomicAdd(&s.hist2[0][(kk >> shift) & 255], 1);
-        }
-        __syncthreads();
-        if (tid < 64) {   // wave 0: bin where the running count reaches `remaining`
-            const int h0 = s.hist2[0][4 * tid], h1 = s.hist2[0][4 * tid + 1], h2 = s.hist2[0][4 * tid + 2], h3 = s.hist2[0][4 * tid + 3];
-            const int mine = h0 + h1 + h2 + h3;
-            int incl = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (tid >= off) incl += o; }
-            const int excl = incl - mine, need = s.remaining;
-            if (excl < need && need <= incl) {
-                int c = excl, b = 4 * tid;
-                if (c + h0 >= need) { } else { c += h0; b += 1; if (c + h1 >= need) { } else { c += h1; b += 1; if (c + h2 >= need) { } else { c += h2; b += 1; } } }
-                const int hb = s.hist2[0][b];
-                s.bin = b;
-                s.remaining = need - c;
-                // the whole bin belongs to the selection, or everything up to and including it fits the caller's buffer
-                if (hb == need - c || pass == 7 || (k - need) + c + hb <= room) s.done = 1;
-            }
-            if (tid == 63 && incl < need) { s.bin = 255; s.done = 2; }   // fewer than k keys present: take everything
-        }
-        __syncthreads();
-        prefix = (prefix << 8) | static_cast<unsigned>(s.bin);
-        if (s.done) {
-            const unsigned long long low = shift ? ((1ull << shift) - 1) : 0ull;
-            if (tid == 0) s.thr = s.done == 2 ? ~0ull - 1 : ((prefix << shift) | low);
-        }
-    }
-    __syncthreads();
 }
 
 // ascending sort of s.sel_key[0 .. 128) (real keys first, then the ~0ull padding).  The real keys are distinct (their low words are
@@ -237,6 +171,110 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     FA_BEAM_ADD(0x111, 0xf) FA_BEAM_ADD(0x112, 0xf) FA_BEAM_ADD(0x114, 0xf) FA_BEAM_ADD(0x118, 0xf) FA_BEAM_ADD(0x142, 0xa) FA_BEAM_ADD(0x143, 0xc)
 #undef FA_BEAM_ADD
     return v;
+}
+
+// ------------------------------------------------------------------------------------------------ top tokens of every frame (pre-pass)
+// Which tokens a frame offers (CtcDecoder.swift:141-144: the tokenCandidates best by log-probability, ties by index, blank aside) does not
+// depend on the beams, so it leaves the serial frame walk: ctc_topk_kernel computes it for every (utterance, frame) row of a launch at once —
+// one wavefront per row, rows spread over the whole chip — and ctc_beam_kernel reads K (token, log-prob) pairs per frame, requested one
+// frame ahead.  (Rounds 1-3 selected inside the walk: 11 900 of 57 000 cycles per frame step, profiles/r02_beam_probe.json.)
+//
+// One row: lane l holds the order keys u = ~ord_f32(x) (smaller = better; NaN = 0xffffffff sorts last) of the tokens l, l + 64, ...  A binary
+// search over the bits of u, from the first bit in which the row's keys differ, keeps T with count(u < T) < K; it stops as soon as a tested
+// bound H has K <= count(u < H) <= 64 — those keys are gathered and ranked, the first K kept — or when all 32 bits are fixed: then T is the
+// K-th smallest key and ties at T enter in index order.  No barrier, no LDS atomics: DPP reductions, ballots and one 512-byte LDS slab per wave.
+struct TopEntry { int32_t tok; float lp; };   // tok: token id, bit 31 = the piece starts a word (TokInfo::boundary)
+
+struct TopArgs {
+    const float *logp; const int32_t *valid; const TokInfo *tok;
+    TopEntry *top; float *blank_lp;            // [utterance of the launch][frame][top_k], [utterance of the launch][frame]
+    int64_t row_stride, matrix_stride, rows;
+    int32_t frames, vocab, blank, top_k, first, use_lm;
+};
+
+__device__ __forceinline__ int wave_sum(int v) {   // total over the wavefront, in every lane's scalar copy
+    return __builtin_amdgcn_readlane(wave_incl_scan(v), 63);
+}
+__device__ __forceinline__ unsigned wave_and(unsigned v) { return ~wave_or(~v); }
+
+constexpr int kTopRegs = 17;   // keys per lane held in registers: rows of up to 1 088 tokens (Parakeet CTC: 1 025); longer rows are re-read (L2)
+
+template <int NREG>   // NREG > 0: the row's keys live in registers; 0: every pass reads the row again
+__global__ __launch_bounds__(kThreads) void ctc_topk_kernel(const TopArgs a) {
+    __shared__ unsigned long long slab[kThreads / 64][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t rowi = static_cast<int64_t>(blockIdx.x) * (kThreads / 64) + wave;
+    if (rowi >= a.rows) return;
+    const int ul = static_cast<int>(rowi / a.frames), t = static_cast<int>(rowi - static_cast<int64_t>(ul) * a.frames), u = a.first + ul;
+    if (a.valid) { const int v = a.valid[u]; if (t >= v) return; }
+    const float *row = a.logp + static_cast<int64_t>(u) * a.matrix_stride + static_cast<int64_t>(t) * a.row_stride;
+    const int V = a.vocab, K = a.top_k, blank = a.blank;
+    const bool has_blank = blank >= 0 && blank < V;
+    if (lane == 0) a.blank_lp[rowi] = has_blank ? row[blank] : -INFINITY;
+    const int npresent = V - (has_blank ? 1 : 0), ntop = npresent < K ? npresent : K;
+    if (ntop <= 0) return;
+    const int nj = (V + 63) >> 6;
+    auto present = [&](const int j) { const int i = lane + 64 * j; return i < V && i != blank; };
+    auto load_key = [&](const int j) -> unsigned { return present(j) ? ~ord_f32(row[lane + 64 * j]) : 0xffffffffu; };
+    unsigned reg[NREG > 0 ? NREG : 1];
+    if (NREG > 0) {
+#pragma unroll
+        for (int j = 0; j < NREG; ++j) reg[j] = load_key(j);
+    }
+    // f(j, key) over this lane's keys; absent positions carry 0xffffffff (never below any bound; `present` tells them from NaN)
+#define FA_TOP_EACH(BODY)                                                                                  \
+    if (NREG > 0) { _Pragma("unroll") for (int j = 0; j < NREG; ++j) { const unsigned key = reg[j]; BODY } } \
+    else { for (int j = 0; j < nj; ++j) { const unsigned key = load_key(j); BODY } }
+    unsigned bound = 0xffffffffu, tie = 0;   // selection: key < bound, plus (ties) the first `quota` present keys == tie in index order
+    int quota = 0;
+    if (npresent > 64) {
+        unsigned kand = 0xffffffffu, kor = 0;
+        FA_TOP_EACH(if (present(j)) { kand &= key; kor |= key; })
+        kand = wave_and(kand); kor = wave_or(kor);
+        const unsigned differ = kand ^ kor;
+        int b = differ ? 31 - __clz(static_cast<int>(differ)) : -1;          // highest bit in which two present keys differ
+        unsigned T = b >= 31 ? 0u : (b < 0 ? kor : (kor >> (b + 1)) << (b + 1));   // every present key is >= T: count(key < T) = 0
+        int below = 0;
+        bool found = false;
+        for (; b >= 0 && !found; --b) {
+            const unsigned cand = T | (1u << b);
+            int c = 0;
+            FA_TOP_EACH(c += key < cand ? 1 : 0;)
+            c = wave_sum(c);
+            if (c < K) { T = cand; below = c; }
+            else if (c <= 64) { bound = cand; found = true; }
+        }
+        if (!found) { bound = T; tie = T; quota = K - below; }                 // T = the K-th smallest key; absent keys never tie (`present`)
+    }
+    // gather the selected keys (<= 64) into the wave's slab as (key, index) words, then rank them
+    int cnt = 0, tcnt = 0;
+    FA_TOP_EACH({
+        const bool pr = present(j);
+        const bool is_tie = quota > 0 && pr && key == tie;
+        const unsigned long long tm = __ballot(is_tie);
+        const int trank = tcnt + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(tm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(tm), 0));
+        tcnt += __popcll(tm);
+        const bool sel = pr && (npresent <= 64 || key < bound || (is_tie && trank < quota));
+        const unsigned long long sm = __ballot(sel);
+        const int pos = cnt + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(sm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(sm), 0));
+        cnt += __popcll(sm);
+        if (sel && pos < 64) slab[wave][pos] = (static_cast<unsigned long long>(key) << 32) | static_cast<unsigned>(lane + 64 * j);
+    })
+#undef FA_TOP_EACH
+    cnt = cnt < 64 ? cnt : 64;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the slab is written by other lanes of this wavefront
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned long long mine = lane < cnt ? slab[wave][lane] : ~0ull;
+    int rank = 0;
+    for (int m = 0; m < cnt; ++m) rank += slab[wave][m] < mine ? 1 : 0;      // distinct words: the rank is a permutation
+    if (lane < cnt && rank < ntop) {
+        const int v = static_cast<int>(mine & 0xffffffffu);
+        TopEntry e;
+        e.tok = v | (a.use_lm && a.tok[v].boundary ? static_cast<int32_t>(0x80000000u) : 0);
+        e.lp = row[v];
+        a.top[rowi * K + rank] = e;
+    }
 }
 
 // One most-significant-digit selection over the keys a thread holds in registers: on return s.thr is a threshold such that the keys <= thr
@@ -363,7 +401,6 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
     const int u = a.first + blockIdx.x;
     int T = a.frames;
     if (a.valid) { const int v = a.valid[u]; T = v < 0 ? 0 : (v < T ? v : T); }
-    const float *mat = a.logp + static_cast<int64_t>(u) * a.matrix_stride;
     unsigned long long *arena = a.arena + static_cast<int64_t>(blockIdx.x) * a.arena_stride;
     const uint32_t arena_mask = static_cast<uint32_t>(a.arena_stride - 1);
     const int W = a.beam_width, K = a.top_k, V = a.vocab;
@@ -379,65 +416,27 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
     unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = clock64();
 #define BEAM_STAMP(i) do { if (a.prof) { const unsigned long long t_now = clock64(); t_acc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
     int cur = 0;
-    constexpr int kPre = 5;                                   // values per thread requested one frame ahead (covers V <= 1280)
-    const bool staged = V <= kMaxCand / 2;                    // the frame's 64-bit keys fit the candidate array
-    float pre[kPre];
-#pragma unroll
-    for (int j = 0; j < kPre; ++j) { const int i = tid + kThreads * j; pre[j] = T > 0 && i < V ? mat[i] : 0.0f; }
+    // ---- 1. the frame's top tokens, best first (sorted { frame[$0] > frame[$1] }, stable: ties by index): computed for all frames by
+    // ctc_topk_kernel; thread r carries entry r of the frame, requested one frame ahead so that its HBM latency hides behind the previous frame
+    const bool has_blank = a.blank >= 0 && a.blank < V;
+    const int ntop = min(K, V - (has_blank ? 1 : 0));
+    const TopEntry *top = a.top + static_cast<int64_t>(blockIdx.x) * a.frames * K;
+    const float *blank_row = a.blank_lp + static_cast<int64_t>(blockIdx.x) * a.frames;
+    TopEntry e_next = TopEntry{0, 0.0f};
+    float blank_next = -INFINITY;
+    if (T > 0) { if (tid < ntop) e_next = top[tid]; blank_next = blank_row[0]; }
     for (int t = 0; t < T; ++t) {
-        const float *frame = mat + static_cast<int64_t>(t) * a.row_stride;
         Beams &b = s.b[cur];
         Beams &nb = s.b[cur ^ 1];
         const int n = s.n_beams;
-        // ---- 1. top-K tokens, best first (sorted { frame[$0] > frame[$1] }, stable: ties by index) ----
-        // The frame's keys are staged in LDS once (over the candidate array, which is dead here) from values that were requested
-        // one frame earlier: every pass of the select reads LDS, and the HBM latency of a frame hides behind the previous frame.
         BEAM_STAMP(7);
-        unsigned long long *tkeys = reinterpret_cast<unsigned long long *>(s.cand_tot);
-        if (staged) {
-            if (tid == 0 && !(a.blank >= 0 && a.blank < V)) s.blank_lp = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < kPre; ++j) {
-                const int i = tid + kThreads * j;
-                if (i < V) { tkeys[i] = i == a.blank ? ~0ull : desc_key(pre[j], static_cast<uint32_t>(i)); if (i == a.blank) s.blank_lp = pre[j]; }
-            }
-            for (int i = tid + kThreads * kPre; i < V; i += kThreads) {
-                const float v = frame[i];
-                tkeys[i] = i == a.blank ? ~0ull : desc_key(v, static_cast<uint32_t>(i));
-                if (i == a.blank) s.blank_lp = v;
-            }
-            if (t + 1 < T) {
-#pragma unroll
-                for (int j = 0; j < kPre; ++j) { const int i = tid + kThreads * j; pre[j] = i < V ? frame[a.row_stride + i] : 0.0f; }
-            }
-            __syncthreads();
-        }
-        const float blank_lp = staged ? s.blank_lp : (a.blank >= 0 && a.blank < V ? frame[a.blank] : -INFINITY);
-        auto tok_key_direct = [&](const int i) -> unsigned long long { return i == a.blank ? ~0ull : desc_key(frame[i], static_cast<uint32_t>(i)); };
-        auto tok_key_lds = [&](const int i) -> unsigned long long { return tkeys[i]; };
-        int tok_sel;
-        if (V <= 5 * kThreads) tok_sel = select_sorted<5>(s, V, K, tok_key_lds);   // V <= 1 280 implies staged
-        else if (staged) tok_sel = select_sorted<(kMaxCand / 2 + kThreads - 1) / kThreads>(s, V, K, tok_key_lds);
-        else {
-            radix_select(s, V, K, kMaxBeam, tok_key_direct);
-            if (tid < kMaxBeam) s.sel_key[tid] = ~0ull;
-            if (tid == 0) s.sel_count = 0;
-            __syncthreads();
-            for (int i = tid; i < V; i += kThreads) {
-                const unsigned long long kk = tok_key_direct(i);
-                if (kk <= s.thr && kk != ~0ull) { const int p = atomicAdd(&s.sel_count, 1); if (p < kMaxBeam) s.sel_key[p] = kk; }
-            }
-            __syncthreads();
-            sort_selected(s);
-            tok_sel = min(s.sel_count, kMaxBeam);
-        }
-        BEAM_STAMP(0);
-        const int ntop = min(tok_sel, K);
+        const float blank_lp = blank_next;
         if (tid < ntop) {
-            const int v = static_cast<int>(s.sel_key[tid] & 0xffffffffu);
-            s.top_tok[tid] = v; s.top_lp[tid] = frame[v];
-            s.top_boundary[tid] = a.use_lm ? a.tok[v].boundary : 0;   // one table read per token and frame, not per candidate
+            s.top_tok[tid] = e_next.tok & 0x7fffffff; s.top_lp[tid] = e_next.lp;
+            s.top_boundary[tid] = static_cast<int32_t>(static_cast<uint32_t>(e_next.tok) >> 31);   // set by the pre-pass only with a language model
         }
+        if (t + 1 < T) { if (tid < ntop) e_next = top[static_cast<int64_t>(t + 1) * K + tid]; blank_next = blank_row[t + 1]; }
+        BEAM_STAMP(0);
         BEAM_STAMP(1);
         // ---- 2. maps over the live beams ----
         s.map_node[tid] = -2;
@@ -770,23 +769,41 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
     const int64_t per = a.arena_stride * static_cast<int64_t>(sizeof(unsigned long long));
     const int chunk = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(batch, (int64_t(2) << 30) / std::max<int64_t>(per, 1))));
     fa::DevBuf d_arena;
-    FA_HIP_TRY(ctx, d_arena.alloc(static_cast<size_t>(per) * chunk));
+    FA_HIP_TRY(ctx, d_arena.alloc(ctx, static_cast<size_t>(per) * chunk));   // the context's buffer cache: a second call pays no hipMalloc
     a.arena = d_arena.as<unsigned long long>();
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_beam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(Shared)));
     fa::DevBuf d_prof;
     if (getenv("FA_BEAM_PROF")) { FA_HIP_TRY(ctx, d_prof.alloc(128)); FA_HIP_TRY(ctx, hipMemsetAsync(d_prof.p, 0, 128, ctx->stream)); a.prof = d_prof.as<unsigned long long>(); }
+    // the pre-pass' tables of one launch: K (token, log-prob) pairs + the blank's log-prob per frame
+    fa::DevBuf d_top, d_blank;
+    const size_t rows_max = static_cast<size_t>(chunk) * std::max(frames, 1);
+    FA_HIP_TRY(ctx, d_top.alloc(ctx, sizeof(TopEntry) * rows_max * std::max(token_candidates, 1)));
+    FA_HIP_TRY(ctx, d_blank.alloc(ctx, sizeof(float) * rows_max));
+    a.top = d_top.as<TopEntry>(); a.blank_lp = d_blank.as<float>();
+    TopArgs ta{};
+    ta.logp = d_log_probs; ta.valid = d_valid_frames; ta.tok = a.tok; ta.top = d_top.as<TopEntry>(); ta.blank_lp = d_blank.as<float>();
+    ta.row_stride = row_stride; ta.matrix_stride = matrix_stride; ta.frames = frames; ta.vocab = vocab; ta.blank = blank_id;
+    ta.top_k = token_candidates; ta.use_lm = a.use_lm;
     for (int first = 0; first < batch; first += chunk) {
+        const int now = std::min(chunk, batch - first);
         a.first = first;
-        FA_HIP_TRY(ctx, hipMemsetAsync(d_arena.p, 0xff, static_cast<size_t>(per) * std::min(chunk, batch - first), ctx->stream));
-        hipLaunchKernelGGL(ctc_beam_kernel, dim3(std::min(chunk, batch - first)), dim3(kThreads), sizeof(Shared), ctx->stream, a);
+        FA_HIP_TRY(ctx, hipMemsetAsync(d_arena.p, 0xff, static_cast<size_t>(per) * now, ctx->stream));
+        if (frames > 0) {
+            ta.first = first; ta.rows = static_cast<int64_t>(now) * frames;
+            const unsigned blocks = static_cast<unsigned>((ta.rows + kThreads / 64 - 1) / (kThreads / 64));
+            if (vocab <= 64 * kTopRegs) hipLaunchKernelGGL(ctc_topk_kernel<kTopRegs>, dim3(blocks), dim3(kThreads), 0, ctx->stream, ta);
+            else hipLaunchKernelGGL(ctc_topk_kernel<0>, dim3(blocks), dim3(kThreads), 0, ctx->stream, ta);
+            FA_HIP_TRY(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL(ctc_beam_kernel, dim3(now), dim3(kThreads), sizeof(Shared), ctx->stream, a);
         FA_HIP_TRY(ctx, hipGetLastError());
     }
-    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the arena is freed on return
+    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the arena and the tables go back to the context's cache on return
     if (a.prof) {
         unsigned long long h[16];
         FA_HIP_TRY(ctx, hipMemcpy(h, d_prof.p, 128, hipMemcpyDeviceToHost));
         const double f = frames > 0 ? frames : 1;
-        fprintf(stderr, "beam profile (cycles per frame, workgroup 0): token select %.0f | token gather+sort %.0f | maps %.0f | candidates %.0f | prune select %.0f | "
+        fprintf(stderr, "beam profile (cycles per frame, workgroup 0): top-token table %.0f | - %.0f | maps %.0f | candidates %.0f | prune select %.0f | "
                         "prune gather+sort %.0f | new beams %.0f | loop head %.0f\n", h[0] / f, h[1] / f, h[2] / f, h[3] / f, h[4] / f, h[5] / f, h[6] / f, h[7] / f);
         fprintf(stderr, "  inside the prune selection: keys %.0f | selection over the per-thread minima %.0f | main selection %.0f | gather %.0f | rank sort %.0f\n",
                 h[8] / f, h[9] / f, h[10] / f, h[11] / f, h[12] / f);

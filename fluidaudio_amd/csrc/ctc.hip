@@ -34,11 +34,34 @@ struct CtcArgs {
     int32_t vector_ok;  // rows are 16-byte aligned and vocab is a multiple of the vector width
 };
 
-__device__ __forceinline__ float sanitize(float x) { return x != x ? -INFINITY : x; }  // NaN never wins
+
+// Every logit is read once: a nontemporal 16-byte load keeps the stream out of the way of the L2 / MALL lines other kernels of the context own.
+#ifndef FA_CTC_NT
+#define FA_CTC_NT 1
+#endif
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 stream_load(const uint4 *p) {
+#if FA_CTC_NT
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ float4 stream_load(const float4 *p) {
+#if FA_CTC_NT
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
 
 __device__ __forceinline__ void take(float x, int idx, float &best, int &bi) {
-    x = sanitize(x);
-    if (x > best) { best = x; bi = idx; }  // strict '>' => lowest index wins ties (CtcDecoder.swift:58-61)
+    const bool t = x > best;  // strict '>' => lowest index wins ties (CtcDecoder.swift:58-61); false for a NaN x, and best never becomes NaN
+    best = t ? x : best;
+    bi = t ? idx : bi;
 }
 
 __device__ __forceinline__ void wave_argmax(float &v, int &i) {
@@ -46,7 +69,9 @@ __device__ __forceinline__ void wave_argmax(float &v, int &i) {
     for (int off = 32; off > 0; off >>= 1) {
         const float ov = __shfl_xor(v, off);
         const int oi = __shfl_xor(i, off);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+        const bool t = (ov > v) | ((ov == v) & (oi < i));
+        v = t ? ov : v;
+        i = t ? oi : i;
     }
 }
 
@@ -61,7 +86,7 @@ __device__ __forceinline__ int row_argmax(const void *row_ptr, const int vocab, 
             const uint4 *r4 = reinterpret_cast<const uint4 *>(row);
             if (lane < nvec) bi = lane * 8;
             for (int i = lane; i < nvec; i += 64) {
-                const uint4 q = r4[i];
+                const uint4 q = stream_load(r4 + i);
                 const unsigned w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -80,7 +105,7 @@ __device__ __forceinline__ int row_argmax(const void *row_ptr, const int vocab, 
             const float4 *r4 = reinterpret_cast<const float4 *>(row);
             if (lane < nvec) bi = lane * 4;
             for (int i = lane; i < nvec; i += 64) {
-                const float4 q = r4[i];
+                const float4 q = stream_load(r4 + i);
                 take(q.x, 4 * i, best, bi);
                 take(q.y, 4 * i + 1, best, bi);
                 take(q.z, 4 * i + 2, best, bi);
@@ -94,6 +119,41 @@ __device__ __forceinline__ int row_argmax(const void *row_ptr, const int vocab, 
     wave_argmax(best, bi);
     return bi;  // all -inf/NaN row: every lane kept its first index, the minimum is 0
 }
+
+// R rows of one wavefront at a time (rows r, r + kWaves, ...): the R 16-byte loads of a step are issued back to back, so a wavefront keeps
+// R times the bytes in flight; every row is still scanned in the order of row_argmax (same winner, same tie rule).
+template <bool F16, int R>
+__device__ __forceinline__ void rows_argmax(const char *row0, const size_t step_bytes, const int vocab, const int lane, int (&bi)[R]) {
+    float best[R];
+    const int nvec = F16 ? vocab >> 3 : vocab >> 2;
+#pragma unroll
+    for (int k = 0; k < R; ++k) { best[k] = -INFINITY; bi[k] = lane < nvec ? lane * (F16 ? 8 : 4) : INT_MAX; }
+    for (int i = lane; i < nvec; i += 64) {
+        uint4 q[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) q[k] = stream_load(reinterpret_cast<const uint4 *>(row0 + k * step_bytes) + i);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const unsigned w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (F16) {
+                    take(__half2float(__ushort_as_half(static_cast<unsigned short>(w[e] & 0xffffu))), 8 * i + 2 * e, best[k], bi[k]);
+                    take(__half2float(__ushort_as_half(static_cast<unsigned short>(w[e] >> 16))), 8 * i + 2 * e + 1, best[k], bi[k]);
+                } else {
+                    take(__uint_as_float(w[e]), 4 * i + e, best[k], bi[k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) wave_argmax(best[k], bi[k]);
+}
+
+#ifndef FA_CTC_ROWS
+#define FA_CTC_ROWS 4  // A/B of 1 / 2 / 4 rows and of the load policy on MI355X: profiles/r04_ctc_ab.txt
+#endif
+constexpr int kRowsAtOnce = FA_CTC_ROWS;
 
 template <bool F16>
 __global__ __launch_bounds__(kThreads) void ctc_greedy_kernel(const CtcArgs a) {
@@ -116,7 +176,22 @@ __global__ __launch_bounds__(kThreads) void ctc_greedy_kernel(const CtcArgs a) {
     for (int c0 = 0; c0 < T; c0 += kChunk) {
         const int n = T - c0 < kChunk ? T - c0 : kChunk;
         // phase 1: one row per wavefront
-        for (int r = wave; r < n; r += kWaves) {
+        int r = wave;
+        if (kRowsAtOnce > 1 && a.vector_ok) {
+            const size_t step_bytes = static_cast<size_t>(kWaves) * a.row_stride * esz;
+            for (; r + (kRowsAtOnce - 1) * kWaves < n; r += kRowsAtOnce * kWaves) {
+                int bi[kRowsAtOnce];
+                rows_argmax<F16, kRowsAtOnce>(mat + static_cast<size_t>(c0 + r) * a.row_stride * esz, step_bytes, a.vocab, lane, bi);
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < kRowsAtOnce; ++k) {
+                        ids[r + k * kWaves] = bi[k];
+                        if (fids) fids[c0 + r + k * kWaves] = bi[k];
+                    }
+                }
+            }
+        }
+        for (; r < n; r += kWaves) {
             const char *row = mat + static_cast<size_t>(c0 + r) * a.row_stride * esz;
             const int bi = row_argmax<F16>(row, a.vocab, a.vector_ok != 0, lane);
             if (lane == 0) {

@@ -236,6 +236,26 @@ def test_reference_demo_cases_on_device(fa, gpu_ctx, oracle_mod):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,V,K,levels,seed", [(30, 200, 40, 6, 0), (20, 1025, 40, 3, 1), (16, 1025, 64, 40, 2), (10, 3000, 33, 4, 3), (25, 70, 64, 5, 4),
+                                               (12, 1088, 17, 2, 5), (8, 1089, 40, 2, 6)])
+def test_top_token_ties_follow_the_index(fa, gpu_ctx, oracle_mod, T, V, K, levels, seed):
+    """The frame's token candidates are `sorted { frame[$0] > frame[$1] }.prefix(tokenCandidates)` (CtcDecoder.swift:141-144, stable: equal
+    log-probabilities keep index order).  Log-probabilities quantised to a few levels — with runs of -inf — put hundreds of exact ties across
+    the K-th place of every frame; the pre-pass (ctc_topk_kernel, one wavefront per frame: registers up to 1 088 tokens, re-read rows above)
+    must offer the walk the same candidates in the same order as the restatement."""
+    rng = np.random.default_rng(100 + seed)
+    blank = V - 1 if seed % 2 == 0 else 3
+    x = -rng.integers(1, levels + 1, size=(2, T, V)).astype(np.float32) * 0.75
+    x[rng.random((2, T, V)) < 0.1] = -np.inf
+    x[:, :, blank] = -1.0
+    x[0, T // 2, :] = -2.0                                              # one frame with every token tied
+    ids, scores = fa.ctc_beam_search_ids_batch(x, None, None, 12, 0.0, 0.0, blank, K, ctx=gpu_ctx)
+    for b in range(2):
+        want, total = oracle_mod.ctc_beam_search(x[b], {}, None, 12, 0.0, 0.0, blank, K)
+        assert ids[b] == want, (b, ids[b], want)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("T,V,W_,K,peaky,use_lm,seed", [(40, 12, 4, 3, 2.0, False, 0), (60, 33, 8, 6, 3.0, True, 1), (25, 9, 16, 8, 1.0, True, 2),
                                                        (120, 70, 10, 40, 4.0, True, 3), (80, 40, 100, 40, 2.5, False, 4), (30, 300, 5, 64, 3.0, True, 5),
                                                        (50, 17, 128, 16, 0.5, True, 6), (90, 6, 3, 5, 0.7, True, 7), (200, 8, 6, 4, 1.0, True, 8),
