@@ -36,7 +36,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxBeam = 128;
 constexpr int kMaxTop = 64;
-constexpr int kMaxCand = kMaxBeam * (kMaxTop + 1);
 constexpr int kMapSlots = 256;
 constexpr uint64_t kHashBase = 0x100000001b3ull;   // odd: multiplication by it is a bijection mod 2^64
 constexpr float kUnkLogProb = -23.026f;            // ARPALanguageModel.unkLogProb (:33)
@@ -81,6 +80,35 @@ __host__ __device__ inline float lm_score(const LmView &lm, uint64_t hw, int32_t
     return backoff + uni;
 }
 
+// The same score on the device with the three first probes (bigram, context unigram, word unigram) requested together: they are dependent
+// HBM / L2 round trips on the serial frame walk, and the bigram usually misses.  Collisions continue with the sequential probes above.
+__device__ inline float lm_score_dev(const LmView &lm, uint64_t hw, int32_t lw, uint64_t hp, int32_t plen) {
+    if (!lm.uni) return lm_score(lm, hw, lw, hp, plen);
+    const uint32_t sw = static_cast<uint32_t>(mix64(hw + static_cast<uint64_t>(lw))) & lm.uni_mask;
+    const UniEntry ew = lm.uni[sw];
+    if (plen < 0) {
+        if (!ew.used) return kUnkLogProb;                       // backoff 0 + unknown word
+        if (ew.h == hw && ew.len == lw) return 0.0f + ew.logp;
+        return lm_score(lm, hw, lw, hp, plen);
+    }
+    const uint32_t sp = static_cast<uint32_t>(mix64(hp + static_cast<uint64_t>(plen))) & lm.uni_mask;
+    const UniEntry ep = lm.uni[sp];
+    bool bi_known = !lm.bi, bi_hit = false;
+    float bi_logp = 0.0f;
+    if (lm.bi) {
+        const uint32_t sb = static_cast<uint32_t>(mix64(mix64(hp + static_cast<uint64_t>(plen)) ^ (hw + static_cast<uint64_t>(lw) * 0x9e3779b97f4a7c15ull))) & lm.bi_mask;
+        const BiEntry eb = lm.bi[sb];
+        if (!eb.used) bi_known = true;
+        else if (eb.hp == hp && eb.hw == hw && eb.lp == plen && eb.lw == lw) { bi_known = true; bi_hit = true; bi_logp = eb.logp; }
+    }
+    const bool w_known = !ew.used || (ew.h == hw && ew.len == lw), p_known = !ep.used || (ep.h == hp && ep.len == plen);
+    if (!(bi_known && w_known && p_known)) return lm_score(lm, hw, lw, hp, plen);   // a first slot held another key: probe on
+    if (bi_hit) return bi_logp;
+    const float backoff = ep.used ? ep.backoff : 0.0f;
+    const float uni = ew.used ? ew.logp : kUnkLogProb;
+    return backoff + uni;
+}
+
 inline void hash_bytes(const char *s, size_t n, uint64_t &h, uint64_t &mult) {
     h = 0; mult = 1;
     for (size_t i = 0; i < n; ++i) { h = h * kHashBase + static_cast<unsigned char>(s[i]); mult *= kHashBase; }
@@ -106,9 +134,11 @@ __device__ __forceinline__ float log_add_exp(float a, float b) {   // CtcDecoder
     return static_cast<float>(static_cast<double>(m) + log(sum));
 }
 
+struct TopEntry { int32_t tok; float lp; };   // tok: token id, bit 31 = the piece starts a word (TokInfo::boundary)
+
 struct Beams {   // structure of arrays in LDS
     int32_t node[kMaxBeam], parent[kMaxBeam], last[kMaxBeam], wlen[kMaxBeam], plen[kMaxBeam];
-    float pb[kMaxBeam], pnb[kMaxBeam], lm[kMaxBeam], wscore[kMaxBeam];
+    float pb[kMaxBeam], pnb[kMaxBeam], tot[kMaxBeam], lm[kMaxBeam], wscore[kMaxBeam];   // tot = logAddExp(pb, pnb) = totalAcoustic (:83), carried along
     uint64_t wh[kMaxBeam], ph[kMaxBeam];
 };
 
@@ -120,22 +150,23 @@ struct BeamArgs {
     int32_t frames, vocab, blank, beam_width, top_k, use_lm, first;
     float lm_weight, word_bonus;
     unsigned long long *prof;   // FA_BEAM_PROF (diagnostics): cycles per step of workgroup 0, thread 0
-    const struct TopEntry *top; const float *blank_lp;   // the pre-pass' tables (ctc_topk_kernel): [workgroup][frame][top_k], [workgroup][frame]
+    const TopEntry *top;   // the pre-pass' table (ctc_topk_kernel): [workgroup][frame][top_k + 1]
 };
 
 struct Shared {
     Beams b[2];
-    float cand_tot[kMaxCand];
-    unsigned short cand_ord[kMaxCand];   // tie-break order of a candidate (its index, or the merged position for a beam's own slot)
-    int32_t stay_ord[kMaxBeam]; float stay_pb[kMaxBeam], stay_pnb[kMaxBeam], tot[kMaxBeam];
-    int32_t top_tok[kMaxTop], top_boundary[kMaxTop]; float top_lp[kMaxTop];
+    float stay_pb[kMaxBeam], stay_pnb[kMaxBeam], stay_tot[kMaxBeam];      // slot 0 of every beam: its blank / repeat parts and their logAddExp
+    TopEntry top_e[kMaxTop];                                               // the frame's top tokens (padded behind the last one with NaN log-probs)
+    int32_t top_len[kMaxTop];
+    unsigned long long top_mult[kMaxTop], top_add[kMaxTop];                // word-hash step of a top token (TokInfo)
+    unsigned long long cancel[kMaxBeam];                                   // bit r: extension r of the beam was merged into a live beam's slot 0
+    unsigned long long wave_sel[kThreads / 64][kMaxBeam];                  // level 1 of the selection: each wavefront's best keys
     unsigned long long sel_key[kMaxBeam];
-    int32_t rank_hi[kMaxBeam], wave_total[4];
-    int32_t hist2[2][256];
+    int32_t rank_hi[kMaxBeam], wave_cnt[kThreads / 64];
     int32_t map_node[kMapSlots], map_node_val[kMapSlots];
     int32_t map_pl_parent[kMapSlots], map_pl_tok[kMapSlots], map_pl_val[kMapSlots];
-    unsigned long long thr, all_and, all_or;
-    int32_t sel_count, bin, remaining, done, n_beams;
+    int32_t sel_count, n_beams;
+    float blank_lp;
 };
 
 // OR over the wavefront of a 32-bit word (DPP row shifts + row broadcasts; lane 63 holds the result)
@@ -183,11 +214,10 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 // search over the bits of u, from the first bit in which the row's keys differ, keeps T with count(u < T) < K; it stops as soon as a tested
 // bound H has K <= count(u < H) <= 64 — those keys are gathered and ranked, the first K kept — or when all 32 bits are fixed: then T is the
 // K-th smallest key and ties at T enter in index order.  No barrier, no LDS atomics: DPP reductions, ballots and one 512-byte LDS slab per wave.
-struct TopEntry { int32_t tok; float lp; };   // tok: token id, bit 31 = the piece starts a word (TokInfo::boundary)
 
 struct TopArgs {
     const float *logp; const int32_t *valid; const TokInfo *tok;
-    TopEntry *top; float *blank_lp;            // [utterance of the launch][frame][top_k], [utterance of the launch][frame]
+    TopEntry *top;                             // [utterance of the launch][frame][top_k + 1]: the K best tokens, then (lp) the blank's log-probability
     int64_t row_stride, matrix_stride, rows;
     int32_t frames, vocab, blank, top_k, first, use_lm;
 };
@@ -210,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void ctc_topk_kernel(const TopArgs a) {
     const float *row = a.logp + static_cast<int64_t>(u) * a.matrix_stride + static_cast<int64_t>(t) * a.row_stride;
     const int V = a.vocab, K = a.top_k, blank = a.blank;
     const bool has_blank = blank >= 0 && blank < V;
-    if (lane == 0) a.blank_lp[rowi] = has_blank ? row[blank] : -INFINITY;
+    if (lane == 0) a.top[rowi * (K + 1) + K] = TopEntry{0, has_blank ? row[blank] : -INFINITY};
     const int npresent = V - (has_blank ? 1 : 0), ntop = npresent < K ? npresent : K;
     if (ntop <= 0) return;
     const int nj = (V + 63) >> 6;
@@ -273,131 +303,105 @@ __global__ __launch_bounds__(kThreads) void ctc_topk_kernel(const TopArgs a) {
         TopEntry e;
         e.tok = v | (a.use_lm && a.tok[v].boundary ? static_cast<int32_t>(0x80000000u) : 0);
         e.lp = row[v];
-        a.top[rowi * K + rank] = e;
+        a.top[rowi * (K + 1) + rank] = e;
     }
 }
 
-// One most-significant-digit selection over the keys a thread holds in registers: on return s.thr is a threshold such that the keys <= thr
-// are the `k` smallest plus at most `room - k` more (everything, if fewer than k keys are present).  All threads must call it.
-//   * the first digit starts at the first bit in which the present keys differ (AND / OR of all keys), not at a byte boundary: the first
-//     histogram already spreads over up to 256 bins (log-probabilities of one frame share sign and most of the exponent; byte-aligned
-//     digits sent every key to ONE bin — 64 lanes on one LDS address, the slowest thing the LDS does);
-//   * the passes stop as soon as the keys below the threshold bin plus the bin itself fit into `room`;
-//   * wave 0 finds the threshold bin with a DPP prefix sum (a ds_bpermute scan costs ~1 000 cycles per pass);
-//   * two histograms alternate, so the next one is cleared while the current one is filled: two barriers per pass.
-template <int MAXK>
-__device__ void select_threshold(Shared &s, const unsigned long long (&keys)[MAXK], const int k, const int room) {
-    const int tid = threadIdx.x;
-    if (tid == 0) { s.done = 0; s.remaining = k; s.all_and = ~0ull; s.all_or = 0; s.thr = 0; }
-    s.hist2[0][tid] = 0;
-    __syncthreads();
-    {
-        unsigned long long kand = ~0ull, kor = 0;
+// ---------------------------------------------------------------------------------------------- selection of the beam width's best candidates
+// The candidates of a frame never touch LDS: the two threads of a beam compute its extension totals straight into 64-bit keys in registers
+// (value descending, candidate order ascending; ~0 = absent), and the W smallest keys are found in two wave-level steps without histograms:
+//   level 1: every wavefront bounds ITS keys — a binary search over the key bits from the first bit in which they differ keeps T with
+//            count(key < T) < W and stops at the first tested bound with W <= count <= 128 (DPP sums, no barrier, no LDS atomics) — and
+//            gathers the <= 128 keys below the bound by ballot prefix sums;
+//   level 2: wavefront 0 does the same over the <= 4 x 128 gathered keys (8 per lane) and leaves <= 128 keys in s.sel_key;
+//   then the rank sort above.  The W best of the whole frame are among the per-wave W best, so the result is the one of a full selection.
+// (Rounds 2-3: candidate totals through LDS arrays, two 8-bit radix selections over LDS histograms, ~20 barriers: 22 300 cycles per frame.)
+// A key is two 32-bit words (kh: value, descending; kl: candidate order); absent = both ~0 (a present key's value word is never ~0: that would
+// be a NaN total, and those are dropped).
+struct KeyBound { unsigned h, l; };   // the keys below (h, l) are selected
+
+template <int NK>
+__device__ __forceinline__ KeyBound wave_bound(const unsigned (&kh)[NK], const unsigned (&kl)[NK], const int k) {
+    int pc = 0;                                                          // per-lane counts (v_cmp + v_addc), one DPP sum per step: counting
+#pragma unroll                                                           // through ballots serialises on the VALU -> SALU latency (870 cycles per step)
+    for (int j = 0; j < NK; ++j) pc += kh[j] != ~0u ? 1 : 0;
+    pc = wave_sum(pc);
+    if (pc <= kMaxBeam) return KeyBound{~0u, ~0u};                      // everything present fits the gather buffer
+    unsigned ah = ~0u, al = ~0u, oh = 0, ol = 0;
 #pragma unroll
-        for (int j = 0; j < MAXK; ++j) if (keys[j] != ~0ull) { kand &= keys[j]; kor |= keys[j]; }
-        const unsigned ah = ~wave_or(~static_cast<unsigned>(kand >> 32)), al = ~wave_or(~static_cast<unsigned>(kand));
-        const unsigned oh = wave_or(static_cast<unsigned>(kor >> 32)), ol = wave_or(static_cast<unsigned>(kor));
-        if ((tid & 63) == 0) { atomicAnd(&s.all_and, (static_cast<unsigned long long>(ah) << 32) | al); atomicOr(&s.all_or, (static_cast<unsigned long long>(oh) << 32) | ol); }
-    }
-    __syncthreads();
-    const unsigned long long differ = s.all_and ^ s.all_or;                 // 0: at most one distinct key present
-    int hi = differ ? 64 - __clzll(static_cast<long long>(differ)) : 1;     // the present keys agree on every bit at or above `hi`
-    unsigned long long prefix = hi < 64 ? s.all_or >> hi : 0ull;
-    for (int pass = 0; hi > 0; ++pass) {
-        const int width = hi < 8 ? hi : 8, shift = hi - width;
-        int32_t *hist = s.hist2[pass & 1];
-        s.hist2[(pass + 1) & 1][tid] = 0;
+    for (int j = 0; j < NK; ++j) { const bool pr = kh[j] != ~0u; ah &= kh[j]; al &= pr ? kl[j] : ~0u; oh |= pr ? kh[j] : 0u; ol |= pr ? kl[j] : 0u; }
+    ah = wave_and(ah); oh = wave_or(oh);
+    const unsigned dh = ah ^ oh;
+    unsigned Th = oh;
+    if (dh) {                                                            // binary search over the value word, from the first bit in which the keys differ
+        int b = 31 - __clz(static_cast<int>(dh));
+        Th = b >= 31 ? 0u : (oh >> (b + 1)) << (b + 1);
+        for (; b >= 0; --b) {
+            const unsigned cand = Th | (1u << b);
+            int c = 0;
 #pragma unroll
-        for (int j = 0; j < MAXK; ++j) {
-            const unsigned long long kk = keys[j];
-            if (kk != ~0ull && (hi >= 64 || (kk >> hi) == prefix)) atomicAdd(&hist[(kk >> shift) & ((1u << width) - 1u)], 1);
-        }
-        __syncthreads();
-        if (tid < 64) {   // wave 0: bin where the running count reaches `remaining`
-            const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-            const int mine = h0 + h1 + h2 + h3;
-            const int incl = wave_incl_scan(mine);
-            const int excl = incl - mine, need = s.remaining;
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            if (excl < need && need <= incl) {
-                int c = excl, b = 4 * tid;
-                if (c + h0 >= need) { } else { c += h0; b += 1; if (c + h1 >= need) { } else { c += h1; b += 1; if (c + h2 >= need) { } else { c += h2; b += 1; } } }
-                const int hb = b == 4 * tid ? h0 : (b == 4 * tid + 1 ? h1 : (b == 4 * tid + 2 ? h2 : h3));
-                s.bin = b;
-                s.remaining = need - c;
-                // the whole bin belongs to the selection, or everything up to and including it fits the caller's room
-                if (hb == need - c || shift == 0 || (k - need) + c + hb <= room) s.done = 1;
-            }
-            if (tid == 0 && total < need) { s.bin = (1 << width) - 1; s.done = 2; }   // fewer than k keys present: take everything
-        }
-        __syncthreads();
-        prefix = (prefix << width) | static_cast<unsigned>(s.bin);
-        hi = shift;
-        if (s.done) {
-            const unsigned long long low = shift ? ((1ull << shift) - 1) : 0ull;
-            if (tid == 0) s.thr = s.done == 2 ? ~0ull - 1 : ((prefix << shift) | low);
-            break;
+            for (int j = 0; j < NK; ++j) c += kh[j] < cand ? 1 : 0;
+            c = wave_sum(c);
+            if (c < k) Th = cand;
+            else if (c <= kMaxBeam) return KeyBound{cand, 0u};
         }
     }
-    __syncthreads();
+    // rare: the k-th place falls inside a run of equal values (Th) — or more than 128 keys share it: the order word decides
+    al = wave_and(al); ol = wave_or(ol);
+    const unsigned dl = dh ? ~0u : (al ^ ol);                            // != 0: more than 128 distinct keys
+    int b = 31 - __clz(static_cast<int>(dl));
+    unsigned Tl = b >= 31 ? 0u : (ol >> (b + 1)) << (b + 1);
+    for (; b >= 0; --b) {
+        const unsigned cand = Tl | (1u << b);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) c += (kh[j] < Th) | ((kh[j] == Th) & (kl[j] < cand)) ? 1 : 0;
+        c = wave_sum(c);
+        if (c < k) Tl = cand;
+        else if (c <= kMaxBeam) return KeyBound{Th, cand};
+    }
+    return KeyBound{Th, Tl + 1u};   // all bits fixed: the keys are distinct, (Th, Tl) is the k-th smallest and exactly k keys lie below (Th, Tl + 1)
 }
 
-// The k smallest of n <= 256 MAXK distinct keys, SORTED, in s.sel_key[0 .. count) (count >= min(k, present keys), at most kMaxBeam; the
-// caller keeps the first k).  Every thread computes its keys ONCE into registers (key() costs LDS reads and float ops).  With many keys per
-// thread a first selection runs over the 256 per-thread MINIMA only: the k-th smallest of those is an upper bound of the k-th smallest key,
-// so everything above it leaves the main selection — ~2 k survivors instead of 4 160 keys hammering the LDS histogram.
-template <int MAXK, class KeyFn>
-__device__ int select_sorted(Shared &s, const int n, const int k, KeyFn key, unsigned long long *acc = nullptr) {
-    const int tid = threadIdx.x;
-    unsigned long long t_prev = acc ? clock64() : 0;
-#define SEL_STAMP(i) do { if (acc) { const unsigned long long t_now = clock64(); acc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
-    unsigned long long keys[MAXK];
+// gathers this wavefront's keys below `bound` into dst[0 ..), lane after lane (their order does not matter: they are sorted later): every lane
+// counts its own, one DPP prefix sum gives its first position
+template <int NK>
+__device__ __forceinline__ int wave_gather(const unsigned (&kh)[NK], const unsigned (&kl)[NK], const KeyBound bound, unsigned long long *dst) {
+    bool sel[NK];
+    int mine = 0;
 #pragma unroll
-    for (int j = 0; j < MAXK; ++j) { const int i = tid + kThreads * j; keys[j] = i < n ? key(i) : ~0ull; }
-    if (tid < kMaxBeam) s.sel_key[tid] = ~0ull;
-    if (tid == 0) s.sel_count = 0;
-    if (k <= 0) { __syncthreads(); return 0; }
-    SEL_STAMP(0);
-    if (MAXK >= 8) {
-        unsigned long long lo[1] = {~0ull};
-#pragma unroll
-        for (int j = 0; j < MAXK; ++j) lo[0] = keys[j] < lo[0] ? keys[j] : lo[0];
-        select_threshold<1>(s, lo, k, kMaxBeam);
-        const unsigned long long bound = s.thr;
-        __syncthreads();                                   // s.thr is rewritten by the main selection
-#pragma unroll
-        for (int j = 0; j < MAXK; ++j) if (keys[j] > bound) keys[j] = ~0ull;
-    }
-    SEL_STAMP(1);
-    select_threshold<MAXK>(s, keys, k, kMaxBeam);
-    SEL_STAMP(2);
-    const unsigned long long thr = s.thr;
-    int mine = 0;                                            // positions by prefix sums (wave scan + the four wave totals), no atomics
-#pragma unroll
-    for (int j = 0; j < MAXK; ++j) mine += keys[j] <= thr && keys[j] != ~0ull ? 1 : 0;
+    for (int j = 0; j < NK; ++j) { sel[j] = (kh[j] < bound.h) | ((kh[j] == bound.h) & (kl[j] < bound.l)); mine += sel[j] ? 1 : 0; }   // bound (~0, ~0): every present key
     const int incl = wave_incl_scan(mine);
-    if ((tid & 63) == 63) s.wave_total[tid >> 6] = incl;
-    __syncthreads();
     int pos = incl - mine;
-    for (int w = 0; w < (tid >> 6); ++w) pos += s.wave_total[w];
-    if (tid == kThreads - 1) s.sel_count = pos + mine;
 #pragma unroll
-    for (int j = 0; j < MAXK; ++j)
-        if (keys[j] <= thr && keys[j] != ~0ull) { if (pos < kMaxBeam) s.sel_key[pos] = keys[j]; ++pos; }
-    __syncthreads();
-    SEL_STAMP(3);
-    sort_selected(s);
-    SEL_STAMP(4);
-#undef SEL_STAMP
-    return min(s.sel_count, kMaxBeam);
+    for (int j = 0; j < NK; ++j) {
+        if (sel[j] && pos < kMaxBeam) dst[pos] = (static_cast<unsigned long long>(kh[j]) << 32) | kl[j];
+        pos += sel[j] ? 1 : 0;
+    }
+    const int cnt = __builtin_amdgcn_readlane(incl, 63);
+    return cnt < kMaxBeam ? cnt : kMaxBeam;
 }
 
-__device__ __forceinline__ uint32_t slot_of(uint32_t a, uint32_t b) { return static_cast<uint32_t>(mix64((static_cast<uint64_t>(a) << 32) | b)) & (kMapSlots - 1); }
+// value word of a key: ~ord_f32(x) for a non-NaN x (larger total, smaller word)
+__device__ __forceinline__ unsigned desc_word(const float x) {
+    const unsigned u = __float_as_uint(x);
+    return u ^ (static_cast<unsigned>(~static_cast<int>(u) >> 31) & 0x7fffffffu);
+}
 
+// slot of a 64-bit key (a, b) in the 256-slot LDS maps: 32-bit multiplies only (the maps compare whole keys, the hash only spreads them)
+__device__ __forceinline__ uint32_t slot_of(uint32_t a, uint32_t b) {
+    uint32_t h = a * 0x9e3779b1u ^ b * 0x85ebca77u;
+    h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+    return h & (kMapSlots - 1);
+}
+
+constexpr int kOrdShift = 7;   // candidate order = beam << 7 | slot (slot 0 = the beam itself, 1 + r = its extension by top token r): beam-major, token-minor
+
+// MAXE: extension keys per thread = ceil(top tokens / 2)
+template <int MAXE, bool PROF>   // PROF: FA_BEAM_PROF cycle stamps (their 16 accumulators cost 32 registers)
 __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Shared &s = *reinterpret_cast<Shared *>(smem_raw);
-    const int tid = threadIdx.x;
+    __shared__ Shared s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = a.first + blockIdx.x;
     int T = a.frames;
     if (a.valid) { const int v = a.valid[u]; T = v < 0 ? 0 : (v < T ? v : T); }
@@ -408,48 +412,102 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
     if (tid == 0) {
         Beams &b = s.b[0];
         b.node[0] = -1; b.parent[0] = -3; b.last[0] = -1; b.wlen[0] = 0; b.plen[0] = -1;
-        b.pb[0] = 0.0f; b.pnb[0] = -INFINITY; b.lm[0] = 0.0f; b.wscore[0] = 0.0f; b.wh[0] = 0; b.ph[0] = 0;
+        b.pb[0] = 0.0f; b.pnb[0] = -INFINITY; b.tot[0] = 0.0f; b.lm[0] = 0.0f; b.wscore[0] = 0.0f; b.wh[0] = 0; b.ph[0] = 0;
         s.n_beams = 1;
     }
     __syncthreads();
 
     unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = clock64();
-#define BEAM_STAMP(i) do { if (a.prof) { const unsigned long long t_now = clock64(); t_acc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+#define BEAM_STAMP(i) do { if (PROF) { const unsigned long long t_now = clock64(); t_acc[i] += t_now - t_prev; t_prev = t_now; } } while (0)
     int cur = 0;
-    // ---- 1. the frame's top tokens, best first (sorted { frame[$0] > frame[$1] }, stable: ties by index): computed for all frames by
-    // ctc_topk_kernel; thread r carries entry r of the frame, requested one frame ahead so that its HBM latency hides behind the previous frame
+    // the frame's top tokens, best first (sorted { frame[$0] > frame[$1] }, stable: ties by index; CtcDecoder.swift:141-144): computed for all
+    // frames by ctc_topk_kernel; thread r carries entry r of the frame, requested one frame ahead so that its HBM latency hides behind the frame
     const bool has_blank = a.blank >= 0 && a.blank < V;
     const int ntop = min(K, V - (has_blank ? 1 : 0));
-    const TopEntry *top = a.top + static_cast<int64_t>(blockIdx.x) * a.frames * K;
-    const float *blank_row = a.blank_lp + static_cast<int64_t>(blockIdx.x) * a.frames;
+    // (entry K of a frame is the blank's log-probability, carried by thread 64: a per-lane request like the others — as a scalar load it would
+    // share the LDS' counter, and the frame's first LDS wait would sit out its HBM latency)
+    const TopEntry *top = a.top + static_cast<int64_t>(blockIdx.x) * a.frames * (K + 1);
+    const bool carries = tid < ntop || tid == kMaxTop;
+    const int my_entry = tid == kMaxTop ? K : tid;
     TopEntry e_next = TopEntry{0, 0.0f};
-    float blank_next = -INFINITY;
-    if (T > 0) { if (tid < ntop) e_next = top[tid]; blank_next = blank_row[0]; }
+    if (T > 0 && carries) e_next = top[my_entry];
+    const int bi = tid >> 1, h = tid & 1;                                // this thread's beam and which half of its extensions
+    // The trie node of a NEW beam (thread = its rank) is found / inserted by an atomic in HBM: a dependent round trip of ~1.5 us on the serial walk.
+    // Nothing needs the node before the next frame's maps, so the atomic is issued LAST in step 5 and its answer is collected in the next frame
+    // behind the extension keys (which need no nodes): the round trip travels under a barrier, the top-token table and the key arithmetic.
+    bool pend = false;
+    uint32_t pend_q = 0;
+    unsigned long long pend_seen = 0, pend_nk = 0;
+    auto resolve_node = [&](Beams &bb) {
+        if (pend) {
+            while (pend_seen != ~0ull && pend_seen != pend_nk) { pend_q = (pend_q + 1) & arena_mask; pend_seen = atomicCAS(&arena[pend_q], ~0ull, pend_nk); }
+            bb.node[tid] = static_cast<int>(pend_q);
+            pend = false;
+        }
+    };
     for (int t = 0; t < T; ++t) {
         Beams &b = s.b[cur];
         Beams &nb = s.b[cur ^ 1];
         const int n = s.n_beams;
-        BEAM_STAMP(7);
-        const float blank_lp = blank_next;
-        if (tid < ntop) {
-            s.top_tok[tid] = e_next.tok & 0x7fffffff; s.top_lp[tid] = e_next.lp;
-            s.top_boundary[tid] = static_cast<int32_t>(static_cast<uint32_t>(e_next.tok) >> 31);   // set by the pre-pass only with a language model
+        // ---- 1. top-token table of the frame into LDS; empty maps ----
+        TokInfo ti_mine = TokInfo{1, 0, 0, 0};
+        if (tid < kMaxTop) {
+            TopEntry e = e_next;
+            if (tid >= ntop) { e.tok = 0x7ffffffe; e.lp = __uint_as_float(0x7fc00000u); }   // padding: equals no beam's last token; NaN total = absent candidate
+            s.top_e[tid] = e;
+            if (a.use_lm && tid < ntop) ti_mine = a.tok[e.tok & 0x7fffffff];   // the word-hash step of the token: used by step 5, most of a frame of latency cover
         }
-        if (t + 1 < T) { if (tid < ntop) e_next = top[static_cast<int64_t>(t + 1) * K + tid]; blank_next = blank_row[t + 1]; }
-        BEAM_STAMP(0);
-        BEAM_STAMP(1);
-        // ---- 2. maps over the live beams ----
+        if (tid == kMaxTop) s.blank_lp = e_next.lp;
+        if (t + 1 < T && carries) e_next = top[static_cast<int64_t>(t + 1) * (K + 1) + my_entry];
         s.map_node[tid] = -2;
         s.map_pl_parent[tid] = -4;
-        if (tid < n) s.tot[tid] = log_add_exp(b.pb[tid], b.pnb[tid]);   // totalAcoustic (:83)
+        if (tid < kMaxBeam) s.cancel[tid] = 0ull;
         __syncthreads();
+        BEAM_STAMP(0);
+        // ---- 2. extension keys (threads 2 i, 2 i + 1: beam i); maps over the live beams (thread i: beam i) ----
+        unsigned kh[MAXE + 1], kl[MAXE + 1];                            // this thread's candidate keys: extensions 2 q + h of its beam, then (h = 0) the beam itself
+        int r_last = -1;                                                 // the top token equal to the beam's last token (at most one)
+        int my_last = -1;
+        float my_tot = 0.0f, my_lm = 0.0f;
+        if (bi < n) {
+            my_last = b.last[bi];
+            my_tot = b.tot[bi]; my_lm = b.lm[bi];
+            const float my_pb = b.pb[bi];
+            const float lm_word = b.wlen[bi] > 0 ? my_lm + b.wscore[bi] : my_lm;   // a word is completed by a boundary piece (:185-189)
+            TopEntry e[MAXE];
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q) e[q] = s.top_e[2 * q + h];    // all requested before the first is used; padded entries give NaN totals
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q) {
+                const int r = 2 * q + h;
+                const bool repeat = (e[q].tok & 0x7fffffff) == my_last;
+                r_last = repeat ? r : r_last;
+                const float pnb = (repeat ? my_pb : my_tot) + e[q].lp;                           // (:196-214)
+                const float total = pnb + (e[q].tok < 0 ? lm_word : my_lm);
+                const bool ok = total == total;
+                kh[q] = ok ? desc_word(total) : ~0u;
+                kl[q] = ok ? static_cast<unsigned>((bi << kOrdShift) | (1 + r)) : ~0u;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q) { kh[q] = ~0u; kl[q] = ~0u; }
+        }
+        kh[MAXE] = ~0u; kl[MAXE] = ~0u;
+        resolve_node(b);                                                 // this thread's beam got its trie node (requested at the end of the previous frame)
         if (tid < n) {
-            for (uint32_t q = slot_of(static_cast<uint32_t>(b.node[tid]), 0x51u);; q = (q + 1) & (kMapSlots - 1))
-                if (atomicCAS(&s.map_node[q], -2, b.node[tid]) == -2) { s.map_node_val[q] = tid; break; }
-            for (uint32_t q = slot_of(static_cast<uint32_t>(b.parent[tid]), static_cast<uint32_t>(b.last[tid]));; q = (q + 1) & (kMapSlots - 1))
-                if (atomicCAS(&s.map_pl_parent[q], -4, b.parent[tid]) == -4) { s.map_pl_tok[q] = b.last[tid]; s.map_pl_val[q] = tid; break; }
+            const int node = b.node[tid], par = b.parent[tid], last = b.last[tid];
+            for (uint32_t q = slot_of(static_cast<uint32_t>(node), 0x51u);; q = (q + 1) & (kMapSlots - 1))
+                if (atomicCAS(&s.map_node[q], -2, node) == -2) { s.map_node_val[q] = tid; break; }
+            for (uint32_t q = slot_of(static_cast<uint32_t>(par), static_cast<uint32_t>(last));; q = (q + 1) & (kMapSlots - 1))
+                if (atomicCAS(&s.map_pl_parent[q], -4, par) == -4) { s.map_pl_tok[q] = last; s.map_pl_val[q] = tid; break; }
+        }
+        {   // the pair's two halves agree on r_last (quad_perm 1,0,3,2: the neighbour lane)
+            const int other = __builtin_amdgcn_update_dpp(-1, r_last, 0xB1, 0xf, 0xf, false);
+            r_last = r_last > other ? r_last : other;
         }
         __syncthreads();
+        BEAM_STAMP(2);
+        // ---- 3. the beam itself (slot 0): blank + repeated token, merged with the extension of the live beam one token shorter ----
         auto find_node = [&](const int node) {
             for (uint32_t q = slot_of(static_cast<uint32_t>(node), 0x51u);; q = (q + 1) & (kMapSlots - 1)) {
                 const int k = s.map_node[q];
@@ -464,102 +522,114 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
                 if (k == parent && s.map_pl_tok[q] == tok) return s.map_pl_val[q];
             }
         };
-        // ---- 3. candidate totals; candidate c = i (K + 1) + slot, slot 0 = the beam itself, slot 1 + r = beam + top token r ----
-        BEAM_STAMP(2);
-        const int stride = ntop + 1, ncand = n * stride;
-        // extensions first (pure arithmetic, every thread busy), then slot 0 of every beam, one thread per beam: that path evaluates
-        // logAddExp in double and knows which extension merges into it — the extension (p, r) of the live beam p that is one token
-        // shorter — so it cancels that candidate itself instead of every one of the n x ntop extensions probing the (parent, token) map
-        for (int e = tid; e < n * ntop; e += kThreads) {
-            const int i = e / ntop, r = e - i * ntop, c = i * stride + 1 + r, v = s.top_tok[r];
-            s.cand_ord[c] = static_cast<unsigned short>(c);
-            const float pnb = (v == b.last[i] ? b.pb[i] : s.tot[i]) + s.top_lp[r];      // (:196-214)
-            float lm = b.lm[i];
-            if (s.top_boundary[r] && b.wlen[i] > 0) lm = lm + b.wscore[i];               // a word is completed (:185-189)
-            s.cand_tot[c] = pnb + lm;
-        }
-        __syncthreads();
-        if (tid < n) {
-            const int i = tid, c = i * stride;
+        if (bi < n && h == 0) {
             float pnb = -INFINITY;
-            int ord = c, r = -1;
-            const int last = b.last[i];
-            for (int q = 0; q < ntop; ++q) if (s.top_tok[q] == last) r = q;
-            if (r >= 0) {
-                pnb = b.pnb[i] + s.top_lp[r];                                        // same prefix, repeated token (:190-194)
-                const int p = b.parent[i] != -3 ? find_node(b.parent[i]) : -1;       // the beam one token shorter extends into this one
+            uint32_t ord = static_cast<uint32_t>(bi << kOrdShift);
+            if (r_last >= 0) {
+                const float lp = s.top_e[r_last].lp;
+                pnb = b.pnb[bi] + lp;                                                // same prefix, repeated token (:190-194)
+                const int par = b.parent[bi];
+                const int p = par != -3 ? find_node(par) : -1;                       // the beam one token shorter extends into this one
                 if (p >= 0) {
-                    const float from_parent = (b.last[p] == last ? b.pb[p] : s.tot[p]) + s.top_lp[r];
+                    const float from_parent = (b.last[p] == my_last ? b.pb[p] : b.tot[p]) + lp;
                     pnb = log_add_exp(pnb, from_parent);
-                    ord = min(ord, p * stride + 1 + r);
-                    s.cand_tot[p * stride + 1 + r] = NAN;                            // merged into this beam's slot 0
+                    const uint32_t merged = static_cast<uint32_t>((p << kOrdShift) | (1 + r_last));
+                    ord = merged < ord ? merged : ord;                               // a merged hypothesis takes the earlier position
+                    atomicOr(&s.cancel[p], 1ull << r_last);                          // that extension is this candidate now
                 }
             }
-            const float pb = s.tot[i] + blank_lp;                                    // blank extension (:172-176)
-            s.stay_pb[i] = pb; s.stay_pnb[i] = pnb; s.stay_ord[i] = ord;
-            s.cand_tot[c] = log_add_exp(pb, pnb) + b.lm[i];
-            s.cand_ord[c] = static_cast<unsigned short>(ord);
+            const float pb = my_tot + s.blank_lp;                                    // blank extension (:172-176)
+            const float stay = log_add_exp(pb, pnb);
+            s.stay_pb[bi] = pb; s.stay_pnb[bi] = pnb; s.stay_tot[bi] = stay;
+            const float total = stay + my_lm;
+            if (total == total) { kh[MAXE] = desc_word(total); kl[MAXE] = ord; }
         }
         __syncthreads();
-        // ---- 4. prune: W best totals, earlier candidate first on ties ----
-        auto cand_key = [&](const int c) -> unsigned long long {
-            const float v = s.cand_tot[c];
-            return v != v ? ~0ull : desc_key(v, s.cand_ord[c]);
-        };
         BEAM_STAMP(3);
-        const int cand_sel = select_sorted<(kMaxCand + kThreads - 1) / kThreads>(s, ncand, W, cand_key, a.prof ? t_acc + 8 : nullptr);
+        // ---- 4. prune: W best totals, earlier candidate first on ties ----
+        if (bi < n) {
+            const unsigned long long gone = s.cancel[bi] >> h;
+            const unsigned g0 = static_cast<unsigned>(gone), g1 = static_cast<unsigned>(gone >> 32);   // 32-bit tests (64-bit compares run at quarter rate)
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q) {
+                const bool c = (((2 * q < 32 ? g0 >> ((2 * q) & 31) : g1 >> ((2 * q - 32) & 31)) & 1u) != 0u);
+                kh[q] = c ? ~0u : kh[q]; kl[q] = c ? ~0u : kl[q];
+            }
+        }
+        BEAM_STAMP(8);
+        {
+            const KeyBound bound = wave_bound<MAXE + 1>(kh, kl, W);
+            BEAM_STAMP(9);
+            const int cnt = wave_gather<MAXE + 1>(kh, kl, bound, s.wave_sel[wave]);
+            if (lane == 0) s.wave_cnt[wave] = cnt;
+        }
+        BEAM_STAMP(10);
+        if (a.use_lm && tid < ntop) { s.top_mult[tid] = ti_mine.mult; s.top_add[tid] = ti_mine.add; s.top_len[tid] = ti_mine.len; }   // requested in step 1
+        __syncthreads();
         BEAM_STAMP(4);
-        const int nsel = min(cand_sel, W);
+        if (wave == 0) {
+            constexpr int N2 = 2 * (kThreads / 64);
+            unsigned h2[N2], l2[N2];
+#pragma unroll
+            for (int j = 0; j < N2; ++j) {
+                const int w = j >> 1, idx = lane + 64 * (j & 1);
+                const unsigned long long kk = idx < s.wave_cnt[w] ? s.wave_sel[w][idx] : ~0ull;
+                h2[j] = static_cast<unsigned>(kk >> 32); l2[j] = static_cast<unsigned>(kk);
+            }
+            const KeyBound bound = wave_bound<N2>(h2, l2, W);
+            const int cnt = wave_gather<N2>(h2, l2, bound, s.sel_key);
+            for (int i = cnt + lane; i < kMaxBeam; i += 64) s.sel_key[i] = ~0ull;
+            if (lane == 0) s.sel_count = cnt;
+        }
+        __syncthreads();
         BEAM_STAMP(5);
+        sort_selected(s);
+        const int nsel = min(s.sel_count, W);
+        BEAM_STAMP(6);
         // ---- 5. survivors -> new beams (rank = sorted position) ----
         if (tid < nsel) {
             const unsigned ord = static_cast<unsigned>(s.sel_key[tid] & 0xffffffffu);
-            // recover the candidate: order values of extensions are their own index; a beam's slot 0 may carry a parent-extension order
-            int c = static_cast<int>(ord);
-            int i = c / stride, slot = c - i * stride;
+            // recover the candidate: order values of extensions are their own; a beam's slot 0 may carry the order of the extension merged into it
+            int i = static_cast<int>(ord >> kOrdShift), slot = static_cast<int>(ord & ((1u << kOrdShift) - 1u));
             if (slot != 0) {
-                const int j = find_child(b.node[i], s.top_tok[slot - 1]);
+                const int j = find_child(b.node[i], s.top_e[slot - 1].tok & 0x7fffffff);
                 if (j >= 0) { i = j; slot = 0; }                                         // it was the merged position of beam j
             }
             if (slot == 0) {
                 nb.node[tid] = b.node[i]; nb.parent[tid] = b.parent[i]; nb.last[tid] = b.last[i];
-                nb.pb[tid] = s.stay_pb[i]; nb.pnb[tid] = s.stay_pnb[i]; nb.lm[tid] = b.lm[i];
+                nb.pb[tid] = s.stay_pb[i]; nb.pnb[tid] = s.stay_pnb[i]; nb.tot[tid] = s.stay_tot[i]; nb.lm[tid] = b.lm[i];
                 nb.wlen[tid] = b.wlen[i]; nb.plen[tid] = b.plen[i]; nb.wh[tid] = b.wh[i]; nb.ph[tid] = b.ph[i]; nb.wscore[tid] = b.wscore[i];
             } else {
-                const int r = slot - 1, v = s.top_tok[r];
+                const int r = slot - 1, v = s.top_e[r].tok & 0x7fffffff;
                 // canonical trie node of (prefix of beam i) + v: find or insert; at most frames x beam_width nodes, table twice that
                 const unsigned long long nk = (static_cast<unsigned long long>(static_cast<uint32_t>(b.node[i])) << 32) | static_cast<uint32_t>(v);
-                int node;
-                for (uint32_t q = static_cast<uint32_t>(mix64(nk)) & arena_mask;; q = (q + 1) & arena_mask) {
-                    const unsigned long long seen = atomicCAS(&arena[q], ~0ull, nk);
-                    if (seen == ~0ull || seen == nk) { node = static_cast<int>(q); break; }
-                }
-                const float tot_i = s.tot[i];
-                nb.node[tid] = node; nb.parent[tid] = b.node[i]; nb.last[tid] = v;
-                nb.pb[tid] = -INFINITY;
-                nb.pnb[tid] = (v == b.last[i] ? b.pb[i] : tot_i) + s.top_lp[r];
+                const float pnb = (v == b.last[i] ? b.pb[i] : b.tot[i]) + s.top_e[r].lp;
+                nb.parent[tid] = b.node[i]; nb.last[tid] = v;
+                nb.pb[tid] = -INFINITY; nb.pnb[tid] = pnb; nb.tot[tid] = pnb;           // logAddExp(-inf, x) = x
                 float lm = b.lm[i], ws = 0.0f;
                 uint64_t wh = b.wh[i], ph = b.ph[i];
                 int wlen = b.wlen[i], plen = b.plen[i];
                 if (a.use_lm) {
-                    const TokInfo ti = a.tok[v];
-                    if (ti.boundary) {                                                   // (:183-194)
+                    if (s.top_e[r].tok < 0) {                                            // a boundary piece (:183-194)
                         if (wlen > 0) { lm = lm + b.wscore[i]; ph = wh; plen = wlen; }
-                        wh = ti.add; wlen = ti.len;
-                    } else { wh = wh * ti.mult + ti.add; wlen += ti.len; }               // wordPieces.append(piece) (:195-197)
-                    if (wlen > 0) ws = a.lm_weight * lm_score(a.lm, wh, wlen, ph, plen) + a.word_bonus;
+                        wh = s.top_add[r]; wlen = s.top_len[r];
+                    } else { wh = wh * s.top_mult[r] + s.top_add[r]; wlen += s.top_len[r]; }   // wordPieces.append(piece) (:195-197)
+                    if (wlen > 0) ws = a.lm_weight * lm_score_dev(a.lm, wh, wlen, ph, plen) + a.word_bonus;
                 }
                 nb.lm[tid] = lm; nb.wscore[tid] = ws; nb.wh[tid] = wh; nb.ph[tid] = ph; nb.wlen[tid] = wlen; nb.plen[tid] = plen;
+                pend = true; pend_nk = nk; pend_q = static_cast<uint32_t>(mix64(nk)) & arena_mask;   // behind the model's probes: memory answers in order
+                pend_seen = atomicCAS(&arena[pend_q], ~0ull, nk);
             }
         }
-        __syncthreads();
         if (tid == 0) s.n_beams = nsel;
         cur ^= 1;
         __syncthreads();
-        BEAM_STAMP(6);
+        BEAM_STAMP(7);
     }
-    if (a.prof && blockIdx.x == 0 && tid == 0 && a.first == 0) for (int i = 0; i < 16; ++i) a.prof[i] = t_acc[i];
+    if (PROF && a.prof && blockIdx.x == 0 && tid == 0 && a.first == 0) for (int i = 0; i < 16; ++i) a.prof[i] = t_acc[i];
 #undef BEAM_STAMP
+    resolve_node(s.b[cur]);
+    __syncthreads();
 
     // ---- finalize: trailing partial word (:222-229), first maximum in rank order, read the prefix back from the trie ----
     if (tid == 0) {
@@ -569,7 +639,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(const BeamArgs a) {
         for (int i = 0; i < s.n_beams; ++i) {
             float lm = b.lm[i];
             if (a.use_lm && b.wlen[i] > 0) lm = lm + b.wscore[i];
-            const float total = log_add_exp(b.pb[i], b.pnb[i]) + lm;
+            const float total = b.tot[i] + lm;
             if (best < 0 || total > best_total) { best = i; best_total = total; }
         }
         int32_t *out = a.tokens + static_cast<int64_t>(u) * a.frames;
@@ -771,17 +841,15 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
     fa::DevBuf d_arena;
     FA_HIP_TRY(ctx, d_arena.alloc(ctx, static_cast<size_t>(per) * chunk));   // the context's buffer cache: a second call pays no hipMalloc
     a.arena = d_arena.as<unsigned long long>();
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_beam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(Shared)));
     fa::DevBuf d_prof;
     if (getenv("FA_BEAM_PROF")) { FA_HIP_TRY(ctx, d_prof.alloc(128)); FA_HIP_TRY(ctx, hipMemsetAsync(d_prof.p, 0, 128, ctx->stream)); a.prof = d_prof.as<unsigned long long>(); }
-    // the pre-pass' tables of one launch: K (token, log-prob) pairs + the blank's log-prob per frame
-    fa::DevBuf d_top, d_blank;
+    // the pre-pass' table of one launch: K (token, log-prob) pairs + the blank's log-prob per frame
+    fa::DevBuf d_top;
     const size_t rows_max = static_cast<size_t>(chunk) * std::max(frames, 1);
-    FA_HIP_TRY(ctx, d_top.alloc(ctx, sizeof(TopEntry) * rows_max * std::max(token_candidates, 1)));
-    FA_HIP_TRY(ctx, d_blank.alloc(ctx, sizeof(float) * rows_max));
-    a.top = d_top.as<TopEntry>(); a.blank_lp = d_blank.as<float>();
+    FA_HIP_TRY(ctx, d_top.alloc(ctx, sizeof(TopEntry) * rows_max * (token_candidates + 1)));
+    a.top = d_top.as<TopEntry>();
     TopArgs ta{};
-    ta.logp = d_log_probs; ta.valid = d_valid_frames; ta.tok = a.tok; ta.top = d_top.as<TopEntry>(); ta.blank_lp = d_blank.as<float>();
+    ta.logp = d_log_probs; ta.valid = d_valid_frames; ta.tok = a.tok; ta.top = d_top.as<TopEntry>();
     ta.row_stride = row_stride; ta.matrix_stride = matrix_stride; ta.frames = frames; ta.vocab = vocab; ta.blank = blank_id;
     ta.top_k = token_candidates; ta.use_lm = a.use_lm;
     for (int first = 0; first < batch; first += chunk) {
@@ -795,7 +863,13 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
             else hipLaunchKernelGGL(ctc_topk_kernel<0>, dim3(blocks), dim3(kThreads), 0, ctx->stream, ta);
             FA_HIP_TRY(ctx, hipGetLastError());
         }
-        hipLaunchKernelGGL(ctc_beam_kernel, dim3(now), dim3(kThreads), sizeof(Shared), ctx->stream, a);
+        const int ntop = std::min(token_candidates, vocab - (blank_id >= 0 && blank_id < vocab ? 1 : 0));   // extension keys per thread = ceil(ntop / 2)
+        if (a.prof && ntop <= 16) hipLaunchKernelGGL((ctc_beam_kernel<8, true>), dim3(now), dim3(kThreads), 0, ctx->stream, a);
+        else if (a.prof && ntop <= 40) hipLaunchKernelGGL((ctc_beam_kernel<20, true>), dim3(now), dim3(kThreads), 0, ctx->stream, a);
+        else if (a.prof) hipLaunchKernelGGL((ctc_beam_kernel<32, true>), dim3(now), dim3(kThreads), 0, ctx->stream, a);
+        else if (ntop <= 16) hipLaunchKernelGGL((ctc_beam_kernel<8, false>), dim3(now), dim3(kThreads), 0, ctx->stream, a);
+        else if (ntop <= 40) hipLaunchKernelGGL((ctc_beam_kernel<20, false>), dim3(now), dim3(kThreads), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((ctc_beam_kernel<32, false>), dim3(now), dim3(kThreads), 0, ctx->stream, a);
         FA_HIP_TRY(ctx, hipGetLastError());
     }
     FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the arena and the tables go back to the context's cache on return
@@ -803,10 +877,9 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
         unsigned long long h[16];
         FA_HIP_TRY(ctx, hipMemcpy(h, d_prof.p, 128, hipMemcpyDeviceToHost));
         const double f = frames > 0 ? frames : 1;
-        fprintf(stderr, "beam profile (cycles per frame, workgroup 0): top-token table %.0f | - %.0f | maps %.0f | candidates %.0f | prune select %.0f | "
-                        "prune gather+sort %.0f | new beams %.0f | loop head %.0f\n", h[0] / f, h[1] / f, h[2] / f, h[3] / f, h[4] / f, h[5] / f, h[6] / f, h[7] / f);
-        fprintf(stderr, "  inside the prune selection: keys %.0f | selection over the per-thread minima %.0f | main selection %.0f | gather %.0f | rank sort %.0f\n",
-                h[8] / f, h[9] / f, h[10] / f, h[11] / f, h[12] / f);
+        fprintf(stderr, "beam profile (cycles per frame, workgroup 0): top-token table + empty maps %.0f | maps + extension keys %.0f | slot 0 of the beams %.0f | "
+                        "selection level 1 %.0f (cancelled extensions %.0f, bound %.0f, gather %.0f, barrier %.0f) | level 2 %.0f | rank sort %.0f | new beams %.0f\n",
+                h[0] / f, h[2] / f, h[3] / f, (h[4] + h[8] + h[9] + h[10]) / f, h[8] / f, h[9] / f, h[10] / f, h[4] / f, h[5] / f, h[6] / f, h[7] / f);
     }
     return FA_SUCCESS;
 }
