@@ -237,7 +237,7 @@ def test_reference_demo_cases_on_device(fa, gpu_ctx, oracle_mod):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,V,K,levels,seed", [(30, 200, 40, 6, 0), (20, 1025, 40, 3, 1), (16, 1025, 64, 40, 2), (10, 3000, 33, 4, 3), (25, 70, 64, 5, 4),
-                                               (12, 1088, 17, 2, 5), (8, 1089, 40, 2, 6)])
+                                               (12, 1088, 17, 2, 5), (8, 1089, 40, 2, 6), (9, 12, 0, 3, 7), (9, 64, 64, 2, 8), (6, 65, 64, 2, 9)])
 def test_top_token_ties_follow_the_index(fa, gpu_ctx, oracle_mod, T, V, K, levels, seed):
     """The frame's token candidates are `sorted { frame[$0] > frame[$1] }.prefix(tokenCandidates)` (CtcDecoder.swift:141-144, stable: equal
     log-probabilities keep index order).  Log-probabilities quantised to a few levels — with runs of -inf — put hundreds of exact ties across
