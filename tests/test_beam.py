@@ -236,6 +236,24 @@ def test_reference_demo_cases_on_device(fa, gpu_ctx, oracle_mod):
 
 
 @pytest.mark.gpu
+def test_batches_beyond_one_trie_allocation_are_walked_in_pieces(fa, gpu_ctx):
+    """The prefix tries of a launch are capped at 2 GiB: 2 049 frames x beam 128 need 8 MB per utterance, so 258 utterances go through TWO launches
+    (256 + 2), each with its own top-token pre-pass and table.  Utterances on both sides of the cut must decode exactly as they do alone."""
+    rng = np.random.default_rng(77)
+    B, T, V, blank = 258, 2049, 5, 4
+    x = rng.standard_normal((B, T, V)).astype(np.float32)
+    x = (x - np.log(np.exp(x.astype(np.float64)).sum(2, keepdims=True))).astype(np.float32)
+    valid = [T] * B
+    valid[255] = T - 7
+    valid[257] = 11
+    ids, scores = fa.ctc_beam_search_ids_batch(x, None, None, 128, 0.0, 0.0, blank, 3, valid_frames=valid, ctx=gpu_ctx)
+    for b in (0, 255, 256, 257):
+        one, sc = fa.ctc_beam_search_ids_batch(x[b:b + 1], None, None, 128, 0.0, 0.0, blank, 3, valid_frames=valid[b:b + 1], ctx=gpu_ctx)
+        assert ids[b] == one[0] and (len(ids[b]) > 0 or b == 257), b
+        assert scores[b] == sc[0]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("T,V,K,levels,seed", [(30, 200, 40, 6, 0), (20, 1025, 40, 3, 1), (16, 1025, 64, 40, 2), (10, 3000, 33, 4, 3), (25, 70, 64, 5, 4),
                                                (12, 1088, 17, 2, 5), (8, 1089, 40, 2, 6), (9, 12, 0, 3, 7), (9, 64, 64, 2, 8), (6, 65, 64, 2, 9)])
 def test_top_token_ties_follow_the_index(fa, gpu_ctx, oracle_mod, T, V, K, levels, seed):
