@@ -11,8 +11,8 @@
 //      pruned and later re-created gets the SAME node — and two observations replace the dictionary: an extension
 //      (beam i, token v) can only collide with the ONE live beam whose (parent node, last token) is (node i, v), and never
 //      with another extension.  Two 256-slot LDS hash maps (node -> beam, (parent, token) -> beam) answer both questions;
-//   3. pruning to the beam width: most-significant-digit radix select on (total descending, candidate order ascending) keys, then a
-//      rank sort of the <= 128 survivors;
+//   3. pruning to the beam width: the candidates are (total descending, candidate order ascending) keys in registers; every wavefront
+//      bounds its own by a binary search over the key bits, wavefront 0 repeats that over the gathered ones; rank sort of the <= 128 survivors;
 //   4. survivors become the new beams; new prefixes get trie nodes, and — when a language model is attached — their
 //      running word (a polynomial hash of its bytes, built from per-token (multiplier, addend) pairs) is scored once
 //      against the unigram / bigram hash tables in HBM, so a frame costs at most beamWidth table probes.
@@ -120,7 +120,6 @@ __device__ __forceinline__ uint32_t ord_f32(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-__device__ __forceinline__ uint64_t desc_key(float value, uint32_t order) { return (static_cast<uint64_t>(~ord_f32(value)) << 32) | order; }
 
 // max + log(exp(a - max) + exp(b - max)) evaluated in double and rounded to float.  exp(0) is exactly 1, so the sum is 1 + exp(-|a - b|)
 // (one exp); and when |a - b| > 18.1 the correction log1p(exp(-d)) < 1.4e-8 is below half an ulp of any |max| >= 1, so the rounded
