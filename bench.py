@@ -207,10 +207,11 @@ def ahc_batch_leg(fa, ctx, recordings=16, n=5400, d=256, speakers=8):
             "note": "host-pointer entries (PCIe copies included); n embeddings = n/3 two-second windows of 3 local speaker slots"}
 
 
-def ctc_leg(fa, ctx, torch, dist, rank, world, total, steps=3, dtype="f32"):
+def ctc_leg(fa, ctx, torch, dist, rank, world, total, steps=3, dtype="f32", vocab=1024):
     """BASELINE configs[3]: `total` matrices [1500, 1024] fp32 sharded over the ranks (contiguous slices, no data-path
-    collective); every rank times its own passes, the slowest rank sets the rate; token ids gather on rank 0 (RCCL)."""
-    T, V = 1500, 1024
+    collective); every rank times its own passes, the slowest rank sets the rate; token ids gather on rank 0 (RCCL).
+    vocab = 1025 is the shape Parakeet CTC really emits (1 024 tokens + blank): rows whose alignment rotates with the frame index."""
+    T, V = 1500, vocab
     lo, hi = fa.shard_range(total, rank, world)
     batch = hi - lo
     g = torch.Generator(device="cuda").manual_seed(7 + rank)
@@ -270,8 +271,8 @@ def ctc_leg(fa, ctx, torch, dist, rank, world, total, steps=3, dtype="f32"):
             rows_exact = rows_exact and bool(np.array_equal(got, ref))
     del fid
     traffic, tsrc = measured_traffic_of("*_ctc_pmc.json", CTC_SOURCES)
-    if half:
-        traffic, tsrc = None, {"file": None, "note": "the PMC pass ran the fp32 launch"}
+    if half or V != 1024:
+        traffic, tsrc = None, {"file": None, "note": "the PMC pass ran the fp32 launch of [1500, 1024] matrices"}
     if traffic is not None:
         traffic = traffic * batch / 10000.0          # the PMC pass runs the 10 000-matrix launch; per launch of this rank's share
     out = {"matrices": total, "matrices_per_rank": batch, "T": T, "V": V, "dtype": dtype, "ms_per_pass": ms, "wall_ms_per_pass": 1e3 * wall,
@@ -280,7 +281,7 @@ def ctc_leg(fa, ctx, torch, dist, rank, world, total, steps=3, dtype="f32"):
            "roofline": {"bound": "hbm", "achieved": gbs_rank, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_rank / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                         "algorithmic_bytes_per_launch": batch * bytes_per_matrix, "note": "per GPU (slowest rank)"},
            "mean_tokens_per_matrix": float(lens.float().mean()), "gather_token_ids_s": t_gather, "gathered_rows_on_rank0": gathered}
-    if world == 1 and not half:   # the row kernel next to it (§8f-3): log-softmax with temperature / blank bias, one read + one write of the matrix
+    if world == 1 and not half and V == 1024:   # the row kernel next to it (§8f-3): log-softmax with temperature / blank bias, one read + one write of the matrix
         try:
             sub = x[: min(batch, 2500)]
             o = torch.empty_like(sub)
@@ -1129,6 +1130,8 @@ def main():
     if solo and not args.skip_ctc:
         try:
             line["ctc_fp16"] = ctc_leg(fa, ctx, torch, None, 0, 1, args.ctc_matrices, dtype="f16")
+            for name, dt in (("ctc_v1025", "f32"), ("ctc_v1025_fp16", "f16")):   # the shape the model really emits: rows of any alignment (head + body + tail path)
+                line[name] = ctc_leg(fa, ctx, torch, None, 0, 1, min(args.ctc_matrices, 4000), dtype=dt, vocab=1025)
         except Exception as e:  # noqa: BLE001
             line["ctc_fp16"] = {"error": repr(e)}
         torch.cuda.empty_cache()
@@ -1201,6 +1204,8 @@ def main():
         "mel_roofline_frac": pick("mel", "roofline", "frac"), "mel_realtime_factor": pick("mel", "realtime_factor"),
         "ctc_roofline_frac": pick("ctc", "roofline", "frac"), "ctc_ids_exact": pick("ctc", "ids_exact"),
         "ctc_fp16_roofline_frac": pick("ctc_fp16", "roofline", "frac"),
+        "ctc_v1025_roofline_frac": pick("ctc_v1025", "roofline", "frac"),
+        "ctc_v1025_fp16_roofline_frac": pick("ctc_v1025_fp16", "roofline", "frac"),
         "resample_44k1_roofline_frac": pick("resample", "44100->16000", "roofline", "frac"),
         "tdt_roofline_frac": pick("tdt", "roofline", "frac"),
         "vbx_sharded_all_ranks_same_elbos": pick("vbx_sharded", "all_ranks_same_elbos"),

@@ -32,6 +32,7 @@ struct CtcArgs {
     int64_t row_stride, matrix_stride;
     int32_t frames, vocab, blank_id;
     int32_t vector_ok;  // rows are 16-byte aligned and vocab is a multiple of the vector width
+    int32_t elem_ok;    // the matrices are aligned to their element type and a row holds two vectors or more: rows of any alignment take the head + 16-byte body + tail path
 };
 
 
@@ -150,12 +151,75 @@ __device__ __forceinline__ void rows_argmax(const char *row0, const size_t step_
     for (int k = 0; k < R; ++k) wave_argmax(best[k], bi[k]);
 }
 
+// The same for rows that do NOT start on a 16-byte boundary or whose length is no multiple of the vector width — the common case in practice:
+// Parakeet CTC logits are [T, 1025] (1 024 tokens + blank), so the alignment of a row rotates with its index.  A row is its head (the < 16 bytes up
+// to the next boundary, lanes 0 ..), its 16-byte body with streaming loads, and its tail (< 16 bytes); a lane meets its elements in ascending index
+// order, so the strict '>' keeps the first maximum as before.  (Until round 4 such rows took 4-byte loads, one row per wavefront.)
+template <bool F16, int R>
+__device__ __forceinline__ void rows_argmax_any(const char *row0, const size_t step_bytes, const int vocab, const int lane, int (&bi)[R]) {
+    constexpr int VW = F16 ? 8 : 4, ESZ = F16 ? 2 : 4;
+    // one element, unconverted: requested with a clamped index by EVERY lane (a load under a lane mask would be waited for on the spot)
+    auto raw = [](const char *p, const int idx) -> unsigned {
+        return F16 ? static_cast<unsigned>(reinterpret_cast<const unsigned short *>(p)[idx]) : reinterpret_cast<const unsigned *>(p)[idx];
+    };
+    auto value = [](const unsigned bits) -> float { return F16 ? __half2float(__ushort_as_half(static_cast<unsigned short>(bits))) : __uint_as_float(bits); };
+    float best[R];
+    unsigned hv[R], tv[R];
+    int head[R], nvec[R], nv_max = 0;
+    // the head and tail elements of all R rows are requested before anything is looked at
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const char *p = row0 + k * step_bytes;
+        int h = static_cast<int>(((16u - static_cast<unsigned>(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u) / ESZ);
+        h = h < vocab ? h : vocab;
+        head[k] = h; nvec[k] = (vocab - h) / VW;
+        nv_max = nvec[k] > nv_max ? nvec[k] : nv_max;
+        best[k] = -INFINITY; bi[k] = INT_MAX;
+        hv[k] = raw(p, lane < h ? lane : 0);
+        const int t0 = h + VW * nvec[k];
+        tv[k] = raw(p, t0 + lane < vocab ? t0 + lane : vocab - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) take(lane < head[k] ? value(hv[k]) : -INFINITY, lane, best[k], bi[k]);   // (-inf never wins: lanes without a head element keep their state)
+    for (int i = lane; i < nv_max; i += 64) {
+        uint4 q[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k)   // clamped, not masked (nvec >= 1: vocab >= 2 VW on this path)
+            q[k] = stream_load(reinterpret_cast<const uint4 *>(row0 + k * step_bytes + head[k] * ESZ) + (i < nvec[k] ? i : nvec[k] - 1));
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            if (i >= nvec[k]) continue;
+            const unsigned w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+            const int base = head[k] + VW * i;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (F16) {
+                    take(__half2float(__ushort_as_half(static_cast<unsigned short>(w[e] & 0xffffu))), base + 2 * e, best[k], bi[k]);
+                    take(__half2float(__ushort_as_half(static_cast<unsigned short>(w[e] >> 16))), base + 2 * e + 1, best[k], bi[k]);
+                } else {
+                    take(__uint_as_float(w[e]), base + e, best[k], bi[k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int ti = head[k] + VW * nvec[k] + lane;
+        take(ti < vocab ? value(tv[k]) : -INFINITY, ti, best[k], bi[k]);
+        wave_argmax(best[k], bi[k]);
+        bi[k] = bi[k] == INT_MAX ? 0 : bi[k];   // nothing above -inf (or all NaN): index 0, as row_argmax
+    }
+}
+
 #ifndef FA_CTC_ROWS
 #define FA_CTC_ROWS 4  // A/B of 1 / 2 / 4 rows and of the load policy on MI355X: profiles/r04_ctc_ab.txt
 #endif
 constexpr int kRowsAtOnce = FA_CTC_ROWS;
 
-template <bool F16>
+// MODE 0: aligned rows of whole vectors; 1: rows of any alignment (head + body + tail); 2: 4-/2-byte loads (misaligned matrices, rows shorter than
+// two vectors).  Separate builds: the any-alignment path needs 117 registers, the aligned one 74 — sharing a kernel cost it two wavefronts per SIMD
+// (fp16: 82.6 -> 75.8 % of the HBM roofline).
+template <bool F16, int MODE>
 __global__ __launch_bounds__(kThreads) void ctc_greedy_kernel(const CtcArgs a) {
     __shared__ int32_t ids[kChunk];
     __shared__ int32_t wave_tot[kWaves];
@@ -177,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void ctc_greedy_kernel(const CtcArgs a) {
         const int n = T - c0 < kChunk ? T - c0 : kChunk;
         // phase 1: one row per wavefront
         int r = wave;
-        if (kRowsAtOnce > 1 && a.vector_ok) {
+        if (kRowsAtOnce > 1 && MODE == 0) {
             const size_t step_bytes = static_cast<size_t>(kWaves) * a.row_stride * esz;
             for (; r + (kRowsAtOnce - 1) * kWaves < n; r += kRowsAtOnce * kWaves) {
                 int bi[kRowsAtOnce];
@@ -191,9 +255,25 @@ __global__ __launch_bounds__(kThreads) void ctc_greedy_kernel(const CtcArgs a) {
                 }
             }
         }
+        if (kRowsAtOnce > 1 && MODE == 1) {
+            const size_t step_bytes = static_cast<size_t>(kWaves) * a.row_stride * esz;
+            for (; r + (kRowsAtOnce - 1) * kWaves < n; r += kRowsAtOnce * kWaves) {
+                int bi[kRowsAtOnce];
+                rows_argmax_any<F16, kRowsAtOnce>(mat + static_cast<size_t>(c0 + r) * a.row_stride * esz, step_bytes, a.vocab, lane, bi);
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < kRowsAtOnce; ++k) {
+                        ids[r + k * kWaves] = bi[k];
+                        if (fids) fids[c0 + r + k * kWaves] = bi[k];
+                    }
+                }
+            }
+        }
         for (; r < n; r += kWaves) {
             const char *row = mat + static_cast<size_t>(c0 + r) * a.row_stride * esz;
-            const int bi = row_argmax<F16>(row, a.vocab, a.vector_ok != 0, lane);
+            int bi;
+            if (MODE == 1) { int one[1]; rows_argmax_any<F16, 1>(row, 0, a.vocab, lane, one); bi = one[0]; }
+            else bi = row_argmax<F16>(row, a.vocab, MODE == 0, lane);
             if (lane == 0) {
                 ids[r] = bi;
                 if (fids) fids[c0 + r] = bi;
@@ -392,8 +472,14 @@ fa_status fa_ctc_greedy_batch_dev(fa_ctx *ctx, const void *d_logits, int32_t dty
     const int vw = dtype == FA_DTYPE_F16 ? 8 : 4;
     a.vector_ok = (vocab % vw == 0) && (row_stride % vw == 0) && (matrix_stride % vw == 0) &&
                   (reinterpret_cast<uintptr_t>(d_logits) % 16 == 0);
-    if (dtype == FA_DTYPE_F16) hipLaunchKernelGGL(ctc_greedy_kernel<true>, dim3(batch), dim3(kThreads), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(ctc_greedy_kernel<false>, dim3(batch), dim3(kThreads), 0, ctx->stream, a);
+    a.elem_ok = reinterpret_cast<uintptr_t>(d_logits) % (dtype == FA_DTYPE_F16 ? 2 : 4) == 0 && vocab >= 2 * vw;   // at least one whole 16-byte piece behind any head
+    const int launch_mode = a.vector_ok ? 0 : (a.elem_ok ? 1 : 2);
+    const bool f16 = dtype == FA_DTYPE_F16;
+#define FA_CTC_LAUNCH(F, M) hipLaunchKernelGGL((ctc_greedy_kernel<F, M>), dim3(batch), dim3(kThreads), 0, ctx->stream, a)
+    if (launch_mode == 0) { if (f16) FA_CTC_LAUNCH(true, 0); else FA_CTC_LAUNCH(false, 0); }
+    else if (launch_mode == 1) { if (f16) FA_CTC_LAUNCH(true, 1); else FA_CTC_LAUNCH(false, 1); }
+    else { if (f16) FA_CTC_LAUNCH(true, 2); else FA_CTC_LAUNCH(false, 2); }
+#undef FA_CTC_LAUNCH
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }

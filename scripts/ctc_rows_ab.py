@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fluidaudio_amd as fa  # noqa: E402
 
 ctx = fa.default_context(0)
-B, T, V = int(os.environ.get("FA_AB_BATCH", "4000")), 1500, 1024
+B, T, V = int(os.environ.get("FA_AB_BATCH", "4000")), 1500, int(os.environ.get("FA_AB_VOCAB", "1024"))
 x32 = torch.randn((B, T, V), generator=torch.Generator(device="cuda").manual_seed(7), device="cuda")
 x32[:, :, V - 1] += 2.0
 stream = torch.cuda.ExternalStream(ctx.stream)

@@ -48,9 +48,34 @@ def test_nan_inf_rows(fa, gpu_ctx, oracle_mod):
     assert fids[0].tolist() == oracle_mod.argmax_rows(x).tolist() == [1, 0, 0, 0, 2, 0]
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_unaligned_rows_head_body_tail(fa, gpu_ctx, oracle_mod, dtype):
+    """Rows of 1 025 logits (their alignment rotates with the frame index): the winner in the head, the body and the tail of a row, ties between
+    them (first index wins), rows of -inf / NaN only (index 0), NaN beside the maximum."""
+    T, V = 64, 1025
+    x = np.full((1, T, V), -3.0, dtype)
+    for t in range(T):
+        kind = t % 8
+        if kind == 0: x[0, t, t % 4] = 1.0                               # head (or first body element, depending on the row's alignment)
+        elif kind == 1: x[0, t, V - 1 - (t % 3)] = 1.0                    # tail
+        elif kind == 2: x[0, t, 500 + t] = 1.0                            # body
+        elif kind == 3: x[0, t, [2, 700, V - 1]] = 2.0                    # tie between head, body and tail: the first
+        elif kind == 4: x[0, t, :] = -np.inf
+        elif kind == 5: x[0, t, :] = np.nan
+        elif kind == 6: x[0, t, :] = np.nan; x[0, t, V - 2] = -7.0       # the only number sits in the tail
+        else: x[0, t, 3] = np.nan; x[0, t, 4] = 0.5; x[0, t, 5] = np.nan
+    _, fids = fa.ctc_greedy_ids_batch(x, blank_id=-1, ctx=gpu_ctx, return_frame_ids=True)
+    np.testing.assert_array_equal(fids[0], oracle_mod.argmax_rows(x[0]))
+    assert fids[0][3] == 2 and fids[0][4] == 0 and fids[0][5] == 0 and fids[0][6] == V - 2 and fids[0][7] == 4
+
+
 @pytest.mark.parametrize("T,V,W,dtype", [(1, 1, 1, np.float32), (7, 3, 5, np.float32), (300, 1025, 1025, np.float32),
                                           (257, 1024, 1032, np.float32), (2049, 64, 64, np.float32), (5000, 16, 16, np.float32),
-                                          (130, 1024, 1024, np.float16), (99, 37, 40, np.float16)])
+                                          (130, 1024, 1024, np.float16), (99, 37, 40, np.float16),
+                                          # rows of any alignment through the head + 16-byte body + tail path (round 4): Parakeet CTC's 1 025 logits per frame
+                                          # in both dtypes, rows shorter than a vector, strides that rotate the alignment, a SenseVoice-sized vocabulary
+                                          (300, 1025, 1025, np.float16), (64, 1027, 1029, np.float32), (50, 9, 9, np.float16), (33, 2, 3, np.float32),
+                                          (21, 25055, 25055, np.float32), (19, 8193, 8198, np.float16), (40, 1030, 1031, np.float16)])
 def test_random_shapes_vs_oracle(fa, gpu_ctx, oracle_mod, T, V, W, dtype):
     rng = np.random.default_rng(T * 31 + V)
     B = 3
