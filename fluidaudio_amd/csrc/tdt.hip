@@ -167,26 +167,29 @@ __device__ __forceinline__ int tdt_dpp(const int old, const int src) { return __
 __device__ __forceinline__ void tdt_wave_argmax(float &v, int &i) {
 #define FA_TDT_STEP(CTRL, MASK)                                                                   \
     { const float ov = tdt_dpp<CTRL, MASK>(-INFINITY, v); const int oi = tdt_dpp<CTRL, MASK>(0x7fffffff, i); \
-      if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; } }
+      const bool t = (ov > v) | ((ov == v) & (oi < i)); v = t ? ov : v; i = t ? oi : i; }
     FA_TDT_STEP(0x111, 0xf) FA_TDT_STEP(0x112, 0xf) FA_TDT_STEP(0x114, 0xf) FA_TDT_STEP(0x118, 0xf)   // row_shr 1, 2, 4, 8: lane 15 of every row holds the row's result
     FA_TDT_STEP(0x142, 0xa) FA_TDT_STEP(0x143, 0xc)                                                   // row_bcast15 into rows 1, 3; row_bcast31 into rows 2, 3: lane 63 holds it all
 #undef FA_TDT_STEP
     v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
     i = __builtin_amdgcn_readlane(i, 63);
 }
-// soft-max partials (m = maximum, s = sum of exp(x - m)) of the 64 lanes -> the wavefront's, in every lane
+// soft-max partials (m = maximum, s = sum of exp(x - m)) of the 64 lanes -> the wavefront's, in every lane: the maximum first (six DPP steps of
+// one v_max), ONE rescale per lane, then the sum (six DPP adds) — the pairwise form spent two exp per step on the decision's dependent chain
 __device__ __forceinline__ void tdt_wave_softmax(float &m, float &s) {
-#define FA_TDT_STEP(CTRL, MASK)                                                                   \
-    { const float om = tdt_dpp<CTRL, MASK>(-INFINITY, m), os = tdt_dpp<CTRL, MASK>(0.0f, s);     \
-      const float nm = om > m ? om : m;                                                           \
-      const float sa = m == -INFINITY ? (nm == -INFINITY ? s : 0.0f) : s * __expf(m - nm);       \
-      const float sb = om == -INFINITY ? (nm == -INFINITY ? os : 0.0f) : os * __expf(om - nm);   \
-      s = sa + sb; m = nm; }
+    float mm = m;
+#define FA_TDT_STEP(CTRL, MASK) { const float om = tdt_dpp<CTRL, MASK>(-INFINITY, mm); mm = om > mm ? om : mm; }
     FA_TDT_STEP(0x111, 0xf) FA_TDT_STEP(0x112, 0xf) FA_TDT_STEP(0x114, 0xf) FA_TDT_STEP(0x118, 0xf)
     FA_TDT_STEP(0x142, 0xa) FA_TDT_STEP(0x143, 0xc)
 #undef FA_TDT_STEP
-    m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
-    s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
+    const float M = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mm), 63));
+    float t = m == -INFINITY ? 0.0f : s * __expf(m - M);     // a lane without a finite value holds s = 0
+#define FA_TDT_STEP(CTRL, MASK) t += tdt_dpp<CTRL, MASK>(0.0f, t);
+    FA_TDT_STEP(0x111, 0xf) FA_TDT_STEP(0x112, 0xf) FA_TDT_STEP(0x114, 0xf) FA_TDT_STEP(0x118, 0xf)
+    FA_TDT_STEP(0x142, 0xa) FA_TDT_STEP(0x143, 0xc)
+#undef FA_TDT_STEP
+    m = M;
+    s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 63));
 }
 
 template <bool F16>
@@ -219,18 +222,25 @@ __global__ __launch_bounds__(64) void tdt_logits_kernel(const TdtArgs a, const T
             const int kbase = k0 - lane;                                             // wave-uniform: pieces at or beyond the row's end are skipped by a scalar branch
             float bm = -INFINITY;                                                    // maximum of the batch first: one exp per value, one rescale per batch
 #pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                if (kbase + 64 * j >= g.V1) break;                                   // (a row of 1 025 logits: the second batch holds ONE piece)
-                if (v[j] > bv) { bv = v[j]; bi = k0 + 64 * j; }                      // (slots beyond the row hold -inf and never win)
+            for (int j = 0; j < kBatch; ++j) {                                       // selects, no per-lane branches: the decision is a dependent chain
+                if (kbase + 64 * j >= g.V1) break;                                   // (wave-uniform; a row of 1 025 logits: the second batch holds ONE piece)
+                const bool t = v[j] > bv;                                            // (slots beyond the row hold -inf and never win)
+                bv = t ? v[j] : bv; bi = t ? k0 + 64 * j : bi;
                 bm = v[j] > bm ? v[j] : bm;
             }
-            if (bm > m) { ssum = m == -INFINITY ? 0.0f : ssum * __expf(m - bm); m = bm; }
+            {
+                const bool up = bm > m;
+                const float rescaled = m == -INFINITY ? 0.0f : ssum * __expf(m - bm);
+                ssum = up ? rescaled : ssum; m = up ? bm : m;
+            }
+            const bool finite_max = m > -INFINITY;
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {
                 if (kbase + 64 * j >= g.V1) break;
                 const bool in_row = k0 + 64 * j < g.V1;
-                nan_seen = nan_seen || (in_row && v[j] != v[j]);
-                if (in_row && m > -INFINITY) ssum += __expf(v[j] - m);
+                nan_seen = nan_seen | (in_row & (v[j] != v[j]));
+                const float e = __expf(v[j] - m);
+                ssum += (in_row & finite_max) ? e : 0.0f;
             }
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) v[j] = vn[j];
