@@ -307,12 +307,12 @@ def test_c_entry_fa_ahc_cut_refuses_dendrograms_it_cannot_walk(fa):
 
 
 def test_bench_line_contract_on_the_committed_line():
-    """The driver parses ONE JSON line of bench.py: the committed line of the round (profiles/r04_bench_v16.json, written on an MI355X)
+    """The driver parses ONE JSON line of bench.py: the committed line of the round (profiles/r04_bench_v17.json, written on an MI355X)
     carries every field of the contract with the right types, and bench.py still spells each of them."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r04_bench_v16.json")) as f:
+    with open(os.path.join(root, "profiles", "r04_bench_v17.json")) as f:
         line = json.loads(f.read().strip().splitlines()[-1])
     need = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float, "higher_is_better": bool,
             "scaling": str, "dtype": str, "data": str, "config": dict, "roofline": dict, "cpu_baseline": dict}
