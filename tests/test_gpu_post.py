@@ -24,6 +24,30 @@ def test_centroids_and_assignment_match_oracle(fa, gpu_ctx, oracle_mod, n, d, S,
     assert ag == ar.tolist()
 
 
+@pytest.mark.parametrize("n", [100, 700])   # the one-wavefront kernel and the tiled one
+def test_skipped_rows_never_touch_the_sums(fa, gpu_ctx, oracle_mod, n):
+    """A row whose weight is not > 0 is skipped by the reference (:655) whatever its embedding holds — inf, NaN, huge values.  The device adds
+    +0.0 for such a row (one add per row on the dependent chain, no select): the sums must keep the reference's bits, and a negative or NaN
+    weight must count as skipped too."""
+    rng = np.random.default_rng(n)
+    d, S = 64, 3
+    emb = rng.standard_normal((n, d))
+    gamma = rng.random((n, S))
+    dead = rng.choice(n, n // 5, replace=False)
+    gamma[dead] = 0.0
+    emb[dead[0::3]] = np.inf
+    emb[dead[1::3]] = np.nan
+    emb[dead[2::3]] = -1e308
+    gamma[dead[0], 1] = -0.25                      # not > 0: skipped
+    gamma[dead[1], 2] = np.nan                     # not > 0: skipped
+    pi = np.full(S, 1.0 / S)
+    cr, mr = oracle_mod.weighted_centroids(emb, gamma, pi)
+    cg, mg = fa.compute_centroids(emb, gamma, pi, ctx=gpu_ctx)
+    assert np.isfinite(cr).all()
+    np.testing.assert_array_equal(mg, mr)
+    np.testing.assert_array_equal(cg, cr)
+
+
 def test_guards(fa, gpu_ctx):
     assert fa.assign_embeddings(np.zeros((0, 4)), np.zeros((2, 4)), ctx=gpu_ctx) == []
     assert fa.assign_embeddings(np.ones((3, 4)), np.zeros((0, 4)), ctx=gpu_ctx) == [0, 0, 0]
