@@ -6,7 +6,7 @@ for gfx950) through the C ABI of include/fluidaudio_hip.h; there is no CPU fallb
 from ._lib import (AHC_MODE_AUTO, AHC_MODE_EXACT, AHC_MODE_REFERENCE_ORDER, ALLOCATION_FAILURE, INVALID_ARGUMENT, RUNTIME_ERROR, SUCCESS, Context, FluidAudioHipError, build, default_context, lib)  # noqa: F401
 from .ahc import AHCClustering, check_dendrogram, cut, fastcluster_compute_centroid_linkage, linkage, linkage_batch  # noqa: F401
 from .beam import ARPAError, ARPALanguageModel, CtcVocabulary, ctc_beam_search, ctc_beam_search_ids_batch  # noqa: F401
-from .ctc import (LogitsArgmax, ctc_greedy_decode, ctc_greedy_ids_batch, ctc_greedy_ids_dev, ctc_log_probs_dev,  # noqa: F401
+from .ctc import (LogitsArgmax, ctc_greedy_decode, ctc_greedy_ids_batch, ctc_greedy_rows, ctc_greedy_ids_dev, ctc_log_probs_dev,  # noqa: F401
                   decode_ctc_token_ids)
 from .formats import AudioWAV, RTTMParser, RTTMParserError, TimedSpeakerSegment, export_embeddings_json  # noqa: F401
 from .kmeans import KMeansClustering, SeededRNG, SpeakerCountConstraints  # noqa: F401

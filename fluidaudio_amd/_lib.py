@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "fa_mel_default_config", "fa_mel_num_frames", "fa_mel_padded_frames", "fa_mel_plan_create", "fa_mel_plan_destroy",
     "fa_mel_plan_utt_stride", "fa_mel_plan_frame_stride", "fa_mel_plan_total_frames", "fa_mel_execute_dev",
     "fa_mel_batch", "fa_mel_hann_window", "fa_mel_filterbank", "fa_mel_normalize_per_feature_dev",
-    "fa_ctc_greedy_batch_dev", "fa_ctc_greedy_batch", "fa_ctc_log_softmax_batch_dev",
+    "fa_ctc_greedy_batch_dev", "fa_ctc_greedy_batch", "fa_ctc_greedy_rows_dev", "fa_ctc_greedy_rows", "fa_ctc_log_softmax_batch_dev",
     "fa_tdt_default_config", "fa_tdt_initial_time_index", "fa_tdt_navigation_state", "fa_tdt_final_time_jump",
     "fa_tdt_map_duration_bin", "fa_tdt_clamp_probability", "fa_tdt_greedy_tables_dev", "fa_tdt_greedy_logits_dev",
     "fastcluster_compute_centroid_linkage", "fa_ahc_linkage", "fa_ahc_linkage_batch", "fa_ahc_row_minima", "fa_ahc_cluster", "fa_ahc_cut",
@@ -162,6 +162,8 @@ def lib() -> C.CDLL:
     L.fa_ctc_greedy_batch_dev.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, vp, i32, vp, vp, vp]
     L.fa_ctc_log_softmax_batch_dev.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, f32, f32, i32, vp]
     L.fa_ctc_greedy_batch.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, vp, i32, vp, vp, vp]
+    L.fa_ctc_greedy_rows_dev.argtypes = [vp, vp, vp, i64, vp, i32, i32, vp, vp, vp]
+    L.fa_ctc_greedy_rows.argtypes = [vp, vp, vp, i64, vp, i32, i32, vp, vp, vp]
     L.fa_tdt_default_config.argtypes = [C.POINTER(TdtConfig)]
     L.fa_tdt_default_config.restype = None
     L.fa_tdt_initial_time_index.argtypes = [i32, i32, i32]

@@ -324,6 +324,142 @@ __global__ __launch_bounds__(kThreads) void ctc_greedy_kernel(const CtcArgs a) {
     if (tid == 0) a.token_lens[b] = carry_count;
 }
 
+// ctcGreedyDecode(logProbs: [[Float]], ...) (CtcDecoder.swift:15-36) is NOT the [1, T, V] overload with another container: it seeds the scan with
+// frame[0] (`bestVal = frame[0]`, :25), so a frame whose element 0 is NaN decodes to index 0 (no later `frame[v] > NaN` is ever true), where the
+// -inf seed of :55-64 skips the NaN and finds the finite maximum; every frame has its own length (`1..<frame.count`, :26); an empty frame is skipped
+// BEFORE `prev` is touched (`guard !frame.isEmpty else { continue }`, :23), so `a, [], a` collapses to one `a`.  For frames whose element 0 is not NaN
+// the two seeds agree (a non-NaN frame[0] beats or equals -inf; later NaNs lose either way; all -inf -> 0 in both).
+//
+// One workgroup per utterance, one wavefront per frame; the frames of utterance u are rows utt_rows[u] .. utt_rows[u + 1] of a flat value array whose
+// row r spans values[row_offsets[r] .. row_offsets[r + 1]).  Frames of eight values or more go through the head + 16-byte body + tail scan above.
+constexpr int32_t kEmptyFrame = INT_MIN;   // LDS marker of an empty frame (a frame id is >= 0)
+
+struct CtcRowsArgs {
+    const float *values;
+    const int64_t *row_offsets;   // [total_rows + 1], non-decreasing
+    const int64_t *utt_rows;      // [batch + 1], non-decreasing; NULL: one utterance of `total_rows` rows
+    int32_t *frame_ids;           // [total_rows] or NULL: argmax per frame, -1 for an empty frame
+    int32_t *token_ids;           // [total_rows]: utterance u writes from token_ids[utt_rows[u]]
+    int32_t *token_lens;          // [batch]
+    int64_t total_rows;
+    int32_t blank_id;
+};
+
+__device__ __forceinline__ int row_argmax_seed_first(const float *row, const int64_t len, const int lane) {
+    int bi;
+    if (len >= 8 && len <= INT_MAX) {
+        int one[1];
+        rows_argmax_any<false, 1>(reinterpret_cast<const char *>(row), 0, static_cast<int>(len), lane, one);
+        bi = one[0];
+    } else {
+        float best = -INFINITY;
+        int64_t b64 = INT64_MAX;
+        for (int64_t i = lane; i < len; i += 64) { const float x = row[i]; const bool t = x > best; best = t ? x : best; b64 = t ? i : b64; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off);
+            const int64_t oi = __shfl_xor(b64, off);
+            const bool t = (ov > best) | ((ov == best) & (oi < b64));
+            best = t ? ov : best; b64 = t ? oi : b64;
+        }
+        bi = b64 == INT64_MAX ? 0 : static_cast<int>(b64 > INT_MAX ? INT_MAX : b64);
+    }
+    const float first = row[0];                 // uniform address: one scalar-like broadcast load
+    return first != first ? 0 : bi;             // `bestVal = frame[0]` (:25): a NaN seed is never beaten
+}
+
+__global__ __launch_bounds__(kThreads) void ctc_greedy_rows_kernel(const CtcRowsArgs a) {
+    __shared__ int32_t ids[kChunk];
+    __shared__ int32_t wave_tot[kWaves], wave_last[kWaves];
+    __shared__ int32_t carry_prev, carry_count;
+
+    const int u = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row_lo = a.utt_rows ? a.utt_rows[u] : 0, row_hi = a.utt_rows ? a.utt_rows[u + 1] : a.total_rows;
+    const int64_t T = row_hi - row_lo;
+    int32_t *out = a.token_ids + row_lo;
+    int32_t *fids = a.frame_ids ? a.frame_ids + row_lo : nullptr;
+
+    if (tid == 0) { carry_prev = -1; carry_count = 0; }
+    __syncthreads();
+
+    for (int64_t c0 = 0; c0 < T; c0 += kChunk) {
+        const int n = T - c0 < kChunk ? static_cast<int>(T - c0) : kChunk;
+        for (int r = wave; r < n; r += kWaves) {
+            const int64_t lo = a.row_offsets[row_lo + c0 + r], hi = a.row_offsets[row_lo + c0 + r + 1];
+            int id = kEmptyFrame;
+            if (hi > lo) id = row_argmax_seed_first(a.values + lo, hi - lo, lane);
+            if (lane == 0) {
+                ids[r] = id;
+                if (fids) fids[c0 + r] = id == kEmptyFrame ? -1 : id;
+            }
+        }
+        __syncthreads();
+        // `prev` of a frame = the id of the nearest non-empty frame before it: a "rightmost non-empty" scan next to the count scan
+        const int prev0 = carry_prev, base = carry_count;
+        int32_t mine[kPerThread];
+        int cnt = 0;
+        const int r0 = tid * kPerThread;
+        int32_t seg_last = kEmptyFrame;
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const int r = r0 + j;
+            mine[j] = r < n ? ids[r] : kEmptyFrame;
+            seg_last = mine[j] != kEmptyFrame ? mine[j] : seg_last;
+        }
+        int32_t last_incl = seg_last;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t o = __shfl_up(last_incl, off);
+            if (lane >= off && last_incl == kEmptyFrame) last_incl = o;
+        }
+        if (lane == 63) wave_last[wave] = last_incl;
+        int32_t prev = __shfl_up(last_incl, 1);
+        if (lane == 0) prev = kEmptyFrame;
+        __syncthreads();
+        if (prev == kEmptyFrame) {
+            for (int w = wave - 1; w >= 0 && prev == kEmptyFrame; --w) prev = wave_last[w];
+            if (prev == kEmptyFrame) prev = prev0;
+        }
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const int32_t id = mine[j];
+            const int keep = (id != kEmptyFrame) && (id != a.blank_id) && (id != prev);
+            prev = id != kEmptyFrame ? id : prev;
+            mine[j] = keep ? id : -1;
+            cnt += keep;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int wave_base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const int t = wave_tot[w];
+            if (w < wave) wave_base += t;
+            total += t;
+        }
+        int pos = base + wave_base + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j)
+            if (mine[j] >= 0) out[pos++] = mine[j];
+        __syncthreads();
+        if (tid == 0) {
+            int32_t last = kEmptyFrame;
+            for (int w = kWaves - 1; w >= 0 && last == kEmptyFrame; --w) last = wave_last[w];
+            carry_prev = last == kEmptyFrame ? prev0 : last;
+            carry_count = base + total;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) a.token_lens[u] = carry_count;
+}
+
 // Per-frame log-softmax with temperature and blank bias as CtcKeywordSpotter.makeLogProbs / logSoftmax do it
 // (reference: Sources/FluidAudio/ASR/Parakeet/SlidingWindow/CustomVocabulary/WordSpotting/CtcKeywordSpotter+Inference.swift:350-431):
 // x / temperature (only when temperature != 1), max, sum of expf(x - max), (x - max) - logf(sum); then blankBias is
@@ -515,6 +651,69 @@ fa_status fa_ctc_greedy_batch(fa_ctx *ctx, const void *logits, int32_t dtype, in
     } while (0);
     if (st != FA_SUCCESS) return st;
     return fa::hip_status(ctx, e, "fa_ctc_greedy_batch");
+}
+
+fa_status fa_ctc_greedy_rows_dev(fa_ctx *ctx, const float *d_values, const int64_t *d_row_offsets, int64_t total_rows, const int64_t *d_utt_rows,
+                                 int32_t batch, int32_t blank_id, int32_t *d_frame_ids, int32_t *d_token_ids, int32_t *d_token_lens) {
+    if (!ctx || !d_token_lens) return FA_INVALID_ARGUMENT;
+    if (batch < 0 || total_rows < 0) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc rows: bad shape");
+    if (batch == 0) return FA_SUCCESS;
+    if (!d_utt_rows && batch != 1) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc rows: a batch needs utt_rows");
+    if (total_rows > 0 && (!d_row_offsets || !d_token_ids)) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc rows: null buffer");
+    fa::DeviceGuard guard(ctx->device);
+    CtcRowsArgs a;
+    a.values = d_values; a.row_offsets = d_row_offsets; a.utt_rows = d_utt_rows; a.frame_ids = d_frame_ids; a.token_ids = d_token_ids;
+    a.token_lens = d_token_lens; a.total_rows = total_rows; a.blank_id = blank_id;
+    hipLaunchKernelGGL(ctc_greedy_rows_kernel, dim3(batch), dim3(kThreads), 0, ctx->stream, a);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    return FA_SUCCESS;
+}
+
+fa_status fa_ctc_greedy_rows(fa_ctx *ctx, const float *values, const int64_t *row_offsets, int64_t total_rows, const int64_t *utt_rows, int32_t batch,
+                             int32_t blank_id, int32_t *frame_ids, int32_t *token_ids, int32_t *token_lens) {
+    if (!ctx || !token_lens) return FA_INVALID_ARGUMENT;
+    if (batch < 0 || total_rows < 0) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc rows: bad shape");
+    if (batch == 0) return FA_SUCCESS;
+    if (!utt_rows && batch != 1) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc rows: a batch needs utt_rows");
+    if (total_rows > 0 && (!row_offsets || !token_ids)) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc rows: null buffer");
+    // the offsets are the caller's: a decreasing pair would make the kernel read outside `values`
+    if (total_rows > 0) {
+        if (row_offsets[0] < 0) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc rows: negative offset");
+        for (int64_t r = 0; r < total_rows; ++r)
+            if (row_offsets[r + 1] < row_offsets[r]) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc rows: row_offsets decrease");
+    }
+    if (utt_rows) {
+        if (utt_rows[0] < 0 || utt_rows[batch] > total_rows) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc rows: utt_rows out of range");
+        for (int32_t u = 0; u < batch; ++u)
+            if (utt_rows[u + 1] < utt_rows[u]) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc rows: utt_rows decrease");
+    }
+    const int64_t n_values = total_rows > 0 ? row_offsets[total_rows] : 0;
+    if (n_values > 0 && !values) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "ctc rows: null values");
+    fa::DeviceGuard guard(ctx->device);
+    const size_t id_bytes = sizeof(int32_t) * static_cast<size_t>(total_rows > 0 ? total_rows : 1);
+    fa::DevBuf d_val, d_off, d_utt, d_fid, d_tok, d_len;
+    hipError_t e;
+    fa_status st = FA_SUCCESS;
+    do {
+        if ((e = d_val.alloc(sizeof(float) * static_cast<size_t>(n_values > 0 ? n_values : 1))) != hipSuccess) break;
+        if ((e = d_off.alloc(sizeof(int64_t) * static_cast<size_t>(total_rows + 1))) != hipSuccess) break;
+        if ((e = d_tok.alloc(id_bytes)) != hipSuccess) break;
+        if ((e = d_len.alloc(sizeof(int32_t) * batch)) != hipSuccess) break;
+        if (frame_ids && (e = d_fid.alloc(id_bytes)) != hipSuccess) break;
+        if (utt_rows && (e = d_utt.alloc(sizeof(int64_t) * (static_cast<size_t>(batch) + 1))) != hipSuccess) break;
+        if (n_values > 0 && (e = hipMemcpyAsync(d_val.p, values, sizeof(float) * static_cast<size_t>(n_values), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        if (total_rows > 0 && (e = hipMemcpyAsync(d_off.p, row_offsets, sizeof(int64_t) * static_cast<size_t>(total_rows + 1), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        if (utt_rows && (e = hipMemcpyAsync(d_utt.p, utt_rows, sizeof(int64_t) * (static_cast<size_t>(batch) + 1), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        st = fa_ctc_greedy_rows_dev(ctx, d_val.as<float>(), d_off.as<int64_t>(), total_rows, utt_rows ? d_utt.as<int64_t>() : nullptr, batch, blank_id,
+                                    frame_ids ? d_fid.as<int32_t>() : nullptr, d_tok.as<int32_t>(), d_len.as<int32_t>());
+        if (st != FA_SUCCESS) break;
+        if (total_rows > 0 && (e = hipMemcpyAsync(token_ids, d_tok.p, sizeof(int32_t) * static_cast<size_t>(total_rows), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        if (total_rows > 0 && frame_ids && (e = hipMemcpyAsync(frame_ids, d_fid.p, sizeof(int32_t) * static_cast<size_t>(total_rows), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(token_lens, d_len.p, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) break;
+        e = hipStreamSynchronize(ctx->stream);
+    } while (0);
+    if (st != FA_SUCCESS) return st;
+    return fa::hip_status(ctx, e, "fa_ctc_greedy_rows");
 }
 
 fa_status fa_ctc_log_softmax_batch_dev(fa_ctx *ctx, const void *d_logits, int32_t dtype, int32_t batch, int32_t frames, int32_t vocab,

@@ -81,19 +81,47 @@ def decode_ctc_token_ids(ids, vocabulary: dict[int, str]) -> str:
     return text.replace(SENTENCEPIECE_WORD_BOUNDARY, " ").strip(" ")
 
 
+def ctc_greedy_rows(frames_per_utt, blank_id: int, ctx: L.Context | None = None, return_frame_ids: bool = False):
+    """The `[[Float]]` overload of ctcGreedyDecode (CtcDecoder.swift:15-36) for a batch of utterances, each a sequence of frames of ANY
+    lengths (empty frames allowed): frame[0] seeds the scan (:25), so NaN in column 0 -> index 0; empty frames never touch `prev` (:23).
+    -> list of collapsed id arrays (and optionally a list of per-frame ids, -1 for empty frames)."""
+    ctx = ctx or L.default_context()
+    utts = [list(u) for u in frames_per_utt]
+    B = len(utts)
+    if B == 0:
+        return ([], []) if return_frame_ids else []
+    rows = [np.asarray(f, np.float32).reshape(-1) for u in utts for f in u]
+    R = len(rows)
+    offs = np.zeros(R + 1, np.int64)
+    if R:
+        offs[1:] = np.cumsum([r.size for r in rows])
+    flat = np.concatenate(rows).astype(np.float32, copy=False) if R and offs[-1] else np.zeros(1, np.float32)
+    utt_rows = np.zeros(B + 1, np.int64)
+    utt_rows[1:] = np.cumsum([len(u) for u in utts])
+    tok = np.zeros(max(R, 1), np.int32)
+    fids = np.zeros(max(R, 1), np.int32) if return_frame_ids else None
+    lens = np.zeros(B, np.int32)
+    ctx.check(L.lib().fa_ctc_greedy_rows(ctx.handle, flat.ctypes.data, offs.ctypes.data, R, utt_rows.ctypes.data, B, blank_id,
+                                         None if fids is None else fids.ctypes.data, tok.ctypes.data, lens.ctypes.data), "fa_ctc_greedy_rows")
+    out = [tok[utt_rows[u]:utt_rows[u] + lens[u]].copy() for u in range(B)]
+    if return_frame_ids:
+        return out, [fids[utt_rows[u]:utt_rows[u + 1]].copy() for u in range(B)]
+    return out
+
+
 def ctc_greedy_decode(log_probs, vocabulary: dict[int, str], blank_id: int = 1024, ctx: L.Context | None = None) -> str:
-    """ctcGreedyDecode(logProbs:vocabulary:blankId:) (:15-36 for [[Float]], :45-70 for [1,T,V])."""
+    """ctcGreedyDecode(logProbs:vocabulary:blankId:): a list / tuple of frames is the `[[Float]]` overload (:15-36: frame[0] seed, per-frame
+    length, empty frames skipped); an array [T, V] / [1, T, V] is the MLMultiArray overload (:45-70: -inf seed, NaN never wins)."""
     if isinstance(log_probs, (list, tuple)):
-        rows = [r for r in log_probs if len(r) > 0]  # `guard !frame.isEmpty else { continue }` (:23)
-        if not rows:
+        if len(log_probs) == 0:
             return ""
-        x = np.asarray(rows, np.float32)
-    else:
-        x = np.asarray(log_probs)
-        if x.ndim == 3:
-            x = x[0]
-        if x.shape[0] == 0:
-            return ""
+        ids = ctc_greedy_rows([log_probs], blank_id, ctx=ctx)[0]
+        return decode_ctc_token_ids(ids, vocabulary)
+    x = np.asarray(log_probs)
+    if x.ndim == 3:
+        x = x[0]
+    if x.shape[0] == 0:
+        return ""
     ids = ctc_greedy_ids_batch(x, blank_id, ctx=ctx)[0]
     return decode_ctc_token_ids(ids, vocabulary)
 

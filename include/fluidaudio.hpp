@@ -167,18 +167,29 @@ inline std::vector<int> argmaxPerFrame(Context &ctx, const float *logits, int fr
     return std::vector<int>(ids.begin(), ids.end());
 }
 
-// ctcGreedyDecode(logProbs:vocabulary:blankId:) (CtcDecoder.swift:15-36): [[Float]] rows, empty frames skipped
+// ctcGreedyDecode(logProbs:vocabulary:blankId:) (CtcDecoder.swift:15-36): the [[Float]] overload — each frame's scan is seeded with frame[0]
+// (a NaN there => index 0, :25), frames keep their own lengths (:26), empty frames are skipped before `prev` is touched (:23)
 inline std::string ctcGreedyDecode(Context &ctx, const std::vector<std::vector<float>> &logProbs, const Vocabulary &vocabulary, int blankId = 1024) {
-    size_t V = 0;
-    for (const auto &r : logProbs) if (!r.empty()) { V = r.size(); break; }
-    if (V == 0) return "";
+    const size_t T = logProbs.size();
+    if (T == 0) return "";
+    std::vector<int64_t> offs(T + 1, 0);
+    for (size_t t = 0; t < T; ++t) offs[t + 1] = offs[t] + static_cast<int64_t>(logProbs[t].size());
     std::vector<float> flat;
-    int T = 0;
-    for (const auto &r : logProbs) if (!r.empty()) { flat.insert(flat.end(), r.begin(), r.begin() + V); ++T; }   // `guard !frame.isEmpty` (:22)
+    flat.reserve(static_cast<size_t>(offs[T]));
+    for (const auto &r : logProbs) flat.insert(flat.end(), r.begin(), r.end());
     std::vector<int32_t> toks(T);
     int32_t n = 0;
-    ctx.check(fa_ctc_greedy_batch(ctx.handle(), flat.data(), FA_DTYPE_F32, 1, T, static_cast<int32_t>(V), static_cast<int64_t>(V), static_cast<int64_t>(T) * V, nullptr,
-                                  blankId, nullptr, toks.data(), &n), "fa_ctc_greedy_batch");
+    ctx.check(fa_ctc_greedy_rows(ctx.handle(), flat.data(), offs.data(), static_cast<int64_t>(T), nullptr, 1, blankId, nullptr, toks.data(), &n), "fa_ctc_greedy_rows");
+    return decodeCtcTokenIds(std::vector<int>(toks.begin(), toks.begin() + n), vocabulary);
+}
+
+// ctcGreedyDecode(logProbs: MLMultiArray [1, T, V], …) (CtcDecoder.swift:45-70): contiguous rows, -inf seed (a NaN never wins)
+inline std::string ctcGreedyDecode(Context &ctx, const float *logProbs, int T, int V, const Vocabulary &vocabulary, int blankId = 1024) {
+    if (T <= 0 || V <= 0) return "";
+    std::vector<int32_t> toks(T);
+    int32_t n = 0;
+    ctx.check(fa_ctc_greedy_batch(ctx.handle(), logProbs, FA_DTYPE_F32, 1, T, V, static_cast<int64_t>(V), static_cast<int64_t>(T) * V, nullptr, blankId, nullptr,
+                                  toks.data(), &n), "fa_ctc_greedy_batch");
     return decodeCtcTokenIds(std::vector<int>(toks.begin(), toks.begin() + n), vocabulary);
 }
 

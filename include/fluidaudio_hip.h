@@ -185,6 +185,21 @@ fa_status fa_ctc_greedy_batch(fa_ctx *ctx, const void *logits, int32_t dtype, in
                               const int32_t *valid_frames, int32_t blank_id, int32_t *frame_ids,
                               int32_t *token_ids, int32_t *token_lens);
 
+/* ctcGreedyDecode(logProbs: [[Float]], ...) — the array-of-arrays overload (CtcDecoder.swift:15-36), whose semantics differ from the
+ * [1, T, V] overload above (:45-70) in three ways, all mirrored here:
+ *   - the scan is seeded with frame[0] (:25), so a frame whose element 0 is NaN decodes to index 0;
+ *   - every frame has its own length (:26): row r is values[row_offsets[r] .. row_offsets[r+1]);
+ *   - an empty frame is skipped before `prev` is updated (:23): `a, [], a` collapses to ONE a.
+ * utt_rows: int64[batch+1] row ranges of the utterances (NULL with batch == 1: all rows are one utterance).
+ * frame_ids (optional): int32[total_rows], -1 for an empty frame.  token_ids: int32[total_rows]; utterance u writes its
+ * token_lens[u] ids from token_ids[utt_rows[u]].  fp32 only ([[Float]]). */
+fa_status fa_ctc_greedy_rows_dev(fa_ctx *ctx, const float *d_values, const int64_t *d_row_offsets, int64_t total_rows,
+                                 const int64_t *d_utt_rows, int32_t batch, int32_t blank_id, int32_t *d_frame_ids,
+                                 int32_t *d_token_ids, int32_t *d_token_lens);
+fa_status fa_ctc_greedy_rows(fa_ctx *ctx, const float *values, const int64_t *row_offsets, int64_t total_rows,
+                             const int64_t *utt_rows, int32_t batch, int32_t blank_id, int32_t *frame_ids,
+                             int32_t *token_ids, int32_t *token_lens);
+
 /* Per-frame log-softmax with temperature and blank bias: CtcKeywordSpotter.makeLogProbs / logSoftmax
  * (FluidAudio/ASR/Parakeet/SlidingWindow/CustomVocabulary/WordSpotting/CtcKeywordSpotter+Inference.swift:350-431).
  * DEVICE pointers; logits addressed like fa_ctc_greedy_batch_dev; d_log_probs: float[batch][frames][vocab] contiguous.

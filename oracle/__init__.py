@@ -87,6 +87,8 @@ def lib() -> C.CDLL:
         L.fa_oracle_ctc_collapse.restype = C.c_long
         L.fa_oracle_ctc_greedy.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_long, C.c_int32, _i32p]
         L.fa_oracle_ctc_greedy.restype = C.c_long
+        L.fa_oracle_ctc_greedy_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int32, C.c_void_p, _i32p]
+        L.fa_oracle_ctc_greedy_rows.restype = C.c_long
         L.fa_oracle_ahc_normalize.argtypes = [_f64p, C.c_long, C.c_long, _f64p]
         L.fa_oracle_ahc_clamp_threshold.argtypes = [C.c_double]
         L.fa_oracle_ahc_clamp_threshold.restype = C.c_double
@@ -258,6 +260,37 @@ def ctc_greedy(logits: np.ndarray, blank_id: int, vocab: int | None = None, fram
     out = np.zeros(max(F, 1), np.int32)
     n = lib().fa_oracle_ctc_greedy(x.ctypes.data, f16, F, V, stride, blank_id, out)
     return out[:n]
+
+
+def ctc_greedy_rows(frames, blank_id: int, return_frame_ids: bool = False):
+    """ctcGreedyDecode(logProbs: [[Float]]) (CtcDecoder.swift:15-36) on a sequence of frames of any lengths (C restatement)."""
+    rows = [np.asarray(f, np.float32).reshape(-1) for f in frames]
+    R = len(rows)
+    offs = np.zeros(R + 1, np.int64)
+    if R:
+        offs[1:] = np.cumsum([r.size for r in rows])
+    flat = np.ascontiguousarray(np.concatenate(rows), np.float32) if R and offs[-1] else np.zeros(1, np.float32)
+    out = np.zeros(max(R, 1), np.int32)
+    fids = np.zeros(max(R, 1), np.int32)
+    n = lib().fa_oracle_ctc_greedy_rows(flat.ctypes.data, offs.ctypes.data, R, blank_id, fids.ctypes.data, out)
+    return (out[:n], fids[:R]) if return_frame_ids else out[:n]
+
+
+def ctc_greedy_rows_py(frames, blank_id: int):
+    """The same overload as a literal pure-Python transcription of :20-34 (second restatement, small cases only)."""
+    ids, prev = [], -1
+    for frame in frames:
+        frame = [np.float32(v) for v in frame]
+        if len(frame) == 0:
+            continue
+        best_idx, best_val = 0, frame[0]
+        for v in range(1, len(frame)):
+            if frame[v] > best_val:
+                best_val, best_idx = frame[v], v
+        if best_idx != blank_id and best_idx != prev:
+            ids.append(best_idx)
+        prev = best_idx
+    return np.asarray(ids, np.int32)
 
 
 # ------------------------------------------------------------------ AHC

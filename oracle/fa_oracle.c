@@ -345,6 +345,30 @@ long fa_oracle_ctc_greedy(const void *logits, int is_f16, long frames, long voca
     return n;
 }
 
+long fa_oracle_ctc_greedy_rows(const float *values, const int64_t *row_offsets, long rows, int32_t blank_id,
+                               int32_t *frame_ids, int32_t *out) {
+    /* CtcDecoder.swift:15-36 — the [[Float]] overload, statement for statement: empty frames are skipped BEFORE prev is
+     * touched (:23), the scan is seeded with frame[0] (:24-25) and runs over 1..<frame.count (:26) with a strict '>' (:27);
+     * a NaN in frame[0] therefore wins (nothing compares greater than NaN), unlike the -inf seed of the [1,T,V] overload
+     * (:55-64, fa_oracle_ctc_greedy above).  frame_ids (optional): the per-frame winner, -1 for an empty frame. */
+    long n = 0;
+    int32_t prev = -1;
+    for (long t = 0; t < rows; ++t) {
+        const float *frame = values + row_offsets[t];
+        const int64_t count = row_offsets[t + 1] - row_offsets[t];
+        if (count <= 0) { if (frame_ids) frame_ids[t] = -1; continue; }
+        int32_t bestIdx = 0;
+        float bestVal = frame[0];
+        for (int64_t v = 1; v < count; ++v) {
+            if (frame[v] > bestVal) { bestVal = frame[v]; bestIdx = (int32_t)v; }
+        }
+        if (frame_ids) frame_ids[t] = bestIdx;
+        if (bestIdx != blank_id && bestIdx != prev) out[n++] = bestIdx;
+        prev = bestIdx;
+    }
+    return n;
+}
+
 /* ================================ AHC pre/post ==================================== */
 
 void fa_oracle_ahc_normalize(const double *x, long n, long d, double *out) {

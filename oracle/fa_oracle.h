@@ -94,6 +94,9 @@ long fa_oracle_ctc_collapse(const int32_t *frame_ids, long frames, int32_t blank
 /* argmax + collapse in one call. */
 long fa_oracle_ctc_greedy(const void *logits, int is_f16, long frames, long vocab, long row_stride,
                           int32_t blank_id, int32_t *out);
+/* ctcGreedyDecode(logProbs: [[Float]]) CtcDecoder.swift:15-36: frame[0] seed, per-frame lengths, empty frames skipped */
+long fa_oracle_ctc_greedy_rows(const float *values, const int64_t *row_offsets, long rows, int32_t blank_id,
+                               int32_t *frame_ids, int32_t *out);
 
 /* ---- AHC pre/post (Diarizer/Offline/Clustering/AHCClustering.swift) ------------- */
 

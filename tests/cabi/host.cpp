@@ -1,5 +1,6 @@
 // A C++ host written against include/fluidaudio.hpp only: the reference's own test cases, restated with the reference's type
 // and method names (file:line of the Swift test next to each block).  Prints one line per check; exit code = failed checks.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <set>
@@ -39,6 +40,16 @@ static void ctcDecoderTests(Context &ctx) {   // Tests/.../CTC/CtcDecoderTests.s
     CHECK(ctcGreedyDecode(ctx, {{0, L}, {L, 0}, {0, L}}, v1, 1) == "hello hello");
     CHECK(ctcGreedyDecode(ctx, {{L, 0}, {L, 0}, {L, 0}}, v1, 1) == "");
     CHECK(ctcGreedyDecode(ctx, {}, v1, 1) == "");
+    {   // where the [[Float]] overload (CtcDecoder.swift:21-31) and the [1, T, V] overload (:55-64) are defined to differ
+        const float nan = std::nanf("");
+        Vocabulary abc = {{0, "a"}, {1, "b"}, {2, "c"}};
+        CHECK(ctcGreedyDecode(ctx, {{nan, 1.0f, 0.0f}, {0.0f, 0.0f, 3.0f}}, abc, 9) == "ac");          // frame[0] seed: the NaN is never beaten
+        const float rect[6] = {nan, 1.0f, 0.0f, 0.0f, 0.0f, 3.0f};
+        CHECK(ctcGreedyDecode(ctx, rect, 2, 3, abc, 9) == "bc");                                       // -inf seed: the NaN never wins
+        CHECK(ctcGreedyDecode(ctx, {{0.0f, 4.0f}, {}, {0.0f, 4.0f}}, abc, 9) == "b");                  // empty frame skipped before prev
+        CHECK(ctcGreedyDecode(ctx, {{0.0f, 1.0f}, {0.0f, 0.0f, 0.0f, 7.0f}, {5.0f}, {9.0f, 1.0f}}, {{0, "a"}, {1, "b"}, {3, "d"}}, 9) == "bda");   // ragged frames
+        CHECK(ctcGreedyDecode(ctx, {{nan, nan}, {}, {nan}}, abc, 9) == "a");
+    }
     const float m[15] = {0.1f, 0.9f, -0.3f, 0.2f, 0.0f, -2.0f, -1.0f, -0.5f, -3.0f, -4.0f, 7.0f, 7.0f, 8.0f, 8.0f, 1.0f};
     CHECK(argmaxPerFrame(ctx, m, 3, 5, 5) == (std::vector<int>{1, 2, 2}));
     CHECK(ctcBeamSearch(ctx, {{0, L, L}, {L, L, 0}, {L, 0, L}}, v2, nullptr, 5, 0.0f, 0.0f, 2) == "hello world");

@@ -139,3 +139,75 @@ def test_log_softmax_with_temperature_and_blank_bias(fa, gpu_ctx, oracle_mod, T,
     p = np.exp(got.astype(np.float64))
     p[:, :, blank] *= np.exp(bias)
     np.testing.assert_allclose(p.sum(-1), 1.0, atol=2e-5)
+
+
+def _ragged_random(rng, n_frames, max_len, p_empty=0.15, p_nan=0.1):
+    frames = []
+    for _ in range(n_frames):
+        if rng.random() < p_empty:
+            frames.append([])
+            continue
+        n = int(rng.integers(1, max_len + 1))
+        f = rng.standard_normal(n).astype(np.float32)
+        f[rng.random(n) < p_nan] = np.nan
+        if rng.random() < 0.2:
+            f[0] = np.nan
+        if rng.random() < 0.1:
+            f[:] = np.nan
+        if rng.random() < 0.1:
+            f[rng.integers(0, n)] = np.inf
+        frames.append(f)
+    return frames
+
+
+def test_rows_overload_defined_differences(fa, gpu_ctx, oracle_mod):
+    """ctcGreedyDecode(logProbs: [[Float]]) (CtcDecoder.swift:15-36): frame[0] seeds the scan (NaN in column 0 -> index 0), frames have
+    their own lengths, empty frames do not touch prev — the cases of tests/test_oracle_ctc.py through the C ABI, bit-exact."""
+    from test_oracle_ctc import _overload_cases
+    for name, frames in _overload_cases().items():
+        for blank in (99, 0, 1):
+            ids, fids = fa.ctc_greedy_rows([frames], blank, ctx=gpu_ctx, return_frame_ids=True)
+            ref, rfids = oracle_mod.ctc_greedy_rows(frames, blank, return_frame_ids=True)
+            assert ids[0].tolist() == ref.tolist(), (name, blank)
+            assert fids[0].tolist() == rfids.tolist(), (name, blank)
+    # the public seam: a list of frames is the [[Float]] overload, an array is the [1, T, V] one — and they differ on a NaN seed
+    nan = np.nan
+    voc = {0: "a", 1: "b", 2: "c"}
+    frames = [[nan, 1.0, 0.0], [0.0, 0.0, 3.0]]
+    assert fa.ctc_greedy_decode(frames, voc, 9, ctx=gpu_ctx) == "ac"                       # :24-25 NaN seed wins
+    assert fa.ctc_greedy_decode(np.asarray(frames, np.float32), voc, 9, ctx=gpu_ctx) == "bc"   # :55-64 NaN never wins
+    assert fa.ctc_greedy_decode([[0.0, 4.0], [], [0.0, 4.0]], voc, 9, ctx=gpu_ctx) == "b"  # :23 empty frame skipped
+    assert fa.ctc_greedy_decode([[], []], voc, 9, ctx=gpu_ctx) == ""
+
+
+def test_rows_overload_random_ragged_batches(fa, gpu_ctx, oracle_mod):
+    rng = np.random.default_rng(11)
+    # short frames (scalar path), long frames (head + 16-byte body + tail path at every alignment), > one LDS chunk of frames, batches
+    for n_frames, max_len, B in ((40, 7, 3), (300, 40, 4), (64, 1100, 2), (5000, 12, 2), (0, 1, 2)):
+        utts = [_ragged_random(rng, n_frames, max_len) for _ in range(B)]
+        for blank in (0, 3, 10 ** 6):
+            ids, fids = fa.ctc_greedy_rows(utts, blank, ctx=gpu_ctx, return_frame_ids=True)
+            for u in range(B):
+                ref, rfids = oracle_mod.ctc_greedy_rows(utts[u], blank, return_frame_ids=True)
+                assert fids[u].tolist() == rfids.tolist()
+                assert ids[u].tolist() == ref.tolist()
+
+
+def test_rows_overload_rectangular_equals_batch_entry_off_the_nan_seed(fa, gpu_ctx):
+    """Without NaN in column 0 the two entries are the same function: [T, 1025] logits through both."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((700, 1025)).astype(np.float32)
+    x[:, 1024] += 2.0
+    a = fa.ctc_greedy_ids_batch(x, 1024, ctx=gpu_ctx)[0]
+    b = fa.ctc_greedy_rows([list(x)], 1024, ctx=gpu_ctx)[0]
+    assert a.tolist() == b.tolist() and len(a) > 100
+
+
+def test_rows_overload_argument_contract(fa, gpu_ctx):
+    L = fa.lib()
+    offs = np.array([0, 3, 2], np.int64)       # decreasing
+    vals = np.zeros(4, np.float32)
+    tok = np.zeros(2, np.int32)
+    n = np.zeros(1, np.int32)
+    assert L.fa_ctc_greedy_rows(gpu_ctx.handle, vals.ctypes.data, offs.ctypes.data, 2, None, 1, 0, None, tok.ctypes.data, n.ctypes.data) == 1   # INVALID_ARGUMENT
+    assert L.fa_ctc_greedy_rows(gpu_ctx.handle, vals.ctypes.data, offs.ctypes.data, 2, None, 2, 0, None, tok.ctypes.data, n.ctypes.data) == 1   # batch without utt_rows

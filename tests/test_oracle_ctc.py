@@ -51,3 +51,53 @@ def test_greedy_collapse_cases(oracle_mod):
     ids = oracle_mod.argmax_rows(x)
     exp = [int(i) for t, i in enumerate(ids) if i != 1024 and (t == 0 or ids[t - 1] != i)]
     assert oracle_mod.ctc_greedy(x, 1024).tolist() == exp
+
+
+def _overload_cases():
+    """Frames on which the two ctcGreedyDecode overloads are DEFINED to differ (CtcDecoder.swift:21-31 vs :55-64) and the ones around them."""
+    nan, inf = np.nan, np.inf
+    return {
+        "nan_in_column_0": [[nan, 1.0, 0.0], [0.0, 2.0, 1.0], [nan, 5.0, 9.0], [3.0, nan, 1.0]],
+        "all_nan": [[nan, nan, nan], [0.0, 1.0, 0.0], [nan, nan, nan]],
+        "neg_inf_seed": [[-inf, -inf, -inf], [-inf, nan, -inf], [-inf, -inf, 1.0]],
+        "ragged": [[0.0, 1.0], [0.0, 0.0, 0.0, 7.0], [5.0], [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 8.0], [9.0, 1.0]],
+        "empty_between_repeats": [[0.0, 4.0, 0.0], [], [0.0, 4.0, 0.0], [], [], [0.0, 0.0, 4.0], [0.0, 4.0, 0.0]],
+        "all_empty": [[], [], []],
+        "nan_later_only": [[1.0, nan, 2.0], [0.5, nan, nan]],
+    }
+
+
+def test_rows_overload_restatements_agree_and_known_answers(oracle_mod):
+    """The C restatement of the [[Float]] overload against its literal Python transcription, and hand-derived answers."""
+    exp = {
+        "nan_in_column_0": [0, 1, 0],          # frames -> 0, 1, 0, 0: the NaN seed is never beaten (:25-27); trailing 0 collapses
+        "all_nan": [0, 1, 0],
+        "neg_inf_seed": [0, 2],
+        "ragged": [1, 3, 0, 9, 0],
+        "empty_between_repeats": [1, 2, 1],     # a, [], a -> ONE a: the empty frame is skipped before prev is touched (:23)
+        "all_empty": [],
+        "nan_later_only": [2, 0],
+    }
+    for name, frames in _overload_cases().items():
+        got = oracle_mod.ctc_greedy_rows(frames, blank_id=99).tolist()
+        assert got == oracle_mod.ctc_greedy_rows_py(frames, 99).tolist() == exp[name], name
+
+
+def test_the_two_overloads_differ_exactly_on_a_nan_seed(oracle_mod):
+    """[1,T,V] overload (-inf seed, :55-64): a NaN never wins.  [[Float]] overload (frame[0] seed, :24-25): a NaN in column 0 wins.  On
+    rectangular input they agree on every frame whose element 0 is not NaN — checked on random matrices with NaN / inf sprinkled in."""
+    x = np.array([[np.nan, 1.0, 0.0], [0.0, 2.0, 1.0]], np.float32)
+    assert oracle_mod.argmax_rows(x).tolist() == [1, 1]
+    assert oracle_mod.ctc_greedy_rows(x, -1, return_frame_ids=True)[1].tolist() == [0, 1]
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        T, V = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+        m = rng.standard_normal((T, V)).astype(np.float32)
+        m[rng.random((T, V)) < 0.1] = np.nan
+        m[rng.random((T, V)) < 0.05] = -np.inf
+        m[rng.random((T, V)) < 0.02] = np.inf
+        a = oracle_mod.argmax_rows(m)
+        b = oracle_mod.ctc_greedy_rows(m, -1, return_frame_ids=True)[1]
+        seed_nan = np.isnan(m[:, 0])
+        assert np.array_equal(a[~seed_nan], b[~seed_nan])
+        assert (b[seed_nan] == 0).all()
