@@ -26,10 +26,11 @@ MEL_SCALE_SLANEY, MEL_SCALE_HTK_NONORM = 0, 1
 MEL_TAIL_ZERO, MEL_TAIL_REPLICATE = 0, 1
 DTYPE_F32, DTYPE_F16 = 0, 1
 AHC_MODE_AUTO, AHC_MODE_EXACT, AHC_MODE_REFERENCE_ORDER = 0, 1, 2
+FAULT_VBX, FAULT_THREAD_START, FAULT_DEVBUF_MALLOC, FAULT_WS_MALLOC, FAULT_AHC = 0, 1, 2, 3, 4   # fa_debug_inject_fault sites (tests)
 
 # Every symbol include/fluidaudio_hip.h + include/FastClusterWrapper.h declare (checked by tests/test_abi.py).
 EXPORTED_SYMBOLS = [
-    "fa_version", "fa_host_alloc", "fa_host_free", "fa_ctx_create", "fa_ctx_destroy", "fa_ctx_synchronize", "fa_ctx_stream", "fa_ctx_last_error",
+    "fa_version", "fa_debug_inject_fault", "fa_ctx_set_timing", "fa_ctx_last_device_ms", "fa_debug_sclk_mhz", "fa_ctc_beam_plan", "fa_host_alloc", "fa_host_free", "fa_ctx_create", "fa_ctx_destroy", "fa_ctx_synchronize", "fa_ctx_stream", "fa_ctx_last_error",
     "fa_ctx_set_workspace_limit", "fa_ctx_set_workspace_cap", "fa_ctx_trim", "fa_ctx_workspace_bytes", "fa_ctx_reserve",
     "fa_mel_default_config", "fa_mel_num_frames", "fa_mel_padded_frames", "fa_mel_plan_create", "fa_mel_plan_destroy",
     "fa_mel_plan_utt_stride", "fa_mel_plan_frame_stride", "fa_mel_plan_total_frames", "fa_mel_execute_dev",
@@ -88,7 +89,8 @@ class OfflineClusterConfig(C.Structure):
 
 class OfflineClusterInfo(C.Structure):
     _fields_ = [("training_rows", C.c_int64), ("initial_clusters", C.c_int32), ("vbx_iterations", C.c_int32),
-                ("was_adjusted", C.c_int32), ("constrained", C.c_int32), ("inputs_s", C.c_double), ("ahc_s", C.c_double),
+                ("was_adjusted", C.c_int32), ("constrained", C.c_int32), ("vbx_degraded", C.c_int32), ("ahc_degraded", C.c_int32),
+                ("inputs_s", C.c_double), ("ahc_s", C.c_double),
                 ("vbx_s", C.c_double), ("assign_s", C.c_double), ("total_s", C.c_double), ("ahc", AhcStats)]
 
 
@@ -121,6 +123,13 @@ def lib() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
     L.fa_version.restype = C.c_char_p
+    L.fa_debug_inject_fault.argtypes = [i32, i32]
+    L.fa_debug_inject_fault.restype = None
+    L.fa_ctx_set_timing.argtypes = [vp, i32]
+    L.fa_ctx_last_device_ms.argtypes = [vp]
+    L.fa_ctx_last_device_ms.restype = f64
+    L.fa_debug_sclk_mhz.argtypes = [vp, i32, vp]
+    L.fa_ctc_beam_plan.argtypes = [i32, i32, i32, i32, i32, i32, vp]
     L.fa_host_alloc.argtypes = [sz]
     L.fa_host_alloc.restype = vp
     L.fa_host_free.argtypes = [vp]
@@ -339,6 +348,12 @@ class Context:
     def check(self, status: int, where: str):
         if status != SUCCESS:
             raise FluidAudioHipError(status, where, self.last_error())
+
+    def sclk_mhz(self, spin_us: int = 200) -> float:
+        """The shader clock right now (fa_debug_sclk_mhz): latency-bound legs print it next to their timing."""
+        v = C.c_double()
+        self.check(lib().fa_debug_sclk_mhz(self._h, spin_us, C.byref(v)), "fa_debug_sclk_mhz")
+        return v.value
 
     def close(self):
         if self._h:

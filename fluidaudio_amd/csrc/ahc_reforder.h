@@ -12,8 +12,9 @@
 //
 // This header is that selection logic, written for host and device (FA_HD): the same text is compiled into the HIP kernels (ahc.hip)
 // and into a CPU emulation used only by the tests (tests/cpu/ahc_reforder_emul.cpp) to check it against the reference build on
-// tie-heavy inputs without a GPU.  It follows the BEHAVIOUR of the cited structures (which comparison is strict, which child wins,
-// what moves where); it shares no code with them.
+// tie-heavy inputs without a GPU.  The heap below RESTATES the reference's binary_min_heap (fastcluster_internal.hpp:845-922: remove / replace /
+// update_geq_ / update_leq_, statement for statement with other array names): the order a heap breaks ties in IS its sequence of swaps — which
+// comparison is strict, which child wins, what moves where — so reproducing that order admits no other sequence.
 #pragma once
 #include <cstdint>
 

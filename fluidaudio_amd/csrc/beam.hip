@@ -851,6 +851,7 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
     ta.logp = d_log_probs; ta.valid = d_valid_frames; ta.tok = a.tok; ta.top = d_top.as<TopEntry>();
     ta.row_stride = row_stride; ta.matrix_stride = matrix_stride; ta.frames = frames; ta.vocab = vocab; ta.blank = blank_id;
     ta.top_k = token_candidates; ta.use_lm = a.use_lm;
+    if (ctx->timing) FA_HIP_TRY(ctx, hipEventRecord(ctx->tim_ev[0], ctx->stream));   // device work of the call: behind the allocations
     for (int first = 0; first < batch; first += chunk) {
         const int now = std::min(chunk, batch - first);
         a.first = first;
@@ -871,7 +872,9 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
         else hipLaunchKernelGGL((ctc_beam_kernel<32, false>), dim3(now), dim3(kThreads), 0, ctx->stream, a);
         FA_HIP_TRY(ctx, hipGetLastError());
     }
+    if (ctx->timing) FA_HIP_TRY(ctx, hipEventRecord(ctx->tim_ev[1], ctx->stream));
     FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the arena and the tables go back to the context's cache on return
+    if (ctx->timing) { float ms = -1.0f; FA_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->tim_ev[0], ctx->tim_ev[1])); ctx->last_device_ms = ms; }
     if (a.prof) {
         unsigned long long h[16];
         FA_HIP_TRY(ctx, hipMemcpy(h, d_prof.p, 128, hipMemcpyDeviceToHost));
@@ -880,6 +883,18 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
                         "selection level 1 %.0f (cancelled extensions %.0f, bound %.0f, gather %.0f, barrier %.0f) | level 2 %.0f | rank sort %.0f | new beams %.0f\n",
                 h[0] / f, h[2] / f, h[3] / f, (h[4] + h[8] + h[9] + h[10]) / f, h[8] / f, h[9] / f, h[10] / f, h[4] / f, h[5] / f, h[6] / f, h[7] / f);
     }
+    return FA_SUCCESS;
+}
+
+// What a call of these shapes launches (bench.py prints it next to its timing): out = { trie slots per utterance (arena_stride), utterances
+// per launch (the ~2 GiB arena cap), launches, extension keys per thread of the ctc_beam_kernel<MAXE, false> instance (8 / 20 / 32) }.
+fa_status fa_ctc_beam_plan(int32_t batch, int32_t frames, int32_t vocab, int32_t beam_width, int32_t blank_id, int32_t token_candidates, int64_t out[4]) {
+    if (!out || batch < 0 || frames < 0 || vocab < 1 || beam_width < 1 || beam_width > kMaxBeam || token_candidates < 0 || token_candidates > kMaxTop) return FA_INVALID_ARGUMENT;
+    const int64_t stride = static_cast<int64_t>(pow2_at_least(static_cast<size_t>(2) * frames * beam_width + 2));
+    const int64_t per = stride * static_cast<int64_t>(sizeof(unsigned long long));
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(batch, (int64_t(2) << 30) / std::max<int64_t>(per, 1)));
+    const int ntop = std::min(token_candidates, vocab - (blank_id >= 0 && blank_id < vocab ? 1 : 0));
+    out[0] = stride; out[1] = chunk; out[2] = batch > 0 ? (batch + chunk - 1) / chunk : 0; out[3] = ntop <= 16 ? 8 : (ntop <= 40 ? 20 : 32);
     return FA_SUCCESS;
 }
 

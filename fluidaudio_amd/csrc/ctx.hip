@@ -1,5 +1,6 @@
 // ctx.hip — context lifetime for libfluidaudio_hip.so.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -16,6 +17,36 @@ void free_caches_locked(fa_ctx *c, bool scratch_too) {   // registry mutex held,
     if (c->ahc_ws) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->ahc_ws); c->ahc_ws = nullptr; c->ahc_ws_bytes = 0; }
     if (scratch_too && c->scratch) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
 }
+
+// HBM pressure on `device`: everything the library holds there WITHOUT using it goes — the buffer caches of every context (the caller's own,
+// its workers and helpers, every other context: a cached buffer is idle by definition) and the linkage workspaces of the contexts that are not
+// inside a linkage call.  The pointers are taken out of the contexts under the locks (a context may be destroyed by its owner the moment the
+// registry lock is dropped); the hipFree calls — each waits for the device — run after the locks are released.  Returns the bytes released.
+size_t release_idle_device_memory(const fa_ctx *self, const int device) {
+    std::vector<void *> doomed;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        for (fa_ctx *c : g_registry) {
+            if (c->device != device) continue;
+            {
+                std::lock_guard<std::mutex> bl(c->buf_mutex);
+                for (auto &b : c->buf_free) { doomed.push_back(b.first); bytes += b.second; }
+                c->buf_free.clear();
+                c->buf_cached_bytes = 0;
+            }
+            if (c != self && !c->ws_busy && c->ahc_ws) { doomed.push_back(c->ahc_ws); bytes += c->ahc_ws_bytes; c->ahc_ws = nullptr; c->ahc_ws_bytes = 0; }
+        }
+    }
+    if (!doomed.empty()) {
+        fa::DeviceGuard guard(device);
+        (void)hipDeviceSynchronize();   // the last users of a cached buffer / an idle workspace may still be in flight on their streams
+        for (void *q : doomed) (void)hipFree(q);
+    }
+    return bytes;
+}
+
+std::atomic<int32_t> g_fault[FA_FAULT_SITES];
 }  // namespace
 
 namespace fa {
@@ -31,15 +62,11 @@ fa_status ws_acquire(fa_ctx *ctx, size_t bytes) {
         if (ctx->ahc_ws_bytes >= bytes) return FA_SUCCESS;
     }
     if (ctx->ahc_ws) { FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ahc_ws); ctx->ahc_ws = nullptr; ctx->ahc_ws_bytes = 0; }
-    hipError_t e = hipMalloc(&ctx->ahc_ws, bytes);
-    if (e != hipSuccess) {   // HBM pressure: the idle linkage workspaces of the other contexts on this device go first (their scratch stays)
+    hipError_t e = fault_hit(FA_FAULT_WS_MALLOC) ? hipErrorOutOfMemory : hipMalloc(&ctx->ahc_ws, bytes);
+    if (e != hipSuccess) {   // HBM pressure: the buffer caches of every context on this device and the idle linkage workspaces of the others go first
         (void)hipGetLastError();
         ctx->ahc_ws = nullptr;
-        {
-            std::lock_guard<std::mutex> lock(g_registry_mutex);
-            for (fa_ctx *c : g_registry)
-                if (c != ctx && c->device == ctx->device && !c->ws_busy && c->ahc_ws) free_caches_locked(c, false);
-        }
+        (void)release_idle_device_memory(ctx, ctx->device);
         e = hipMalloc(&ctx->ahc_ws, bytes);
     }
     if (e != hipSuccess) {
@@ -57,8 +84,15 @@ void ws_release(fa_ctx *ctx) {
     if (ctx->ahc_ws && ctx->ahc_ws_bytes > ctx->ws_limit) free_caches_locked(ctx, false);
 }
 
+// ---- fault injection for the tests (fa_debug_inject_fault): the next `count` passes through a site fail
+bool fault_hit(const int site) {
+    if (site < 0 || site >= FA_FAULT_SITES) return false;
+    if (g_fault[site].load(std::memory_order_relaxed) <= 0) return false;
+    return g_fault[site].fetch_sub(1, std::memory_order_relaxed) > 0;
+}
+
 // ---- buffer cache of a context (see fa_ctx::buf_free)
-constexpr size_t kBufCacheLimit = static_cast<size_t>(3) << 30;   // bytes a context keeps; beyond that a returned buffer is released
+constexpr size_t kBufCacheLimit = static_cast<size_t>(3) << 30;   // bytes a context keeps at most; ws_limit (fa_ctx_set_workspace_limit) bounds it further
 void buf_cache_flush(fa_ctx *ctx) {                               // caller holds ctx->buf_mutex
     for (auto &b : ctx->buf_free) (void)hipFree(b.first);
     ctx->buf_free.clear();
@@ -80,10 +114,10 @@ hipError_t devbuf_take(fa_ctx *ctx, size_t bytes, void **p, size_t *cap) {
         }
     }
     const size_t want = (bytes + 255) & ~static_cast<size_t>(255);
-    hipError_t e = hipMalloc(p, want);
-    if (e != hipSuccess) {   // HBM pressure: this context's own cache goes first
+    hipError_t e = fault_hit(FA_FAULT_DEVBUF_MALLOC) ? hipErrorOutOfMemory : hipMalloc(p, want);
+    if (e != hipSuccess) {   // HBM pressure: every idle byte the library holds on this device goes (the caches of ALL its contexts, idle linkage workspaces)
         (void)hipGetLastError();
-        { std::lock_guard<std::mutex> lock(ctx->buf_mutex); buf_cache_flush(ctx); }
+        (void)release_idle_device_memory(ctx, ctx->device);
         e = hipMalloc(p, want);
     }
     *cap = want;
@@ -92,7 +126,8 @@ hipError_t devbuf_take(fa_ctx *ctx, size_t bytes, void **p, size_t *cap) {
 void devbuf_give(fa_ctx *ctx, void *p, size_t cap) {
     {
         std::lock_guard<std::mutex> lock(ctx->buf_mutex);
-        if (ctx->buf_cached_bytes + cap <= kBufCacheLimit && ctx->buf_free.size() < 256) {
+        const size_t limit = ctx->ws_limit < kBufCacheLimit ? ctx->ws_limit : kBufCacheLimit;   // ws_limit 0 = keep nothing between calls
+        if (ctx->buf_cached_bytes + cap <= limit && ctx->buf_free.size() < 256) {
             ctx->buf_free.emplace_back(p, cap);
             ctx->buf_cached_bytes += cap;
             return;
@@ -118,6 +153,10 @@ fa_status ensure_scratch(fa_ctx *ctx, size_t bytes) {
 extern "C" {
 
 const char *fa_version(void) { return "fluidaudio_hip 0.1 gfx950"; }
+
+void fa_debug_inject_fault(int32_t site, int32_t count) {
+    if (site >= 0 && site < FA_FAULT_SITES) g_fault[site].store(count < 0 ? 0 : count, std::memory_order_relaxed);
+}
 
 fa_status fa_ctx_create(int device, void *stream, fa_ctx **out) {
     if (!out) return FA_INVALID_ARGUMENT;
@@ -160,6 +199,7 @@ void fa_ctx_destroy(fa_ctx *ctx) {
     if (ctx->ahc_graph && ctx->ahc_graph_free) ctx->ahc_graph_free(ctx->ahc_graph);
     if (ctx->mel_cache && ctx->mel_cache_free) ctx->mel_cache_free(ctx->mel_cache);
     for (auto &e : ctx->ahc_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->tim_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -172,9 +212,23 @@ fa_status fa_ctx_set_workspace_limit(fa_ctx *ctx, size_t bytes) {
     if (!ctx) return FA_INVALID_ARGUMENT;
     for (fa_ctx *h : ctx->helpers) if (h) (void)fa_ctx_set_workspace_limit(h, bytes);
     for (fa_ctx *h : ctx->workers) if (h) (void)fa_ctx_set_workspace_limit(h, bytes);
-    std::lock_guard<std::mutex> lock(g_registry_mutex);
-    ctx->ws_limit = bytes;
-    if (!ctx->ws_busy && ctx->ahc_ws && ctx->ahc_ws_bytes > bytes) free_caches_locked(ctx, false);
+    std::vector<void *> doomed;
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        ctx->ws_limit = bytes;
+        if (!ctx->ws_busy && ctx->ahc_ws && ctx->ahc_ws_bytes > bytes) free_caches_locked(ctx, false);
+        std::lock_guard<std::mutex> bl(ctx->buf_mutex);   // the buffer cache obeys the same limit
+        while (!ctx->buf_free.empty() && ctx->buf_cached_bytes > bytes) {
+            doomed.push_back(ctx->buf_free.back().first);
+            ctx->buf_cached_bytes -= ctx->buf_free.back().second;
+            ctx->buf_free.pop_back();
+        }
+    }
+    if (!doomed.empty()) {
+        fa::DeviceGuard guard(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void *q : doomed) (void)hipFree(q);
+    }
     return FA_SUCCESS;
 }
 
@@ -191,10 +245,24 @@ fa_status fa_ctx_trim(fa_ctx *ctx) {
     if (!ctx) return FA_INVALID_ARGUMENT;
     for (fa_ctx *h : ctx->helpers) if (h) (void)fa_ctx_trim(h);
     for (fa_ctx *h : ctx->workers) if (h) (void)fa_ctx_trim(h);
-    std::lock_guard<std::mutex> lock(g_registry_mutex);
-    if (ctx->ws_busy) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "trim: the context is inside a linkage call");
-    free_caches_locked(ctx, true);
-    { fa::DeviceGuard guard(ctx->device); (void)hipStreamSynchronize(ctx->stream); std::lock_guard<std::mutex> bl(ctx->buf_mutex); fa::buf_cache_flush(ctx); }
+    // the registry lock guards the bookkeeping only: the pointers are taken out under it, the stream synchronisation and the hipFree calls (each
+    // waits for the whole device) happen after it is dropped — another context's ws_acquire / ws_release never waits for this context's kernels
+    std::vector<void *> doomed;
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        if (ctx->ws_busy) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "trim: the context is inside a linkage call");
+        if (ctx->ahc_ws) { doomed.push_back(ctx->ahc_ws); ctx->ahc_ws = nullptr; ctx->ahc_ws_bytes = 0; }
+        if (ctx->scratch) { doomed.push_back(ctx->scratch); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+        std::lock_guard<std::mutex> bl(ctx->buf_mutex);
+        for (auto &b : ctx->buf_free) doomed.push_back(b.first);
+        ctx->buf_free.clear();
+        ctx->buf_cached_bytes = 0;
+    }
+    {
+        fa::DeviceGuard guard(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void *q : doomed) (void)hipFree(q);
+    }
     if (ctx->mel_cache && ctx->mel_cache_free) { ctx->mel_cache_free(ctx->mel_cache); ctx->mel_cache = nullptr; }
     return FA_SUCCESS;
 }
@@ -206,6 +274,47 @@ size_t fa_ctx_workspace_bytes(const fa_ctx *ctx) {
     for (const fa_ctx *h : ctx->helpers) if (h) total += h->ahc_ws_bytes + h->scratch_bytes + h->buf_cached_bytes;
     for (const fa_ctx *h : ctx->workers) if (h) total += h->ahc_ws_bytes + h->scratch_bytes + h->buf_cached_bytes;
     return total;
+}
+
+// Device-time bracket of the entries that support it (today: fa_ctc_beam_search_batch_dev): events on the context's stream around the
+// device work of a call, after its allocations.  fa_ctx_last_device_ms: milliseconds of the last bracketed call, < 0 if none.
+fa_status fa_ctx_set_timing(fa_ctx *ctx, int32_t enable) {
+    if (!ctx) return FA_INVALID_ARGUMENT;
+    fa::DeviceGuard guard(ctx->device);
+    if (enable) for (auto &e : ctx->tim_ev) if (!e) FA_HIP_TRY(ctx, hipEventCreate(&e));
+    ctx->timing = enable != 0;
+    ctx->last_device_ms = -1.0;
+    return FA_SUCCESS;
+}
+double fa_ctx_last_device_ms(const fa_ctx *ctx) { return ctx ? ctx->last_device_ms : -1.0; }
+
+// The shader clock the device runs at right now: one wavefront spins for ~`spin_us` microseconds of the constant 100 MHz counter
+// (s_memrealtime) and counts shader cycles (s_memtime) meanwhile.  A latency-bound kernel (the beam search walk, the merge chain) scales
+// with this clock; bench.py prints it next to such legs so that a run at idle clocks can be told from a slow kernel.
+namespace {
+__global__ void sclk_probe_kernel(unsigned long long *out, const unsigned long long ticks) {
+    const unsigned long long r0 = wall_clock64(), c0 = clock64();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) r1 = wall_clock64();
+    const unsigned long long c1 = clock64();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+}  // namespace
+fa_status fa_debug_sclk_mhz(fa_ctx *ctx, int32_t spin_us, double *mhz) {
+    if (!ctx || !mhz) return FA_INVALID_ARGUMENT;
+    *mhz = 0.0;
+    if (spin_us < 1) spin_us = 1;
+    if (spin_us > 100000) spin_us = 100000;
+    fa::DeviceGuard guard(ctx->device);
+    FA_TRY(fa::ensure_scratch(ctx, 256));
+    unsigned long long *d = static_cast<unsigned long long *>(ctx->scratch);
+    hipLaunchKernelGGL(sclk_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, d, static_cast<unsigned long long>(spin_us) * 100ull);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    FA_HIP_TRY(ctx, hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (h[1] > 0) *mhz = 100.0 * static_cast<double>(h[0]) / static_cast<double>(h[1]);
+    return FA_SUCCESS;
 }
 
 fa_status fa_ctx_synchronize(fa_ctx *ctx) {

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -53,6 +54,11 @@ struct fa_ctx {
     std::mutex buf_mutex;                      // buffers may come back from another thread than the one using the context
     std::vector<std::pair<void *, size_t>> buf_free;
     size_t buf_cached_bytes = 0;
+    // fa_ctx_set_timing: entries that support it bracket their DEVICE work (after their allocations) with two events on the stream, so a caller
+    // can tell kernel time from host-side allocation time (bench.py's beam-search leg); last_device_ms < 0: nothing recorded
+    bool timing = false;
+    hipEvent_t tim_ev[2] = {nullptr, nullptr};
+    double last_device_ms = -1.0;
     // fa_offline_cluster_batch prepares / finishes its recordings on worker contexts (own stream each); kept between calls since round 4
     fa_ctx *workers[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -102,6 +108,23 @@ inline fa_status no_throw(fa_ctx *ctx, const char *what, F &&f) noexcept {
         if (fa_s_ != FA_SUCCESS) return fa_s_;  \
     } while (0)
 
+// Test hook (fa_debug_inject_fault, ctx.hip): true for the next `count` passes through `site`.  One relaxed atomic load when nothing is armed.
+bool fault_hit(int site);
+
+// A host thread for `f`, appended to `pool`; false when none is to be had (std::system_error from the constructor, std::bad_alloc from the
+// vector, or an armed FA_FAULT_THREAD_START) — the caller then runs that share itself.  An exception escaping while `pool` holds joinable threads
+// would std::terminate the process across the C ABI.
+template <class F>
+inline bool start_thread(std::vector<std::thread> &pool, F &&f) noexcept {
+    if (fault_hit(FA_FAULT_THREAD_START)) return false;
+    try {
+        pool.emplace_back(std::forward<F>(f));
+        return true;
+    } catch (...) {
+        return false;
+    }
+}
+
 // RAII device buffer.  alloc(bytes): a one-call temporary of the host-pointer entry points (hipMalloc / hipFree).  alloc(ctx, bytes): taken
 // from / returned to the context's buffer cache (ctx.hip) — for buffers used on that context's stream only.
 hipError_t devbuf_take(fa_ctx *ctx, size_t bytes, void **p, size_t *cap);
@@ -110,7 +133,13 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     fa_ctx *owner = nullptr;
-    ~DevBuf() { if (p) { if (owner) devbuf_give(owner, p, cap); else (void)hipFree(p); } }
+    ~DevBuf() { reset(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;             // one owner: a copy would release the buffer twice
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap), owner(o.owner) { o.p = nullptr; o.cap = 0; o.owner = nullptr; }
+    DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { reset(); p = o.p; cap = o.cap; owner = o.owner; o.p = nullptr; o.cap = 0; o.owner = nullptr; } return *this; }
+    void reset() { if (p) { if (owner) devbuf_give(owner, p, cap); else (void)hipFree(p); } p = nullptr; cap = 0; owner = nullptr; }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
     hipError_t alloc(fa_ctx *ctx, size_t bytes) {
         const hipError_t e = devbuf_take(ctx, bytes ? bytes : 1, &p, &cap);
@@ -149,6 +178,9 @@ struct VbxDevice {   // buffers of one VBx run; gamma [T][S], pi [S] and hard [T
 };
 fa_status vbx_run_dev(fa_ctx *ctx, const double *d_X, int64_t T, int32_t D, const int32_t *d_labels, int32_t S, const double *phi_host,
                       double Fa, double Fb, int32_t max_iter, double epsilon, double *elbos_host, int32_t *n_iters, VbxDevice &out);   // vbx.hip
+
+// VBxClustering.refine's catch block (VBxClustering.swift:136-141) on the device: gamma = one-hot labels, pi = 1/S, hard = clamped labels
+fa_status vbx_degrade_dev(fa_ctx *ctx, int64_t T, int32_t S, const int32_t *d_labels, VbxDevice &out);                             // vbx.hip
 
 fa_status centroids_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_gamma, int32_t S, const int32_t *d_spk, int32_t K,
                         double *d_cent);                                                                                             // post.hip

@@ -163,7 +163,7 @@ struct ClusterJob {
         fa::DevBuf b_lab;
         std::vector<double> pi;
         std::vector<int32_t> hard;
-        bool have_vbx = false, adjusted = false;
+        bool have_vbx = false, adjusted = false, vbx_degraded = false;
         int32_t vbx_iters = 0;
         std::vector<double> km_centroids;
         std::vector<int32_t> km_labels;
@@ -172,8 +172,13 @@ struct ClusterJob {
             if (b_lab.alloc(ctx, sizeof(int32_t) * nt) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
             FA_HIP_TRY(ctx, hipMemcpyAsync(b_lab.p, initial.data(), sizeof(int32_t) * nt, hipMemcpyHostToDevice, st));
             std::vector<double> elbos(static_cast<size_t>(std::max(config->max_vbx_iterations, 1)));
-            FA_TRY(fa::vbx_run_dev(ctx, d_trho, nt, rho_dim, b_lab.as<int32_t>(), S, phi, config->warm_start_fa, config->warm_start_fb,
-                                   config->max_vbx_iterations, config->convergence_tolerance, elbos.data(), &vbx_iters, vbx));
+            const fa_status vbx_st = fa::vbx_run_dev(ctx, d_trho, nt, rho_dim, b_lab.as<int32_t>(), S, phi, config->warm_start_fa, config->warm_start_fb,
+                                                     config->max_vbx_iterations, config->convergence_tolerance, elbos.data(), &vbx_iters, vbx);
+            if (vbx_st != FA_SUCCESS) {   // VBxClustering.refine's catch block (VBxClustering.swift:136-141): gamma = one-hot AHC labels, pi = 1/S, no ELBOs — and on
+                vbx_iters = 0;
+                vbx_degraded = true;
+                FA_TRY(fa::vbx_degrade_dev(ctx, nt, S, b_lab.as<int32_t>(), vbx));
+            }
             pi.resize(S);
             FA_HIP_TRY(ctx, hipMemcpyAsync(pi.data(), vbx.pi.p, sizeof(double) * S, hipMemcpyDeviceToHost, st));
             const bool has_constraints = config->num_speakers >= 0 || config->min_speakers >= 0 || config->max_speakers >= 0;   // :309-312
@@ -267,7 +272,7 @@ struct ClusterJob {
         const double t_end = now_s();
         if (info) {
             info->training_rows = nt; info->initial_clusters = S; info->vbx_iterations = vbx_iters; info->was_adjusted = adjusted ? 1 : 0;
-            info->constrained = constrained ? 1 : 0;
+            info->constrained = constrained ? 1 : 0; info->vbx_degraded = vbx_degraded ? 1 : 0; info->ahc_degraded = (nt >= 2 && ahc_status != FA_SUCCESS) ? 1 : 0;
             info->inputs_s = t_inputs - t_begin; info->ahc_s = t_ahc - t_inputs; info->vbx_s = t_vbx - t_ahc; info->assign_s = t_end - t_vbx;
             info->total_s = t_end - t_begin; info->ahc = ahc_stats;
         }
@@ -309,7 +314,8 @@ fa_status fa_offline_cluster(fa_ctx *ctx, const float *embeddings, int64_t n, in
         FA_TRY(job.prepare());
         fa_status ahc_st = FA_SUCCESS;
         if (job.nt >= 2)
-            ahc_st = fa::ahc_run_device(ctx, job.b_norm.as<double>(), static_cast<size_t>(job.nt), static_cast<size_t>(d), job.b_z.as<double>(), config->ahc_mode, &job.ahc_stats);
+            ahc_st = fa::fault_hit(FA_FAULT_AHC) ? FA_RUNTIME_ERROR
+                                                 : fa::ahc_run_device(ctx, job.b_norm.as<double>(), static_cast<size_t>(job.nt), static_cast<size_t>(d), job.b_z.as<double>(), config->ahc_mode, &job.ahc_stats);
         return job.finish(ahc_st);
     });
 }
@@ -330,7 +336,8 @@ fa_status fa_offline_cluster_ex(fa_ctx *ctx, const float *embeddings, int64_t n,
         FA_TRY(job.prepare());
         fa_status ahc_st = FA_SUCCESS;
         if (job.nt >= 2)
-            ahc_st = fa::ahc_run_device(ctx, job.b_norm.as<double>(), static_cast<size_t>(job.nt), static_cast<size_t>(d), job.b_z.as<double>(), config->ahc_mode, &job.ahc_stats);
+            ahc_st = fa::fault_hit(FA_FAULT_AHC) ? FA_RUNTIME_ERROR
+                                                 : fa::ahc_run_device(ctx, job.b_norm.as<double>(), static_cast<size_t>(job.nt), static_cast<size_t>(d), job.b_z.as<double>(), config->ahc_mode, &job.ahc_stats);
         return job.finish(ahc_st);
     });
 }
@@ -379,10 +386,15 @@ fa_status fa_offline_cluster_batch(fa_ctx *ctx, int32_t count, const float *cons
                 (void)hipStreamSynchronize(c->stream);
             };
             std::vector<std::thread> th;
-            for (int t = 1; t < workers; ++t) if (wctx[t]) th.emplace_back(work, t, t);
+            std::vector<char> started(static_cast<size_t>(workers), 0);
+            th.reserve(static_cast<size_t>(workers));
+            for (int t = 1; t < workers; ++t) if (wctx[t]) started[static_cast<size_t>(t)] = fa::start_thread(th, [&work, t]() { work(t, t); }) ? 1 : 0;
             work(0, 0);
             for (auto &x : th) x.join();
-            for (int t = 1; t < workers; ++t) if (!wctx[t]) work(0, t);   // a worker without a stream of its own: the caller's context takes its share
+            for (int t = 1; t < workers; ++t) {
+                if (!wctx[t]) work(0, t);                               // a worker without a stream of its own: the caller's context takes its share
+                else if (!started[static_cast<size_t>(t)]) work(t, t);   // no host thread to be had: the calling thread runs that worker's share on the worker's stream
+            }
         };
         on_workers([&](const int32_t r) { return jobs[r].prepare(); });
         // the merge chains of all recordings advance together (one launch = one round of every unfinished recording)

@@ -81,7 +81,7 @@ fa_status run_sharded(fa_pool *pool, const std::vector<int32_t> &cut, Job job) {
             catch (...) { st[static_cast<size_t>(i)] = FA_RUNTIME_ERROR; }
         };
         if (i == last) body();               // the calling thread takes the last shard
-        else th.emplace_back(body);
+        else if (!fa::start_thread(th, body)) body();   // no host thread to be had: that shard runs here, before the next one starts
     }
     for (auto &t : th) t.join();
     for (const fa_status s : st) if (s != FA_SUCCESS) return s;

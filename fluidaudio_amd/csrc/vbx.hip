@@ -403,7 +403,13 @@ fa_status fa_vbx_refine(fa_ctx *ctx, const double *rho, int64_t T, int32_t D, co
         FA_HIP_TRY(ctx, hipMemcpyAsync(bX.p, rho, 8 * TD, hipMemcpyHostToDevice, st));
         FA_HIP_TRY(ctx, hipMemcpyAsync(blab.p, initial, 4 * T, hipMemcpyHostToDevice, st));
         fa::VbxDevice dev;
-        FA_TRY(fa::vbx_run_dev(ctx, bX.as<double>(), T, D, blab.as<int32_t>(), S, phi, Fa, Fb, max_iter, epsilon, elbos, n_iters, dev));
+        const fa_status run = fa::vbx_run_dev(ctx, bX.as<double>(), T, D, blab.as<int32_t>(), S, phi, Fa, Fb, max_iter, epsilon, elbos, n_iters, dev);
+        if (run != FA_SUCCESS) {   // VBxClustering.refine's catch block (:136-141): the refinement degrades to its start, it does not fail
+            const std::string why = ctx->last_error;
+            *n_iters = 0;          // elboHistory = []
+            FA_TRY(fa::vbx_degrade_dev(ctx, T, S, blab.as<int32_t>(), dev));
+            fa::set_error(ctx, FA_SUCCESS, "vbx: degraded to the initial clusters (%s)", why.c_str());
+        }
         FA_HIP_TRY(ctx, hipMemcpyAsync(gamma, dev.gamma.p, 8 * TS, hipMemcpyDeviceToHost, st));
         FA_HIP_TRY(ctx, hipMemcpyAsync(pi, dev.pi.p, 8 * S, hipMemcpyDeviceToHost, st));
         FA_HIP_TRY(ctx, hipMemcpyAsync(hard, dev.hard.p, 4 * T, hipMemcpyDeviceToHost, st));
@@ -507,6 +513,7 @@ fa_status fa::vbx_run_dev(fa_ctx *ctx, const double *d_X, int64_t T, int32_t D, 
     if (n_iters) *n_iters = 0;
     VbxWs w;
     FA_TRY(vbx_setup(ctx, d_X, T, T, 0, D, d_labels, S, phi_host, Fa, Fb, 0, kSplit, o, w));
+    if (fa::fault_hit(FA_FAULT_VBX)) return fa::set_error(ctx, FA_RUNTIME_ERROR, "vbx: injected failure");
     FA_TRY(vbx_records(ctx, w));
     double prev = -1.7976931348623157e308;
     int iters = 0;
@@ -522,6 +529,39 @@ fa_status fa::vbx_run_dev(fa_ctx *ctx, const double *d_X, int64_t T, int32_t D, 
     }
     FA_TRY(vbx_hard_phase(ctx, w, o.hard.as<int32_t>()));
     if (n_iters) *n_iters = iters;
+    return FA_SUCCESS;
+}
+
+// VBxClustering.refine's catch block (VBxClustering.swift:136-141): when runVBx throws, the refinement does not fail — it returns
+// gamma = initialGamma (the plain one-hot of the clamped initial labels, :100-104, NOT the smoothed start of runVBx), pi = 1/S, no ELBOs,
+// and hardClusters = argmax of that gamma = the clamped labels (:144-146).  The stages behind it go on with those.  Buffers of `o` that a
+// failed run left allocated are reused; the three outputs are (re)allocated if the failure was the allocation itself.
+__global__ void vbx_degrade_kernel(const int32_t *__restrict__ labels, double *__restrict__ gamma, int32_t *__restrict__ hard, const int64_t T, const int32_t S) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= T * S) return;
+    const int64_t t = i / S;
+    const int32_t s = static_cast<int32_t>(i - t * S);
+    int32_t l = labels[t];
+    l = l < 0 ? 0 : (l > S - 1 ? S - 1 : l);   // max(0, min(cluster, speakerCount - 1)) (:102)
+    gamma[i] = s == l ? 1.0 : 0.0;
+    if (s == 0) hard[t] = l;
+}
+fa_status fa::vbx_degrade_dev(fa_ctx *ctx, int64_t T, int32_t S, const int32_t *d_labels, fa::VbxDevice &o) {
+    (void)hipGetLastError();
+    if (T < 0 || S < 1) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "vbx degrade: bad shape");
+    const size_t Tn = static_cast<size_t>(T > 0 ? T : 1);
+    hipError_t e = hipSuccess;
+    auto need = [&](fa::DevBuf &b, size_t bytes) { if (e == hipSuccess && (!b.p || b.cap < bytes)) { b.reset(); e = b.alloc(ctx, bytes); } };
+    need(o.gamma, 8 * Tn * S); need(o.pi, 8 * static_cast<size_t>(S)); need(o.hard, 4 * Tn);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "vbx degrade: device allocation failed"); }
+    o.T = T; o.S = S;
+    if (T > 0) {
+        const int64_t total = T * S;
+        hipLaunchKernelGGL(vbx_degrade_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, ctx->stream, d_labels, o.gamma.as<double>(),
+                           o.hard.as<int32_t>(), T, S);
+    }
+    hipLaunchKernelGGL(vbx_fill, dim3((S + 255) / 256), dim3(256), 0, ctx->stream, o.pi.as<double>(), S, 1.0 / static_cast<double>(S));   // :139
+    FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }
 

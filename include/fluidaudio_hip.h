@@ -75,6 +75,23 @@ const char *fa_ctx_last_error(const fa_ctx *ctx);
 /* Library build identification, e.g. "fluidaudio_hip 0.1 gfx950". */
 const char *fa_version(void);
 
+/* Test hook: the next `count` passes through `site` fail the way the real failure would (count 0 disarms).  Process-wide; one relaxed
+ * atomic load on the paths that carry a site.  Used by the fault-injection tests of the degrade contracts:
+ *   FA_FAULT_VBX            fa::vbx_run_dev returns RUNTIME_ERROR  -> VBxClustering.refine's catch block (VBxClustering.swift:136-141)
+ *   FA_FAULT_THREAD_START   no host thread to be had (std::system_error) -> the share runs on the calling thread
+ *   FA_FAULT_DEVBUF_MALLOC  the first hipMalloc of a cached-buffer request fails -> idle caches of the device released, retried
+ *   FA_FAULT_WS_MALLOC      the first hipMalloc of a linkage workspace fails     -> the same
+ *   FA_FAULT_AHC            the linkage of fa_offline_cluster fails -> singletons (AHCClustering.swift:52-55) */
+enum { FA_FAULT_VBX = 0, FA_FAULT_THREAD_START = 1, FA_FAULT_DEVBUF_MALLOC = 2, FA_FAULT_WS_MALLOC = 3, FA_FAULT_AHC = 4, FA_FAULT_SITES = 5 };
+void fa_debug_inject_fault(int32_t site, int32_t count);
+/* Measurement support.  fa_ctx_set_timing(1): entries that support it (fa_ctc_beam_search_batch_dev) bracket the DEVICE work of a call —
+ * behind its allocations — with two events on the context's stream; fa_ctx_last_device_ms returns that time (< 0: none recorded), so a
+ * caller can tell kernel time from host-side allocation time.  fa_debug_sclk_mhz: the shader clock right now (one wavefront counts
+ * s_memtime cycles over spin_us microseconds of the constant 100 MHz s_memrealtime counter). */
+fa_status fa_ctx_set_timing(fa_ctx *ctx, int32_t enable);
+double fa_ctx_last_device_ms(const fa_ctx *ctx);
+fa_status fa_debug_sclk_mhz(fa_ctx *ctx, int32_t spin_us, double *mhz);
+
 /* ------------------------------------------------------------------ mel ------------- */
 /* Replaces AudioMelSpectrogram (FluidAudio/Shared/AudioMelSpectrogram.swift):
  *   ctor parameters :59-70, computeFlat :185-292, computeFlatTransposed :325-456,
@@ -399,6 +416,8 @@ typedef struct {
     int32_t vbx_iterations;
     int32_t was_adjusted;            /* the K-Means fallback replaced the VBx posteriors (VBxOutput.wasAdjusted) */
     int32_t constrained;             /* the constrained per-chunk assignment was used */
+    int32_t vbx_degraded;            /* VBx failed: gamma = one-hot AHC labels, pi = 1/S, no ELBOs, the stage went on (VBxClustering.swift:136-141) */
+    int32_t ahc_degraded;            /* the linkage failed: every training row its own cluster (AHCClustering.swift:52-55) */
     double inputs_s, ahc_s, vbx_s, assign_s, total_s;   /* host wall-clock per stage (copies included) */
     fa_ahc_stats ahc;
 } fa_offline_cluster_info;
@@ -486,6 +505,10 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
                                        float word_bonus, int32_t blank_id, int32_t token_candidates, int32_t *d_tokens,
                                        int32_t *d_lens, float *d_scores);
 /* Same with HOST pointers and contiguous matrices. */
+/* What a search of these shapes launches: out = { trie slots per utterance, utterances per launch (the ~2 GiB arena cap), launches,
+ * extension keys per thread of the ctc_beam_kernel instance (8 / 20 / 32) }.  Host only. */
+fa_status fa_ctc_beam_plan(int32_t batch, int32_t frames, int32_t vocab, int32_t beam_width, int32_t blank_id, int32_t token_candidates,
+                           int64_t out[4]);
 fa_status fa_ctc_beam_search_batch(fa_ctx *ctx, const float *log_probs, int32_t batch, int32_t frames, int32_t vocab,
                                    const int32_t *valid_frames, const fa_ctc_vocab *vocabulary, fa_arpa_lm *lm,
                                    int32_t beam_width, float lm_weight, float word_bonus, int32_t blank_id,

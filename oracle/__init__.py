@@ -359,6 +359,20 @@ def vbx_refine(rho, initial, phi, max_iter=20, epsilon=1e-4, Fa=0.07, Fb=0.8):
     return gamma, pi, hard, elbos[:it]
 
 
+def vbx_refine_degraded(initial):
+    """What VBxClustering.refine returns when runVBx throws (VBxClustering.swift:136-146): gamma = initialGamma — the plain one-hot of
+    max(0, min(cluster, S - 1)) (:100-104), pi = 1/S (:139), no ELBOs (:140), hardClusters = first-max argmax of gamma (:144-146)."""
+    initial = np.ascontiguousarray(initial, np.int32)
+    T = initial.size
+    S = max(1, len(np.unique(initial)))                                            # :78
+    gamma = np.zeros((T, S), np.float64)
+    for i, c in enumerate(initial.tolist()):
+        gamma[i, max(0, min(c, S - 1))] = 1.0
+    pi = np.full(S, 1.0 / S)
+    hard = np.argmax(gamma, axis=1).astype(np.int32) if T else np.zeros(0, np.int32)
+    return gamma, pi, hard, np.zeros(0)
+
+
 def weighted_centroids(emb, gamma, pi):
     emb = np.ascontiguousarray(emb, np.float64)
     gamma = np.ascontiguousarray(gamma, np.float64)
@@ -441,7 +455,8 @@ def centroid_scores(emb, centroids) -> np.ndarray:
 
 
 def cluster_embeddings(embedding256, rho128, chunk_indices, phi, threshold=0.6, Fa=0.07, Fb=0.8, max_iter=20, tol=1e-4,
-                       constrained=True, num_speakers=None, min_speakers=None, max_speakers=None, initial=None):
+                       constrained=True, num_speakers=None, min_speakers=None, max_speakers=None, initial=None, vbx_fails=False,
+                       ahc_fails=False):
     """CPU restatement of OfflineDiarizerManager.cluster (:270-375) on precomputed embeddings, including the speaker-count
     constraints of VBxClustering.refineWithConstraints (VBxClustering.swift:685-733)."""
     e32 = np.asarray(embedding256, np.float32)
@@ -451,7 +466,12 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, threshold=0.6, 
     temb, trho = emb[train], np.ascontiguousarray(rho128, np.float64)[train]
     if initial is None:       # `initial`: AHC labels of the same input computed earlier (the 8 h digest runs two variants on one linkage)
         initial = ahc_cluster(temb, threshold) if len(train) >= 2 else np.zeros(len(train), np.int32)
-    gamma, pi, hard, elbos = vbx_refine(trho, initial, phi, max_iter, tol, Fa, Fb)
+    if ahc_fails and len(train) >= 2:     # AHCClustering.swift:52-55: a non-zero wrapper status degrades to one cluster per row
+        initial = np.arange(len(train), dtype=np.int32)
+    if vbx_fails:
+        gamma, pi, hard, elbos = vbx_refine_degraded(initial)
+    else:
+        gamma, pi, hard, elbos = vbx_refine(trho, initial, phi, max_iter, tol, Fa, Fb)
     out = dict(initial=np.asarray(initial), gamma=gamma, pi=pi, hard=hard, elbos=elbos, was_adjusted=False)
     if num_speakers is not None or min_speakers is not None or max_speakers is not None:
         _, lo, hi = speaker_constraints(len(train), num_speakers, min_speakers, max_speakers)

@@ -1,8 +1,10 @@
 /* A plain C host of the drop-in symbol: compiled with gcc against include/FastClusterWrapper.h and include/fluidaudio_hip.h
  * and linked to libfluidaudio_hip.so the way the reference's SwiftPM target links its FastClusterWrapper.
  * Mode "args": only the argument contract (FastClusterWrapper.cpp:203-226), needs no GPU.
- * Mode "cluster <file>": the whole clustering stage through fa_offline_cluster on a session written by the test (int64 n, int32 d,
- *   int32 rho_dim, float emb[n*d], double rho[n*rho_dim], int32 chunk[n], double phi[rho_dim]); prints one label per line.
+ * Mode "cluster <file> [fault-site]": the whole clustering stage through fa_offline_cluster on a session written by the test (int64 n,
+ *   int32 d, int32 rho_dim, float emb[n*d], double rho[n*rho_dim], int32 chunk[n], double phi[rho_dim]); prints one label per line.
+ *   With a fault site (fa_debug_inject_fault) the stage must degrade the way the reference does (VBxClustering.swift:136-141,
+ *   AHCClustering.swift:52-55) and still return SUCCESS.
  * Mode "pool": the device set (fa_pool_*): a pool over device 0 listed twice; fa_mel_batch_sharded must write exactly what fa_mel_batch
  *   writes, and 6 pthreads calling the context-free drop-in symbol at once must each get the dendrogram of a lone call.
  * Mode "run": a tie-free variant of the 6-point orthogonal-groups case probed on the reference build in SURVEY.md §8(c); prints the dendrogram. */
@@ -88,7 +90,7 @@ int main(int argc, char **argv) {
         int d = 0, rd = 0;
         if (!f || fread(&n, 8, 1, f) != 1 || fread(&d, 4, 1, f) != 1 || fread(&rd, 4, 1, f) != 1) return 90;
         float *emb = malloc(sizeof(float) * n * d);
-        double *rho = malloc(sizeof(double) * n * rd), *phi = malloc(sizeof(double) * rd), *cen = malloc(sizeof(double) * 64 * d);
+        double *rho = malloc(sizeof(double) * n * rd), *phi = malloc(sizeof(double) * rd), *cen = malloc(sizeof(double) * (64 < n ? n : 64) * d);
         int *chunk = malloc(sizeof(int) * n), *labels = malloc(sizeof(int) * n);
         if (fread(emb, sizeof(float), n * d, f) != (size_t)(n * d) || fread(rho, sizeof(double), n * rd, f) != (size_t)(n * rd) ||
             fread(chunk, sizeof(int), n, f) != (size_t)n || fread(phi, sizeof(double), rd, f) != (size_t)rd) return 91;
@@ -99,9 +101,10 @@ int main(int argc, char **argv) {
         fa_offline_cluster_default_config(&cfg);
         fa_offline_cluster_info info;
         int k = 0;
-        const fa_status st = fa_offline_cluster(ctx, emb, n, d, rho, rd, chunk, phi, &cfg, 0, labels, cen, 64, &k, &info);
-        printf("status %d clusters %d training %lld initial %d vbx_iterations %d constrained %d\n", (int)st, k, (long long)info.training_rows,
-               info.initial_clusters, info.vbx_iterations, info.constrained);
+        if (argc > 3) fa_debug_inject_fault(atoi(argv[3]), 1);
+        const fa_status st = fa_offline_cluster(ctx, emb, n, d, rho, rd, chunk, phi, &cfg, 0, labels, cen, 64 < n ? (int)n : 64, &k, &info);
+        printf("status %d clusters %d training %lld initial %d vbx_iterations %d constrained %d vbx_degraded %d ahc_degraded %d\n", (int)st, k,
+               (long long)info.training_rows, info.initial_clusters, info.vbx_iterations, info.constrained, info.vbx_degraded, info.ahc_degraded);
         for (long long i = 0; i < n; ++i) printf("%d\n", labels[i]);
         fa_ctx_destroy(ctx);
         return st;

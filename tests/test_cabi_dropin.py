@@ -95,5 +95,31 @@ def test_c_host_runs_the_whole_clustering_stage(fa, oracle_mod, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = r.stdout.strip().splitlines()
     ref = oracle_mod.cluster_embeddings(emb, rho, chunks, phi)
-    assert lines[0].startswith("status 0 clusters %d training %d " % (ref["centroids"].shape[0], emb.shape[0])) and lines[0].endswith("constrained 1")
+    assert lines[0].startswith("status 0 clusters %d training %d " % (ref["centroids"].shape[0], emb.shape[0])) and lines[0].endswith("constrained 1 vbx_degraded 0 ahc_degraded 0")
+    assert [int(v) for v in lines[1:]] == ref["assignments"].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("site,kw,flags", [(0, dict(vbx_fails=True), "vbx_degraded 1 ahc_degraded 0"), (4, dict(ahc_fails=True), "vbx_degraded 0 ahc_degraded 1")])
+def test_c_host_clustering_stage_degrades_like_the_reference(fa, oracle_mod, tmp_path, site, kw, flags):
+    """Fault injection through the plain C host: a failing VBx leaves gamma = one-hot AHC labels, pi = 1/S, no ELBOs and the stage goes on
+    (VBxClustering.swift:136-141); a failing linkage leaves one cluster per training row (AHCClustering.swift:52-55).  Status stays SUCCESS,
+    labels equal the CPU restatement of the same degrade."""
+    import struct
+    from test_gpu_pipeline import synth_session
+    emb, rho, chunks, phi, _ = synth_session(40, 4, 11)
+    path = tmp_path / "session.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<qii", emb.shape[0], emb.shape[1], rho.shape[1]))
+        f.write(np.ascontiguousarray(emb, np.float32).tobytes())
+        f.write(np.ascontiguousarray(rho, np.float64).tobytes())
+        f.write(np.ascontiguousarray(chunks, np.int32).tobytes())
+        f.write(np.ascontiguousarray(phi, np.float64).tobytes())
+    r = subprocess.run([build(fa), "cluster", str(path), str(site)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    ref = oracle_mod.cluster_embeddings(emb, rho, chunks, phi, **kw)
+    assert lines[0].startswith("status 0 clusters %d " % ref["centroids"].shape[0]) and lines[0].endswith(flags), lines[0]
+    if site == 0:
+        assert " vbx_iterations 0 " in lines[0]
     assert [int(v) for v in lines[1:]] == ref["assignments"].tolist()
