@@ -1,4 +1,4 @@
-"""A/B of the number of rows a wavefront of ctc_greedy_kernel keeps in flight: one library per value (built by scripts/gpu_r4_call16.sh with
+"""A/B of the number of rows a wavefront of ctc_greedy_kernel keeps in flight: one library per value (built by scripts/archive/gpu_r4_call16.sh with
 -DFA_CTC_ROWS=n, chosen through FLUIDAUDIO_HIP_LIBRARY), BASELINE configs[3] shapes ([1500, 1024] matrices), fp32 and fp16, HIP-event times."""
 import os
 import sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One line per library build: ms per pass of bench.resample_leg's four rate pairs (1 h of audio resident in HBM, HIP events).  The build is chosen by
-FLUIDAUDIO_HIP_LIBRARY (scripts/gpu_r4_call25.sh: default policy, nontemporal loads, nontemporal stores, both — builds of a patch that was not kept,
+FLUIDAUDIO_HIP_LIBRARY (scripts/archive/gpu_r4_call25.sh: default policy, nontemporal loads, nontemporal stores, both — builds of a patch that was not kept,
 see profiles/r04_resample_nt_ab.txt)."""
 import json
 import os
