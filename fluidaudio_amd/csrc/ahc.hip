@@ -631,7 +631,58 @@ struct WaveOut {                                                          // qua
     int cnt[kWaves];                                                      //      2 + p: partial minimum of produced row p (slot, node)
 };
 
-__device__ __forceinline__ void block_record(const Ws &w, const int par, const int blk, const double eps, const double key,
+// ---- a thread's CPT consecutive slots (columns x0 .. x0 + CPT - 1; x0 is a multiple of CPT, the arrays are 256-byte aligned): one request per
+// array and thread instead of CPT.  CPT = 1 is the round-2 .. 4 form (one slot per thread).
+template <int CPT> __device__ __forceinline__ void load_i32(const int *p, int (&v)[CPT]) {
+    static_assert(CPT == 1 || CPT == 2 || CPT == 4, "columns per thread");
+    if constexpr (CPT == 4) { const int4 q = *reinterpret_cast<const int4 *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    else if constexpr (CPT == 2) { const int2 q = *reinterpret_cast<const int2 *>(p); v[0] = q.x; v[1] = q.y; }
+    else v[0] = p[0];
+}
+template <int CPT> __device__ __forceinline__ void load_f64(const double *p, double (&v)[CPT]) {
+    if constexpr (CPT == 1) v[0] = p[0];
+    else {
+#pragma unroll
+        for (int j = 0; j < CPT; j += 2) { const double2 q = *reinterpret_cast<const double2 *>(p + j); v[j] = q.x; v[j + 1] = q.y; }
+    }
+}
+template <int CPT> __device__ __forceinline__ void store_f64(double *p, const double (&v)[CPT]) {
+    if constexpr (CPT == 1) p[0] = v[0];
+    else {
+#pragma unroll
+        for (int j = 0; j < CPT; j += 2) *reinterpret_cast<double2 *>(p + j) = make_double2(v[j], v[j + 1]);
+    }
+}
+// pair_entry for the thread's CPT columns against row slot r (node nr); columns that are dead or equal skip0 / skip1 get 0.  The ROW copies of the
+// CPT columns are one contiguous piece of row r and are requested together whenever any column wants an entry (the bytes share cache lines with
+// the wanted ones); a column whose valid copy is the column copy M[x][r] is requested on top — the rare case (see pair_entry).
+template <int CPT>
+__device__ __forceinline__ void pair_entries(const double *M, const int Np, const int r, const int nr, const int x0, const int (&nx)[CPT], const int sym_limit,
+                                             const int skip0, const int skip1, double (&out)[CPT]) {
+    if constexpr (CPT == 1) {
+        out[0] = (nx[0] != kDead && x0 != skip0 && x0 != skip1) ? pair_entry(M, Np, r, nr, x0, nx[0], sym_limit) : 0.0;
+    } else {
+        // No branch per column: every column requests ONE entry from an address that is always valid — its column copy where that is the valid one,
+        // else its row copy (also for a column that wants nothing: the value is dropped).  CPT independent requests, issued back to back.
+        const double *rowp = M + static_cast<size_t>(r) * Np + x0;
+        double v[CPT];
+        bool want[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            want[j] = nx[j] != kDead && x0 + j != skip0 && x0 + j != skip1;
+            const bool rc = nr > nx[j] || (nr < sym_limit && nx[j] < sym_limit);
+            const double *colp = M + static_cast<size_t>(x0 + j) * Np + r;
+            const double *pj = (want[j] && !rc) ? colp : rowp + j;
+            v[j] = *pj;
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) out[j] = want[j] ? v[j] : 0.0;
+    }
+}
+
+// `key` is the thread's smallest row minimum over its CPT slots (x, nx, nnx, nnnodex: that slot's), `keys_all` all of them (the window count).
+template <int CPT>
+__device__ __forceinline__ void block_record(const Ws &w, const int par, const int blk, const double eps, const double key, const double (&keys_all)[CPT],
                                              const double skey, const double (&pkey)[kPend], const int (&pslot)[kPend],
                                              const int (&pnode)[kPend], const int x, const int nx, const int nnx,
                                              const int nnnodex, WaveOut *s_out) {
@@ -649,7 +700,14 @@ __device__ __forceinline__ void block_record(const Ws &w, const int par, const i
     if (kStaleQ) { o[kStaleQ].v = m[kStaleQ]; o[kStaleQ].a = lane_value(x, L[kStaleQ]); o[kStaleQ].b = lane_value(nx, L[kStaleQ]); o[kStaleQ].c = 0; o[kStaleQ].d = 0; }
 #pragma unroll
     for (int p = 0; p < kPend; ++p) { o[kP0 + p].v = m[kP0 + p]; o[kP0 + p].a = lane_value(pslot[p], L[kP0 + p]); o[kP0 + p].b = lane_value(pnode[p], L[kP0 + p]); o[kP0 + p].c = 0; o[kP0 + p].d = 0; }
-    const int cnt = wave_count(key <= m[0] + 2.0 * eps && key < dinf());
+    // rows of this wave within 2 eps of its minimum: exact up to 3 per lane — the decision only asks whether the window holds exactly two
+    const double wl = m[0] + 2.0 * eps;
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) mine += (keys_all[j] <= wl && keys_all[j] < dinf()) ? 1 : 0;
+    int cnt = wave_count(mine >= 1);
+    if (CPT >= 2) cnt += wave_count(mine >= 2);
+    if (CPT >= 3) cnt += wave_count(mine >= 3);
     if (lane == 0) {
 #pragma unroll
         for (int q = 0; q < kNQ; ++q) s_out->q[wave][q] = o[q];
@@ -689,18 +747,27 @@ __device__ __forceinline__ void block_record(const Ws &w, const int par, const i
     }
 }
 
-__global__ __launch_bounds__(kBlk) void ahc_records(Ws w) {  // records of parity 0 from the row arrays
+template <int CPT>
+__global__ __launch_bounds__(kBlk) void ahc_records(Ws w) {  // records of parity 0 from the row arrays; one workgroup per block of kBlk * CPT slots
     __shared__ WaveOut s_out[1];
-    const int tid = threadIdx.x, blk = blockIdx.x, x = blk * kBlk + tid;
-    const int nx = w.node[x];
-    const RowSt r = w.row[x];
+    const int tid = threadIdx.x, blk = blockIdx.x, x0 = (blk * kBlk + tid) * CPT;
+    int nx[CPT];
+    load_i32<CPT>(w.node + x0, nx);
     double pkey[kPend];
     int pslot[kPend], pnode[kPend];
 #pragma unroll
     for (int p = 0; p < kPend; ++p) { pkey[p] = dinf(); pslot[p] = -1; pnode[p] = -1; }
-    const bool live = nx != kDead;
-    block_record(w, 0, blk, w.state[0].eps, live ? r.d1 : dinf(), live && r.nn < 0 ? r.d1 : dinf(), pkey, pslot, pnode, x, nx, r.nn,
-                 r.nnnode, s_out);
+    double keys_all[CPT], key = dinf(), skey = dinf();
+    int bx = x0, bnx = nx[0], bnn = -1, bnnnode = -1;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const RowSt r = w.row[x0 + j];
+        const bool live = nx[j] != kDead;
+        keys_all[j] = live ? r.d1 : dinf();
+        if (j == 0 || keys_all[j] < key) { key = keys_all[j]; bx = x0 + j; bnx = nx[j]; bnn = r.nn; bnnnode = r.nnnode; }
+        if (live && r.nn < 0 && r.d1 < skey) skey = r.d1;
+    }
+    block_record<CPT>(w, 0, blk, w.state[0].eps, key, keys_all, skey, pkey, pslot, pnode, bx, bnx, bnn, bnnnode, s_out);
 }
 
 // ------------------------------------------------------------------------------ the round kernel
@@ -819,8 +886,16 @@ struct Dec {
 // BIG: more than 65 536 points, i.e. more than four block records per lane in the first reduction.  That path holds 2 x 12 records in registers
 // and alone raised the whole kernel from 106 to 180 VGPRs (2 instead of 4 wavefronts per SIMD): it is compiled only into the kernels that
 // serve such problems, so that four times as many workgroups of the common sizes are resident — what a launch over several problems needs.
-template <bool N_IN_STATE = false, bool BIG = true>
+// CPT: slots (columns) per thread.  A block = kBlk * CPT consecutive slots, thread t owns the CPT consecutive slots from (blk * kBlk + t) * CPT on (lane
+// order == row order as before).  1 is the latency-optimal form of the single chain (the fewest dependent instructions per round).  A launch
+// over several problems (ahc_round_uni) is bound by instruction ISSUE instead — every workgroup repeats the reduction of all block records, every
+// wavefront its DPP reductions, the centroid sum, the decision arithmetic: ~830 instructions per wavefront and round whatever it owns — so
+// there a thread owns 4 slots: a quarter of the workgroups, wavefronts and block records per problem, and only the per-slot part of a round
+// (the two matrix entries, the Lance-Williams value, the row bookkeeping) is repeated per slot.
+template <bool N_IN_STATE = false, bool BIG = true, int CPT = 1>
 __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, const int ph /* round index & 3 */, const size_t late_shift = 0) {
+    static_assert(CPT == 1 || kPiggy == 0, "piggy-backed re-scans were only ever built for one slot per thread");
+    constexpr int kCols = kBlk * CPT;
     Ws w = w_in;
     extern __shared__ double s_cvec[];  // [d] merged centroid (EXACT rows)
     __shared__ WaveOut s_out[1];
@@ -829,7 +904,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     __shared__ double s_val[kWaves];
     __shared__ int s_idx[2 * kWaves];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = blk * kBlk + tid;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x0 = (blk * kBlk + tid) * CPT;   // x0: the first of this thread's slots
     const int par = ph & 1, npar = par ^ 1;
     const int Np = w.Np, nblk = w.nblk, d = w.d, N_arg = w.N;
 #ifdef FA_AHC_PROFILE
@@ -845,7 +920,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     const int pk0 = wave == 2 ? 1 : 0, pk1r = wave == 2 ? 2 : 3;
     const bool phas1 = pk1r < kPend;
     const int pk1 = phas1 ? pk1r : pk0;
-    constexpr int kC4 = 4;                                              // records per lane held in registers (N <= 65 536); beyond: the generic path
+    constexpr int kC4 = 4 / CPT;                                        // block records per lane held in registers (N <= 65 536 = 64 lanes x kC4 x kBlk x CPT); beyond: the generic path
     int4 q0[kC4], q1[kC4];
     bool qok[kC4];
     {
@@ -871,9 +946,13 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     // counter itself travels in the hot state.  Round 3 fetched the cold part in every thread next to the hot part (a broadcast line, but
     // 12 VGPRs per thread for the whole round and three more requests in the first batch).
     AhcState *const nst = w.state + npar;
-    int nx = w.node[x];
-    RowSt rs = w.row[x];
-    double e2x = w.e2[x];   // lower bound of the entries of row x other than its nearest neighbour's
+    int nx[CPT];
+    RowSt rs[CPT];
+    double e2x[CPT];        // lower bound of the entries of a row other than its nearest neighbour's
+    load_i32<CPT>(w.node + x0, nx);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) rs[j] = w.row[x0 + j];
+    load_f64<CPT>(w.e2 + x0, e2x);
     const int nanflag = w.flags[0];
     __builtin_amdgcn_sched_barrier(0);
 #ifndef FA_AHC_LATE_KERNARGS
@@ -1001,7 +1080,11 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
         pd1[k] = dv.pd[k]; pnn[k] = dv.ps[k]; pnnnode[k] = dv.pn[k];
         if (!(pd1[k] < dinf())) { pnn[k] = -1; pnnnode[k] = -1; }
         if (st.pend_row[k] < 0) { pd1[k] = dinf(); pnn[k] = -1; pnnnode[k] = -1; }
-        else if (x == st.pend_row[k]) { rs.d1 = pd1[k]; rs.nn = pnn[k]; rs.nnnode = pnnnode[k]; e2x = pd1[k]; }   // a scan yields no second minimum: the others are >= d1
+        else {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j)
+                if (x0 + j == st.pend_row[k]) { rs[j].d1 = pd1[k]; rs[j].nn = pnn[k]; rs[j].nnnode = pnnnode[k]; e2x[j] = pd1[k]; }   // a scan yields no second minimum: the others are >= d1
+        }
     }
     // (b) smallest row minimum (with its row) over all blocks and the finished rows; rows within 2 eps of it
     double g1 = dinf();
@@ -1020,12 +1103,14 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     const bool spec = FA_AHC_SPECULATE && R1 >= 0 && Q1 >= 0;
     const bool spec_lo = R1 < Q1;
     const int sp_a = spec_lo ? R1 : Q1, sp_b = spec_lo ? Q1 : R1, sp_na = spec_lo ? NR1 : NQ1, sp_nb = spec_lo ? NQ1 : NR1;
-    double sp_ma = 0.0, sp_mb = 0.0, sp_da = 0.0, sp_db = 0.0, sp_xa[kCk], sp_xb[kCk];
+    double sp_ma = 0.0, sp_mb = 0.0, sp_da[CPT], sp_db[CPT], sp_xa[kCk], sp_xb[kCk];
 #pragma unroll
     for (int j = 0; j < kCk; ++j) { sp_xa[j] = 0.0; sp_xb[j] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) { sp_da[j] = 0.0; sp_db[j] = 0.0; }
     // (the youngest load of the round's first batch is consumed here: the load counter completes in order, so everything older has arrived and
     // nothing in the decision below has to wait on the counter — a wait there would also wait for the requests that follow)
-    asm volatile("" :: "v"(nanflag), "v"(e2x), "v"(rs.d1), "v"(nx));
+    asm volatile("" :: "v"(nanflag), "v"(e2x[CPT - 1]), "v"(rs[CPT - 1].d1), "v"(nx[CPT - 1]));
     if (spec) {
         // sizes and centroids first, the two matrix entries (a cold row each) last: loads complete in order.  (Requesting the entries from
         // every thread, so that the wait for the centroids need not cover them, was measured: dead columns then read cold column copies
@@ -1035,9 +1120,9 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
 #pragma unroll
         for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; sp_xa[j] = k < d ? ca[k] : 0.0; sp_xb[j] = k < d ? cb[k] : 0.0; }
         __builtin_amdgcn_sched_barrier(0);
-        if (nx != kDead && x != sp_a && x != sp_b && st.mode == FA_AHC_MODE_AUTO) {
-            sp_da = pair_entry(w.M, Np, sp_a, sp_na, x, nx, st.sym_limit);
-            sp_db = pair_entry(w.M, Np, sp_b, sp_nb, x, nx, st.sym_limit);
+        if (st.mode == FA_AHC_MODE_AUTO) {
+            pair_entries<CPT>(w.M, Np, sp_a, sp_na, x0, nx, st.sym_limit, sp_a, sp_b, sp_da);
+            pair_entries<CPT>(w.M, Np, sp_b, sp_nb, x0, nx, st.sym_limit, sp_a, sp_b, sp_db);
         }
     }
     const double glim = g1 + 2.0 * st.eps;
@@ -1127,9 +1212,16 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     AHC_STAMP(1);
 
     // ---- phase 2 ------------------------------------------------------------------------------------------------
+    bool dirty[CPT], e2_dirty[CPT], in_flight[CPT];   // in_flight: the row is being (re)produced: it leaves the record until the next round finishes it
     bool was_pending = false;
 #pragma unroll
-    for (int k = 0; k < kPend; ++k) was_pending = was_pending || x == st.pend_row[k];
+    for (int j = 0; j < CPT; ++j) {
+        bool wp = false;
+#pragma unroll
+        for (int k = 0; k < kPend; ++k) wp = wp || x0 + j == st.pend_row[k];
+        dirty[j] = wp; e2_dirty[j] = wp; in_flight[j] = false;
+        was_pending = was_pending || wp;
+    }
     if (D.done || D.halt) {
         if (blk == 0 && tid == 0) {
             AhcHot n = st;
@@ -1138,37 +1230,45 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
             for (int k = 0; k < kPend; ++k) n.pend_row[k] = -1;
             *nhot = n;
         }
-        if (was_pending) { w.row[x] = rs; w.e2[x] = e2x; }
+        if (was_pending) {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) if (dirty[j]) { w.row[x0 + j] = rs[j]; w.e2[x0 + j] = e2x[j]; }
+        }
         return;
     }
 
-    double pkey[kPend];  // this column's entry of each row being produced
+    double pkey[kPend];  // the smallest of this thread's entries of each row being produced (and the slot / node it belongs to)
     int pslot[kPend], pnd[kPend];
 #pragma unroll
-    for (int k = 0; k < kPend; ++k) { pkey[k] = dinf(); pslot[k] = x; pnd[k] = nx; }
-    bool dirty = was_pending, e2_dirty = was_pending;
-    bool in_flight = false;  // this row is being (re)produced: it leaves the record until the next round finishes it
+    for (int k = 0; k < kPend; ++k) { pkey[k] = dinf(); pslot[k] = x0; pnd[k] = nx[0]; }
 
     if (D.op == OP_MERGE) {
         const int a = D.a, b = D.b, na = D.na, nb = D.nb, nnew = N + st.step;
         const bool sp_hit = spec && a == sp_a && b == sp_b && na == sp_na && nb == sp_nb;   // uniform; false only for the pair an exact window picked
         const double *ca = w.C + static_cast<size_t>(na) * d, *cb = w.C + static_cast<size_t>(nb) * d;
-        const bool act = nx != kDead && x != a && x != b;
-        double ma = sp_ma, mb = sp_mb, da = sp_da, db = sp_db;
+        bool act[CPT], any_act = false, all_act = true;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) { act[j] = nx[j] != kDead && x0 + j != a && x0 + j != b; any_act = any_act || act[j]; all_act = all_act && act[j]; }
+        double ma = sp_ma, mb = sp_mb, da[CPT], db[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) { da[j] = sp_da[j]; db[j] = sp_db[j]; }
         if (!sp_hit) {
             ma = w.sizes[na]; mb = w.sizes[nb];
-            da = 0.0; db = 0.0;
-            if (act && st.mode == FA_AHC_MODE_AUTO) {  // valid copy of a pair lives in the row of the younger node
-                da = pair_entry(w.M, Np, a, na, x, nx, st.sym_limit);
-                db = pair_entry(w.M, Np, b, nb, x, nx, st.sym_limit);
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) { da[j] = 0.0; db[j] = 0.0; }
+            if (st.mode == FA_AHC_MODE_AUTO) {  // valid copy of a pair lives in the row of the younger node
+                pair_entries<CPT>(w.M, Np, a, na, x0, nx, st.sym_limit, a, b, da);
+                pair_entries<CPT>(w.M, Np, b, nb, x0, nx, st.sym_limit, a, b, db);
             }
         }
         const double den = ma + mb;
+        if constexpr (kPend > 1) {
 #pragma unroll
-        for (int k = 1; k < kPend; ++k) {  // piggy-backed re-scans: pairs not touched by this merge
-            const int S = prow[k];
-            if (S >= 0 && act && x != S)
-                pkey[k] = pair_entry(w.M, Np, S, pnode_[k], x, nx, st.sym_limit);
+            for (int k = 1; k < kPend; ++k) {  // piggy-backed re-scans: pairs not touched by this merge (CPT == 1 only)
+                const int S = prow[k];
+                if (S >= 0 && act[0] && x0 != S)
+                    pkey[k] = pair_entry(w.M, Np, S, pnode_[k], x0, nx[0], st.sym_limit);
+            }
         }
         // merged centroid (FastClusterWrapper.cpp:89-100), and |ca - cb|^2 summed as a tree (error <= ~10 ulp, independent of the merge
         // depth).  Every wave evaluates the whole sum: no workgroup barrier.  The centroid elements are REQUESTED together (an un-unrolled
@@ -1208,56 +1308,116 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
         double dab = wave_sum(part);
         if (D.dab >= 0.0) dab = D.dab;
         AHC_STAMP(2);
-        double dc = dinf();
+        double dc[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) dc[j] = dinf();
         if (st.mode == FA_AHC_MODE_AUTO) {
-            if (act) {  // Lance-Williams centroid update: a filter only, ties/near-ties are re-evaluated exactly
-                // weights from ONE division (the values are a filter, certified by the 2 eps window: the two extra roundings stay inside the
-                // 16 u per merge level that eps budgets for 8); three IEEE fp64 divisions were ~40 dependent instructions per round
-                const double inv = 1.0 / den, wa = ma * inv, wb = mb * inv, wab = wa * wb;
-                dc = wa * da + wb * db - wab * dab;
-                if (!(dc > 0.0)) dc = 0.0;  // also keeps -0.0 out of the bit-pattern reductions
+            // Lance-Williams centroid update: a filter only, ties/near-ties are re-evaluated exactly.
+            // weights from ONE division (the values are a filter, certified by the 2 eps window: the two extra roundings stay inside the
+            // 16 u per merge level that eps budgets for 8); three IEEE fp64 divisions were ~40 dependent instructions per round
+            const double inv = 1.0 / den, wa = ma * inv, wb = mb * inv, wab = wa * wb;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                if (act[j]) {
+                    dc[j] = wa * da[j] + wb * db[j] - wab * dab;
+                    if (!(dc[j] > 0.0)) dc[j] = 0.0;  // also keeps -0.0 out of the bit-pattern reductions
+                }
             }
         } else {
             __syncthreads();
-            const double *col = w.XT + x;
-            double sum = 0.0;
+            double sum[CPT];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) sum[j] = 0.0;
 #pragma unroll 8
             for (int k = 0; k < d; ++k) {
-                const double diff = __dsub_rn(s_cvec[k], col[static_cast<size_t>(k) * Np]);
-                sum = __dadd_rn(sum, __dmul_rn(diff, diff));  // sqeuclidean_extended (FastClusterWrapper.cpp:68-75)
+                double col[CPT];
+                load_f64<CPT>(w.XT + static_cast<size_t>(k) * Np + x0, col);
+                const double ck = s_cvec[k];
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    const double diff = __dsub_rn(ck, col[j]);
+                    sum[j] = __dadd_rn(sum[j], __dmul_rn(diff, diff));  // sqeuclidean_extended (FastClusterWrapper.cpp:68-75): sequential in k per column
+                }
             }
-            if (act) { dc = sum; if (sum != sum) w.flags[0] = 1; }
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) if (act[j]) { dc[j] = sum[j]; if (sum[j] != sum[j]) w.flags[0] = 1; }
             __syncthreads();
-            if (a / kBlk == blk)
+            if (a / kCols == blk)
                 for (int k = tid; k < d; k += kBlk) w.XT[static_cast<size_t>(k) * Np + a] = s_cvec[k];
         }
-        if (act) {
-            w.M[static_cast<size_t>(a) * Np + x] = dc;
-            // Row x against its entry for the new cluster.  e2x bounds the entries of the row OTHER than the nearest neighbour's from below
-            // (exact second minimum after the start-up scan, then maintained: an entry that appears lowers it, entries that disappear
-            // leave it a bound).  It decides the case that used to make half of all rows stale on chaining data — the nearest neighbour
-            // WAS one of the merged slots (every point's nearest neighbour is the growing cluster) and the new entry is larger than the
-            // old minimum: if it is still below everything else (dc < e2x) the row simply keeps the cluster as its neighbour.
-            const bool vld = rs.nn >= 0;
-            const bool hit = vld && (rs.nn == a || rs.nn == b);
-            if (!hit) {
-                if (dc < rs.d1 || (vld && dc == rs.d1 && a <= rs.nn)) {   // new minimum (a stale row: dc below its bound IS its minimum)
-                    e2x = rs.d1; rs.d1 = dc; rs.nn = a; rs.nnnode = nnew; dirty = true; e2_dirty = true;
-                } else if (dc < e2x) { e2x = dc; e2_dirty = true; }
-            } else if (dc < e2x) {                                         // unique minimum again (strict: a tie goes to a re-scan)
-                rs.d1 = dc; rs.nn = a; rs.nnnode = nnew; dirty = true;
-            } else {                                                        // minimum lost: every entry is >= min(e2x, dc) = e2x, a lower bound
-                rs.d1 = e2x; rs.nn = -1; dirty = true;
-            }
-            pkey[0] = dc;
+        if constexpr (CPT == 1) {
+            const int x = x0;
+            if (act[0]) {
+                w.M[static_cast<size_t>(a) * Np + x] = dc[0];
+                // Row x against its entry for the new cluster.  e2x bounds the entries of the row OTHER than the nearest neighbour's from below
+                // (exact second minimum after the start-up scan, then maintained: an entry that appears lowers it, entries that disappear
+                // leave it a bound).  It decides the case that used to make half of all rows stale on chaining data — the nearest neighbour
+                // WAS one of the merged slots (every point's nearest neighbour is the growing cluster) and the new entry is larger than the
+                // old minimum: if it is still below everything else (dc < e2x) the row simply keeps the cluster as its neighbour.
+                const bool vld = rs[0].nn >= 0;
+                const bool hit = vld && (rs[0].nn == a || rs[0].nn == b);
+                if (!hit) {
+                    if (dc[0] < rs[0].d1 || (vld && dc[0] == rs[0].d1 && a <= rs[0].nn)) {   // new minimum (a stale row: dc below its bound IS its minimum)
+                        e2x[0] = rs[0].d1; rs[0].d1 = dc[0]; rs[0].nn = a; rs[0].nnnode = nnew; dirty[0] = true; e2_dirty[0] = true;
+                    } else if (dc[0] < e2x[0]) { e2x[0] = dc[0]; e2_dirty[0] = true; }
+                } else if (dc[0] < e2x[0]) {                                   // unique minimum again (strict: a tie goes to a re-scan)
+                    rs[0].d1 = dc[0]; rs[0].nn = a; rs[0].nnnode = nnew; dirty[0] = true;
+                } else {                                                        // minimum lost: every entry is >= min(e2x, dc) = e2x, a lower bound
+                    rs[0].d1 = e2x[0]; rs[0].nn = -1; dirty[0] = true;
+                }
+                pkey[0] = dc[0];
 #pragma unroll
-            for (int k = 1; k < kPend; ++k)
-                if (x == prow[k]) { pkey[k] = dc; pslot[k] = a; pnd[k] = nnew; in_flight = true; }  // its entry for the new cluster
-        } else if (x == a) {
-            nx = nnew; rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; e2x = dinf(); dirty = true; e2_dirty = true; in_flight = true;
-            w.sizes[nnew] = den;
-        } else if (x == b) {
-            nx = kDead; rs.d1 = dinf(); rs.nn = -1; rs.nnnode = -1; dirty = true;
+                for (int k = 1; k < kPend; ++k)
+                    if (x == prow[k]) { pkey[k] = dc[0]; pslot[k] = a; pnd[k] = nnew; in_flight[0] = true; }  // its entry for the new cluster
+            } else if (x == a) {
+                nx[0] = nnew; rs[0].d1 = dinf(); rs[0].nn = -1; rs[0].nnnode = -1; e2x[0] = dinf(); dirty[0] = true; e2_dirty[0] = true; in_flight[0] = true;
+                w.sizes[nnew] = den;
+                w.node[x] = nnew;
+            } else if (x == b) {
+                nx[0] = kDead; rs[0].d1 = dinf(); rs[0].nn = -1; rs[0].nnnode = -1; dirty[0] = true;
+                w.node[x] = kDead;
+            }
+        } else {
+            // Several slots per thread: the same rules as selects, no branch per column (the CPT chains interleave).  The new row leaves as ONE store
+            // per thread: the entry of a dead or merged column is never read again (readers ask for live columns only; slot b stays dead, (a, a)
+            // is no pair), so it is written as 0 rather than skipped.
+            double dcs[CPT];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) dcs[j] = act[j] ? dc[j] : 0.0;
+            store_f64<CPT>(w.M + static_cast<size_t>(a) * Np + x0, dcs);
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const bool vld = rs[j].nn >= 0;
+                const bool hit = vld && (rs[j].nn == a || rs[j].nn == b);
+                const bool below_e2 = dc[j] < e2x[j];
+                const bool c_new = act[j] && !hit && (dc[j] < rs[j].d1 || (vld && dc[j] == rs[j].d1 && a <= rs[j].nn));   // new minimum
+                const bool c_e2 = act[j] && !hit && !c_new && below_e2;                                                   // new second minimum
+                const bool c_keep = act[j] && hit && below_e2;                                                            // unique minimum again
+                const bool c_lost = act[j] && hit && !below_e2;                                                           // minimum lost: e2x is a lower bound
+                const bool take = c_new || c_keep;
+                const double d1_old = rs[j].d1, e2_old = e2x[j];
+                e2x[j] = c_new ? d1_old : (c_e2 ? dc[j] : e2_old);
+                rs[j].d1 = take ? dc[j] : (c_lost ? e2_old : d1_old);
+                rs[j].nn = take ? a : (c_lost ? -1 : rs[j].nn);
+                rs[j].nnnode = take ? nnew : rs[j].nnnode;
+                dirty[j] = dirty[j] || take || c_lost;
+                e2_dirty[j] = e2_dirty[j] || c_new || c_e2;
+                const bool lower = act[j] && dc[j] < pkey[0];          // ascending j: the lowest slot keeps a tie
+                pkey[0] = lower ? dc[j] : pkey[0]; pslot[0] = lower ? x0 + j : pslot[0]; pnd[0] = lower ? nx[j] : pnd[0];
+            }
+            if (a >= x0 && a < x0 + CPT) {          // the thread that owns slot a (one in the grid) — and the one that owns b
+#pragma unroll
+                for (int j = 0; j < CPT; ++j)
+                    if (x0 + j == a) { nx[j] = nnew; rs[j].d1 = dinf(); rs[j].nn = -1; rs[j].nnnode = -1; e2x[j] = dinf(); dirty[j] = true; e2_dirty[j] = true; in_flight[j] = true; }
+                w.sizes[nnew] = den;
+                w.node[a] = nnew;
+            }
+            if (b >= x0 && b < x0 + CPT) {
+#pragma unroll
+                for (int j = 0; j < CPT; ++j)
+                    if (x0 + j == b) { nx[j] = kDead; rs[j].d1 = dinf(); rs[j].nn = -1; rs[j].nnnode = -1; dirty[j] = true; }
+                w.node[b] = kDead;
+            }
         }
         if (blk == 0 && tid == 0) {
             double *z = w.Z + static_cast<size_t>(st.step) * 4;
@@ -1271,9 +1431,13 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
         for (int k = 0; k < kPend; ++k) {
             const int S = prow[k];
             if (S < 0) continue;
-            if (nx != kDead && x != S)
-                pkey[k] = pair_entry(w.M, Np, S, pnode_[k], x, nx, st.sym_limit);
-            if (x == S) in_flight = true;
+            double ent[CPT];
+            pair_entries<CPT>(w.M, Np, S, pnode_[k], x0, nx, st.sym_limit, S, -1, ent);
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                if (nx[j] != kDead && x0 + j != S && (CPT == 1 || ent[j] < pkey[k])) { pkey[k] = ent[j]; pslot[k] = x0 + j; pnd[k] = nx[j]; }
+                if (x0 + j == S) in_flight[j] = true;
+            }
         }
         // consumed inside the branch: a load still pending where the branches join makes the compiler wait on the in-order memory counter at
         // the join's first use of pkey — and on the MERGE path that wait finds only this round's STORES outstanding: a store round trip in
@@ -1282,33 +1446,60 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
         for (int k = 0; k < kPend; ++k) asm volatile("" :: "v"(pkey[k]));
     } else if (D.op == OP_COLLECT) {
         WinCounters *cw = w.cnt + (ph & 3);
-        if (nx != kDead && rs.d1 <= D.lim) {
-            if (rs.nn < 0) atomicMin(&cw->stale_key, (static_cast<unsigned long long>(x) << 32) | static_cast<unsigned>(nx));
-            else { const int i = atomicAdd(&cw->ncand, 1); if (i < kMaxCand) w.cand[i] = make_int2(x, nx); }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            if (nx[j] != kDead && rs[j].d1 <= D.lim) {
+                if (rs[j].nn < 0) atomicMin(&cw->stale_key, (static_cast<unsigned long long>(x0 + j) << 32) | static_cast<unsigned>(nx[j]));
+                else { const int i = atomicAdd(&cw->ncand, 1); if (i < kMaxCand) w.cand[i] = make_int2(x0 + j, nx[j]); }
+            }
         }
     } else if (D.op == OP_PAIRS) {
         WinCounters *cw = w.cnt + (ph & 3);
         const int nc = cr->ncand;
-        for (int j = 0; j < nc; ++j) {
-            const int2 cj = w.cand[j];
-            if (nx == kDead || x == cj.x) continue;
-            const double val = pair_entry(w.M, Np, cj.x, cj.y, x, nx, st.sym_limit);
-            if (val <= D.lim) {
-                const int slot = atomicAdd(&cw->npairs, 1);
-                if (slot < kMaxPairs) w.pairs[slot] = cj.x < x ? make_int4(cj.x, x, cj.y, nx) : make_int4(x, cj.x, nx, cj.y);
+        for (int q = 0; q < nc; ++q) {
+            const int2 cj = w.cand[q];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int x = x0 + j;
+                if (nx[j] == kDead || x == cj.x) continue;
+                const double val = pair_entry(w.M, Np, cj.x, cj.y, x, nx[j], st.sym_limit);
+                if (val <= D.lim) {
+                    const int slot = atomicAdd(&cw->npairs, 1);
+                    if (slot < kMaxPairs) w.pairs[slot] = cj.x < x ? make_int4(cj.x, x, cj.y, nx[j]) : make_int4(x, cj.x, nx[j], cj.y);
+                }
             }
         }
     }
     AHC_STAMP(3);
 
     // own row state back to HBM (only when it changed), then the record of the next round
-    if (e2_dirty) w.e2[x] = e2x;
-    if (dirty) {
-        w.row[x] = rs;
-        if (D.op == OP_MERGE && (x == D.a || x == D.b)) w.node[x] = nx;
+    {
+        bool any_e2 = false;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) any_e2 = any_e2 || e2_dirty[j];
+        if (any_e2) store_f64<CPT>(w.e2 + x0, e2x);       // the thread's CPT bounds as one store (the unchanged ones rewrite their own value)
+        if constexpr (CPT == 1) {
+            if (dirty[0]) w.row[x0] = rs[0];
+        } else {
+            bool any_row = false;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) any_row = any_row || dirty[j];
+            if (any_row) {
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) w.row[x0 + j] = rs[j];
+            }
+        }
     }
-    const bool live = nx != kDead && !in_flight;
-    block_record(w, npar, blk, st.eps, live ? rs.d1 : dinf(), live && rs.nn < 0 ? rs.d1 : dinf(), pkey, pslot, pnd, x, nx, rs.nn, rs.nnnode, s_out);
+    double keys_all[CPT], key = dinf(), skey = dinf();
+    int bx = x0, bnx = nx[0], bnn = rs[0].nn, bnnnode = rs[0].nnnode;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const bool live = nx[j] != kDead && !in_flight[j];
+        keys_all[j] = live ? rs[j].d1 : dinf();
+        if (j == 0 || keys_all[j] < key) { key = keys_all[j]; bx = x0 + j; bnx = nx[j]; bnn = rs[j].nn; bnnnode = rs[j].nnnode; }
+        if (live && rs[j].nn < 0 && rs[j].d1 < skey) skey = rs[j].d1;
+    }
+    block_record<CPT>(w, npar, blk, st.eps, key, keys_all, skey, pkey, pslot, pnd, bx, bnx, bnn, bnnnode, s_out);
     AHC_STAMP(4);
     if (blk == 0 && tid == 0) {  // clear the window counters of the next round (here, in the tail: in front of the decision the store's round
         WinCounters *z = w.cnt + ((ph + 1) & 3);   // trip sat on the critical path of workgroup 0 — the next wait for a load also waits for it)
@@ -1340,7 +1531,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
 //                       (constant address space = scalar loads): two dependent memory round trips before the round can start.
 //   ahc_round_args    : up to kArgProblems problems with their workspaces and block ranges IN the kernel arguments: no extra round trip
 //                       (fa_ahc_linkage_batch / fa_offline_cluster_batch with <= 16 recordings).
-template <bool BATCH, bool BIG>
+template <bool BATCH, bool BIG, int CPT = 1>
 __global__ __launch_bounds__(kBlk) void ahc_round_t(const int ph, const int nblk_, AhcState *const state_, RecA *const recA_, int4 *const recI_, RecP *const recP_,
                                                     const unsigned off_row, const unsigned off_node, const unsigned off_e2, const unsigned off_flags,
                                                     const Ws w_one, const Ws *__restrict__ table, const int2 *__restrict__ blkmap) {
@@ -1351,7 +1542,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const int ph, const int nblk
     int blk_ = blockIdx.x;
     Ws w_ = w_one;
     if (!BATCH) {
-        w_.nblk = nblk_; w_.Np = nblk_ * kBlk; w_.state = state_; w_.recA = recA_; w_.recI = recI_; w_.recP = recP_;
+        w_.nblk = nblk_; w_.Np = nblk_ * kBlk * CPT; w_.state = state_; w_.recA = recA_; w_.recI = recI_; w_.recP = recP_;
         char *base = reinterpret_cast<char *>(state_);
         w_.row = reinterpret_cast<RowSt *>(base + off_row); w_.node = reinterpret_cast<int *>(base + off_node);
         w_.e2 = reinterpret_cast<double *>(base + off_e2); w_.flags = reinterpret_cast<int *>(base + off_flags);
@@ -1368,16 +1559,17 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const int ph, const int nblk
         for (unsigned i = 0; i < sizeof(Ws) / 8; ++i) words[i] = src[i];
         __builtin_memcpy(&w_, words, sizeof(Ws));
     }
-    ahc_round_body<false, BIG>(w_, blk_, ph);
+    ahc_round_body<false, BIG, CPT>(w_, blk_, ph);
 }
 
 // A problem of at most 256 points is ONE block: its rounds need no device-wide barrier at all, a workgroup barrier between them (with
 // the release / acquire that makes the records and row states written by some threads visible to the others) is enough — all rounds
 // of a replay in one launch, no kernel boundary, operands in the local caches (agent-scope fences around the barrier were measured
 // 0.5 us per round slower and are not needed inside one workgroup).
+template <int CPT>   // up to kBlk * CPT points
 __global__ __launch_bounds__(kBlk) void ahc_rounds_single_block(const Ws w, const int rounds) {
     for (int r = 0; r < rounds; ++r) {
-        ahc_round_body<false, false>(w, 0, r & 3);
+        ahc_round_body<false, false, CPT>(w, 0, r & 3);
         __syncthreads();   // workgroup-scope release / acquire: the waves of one workgroup share the CU's caches
     }
 }
@@ -1391,12 +1583,7 @@ __global__ __launch_bounds__(kBlk) void ahc_rounds_single_block(const Ws w, cons
 // indexed by the problem — in front of its first request: 11 us per round of 16 problems against 5.3 us for one.)  Only N differs per
 // problem: it comes from the hot part of the problem's state, with the first batch of loads.
 // arg 0 = (blocks << 2) | (round & 3), stride in 4 KB pages: 14 preloaded dwords like ahc_round_t.
-#define FA_AHC_UNI_KERNEL(NAME, ATTR)                                                                                                                   \
-    __global__ __launch_bounds__(kBlk) ATTR void NAME(const unsigned nblk_ph, const unsigned stride_pages, AhcState *const state_, RecA *const recA_,  \
-                                                      int4 *const recI_, RecP *const recP_, const unsigned off_row, const unsigned off_node,           \
-                                                      const unsigned off_e2, const unsigned off_flags, const Ws w_one) {                              \
-        ahc_round_uni_body(nblk_ph, stride_pages, state_, recA_, recI_, recP_, off_row, off_node, off_e2, off_flags, w_one);                           \
-    }
+template <int CPT>
 __device__ __forceinline__ void ahc_round_uni_body(const unsigned nblk_ph, const unsigned stride_pages, AhcState *const state_, RecA *const recA_, int4 *const recI_,
                                                    RecP *const recP_, const unsigned off_row, const unsigned off_node, const unsigned off_e2, const unsigned off_flags,
                                                    const Ws &w_one) {
@@ -1404,16 +1591,25 @@ __device__ __forceinline__ void ahc_round_uni_body(const unsigned nblk_ph, const
     auto at = [sh](auto *p) { return reinterpret_cast<decltype(p)>(reinterpret_cast<char *>(p) + sh); };
     Ws w_ = w_one;
     const int nblk_ = static_cast<int>(nblk_ph >> 2);
-    w_.nblk = nblk_; w_.Np = nblk_ * kBlk; w_.state = at(state_); w_.recA = at(recA_); w_.recI = at(recI_); w_.recP = at(recP_);
+    w_.nblk = nblk_; w_.Np = nblk_ * kBlk * CPT; w_.state = at(state_); w_.recA = at(recA_); w_.recI = at(recI_); w_.recP = at(recP_);
     char *base = reinterpret_cast<char *>(w_.state);
     w_.row = reinterpret_cast<RowSt *>(base + off_row); w_.node = reinterpret_cast<int *>(base + off_node);
     w_.e2 = reinterpret_cast<double *>(base + off_e2); w_.flags = reinterpret_cast<int *>(base + off_flags);
-    ahc_round_body<true, false>(w_, blockIdx.x, static_cast<int>(nblk_ph & 3u), sh);   // the host sends problems of more than 65 536 points elsewhere
+    ahc_round_body<true, false, CPT>(w_, blockIdx.x, static_cast<int>(nblk_ph & 3u), sh);   // the host sends problems of more than 65 536 points elsewhere
 }
-// the same kernel at three register budgets: more co-resident workgroups per CU against spills (which one serves a batch: ahc_batch_uniform)
-FA_AHC_UNI_KERNEL(ahc_round_uni, )
-FA_AHC_UNI_KERNEL(ahc_round_uni_w3, __attribute__((amdgpu_waves_per_eu(6, 6))))   // "w3" / "w4": the second and third budget
-FA_AHC_UNI_KERNEL(ahc_round_uni_w4, __attribute__((amdgpu_waves_per_eu(8, 8))))
+#define FA_AHC_UNI_KERNEL(NAME, ATTR, CPT)                                                                                                              \
+    __global__ __launch_bounds__(kBlk) ATTR void NAME(const unsigned nblk_ph, const unsigned stride_pages, AhcState *const state_, RecA *const recA_,  \
+                                                      int4 *const recI_, RecP *const recP_, const unsigned off_row, const unsigned off_node,           \
+                                                      const unsigned off_e2, const unsigned off_flags, const Ws w_one) {                              \
+        ahc_round_uni_body<CPT>(nblk_ph, stride_pages, state_, recA_, recI_, recP_, off_row, off_node, off_e2, off_flags, w_one);                      \
+    }
+// one slot per thread at three register budgets (more co-resident workgroups per CU against spills; round 4) and the round-5 forms with 2 / 4 slots per
+// thread (which one serves a batch: ahc_batch_uniform)
+FA_AHC_UNI_KERNEL(ahc_round_uni, , 1)
+FA_AHC_UNI_KERNEL(ahc_round_uni_w3, __attribute__((amdgpu_waves_per_eu(6, 6))), 1)   // "w3" / "w4": the second and third budget
+FA_AHC_UNI_KERNEL(ahc_round_uni_w4, __attribute__((amdgpu_waves_per_eu(8, 8))), 1)
+FA_AHC_UNI_KERNEL(ahc_round_uni_c2, , 2)
+FA_AHC_UNI_KERNEL(ahc_round_uni_c4, , 4)
 
 constexpr int kArgProblems = 16;
 struct BatchArgs {
@@ -1693,6 +1889,7 @@ struct Prob {   // one linkage problem: its workspace, its copy of the device st
     Layout L{};
     char *base = nullptr;
     size_t N = 0, Np = 0, d = 0;
+    int cpt = 1;             // slots per thread of the round kernel that serves the problem: a block record covers kBlk * cpt slots, Np is a multiple of that
     const double *d_data = nullptr;
     double *d_Z = nullptr;
     int mode = FA_AHC_MODE_AUTO;
@@ -1738,7 +1935,7 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
     w.C = reinterpret_cast<double *>(base + L.c);
     w.XT = reinterpret_cast<double *>(base + L.xt);
     w.M = reinterpret_cast<double *>(base + L.m);
-    w.N = static_cast<int32_t>(N); w.Np = static_cast<int32_t>(Np); w.d = static_cast<int32_t>(d); w.nblk = static_cast<int32_t>(Np / kBlk);
+    w.N = static_cast<int32_t>(N); w.Np = static_cast<int32_t>(Np); w.d = static_cast<int32_t>(d); w.nblk = static_cast<int32_t>(Np / (static_cast<size_t>(kBlk) * p.cpt));
 
     const int dev_mode = p.mode == FA_AHC_MODE_EXACT ? FA_AHC_MODE_EXACT : FA_AHC_MODE_AUTO;
     hipLaunchKernelGGL(ahc_init_state, dim3(1), dim3(64), 0, ctx->stream, w, dev_mode);
@@ -1760,7 +1957,9 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
     }
     hipLaunchKernelGGL(ahc_row_minima, dim3(w.Np), dim3(kBlk), 0, ctx->stream, w);
     hipLaunchKernelGGL(ahc_set_eps, dim3(1), dim3(64), 0, ctx->stream, w);
-    hipLaunchKernelGGL(ahc_records, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);  // window counts need eps
+    if (p.cpt == 4) hipLaunchKernelGGL(ahc_records<4>, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);  // window counts need eps
+    else if (p.cpt == 2) hipLaunchKernelGGL(ahc_records<2>, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);
+    else hipLaunchKernelGGL(ahc_records<1>, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }
@@ -1940,6 +2139,7 @@ struct CachedGraph {   // the round launches of one problem shape, kept in the c
     RoundGraph rg;
     const void *base = nullptr;
     size_t N = 0, d = 0;
+    int cpt = 1;
 };
 void cached_graph_free(void *p) { delete static_cast<CachedGraph *>(p); }
 fa_status ctx_events(fa_ctx *ctx, hipEvent_t (&ev)[3]) {
@@ -1975,8 +2175,16 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     }
     Prob p;
     p.z_on_host = z_on_host;
-    p.N = N; p.d = d; p.Np = (N + kBlk - 1) / kBlk * kBlk; p.d_data = d_data; p.d_Z = d_Z; p.mode = mode;
-    p.L = make_layout(N, p.Np, d, p.Np / kBlk);
+    // slots per thread of the round: 1 for a chain of its own (the fewest dependent instructions per round: 5.09 us at 43 200 points against 5.60 / 6.69 with
+    // 2 / 4); 2 where that makes the problem ONE block (257 .. 512 points: all rounds of a replay inside one launch, no kernel boundary between them:
+    // 400 points 2.35 -> 2.08 ms per call; four slots per thread for <= 1 024 points lose to the multi-block chain, 5.0 against 4.9 ms at 900).
+    // FA_AHC_CPT forces a value (measurements: profiles/r05_cpt_probe_v2.json).
+    const int env_cpt = [] { const char *e = getenv("FA_AHC_CPT"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? v : 0; }();   // per call, like the other switches (the tests flip them)
+    const bool no_single_block = getenv("FA_AHC_NO_SINGLE_BLOCK") != nullptr;
+    p.cpt = env_cpt ? env_cpt : (no_single_block || N <= kBlk || N > 2 * kBlk ? 1 : 2);
+    const size_t cols = static_cast<size_t>(kBlk) * p.cpt;
+    p.N = N; p.d = d; p.Np = (N + cols - 1) / cols * cols; p.d_data = d_data; p.d_Z = d_Z; p.mode = mode;
+    p.L = make_layout(N, p.Np, d, p.Np / cols);
     {
         const fa_status ws = fa::ws_acquire(ctx, p.L.total);
         if (ws == FA_ALLOCATION_FAILURE && may_fall_back) return without_matrix();
@@ -1991,33 +2199,46 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     FA_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
 
     const Ws w = p.w;
-    const bool big = w.nblk > 4 * 64 || getenv("FA_AHC_ROUND_BIG") != nullptr;   // more than four block records per lane: the kernel with the many-record reduction
+    const bool env_big = getenv("FA_AHC_ROUND_BIG") != nullptr;
+    const bool big = w.nblk > (4 / p.cpt) * 64 || env_big;   // more than 65 536 points (four block records per lane at one slot per thread): the kernel with the many-record reduction
     if (lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     }
     auto off_of = [&](const void *p) { return static_cast<unsigned>(static_cast<const char *>(p) - reinterpret_cast<const char *>(w.state)); };   // small arrays: within 4 GB of the state (make_layout puts the matrix last)
     const unsigned o_row = off_of(w.row), o_node = off_of(w.node), o_e2 = off_of(w.e2), o_flags = off_of(w.flags);
+#define FA_AHC_ROUND_LAUNCH(BIG_, CPT_) hipLaunchKernelGGL((ahc_round_t<false, BIG_, CPT_>), dim3(w.nblk), dim3(kBlk), lds, ctx->stream, ph, w.nblk, w.state, w.recA, w.recI, w.recP, \
+                                                          o_row, o_node, o_e2, o_flags, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr))
     auto launch = [&](const int ph) {
-        if (big) hipLaunchKernelGGL((ahc_round_t<false, true>), dim3(w.nblk), dim3(kBlk), lds, ctx->stream, ph, w.nblk, w.state, w.recA, w.recI, w.recP, o_row, o_node, o_e2, o_flags, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr));
-        else hipLaunchKernelGGL((ahc_round_t<false, false>), dim3(w.nblk), dim3(kBlk), lds, ctx->stream, ph, w.nblk, w.state, w.recA, w.recI, w.recP, o_row, o_node, o_e2, o_flags, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr));
+        if (p.cpt == 4) { if (big) FA_AHC_ROUND_LAUNCH(true, 4); else FA_AHC_ROUND_LAUNCH(false, 4); }
+        else if (p.cpt == 2) { if (big) FA_AHC_ROUND_LAUNCH(true, 2); else FA_AHC_ROUND_LAUNCH(false, 2); }
+        else { if (big) FA_AHC_ROUND_LAUNCH(true, 1); else FA_AHC_ROUND_LAUNCH(false, 1); }
     };
+#undef FA_AHC_ROUND_LAUNCH
     // The captured graph only holds launch parameters (workspace pointers, block count): it is reused as long as the workspace sits at
     // the same address and the shape is the same — repeated calls on recordings of one length skip capture + instantiation.
     RoundGraph single_rg;
     RoundGraph *rgp = &single_rg;
-    const bool single_block = w.nblk == 1 && !getenv("FA_AHC_NO_SINGLE_BLOCK");
+    const bool single_block = w.nblk == 1 && !no_single_block;
     if (single_block) {
         single_rg.rounds = rounds_for(N);
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_rounds_single_block), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (lds > 48 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_rounds_single_block<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_rounds_single_block<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_rounds_single_block<4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        }
     } else {
         CachedGraph *cg = static_cast<CachedGraph *>(ctx->ahc_graph);
-        if (!cg || cg->base != ctx->ahc_ws || cg->N != N || cg->d != d || !cg->rg.ok) {
+        if (!cg || cg->base != ctx->ahc_ws || cg->N != N || cg->d != d || cg->cpt != p.cpt || !cg->rg.ok) {
             delete cg;
             cg = new CachedGraph();
             ctx->ahc_graph = cg;
             ctx->ahc_graph_free = cached_graph_free;
-            cg->base = ctx->ahc_ws; cg->N = N; cg->d = d;
+            cg->base = ctx->ahc_ws; cg->N = N; cg->d = d; cg->cpt = p.cpt;
             cg->rg.capture(ctx, launch, rounds_for(N));
         }
         rgp = &cg->rg;
@@ -2025,7 +2246,12 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     RoundGraph &rg = *rgp;
     const long long max_batches = 64 + 8 * static_cast<long long>(N) / rg.rounds;  // bound on rounds (merges + rescans + windows)
     for (long long it = 0; it < max_batches && p.active; ++it) {
-        if (single_block) { hipLaunchKernelGGL(ahc_rounds_single_block, dim3(1), dim3(kBlk), lds, ctx->stream, w, rg.rounds); FA_HIP_TRY(ctx, hipGetLastError()); }
+        if (single_block) {
+            if (p.cpt == 4) hipLaunchKernelGGL(ahc_rounds_single_block<4>, dim3(1), dim3(kBlk), lds, ctx->stream, w, rg.rounds);
+            else if (p.cpt == 2) hipLaunchKernelGGL(ahc_rounds_single_block<2>, dim3(1), dim3(kBlk), lds, ctx->stream, w, rg.rounds);
+            else hipLaunchKernelGGL(ahc_rounds_single_block<1>, dim3(1), dim3(kBlk), lds, ctx->stream, w, rg.rounds);
+            FA_HIP_TRY(ctx, hipGetLastError());
+        }
         else FA_TRY(rg.replay(ctx, launch));
         FA_HIP_TRY(ctx, hipMemcpyAsync(&p.h, w.state, sizeof(p.h), hipMemcpyDeviceToHost, ctx->stream));
         FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2244,7 +2470,17 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
     std::vector<int> ord(static_cast<size_t>(count));
     for (int k = 0; k < count; ++k) ord[k] = k;
     std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return n[a] > n[b]; });
-    const size_t Nmax = n[ord[0]], Npmax = (Nmax + kBlk - 1) / kBlk * kBlk, nblk = Npmax / kBlk;
+    // Slots per thread of the round (ahc_round_body's CPT): a launch over several problems is bound by instruction issue, and a thread that owns four
+    // slots leaves a quarter of the workgroups, wavefronts and block records per problem; small problems keep enough blocks to spread over.
+    // FA_AHC_UNI_CPT forces 1 / 2 / 4 (measurements).
+    const int env_cpt = [] { const char *e = getenv("FA_AHC_UNI_CPT"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? v : 0; }();
+    const size_t Nmax = n[ord[0]];
+    // Measured (profiles/r05_cpt_probe_v2.json, us per round of 43 200-point problems, one batch): K = 2: 5.80 / 5.93 / 6.83 with 1 / 2 / 4 slots per thread,
+    // K = 4: 6.89 / 6.66 / 7.15, K = 8: 10.83 / 7.93 / 8.49, K = 12: 13.41 / 10.00 / 9.80; two batches side by side, K = 8: 8.82 / 7.59 / 8.12, K = 12: 11.17 /
+    // 8.18 / 8.90; 16 x 5 400: 6.74 / 6.88 / 7.90.  Two slots per thread pay once a launch holds more than ~2 workgroups per CU at one slot per thread.
+    const size_t wgs1 = static_cast<size_t>(count) * ((Nmax + kBlk - 1) / kBlk);
+    const int cpt = env_cpt ? env_cpt : (wgs1 >= 600 && Nmax >= 1024 ? 2 : 1);
+    const size_t cols = static_cast<size_t>(kBlk) * cpt, Npmax = (Nmax + cols - 1) / cols * cols, nblk = Npmax / cols;
     FA_TRY(prob_check_shape(ctx, Nmax, d));
     const Layout L = make_layout(Nmax, Npmax, d, nblk);
     const size_t stride = (L.total + 4095) & ~static_cast<size_t>(4095);
@@ -2260,7 +2496,7 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
     for (int j = 0; j < count; ++j) {
         Prob &p = probs[j];
         const int k = ord[j];
-        p.N = n[k]; p.d = d; p.Np = Npmax; p.d_data = d_data[k]; p.d_Z = d_Z[k]; p.mode = mode; p.L = L;
+        p.N = n[k]; p.d = d; p.Np = Npmax; p.cpt = cpt; p.d_data = d_data[k]; p.d_Z = d_Z[k]; p.mode = mode; p.L = L;
         if (statuses) statuses[k] = FA_SUCCESS;
         // every problem of the grid gets workgroups, so every state must be initialised: a set-up that fails (a failing launch or copy: the device
         // is in trouble) fails the batch, the caller's splitting logic takes over
@@ -2277,7 +2513,9 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
     auto launch = [&](const int ph) {
         const unsigned a0 = (static_cast<unsigned>(w0.nblk) << 2) | static_cast<unsigned>(ph & 3);
         const dim3 grid(static_cast<unsigned>(w0.nblk), static_cast<unsigned>(grid_y));
-        if (kernel == 4) hipLaunchKernelGGL(ahc_round_uni_w4, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
+        if (cpt == 4) hipLaunchKernelGGL(ahc_round_uni_c4, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
+        else if (cpt == 2) hipLaunchKernelGGL(ahc_round_uni_c2, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
+        else if (kernel == 4) hipLaunchKernelGGL(ahc_round_uni_w4, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
         else if (kernel == 3) hipLaunchKernelGGL(ahc_round_uni_w3, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
         else hipLaunchKernelGGL(ahc_round_uni, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
     };
@@ -2285,6 +2523,8 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_w3), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_w4), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_c2), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_c4), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     }
     const long long max_batches = 64 + 8 * static_cast<long long>(Nmax) / rounds_for(Nmax);
     RoundGraph *rg = nullptr;

@@ -450,3 +450,55 @@ def test_random_batches_through_whichever_path_serves_them(fa, gpu_ctx, oracle_m
             sr, zr = oracle_mod.linkage_ref(x)
             assert sr == 0
             np.testing.assert_array_equal(z, zr, err_msg=f"trial {trial}, sizes {[len(p) for p in probs]}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cpt", ["1", "2", "4"])
+def test_slots_per_thread_forms_equal_reference_build(fa, gpu_ctx, oracle_mod, monkeypatch, cpt):
+    """Round 5: a thread of the round kernel may own 1, 2 or 4 consecutive slots (ahc_round_body's CPT; a block record then covers 256 x CPT slots).
+    Which form serves a call is a matter of speed (one slot per thread for a chain of its own, two where a launch holds many workgroups or where
+    that makes a short recording one block); every form must give the reference build's dendrogram bit for bit — single problems through the
+    multi-block and the single-block kernels in both modes, exact ties through the reference-order route, a NaN as status 5, and uniform batches."""
+    rng = np.random.default_rng(int(cpt))
+    cases = [oracle_mod.ahc_normalize(rng.standard_normal((n, d))) for n, d in ((2, 3), (3, 5), (257, 16), (513, 32), (700, 64), (1024, 8), (1500, 24))]
+    cases.append(speaker_mixture(2300, 32, 12, 0.03, 7))
+    dup = oracle_mod.ahc_normalize(rng.standard_normal((400, 8)))
+    dup = np.concatenate([dup, dup[:150]])                     # exact ties at the minimum
+    for single_block in (True, False):
+        monkeypatch.setenv("FA_AHC_CPT", cpt)
+        if single_block:
+            monkeypatch.delenv("FA_AHC_NO_SINGLE_BLOCK", raising=False)
+        else:
+            monkeypatch.setenv("FA_AHC_NO_SINGLE_BLOCK", "1")
+        for mode in (fa.AHC_MODE_AUTO, fa.AHC_MODE_EXACT):
+            for x in cases:
+                st, z = fa.linkage(x, ctx=gpu_ctx, mode=mode)
+                sr, zr = oracle_mod.linkage_ref(x)
+                assert st == sr == 0
+                np.testing.assert_array_equal(z, zr)
+        st, z, stats = fa.linkage(dup, ctx=gpu_ctx, return_stats=True)
+        assert st == 0 and stats["reference_order"] == 1
+        np.testing.assert_array_equal(z, oracle_mod.linkage_ref(dup)[1])
+        bad = cases[4].copy()
+        bad[300, 5] = np.nan
+        assert fa.linkage(bad, ctx=gpu_ctx)[0] == 5
+    monkeypatch.delenv("FA_AHC_CPT")
+    monkeypatch.delenv("FA_AHC_NO_SINGLE_BLOCK", raising=False)
+    monkeypatch.setenv("FA_AHC_UNI_CPT", cpt)
+    base = cases[-1]
+    tied = base[:2000].copy()
+    tied[1000:2000] = tied[0:1000]
+    nan = base[:1900].copy()
+    nan[11, 2] = np.nan
+    group = [base, base[:2100], base[:1800], tied, base[:1300], nan]
+    for mode in (fa.AHC_MODE_AUTO, fa.AHC_MODE_EXACT):
+        st, zs, stats = fa.linkage_batch(group, mode=mode, ctx=gpu_ctx, return_stats=True)
+        assert st[:5] == [0] * 5 and st[5] == 5, st
+        for k, (x, z) in enumerate(zip(group[:5], zs[:5])):
+            zr = oracle_mod.linkage_ref(x)[1]
+            if k == 3 and mode == fa.AHC_MODE_EXACT:             # exact mode keeps its own order among exact ties: heights only
+                np.testing.assert_array_equal(np.sort(z[:, 2]), np.sort(zr[:, 2]))
+                continue
+            np.testing.assert_array_equal(z, zr)
+        if mode == fa.AHC_MODE_AUTO:
+            assert stats[3]["reference_order"] == 1 and stats[0]["reference_order"] == 0
