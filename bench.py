@@ -535,10 +535,13 @@ def tdt_leg(fa, ctx, torch, B=1024, U=64, T=188, V1=1025, nd=5, dtype="float32")
     import oracle
     W = V1 + nd
     g = torch.Generator(device="cuda").manual_seed(17)
-    lg = torch.randn((B, U, T, W), generator=g, device="cuda", dtype=torch.float32)
-    lg[..., V1 - 1] += 4.0
-    if dtype == "float16":
-        lg = lg.half()
+    SL = 256                                                      # chunks per slice of the generation / verification (the fp32 grid of 4 096 chunks would be 203 GB)
+    lg = torch.empty((B, U, T, W), device="cuda", dtype=torch.float16 if dtype == "float16" else torch.float32)
+    for b0 in range(0, B, SL):
+        part = torch.randn((min(SL, B - b0), U, T, W), generator=g, device="cuda", dtype=torch.float32)
+        part[..., V1 - 1] += 4.0
+        lg[b0:b0 + SL] = part.to(lg.dtype)
+        del part
     enc = np.full(B, T, np.int32)
     stream = torch.cuda.ExternalStream(ctx.stream)
     from fluidaudio_amd.tdt import TdtConfig
@@ -569,29 +572,34 @@ def tdt_leg(fa, ctx, torch, B=1024, U=64, T=188, V1=1025, nd=5, dtype="float32")
     ms = e0.elapsed_time(e1) / reps
     tokens = int(sum(r["count"] for r in res))
     elem = 2 if dtype == "float16" else 4
-    # tables for the whole grid on the device (torch), walked by the table kernel: same tokens / timestamps / durations for ALL chunks
-    x32 = lg.float()
-    tok_t = torch.argmax(x32[..., :V1], dim=-1).to(torch.int32)
-    bin_t = torch.argmax(x32[..., V1:], dim=-1).to(torch.int32)
-    prob_t = torch.softmax(x32[..., :V1], dim=-1).amax(dim=-1)
-    del x32
-    tab = fa.tdt_decode_tables(tok_t, bin_t, prob_t, enc, config=tcfg, max_out=U, ctx=ctx)
-    same = all(np.array_equal(a["tokens"], b["tokens"]) and np.array_equal(a["timestamps"], b["timestamps"]) and np.array_equal(a["durations"], b["durations"])
-               and a["final_time"] == b["final_time"] for a, b in zip(res, tab))
-    # every chunk against the CPU restatement on the same tables; the restatement also counts its joint evaluations = the rows of W logits the
-    # device walk read (one row per decision): the algorithmic bytes of the launch
-    ok_cpu, visited = True, 0
-    tok_h, bin_h, prob_h = tok_t.cpu().numpy(), bin_t.cpu().numpy(), prob_t.cpu().numpy()
-    for b in range(B):
-        ref = oracle.tdt_greedy(tok_h[b], bin_h[b], prob_h[b], int(enc[b]), int(enc[b]), 0, False, 0, None, blank_id=V1 - 1, max_out=U)
-        visited += ref["joint_calls"]
-        ok_cpu = ok_cpu and ref["status"] == res[b]["status"] and np.array_equal(ref["tokens"], res[b]["tokens"]) and np.array_equal(ref["timestamps"], res[b]["timestamps"]) \
-            and np.array_equal(ref["durations"], res[b]["durations"])
+    # tables for the whole grid on the device (torch, a slice of chunks at a time), walked by the table kernel: same tokens / timestamps / durations for
+    # ALL chunks; every chunk against the CPU restatement on the same tables; the restatement also counts its joint evaluations = the rows of W logits
+    # the device walk read (one row per decision): the algorithmic bytes of the launch
+    same, ok_cpu, visited, longest = True, True, 0, 0
+    for b0 in range(0, B, SL):
+        x32 = lg[b0:b0 + SL].float()
+        tok_t = torch.argmax(x32[..., :V1], dim=-1).to(torch.int32)
+        bin_t = torch.argmax(x32[..., V1:], dim=-1).to(torch.int32)
+        prob_t = torch.softmax(x32[..., :V1], dim=-1).amax(dim=-1)
+        del x32
+        tab = fa.tdt_decode_tables(tok_t, bin_t, prob_t, enc[b0:b0 + SL], config=tcfg, max_out=U, ctx=ctx)
+        same = same and all(np.array_equal(a["tokens"], b["tokens"]) and np.array_equal(a["timestamps"], b["timestamps"]) and np.array_equal(a["durations"], b["durations"])
+                            and a["final_time"] == b["final_time"] for a, b in zip(res[b0:b0 + SL], tab))
+        tok_h, bin_h, prob_h = tok_t.cpu().numpy(), bin_t.cpu().numpy(), prob_t.cpu().numpy()
+        for i in range(tok_h.shape[0]):
+            b = b0 + i
+            ref = oracle.tdt_greedy(tok_h[i], bin_h[i], prob_h[i], int(enc[b]), int(enc[b]), 0, False, 0, None, blank_id=V1 - 1, max_out=U)
+            visited += ref["joint_calls"]
+            longest = max(longest, ref["joint_calls"])
+            ok_cpu = ok_cpu and ref["status"] == res[b]["status"] and np.array_equal(ref["tokens"], res[b]["tokens"]) and np.array_equal(ref["timestamps"], res[b]["timestamps"]) \
+                and np.array_equal(ref["durations"], res[b]["durations"])
+        del tok_t, bin_t, prob_t
     bytes_read = visited * W * elem
     gbs = bytes_read / (ms * 1e-3) / 1e9
     return {"workload": f"{B} chunks x joint logits [U={U}, T={T}, W={W}] {dtype}, greedy TDT walk, logits resident in HBM ({lg.numel() * elem / 1e9:.1f} GB)",
             "ms_per_pass": ms, "chunks_per_s": B / (ms * 1e-3), "audio_hours_per_s": B * 15.0 / 3600.0 / (ms * 1e-3), "tokens_emitted": tokens,
             "ids_equal_table_walk_all_chunks": bool(same), "ids_equal_cpu_restatement_all_chunks": bool(ok_cpu), "rows_read": visited,
+            "rows_of_the_longest_chunk": longest, "rows_per_chunk_mean": visited / B,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": measured_traffic_of("*_tdt_pmc.json", TDT_SOURCES)[0] if (B, U, T, V1, dtype) == (1024, 64, 188, 1025, "float32") else None,
                          "algorithmic_bytes_per_launch": bytes_read,
@@ -1176,6 +1184,12 @@ def main():
         except Exception as e:  # noqa: BLE001
             line["tdt"] = {"error": repr(e)}
         torch.cuda.empty_cache()
+        for name, kw in (("tdt_4096_fp16", dict(B=4096, dtype="float16")), ("tdt_4096", dict(B=4096))):   # the batch is the parallel axis: four chunks per SIMD
+            try:                                                                                           # instead of one (101 GB of fp16 / 203 GB of fp32 logits resident)
+                line[name] = tdt_leg(fa, ctx, torch, **kw)
+            except Exception as e:  # noqa: BLE001
+                line[name] = {"error": repr(e)}
+            torch.cuda.empty_cache()
     if solo and not args.skip_resample:
         try:
             line["resample"] = resample_leg(fa, ctx, torch)
@@ -1243,7 +1257,8 @@ def main():
         "ctc_v1025_roofline_frac": pick("ctc_v1025", "roofline", "frac"),
         "ctc_v1025_fp16_roofline_frac": pick("ctc_v1025_fp16", "roofline", "frac"),
         "resample_44k1_roofline_frac": pick("resample", "44100->16000", "roofline", "frac"),
-        "tdt_roofline_frac": pick("tdt", "roofline", "frac"),
+        "tdt_roofline_frac": pick("tdt", "roofline", "frac"), "tdt_4096_fp16_roofline_frac": pick("tdt_4096_fp16", "roofline", "frac"),
+        "tdt_4096_roofline_frac": pick("tdt_4096", "roofline", "frac"),
         "vbx_sharded_all_ranks_same_elbos": pick("vbx_sharded", "all_ranks_same_elbos"),
         # N > 1: what the driver's scaling record needs from the legs it drops — the strong-scaled configs[3] rate and every rank's own e2e rate
         "e2e_per_rank_audio_hours_per_s": pick("e2e_8h", "per_rank_audio_hours_per_s"),

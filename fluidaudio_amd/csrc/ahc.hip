@@ -2140,6 +2140,7 @@ struct CachedGraph {   // the round launches of one problem shape, kept in the c
     const void *base = nullptr;
     size_t N = 0, d = 0;
     int cpt = 1;
+    int grid_y = 0, kernel = 0;   // uniform batches: problems in the grid and which build of the round serves them
 };
 void cached_graph_free(void *p) { delete static_cast<CachedGraph *>(p); }
 fa_status ctx_events(fa_ctx *ctx, hipEvent_t (&ev)[3]) {
@@ -2527,8 +2528,12 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_c4), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     }
     const long long max_batches = 64 + 8 * static_cast<long long>(Nmax) / rounds_for(Nmax);
+    // The captured launches hold the workspace address, the layout (N of the largest problem, d, slots per thread), the grid and the kernel build:
+    // the graph of the FIRST capture of a call is kept in the context and reused while all of that is unchanged — a batch job repeats one shape,
+    // and capture + instantiation of 512 launches is ~3 ms (6 % of a 16 x 1 h call).  The smaller grids of a shrinking batch are captured per call.
     RoundGraph *rg = nullptr;
-    struct RgGuard { RoundGraph *&p; ~RgGuard() { delete p; } } rgg{rg};
+    bool rg_owned = false;
+    struct RgGuard { RoundGraph *&p; bool &owned; ~RgGuard() { if (owned) delete p; } } rgg{rg, rg_owned};
     int captured_y = -1;
     for (long long it = 0; it < max_batches; ++it) {
         int last_active = -1;
@@ -2540,9 +2545,25 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
             kernel = uniform_kernel_choice(static_cast<size_t>(grid_y) * w0.nblk);
             size_t longest = 0;
             for (int j = 0; j <= last_active; ++j) if (probs[j].active && probs[j].N > longest) longest = probs[j].N;
-            delete rg;
-            rg = new RoundGraph();
-            rg->capture(ctx, launch, rounds_for(longest));
+            if (rg_owned) delete rg;
+            rg = nullptr; rg_owned = false;
+            const int want_rounds = rounds_for(longest);
+            if (grid_y == count) {   // the full grid of the call: the context's cached graph serves it when nothing it bakes in has changed
+                CachedGraph *cg = static_cast<CachedGraph *>(ctx->ahc_uni_graph);
+                if (!cg || cg->base != base || cg->N != Nmax || cg->d != d || cg->cpt != cpt || cg->grid_y != grid_y || cg->kernel != kernel || cg->rg.rounds != want_rounds || !cg->rg.ok) {
+                    delete cg;
+                    cg = new CachedGraph();
+                    ctx->ahc_uni_graph = cg;
+                    ctx->ahc_graph_free = cached_graph_free;
+                    cg->base = base; cg->N = Nmax; cg->d = d; cg->cpt = cpt; cg->grid_y = grid_y; cg->kernel = kernel;
+                    cg->rg.capture(ctx, launch, want_rounds);
+                }
+                rg = &cg->rg;
+            } else {
+                rg = new RoundGraph();
+                rg_owned = true;
+                rg->capture(ctx, launch, want_rounds);
+            }
             captured_y = grid_y;
         }
         FA_TRY(rg->replay(ctx, launch));

@@ -197,6 +197,7 @@ void fa_ctx_destroy(fa_ctx *ctx) {
     if (ctx->poly_taps) (void)hipFree(ctx->poly_taps);
     if (ctx->poly_rows && ctx->poly_rows_free) ctx->poly_rows_free(ctx->poly_rows);
     if (ctx->ahc_graph && ctx->ahc_graph_free) ctx->ahc_graph_free(ctx->ahc_graph);
+    if (ctx->ahc_uni_graph && ctx->ahc_graph_free) ctx->ahc_graph_free(ctx->ahc_uni_graph);
     if (ctx->mel_cache && ctx->mel_cache_free) ctx->mel_cache_free(ctx->mel_cache);
     for (auto &e : ctx->ahc_ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->tim_ev) if (e) (void)hipEventDestroy(e);

@@ -36,6 +36,7 @@ struct fa_ctx {
     hipEvent_t ahc_ev[3] = {nullptr, nullptr, nullptr};
     void *ahc_graph = nullptr;                 // owned by ahc.hip (ahc_graph_free releases it)
     void (*ahc_graph_free)(void *) = nullptr;
+    void *ahc_uni_graph = nullptr;             // the same for the round launches of a uniform batch (ahc_batch_uniform): a batch job repeats one shape
     // linkage batches of a few LARGE problems run their merge chains concurrently, one per helper context (own stream, own workspace): see
     // ahc_run_device_batch.  Created on first use, trimmed and destroyed with this context.
     fa_ctx *helpers[3] = {nullptr, nullptr, nullptr};

@@ -14,6 +14,8 @@
 // UNPINNED (models absent); the navigation helpers are pinned by TdtRefactoredComponentsTests.swift:12-195.
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "fa_common.h"
 
 namespace {
@@ -36,24 +38,27 @@ __host__ __device__ inline float clamp_probability(const float v) {  // TdtDurat
     return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
 }
 
-// The control loop for chunk b.  `raw(u, frame, tok, prob, bin)` supplies one joint decision (false: out of the supplied range);
-// `writer` is true for the thread that stores the outputs (the table walk runs one thread per chunk; the logits walk runs a
-// whole workgroup per chunk through the same, workgroup-uniform, control flow).
-template <class Raw>
-__device__ __forceinline__ void tdt_walk(const TdtArgs &a, const int b, const bool writer, Raw &&raw) {
+// The control loop for chunk b.  `raw(u, frame, tok, bin)` supplies one joint decision — the token and the duration bin, which decide the next
+// cell —, `prob_of_last()` the probability of the token of the MOST RECENT decision, asked for only when that token is emitted (the reference's
+// joint returns it with every decision, TdtModelInference.swift:107-138, but only an emitted token's confidence is ever used, :409-463): three of
+// four decisions are blanks, and the soft-max denominator is most of a decision's arithmetic.  `writer` is true for the thread that stores the
+// outputs (the table walk runs one thread per chunk; the logits walk runs a wavefront per chunk through the same, wave-uniform, control flow).
+template <class Raw, class Prob>
+__device__ __forceinline__ void tdt_walk(const TdtArgs &a, const int b, const bool writer, Raw &&raw, Prob &&prob_of_last) {
+    auto uni = [](const int x) { return x; };
     const fa_tdt_config &c = a.cfg;
     int32_t *otok = a.out_tok + static_cast<int64_t>(b) * a.max_out, *otime = a.out_time + static_cast<int64_t>(b) * a.max_out;
     int32_t *odur = a.out_dur + static_cast<int64_t>(b) * a.max_out;
     float *oconf = a.out_conf + static_cast<int64_t>(b) * a.max_out;
     int count = 0, st = FA_SUCCESS, u = 0;
-    const int enc_len = a.enc_len[b];
-    const int goff = a.global_offset ? a.global_offset[b] : 0;
-    const int emit_after = a.emit_after ? a.emit_after[b] : -1;
-    int t = a.t0 ? a.t0[b] : 0;
+    const int enc_len = uni(a.enc_len[b]);
+    const int goff = uni(a.global_offset ? a.global_offset[b] : 0);
+    const int emit_after = uni(a.emit_after ? a.emit_after[b] : -1);
+    int t = uni(a.t0 ? a.t0[b] : 0);
     if (writer) a.final_time[b] = INT32_MIN;  // "timeJump not updated" (early returns, :110-112,:150-152)
     auto finish = [&]() { if (writer) { a.out_count[b] = count; a.final_u[b] = u; a.status[b] = st; } };
     if (enc_len <= 1) { finish(); return; }                        // :110-112
-    const int Teff = min(enc_len, a.audio_frames ? a.audio_frames[b] : enc_len);  // TdtFrameNavigation.swift:59-78
+    const int Teff = min(enc_len, uni(a.audio_frames ? a.audio_frames[b] : enc_len));  // TdtFrameNavigation.swift:59-78
     if (t >= Teff) { finish(); return; }                           // :150-152
     const int last = Teff - 1;
     int safe = min(t, last);
@@ -62,16 +67,21 @@ __device__ __forceinline__ void tdt_walk(const TdtArgs &a, const int b, const bo
     float score = 0.0f;
     auto joint = [&](const int frame) -> bool {  // one joint decision; false on a table / duration-bin error
         if (u >= a.U || frame < 0 || frame >= a.T) { st = FA_OUTPUT_TOO_SMALL; return false; }
-        float pr = 0.0f;
         int bi = 0;
-        raw(u, frame, tok, pr, bi);
-        score = clamp_probability(pr);
+        raw(u, frame, tok, bi);
+        tok = uni(tok); bi = uni(bi);
         if (bi < 0 || bi >= c.n_duration_bins) { st = FA_RUNTIME_ERROR; return false; }  // mapDurationBin throws (:17-22)
-        dur = c.duration_bins[bi];
+        // (a dynamic index into the by-value config goes through a private copy — a per-lane load whose result counts as divergent and drags the whole
+        // walk into vector registers; eight selects on the uniform bin keep it scalar)
+        int dsel = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dsel = bi == q ? c.duration_bins[q] : dsel;
+        dur = uni(dsel);
         return true;
     };
     auto emit = [&](const int ts) {
         if (emit_after >= 0 && ts < emit_after) return;  // shouldEmitToken (:600-606)
+        score = clamp_probability(prob_of_last());
         if (count < a.max_out) { if (writer) { otok[count] = tok; otime[count] = ts; odur[count] = dur; oconf[count] = score; } }
         else st = FA_OUTPUT_TOO_SMALL;
         ++count;
@@ -110,11 +120,12 @@ __device__ __forceinline__ void tdt_walk(const TdtArgs &a, const int b, const bo
         }
         active = t < Teff;
     }
-    if (a.is_last && a.is_last[b]) {  // last-chunk flush (:472-571)
+    if (uni(a.is_last ? a.is_last[b] : 0)) {  // last-chunk flush (:472-571)
         int steps = 0, blanks = 0, fp = t;
         while (steps < c.max_symbols_per_step && blanks < c.consecutive_blank_limit) {
-            const int var3[3] = {min(fp, enc_len - 1), min(Teff - 1, enc_len - 1), min(max(0, Teff - 2), enc_len - 1)};
-            if (!joint(var3[steps % 3])) { finish(); return; }
+            const int sel = steps % 3;   // the three boundary-frame variants (:487-499) by selects: an indexed local array lives in scratch
+            const int frame3 = sel == 0 ? min(fp, enc_len - 1) : (sel == 1 ? min(Teff - 1, enc_len - 1) : min(max(0, Teff - 2), enc_len - 1));
+            if (!joint(frame3)) { finish(); return; }
             if (tok == c.blank_id) ++blanks;
             else {
                 blanks = 0;
@@ -129,14 +140,109 @@ __device__ __forceinline__ void tdt_walk(const TdtArgs &a, const int b, const bo
     finish();
 }
 
+// The same control loop for a WAVEFRONT that walks one chunk (tdt_logits_kernel), written as a state machine with ONE joint evaluation per
+// iteration.  tdt_walk above calls the joint from three places (first decision of an outer step, the blank-advance loop, the last-chunk flush): inlined
+// three times, with its state captured by reference, the compiler kept token / duration in scratch memory and the time / step counters in vector
+// registers (every branch of the walk an exec-mask save + restore, every row address 64-bit per-lane arithmetic: the round-4 listing).  Here the state
+// is a handful of integers forced uniform (readfirstlane) where they are loaded or decided: scalar registers, scalar branches, a scalar row address.
+// `decide(u, frame, tok, bin)` -> one joint decision, `prob_of_last()` -> the probability of its token (asked for only when the token is emitted).
+template <class Decide, class Prob>
+__device__ __forceinline__ void tdt_walk_wave(const TdtArgs &a, const int b, const bool writer, Decide &&decide, Prob &&prob_of_last) {
+    auto uni = [](const int x) { return __builtin_amdgcn_readfirstlane(x); };
+    const fa_tdt_config &c = a.cfg;
+    int32_t *otok = a.out_tok + static_cast<int64_t>(b) * a.max_out, *otime = a.out_time + static_cast<int64_t>(b) * a.max_out;
+    int32_t *odur = a.out_dur + static_cast<int64_t>(b) * a.max_out;
+    float *oconf = a.out_conf + static_cast<int64_t>(b) * a.max_out;
+    int count = 0, st = FA_SUCCESS, u = 0;
+    const int enc_len = uni(a.enc_len[b]);
+    const int goff = uni(a.global_offset ? a.global_offset[b] : 0);
+    const int emit_after = uni(a.emit_after ? a.emit_after[b] : -1);
+    const int is_last = uni(a.is_last ? a.is_last[b] : 0);
+    int t = uni(a.t0 ? a.t0[b] : 0);
+    if (writer) a.final_time[b] = INT32_MIN;  // "timeJump not updated" (early returns, :110-112,:150-152)
+    auto finish = [&]() { if (writer) { a.out_count[b] = count; a.final_u[b] = u; a.status[b] = st; } };
+    if (enc_len <= 1) { finish(); return; }                        // :110-112
+    const int Teff = min(enc_len, uni(a.audio_frames ? a.audio_frames[b] : enc_len));  // TdtFrameNavigation.swift:59-78
+    if (t >= Teff) { finish(); return; }                           // :150-152
+    const int last = Teff - 1;
+    enum { OUTER = 0, INNER = 1, FLUSH = 2 };
+    int phase = OUTER, last_emit_t = -1, n_at_t = 0, processed = 0, t_label = t;
+    int steps = 0, blanks = 0, fp = 0;                             // last-chunk flush (:472-571)
+    auto emit = [&](const int ts, const int tok, const int dur) {
+        if (emit_after >= 0 && ts < emit_after) return;           // shouldEmitToken (:600-606)
+        if (count < a.max_out) {
+            const float score = clamp_probability(prob_of_last());
+            if (writer) { otok[count] = tok; otime[count] = ts; odur[count] = dur; oconf[count] = score; }
+        } else st = FA_OUTPUT_TOO_SMALL;
+        ++count;
+    };
+    for (;;) {
+        int frame;
+        if (phase == FLUSH) {
+            if (!(steps < c.max_symbols_per_step && blanks < c.consecutive_blank_limit)) break;
+            const int sel = steps % 3;                             // the three boundary-frame variants (:487-499)
+            frame = sel == 0 ? min(fp, enc_len - 1) : (sel == 1 ? min(Teff - 1, enc_len - 1) : min(max(0, Teff - 2), enc_len - 1));
+        } else {
+            if (phase == INNER) t_label = t;                       // :349: the blank-advance loop labels the frame it is about to look at
+            frame = min(t, last);
+        }
+        // ---- one joint decision (the single call site)
+        if (u >= a.U || frame < 0 || frame >= a.T) { st = FA_OUTPUT_TOO_SMALL; finish(); return; }
+        int tok = 0, bi = 0;
+        decide(u, frame, tok, bi);
+        tok = uni(tok); bi = uni(bi);
+        if (bi < 0 || bi >= c.n_duration_bins) { st = FA_RUNTIME_ERROR; finish(); return; }  // mapDurationBin throws (TdtDurationMapping.swift:17-22)
+        int dur = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dur = bi == q ? c.duration_bins[q] : dur;   // (selects on the uniform bin: an indexed copy of the config would sit in scratch)
+        const bool blank = tok == c.blank_id;
+        if (phase == FLUSH) {
+            if (blank) ++blanks;
+            else { blanks = 0; emit(min(fp, Teff - 1) + goff, tok, dur); ++u; }
+            fp = min(fp + max(1, dur), Teff);
+            ++steps;
+            continue;
+        }
+        if (phase == OUTER) {
+            if (!blank && dur == 0 && t == last_emit_t && n_at_t >= 1) dur = 1;  // :318-323
+            t_label = t;
+        }
+        if (blank && dur == 0) dur = 1;                                           // :327-329 / :377-379
+        t += dur;
+        bool active = t < Teff;
+        if (active && blank) { phase = INNER; continue; }                         // :348-405: same predictor state, blanks only move the frame pointer
+        bool stop = false;
+        if (active && !blank) {                                                   // :409-463
+            if (++processed > c.max_tokens_per_chunk) stop = true;
+            else {
+                emit(t_label + goff, tok, dur);
+                ++u;                                                              // decoder LSTM step on the emitted token (:433-444)
+                if (t_label == last_emit_t) ++n_at_t; else { last_emit_t = t_label; n_at_t = 1; }
+                if (n_at_t >= c.max_symbols_per_step) {                           // force-advance (:453-462)
+                    t = min(t + 1, last);
+                    n_at_t = 0;
+                    last_emit_t = -1;
+                }
+            }
+        }
+        active = t < Teff;
+        if (active && !stop) { phase = OUTER; continue; }
+        if (!is_last) break;
+        phase = FLUSH; steps = 0; blanks = 0; fp = t;
+    }
+    if (writer) a.final_time[b] = t;
+    finish();
+}
+
 __global__ void tdt_kernel(const TdtArgs a) {   // joint decisions from tables [B][U][T], one thread per chunk
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.B) return;
     const int64_t tb = static_cast<int64_t>(b) * a.U * a.T;
-    tdt_walk(a, b, true, [&](const int u, const int frame, int &tok, float &prob, int &bin) {
-        const int64_t i = tb + static_cast<int64_t>(u) * a.T + frame;
-        tok = a.tok[i]; prob = a.prob[i]; bin = a.bin[i];
-    });
+    int64_t last = 0;
+    tdt_walk(a, b, true, [&](const int u, const int frame, int &tok, int &bin) {
+        last = tb + static_cast<int64_t>(u) * a.T + frame;
+        tok = a.tok[last]; bin = a.bin[last];
+    }, [&]() -> float { return a.prob[last]; });
 }
 
 // Joint decisions computed on the fly from joint LOGITS [B][U][T][row_stride] (token logits [0, V1), duration logits [V1, V1 + nd)):
@@ -174,6 +280,16 @@ __device__ __forceinline__ void tdt_wave_argmax(float &v, int &i) {
     v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
     i = __builtin_amdgcn_readlane(i, 63);
 }
+// the same over lanes 0 .. 7 only (values elsewhere are ignored): row_shr 1, 2, 4 leave the result in lane 7
+__device__ __forceinline__ void tdt_low8_argmax(float &v, int &i) {
+#define FA_TDT_STEP(CTRL, MASK)                                                                   \
+    { const float ov = tdt_dpp<CTRL, MASK>(-INFINITY, v); const int oi = tdt_dpp<CTRL, MASK>(0x7fffffff, i); \
+      const bool t = (ov > v) | ((ov == v) & (oi < i)); v = t ? ov : v; i = t ? oi : i; }
+    FA_TDT_STEP(0x111, 0xf) FA_TDT_STEP(0x112, 0xf) FA_TDT_STEP(0x114, 0xf)
+#undef FA_TDT_STEP
+    v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 7));
+    i = __builtin_amdgcn_readlane(i, 7);
+}
 // soft-max partials (m = maximum, s = sum of exp(x - m)) of the 64 lanes -> the wavefront's, in every lane: the maximum first (six DPP steps of
 // one v_max), ONE rescale per lane, then the sum (six DPP adds) — the pairwise form spent two exp per step on the decision's dependent chain
 __device__ __forceinline__ void tdt_wave_softmax(float &m, float &s) {
@@ -192,26 +308,106 @@ __device__ __forceinline__ void tdt_wave_softmax(float &m, float &s) {
     s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 63));
 }
 
+// ---- rows of at most 17 x 64 logits (Parakeet-TDT's 1 025 + 5, the CTC-sized heads): the row stays in registers, in its own element type, from
+// the decision until the next one.  A decision is: 17 + 1 requests from a scalar row address (the lane's byte offsets are loop invariants; offsets
+// beyond the row are clamped to its last element — a duplicate of a real element can tie with it but never beat it, and the true holder has the
+// lower index), the lane maximum (v_max: a NaN operand is dropped), six DPP steps for the row maximum M, and the FIRST index holding M as 17
+// compares whose lane masks the scalar unit searches (piece j before piece j + 1, lowest lane within a piece: index = lane + 64 j) — ~90 vector
+// instructions where the (value, index) scan + (value, index) DPP reduction of round 4 took ~250.  The soft-max runs from the registers, and only
+// when the token is emitted.
+__device__ __forceinline__ float tdt_wave_max(float v) {
+#define FA_TDT_STEP(CTRL, MASK) v = __builtin_fmaxf(v, tdt_dpp<CTRL, MASK>(-INFINITY, v));
+    FA_TDT_STEP(0x111, 0xf) FA_TDT_STEP(0x112, 0xf) FA_TDT_STEP(0x114, 0xf) FA_TDT_STEP(0x118, 0xf)
+    FA_TDT_STEP(0x142, 0xa) FA_TDT_STEP(0x143, 0xc)
+#undef FA_TDT_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float tdt_low8_max(float v) {   // over lanes 0 .. 7
+#define FA_TDT_STEP(CTRL, MASK) v = __builtin_fmaxf(v, tdt_dpp<CTRL, MASK>(-INFINITY, v));
+    FA_TDT_STEP(0x111, 0xf) FA_TDT_STEP(0x112, 0xf) FA_TDT_STEP(0x114, 0xf)
+#undef FA_TDT_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 7));
+}
+
+template <bool F16>
+__global__ __launch_bounds__(64) void tdt_logits_fits_kernel(const TdtArgs a, const TdtLogitArgs g) {
+    using E = std::conditional_t<F16, __half, float>;
+    constexpr int kP = 17;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t tb = static_cast<int64_t>(b) * a.U * a.T;
+    const int last_k = g.V1 - 1;
+    unsigned off[kP];
+#pragma unroll
+    for (int j = 0; j < kP; ++j) { const int k = lane + 64 * j; off[j] = static_cast<unsigned>(k < last_k ? k : last_k) * static_cast<unsigned>(sizeof(E)); }
+    const unsigned doff = static_cast<unsigned>(g.V1 + (lane < g.nd ? lane : g.nd - 1)) * static_cast<unsigned>(sizeof(E));
+    const int row_bytes = (g.V1 + g.nd) * static_cast<int>(sizeof(E));
+    float v[kP];   // fp16 rows are widened as they arrive (LogitsArgmax.swift:31-55 widens fp16 logits before the scan): one conversion per element —
+                   // half-precision maxima (__hmax) compile to a NaN-handling branch per element
+    tdt_walk_wave(a, b, lane == 0, [&](const int u, const int frame, int &tok, int &bin) {
+        // the row through a buffer descriptor: scalar base (the walk's state is scalar) + the lane's 32-bit byte offset = ONE instruction per
+        // request (a flat global load of scalar base + lane offset is compiled as a 64-bit per-lane add and the load)
+        char *rp = const_cast<char *>(static_cast<const char *>(g.logits)) + (tb + static_cast<int64_t>(u) * a.T + frame) * g.row_stride * static_cast<int64_t>(sizeof(E));
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rp, 0, row_bytes, 0x00020000);
+        auto fetch = [&](const unsigned byte_off) -> float {
+            if constexpr (F16) return __half2float(__ushort_as_half(__builtin_amdgcn_raw_buffer_load_b16(rsrc, static_cast<int>(byte_off), 0, 0)));
+            else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, static_cast<int>(byte_off), 0, 0));
+        };
+        const float dve = fetch(doff);                                         // the duration logits travel with the row
+#pragma unroll
+        for (int j = 0; j < kP; ++j) v[j] = fetch(off[j]);
+        float dv = lane < g.nd ? dve : -INFINITY;
+        dv = dv != dv ? -INFINITY : dv;                                          // NaN never wins the first-maximum scan
+        float me = v[0];
+#pragma unroll
+        for (int j = 1; j < kP; ++j) me = __builtin_fmaxf(me, v[j]);            // a NaN operand is dropped
+        const float M = tdt_wave_max(me);                                         // all NaN: NaN; nothing above -inf: -inf
+        int found = 0, idx = 0;
+#pragma unroll
+        for (int j = 0; j < kP; ++j) {
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(v[j] == M);
+            const int here = mask != 0 && !found;
+            idx = here ? 64 * j + __ffsll(static_cast<long long>(mask)) - 1 : idx;
+            found |= here;
+        }
+        tok = (M > -INFINITY && found) ? idx : 0;                                // all NaN / -inf: index 0 (LogitsArgmax semantics: nothing beats the -inf seed)
+        const float DM = tdt_low8_max(dv);
+        const unsigned long long dmask = __builtin_amdgcn_ballot_w64(lane < g.nd && dv == DM);
+        bin = (DM > -INFINITY && dmask != 0) ? __ffsll(static_cast<long long>(dmask)) - 1 : 0;   // first maximum; nothing above -inf: bin 0 (the scan's initial value)
+    }, [&]() -> float {
+        // soft-max of the row in the registers: lane maximum (NaN dropped), one exp per in-row value, then the wavefront's partials
+        float m = -INFINITY, ssum = 0.0f;
+        bool nan_seen = false;                     // a NaN logit anywhere in the row: probability 0 after the clamp
+#pragma unroll
+        for (int j = 0; j < kP; ++j) { const float x = v[j]; m = x > m ? x : m; nan_seen = nan_seen | (x != x); }
+        const bool finite_max = m > -INFINITY;
+#pragma unroll
+        for (int j = 0; j < kP; ++j) { const float e = __expf(v[j] - m); ssum += (finite_max & (lane + 64 * j <= last_k)) ? e : 0.0f; }
+        tdt_wave_softmax(m, ssum);
+        return __builtin_amdgcn_ballot_w64(nan_seen) ? NAN : 1.0f / ssum;
+    });
+}
+
+// ---- longer rows (8 198 logits: Parakeet-TDT v3): one pass, the soft-max partials (m, ssum) accumulated against the running maximum while the
+// row streams through sixteen 256-byte pieces at a time, the NEXT sixteen requested before the present ones are looked at
 template <bool F16>
 __global__ __launch_bounds__(64) void tdt_logits_kernel(const TdtArgs a, const TdtLogitArgs g) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int64_t tb = static_cast<int64_t>(b) * a.U * a.T;
-    auto at = [&](const int64_t row, const int k) -> float {
-        if (F16) return __half2float(static_cast<const __half *>(g.logits)[row * g.row_stride + k]);
-        return static_cast<const float *>(g.logits)[row * g.row_stride + k];
+    auto at = [&](const int64_t row, const int k) -> float {   // row: wave-uniform (a scalar base address), k: the lane's element
+        if (F16) return __half2float((static_cast<const __half *>(g.logits) + row * g.row_stride)[k]);
+        return (static_cast<const float *>(g.logits) + row * g.row_stride)[k];
     };
-    tdt_walk(a, b, lane == 0, [&](const int u, const int frame, int &tok, float &prob, int &bin) {
+    constexpr int kBatch = 16;
+    float m_on = -INFINITY, s_on = 0.0f;              // one-pass partials of the present row
+    bool nan_seen = false;                            // a NaN logit anywhere in the row: probability 0 after the clamp (what the two-pass sum of round 3 gave)
+    tdt_walk_wave(a, b, lane == 0, [&](const int u, const int frame, int &tok, int &bin) {
         const int64_t row = tb + static_cast<int64_t>(u) * a.T + frame;
         float dvl = lane < g.nd ? at(row, g.V1 + lane) : -INFINITY;            // the duration logits travel with the first batch of the row
         if (dvl != dvl) dvl = -INFINITY;                                       // NaN never wins the first-maximum scan
         // per-lane: first maximum over k = lane, lane + 64, ... (ascending, strict '>': NaN never wins) and the soft-max partials (m, ssum)
-        float bv = -INFINITY, m = -INFINITY, ssum = 0.0f;
+        float bv = -INFINITY, m = -INFINITY, ssum = 0.0f, v[kBatch], vn[kBatch];
         int bi = 0x7fffffff;
-        bool nan_seen = false;                     // a NaN logit anywhere in the row: probability 0 after the clamp (what the two-pass sum of round 3 gave)
-        // the row is requested sixteen 256-byte pieces at a time, and the NEXT sixteen before the present ones are looked at: a row of 1 030 logits
-        // is one memory round trip, a row of 8 198 (Parakeet-TDT v3) four overlapped ones
-        constexpr int kBatch = 16;
-        float v[kBatch], vn[kBatch];
+        nan_seen = false;
         auto request = [&](float (&dst)[kBatch], const int k0) {
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) { const int k = k0 + 64 * j; dst[j] = k < g.V1 ? at(row, k) : -INFINITY; }
@@ -223,7 +419,7 @@ __global__ __launch_bounds__(64) void tdt_logits_kernel(const TdtArgs a, const T
             float bm = -INFINITY;                                                    // maximum of the batch first: one exp per value, one rescale per batch
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) {                                       // selects, no per-lane branches: the decision is a dependent chain
-                if (kbase + 64 * j >= g.V1) break;                                   // (wave-uniform; a row of 1 025 logits: the second batch holds ONE piece)
+                if (kbase + 64 * j >= g.V1) break;
                 const bool t = v[j] > bv;                                            // (slots beyond the row hold -inf and never win)
                 bv = t ? v[j] : bv; bi = t ? k0 + 64 * j : bi;
                 bm = v[j] > bm ? v[j] : bm;
@@ -245,14 +441,17 @@ __global__ __launch_bounds__(64) void tdt_logits_kernel(const TdtArgs a, const T
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) v[j] = vn[j];
         }
+        m_on = m; s_on = ssum;
         tdt_wave_argmax(bv, bi);
-        tdt_wave_softmax(m, ssum);
         tok = bi == 0x7fffffff ? 0 : bi;           // all NaN / -inf: index 0 (LogitsArgmax semantics)
-        prob = __builtin_amdgcn_ballot_w64(nan_seen) ? NAN : 1.0f / ssum;
         float dv = dvl;
         int di = lane < g.nd ? lane : 0x7fffffff;
-        tdt_wave_argmax(dv, di);
+        tdt_low8_argmax(dv, di);                                                // the <= 8 duration logits sit in lanes 0 .. 7: three DPP steps
         bin = (di == 0x7fffffff || !(dv > -INFINITY)) ? 0 : di;                 // first maximum; nothing above -inf: bin 0 (the scan's initial value)
+    }, [&]() -> float {
+        float m = m_on, ssum = s_on;
+        tdt_wave_softmax(m, ssum);
+        return __builtin_amdgcn_ballot_w64(nan_seen) ? NAN : 1.0f / ssum;
     });
 }
 
@@ -342,8 +541,9 @@ fa_status fa_tdt_greedy_logits_dev(fa_ctx *ctx, const fa_tdt_config *cfg, const 
     a.final_time = d_final_time; a.final_u = d_final_u; a.status = d_status;
     a.B = batch; a.U = U; a.T = T; a.max_out = max_out; a.cfg = *cfg;
     TdtLogitArgs g{d_logits, dtype == FA_DTYPE_F16 ? 1 : 0, vocab_with_blank, cfg->n_duration_bins, row_stride};
-    if (g.f16) hipLaunchKernelGGL(tdt_logits_kernel<true>, dim3(batch), dim3(64), 0, ctx->stream, a, g);
-    else hipLaunchKernelGGL(tdt_logits_kernel<false>, dim3(batch), dim3(64), 0, ctx->stream, a, g);
+    const bool fits = vocab_with_blank <= 64 * 17;   // the row stays in registers between its argmax and the (rare) request for its probability
+    if (g.f16) { if (fits) hipLaunchKernelGGL(tdt_logits_fits_kernel<true>, dim3(batch), dim3(64), 0, ctx->stream, a, g); else hipLaunchKernelGGL(tdt_logits_kernel<true>, dim3(batch), dim3(64), 0, ctx->stream, a, g); }
+    else { if (fits) hipLaunchKernelGGL(tdt_logits_fits_kernel<false>, dim3(batch), dim3(64), 0, ctx->stream, a, g); else hipLaunchKernelGGL(tdt_logits_kernel<false>, dim3(batch), dim3(64), 0, ctx->stream, a, g); }
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }
