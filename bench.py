@@ -479,13 +479,14 @@ def beam_leg(fa, ctx, torch, batch=512, frames=1500, vocab=1025):
 def resample_leg(fa, ctx, torch, seconds=3600):
     """The polyphase resampler (north star; the default path of AudioConverter.swift:60-71,299-370 is Apple's closed AVAudioConverter, so the
     kernel is a labelled extension with scipy.signal.resample_poly as its CPU second opinion): `seconds` of mono fp32 audio resident in HBM
-    at 48 / 44.1 / 22.05 / 8 kHz -> 16 kHz, taps of the pair cached in the context (designed and uploaded by the first call, not per call),
+    at 48 / 44.1 / 22.05 / 8 / 96 / 88.2 kHz -> 16 kHz, taps of the pair cached in the context (designed and uploaded by the first call, not per call),
     HIP events on the context's stream.  Algorithmic bytes = 4 (n_in + n_out): every sample read once, every output written once."""
     import ctypes as C
     from scipy import signal
     stream = torch.cuda.ExternalStream(ctx.stream)
     out = {}
-    for name, rate, up, down in (("48000->16000", 48000, 1, 3), ("44100->16000", 44100, 160, 441), ("22050->16000", 22050, 320, 441), ("8000->16000", 8000, 2, 1)):
+    for name, rate, up, down in (("48000->16000", 48000, 1, 3), ("44100->16000", 44100, 160, 441), ("22050->16000", 22050, 320, 441), ("8000->16000", 8000, 2, 1),
+                                 ("96000->16000", 96000, 1, 6), ("88200->16000", 88200, 80, 441)):
         n = rate * seconds
         g = torch.Generator(device="cuda").manual_seed(rate)
         x = torch.randn(n, generator=g, device="cuda", dtype=torch.float32) * 0.1
@@ -1257,6 +1258,7 @@ def main():
         "ctc_v1025_roofline_frac": pick("ctc_v1025", "roofline", "frac"),
         "ctc_v1025_fp16_roofline_frac": pick("ctc_v1025_fp16", "roofline", "frac"),
         "resample_44k1_roofline_frac": pick("resample", "44100->16000", "roofline", "frac"),
+        "resample_96k_roofline_frac": pick("resample", "96000->16000", "roofline", "frac"), "resample_88k2_roofline_frac": pick("resample", "88200->16000", "roofline", "frac"),
         "tdt_roofline_frac": pick("tdt", "roofline", "frac"), "tdt_4096_fp16_roofline_frac": pick("tdt_4096_fp16", "roofline", "frac"),
         "tdt_4096_roofline_frac": pick("tdt_4096", "roofline", "frac"),
         "vbx_sharded_all_ranks_same_elbos": pick("vbx_sharded", "all_ranks_same_elbos"),

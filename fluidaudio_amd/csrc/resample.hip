@@ -13,6 +13,7 @@
 //     phase; consecutive threads read consecutive input samples and taps `up` apart.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -112,14 +113,31 @@ __global__ __launch_bounds__(kThreads) void poly_lds_kernel(const float *__restr
 // pre_remove = 11: output m reads inputs (m - 10) DOWN ... (m + 11) DOWN with tap (m + 11) DOWN - k.  The launch covers outputs
 // [m_begin, m_begin + count R) whose inputs all exist; m_begin = 10 (mod 4) and R DOWN = 0 (mod 4) make every thread's first input a
 // multiple of 4 samples: aligned 16-byte loads with a compile-time lane layout.  The edges go to poly_kernel.
+// A tap as the DPP operand of the multiply-add (round 5): v_fmac_f32_dpp ... row_newbcast:K multiplies with lane K of the lane's own 16-lane row of
+// `taps16`, so a register holds 16 taps (replicated in its four rows) and a multiply-add with a wave-uniform tap is ONE vector instruction without
+// a scalar register per tap (down = 6 has 127 taps: more than the scalar file holds as asm operands) and without a v_readlane per tap.
+template <int K>
+__device__ __forceinline__ void fmac_bcast(float &acc, const float taps16, const float x) {   // acc += taps16[lane K of this lane's row] * x
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(taps16), "v"(x), "n"(K));
+}
+// compile-time loop (the DPP lane is an immediate of the instruction: the index must be a constant expression, not a value the unroller may or may not
+// fold — the 169 x 8 body of down = 6 is beyond what it unrolls)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 constexpr int kDecimR = 8;
 template <int DOWN>
 __global__ __launch_bounds__(kThreads) void poly_decim_kernel(const float *__restrict__ x, const float *__restrict__ h, float *__restrict__ y, int64_t m_begin,
                                                               int64_t groups) {
     constexpr int R = kDecimR, NT = 21 * DOWN + 1, NIN = NT + (R - 1) * DOWN, NV = (NIN + 3) / 4;
     static_assert((R * DOWN) % 4 == 0, "aligned 16-byte loads need R * DOWN = 0 (mod 4)");
-    const int64_t g = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-    if (g >= groups) return;
+    const int64_t g_own = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    // every lane of a wavefront stays active to the end: the DPP form of the multiply-add reads its tap from ANOTHER lane of the row, and a lane
+    // that has left reads as zero — the threads behind the last group recompute that group and skip the store
+    const bool mine = g_own < groups;
+    const int64_t g = mine ? g_own : groups - 1;
     const int64_t m0 = m_begin + g * R;
     const float4 *src = reinterpret_cast<const float4 *>(x + (m0 - 10) * DOWN);
     float xin[4 * NV];
@@ -127,6 +145,13 @@ __global__ __launch_bounds__(kThreads) void poly_decim_kernel(const float *__res
     for (int v = 0; v < NV; ++v) { const float4 q = src[v]; xin[4 * v] = q.x; xin[4 * v + 1] = q.y; xin[4 * v + 2] = q.z; xin[4 * v + 3] = q.w; }
     typedef const float __attribute__((address_space(4))) *c_f32;
     const c_f32 taps = (c_f32)h;
+    constexpr int NQ = (NT + 15) / 16;
+    float tq[NQ];                                   // DOWN >= 4: the taps in vector registers, 16 per register, for the DPP form of the multiply-add
+    if constexpr (DOWN >= 4) {
+        const int l16 = threadIdx.x & 15;
+#pragma unroll
+        for (int qv = 0; qv < NQ; ++qv) { const int ti = 16 * qv + l16; tq[qv] = h[ti < NT ? ti : NT - 1]; }
+    }
     float acc[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) acc[j] = 0.0f;
@@ -134,18 +159,27 @@ __global__ __launch_bounds__(kThreads) void poly_decim_kernel(const float *__res
     // vectoriser paired the outputs into v_pk_fma_f32, whose operands must be consecutive register PAIRS; the inputs of two outputs lie DOWN
     // registers apart, so every packed instruction came with ~1.3 register moves (DOWN = 3: 256 v_pk_fma + 361 moves = 774 instructions for 8
     // outputs; now 512 v_fmac + the loads and stores).  The same fused multiply-add, the same order: identical bits.
+    if constexpr (DOWN <= 3) {
 #pragma unroll
-    for (int i = 0; i < NIN; ++i)          // ascending input index; output j meets it with tap NT - 1 + j DOWN - i
+        for (int i = 0; i < NIN; ++i)          // ascending input index; output j meets it with tap NT - 1 + j DOWN - i
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int ti = NT - 1 + j * DOWN - i;
-            if (ti >= 0 && ti < NT) {
-                if (DOWN <= 3) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[j]) : "s"(taps[ti]), "v"(xin[i]));   // <= 64 taps: they all fit the scalar registers
-                else acc[j] = fmaf(taps[ti], xin[i], acc[j]);        // 85 / 106 taps: left to the compiler (the constraint would spill scalar registers)
+            for (int j = 0; j < R; ++j) {
+                const int ti = NT - 1 + j * DOWN - i;
+                if (ti >= 0 && ti < NT) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc[j]) : "s"(taps[ti]), "v"(xin[i]));   // <= 64 taps: they all fit the scalar registers
             }
-        }
+    } else {
+        // 85 / 106 / 127 taps: through DPP from six to eight registers (round 4 left down = 4, 5 to the compiler's packed pairs + register moves and had no
+        // instance for down = 6: 96 kHz went to the LDS-staged kernel at 12 % of the HBM roofline)
+        static_for<0, NIN>([&](auto ic) {
+            static_for<0, R>([&](auto jc) {
+                constexpr int i = decltype(ic)::value, j = decltype(jc)::value, ti = NT - 1 + j * DOWN - i;
+                if constexpr (ti >= 0 && ti < NT) fmac_bcast<ti % 16>(acc[j], tq[ti / 16], xin[i]);
+            });
+        });
+    }
     float4 *dst = reinterpret_cast<float4 *>(y + m0);   // m0 = 10 (mod 4) + multiple of 8: 8-byte aligned only -> two-float stores
     (void)dst;
+    if (!mine) return;
 #pragma unroll
     for (int j = 0; j < R; j += 2) *reinterpret_cast<float2 *>(y + m0 + j) = make_float2(acc[j], acc[j + 1]);
 }
@@ -224,26 +258,42 @@ void poly_interp_launch(fa_ctx *ctx, const float *d_x, const float *d_h, float *
 // The table row holds the phase's taps SHIFTED by the misalignment of its window (zeros in front and behind), so the window is read from the
 // 16-byte boundary below it and every multiply-add has compile-time register indices — no per-alignment code paths.  The padding taps are
 // zeros: on finite inputs x * 0 adds +-0 and the sum keeps the bits of poly_kernel's (scipy's upfirdn pads its phases with zeros the same way).
-template <int NV>
-__device__ __forceinline__ float rows_phase(const float trow, const float *rowp) {
-    const int tb = __float_as_int(trow);
-    const int off4 = __builtin_amdgcn_readlane(tb, kRowsOffLane);      // window offset rounded down to a multiple of 4
-    const float4 *wp = reinterpret_cast<const float4 *>(rowp + off4);
-    float xr[4 * NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) { const float4 q = wp[v]; xr[4 * v] = q.x; xr[4 * v + 1] = q.y; xr[4 * v + 2] = q.z; xr[4 * v + 3] = q.w; }
-    float acc = 0.0f;
-    constexpr int NT = 4 * NV < kRowsOffLane ? 4 * NV : kRowsOffLane;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(tb, j)), xr[j], acc);
-    return acc;
+// Round 5 (44.1 kHz: 29 -> see profiles/r05_resample_probe.json): two changes to the inner loop, none to the tiling.
+//   * `SHARE` consecutive phases read ONE register window (resample_geom.h): at 44.1 -> 16 kHz two phases share 16 reads (round 4: 16 each; LDS reads
+//     of a launch halve), at 22.05 kHz four phases share 10 (round 4: 8 each);
+//   * a tap reaches its multiply-add through DPP: v_fmac_f32_dpp ... row_newbcast:n multiplies with lane n of the lane's own 16-lane row of the
+//     table register, so a table register holds 16 taps, replicated in its four rows, and a multiply-add is ONE instruction (round 4: v_readlane
+//     into a scalar register + v_fmac, two instructions per tap and 62 taps per output: the kernel's arithmetic half).
+// Per output the terms are still added in ascending input order over the window, zeros in front and behind: identical bits on finite input.
+// (Non-finite input: a zero tap times Inf / NaN is NaN — an Inf or NaN sample reaches every output whose SHARED window covers it, a few samples
+// more on either side than its true FIR window; poly_kernel, the edges and the register-tiled kernels skip taps instead.  Documented, tested.)
+template <int NTW>
+__device__ __forceinline__ void rows_dot(float &acc, const float *tq, const float *xr) {   // acc += sum over the window positions i < NTW of tap i * xr[i], ascending i
+#define FA_ROWS_Q(Q)                                                                                                  \
+    if constexpr (16 * Q < NTW) {                                                                                     \
+        if constexpr (16 * Q + 0 < NTW) fmac_bcast<0>(acc, tq[Q], xr[16 * Q + 0]);   if constexpr (16 * Q + 1 < NTW) fmac_bcast<1>(acc, tq[Q], xr[16 * Q + 1]);   \
+        if constexpr (16 * Q + 2 < NTW) fmac_bcast<2>(acc, tq[Q], xr[16 * Q + 2]);   if constexpr (16 * Q + 3 < NTW) fmac_bcast<3>(acc, tq[Q], xr[16 * Q + 3]);   \
+        if constexpr (16 * Q + 4 < NTW) fmac_bcast<4>(acc, tq[Q], xr[16 * Q + 4]);   if constexpr (16 * Q + 5 < NTW) fmac_bcast<5>(acc, tq[Q], xr[16 * Q + 5]);   \
+        if constexpr (16 * Q + 6 < NTW) fmac_bcast<6>(acc, tq[Q], xr[16 * Q + 6]);   if constexpr (16 * Q + 7 < NTW) fmac_bcast<7>(acc, tq[Q], xr[16 * Q + 7]);   \
+        if constexpr (16 * Q + 8 < NTW) fmac_bcast<8>(acc, tq[Q], xr[16 * Q + 8]);   if constexpr (16 * Q + 9 < NTW) fmac_bcast<9>(acc, tq[Q], xr[16 * Q + 9]);   \
+        if constexpr (16 * Q + 10 < NTW) fmac_bcast<10>(acc, tq[Q], xr[16 * Q + 10]); if constexpr (16 * Q + 11 < NTW) fmac_bcast<11>(acc, tq[Q], xr[16 * Q + 11]); \
+        if constexpr (16 * Q + 12 < NTW) fmac_bcast<12>(acc, tq[Q], xr[16 * Q + 12]); if constexpr (16 * Q + 13 < NTW) fmac_bcast<13>(acc, tq[Q], xr[16 * Q + 13]); \
+        if constexpr (16 * Q + 14 < NTW) fmac_bcast<14>(acc, tq[Q], xr[16 * Q + 14]); if constexpr (16 * Q + 15 < NTW) fmac_bcast<15>(acc, tq[Q], xr[16 * Q + 15]); \
+    }
+    FA_ROWS_Q(0) FA_ROWS_Q(1) FA_ROWS_Q(2) FA_ROWS_Q(3)
+#undef FA_ROWS_Q
 }
 
-template <int NV, int IT>   // NV: 16-byte reads per window (4 (NV - 1) taps at most); IT: 64-float pieces per staged row (sld <= 64 IT)
+template <int NV, int IT, int SHARE, int HALVES = 1>   // NV: 16-byte reads per window; IT: 64-float pieces per staged row (sld <= 64 IT); SHARE: phases per window;
+                                                      // HALVES = 2 (NV = 16, SHARE = 1): a phase of more than 64 taps reads two windows, one right behind the other
 __global__ __launch_bounds__(kRowsThreads) void poly_rows_kernel(const float *__restrict__ x, const float *__restrict__ tt, const int2 *__restrict__ gtab,
                                                                 float *__restrict__ y, const PolyRowsGeom g, const int64_t tiles, const int64_t m_end, const int vec_ok) {
     extern __shared__ float xs[];
     typedef const int __attribute__((address_space(4))) *c_i32;
+    static_assert(HALVES == 1 || (NV == 16 && SHARE == 1), "two windows per phase: full windows, no sharing");
+    constexpr int NTW = 4 * NV;                                          // window positions that can carry a tap
+    constexpr int NQ = HALVES * ((NTW + 15) / 16);                       // table registers per phase (16 taps each)
+    constexpr int NW = 4 / SHARE;                                        // shared windows per chunk of four phases
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Workgroups are dealt to the 8 XCDs round-robin by their index, and each XCD has its own L2.  The phase groups of ONE tile stage overlapping
     // input spans (a window reaches ~60 samples into the neighbouring group's span: 27 % of the input at 44.1 -> 16 kHz), so they are given indices
@@ -255,40 +305,81 @@ __global__ __launch_bounds__(kRowsThreads) void poly_rows_kernel(const float *__
     if (tile >= tiles) return;
     const int ph0 = grp * g.ppg, ph1 = ph0 + g.ppg < g.up ? ph0 + g.ppg : g.up;
     const int nchunks = (ph1 - ph0 + 3) >> 2;
-    auto row = [&](const int ph) -> float { return ph < ph1 ? tt[static_cast<size_t>(ph) * 64 + lane] : 0.0f; };   // ph is wave-uniform
+    const int l16 = lane & 15;
+    struct Chunk { float t[4][NQ]; int off[NW]; };
+    const int ph_last = g.up - 1;
+    auto fetch = [&](Chunk &c, const int p) {                            // table rows + window offsets of the chunk of four phases from p on (p: wave-uniform)
+        // requested UNCONDITIONALLY from a clamped phase (a request under a condition is an exec save / restore and a branch around every load): the
+        // row of a phase beyond the group's last is never used — its window is skipped or its output is not stored
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t ph = static_cast<size_t>(p + u < ph_last ? p + u : ph_last);
+#pragma unroll
+            for (int qv = 0; qv < NQ; ++qv) c.t[u][qv] = tt[ph * fa::kRowsTT + 16 * qv + l16];
+        }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const size_t ph = static_cast<size_t>(p + w * SHARE < ph_last ? p + w * SHARE : ph_last);
+            c.off[w] = __float_as_int(tt[ph * fa::kRowsTT + fa::kRowsOffPos]);
+        }
+    };
     int c = wave;
-    float t0 = row(ph0 + 4 * c), t1 = row(ph0 + 4 * c + 1), t2 = row(ph0 + 4 * c + 2), t3 = row(ph0 + 4 * c + 3);   // requested before the staging
+    Chunk cur;
+    fetch(cur, ph0 + 4 * c);                                              // requested before the staging
     const c_i32 gt = (c_i32) reinterpret_cast<const int *>(gtab);
     const int smin = gt[2 * grp], span = gt[2 * grp + 1];
     const int64_t kt = g.k_begin + tile * 64 * g.down + smin;
     {   // wavefront w stages rows 8 w .. 8 w + 7 with coalesced 256-byte requests — ALL of them requested before the first is written to LDS
         // (writing each element as it arrived made 40 dependent HBM round trips per thread: 18.8 % of the HBM roofline at 44.1 -> 16 kHz)
-        constexpr int kRowsPerWave = 64 / kRowsWaves;
-        float v[kRowsPerWave][IT];
+        // Round 5: 16 bytes per lane and request (rows start `down` samples apart, i.e. at any 4-byte alignment: the hardware's unaligned access mode
+        // serves them, as in poly_interp_kernel; the LDS side is 16-byte aligned: sld and the staged offsets are multiples of 4).  The span of a group
+        // is a multiple of 4, so a lane's piece lies inside it or outside it as a whole: 2 requests + 2 LDS writes per row where round 4 issued 5 + 5,
+        // each under its own branch.
+        constexpr int kRowsPerWave = 64 / kRowsWaves, IT4 = (64 * IT + 255) / 256;
+        f4u v[kRowsPerWave][IT4];
 #pragma unroll
         for (int r = 0; r < kRowsPerWave; ++r) {
             const float *src = x + kt + static_cast<int64_t>(wave * kRowsPerWave + r) * g.down;
 #pragma unroll
-            for (int it = 0; it < IT; ++it) { const int sidx = lane + 64 * it; v[r][it] = sidx < span ? src[sidx] : 0.0f; }
+            for (int it = 0; it < IT4; ++it) {
+                const int sidx = 4 * lane + 256 * it;
+                if (sidx < span) v[r][it] = *reinterpret_cast<const f4u *>(src + sidx);
+            }
         }
 #pragma unroll
         for (int r = 0; r < kRowsPerWave; ++r) {
             float *dst = xs + (wave * kRowsPerWave + r) * g.sld;
 #pragma unroll
-            for (int it = 0; it < IT; ++it) { const int sidx = lane + 64 * it; if (sidx < span) dst[sidx] = v[r][it]; }
+            for (int it = 0; it < IT4; ++it) {
+                const int sidx = 4 * lane + 256 * it;
+                if (sidx < span) *reinterpret_cast<float4 *>(dst + sidx) = make_float4(v[r][it].x, v[r][it].y, v[r][it].z, v[r][it].w);
+            }
         }
     }
     __syncthreads();
     const float *rowp = xs + lane * g.sld - smin;
     const int64_t mlane = g.m_begin + tile * 64 * g.up + static_cast<int64_t>(lane) * g.up;
     for (; c < nchunks; c += kRowsWaves) {
-        const int p = ph0 + 4 * c, pn = p + 4 * kRowsWaves;
-        const float n0 = row(pn), n1 = row(pn + 1), n2 = row(pn + 2), n3 = row(pn + 3);   // the next chunk's table rows travel under this chunk's arithmetic
+        const int p = ph0 + 4 * c;
+        Chunk nxt;
+        fetch(nxt, p + 4 * kRowsWaves);                                   // the next chunk's table rows travel under this chunk's arithmetic
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        acc[0] = rows_phase<NV>(t0, rowp);                                                   // p < ph1 by construction of nchunks
-        if (p + 1 < ph1) acc[1] = rows_phase<NV>(t1, rowp);
-        if (p + 2 < ph1) acc[2] = rows_phase<NV>(t2, rowp);
-        if (p + 3 < ph1) acc[3] = rows_phase<NV>(t3, rowp);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            if (p + w * SHARE >= ph1) break;                              // (wave-uniform)
+            const int off4 = __builtin_amdgcn_readfirstlane(cur.off[w]);  // the window's first staged offset: a multiple of 4, the same in every lane
+            const float4 *wp = reinterpret_cast<const float4 *>(rowp + off4);
+            float xr[4 * NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) { const float4 qq = wp[v]; xr[4 * v] = qq.x; xr[4 * v + 1] = qq.y; xr[4 * v + 2] = qq.z; xr[4 * v + 3] = qq.w; }
+#pragma unroll
+            for (int u = 0; u < SHARE; ++u) rows_dot<NTW>(acc[w * SHARE + u], cur.t[w * SHARE + u], xr);   // (a phase beyond ph1: its output is not stored)
+            if constexpr (HALVES == 2) {                                  // the second window of the (single) phase, behind the first: positions 64 .. 127
+#pragma unroll
+                for (int v = 0; v < NV; ++v) { const float4 qq = wp[NV + v]; xr[4 * v] = qq.x; xr[4 * v + 1] = qq.y; xr[4 * v + 2] = qq.z; xr[4 * v + 3] = qq.w; }
+                rows_dot<NTW>(acc[w], cur.t[w] + NQ / 2, xr);
+            }
+        }
         const int64_t m = mlane + p;
         if (vec_ok && p + 3 < ph1 && m + 3 < m_end) {
             *reinterpret_cast<float4 *>(y + m) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -296,7 +387,7 @@ __global__ __launch_bounds__(kRowsThreads) void poly_rows_kernel(const float *__
 #pragma unroll
             for (int u = 0; u < 4; ++u) if (p + u < ph1 && m + u < m_end) y[m + u] = acc[u];
         }
-        t0 = n0; t1 = n1; t2 = n2; t3 = n3;
+        cur = nxt;
     }
 }
 
@@ -316,24 +407,33 @@ void poly_rows_free(void *p) { delete static_cast<PolyRows *>(p); }
 bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt) {
     size_t budget = 0;                                                  // automatic (resample_geom.h); FA_RESAMPLE_ROWS_LDS_KB: measurements (r04_rows_lds_probe.json)
     if (const char *e = getenv("FA_RESAMPLE_ROWS_LDS_KB")) { const int v = atoi(e); if (v >= 16 && v <= 150) budget = static_cast<size_t>(v) * 1024; }
-    if (!fa::rows_geometry(R.g, R.nv, h, up, down, pre_remove, gtab, tt, budget)) return false;
+    int share_max = 4;                                                  // FA_RESAMPLE_ROWS_SHARE = 1 | 2 | 4: measurements (1 = every phase its own window, round 4's reads)
+    if (const char *e = getenv("FA_RESAMPLE_ROWS_SHARE")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) share_max = v; }
+    if (!fa::rows_geometry(R.g, R.nv, h, up, down, pre_remove, gtab, tt, budget, share_max)) return false;
+    if (R.g.sld > 64 * 5 && R.g.share != 1 && !fa::rows_geometry(R.g, R.nv, h, up, down, pre_remove, gtab, tt, budget, 1)) return false;   // the long-row build is instantiated for share = 1 only
     R.lds = static_cast<size_t>(R.g.sld) * 64 * sizeof(float); R.up = up; R.down = down;
     return true;
 }
 
-template <int NV, int IT>
+template <int NV, int IT, int SHARE, int HALVES = 1>
 void poly_rows_launch_it(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end) {
     const int2 *gtab = static_cast<const int2 *>(R.d_tables);
     const float *tt = reinterpret_cast<const float *>(static_cast<const char *>(R.d_tables) + R.tt_offset);
     const int vec_ok = R.up % 4 == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0 ? 1 : 0;   // m_begin and the chunk starts are multiples of 4
-    if (R.lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(poly_rows_kernel<NV, IT>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(R.lds));
+    if (R.lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(poly_rows_kernel<NV, IT, SHARE, HALVES>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(R.lds));
     const int64_t tiles8 = (tiles + 7) / 8 * 8;   // whole rounds of the 8 XCDs: the index -> (tile, group) map of the kernel
-    hipLaunchKernelGGL((poly_rows_kernel<NV, IT>), dim3(static_cast<unsigned>(tiles8 * R.g.groups)), dim3(kRowsThreads), R.lds, ctx->stream, d_x, tt, gtab, d_y, R.g, tiles, m_end, vec_ok);
+    hipLaunchKernelGGL((poly_rows_kernel<NV, IT, SHARE, HALVES>), dim3(static_cast<unsigned>(tiles8 * R.g.groups)), dim3(kRowsThreads), R.lds, ctx->stream, d_x, tt, gtab, d_y, R.g, tiles, m_end, vec_ok);
 }
 template <int NV>
 void poly_rows_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end) {
-    if (R.g.sld <= 64 * 5) poly_rows_launch_it<NV, 5>(ctx, R, d_x, d_y, tiles, m_end);       // rows of a group within 74 KB (the common case)
-    else poly_rows_launch_it<NV, 10>(ctx, R, d_x, d_y, tiles, m_end);                       // few phases with long windows: one group per tile
+    if constexpr (NV == 32) {                                                               // phases of 65 .. 128 taps (88.2 -> 16 kHz): two windows of 16 reads per phase
+        if (R.g.sld > 64 * 5) poly_rows_launch_it<16, 10, 1, 2>(ctx, R, d_x, d_y, tiles, m_end);
+        else poly_rows_launch_it<16, 5, 1, 2>(ctx, R, d_x, d_y, tiles, m_end);
+    } else
+    if (R.g.sld > 64 * 5) poly_rows_launch_it<NV, 10, 1>(ctx, R, d_x, d_y, tiles, m_end);   // few phases with long windows: one group per tile (built with share = 1)
+    else if (R.g.share == 4) poly_rows_launch_it<NV, 5, 4>(ctx, R, d_x, d_y, tiles, m_end);  // rows of a group within 74 KB (the common case)
+    else if (R.g.share == 2) poly_rows_launch_it<NV, 5, 2>(ctx, R, d_x, d_y, tiles, m_end);
+    else poly_rows_launch_it<NV, 5, 1>(ctx, R, d_x, d_y, tiles, m_end);
 }
 
 double bessel_i0(double x) {  // power series, converges fast for the beta used here
@@ -487,7 +587,7 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
         };
         // integer decimation: register-tiled kernel on the outputs whose inputs all exist, poly_kernel on the two edges
         bool decim = false;
-        if (!simple && u == 1 && (dn == 2 || dn == 3 || dn == 4 || dn == 5) && getenv("FA_RESAMPLE_NO_DECIM") == nullptr &&
+        if (!simple && u == 1 && dn >= 2 && dn <= 6 && getenv("FA_RESAMPLE_NO_DECIM") == nullptr &&
             (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_y) & 7) == 0 && n_taps == 21 * dn + 1 && pre_remove == 11) {
             const int64_t m_begin = 10;                                                  // inputs start at (m - 10) dn >= 0; 10 = 10 (mod 4)
             const int64_t m_last = (frames - 1) / dn - 11;                               // (m + 11) dn <= frames - 1
@@ -501,7 +601,8 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
                     case 2: hipLaunchKernelGGL(poly_decim_kernel<2>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;
                     case 3: hipLaunchKernelGGL(poly_decim_kernel<3>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;
                     case 4: hipLaunchKernelGGL(poly_decim_kernel<4>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;
-                    default: hipLaunchKernelGGL(poly_decim_kernel<5>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;   // (6: 127 taps + 169 inputs spill)
+                    case 5: hipLaunchKernelGGL(poly_decim_kernel<5>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;
+                    default: hipLaunchKernelGGL(poly_decim_kernel<6>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;   // 96 kHz: 127 taps in eight registers, 169 inputs
                 }
                 edges(0, m_begin);
                 edges(m_begin + gr * kDecimR, n_out);
@@ -534,7 +635,7 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
                 const int64_t m_stop = std::min(n_out, G.m_begin + tiles * per_tile);
                 switch (R.nv) {
 #define FA_ROWS_CASE(V) case V: poly_rows_launch<V>(ctx, R, d_x, d_y, tiles, m_stop); break;
-                    FA_ROWS_CASE(4) FA_ROWS_CASE(6) FA_ROWS_CASE(8) FA_ROWS_CASE(10) FA_ROWS_CASE(12) FA_ROWS_CASE(14) FA_ROWS_CASE(16)
+                    FA_ROWS_CASE(4) FA_ROWS_CASE(6) FA_ROWS_CASE(8) FA_ROWS_CASE(10) FA_ROWS_CASE(12) FA_ROWS_CASE(14) FA_ROWS_CASE(16) FA_ROWS_CASE(32)
 #undef FA_ROWS_CASE
                     default: tiles = 0; break;
                 }

@@ -14,27 +14,28 @@ struct PolyRowsGeom {
     int32_t groups, ppg;            // phase groups per tile, phases per group (a multiple of 4)
     int32_t sld;                    // LDS row stride in floats (4 x odd)
     int32_t smax;                   // last staged offset + 1 within a row over all phases (for the tile-count bound)
+    int32_t share;                  // consecutive phases that read ONE register window (1, 2 or 4; round 5)
 };
 constexpr int kRowsThreads = 512, kRowsWaves = kRowsThreads / 64;
-constexpr int kRowsOffLane = 62;   // lane of a phase's table row that carries its (aligned) window offset; taps: lanes 0 .. 61
+constexpr int kRowsOffLane = 128;  // window positions a table row can carry taps for: 0 .. 63 = one window of 16 x 16-byte reads (four table registers of 16
+                                   // taps), 64 .. 127 = a second window right behind it for phases of more than 64 taps (88.2 -> 16 kHz: 116 taps per phase)
+constexpr int kRowsOffPos = 128;   // position of a table row that carries the aligned window offset
+constexpr int kRowsTT = 144;       // floats per table row (a multiple of 16: the 64-byte table pieces stay aligned)
 
 // poly_rows_kernel: tables of one rate pair.  h = the FIR of fa_resample_poly_taps (leading zero taps included), gtab = {first staged offset,
-// staged span} per phase group, tt = 64 floats per phase (taps shifted by the window's misalignment, zeros around them; lane 62: the aligned
-// window offset).  nv = 16-byte reads per window.  false: the pair does not suit the kernel.
+// staged span} per phase group, tt = kRowsTT floats per phase, nv = 16-byte reads per register window.
+// Round 5: `share` consecutive phases (aligned to `share` within a group) read ONE window of 4 nv floats from the lane's LDS row: their input windows
+// overlap almost completely (consecutive phases start down / up = 2.76 samples apart at 44.1 -> 16 kHz and hold 56 taps), so the round-4 form —
+// every phase its own 16 x 16-byte LDS reads — read each staged sample ~20 times and was LDS-bandwidth bound next to its arithmetic.  tt[ph][i] =
+// the tap that multiplies window position i of the phase's SHARED window (zeros in front and behind: the shift of the phase inside the window
+// is absorbed by the table, so every multiply-add has compile-time register indices); tt[ph][128] = the window's first staged offset (a
+// multiple of 4, the same for the phases that share it).  false: the pair does not suit the kernel.
 inline bool rows_geometry(PolyRowsGeom &g, int &nv_out, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt,
-                          size_t lds_budget = 0) {
+                          size_t lds_budget = 0, int share_max = 4) {
     const int64_t h_len = static_cast<int64_t>(h.size());
     if (up < 8 || up > 4096 || down > 8192) return false;               // few phases: the register-tiled kernels; huge ones: tables too large
     const int q1 = static_cast<int>((h_len + up - 1) / up);             // a window holds floor(h_len / up) or that + 1 taps
-    if (q1 + 3 > kRowsOffLane) return false;                            // shifted taps of a phase + its offset share one 64-lane table row
-    int nv = (q1 + 3 + 3) / 4;                                          // 4 nv >= misalignment (<= 3) + taps
-    {   // instantiated sizes (poly_rows_launch); a larger one only reads a little further into the row
-        static const int sizes[] = {4, 6, 8, 10, 12, 14, 16};
-        int pick = 0;
-        for (int v : sizes) if (v >= nv) { pick = v; break; }
-        if (!pick) return false;
-        nv = pick;
-    }
+    if (q1 + 3 > kRowsOffLane) return false;                            // the shifted taps of a phase must fit the 128 positions of a table row
     // first output whose window lies inside the signal: p - (h_len - 1) >= 0; rounded up to a multiple of 4 (16-byte output pieces)
     int64_t m_begin = (h_len - 1 + down - 1) / down - pre_remove;
     if (m_begin < 0) m_begin = 0;
@@ -42,33 +43,50 @@ inline bool rows_geometry(PolyRowsGeom &g, int &nv_out, const std::vector<float>
     const int64_t p0 = (m_begin + pre_remove) * down;
     const int64_t k_begin = (p0 - (h_len - 1) + up - 1) / up;           // k_lo of the first output
     std::vector<int> off(up), cnt(up);
-    tt.assign(static_cast<size_t>(up) * 64, 0.0f);
-    int smax = 0;
     for (int ph = 0; ph < up; ++ph) {
         const int64_t p = p0 + static_cast<int64_t>(ph) * down;
         const int64_t k_hi = p / up, k_lo = (p - (h_len - 1) + up - 1) / up;   // p - (h_len - 1) >= 0 here
         cnt[ph] = static_cast<int>(k_hi - k_lo + 1);
         off[ph] = static_cast<int>(k_lo - k_begin);
-        const int a = off[ph] & 3, off4 = off[ph] - a;
-        if (cnt[ph] < 1 || a + cnt[ph] > std::min(4 * nv, kRowsOffLane)) return false;
-        float *rowp = tt.data() + static_cast<size_t>(ph) * 64;
-        for (int j = 0; j < cnt[ph]; ++j) rowp[a + j] = h[static_cast<size_t>(p - (k_lo + j) * up)];
-        memcpy(rowp + kRowsOffLane, &off4, sizeof(int));
-        smax = std::max(smax, off4 + 4 * nv);
+        if (cnt[ph] < 1) return false;
     }
+    static const int sizes[] = {4, 6, 8, 10, 12, 14, 16};               // instantiated window sizes (poly_rows_launch); a larger one only reads a little further into the row
+    // the reach of a shared window: phases q .. q + share - 1 (q a multiple of `share`; groups start at multiples of 4) measured from off[q] & ~3
+    auto reach_of = [&](const int share) {
+        int reach = 0;
+        for (int q = 0; q < up; q += share) {
+            const int base4 = off[q] & ~3;
+            for (int u = 0; u < share && q + u < up; ++u) reach = std::max(reach, off[q + u] - base4 + cnt[q + u]);
+        }
+        return reach;
+    };
+    int share = 1, nv = 0;
+    for (int c : {4, 2, 1}) {
+        if (c > share_max) continue;
+        const int reach = reach_of(c);
+        if (reach > kRowsOffLane) continue;
+        int pick = 0;
+        for (int v : sizes) if (4 * v >= reach) { pick = v; break; }
+        if (!pick && c == 1 && reach <= 128) pick = 32;                 // more than 64 taps per phase: two windows of 16 reads, one behind the other (no sharing)
+        if (!pick) continue;
+        share = c; nv = pick;
+        break;
+    }
+    if (!nv) return false;
     // phase groups (a multiple of 4 phases each): the rows of a group within the LDS budget; rows are `sld` floats apart, sld = 4 x odd >= the longest
-    // staged span of a group.  Budget (0 = automatic): short windows (<= 8 reads per window: the kernel needs 56 VGPRs, 8 wavefronts per SIMD fit) get
-    // 38 KB = three to four workgroups per CU staging and computing side by side (22.05 kHz: -4 %); long windows (16 reads: 84 VGPRs, 5 wavefronts per
-    // SIMD) gain nothing from more, smaller workgroups and keep 74 KB = two per CU (profiles/r04_rows_lds_probe.json, r04_rows_lds_ab.json)
+    // staged span of a group.  Budget (0 = automatic): short windows (<= 8 reads per window) get 38 KB = three to four workgroups per CU staging and
+    // computing side by side; long windows keep 74 KB = two per CU (profiles/r04_rows_lds_probe.json, r04_rows_lds_ab.json)
     if (lds_budget == 0) lds_budget = nv <= 8 ? 38 * 1024 : 74 * 1024;
+    auto span_of = [&](const int a0, const int a1) {     // staged span of the phases [a0, a1): from the first window's start to the end of the last window read
+        int hi = 0;
+        for (int q = a0; q < a1; q += share) hi = std::max(hi, (off[q] & ~3) + 4 * nv);
+        return hi - (off[a0] & ~3);
+    };
     int groups = 1, ppg = up, sld = 0;
     for (;; ++groups) {
         ppg = ((up + groups - 1) / groups + 3) & ~3;
         int span = 0;
-        for (int a0 = 0; a0 < up; a0 += ppg) {
-            const int a1 = std::min(up, a0 + ppg);
-            span = std::max(span, (off[a1 - 1] & ~3) + 4 * nv - (off[a0] & ~3));
-        }
+        for (int a0 = 0; a0 < up; a0 += ppg) span = std::max(span, span_of(a0, std::min(up, a0 + ppg)));
         sld = (span + 3) / 4;
         if (sld % 2 == 0) ++sld;
         sld *= 4;
@@ -77,12 +95,24 @@ inline bool rows_geometry(PolyRowsGeom &g, int &nv_out, const std::vector<float>
     groups = (up + ppg - 1) / ppg;
     if (static_cast<size_t>(sld) * 64 * sizeof(float) > 150 * 1024 || sld > 64 * 10) return false;
     gtab.assign(2 * static_cast<size_t>(groups), 0);
+    int smax = 0;
     for (int gq = 0; gq < groups; ++gq) {
         const int a0 = gq * ppg, a1 = std::min(up, a0 + ppg);
         gtab[2 * gq] = off[a0] & ~3;
-        gtab[2 * gq + 1] = (off[a1 - 1] & ~3) + 4 * nv - (off[a0] & ~3);
+        gtab[2 * gq + 1] = span_of(a0, a1);
+        smax = std::max(smax, gtab[2 * gq] + gtab[2 * gq + 1]);
     }
-    g.m_begin = m_begin; g.k_begin = k_begin; g.up = up; g.down = down; g.groups = groups; g.ppg = ppg; g.sld = sld; g.smax = smax;
+    tt.assign(static_cast<size_t>(up) * kRowsTT, 0.0f);
+    for (int ph = 0; ph < up; ++ph) {
+        const int q = ph - ph % share;                                  // (groups start at multiples of 4: a shared window never straddles two groups)
+        const int base4 = off[q] & ~3, a = off[ph] - base4;
+        const int64_t p = p0 + static_cast<int64_t>(ph) * down;
+        const int64_t k_lo = k_begin + off[ph];
+        float *rowp = tt.data() + static_cast<size_t>(ph) * kRowsTT;
+        for (int j = 0; j < cnt[ph]; ++j) rowp[a + j] = h[static_cast<size_t>(p - (k_lo + j) * up)];
+        memcpy(rowp + kRowsOffPos, &base4, sizeof(int));
+    }
+    g.m_begin = m_begin; g.k_begin = k_begin; g.up = up; g.down = down; g.groups = groups; g.ppg = ppg; g.sld = sld; g.smax = smax; g.share = share;
     nv_out = nv;
     return true;
 }

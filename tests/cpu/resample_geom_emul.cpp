@@ -25,18 +25,19 @@ void poly_simple(const float *x, int64_t n_in, const float *h, int64_t h_len, in
 }
 
 // returns 0 and the covered range, or a negative code: -1 pair not served, -2 staged index out of the signal, -3 window read outside the staged
-// span, -4 an output written twice / outside [m_begin, m_stop), -5 an output of the range not written, -6 misaligned window read
+// span, -4 an output written twice / outside [m_begin, m_stop), -5 an output of the range not written, -6 misaligned window read,
+// -7 the phases of a shared window disagree about it, -8 a tap at a window position the kernel does not multiply
 int rows_emulate(const float *x, int64_t n_in, const float *h, int64_t h_len, int up, int down, int64_t pre_remove, int64_t n_out, float *y, int64_t *m_lo, int64_t *m_hi,
-                 int32_t *info /* nv, groups, ppg, sld, tiles */) {
+                 int32_t *info /* nv, groups, ppg, sld, tiles, share */, int share_max) {
     fa::PolyRowsGeom g{};
     int nv = 0;
     std::vector<int> gtab;
     std::vector<float> tt;
     std::vector<float> hv(h, h + h_len);
     *m_lo = *m_hi = 0;
-    if (!fa::rows_geometry(g, nv, hv, up, down, pre_remove, gtab, tt)) return -1;
+    if (!fa::rows_geometry(g, nv, hv, up, down, pre_remove, gtab, tt, 0, share_max)) return -1;
     const int64_t tiles = fa::rows_tiles(g, n_in, n_out);
-    info[0] = nv; info[1] = g.groups; info[2] = g.ppg; info[3] = g.sld; info[4] = static_cast<int32_t>(tiles);
+    info[0] = nv; info[1] = g.groups; info[2] = g.ppg; info[3] = g.sld; info[4] = static_cast<int32_t>(tiles); info[5] = g.share;
     if (tiles <= 0) return 0;
     const int64_t m_stop = std::min<int64_t>(n_out, g.m_begin + tiles * 64 * static_cast<int64_t>(g.up));
     std::vector<char> written(static_cast<size_t>(m_stop - g.m_begin), 0);
@@ -58,10 +59,16 @@ int rows_emulate(const float *x, int64_t n_in, const float *h, int64_t h_len, in
                     staged[static_cast<size_t>(l) * g.sld + sidx] = 1;
                 }
             for (int ph = ph0; ph < ph1; ++ph) {
-                const float *row = tt.data() + static_cast<size_t>(ph) * 64;
-                int off4;
-                memcpy(&off4, row + fa::kRowsOffLane, sizeof(int));
+                const float *row = tt.data() + static_cast<size_t>(ph) * fa::kRowsTT;
+                // the phase reads the window of its share-aligned sub-chunk (the kernel fetches the offset from the sub-chunk's FIRST phase)
+                const int qph = ph0 + (ph - ph0) / g.share * g.share;
+                if (qph % g.share != 0) return -7;                          // groups start at multiples of 4 >= share: local and global alignment agree
+                int off4, off4_own;
+                memcpy(&off4, tt.data() + static_cast<size_t>(qph) * fa::kRowsTT + fa::kRowsOffPos, sizeof(int));
+                memcpy(&off4_own, row + fa::kRowsOffPos, sizeof(int));
+                if (off4 != off4_own) return -7;                            // every phase of a shared window carries the same offset
                 if (off4 & 3) return -6;
+                for (int j = NT; j < fa::kRowsOffPos; ++j) if (row[j] != 0.0f) return -8;   // no tap beyond the positions the kernel multiplies
                 for (int l = 0; l < 64; ++l) {
                     const int base = l * g.sld + (off4 - smin);
                     if (off4 - smin < 0 || off4 - smin + 4 * nv > g.sld) return -3;

@@ -37,10 +37,10 @@ def test_polyphase_extension_vs_scipy(fa, gpu_ctx, up, down, n):
 
 
 @pytest.mark.parametrize("up,down,n", [(1, 3, 250001), (160, 441, 132300), (2, 1, 40000), (640, 441, 33075), (1, 6, 96000), (1, 1, 5000), (3, 2, 5), (160, 147, 14700),
-                                       (1, 2, 100003), (1, 4, 64000), (1, 5, 80007), (1, 3, 62), (1, 3, 63), (1, 3, 64), (1, 3, 130), (1, 3, 1000), (1, 2, 45), (1, 5, 200),
+                                       (1, 2, 100003), (1, 4, 64000), (1, 5, 80007), (1, 6, 300007), (1, 6, 96000), (1, 6, 700), (1, 6, 130), (1, 4, 1000003), (1, 5, 500000), (1, 3, 62), (1, 3, 63), (1, 3, 64), (1, 3, 130), (1, 3, 1000), (1, 2, 45), (1, 5, 200),
                                        # the row-tiled kernel of non-integer ratios (round 4): several tiles, the last one partial, signals too short for a tile
                                        (160, 441, 1000003), (160, 441, 40000), (160, 441, 37000), (320, 441, 300007), (640, 441, 150000), (80, 441, 500000),
-                                       (160, 147, 200000), (16, 15, 90000), (8, 7, 50000), (147, 160, 120000),
+                                       (160, 147, 200000), (16, 15, 90000), (8, 7, 50000), (147, 160, 120000), (80, 441, 2000003), (80, 441, 60000), (40, 441, 900000),
                                        # the register-tiled kernel of small interpolation factors (8 / 12 / 24 / 4 / 5.33 / 10.67 kHz -> 16 kHz)
                                        (2, 1, 1000003), (2, 1, 100), (2, 1, 57), (2, 3, 240000), (2, 3, 130), (4, 3, 120001), (4, 1, 40000), (3, 1, 53333), (3, 2, 106667),
                                        (4, 3, 64), (3, 2, 40)])
@@ -91,3 +91,37 @@ def test_rows_kernel_actually_serves_the_common_non_integer_pairs(fa, gpu_ctx, m
         monkeypatch.delenv("FA_RESAMPLE_NO_ROWS")
         assert torch.equal(y, y2)
         assert t_rows < 0.85 * t_lds, (up, down, t_rows, t_lds)
+
+
+@pytest.mark.parametrize("up,down", [(160, 441), (320, 441)])
+def test_rows_kernel_on_non_finite_input(fa, gpu_ctx, monkeypatch, up, down):
+    """The row-tiled kernel multiplies a register window by a table row whose unused positions hold ZERO taps (the shift of a phase inside its —
+    since round 5 shared — window is absorbed by the table).  On finite input that adds +-0 and changes no bit.  An Inf / NaN sample times a zero
+    tap is NaN: it reaches every output whose padded window covers it, a few samples more on either side than the true FIR support (where the
+    one-output-at-a-time kernel, which skips taps, stays finite).  This is the documented behaviour: outside that neighbourhood the outputs
+    equal the simple kernel's bit for bit, inside it they are non-finite in both or only in the row-tiled kernel — never finite-but-different."""
+    n = 400000
+    rng = np.random.default_rng(up)
+    x = (0.1 * rng.standard_normal(n)).astype(np.float32)
+    x[n // 2] = np.inf
+    x[n // 2 + 50000] = np.nan
+    got = fa.resample_poly(x, up, down, ctx=gpu_ctx)
+    monkeypatch.setenv("FA_RESAMPLE_SIMPLE", "1")
+    ref = fa.resample_poly(x, up, down, ctx=gpu_ctx)
+    monkeypatch.delenv("FA_RESAMPLE_SIMPLE")
+    bad_ref, bad_got = ~np.isfinite(ref), ~np.isfinite(got)
+    assert bad_ref.sum() > 0 and (bad_got | ~bad_ref).all()                 # wherever the simple kernel is non-finite, so is the row-tiled one
+    both_ok = ~bad_got
+    np.testing.assert_array_equal(got[both_ok], ref[both_ok])             # never finite-but-different
+    extra = bad_got & ~bad_ref
+    taps, _ = fa.poly_taps(up, down)
+    support = (taps.size + down - 1) // down + 2                          # outputs one input sample can reach through the FIR
+    for centre in (n // 2, n // 2 + 50000):
+        m = centre * up // down
+        idx = np.nonzero(extra[max(0, m - 4 * support):m + 4 * support])[0]
+        assert idx.size <= 16 * (up // 160 + 1) + 64                      # the padding widens the neighbourhood by a few outputs per phase, not more
+    far = np.ones(got.size, bool)
+    for centre in (n // 2, n // 2 + 50000):
+        m = centre * up // down
+        far[max(0, m - 2 * support):m + 2 * support] = False
+    assert np.isfinite(got[far]).all()

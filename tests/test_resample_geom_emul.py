@@ -20,7 +20,7 @@ def emul():
     f32p, i64 = np.ctypeslib.ndpointer(np.float32, flags="C"), C.c_int64
     L.poly_simple.argtypes = [f32p, i64, f32p, i64, C.c_int, C.c_int, i64, f32p, i64, i64]
     L.poly_simple.restype = None
-    L.rows_emulate.argtypes = [f32p, i64, f32p, i64, C.c_int, C.c_int, i64, i64, f32p, C.POINTER(i64), C.POINTER(i64), np.ctypeslib.ndpointer(np.int32, flags="C")]
+    L.rows_emulate.argtypes = [f32p, i64, f32p, i64, C.c_int, C.c_int, i64, i64, f32p, C.POINTER(i64), C.POINTER(i64), np.ctypeslib.ndpointer(np.int32, flags="C"), C.c_int]
     L.interp_emulate.argtypes = [f32p, i64, f32p, C.c_int, C.c_int, C.c_int, i64, i64, f32p, C.POINTER(i64), C.POINTER(i64)]
     return L
 
@@ -32,24 +32,31 @@ def signal_of(n, seed):
 
 @pytest.mark.parametrize("up,down,n", [(160, 441, 132300), (160, 441, 40000), (160, 441, 37000), (160, 441, 28223), (320, 441, 90007), (640, 441, 60000), (160, 147, 70000),
                                        (16, 15, 9000), (8, 7, 3000), (147, 160, 50000), (80, 441, 100000), (12, 5, 4000), (9, 8, 1000), (441, 160, 30000)])
-def test_rows_kernel_indexing_on_the_library_geometry(fa, emul, up, down, n):
+@pytest.mark.parametrize("share_max", [4, 2, 1])
+def test_rows_kernel_indexing_on_the_library_geometry(fa, emul, up, down, n, share_max):
+    """share_max: the most consecutive phases that may read one register window (round 5; 1 = every phase its own window, the round-4 reads)."""
     from scipy import signal
     taps, pre = fa.poly_taps(up, down)
     x = signal_of(n, n)
     n_out = fa.lib().fa_resample_poly_frames(n, up, down)
     y = np.full(n_out, np.nan, np.float32)
     lo, hi = C.c_int64(), C.c_int64()
-    info = np.zeros(5, np.int32)
-    rc = emul.rows_emulate(x, n, taps, taps.size, up, down, pre, n_out, y, C.byref(lo), C.byref(hi), info)
+    info = np.zeros(6, np.int32)
+    rc = emul.rows_emulate(x, n, taps, taps.size, up, down, pre, n_out, y, C.byref(lo), C.byref(hi), info, share_max)
     assert rc in (0, -1), (rc, info.tolist())
     if rc == -1:
-        assert (taps.size + up - 1) // up + 3 > 62 or up < 8, "only pairs whose phase does not fit a table row may be refused"
+        assert (taps.size + up - 1) // up + 3 > 128 or up < 8, "only pairs whose phase does not fit a table row may be refused"
         return
     ref = np.zeros(n_out, np.float32)
     emul.poly_simple(x, n, taps, taps.size, up, down, pre, ref, 0, n_out)
     np.testing.assert_allclose(ref, signal.resample_poly(x.astype(np.float64), up, down, window=("kaiser", 5.0)), rtol=0, atol=2e-5)
     if hi.value > lo.value:
         assert lo.value % 4 == 0 and info[2] % 4 == 0 and (info[3] // 4) % 2 == 1 and info[3] * 256 <= 150 * 1024
+        assert info[5] in (1, 2, 4) and info[5] <= share_max
+        if (up, down) == (160, 441):
+            assert (info[5], info[0]) == (min(share_max, 2), 16)             # 44.1 kHz: two phases share the 16 reads one phase needed
+        if (up, down) == (320, 441) and share_max == 4:
+            assert info[5] == 4 and info[0] <= 10                            # 22.05 kHz: four phases share <= 10 reads (8 each before)
         np.testing.assert_array_equal(y[lo.value:hi.value], ref[lo.value:hi.value])
         assert np.isnan(y[:lo.value]).all() and np.isnan(y[hi.value:]).all()      # the edges belong to poly_kernel
         assert hi.value - lo.value > 0.5 * n_out or n < 64 * down * 3              # long signals are mostly served by the tiles
