@@ -2465,6 +2465,18 @@ int uniform_kernel_choice(size_t blocks_total) {
     return 2;
 }
 
+// slots per thread of the round that serves a uniform batch of `count` problems of up to Nmax points (the measurements: ahc_batch_uniform)
+int uniform_cpt(int count, size_t Nmax) {
+    const size_t wgs1 = static_cast<size_t>(count) * ((Nmax + kBlk - 1) / kBlk);
+    return wgs1 >= 600 && Nmax >= 1024 ? 2 : 1;
+}
+// bytes of ONE problem's slot in the uniform layout of such a batch
+size_t uniform_stride(int count, size_t Nmax, size_t d) {
+    const int cpt = uniform_cpt(count, Nmax);
+    const size_t cols = static_cast<size_t>(kBlk) * cpt, Np = (Nmax + cols - 1) / cols * cols;
+    return (make_layout(Nmax, Np, d, Np / cols).total + 4095) & ~static_cast<size_t>(4095);
+}
+
 fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data, const size_t *n, size_t d, double *const *d_Z, int mode,
                             fa_ahc_stats *stats, fa_status *statuses, bool *completed) {
     *completed = false;
@@ -2479,8 +2491,7 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
     // Measured (profiles/r05_cpt_probe_v2.json, us per round of 43 200-point problems, one batch): K = 2: 5.80 / 5.93 / 6.83 with 1 / 2 / 4 slots per thread,
     // K = 4: 6.89 / 6.66 / 7.15, K = 8: 10.83 / 7.93 / 8.49, K = 12: 13.41 / 10.00 / 9.80; two batches side by side, K = 8: 8.82 / 7.59 / 8.12, K = 12: 11.17 /
     // 8.18 / 8.90; 16 x 5 400: 6.74 / 6.88 / 7.90.  Two slots per thread pay once a launch holds more than ~2 workgroups per CU at one slot per thread.
-    const size_t wgs1 = static_cast<size_t>(count) * ((Nmax + kBlk - 1) / kBlk);
-    const int cpt = env_cpt ? env_cpt : (wgs1 >= 600 && Nmax >= 1024 ? 2 : 1);
+    const int cpt = env_cpt ? env_cpt : uniform_cpt(count, Nmax);
     const size_t cols = static_cast<size_t>(kBlk) * cpt, Npmax = (Nmax + cols - 1) / cols * cols, nblk = Npmax / cols;
     FA_TRY(prob_check_shape(ctx, Nmax, d));
     const Layout L = make_layout(Nmax, Npmax, d, nblk);
@@ -2739,6 +2750,38 @@ fa_status run_device_batch_impl(fa_ctx *ctx, int count, const double *const *d_d
     if (count <= 0) return FA_SUCCESS;
     std::vector<fa_status> local(static_cast<size_t>(count), FA_SUCCESS);
     fa_status *sts = statuses ? statuses : local.data();
+    if (count > 1 && mode != FA_AHC_MODE_REFERENCE_ORDER) {
+        // A problem the matrix-based rounds cannot hold (more points than block records: N > 196 608) runs alone through the single-problem entry,
+        // which takes the matrix-free route (fluidaudio_hip.h promises that; inside a batch such a problem used to be marked ALLOCATION_FAILURE and the
+        // clustering stage degraded its recording to singletons).  The others stay a batch.
+        std::vector<int> small;
+        bool any_big = false;
+        for (int k = 0; k < count; ++k) {
+            const bool fits = (n[k] + kBlk - 1) / kBlk <= static_cast<size_t>(kMaxBlocks);
+            if (fits || n[k] < 2) small.push_back(k); else any_big = true;
+        }
+        if (any_big) {
+            fa_status worst = FA_SUCCESS;
+            for (int k = 0; k < count; ++k) {
+                if ((n[k] + kBlk - 1) / kBlk <= static_cast<size_t>(kMaxBlocks) || n[k] < 2) continue;
+                sts[k] = fa::ahc_run_device(ctx, d_data[k], n[k], d, d_Z[k], mode, stats ? &stats[k] : nullptr, false);
+                if (sts[k] != FA_SUCCESS && worst == FA_SUCCESS) worst = sts[k];
+            }
+            if (!small.empty()) {
+                const int m = static_cast<int>(small.size());
+                std::vector<const double *> dd(m);
+                std::vector<size_t> nn(m);
+                std::vector<double *> zz(m);
+                std::vector<fa_ahc_stats> ss(m);
+                std::vector<fa_status> st2(m, FA_SUCCESS);
+                for (int j = 0; j < m; ++j) { dd[j] = d_data[small[j]]; nn[j] = n[small[j]]; zz[j] = d_Z[small[j]]; }
+                const fa_status r = run_device_batch_impl(ctx, m, dd.data(), nn.data(), d, zz.data(), mode, stats ? ss.data() : nullptr, st2.data(), allow_groups);
+                for (int j = 0; j < m; ++j) { sts[small[j]] = st2[j]; if (stats) stats[small[j]] = ss[j]; }
+                if (r != FA_SUCCESS && worst == FA_SUCCESS) worst = r;
+            }
+            return worst;
+        }
+    }
     if (allow_groups && uniform_eligible(count, n, mode) && ctx->ws_cap == static_cast<size_t>(-1)) {   // a capped context keeps its promise: ONE workspace within the cap
         const int groups = uniform_groups(count, n);
         if (groups > 1) return ahc_batch_uniform_groups(ctx, groups, count, d_data, n, d, d_Z, mode, stats, sts);
@@ -2923,11 +2966,34 @@ fa_status fa_ctx_reserve(fa_ctx *ctx, size_t n_max, size_t d, int32_t recordings
     return fa::no_throw(ctx, "fa_ctx_reserve", [&]() -> fa_status {
         fa::DeviceGuard guard(ctx->device);
         FA_TRY(prob_check_shape(ctx, n_max, d));
-        const size_t Np = (n_max + kBlk - 1) / kBlk * kBlk;
-        const Layout L = make_layout(n_max, Np, d, Np / kBlk);
-        const size_t stride = (L.total + 4095) & ~static_cast<size_t>(4095);
-        fa::WsUse use(ctx);
-        return fa::ws_acquire(ctx, recordings > 1 ? stride * static_cast<size_t>(recordings) : L.total);
+        if (recordings == 1) {
+            const size_t Np = (n_max + kBlk - 1) / kBlk * kBlk;
+            fa::WsUse use(ctx);
+            return fa::ws_acquire(ctx, make_layout(n_max, Np, d, Np / kBlk).total);
+        }
+        // The reservation follows the dispatch of a batch of `recordings` problems of n_max points (run_device_batch_impl): six or more long recordings
+        // run as two uniform batches side by side, the second on a helper context with a workspace of its OWN — reserved here as well, so that the
+        // first request pays no hipMalloc on either (until round 5 everything was reserved on the caller's context: the helper still allocated inside
+        // the first request, and the two together held ~1.5 x the need).  The slot size is that of the round kernel the batch will run with.
+        std::vector<size_t> n(static_cast<size_t>(recordings), n_max);
+        const bool capped = ctx->ws_cap != static_cast<size_t>(-1);
+        int groups = !capped && uniform_eligible(recordings, n.data(), FA_AHC_MODE_AUTO) ? uniform_groups(recordings, n.data()) : 1;
+        for (int g = 1; g < groups; ++g) {
+            fa_ctx *&h = ctx->helpers[g - 1];
+            if (!h) {
+                if (fa_ctx_create(ctx->device, nullptr, &h) != FA_SUCCESS) { h = nullptr; groups = g; break; }
+                h->ws_limit = ctx->ws_limit;
+                h->ws_cap = ctx->ws_cap;
+            }
+        }
+        for (int g = 0; g < groups; ++g) {
+            const int m = static_cast<int>(static_cast<long long>(recordings) * (g + 1) / groups - static_cast<long long>(recordings) * g / groups);
+            fa_ctx *c = g == 0 ? ctx : ctx->helpers[g - 1];
+            fa::WsUse use(c);
+            const fa_status st = fa::ws_acquire(c, uniform_stride(m, n_max, d) * static_cast<size_t>(m));
+            if (st != FA_SUCCESS) { if (c != ctx) ctx->last_error = c->last_error; return st; }
+        }
+        return FA_SUCCESS;
     });
 }
 

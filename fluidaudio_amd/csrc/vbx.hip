@@ -46,6 +46,7 @@ struct VbxWs {
     int32_t D, S;
     int32_t z_lo, z_n; // slices owned
     double Fa, Fb;
+    int32_t tiled;     // host side: the tiled products serve S >= kVbxTiledMinS (FA_VBX_NO_TILED, read ONCE per refinement when the workspace is set up)
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -451,6 +452,7 @@ fa_status vbx_setup(fa_ctx *ctx, const double *d_X, int64_t T, int64_t Tg, int64
     w.rec_in = o.part.as<double>(); w.rec_out = o.part.as<double>() + static_cast<int64_t>(z_lo) * stride;
     w.alpha = o.alpha.as<double>(); w.invL = o.invL.as<double>(); w.phiT = o.phiT.as<double>(); w.llrow = o.ll.as<double>();
     w.scal = o.scal.as<double>(); w.T = T; w.Tg = Tg; w.t0g = t0g; w.stride = stride; w.D = D; w.S = S; w.z_lo = z_lo; w.z_n = z_n; w.Fa = Fa; w.Fb = Fb;
+    w.tiled = getenv("FA_VBX_NO_TILED") == nullptr ? 1 : 0;   // once per refinement: not inside the iteration (several host threads run refinements at once)
     if (static_cast<size_t>(8) * 4 * D > 64 * 1024) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "vbx: feature dimension too large");
     if (T > 0) {
         const int wave_blocks = static_cast<int>((T + 3) / 4);
@@ -466,7 +468,7 @@ fa_status vbx_setup(fa_ctx *ctx, const double *d_X, int64_t T, int64_t Tg, int64
 // the records of the owned slices from the present posteriors (and the present per-frame log-likelihoods)
 fa_status vbx_records(fa_ctx *ctx, const VbxWs &w) {
     if (w.z_n <= 0) return FA_SUCCESS;
-    if (w.S >= kVbxTiledMinS && getenv("FA_VBX_NO_TILED") == nullptr)
+    if (w.S >= kVbxTiledMinS && w.tiled)
         hipLaunchKernelGGL(vbx_gt_rho_tiled, dim3((w.D + 1 + kVT - 1) / kVT, (w.S + kVT - 1) / kVT, w.z_n), dim3(kThreads), 0, ctx->stream, w);
     else
         hipLaunchKernelGGL(vbx_gt_rho, dim3((w.D + 1 + 63) / 64, (w.S + 3) / 4, w.z_n), dim3(kThreads), 0, ctx->stream, w);
@@ -479,7 +481,7 @@ fa_status vbx_estep_phase(fa_ctx *ctx, const VbxWs &w) {
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(vbx_speaker, dim3(w.S), dim3(kThreads), 0, st, w, 0);
     hipLaunchKernelGGL(vbx_logpi, dim3((w.S + 255) / 256), dim3(256), 0, st, w);
-    if (w.T > 0 && w.S >= kVbxTiledMinS && getenv("FA_VBX_NO_TILED") == nullptr) {
+    if (w.T > 0 && w.S >= kVbxTiledMinS && w.tiled) {
         hipLaunchKernelGGL(vbx_logits_tiled, dim3((w.S + kVT - 1) / kVT, static_cast<unsigned>((w.T + kVT - 1) / kVT)), dim3(kThreads), 0, st, w);
         hipLaunchKernelGGL(vbx_softmax_rows, dim3(static_cast<int>((w.T + 3) / 4)), dim3(kThreads), 0, st, w);
     } else if (w.T > 0)

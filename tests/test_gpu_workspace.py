@@ -67,6 +67,35 @@ def test_n_beyond_any_matrix_equals_the_reference_digest(fa):
     assert ctx.workspace_bytes() < (1 << 28)              # O(N d): 2 N x 4 centroids, the transpose, heap and list arrays
 
 
+def test_problem_beyond_the_block_records_inside_a_batch(fa, oracle_mod):
+    """A batch that contains a problem of more points than the matrix-based rounds have block records for (N > 196 608): that problem runs alone in
+    the matrix-free mode — its dendrogram is the reference build's by digest —, the others stay a batch.  (Until round 5 it was marked
+    ALLOCATION_FAILURE inside a batch of two or more and fa_offline_cluster_batch degraded that recording to singletons.)"""
+    import json
+    import os
+    import sys
+    gold_dir = os.path.join(os.path.dirname(__file__), "golden")
+    sys.path.insert(0, gold_dir)
+    from ahc_full_inputs import ahc_input, dendrogram_digest, sha256
+    jp = os.path.join(gold_dir, "ahc_mf_iid_200000x4.json")
+    if not os.path.exists(jp):
+        pytest.skip("ahc_mf_iid_200000x4.json not committed")
+    with open(jp) as f:
+        gold = json.load(f)
+    big = ahc_input("iid", gold["n"], gold["d"])
+    assert sha256(big) == gold["input_sha256"]
+    rng = np.random.default_rng(9)
+    small = [rng.standard_normal((n, gold["d"])) for n in (700, 1, 900)]
+    ctx = fa.Context(0)
+    st, zs, stats = fa.linkage_batch([small[0], big, small[1], small[2]], ctx=ctx, return_stats=True)
+    assert st == [0, 0, 0, 0], (st, ctx.last_error())
+    assert stats[1]["reference_order"] == 2 and stats[1]["merges"] == gold["n"] - 1 and stats[0]["reference_order"] == 0
+    assert dendrogram_digest(zs[1])["dendrogram_sha256"] == gold["dendrogram_sha256"]
+    for k, j in ((0, 0), (2, 3)):
+        np.testing.assert_array_equal(zs[j], oracle_mod.linkage_ref(small[k])[1])
+    ctx.close()
+
+
 def test_batch_statuses_under_memory_pressure(fa, oracle_mod):
     """The combined workspace of a batch exceeds what the context may take: the batch is split until the parts fit (every dendrogram =
     the reference's); when not even one problem fits, EVERY problem reports ALLOCATION_FAILURE (round 2: SUCCESS + garbage) and the
@@ -184,6 +213,16 @@ def test_reserve_takes_the_workspace_before_the_first_request(fa, oracle_mod):
     st, zs = fa.linkage_batch([x, x[:2900], x[:2800]], ctx=ctx)
     assert st == [0, 0, 0] and 0 <= ctx.workspace_bytes() - held3 <= 3 * x.nbytes + 4096
     np.testing.assert_array_equal(zs[0], zr)
+    ctx.trim()
+    # a batch large enough for two uniform batches side by side (eight recordings of >= 4 096 points): the reservation follows that dispatch — the
+    # helper context's workspace is taken now as well, and the first request allocates nothing on either context (round 5)
+    probs = [speaker_mixture(4300 - 20 * k, 32, 6, 0.04, 40 + k) for k in range(8)]
+    ctx.reserve(4300, 32, recordings=8)
+    held8 = ctx.workspace_bytes()                          # the caller's context + its helper
+    assert 8 * ws_need(4300) <= held8 <= int(1.1 * 8 * ws_need(4352)) + (1 << 24)
+    st, zs = fa.linkage_batch(probs, ctx=ctx)
+    assert st == [0] * 8 and 0 <= ctx.workspace_bytes() - held8 <= sum(p.nbytes for p in probs) + 65536
+    np.testing.assert_array_equal(zs[3], oracle_mod.linkage_ref(probs[3])[1])
     ctx.trim()
     ctx.set_workspace_cap(ws_need(3000) // 2)
     with pytest.raises(fa.FluidAudioHipError):
