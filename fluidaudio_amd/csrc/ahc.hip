@@ -2468,7 +2468,7 @@ int uniform_kernel_choice(size_t blocks_total) {
 // slots per thread of the round that serves a uniform batch of `count` problems of up to Nmax points (the measurements: ahc_batch_uniform)
 int uniform_cpt(int count, size_t Nmax) {
     const size_t wgs1 = static_cast<size_t>(count) * ((Nmax + kBlk - 1) / kBlk);
-    return wgs1 >= 600 && Nmax >= 1024 ? 2 : 1;
+    return wgs1 >= 450 && Nmax >= 1024 ? 2 : 1;   // (three 8 h recordings: a batch of K = 6 splits into two of three that run side by side: 1 014 workgroups at one slot per thread)
 }
 // bytes of ONE problem's slot in the uniform layout of such a batch
 size_t uniform_stride(int count, size_t Nmax, size_t d) {
@@ -2491,6 +2491,7 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
     // Measured (profiles/r05_cpt_probe_v2.json, us per round of 43 200-point problems, one batch): K = 2: 5.80 / 5.93 / 6.83 with 1 / 2 / 4 slots per thread,
     // K = 4: 6.89 / 6.66 / 7.15, K = 8: 10.83 / 7.93 / 8.49, K = 12: 13.41 / 10.00 / 9.80; two batches side by side, K = 8: 8.82 / 7.59 / 8.12, K = 12: 11.17 /
     // 8.18 / 8.90; 16 x 5 400: 6.74 / 6.88 / 7.90.  Two slots per thread pay once a launch holds more than ~2 workgroups per CU at one slot per thread.
+    // (Three batches side by side instead of two, profiles/r05_groups_probe.txt: K = 8: 145 -> 152 audio-hours/s linkage-only, K = 12: 187 -> 180: not adopted.)
     const int cpt = env_cpt ? env_cpt : uniform_cpt(count, Nmax);
     const size_t cols = static_cast<size_t>(kBlk) * cpt, Npmax = (Nmax + cols - 1) / cols * cols, nblk = Npmax / cols;
     FA_TRY(prob_check_shape(ctx, Nmax, d));
