@@ -340,7 +340,7 @@ def e2e_in_flight_leg(fa, torch, in_flight=4, steps=3, hours=8.0):
             "note": "clustering stage only (mel of the same audio adds 1.2 ms per recording); inputs resident in HBM; one process, one GPU"}
 
 
-def e2e_batch_leg(fa, ctx, ks=(2, 4, 8), hours=8.0):
+def e2e_batch_leg(fa, ctx, ks=(2, 4, 8, 12), hours=8.0):
     """Throughput of ONE GPU, queue-independent form: K recordings of configs[4] through ONE fa_offline_cluster_batch call — their merge chains
     advance by ONE launch per round (uniform workspace layout, ahc_round_uni: the problem is the workgroup id in y), on one stream, whatever
     hardware queues the process's other streams occupy (the in-flight leg below depends on them).  Recording k = the session of seed 5 + k;
@@ -369,7 +369,9 @@ def e2e_batch_leg(fa, ctx, ks=(2, 4, 8), hours=8.0):
                         "us_per_round": 1e3 * a["merge_ms"] / max(1, a["rounds"]), "rounds": a["rounds"], "ahc_init_ms": a["init_ms"], "ahc_merge_ms": a["merge_ms"],
                         "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                      "achieved": k * 3 * ((len(recs[0][0]) + 255) // 256 * 256) * 8 / (1e-6 * 1e3 * a["merge_ms"] / max(1, a["rounds"])) / 1e9,
-                                     "kernel": "ahc_round_uni", "note": "K x (two operand rows + one written row) per launch / launch period"}}
+                                     "kernel": "ahc_round_uni (one slot per thread)" if (k if k < 6 else (k + 1) // 2) * ((len(recs[0][0]) + 255) // 256) < 450 else
+                                               "ahc_round_uni_c2 (two slots per thread; six or more recordings: two batches side by side)",
+                                     "note": "K x (two operand rows + one written row) per launch / launch period (of the caller's batch when two run side by side)"}}
         out[f"x{k}"]["roofline"]["frac"] = out[f"x{k}"]["roofline"]["achieved"] / HBM_PEAK_GBS
     ctx.trim()
     return out

@@ -284,9 +284,12 @@ __device__ __forceinline__ void rows_dot(float &acc, const float *tq, const floa
 #undef FA_ROWS_Q
 }
 
+#ifndef FA_ROWS_ATTR
+#define FA_ROWS_ATTR   // measurements: -DFA_ROWS_ATTR='__attribute__((amdgpu_waves_per_eu(6, 6)))' caps the registers for three workgroups per CU
+#endif
 template <int NV, int IT, int SHARE, int HALVES = 1>   // NV: 16-byte reads per window; IT: 64-float pieces per staged row (sld <= 64 IT); SHARE: phases per window;
                                                       // HALVES = 2 (NV = 16, SHARE = 1): a phase of more than 64 taps reads two windows, one right behind the other
-__global__ __launch_bounds__(kRowsThreads) void poly_rows_kernel(const float *__restrict__ x, const float *__restrict__ tt, const int2 *__restrict__ gtab,
+__global__ __launch_bounds__(kRowsThreads) FA_ROWS_ATTR void poly_rows_kernel(const float *__restrict__ x, const float *__restrict__ tt, const int2 *__restrict__ gtab,
                                                                 float *__restrict__ y, const PolyRowsGeom g, const int64_t tiles, const int64_t m_end, const int vec_ok) {
     extern __shared__ float xs[];
     typedef const int __attribute__((address_space(4))) *c_i32;
