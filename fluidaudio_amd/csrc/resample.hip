@@ -394,8 +394,184 @@ __global__ __launch_bounds__(kRowsThreads) FA_ROWS_ATTR void poly_rows_kernel(co
     }
 }
 
+// poly_rows_wide_kernel (round 5): the tile arithmetic of poly_rows_kernel in a PERSISTENT workgroup, one per CU, with two LDS buffers and ALL the phases of
+// a tile in one item.  What the measurements of poly_rows_kernel and of two intermediate builds said (profiles/r05_resample_wide_steps.json):
+//  * a phase group's staged span is its inputs + one FIR reach (~64 floats): groups of 80 phases stage 1.3 x the signal, groups of 32 phases (what fits two
+//    buffers of 64-row tiles) 1.7 x — and a global -> LDS stream alone runs at ~25 GB/s per CU (5.9 TB/s over the chip, the rate MI355X_MICROARCH.md quotes
+//    for this path): staging volume, not HBM, set the floor.  Here a tile is 32 rows and holds the whole span of every phase: 1.13 x the signal.
+//  * the lanes of a wavefront are 2 phase halves x 32 rows: lane 32 h + r computes row r for the phases 8 c + 4 h .. + 3 of a UNIT c of eight phases (the DPP
+//    tap broadcast works within 16-lane rows, so the halves carry different taps).  Unit c = wavefront + 8 j: a wavefront's units — and with them its table
+//    rows, CH x 4 x NQ registers — are the same for every tile: they are loaded once per kernel, and a period has no table fetch at all.
+//  * the rows of tile i + 1 travel global -> LDS without registers (global_load_lds, 16 bytes per lane: lane l's piece lands at the wave-uniform LDS address
+//    + 16 l while every lane brings its own global address, so the [32][sld] image is ONE linear run of pieces) into the buffer tile i - 1 used, while tile i
+//    is computed from the other one.  TWO STATIC arrays and a loop unrolled by two, not one array and a toggling offset: the compiler orders LDS reads behind
+//    outstanding global -> LDS requests it cannot tell apart from them (s_waitcnt vmcnt(0) in front of the first ds_read: the overlap gone).
+//  * a tile's outputs are stored at the START of the next period, in front of that period's requests: the one wait per period (vmcnt(0) + barrier) then covers
+//    stores that are a whole period old (their acknowledgement takes ~1 us) and the young requests it is there for.  The barrier is the bare instruction:
+//    __syncthreads() carries a workgroup fence, which next to global -> LDS requests the compiler implements as one more s_waitcnt vmcnt(0).
+// Same tables, same order of additions: the bits of poly_rows_kernel.
+constexpr int kWideRows = 32, kWideBuf = 16384;       // floats per LDS buffer: 32 rows of <= 512 floats; two of them = 128 KB, one workgroup of 8 wavefronts per CU
+template <int NV, int SHARE, int CH>
+__global__ __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void poly_rows_wide_kernel(const float *__restrict__ x, const float *__restrict__ tt, float *__restrict__ y, const PolyRowsGeom g_,
+                                                                     const int smin_, const int tiles_, const int64_t m_end_, const int64_t k_lim_, const int vec_ok_, const int dbg_) {
+    __shared__ float buf_a[kWideBuf];
+    __shared__ float buf_b[kWideBuf];
+    constexpr int NTW = 4 * NV, NQ = (NTW + 15) / 16, NW = 4 / SHARE;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l16 = lane & 15, half = lane >> 5, r = lane & 31;
+    // the arguments the loop uses, as values the compiler cannot re-load: under register pressure it would fetch kernel arguments again INSIDE the loop, and a
+    // scalar load outstanding next to LDS reads leaves it only s_waitcnt lgkmcnt(0) (scalar loads return out of order) — the read pipeline below gone
+    int64_t m_end = m_end_, k_lim = k_lim_, k_begin = g_.k_begin, m_begin = g_.m_begin;
+    int up = g_.up, down = g_.down, sld = g_.sld, tiles = tiles_, vec_ok = vec_ok_, dbg = dbg_, smin = smin_, grid = static_cast<int>(gridDim.x);
+    asm volatile("" : "+s"(m_end), "+s"(k_lim), "+s"(k_begin), "+s"(m_begin), "+s"(up), "+s"(down), "+s"(sld), "+s"(tiles), "+s"(vec_ok), "+s"(dbg), "+s"(smin), "+s"(grid));
+    struct { int64_t k_begin, m_begin; int up, down, sld; } g{k_begin, m_begin, up, down, sld};
+    const int n_units = (g.up + 7) / 8;
+    // this wavefront's units: table rows (the table has eight empty rows behind the last phase) and LDS window addresses, for the whole kernel
+    float t[CH][4][NQ];
+    int xa[CH][NW];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int unit = wave + 8 * j < n_units ? wave + 8 * j : n_units - 1;
+        const float *row = tt + static_cast<size_t>(8 * unit + 4 * half) * fa::kRowsTT;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int qv = 0; qv < NQ; ++qv) t[j][u][qv] = row[u * fa::kRowsTT + 16 * qv + l16];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) xa[j][w] = 4 * (r * g.sld - smin + __float_as_int(row[w * SHARE * fa::kRowsTT + fa::kRowsOffPos]));     // (bytes)
+    }
+    // staging: piece i (16 bytes) of the linear LDS image = row i / (sld / 4), floats 4 (i % (sld / 4)) .. + 3 of that row; the pieces behind the 32nd row
+    // (8 sld < 4096) re-read the last one into the buffer's unused tail — every wavefront issues the same eight requests, no branches.  Rows start at odd
+    // multiples of 4 bytes: unaligned 16-byte requests, as in poly_rows_kernel.  The floats behind a row's span are never read by the arithmetic; where they
+    // would lie behind the signal's end the address is clamped (k_lim).
+    constexpr int kPieces = kWideBuf / 4 / kRowsThreads;     // 8
+    int soff[kPieces];
+    const int sld4 = g.sld / 4;
+#pragma unroll
+    for (int it = 0; it < kPieces; ++it) {
+        int i = it * kRowsThreads + static_cast<int>(threadIdx.x);
+        if (i >= kWideRows * sld4) i = kWideRows * sld4 - 1;
+        const int row = i / sld4, c4 = i - row * sld4;
+        soff[it] = row * g.down + 4 * c4;
+    }
+    const int tile_step = kWideRows * g.down;
+    auto stage = [&](const int tile, float *buf) {
+        const int64_t kt = g.k_begin + static_cast<int64_t>(tile) * tile_step + smin;
+        const float *src = x + kt;
+        const int64_t lim64 = k_lim - kt;
+        const int lim = lim64 < 0x3fffffff ? static_cast<int>(lim64) : 0x3fffffff;
+#pragma unroll
+        for (int it = 0; it < kPieces; ++it) {
+            if (dbg != 7) __builtin_amdgcn_global_load_lds(src + (soff[it] < lim ? soff[it] : lim), buf + 4 * (it * kRowsThreads + wave * 64), 16, 0, 2);
+            else __builtin_amdgcn_global_load_lds(src + (soff[it] < lim ? soff[it] : lim), buf + 4 * (it * kRowsThreads + wave * 64), 16, 0, 0);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile >= tiles) return;
+    stage(tile, buf_a);
+    // (the table registers pass through an empty statement: the compiler waits for their loads HERE, not at their first use inside the loop — behind the
+    // next tile's requests, which it would wait out with them)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int qv = 0; qv < NQ; ++qv) asm volatile("" : "+v"(t[j][u][qv]));
+#pragma unroll
+        for (int w = 0; w < NW; ++w) asm volatile("" : "+v"(xa[j][w]));
+    }
+    float st_acc[CH][4];
+    int st_tile = -1;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v xq[4][4] = {};                                      // the ring of window quarters (see the arithmetic below)
+    auto flush = [&]() {
+        if (st_tile < 0) return;
+        const int64_t m_row = g.m_begin + (static_cast<int64_t>(st_tile) * kWideRows + r) * g.up;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (wave + 8 * j >= n_units) break;
+            const int ph = 8 * (wave + 8 * j) + 4 * half;
+            const int64_t m = m_row + ph;
+            if (vec_ok && ph + 3 < g.up && m + 3 < m_end) {
+                f4v o = {st_acc[j][0], st_acc[j][1], st_acc[j][2], st_acc[j][3]};
+                if (dbg == 6) __builtin_nontemporal_store(o, reinterpret_cast<f4v *>(y + m)); else *reinterpret_cast<f4v *>(y + m) = o;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (ph + u < g.up && m + u < m_end) y[m + u] = st_acc[j][u];
+            }
+        }
+        st_tile = -1;
+    };
+    // one tile: computed from `mine` while the next one travels into `other`
+    auto step = [&](const float *mine, float *other) {
+        const int tile_n = tile + grid;
+        if (dbg < 3 || dbg >= 5) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's pieces of the present tile have landed ...
+        __builtin_amdgcn_s_barrier();                       // ... everybody's have, and nobody reads the other buffer any more
+        asm volatile("" ::: "memory");
+        }
+        if (dbg < 4 || dbg == 6) flush();
+        if (tile_n < tiles && (dbg < 2 || dbg >= 5)) stage(tile_n, other);
+        if (dbg != 1) {
+            // a software pipeline over PIECES of a window (four 16-byte LDS reads = 16 window positions): the reads of piece i + 3 are issued before the
+            // multiply-adds of piece i, through a ring of four register quarters.  A CU holds ONE workgroup here, two wavefronts per SIMD: nobody else covers a
+            // read's latency (first build, whole windows read and then used: 4.5 us of arithmetic per tile where the multiply-adds need 2.4 —
+            // profiles/r05_resample_wide_steps.json).  Three pieces ahead = 12 reads in flight: the LDS counter (lgkmcnt) has four bits.
+            // The reads and their waits are WRITTEN OUT (ds_read_b128 / s_waitcnt lgkmcnt(n) statements): left to the compiler, every variant of this loop
+            // ended in s_waitcnt lgkmcnt(0) in front of each piece (the wavefront-uniform branch around a unit's arithmetic, a kernel argument re-loaded inside
+            // the loop, the scheduler moving a later window's reads first) or in s_waitcnt vmcnt(0) in front of the first read (the next tile's requests).
+            // A wait names the reads issued behind the piece it is for; the counter retires LDS reads in issue order, and a scalar load the compiler might
+            // add in between only makes the wait longer (it raises the outstanding count, never lowers it below what the reads in front need).  The
+            // multiply-adds take their inputs from the wait statement's outputs: they cannot move in front of it.
+            constexpr int PC = (NV + 3) / 4, NP = CH * NW * PC;
+            const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) float *) mine));
+            auto reads_of = [](const int i) { const int pc = i % PC; return NV - 4 * pc < 4 ? NV - 4 * pc : 4; };
+            auto load = [&](auto ic) {
+                constexpr int i = decltype(ic)::value, j = i / (NW * PC), w = (i / PC) % NW, pc = i % PC;
+                const unsigned addr = lds_base + static_cast<unsigned>(xa[j][w]);
+                f4v *q = xq[i & 3];
+                if constexpr (4 * pc + 0 < NV) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[0]) : "v"(addr), "n"(64 * pc));
+                if constexpr (4 * pc + 1 < NV) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[1]) : "v"(addr), "n"(64 * pc + 16));
+                if constexpr (4 * pc + 2 < NV) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[2]) : "v"(addr), "n"(64 * pc + 32));
+                if constexpr (4 * pc + 3 < NV) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[3]) : "v"(addr), "n"(64 * pc + 48));
+            };
+            static_for<0, (NP < 3 ? NP : 3)>(load);
+            static_for<0, NP>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, j = i / (NW * PC), w = (i / PC) % NW, pc = i % PC;
+                if constexpr (i + 3 < NP) load(std::integral_constant<int, i + 3>{});
+                constexpr int behind = (i + 1 < NP ? reads_of(i + 1) : 0) + (i + 2 < NP ? reads_of(i + 2) : 0) + (i + 3 < NP ? reads_of(i + 3) : 0);
+                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(xq[i & 3][0]), "+v"(xq[i & 3][1]), "+v"(xq[i & 3][2]), "+v"(xq[i & 3][3]) : "n"(behind));
+                if (wave + 8 * j < n_units) {                   // (wave-uniform)
+                    if constexpr (w == 0 && pc == 0) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) st_acc[j][u] = 0.0f;
+                    }
+                    static_for<0, 16>([&](auto pcst) {          // position by position, the phases of the window side by side (independent accumulators)
+                        constexpr int pos = decltype(pcst)::value;
+                        if constexpr (16 * pc + pos < NTW) {
+#pragma unroll
+                            for (int u = 0; u < SHARE; ++u) fmac_bcast<pos>(st_acc[j][w * SHARE + u], t[j][w * SHARE + u][pc], xq[i & 3][pos / 4][pos % 4]);
+                        }
+                    });
+                }
+            });
+            st_tile = tile;
+        }
+        tile = tile_n;
+    };
+    for (;;) {
+        step(buf_a, buf_b);
+        if (tile >= tiles) break;
+        step(buf_b, buf_a);
+        if (tile >= tiles) break;
+    }
+    flush();
+}
+
 // host side of poly_rows_kernel: the tables of one rate pair, resident on the device with the context
 struct PolyRows {
+    bool wide = false;              // served by poly_rows_wide_kernel (32-row tiles, every phase in one item, two LDS buffers)
+    int ch = 0;                     // its units of eight phases per wavefront
+    int smin0 = 0;                  // first staged offset of its single phase group
     PolyRowsGeom g{};
     int nv = 0;                     // 16-byte reads per phase window
     size_t lds = 0;
@@ -405,6 +581,7 @@ struct PolyRows {
     ~PolyRows() { if (d_tables) (void)hipFree(d_tables); }
 };
 void poly_rows_free(void *p) { delete static_cast<PolyRows *>(p); }
+bool wide_instance(int nv, int share, int ch);
 
 // Geometry + tables (resample_geom.h); false when the pair does not suit the kernel (then poly_lds_kernel serves it).
 bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt) {
@@ -412,6 +589,25 @@ bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down,
     if (const char *e = getenv("FA_RESAMPLE_ROWS_LDS_KB")) { const int v = atoi(e); if (v >= 16 && v <= 150) budget = static_cast<size_t>(v) * 1024; }
     int share_max = 4;                                                  // FA_RESAMPLE_ROWS_SHARE = 1 | 2 | 4: measurements (1 = every phase its own window, round 4's reads)
     if (const char *e = getenv("FA_RESAMPLE_ROWS_SHARE")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) share_max = v; }
+    // the persistent kernel with two buffers (FA_RESAMPLE_NO_WIDE=1: the one-tile-per-workgroup kernel): one phase group — an unbounded LDS budget keeps
+    // rows_geometry from splitting —, rows of at most 512 floats, and one of the instantiated (window, sharing, units per wavefront) combinations
+    R.wide = false;
+    if (budget == 0 && getenv("FA_RESAMPLE_NO_WIDE") == nullptr) {
+        PolyRowsGeom g2{};
+        int nv2 = 0;
+        std::vector<int> gtab2;
+        std::vector<float> tt2;
+        if (fa::rows_geometry(g2, nv2, h, up, down, pre_remove, gtab2, tt2, size_t{1} << 30, share_max) && g2.groups == 1 && g2.sld * kWideRows <= kWideBuf) {
+            const int ch = ((up + 7) / 8 + kRowsWaves - 1) / kRowsWaves;
+            if (wide_instance(nv2, g2.share, ch)) {
+                R.g = g2; R.nv = nv2; R.ch = ch; gtab.swap(gtab2); tt.swap(tt2);
+                R.smin0 = gtab[0];
+                R.wide = true;
+                R.lds = 0; R.up = up; R.down = down;     // (static LDS)
+                return true;
+            }
+        }
+    }
     if (!fa::rows_geometry(R.g, R.nv, h, up, down, pre_remove, gtab, tt, budget, share_max)) return false;
     if (R.g.sld > 64 * 5 && R.g.share != 1 && !fa::rows_geometry(R.g, R.nv, h, up, down, pre_remove, gtab, tt, budget, 1)) return false;   // the long-row build is instantiated for share = 1 only
     R.lds = static_cast<size_t>(R.g.sld) * 64 * sizeof(float); R.up = up; R.down = down;
@@ -427,8 +623,31 @@ void poly_rows_launch_it(fa_ctx *ctx, const PolyRows &R, const float *d_x, float
     const int64_t tiles8 = (tiles + 7) / 8 * 8;   // whole rounds of the 8 XCDs: the index -> (tile, group) map of the kernel
     hipLaunchKernelGGL((poly_rows_kernel<NV, IT, SHARE, HALVES>), dim3(static_cast<unsigned>(tiles8 * R.g.groups)), dim3(kRowsThreads), R.lds, ctx->stream, d_x, tt, gtab, d_y, R.g, tiles, m_end, vec_ok);
 }
+// the instantiated combinations of poly_rows_wide_kernel: {16-byte reads per window, phases per window, units per wavefront}
+//   44.1 -> 16 kHz {16, 2, 3}, 22.05 -> 16 kHz {10, 4, 5}, 11.025 -> 16 kHz {8, 4, 10}, 37.8 -> 16 kHz {16, 4, 2}; other pairs: poly_rows_kernel
+#define FA_WIDE_INSTANCES(X) X(16, 2, 3) X(10, 4, 5) X(8, 4, 10) X(16, 4, 2)
+bool wide_instance(int nv, int share, int ch) {
+#define FA_WIDE_IS(V, S, C) if (nv == V && share == S && ch == C) return true;
+    FA_WIDE_INSTANCES(FA_WIDE_IS)
+#undef FA_WIDE_IS
+    return false;
+}
+void poly_rows_wide_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end, int64_t frames, int smin) {
+    const float *tt = reinterpret_cast<const float *>(static_cast<const char *>(R.d_tables) + R.tt_offset);
+    const int vec_ok = R.up % 4 == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0 ? 1 : 0;
+    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(tiles, 256));   // one resident workgroup per CU (128 KB of LDS)
+    const int dbg = getenv("FA_DBG") ? atoi(getenv("FA_DBG")) : 0;
+#define FA_WIDE_GO(V, S, C)                                                                                                                        \
+    if (R.nv == V && R.g.share == S && R.ch == C) {                                                                                                \
+        hipLaunchKernelGGL((poly_rows_wide_kernel<V, S, C>), dim3(grid), dim3(kRowsThreads), 0, ctx->stream, d_x, tt, d_y, R.g, smin, static_cast<int>(tiles), m_end, \
+                           frames - 4, vec_ok, dbg);                                                                                              \
+        return;                                                                                                                                    \
+    }
+    FA_WIDE_INSTANCES(FA_WIDE_GO)
+#undef FA_WIDE_GO
+}
 template <int NV>
-void poly_rows_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end) {
+void poly_rows_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end, int64_t frames) {
     if constexpr (NV == 32) {                                                               // phases of 65 .. 128 taps (88.2 -> 16 kHz): two windows of 16 reads per phase
         if (R.g.sld > 64 * 5) poly_rows_launch_it<16, 10, 1, 2>(ctx, R, d_x, d_y, tiles, m_end);
         else poly_rows_launch_it<16, 5, 1, 2>(ctx, R, d_x, d_y, tiles, m_end);
@@ -632,12 +851,14 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
         if (!decim && !simple && ctx->poly_rows && getenv("FA_RESAMPLE_NO_ROWS") == nullptr) {
             const PolyRows &R = *static_cast<const PolyRows *>(ctx->poly_rows);
             const PolyRowsGeom &G = R.g;
-            int64_t tiles = fa::rows_tiles(G, frames, n_out);                  // tiles whose staged inputs all exist (resample_geom.h)
-            const int64_t per_tile = 64LL * G.up;
+            const int tile_rows = R.wide ? kWideRows : 64;
+            int64_t tiles = fa::rows_tiles(G, frames, n_out, tile_rows);       // tiles whose staged inputs all exist (resample_geom.h)
+            const int64_t per_tile = static_cast<int64_t>(tile_rows) * G.up;
             if (tiles > 0 && (tiles + 8) * G.groups < (1LL << 31)) {
                 const int64_t m_stop = std::min(n_out, G.m_begin + tiles * per_tile);
-                switch (R.nv) {
-#define FA_ROWS_CASE(V) case V: poly_rows_launch<V>(ctx, R, d_x, d_y, tiles, m_stop); break;
+                if (R.wide) poly_rows_wide_launch(ctx, R, d_x, d_y, tiles, m_stop, frames, R.smin0);
+                else switch (R.nv) {
+#define FA_ROWS_CASE(V) case V: poly_rows_launch<V>(ctx, R, d_x, d_y, tiles, m_stop, frames); break;
                     FA_ROWS_CASE(4) FA_ROWS_CASE(6) FA_ROWS_CASE(8) FA_ROWS_CASE(10) FA_ROWS_CASE(12) FA_ROWS_CASE(14) FA_ROWS_CASE(16) FA_ROWS_CASE(32)
 #undef FA_ROWS_CASE
                     default: tiles = 0; break;

@@ -102,7 +102,7 @@ inline bool rows_geometry(PolyRowsGeom &g, int &nv_out, const std::vector<float>
         gtab[2 * gq + 1] = span_of(a0, a1);
         smax = std::max(smax, gtab[2 * gq] + gtab[2 * gq + 1]);
     }
-    tt.assign(static_cast<size_t>(up) * kRowsTT, 0.0f);
+    tt.assign(static_cast<size_t>(up + 8) * kRowsTT, 0.0f);              // empty rows behind the last phase: poly_rows_wide_kernel fetches units of eight phases without clamps
     for (int ph = 0; ph < up; ++ph) {
         const int q = ph - ph % share;                                  // (groups start at multiples of 4: a shared window never straddles two groups)
         const int base4 = off[q] & ~3, a = off[ph] - base4;
@@ -117,11 +117,12 @@ inline bool rows_geometry(PolyRowsGeom &g, int &nv_out, const std::vector<float>
     return true;
 }
 
-// tiles of 64 up outputs whose staged inputs all exist: tile t stages x[k_begin + 64 down t ... + 63 down + smax)
-inline int64_t rows_tiles(const PolyRowsGeom &G, int64_t frames, int64_t n_out) {
-    const int64_t last_need = G.k_begin + 63LL * G.down + G.smax;      // exclusive end of tile 0's staged range
-    int64_t tiles = frames >= last_need ? (frames - last_need) / (64LL * G.down) + 1 : 0;
-    const int64_t per_tile = 64LL * G.up;
+// tiles of `rows` x up outputs whose staged inputs all exist: tile t stages x[k_begin + rows down t ... + (rows - 1) down + smax)
+// (rows = 64: poly_rows_kernel; 32: poly_rows_wide_kernel)
+inline int64_t rows_tiles(const PolyRowsGeom &G, int64_t frames, int64_t n_out, int rows = 64) {
+    const int64_t last_need = G.k_begin + static_cast<int64_t>(rows - 1) * G.down + G.smax;      // exclusive end of tile 0's staged range
+    int64_t tiles = frames >= last_need ? (frames - last_need) / (static_cast<int64_t>(rows) * G.down) + 1 : 0;
+    const int64_t per_tile = static_cast<int64_t>(rows) * G.up;
     if (G.m_begin < n_out) tiles = std::min(tiles, (n_out - G.m_begin + per_tile - 1) / per_tile); else tiles = 0;
     return tiles;
 }

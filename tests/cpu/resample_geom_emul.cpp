@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../../fluidaudio_amd/csrc/resample_geom.h"
@@ -26,32 +27,37 @@ void poly_simple(const float *x, int64_t n_in, const float *h, int64_t h_len, in
 
 // returns 0 and the covered range, or a negative code: -1 pair not served, -2 staged index out of the signal, -3 window read outside the staged
 // span, -4 an output written twice / outside [m_begin, m_stop), -5 an output of the range not written, -6 misaligned window read,
-// -7 the phases of a shared window disagree about it, -8 a tap at a window position the kernel does not multiply
+// -7 the phases of a shared window disagree about it, -8 a tap at a window position the kernel does not multiply, -10 a row-count other than 64 with more than one phase group
 int rows_emulate(const float *x, int64_t n_in, const float *h, int64_t h_len, int up, int down, int64_t pre_remove, int64_t n_out, float *y, int64_t *m_lo, int64_t *m_hi,
-                 int32_t *info /* nv, groups, ppg, sld, tiles, share */, int share_max) {
+                 int32_t *info /* nv, groups, ppg, sld, tiles, share */, int share_max, int64_t lds_budget, int rows) {
     fa::PolyRowsGeom g{};
     int nv = 0;
     std::vector<int> gtab;
     std::vector<float> tt;
     std::vector<float> hv(h, h + h_len);
     *m_lo = *m_hi = 0;
-    if (!fa::rows_geometry(g, nv, hv, up, down, pre_remove, gtab, tt, 0, share_max)) return -1;
-    const int64_t tiles = fa::rows_tiles(g, n_in, n_out);
+    if (!fa::rows_geometry(g, nv, hv, up, down, pre_remove, gtab, tt, static_cast<size_t>(lds_budget), share_max)) return -1;
+    if (rows != 64 && g.groups != 1) return -10;                       // poly_rows_wide_kernel: every phase of a tile in one item
+    const int64_t tiles = fa::rows_tiles(g, n_in, n_out, rows);
     info[0] = nv; info[1] = g.groups; info[2] = g.ppg; info[3] = g.sld; info[4] = static_cast<int32_t>(tiles); info[5] = g.share;
     if (tiles <= 0) return 0;
-    const int64_t m_stop = std::min<int64_t>(n_out, g.m_begin + tiles * 64 * static_cast<int64_t>(g.up));
+    const int64_t m_stop = std::min<int64_t>(n_out, g.m_begin + tiles * rows * static_cast<int64_t>(g.up));
     std::vector<char> written(static_cast<size_t>(m_stop - g.m_begin), 0);
-    std::vector<float> xs(static_cast<size_t>(64) * g.sld);
+    std::vector<float> xs(static_cast<size_t>(rows) * g.sld);
     std::vector<char> staged(xs.size());
     const int NT = std::min(4 * nv, fa::kRowsOffLane);
-    for (int64_t tile = 0; tile < tiles; ++tile)
-        for (int grp = 0; grp < g.groups; ++grp) {
+    std::vector<std::pair<int64_t, int>> order;
+    for (int64_t tile = 0; tile < tiles; ++tile) for (int grp = 0; grp < g.groups; ++grp) order.emplace_back(tile, grp);
+    for (const auto &item : order) {
+            const int64_t tile = item.first;
+            const int grp = item.second;
+            {
             const int ph0 = grp * g.ppg, ph1 = std::min(ph0 + g.ppg, g.up);
             const int smin = gtab[2 * grp], span = gtab[2 * grp + 1];
             if (span > g.sld || (smin & 3)) return -3;
             std::fill(staged.begin(), staged.end(), 0);
-            const int64_t kt = g.k_begin + tile * 64 * g.down + smin;
-            for (int l = 0; l < 64; ++l)
+            const int64_t kt = g.k_begin + tile * rows * g.down + smin;
+            for (int l = 0; l < rows; ++l)
                 for (int sidx = 0; sidx < span; ++sidx) {
                     const int64_t k = kt + static_cast<int64_t>(l) * g.down + sidx;
                     if (k < 0 || k >= n_in) return -2;
@@ -69,19 +75,20 @@ int rows_emulate(const float *x, int64_t n_in, const float *h, int64_t h_len, in
                 if (off4 != off4_own) return -7;                            // every phase of a shared window carries the same offset
                 if (off4 & 3) return -6;
                 for (int j = NT; j < fa::kRowsOffPos; ++j) if (row[j] != 0.0f) return -8;   // no tap beyond the positions the kernel multiplies
-                for (int l = 0; l < 64; ++l) {
+                for (int l = 0; l < rows; ++l) {
                     const int base = l * g.sld + (off4 - smin);
                     if (off4 - smin < 0 || off4 - smin + 4 * nv > g.sld) return -3;
                     float acc = 0.0f;
                     for (int v = 0; v < 4 * nv; ++v) if (!staged[static_cast<size_t>(base) + v]) return -3;   // the 16-byte reads touch staged data only
                     for (int j = 0; j < NT; ++j) acc = fmaf(row[j], xs[static_cast<size_t>(base) + j], acc);
-                    const int64_t m = g.m_begin + tile * 64 * g.up + static_cast<int64_t>(l) * g.up + ph;
+                    const int64_t m = g.m_begin + tile * rows * g.up + static_cast<int64_t>(l) * g.up + ph;
                     if (m < m_stop) {
                         if (m < g.m_begin || written[static_cast<size_t>(m - g.m_begin)]) return -4;
                         written[static_cast<size_t>(m - g.m_begin)] = 1;
                         y[m] = acc;
                     }
                 }
+            }
             }
         }
     for (char c : written) if (!c) return -5;
