@@ -15,6 +15,7 @@
 #include <cmath>
 #include <type_traits>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -410,28 +411,40 @@ __global__ __launch_bounds__(kRowsThreads) FA_ROWS_ATTR void poly_rows_kernel(co
 //    stores that are a whole period old (their acknowledgement takes ~1 us) and the young requests it is there for.  The barrier is the bare instruction:
 //    __syncthreads() carries a workgroup fence, which next to global -> LDS requests the compiler implements as one more s_waitcnt vmcnt(0).
 // Same tables, same order of additions: the bits of poly_rows_kernel.
-constexpr int kWideRows = 32, kWideBuf = 16384;       // floats per LDS buffer: 32 rows of <= 512 floats; two of them = 128 KB, one workgroup of 8 wavefronts per CU
-template <int NV, int SHARE, int CH>
-__global__ __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void poly_rows_wide_kernel(const float *__restrict__ x, const float *__restrict__ tt, float *__restrict__ y, const PolyRowsGeom g_,
-                                                                     const int smin_, const int tiles_, const int64_t m_end_, const int64_t k_lim_, const int vec_ok_, const int dbg_) {
+// ROWS = rows of a tile: 32 (one workgroup per CU, two buffers of 64 KB, lanes = 2 phase quads x 32 rows) or 16 (two workgroups per CU, buffers of 32 KB,
+// lanes = 4 phase quads x 16 rows — one quad per DPP row); a UNIT is the 4 x 64 / ROWS phases one wavefront-instruction covers.
+// floats per LDS row, at most: two buffers of 32 x 512 floats = 128 KB (one workgroup per CU), of 16 x 512 = 64 KB or of 32 x 288 = 72 KB (two per CU)
+constexpr int wide_row_floats(int rows, int waves) { return rows == 32 && waves == 10 ? 288 : 512; }
+template <int ROWS, int WAVES, int NV, int SHARE, int CH>
+__device__ __forceinline__ void poly_rows_wide_body(const float *__restrict__ x, const float *__restrict__ tt, float *__restrict__ y, const PolyRowsGeom g_,
+                                                    const int2 *__restrict__ gtab, const int tiles_, const int64_t m_end_, const int64_t k_lim_, const int vec_ok_, const int dbg_) {
+    constexpr int kWideBuf = ROWS * wide_row_floats(ROWS, WAVES), PU = 4 * 64 / ROWS;     // floats per LDS buffer; phases per unit
     __shared__ float buf_a[kWideBuf];
     __shared__ float buf_b[kWideBuf];
     constexpr int NTW = 4 * NV, NQ = (NTW + 15) / 16, NW = 4 / SHARE;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l16 = lane & 15, half = lane >> 5, r = lane & 31;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l16 = lane & 15, quad = lane / ROWS, r = lane % ROWS;
     // the arguments the loop uses, as values the compiler cannot re-load: under register pressure it would fetch kernel arguments again INSIDE the loop, and a
     // scalar load outstanding next to LDS reads leaves it only s_waitcnt lgkmcnt(0) (scalar loads return out of order) — the read pipeline below gone
     int64_t m_end = m_end_, k_lim = k_lim_, k_begin = g_.k_begin, m_begin = g_.m_begin;
-    int up = g_.up, down = g_.down, sld = g_.sld, tiles = tiles_, vec_ok = vec_ok_, dbg = dbg_, smin = smin_, grid = static_cast<int>(gridDim.x);
-    asm volatile("" : "+s"(m_end), "+s"(k_lim), "+s"(k_begin), "+s"(m_begin), "+s"(up), "+s"(down), "+s"(sld), "+s"(tiles), "+s"(vec_ok), "+s"(dbg), "+s"(smin), "+s"(grid));
+    // a workgroup serves ONE phase group for the whole kernel (its wavefronts' table rows never change) and every n_chains-th tile: workgroup b -> XCD b & 7,
+    // group (b >> 3) % groups, tiles (b & 7) + 8 ((b >> 3) / groups) + k n_chains — the workgroups that stage the overlapping spans of a tile's groups are 8
+    // apart: the same XCD's L2, at about the same time
+    const int groups = g_.groups, qb = static_cast<int>(blockIdx.x) >> 3, grp = qb % groups;
+    int up = g_.up, down = g_.down, sld = g_.sld, tiles = tiles_, vec_ok = vec_ok_, dbg = dbg_, smin = reinterpret_cast<const int *>(gtab)[2 * grp];
+    int n_chains = 8 * (static_cast<int>(gridDim.x) / (8 * groups)), ph0 = grp * g_.ppg, ph1 = ph0 + g_.ppg < up ? ph0 + g_.ppg : up;
+    int tile = (static_cast<int>(blockIdx.x) & 7) + 8 * (qb / groups);
+    asm volatile("" : "+s"(m_end), "+s"(k_lim), "+s"(k_begin), "+s"(m_begin), "+s"(up), "+s"(down), "+s"(sld), "+s"(tiles), "+s"(vec_ok), "+s"(dbg), "+s"(smin), "+s"(n_chains),
+                 "+s"(ph0), "+s"(ph1), "+s"(tile));
     struct { int64_t k_begin, m_begin; int up, down, sld; } g{k_begin, m_begin, up, down, sld};
-    const int n_units = (g.up + 7) / 8;
+    const int n_units = (ph1 - ph0 + PU - 1) / PU;
+    if (qb / groups >= static_cast<int>(gridDim.x) / (8 * groups)) return;      // (a grid that is not a multiple of 8 groups: the workgroups behind the last whole set)
     // this wavefront's units: table rows (the table has eight empty rows behind the last phase) and LDS window addresses, for the whole kernel
     float t[CH][4][NQ];
     int xa[CH][NW];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-        const int unit = wave + 8 * j < n_units ? wave + 8 * j : n_units - 1;
-        const float *row = tt + static_cast<size_t>(8 * unit + 4 * half) * fa::kRowsTT;
+        const int unit = wave + WAVES * j < n_units ? wave + WAVES * j : n_units - 1;
+        const float *row = tt + static_cast<size_t>(ph0 + PU * unit + 4 * quad) * fa::kRowsTT;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -443,17 +456,17 @@ __global__ __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(2,
     // (8 sld < 4096) re-read the last one into the buffer's unused tail — every wavefront issues the same eight requests, no branches.  Rows start at odd
     // multiples of 4 bytes: unaligned 16-byte requests, as in poly_rows_kernel.  The floats behind a row's span are never read by the arithmetic; where they
     // would lie behind the signal's end the address is clamped (k_lim).
-    constexpr int kPieces = kWideBuf / 4 / kRowsThreads;     // 8
+    constexpr int kThreadsW = 64 * WAVES, kPieces = (kWideBuf / 4 + kThreadsW - 1) / kThreadsW;
     int soff[kPieces];
     const int sld4 = g.sld / 4;
 #pragma unroll
     for (int it = 0; it < kPieces; ++it) {
-        int i = it * kRowsThreads + static_cast<int>(threadIdx.x);
-        if (i >= kWideRows * sld4) i = kWideRows * sld4 - 1;
+        int i = it * kThreadsW + static_cast<int>(threadIdx.x);
+        if (i >= ROWS * sld4) i = ROWS * sld4 - 1;
         const int row = i / sld4, c4 = i - row * sld4;
         soff[it] = row * g.down + 4 * c4;
     }
-    const int tile_step = kWideRows * g.down;
+    const int tile_step = ROWS * g.down;
     auto stage = [&](const int tile, float *buf) {
         const int64_t kt = g.k_begin + static_cast<int64_t>(tile) * tile_step + smin;
         const float *src = x + kt;
@@ -461,11 +474,10 @@ __global__ __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(2,
         const int lim = lim64 < 0x3fffffff ? static_cast<int>(lim64) : 0x3fffffff;
 #pragma unroll
         for (int it = 0; it < kPieces; ++it) {
-            if (dbg != 7) __builtin_amdgcn_global_load_lds(src + (soff[it] < lim ? soff[it] : lim), buf + 4 * (it * kRowsThreads + wave * 64), 16, 0, 2);
-            else __builtin_amdgcn_global_load_lds(src + (soff[it] < lim ? soff[it] : lim), buf + 4 * (it * kRowsThreads + wave * 64), 16, 0, 0);
+            const int base = it * kThreadsW + wave * 64;         // first piece of this wavefront's request
+            if (kWideBuf / 4 % kThreadsW == 0 || base < kWideBuf / 4) __builtin_amdgcn_global_load_lds(src + (soff[it] < lim ? soff[it] : lim), buf + 4 * base, 16, 0, 2);
         }
     };
-    int tile = blockIdx.x;
     if (tile >= tiles) return;
     stage(tile, buf_a);
     // (the table registers pass through an empty statement: the compiler waits for their loads HERE, not at their first use inside the loop — behind the
@@ -482,40 +494,43 @@ __global__ __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(2,
     float st_acc[CH][4];
     int st_tile = -1;
     typedef float f4v __attribute__((ext_vector_type(4)));
-    f4v xq[4][4] = {};                                      // the ring of window quarters (see the arithmetic below)
+    constexpr int AHEAD = WAVES == 10 ? 1 : (ROWS == 32 ? 3 : 2), RING = AHEAD + 1;    // pieces read ahead (two workgroups per CU: 4 - 5 wavefronts per SIMD cover each other, and 128 / 96 registers are all there is)
+    f4v xq[RING][4] = {};                                   // the ring of window quarters (see the arithmetic below)
     auto flush = [&]() {
         if (st_tile < 0) return;
-        const int64_t m_row = g.m_begin + (static_cast<int64_t>(st_tile) * kWideRows + r) * g.up;
+        const int64_t m_row = g.m_begin + (static_cast<int64_t>(st_tile) * ROWS + r) * g.up;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            if (wave + 8 * j >= n_units) break;
-            const int ph = 8 * (wave + 8 * j) + 4 * half;
+            if (wave + WAVES * j >= n_units) break;
+            const int ph = ph0 + PU * (wave + WAVES * j) + 4 * quad;
             const int64_t m = m_row + ph;
-            if (vec_ok && ph + 3 < g.up && m + 3 < m_end) {
+            if (vec_ok && ph + 3 < ph1 && m + 3 < m_end) {
                 f4v o = {st_acc[j][0], st_acc[j][1], st_acc[j][2], st_acc[j][3]};
-                if (dbg == 6) __builtin_nontemporal_store(o, reinterpret_cast<f4v *>(y + m)); else *reinterpret_cast<f4v *>(y + m) = o;
+                *reinterpret_cast<f4v *>(y + m) = o;
             } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) if (ph + u < g.up && m + u < m_end) y[m + u] = st_acc[j][u];
+                for (int u = 0; u < 4; ++u) if (ph + u < ph1 && m + u < m_end) y[m + u] = st_acc[j][u];
             }
         }
         st_tile = -1;
     };
     // one tile: computed from `mine` while the next one travels into `other`
     auto step = [&](const float *mine, float *other) {
-        const int tile_n = tile + grid;
-        if (dbg < 3 || dbg >= 5) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's pieces of the present tile have landed ...
-        __builtin_amdgcn_s_barrier();                       // ... everybody's have, and nobody reads the other buffer any more
-        asm volatile("" ::: "memory");
+        const int tile_n = tile + n_chains;
+        // (dbg = FA_RESAMPLE_WIDE_PART, 0 in production: 1 = staging only, 2 = everything but staging, 3 = arithmetic and stores without the period's wait and
+        // barrier, 4 = arithmetic alone — the decomposition of profiles/r05_resample_wide_steps.json; wave-uniform branches on a scalar)
+        if (dbg < 3) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's pieces of the present tile have landed ...
+            __builtin_amdgcn_s_barrier();                       // ... everybody's have, and nobody reads the other buffer any more
+            asm volatile("" ::: "memory");
         }
-        if (dbg < 4 || dbg == 6) flush();
-        if (tile_n < tiles && (dbg < 2 || dbg >= 5)) stage(tile_n, other);
+        if (dbg < 4) flush();
+        if (tile_n < tiles && dbg < 2) stage(tile_n, other);
         if (dbg != 1) {
-            // a software pipeline over PIECES of a window (four 16-byte LDS reads = 16 window positions): the reads of piece i + 3 are issued before the
-            // multiply-adds of piece i, through a ring of four register quarters.  A CU holds ONE workgroup here, two wavefronts per SIMD: nobody else covers a
+            // a software pipeline over PIECES of a window (four 16-byte LDS reads = 16 window positions): the reads of piece i + AHEAD are issued before the
+            // multiply-adds of piece i, through a ring of AHEAD + 1 register quarters.  A CU holds ONE workgroup here, two wavefronts per SIMD: nobody else covers a
             // read's latency (first build, whole windows read and then used: 4.5 us of arithmetic per tile where the multiply-adds need 2.4 —
-            // profiles/r05_resample_wide_steps.json).  Three pieces ahead = 12 reads in flight: the LDS counter (lgkmcnt) has four bits.
+            // profiles/r05_resample_wide_steps.json).  At most three pieces ahead = 12 reads in flight: the LDS counter (lgkmcnt) has four bits.
             // The reads and their waits are WRITTEN OUT (ds_read_b128 / s_waitcnt lgkmcnt(n) statements): left to the compiler, every variant of this loop
             // ended in s_waitcnt lgkmcnt(0) in front of each piece (the wavefront-uniform branch around a unit's arithmetic, a kernel argument re-loaded inside
             // the loop, the scheduler moving a later window's reads first) or in s_waitcnt vmcnt(0) in front of the first read (the next tile's requests).
@@ -528,19 +543,22 @@ __global__ __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(2,
             auto load = [&](auto ic) {
                 constexpr int i = decltype(ic)::value, j = i / (NW * PC), w = (i / PC) % NW, pc = i % PC;
                 const unsigned addr = lds_base + static_cast<unsigned>(xa[j][w]);
-                f4v *q = xq[i & 3];
+                f4v *q = xq[i % RING];
                 if constexpr (4 * pc + 0 < NV) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[0]) : "v"(addr), "n"(64 * pc));
                 if constexpr (4 * pc + 1 < NV) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[1]) : "v"(addr), "n"(64 * pc + 16));
                 if constexpr (4 * pc + 2 < NV) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[2]) : "v"(addr), "n"(64 * pc + 32));
                 if constexpr (4 * pc + 3 < NV) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[3]) : "v"(addr), "n"(64 * pc + 48));
             };
-            static_for<0, (NP < 3 ? NP : 3)>(load);
+            static_for<0, (NP < AHEAD ? NP : AHEAD)>(load);
             static_for<0, NP>([&](auto ic) {
                 constexpr int i = decltype(ic)::value, j = i / (NW * PC), w = (i / PC) % NW, pc = i % PC;
-                if constexpr (i + 3 < NP) load(std::integral_constant<int, i + 3>{});
-                constexpr int behind = (i + 1 < NP ? reads_of(i + 1) : 0) + (i + 2 < NP ? reads_of(i + 2) : 0) + (i + 3 < NP ? reads_of(i + 3) : 0);
-                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(xq[i & 3][0]), "+v"(xq[i & 3][1]), "+v"(xq[i & 3][2]), "+v"(xq[i & 3][3]) : "n"(behind));
-                if (wave + 8 * j < n_units) {                   // (wave-uniform)
+                // (the reads are unconditional — behind a wavefront's last real unit they fetch pieces nobody uses; skipping them, with waits that name only the
+                // reads issued, measured slower where most wavefronts have all their units: 22.05 kHz 125 -> 140 us, 11.025 kHz 117 -> 154 us per audio hour)
+                if constexpr (i + AHEAD < NP) load(std::integral_constant<int, i + AHEAD>{});
+                constexpr int behind = (i + 1 < NP && AHEAD >= 1 ? reads_of(i + 1) : 0) + (i + 2 < NP && AHEAD >= 2 ? reads_of(i + 2) : 0) + (i + 3 < NP && AHEAD >= 3 ? reads_of(i + 3) : 0);
+                f4v *q = xq[i % RING];
+                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "n"(behind));
+                if (wave + WAVES * j < n_units) {               // (wave-uniform)
                     if constexpr (w == 0 && pc == 0) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) st_acc[j][u] = 0.0f;
@@ -549,7 +567,7 @@ __global__ __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(2,
                         constexpr int pos = decltype(pcst)::value;
                         if constexpr (16 * pc + pos < NTW) {
 #pragma unroll
-                            for (int u = 0; u < SHARE; ++u) fmac_bcast<pos>(st_acc[j][w * SHARE + u], t[j][w * SHARE + u][pc], xq[i & 3][pos / 4][pos % 4]);
+                            for (int u = 0; u < SHARE; ++u) fmac_bcast<pos>(st_acc[j][w * SHARE + u], t[j][w * SHARE + u][pc], q[pos / 4][pos % 4]);
                         }
                     });
                 }
@@ -567,11 +585,24 @@ __global__ __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(2,
     flush();
 }
 
+// (separate kernels, not one with launch bounds that depend on ROWS / WAVES: hipcc emits no host stub for a kernel template whose bounds are value-dependent)
+#define FA_WIDE_KERNEL(NAME, ROWS_, WAVES_, MINW)                                                                                                     \
+    template <int NV, int SHARE, int CH>                                                                                                              \
+    __global__ __launch_bounds__(64 * WAVES_, MINW) void NAME(const float *__restrict__ x, const float *__restrict__ tt, float *__restrict__ y, const PolyRowsGeom g, \
+                                                              const int2 *__restrict__ gtab, const int tiles, const int64_t m_end, const int64_t k_lim, const int vec_ok, const int dbg) { \
+        poly_rows_wide_body<ROWS_, WAVES_, NV, SHARE, CH>(x, tt, y, g, gtab, tiles, m_end, k_lim, vec_ok, dbg);                                        \
+    }
+FA_WIDE_KERNEL(poly_rows_wide32_kernel, 32, 8, 2)        // one workgroup per CU: 2 wavefronts per SIMD, 256 registers
+FA_WIDE_KERNEL(poly_rows_wide16_kernel, 16, 8, 4)        // two per CU: 4 per SIMD, 128 registers
+FA_WIDE_KERNEL(poly_rows_wide16w10_kernel, 16, 10, 5)    // two of ten wavefronts: 5 per SIMD, 96 registers
+FA_WIDE_KERNEL(poly_rows_wide32w10_kernel, 32, 10, 5)    // the same with 32-row tiles of one phase GROUP (rows of <= 288 floats): groups of 80 k phases = 10 k units (44.1 / 22.05 / 11.025 kHz)
+#undef FA_WIDE_KERNEL
+
 // host side of poly_rows_kernel: the tables of one rate pair, resident on the device with the context
 struct PolyRows {
     bool wide = false;              // served by poly_rows_wide_kernel (32-row tiles, every phase in one item, two LDS buffers)
-    int ch = 0;                     // its units of eight phases per wavefront
-    int smin0 = 0;                  // first staged offset of its single phase group
+    int ch = 0, wide_rows = 0, wide_waves = 0;   // its units per wavefront; rows per tile (32: units of 8 phases, 16: of 16); wavefronts per workgroup
+    int wide_part = 0;              // FA_RESAMPLE_WIDE_PART (read when the tables are built): time PARTS of the kernel — results are wrong for any value but 0
     PolyRowsGeom g{};
     int nv = 0;                     // 16-byte reads per phase window
     size_t lds = 0;
@@ -581,7 +612,7 @@ struct PolyRows {
     ~PolyRows() { if (d_tables) (void)hipFree(d_tables); }
 };
 void poly_rows_free(void *p) { delete static_cast<PolyRows *>(p); }
-bool wide_instance(int nv, int share, int ch);
+bool wide_instance(int rows, int waves, int nv, int share, int ch);
 
 // Geometry + tables (resample_geom.h); false when the pair does not suit the kernel (then poly_lds_kernel serves it).
 bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt) {
@@ -593,19 +624,34 @@ bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down,
     // rows_geometry from splitting —, rows of at most 512 floats, and one of the instantiated (window, sharing, units per wavefront) combinations
     R.wide = false;
     if (budget == 0 && getenv("FA_RESAMPLE_NO_WIDE") == nullptr) {
-        PolyRowsGeom g2{};
-        int nv2 = 0;
-        std::vector<int> gtab2;
-        std::vector<float> tt2;
-        if (fa::rows_geometry(g2, nv2, h, up, down, pre_remove, gtab2, tt2, size_t{1} << 30, share_max) && g2.groups == 1 && g2.sld * kWideRows <= kWideBuf) {
-            const int ch = ((up + 7) / 8 + kRowsWaves - 1) / kRowsWaves;
-            if (wide_instance(nv2, g2.share, ch)) {
-                R.g = g2; R.nv = nv2; R.ch = ch; gtab.swap(gtab2); tt.swap(tt2);
-                R.smin0 = gtab[0];
-                R.wide = true;
-                R.lds = 0; R.up = up; R.down = down;     // (static LDS)
-                return true;
-            }
+        // candidates, in order: {rows, wavefronts, LDS budget of rows_geometry (per 64 rows: it decides the phase groups)}.  FA_RESAMPLE_WIDE = "rows:waves" picks
+        // one.  Measured per audio hour (profiles/r05_resample_wide_steps.json): 16-row tiles, 8 wavefronts, two workgroups per CU — 44.1 kHz 233 - 250 us,
+        // 22.05 kHz 128, 11.025 kHz 116; 32-row tiles with one workgroup per CU 243 - 262 / 152 / (no instance); 32-row tiles of one phase GROUP (80 k phases:
+        // rows of <= 288 floats, two workgroups of ten wavefronts, no LDS bank conflicts, every wavefront the same number of units) 245 - 257 / 152 / 159.
+        // The 16-row form wins or ties in spite of its 2-way LDS bank conflicts (two phase quads with different window offsets share a ds_read_b128 lane group)
+        struct Cand { int rows, waves; size_t budget; };
+        const size_t group_budget = size_t{64} * 288 * 4;      // (rows_geometry budgets 64 rows)
+        std::vector<Cand> cands = {{16, 8, size_t{1} << 30}, {32, 10, group_budget}, {32, 8, size_t{1} << 30}};
+        if (const char *e = getenv("FA_RESAMPLE_WIDE")) {
+            int r_ = 0, w_ = 0;
+            if (sscanf(e, "%d:%d", &r_, &w_) == 2) cands = {{r_, w_, r_ == 32 && w_ == 10 ? group_budget : size_t{1} << 30}};
+        }
+        for (const Cand &c : cands) {
+            PolyRowsGeom g2{};
+            int nv2 = 0;
+            std::vector<int> gtab2;
+            std::vector<float> tt2;
+            if (!fa::rows_geometry(g2, nv2, h, up, down, pre_remove, gtab2, tt2, c.budget, share_max)) continue;
+            if (g2.sld > wide_row_floats(c.rows, c.waves) || g2.groups > 8) continue;
+            if (!(c.rows == 32 && c.waves == 10) && g2.groups != 1) continue;
+            const int pu = 4 * 64 / c.rows, units = (g2.ppg + pu - 1) / pu, ch = (units + c.waves - 1) / c.waves;
+            if (c.waves == 10 && units % 10 != 0) continue;              // (ten wavefronts only where they divide the units)
+            if (!wide_instance(c.rows, c.waves, nv2, g2.share, ch)) continue;
+            R.g = g2; R.nv = nv2; R.ch = ch; R.wide_rows = c.rows; R.wide_waves = c.waves; gtab.swap(gtab2); tt.swap(tt2);
+            R.wide = true;
+            R.wide_part = getenv("FA_RESAMPLE_WIDE_PART") ? atoi(getenv("FA_RESAMPLE_WIDE_PART")) : 0;
+            R.lds = 0; R.up = up; R.down = down;     // (static LDS)
+            return true;
         }
     }
     if (!fa::rows_geometry(R.g, R.nv, h, up, down, pre_remove, gtab, tt, budget, share_max)) return false;
@@ -623,24 +669,35 @@ void poly_rows_launch_it(fa_ctx *ctx, const PolyRows &R, const float *d_x, float
     const int64_t tiles8 = (tiles + 7) / 8 * 8;   // whole rounds of the 8 XCDs: the index -> (tile, group) map of the kernel
     hipLaunchKernelGGL((poly_rows_kernel<NV, IT, SHARE, HALVES>), dim3(static_cast<unsigned>(tiles8 * R.g.groups)), dim3(kRowsThreads), R.lds, ctx->stream, d_x, tt, gtab, d_y, R.g, tiles, m_end, vec_ok);
 }
-// the instantiated combinations of poly_rows_wide_kernel: {16-byte reads per window, phases per window, units per wavefront}
-//   44.1 -> 16 kHz {16, 2, 3}, 22.05 -> 16 kHz {10, 4, 5}, 11.025 -> 16 kHz {8, 4, 10}, 37.8 -> 16 kHz {16, 4, 2}; other pairs: poly_rows_kernel
-#define FA_WIDE_INSTANCES(X) X(16, 2, 3) X(10, 4, 5) X(8, 4, 10) X(16, 4, 2)
-bool wide_instance(int nv, int share, int ch) {
-#define FA_WIDE_IS(V, S, C) if (nv == V && share == S && ch == C) return true;
+// the instantiated combinations of the wide kernels: {rows per tile, wavefronts, 16-byte reads per window, phases per window, units per wavefront}
+//   44.1 -> 16 kHz: windows {16, 2}, 10 units of 16 phases or 20 of 8; 22.05 -> 16 kHz {10, 4}, 20 or 40 units; 11.025 -> 16 kHz {8, 4}, 40 units; 37.8 -> 16 kHz {16, 4}, 5 units;
+//   other pairs: poly_rows_kernel
+#define FA_WIDE_INSTANCES(X) X(32, 8, 16, 2, 3) X(32, 8, 10, 4, 5) X(16, 8, 16, 2, 2) X(16, 8, 10, 4, 3) X(16, 8, 8, 4, 5) X(16, 8, 16, 4, 1) X(16, 10, 16, 2, 1) X(16, 10, 10, 4, 2) X(16, 10, 8, 4, 4) \
+    X(32, 10, 16, 2, 1) X(32, 10, 10, 4, 2) X(32, 10, 8, 4, 4) X(32, 10, 16, 4, 1)
+bool wide_instance(int rows, int waves, int nv, int share, int ch) {
+#define FA_WIDE_IS(R_, W_, V, S, C) if (rows == R_ && waves == W_ && nv == V && share == S && ch == C) return true;
     FA_WIDE_INSTANCES(FA_WIDE_IS)
 #undef FA_WIDE_IS
     return false;
 }
-void poly_rows_wide_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end, int64_t frames, int smin) {
+void poly_rows_wide_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, float *d_y, int64_t tiles, int64_t m_end, int64_t frames) {
+    const int2 *gtab = static_cast<const int2 *>(R.d_tables);
     const float *tt = reinterpret_cast<const float *>(static_cast<const char *>(R.d_tables) + R.tt_offset);
     const int vec_ok = R.up % 4 == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0 ? 1 : 0;
-    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(tiles, 256));   // one resident workgroup per CU (128 KB of LDS)
-    const int dbg = getenv("FA_DBG") ? atoi(getenv("FA_DBG")) : 0;
-#define FA_WIDE_GO(V, S, C)                                                                                                                        \
-    if (R.nv == V && R.g.share == S && R.ch == C) {                                                                                                \
-        hipLaunchKernelGGL((poly_rows_wide_kernel<V, S, C>), dim3(grid), dim3(kRowsThreads), 0, ctx->stream, d_x, tt, d_y, R.g, smin, static_cast<int>(tiles), m_end, \
-                           frames - 4, vec_ok, dbg);                                                                                              \
+    // the resident workgroups: one (128 KB of LDS) or two (64 / 72 KB) per CU, in whole sets of 8 x groups (kernel: workgroup -> XCD, group, tile chain)
+    const int per_cu = R.wide_rows == 32 && R.wide_waves == 8 ? 1 : 2, set = 8 * R.g.groups;
+    int64_t sets = 256 * per_cu / set;
+    sets = std::max<int64_t>(1, std::min<int64_t>(sets, (tiles + 7) / 8));
+    const unsigned grid = static_cast<unsigned>(sets * set);
+    const int dbg = R.wide_part;
+    const int n_tiles = static_cast<int>(tiles);
+    const int64_t k_lim = frames - 4;
+#define FA_WIDE_GO(R_, W_, V, S, C)                                                                                                                 \
+    if (R.wide_rows == R_ && R.wide_waves == W_ && R.nv == V && R.g.share == S && R.ch == C) {                                                     \
+        if constexpr (R_ == 32 && W_ == 8) hipLaunchKernelGGL((poly_rows_wide32_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg);   \
+        else if constexpr (R_ == 32) hipLaunchKernelGGL((poly_rows_wide32w10_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg); \
+        else if constexpr (W_ == 8) hipLaunchKernelGGL((poly_rows_wide16_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg); \
+        else hipLaunchKernelGGL((poly_rows_wide16w10_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg); \
         return;                                                                                                                                    \
     }
     FA_WIDE_INSTANCES(FA_WIDE_GO)
@@ -851,12 +908,12 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
         if (!decim && !simple && ctx->poly_rows && getenv("FA_RESAMPLE_NO_ROWS") == nullptr) {
             const PolyRows &R = *static_cast<const PolyRows *>(ctx->poly_rows);
             const PolyRowsGeom &G = R.g;
-            const int tile_rows = R.wide ? kWideRows : 64;
+            const int tile_rows = R.wide ? R.wide_rows : 64;
             int64_t tiles = fa::rows_tiles(G, frames, n_out, tile_rows);       // tiles whose staged inputs all exist (resample_geom.h)
             const int64_t per_tile = static_cast<int64_t>(tile_rows) * G.up;
             if (tiles > 0 && (tiles + 8) * G.groups < (1LL << 31)) {
                 const int64_t m_stop = std::min(n_out, G.m_begin + tiles * per_tile);
-                if (R.wide) poly_rows_wide_launch(ctx, R, d_x, d_y, tiles, m_stop, frames, R.smin0);
+                if (R.wide) poly_rows_wide_launch(ctx, R, d_x, d_y, tiles, m_stop, frames);
                 else switch (R.nv) {
 #define FA_ROWS_CASE(V) case V: poly_rows_launch<V>(ctx, R, d_x, d_y, tiles, m_stop, frames); break;
                     FA_ROWS_CASE(4) FA_ROWS_CASE(6) FA_ROWS_CASE(8) FA_ROWS_CASE(10) FA_ROWS_CASE(12) FA_ROWS_CASE(14) FA_ROWS_CASE(16) FA_ROWS_CASE(32)

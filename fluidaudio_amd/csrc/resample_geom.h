@@ -102,7 +102,7 @@ inline bool rows_geometry(PolyRowsGeom &g, int &nv_out, const std::vector<float>
         gtab[2 * gq + 1] = span_of(a0, a1);
         smax = std::max(smax, gtab[2 * gq] + gtab[2 * gq + 1]);
     }
-    tt.assign(static_cast<size_t>(up + 8) * kRowsTT, 0.0f);              // empty rows behind the last phase: poly_rows_wide_kernel fetches units of eight phases without clamps
+    tt.assign(static_cast<size_t>(up + 16) * kRowsTT, 0.0f);             // empty rows behind the last phase: poly_rows_wide_kernel fetches units of 8 / 16 phases without clamps
     for (int ph = 0; ph < up; ++ph) {
         const int q = ph - ph % share;                                  // (groups start at multiples of 4: a shared window never straddles two groups)
         const int base4 = off[q] & ~3, a = off[ph] - base4;

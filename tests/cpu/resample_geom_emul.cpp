@@ -27,7 +27,7 @@ void poly_simple(const float *x, int64_t n_in, const float *h, int64_t h_len, in
 
 // returns 0 and the covered range, or a negative code: -1 pair not served, -2 staged index out of the signal, -3 window read outside the staged
 // span, -4 an output written twice / outside [m_begin, m_stop), -5 an output of the range not written, -6 misaligned window read,
-// -7 the phases of a shared window disagree about it, -8 a tap at a window position the kernel does not multiply, -10 a row-count other than 64 with more than one phase group
+// -7 the phases of a shared window disagree about it, -8 a tap at a window position the kernel does not multiply
 int rows_emulate(const float *x, int64_t n_in, const float *h, int64_t h_len, int up, int down, int64_t pre_remove, int64_t n_out, float *y, int64_t *m_lo, int64_t *m_hi,
                  int32_t *info /* nv, groups, ppg, sld, tiles, share */, int share_max, int64_t lds_budget, int rows) {
     fa::PolyRowsGeom g{};
@@ -37,7 +37,6 @@ int rows_emulate(const float *x, int64_t n_in, const float *h, int64_t h_len, in
     std::vector<float> hv(h, h + h_len);
     *m_lo = *m_hi = 0;
     if (!fa::rows_geometry(g, nv, hv, up, down, pre_remove, gtab, tt, static_cast<size_t>(lds_budget), share_max)) return -1;
-    if (rows != 64 && g.groups != 1) return -10;                       // poly_rows_wide_kernel: every phase of a tile in one item
     const int64_t tiles = fa::rows_tiles(g, n_in, n_out, rows);
     info[0] = nv; info[1] = g.groups; info[2] = g.ppg; info[3] = g.sld; info[4] = static_cast<int32_t>(tiles); info[5] = g.share;
     if (tiles <= 0) return 0;

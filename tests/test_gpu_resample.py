@@ -93,6 +93,33 @@ def test_rows_kernel_actually_serves_the_common_non_integer_pairs(fa, gpu_ctx, m
         assert t_rows < 0.85 * t_lds, (up, down, t_rows, t_lds)
 
 
+@pytest.mark.parametrize("form", ["16:8", "32:8", "32:10", "one-tile-per-workgroup"])
+@pytest.mark.parametrize("up,down,n", [(160, 441, 1000003), (160, 441, 40000), (160, 441, 15000), (320, 441, 300007), (640, 441, 150000), (80, 189, 200000)])
+def test_every_row_kernel_form_equals_simple_kernel(fa, monkeypatch, form, up, down, n):
+    """Round 5: the persistent double-buffered row kernels (poly_rows_wide_body: 16-row tiles with two workgroups per CU — the default —, 32-row tiles with one,
+    32-row tiles of one phase group with ten wavefronts; FA_RESAMPLE_WIDE picks the form when a context builds its tables) and the one-tile-per-workgroup
+    kernel they replaced for 44.1 / 22.05 / 11.025 / 37.8 kHz produce the bits of the one-thread-per-output kernel: several tiles per workgroup, a ragged
+    last tile, signals shorter than one tile."""
+    if form == "one-tile-per-workgroup":
+        monkeypatch.setenv("FA_RESAMPLE_NO_WIDE", "1")
+    else:
+        monkeypatch.setenv("FA_RESAMPLE_WIDE", form)
+    rng = np.random.default_rng(n + up)
+    x = (0.4 * np.sin(2 * np.pi * 440 * np.arange(n) / 16000.0) + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    ctx = fa.Context(0)                     # the tables (and the kernel form) of a pair are fixed when a context first resamples it
+    try:
+        got = fa.resample_poly(x, up, down, ctx=ctx)
+    finally:
+        ctx.close()
+    monkeypatch.setenv("FA_RESAMPLE_SIMPLE", "1")
+    ref_ctx = fa.Context(0)
+    try:
+        ref = fa.resample_poly(x, up, down, ctx=ref_ctx)
+    finally:
+        ref_ctx.close()
+    np.testing.assert_array_equal(got, ref)
+
+
 @pytest.mark.parametrize("up,down", [(160, 441), (320, 441)])
 def test_rows_kernel_on_non_finite_input(fa, gpu_ctx, monkeypatch, up, down):
     """The row-tiled kernel multiplies a register window by a table row whose unused positions hold ZERO taps (the shift of a phase inside its —

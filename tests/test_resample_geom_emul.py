@@ -32,9 +32,10 @@ def signal_of(n, seed):
 
 @pytest.mark.parametrize("up,down,n", [(160, 441, 132300), (160, 441, 40000), (160, 441, 37000), (160, 441, 28223), (320, 441, 90007), (640, 441, 60000), (160, 147, 70000),
                                        (16, 15, 9000), (8, 7, 3000), (147, 160, 50000), (80, 441, 100000), (12, 5, 4000), (9, 8, 1000), (441, 160, 30000)])
-@pytest.mark.parametrize("share_max,budget,rows", [(4, 0, 64), (2, 0, 64), (1, 0, 64), (4, 1 << 30, 32), (4, 1 << 30, 16)])
+@pytest.mark.parametrize("share_max,budget,rows", [(4, 0, 64), (2, 0, 64), (1, 0, 64), (4, 1 << 30, 32), (4, 1 << 30, 16), (4, 73728, 32)])
 def test_rows_kernel_indexing_on_the_library_geometry(fa, emul, up, down, n, share_max, budget, rows):
-    """budget 2^30, rows 32 / 16: the geometry of poly_rows_wide_kernel (every phase of a tile of `rows` rows in one item).  share_max: the most consecutive phases that may read one register window (round 5; 1 = every phase its own window, the round-4 reads)."""
+    """budget 2^30, rows 32 / 16: the geometry of the wide kernels (every phase of a tile of `rows` rows in one item); budget 72 KB, rows 32: their grouped
+    form (phase groups whose 32 rows of at most 288 floats fit two buffers twice per CU).  share_max: the most consecutive phases that may read one register window (round 5; 1 = every phase its own window, the round-4 reads)."""
     from scipy import signal
     taps, pre = fa.poly_taps(up, down)
     x = signal_of(n, n)
@@ -43,9 +44,7 @@ def test_rows_kernel_indexing_on_the_library_geometry(fa, emul, up, down, n, sha
     lo, hi = C.c_int64(), C.c_int64()
     info = np.zeros(6, np.int32)
     rc = emul.rows_emulate(x, n, taps, taps.size, up, down, pre, n_out, y, C.byref(lo), C.byref(hi), info, share_max, budget, rows)
-    assert rc in (0, -1) or (rc == -10 and rows != 64), (rc, info.tolist())
-    if rc == -10:
-        return          # the pair needs phase groups: not a pair of the wide kernel
+    assert rc in (0, -1), (rc, info.tolist())
     if rc == -1:
         assert (taps.size + up - 1) // up + 3 > 128 or up < 8, "only pairs whose phase does not fit a table row may be refused"
         return
