@@ -417,12 +417,12 @@ __global__ __launch_bounds__(kRowsThreads) FA_ROWS_ATTR void poly_rows_kernel(co
 constexpr int wide_row_floats(int rows, int waves) { return rows == 32 && waves == 10 ? 288 : 512; }
 template <int ROWS, int WAVES, int NV, int SHARE, int CH>
 __device__ __forceinline__ void poly_rows_wide_body(const float *__restrict__ x, const float *__restrict__ tt, float *__restrict__ y, const PolyRowsGeom g_,
-                                                    const int2 *__restrict__ gtab, const int tiles_, const int64_t m_end_, const int64_t k_lim_, const int vec_ok_, const int dbg_) {
+                                                    const int2 *__restrict__ gtab, const int tiles_, const int64_t m_end_, const int64_t k_lim_, const int vec_ok_, const int dbg_, const int rot) {
     constexpr int kWideBuf = ROWS * wide_row_floats(ROWS, WAVES), PU = 4 * 64 / ROWS;     // floats per LDS buffer; phases per unit
     __shared__ float buf_a[kWideBuf];
     __shared__ float buf_b[kWideBuf];
     constexpr int NTW = 4 * NV, NQ = (NTW + 15) / 16, NW = 4 / SHARE;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l16 = lane & 15, quad = lane / ROWS, r = lane % ROWS;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l16 = lane & 15, quad = lane / ROWS;
     // the arguments the loop uses, as values the compiler cannot re-load: under register pressure it would fetch kernel arguments again INSIDE the loop, and a
     // scalar load outstanding next to LDS reads leaves it only s_waitcnt lgkmcnt(0) (scalar loads return out of order) — the read pipeline below gone
     int64_t m_end = m_end_, k_lim = k_lim_, k_begin = g_.k_begin, m_begin = g_.m_begin;
@@ -440,7 +440,7 @@ __device__ __forceinline__ void poly_rows_wide_body(const float *__restrict__ x,
     if (qb / groups >= static_cast<int>(gridDim.x) / (8 * groups)) return;      // (a grid that is not a multiple of 8 groups: the workgroups behind the last whole set)
     // this wavefront's units: table rows (the table has eight empty rows behind the last phase) and LDS window addresses, for the whole kernel
     float t[CH][4][NQ];
-    int xa[CH][NW];
+    int xa[CH][NW], rj[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
         const int unit = wave + WAVES * j < n_units ? wave + WAVES * j : n_units - 1;
@@ -449,8 +449,17 @@ __device__ __forceinline__ void poly_rows_wide_body(const float *__restrict__ x,
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int qv = 0; qv < NQ; ++qv) t[j][u][qv] = row[u * fa::kRowsTT + 16 * qv + l16];
+        int woff[NW];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) xa[j][w] = 4 * (r * g.sld - smin + __float_as_int(row[w * SHARE * fa::kRowsTT + fa::kRowsOffPos]));     // (bytes)
+        for (int w = 0; w < NW; ++w) woff[w] = __float_as_int(row[w * SHARE * fa::kRowsTT + fa::kRowsOffPos]) - smin;
+        // the row of a lane.  ROWS = 32: lane % 32.  ROWS = 16: a ds_read_b128 is served in groups of 16 lanes that belong to TWO phase quads, whose windows start
+        // at different offsets — 16-byte slot (row sld / 4 + offset / 4) mod 16: the rows of a group are all different (sld / 4 is odd), the two offsets shift
+        // eight of them onto the other eight's slots, 2-way conflicts on every read (profiles/r05_resample_wide_w16_8_dbg0_pmc.json: half of the LDS cycles).  A quad
+        // therefore takes its rows ROTATED by rot (-offset / 4) with rot = (sld / 4)^-1 mod 16: lane i of every quad then reads slot i sld / 4 of the unit's first
+        // window — conflict-free; a unit's second window (two phases further: 1 or 2 slots, not always the same for two quads) keeps some
+        if constexpr (ROWS == 16) rj[j] = ((lane & 15) + rot * (16 - ((woff[0] >> 2) & 15))) & 15; else rj[j] = lane % ROWS;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) xa[j][w] = 4 * (rj[j] * g.sld + woff[w]);     // (bytes)
     }
     // staging: piece i (16 bytes) of the linear LDS image = row i / (sld / 4), floats 4 (i % (sld / 4)) .. + 3 of that row; the pieces behind the 32nd row
     // (8 sld < 4096) re-read the last one into the buffer's unused tail — every wavefront issues the same eight requests, no branches.  Rows start at odd
@@ -490,6 +499,7 @@ __device__ __forceinline__ void poly_rows_wide_body(const float *__restrict__ x,
             for (int qv = 0; qv < NQ; ++qv) asm volatile("" : "+v"(t[j][u][qv]));
 #pragma unroll
         for (int w = 0; w < NW; ++w) asm volatile("" : "+v"(xa[j][w]));
+        asm volatile("" : "+v"(rj[j]));
     }
     float st_acc[CH][4];
     int st_tile = -1;
@@ -498,12 +508,12 @@ __device__ __forceinline__ void poly_rows_wide_body(const float *__restrict__ x,
     f4v xq[RING][4] = {};                                   // the ring of window quarters (see the arithmetic below)
     auto flush = [&]() {
         if (st_tile < 0) return;
-        const int64_t m_row = g.m_begin + (static_cast<int64_t>(st_tile) * ROWS + r) * g.up;
+        const int64_t m_tile = g.m_begin + static_cast<int64_t>(st_tile) * ROWS * g.up;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             if (wave + WAVES * j >= n_units) break;
             const int ph = ph0 + PU * (wave + WAVES * j) + 4 * quad;
-            const int64_t m = m_row + ph;
+            const int64_t m = m_tile + rj[j] * g.up + ph;
             if (vec_ok && ph + 3 < ph1 && m + 3 < m_end) {
                 f4v o = {st_acc[j][0], st_acc[j][1], st_acc[j][2], st_acc[j][3]};
                 *reinterpret_cast<f4v *>(y + m) = o;
@@ -589,8 +599,8 @@ __device__ __forceinline__ void poly_rows_wide_body(const float *__restrict__ x,
 #define FA_WIDE_KERNEL(NAME, ROWS_, WAVES_, MINW)                                                                                                     \
     template <int NV, int SHARE, int CH>                                                                                                              \
     __global__ __launch_bounds__(64 * WAVES_, MINW) void NAME(const float *__restrict__ x, const float *__restrict__ tt, float *__restrict__ y, const PolyRowsGeom g, \
-                                                              const int2 *__restrict__ gtab, const int tiles, const int64_t m_end, const int64_t k_lim, const int vec_ok, const int dbg) { \
-        poly_rows_wide_body<ROWS_, WAVES_, NV, SHARE, CH>(x, tt, y, g, gtab, tiles, m_end, k_lim, vec_ok, dbg);                                        \
+                                                              const int2 *__restrict__ gtab, const int tiles, const int64_t m_end, const int64_t k_lim, const int vec_ok, const int dbg, const int rot) { \
+        poly_rows_wide_body<ROWS_, WAVES_, NV, SHARE, CH>(x, tt, y, g, gtab, tiles, m_end, k_lim, vec_ok, dbg, rot);                                        \
     }
 FA_WIDE_KERNEL(poly_rows_wide32_kernel, 32, 8, 2)        // one workgroup per CU: 2 wavefronts per SIMD, 256 registers
 FA_WIDE_KERNEL(poly_rows_wide16_kernel, 16, 8, 4)        // two per CU: 4 per SIMD, 128 registers
@@ -602,6 +612,7 @@ FA_WIDE_KERNEL(poly_rows_wide32w10_kernel, 32, 10, 5)    // the same with 32-row
 struct PolyRows {
     bool wide = false;              // served by poly_rows_wide_kernel (32-row tiles, every phase in one item, two LDS buffers)
     int ch = 0, wide_rows = 0, wide_waves = 0;   // its units per wavefront; rows per tile (32: units of 8 phases, 16: of 16); wavefronts per workgroup
+    bool wide_no_rot = false;
     int wide_part = 0;              // FA_RESAMPLE_WIDE_PART (read when the tables are built): time PARTS of the kernel — results are wrong for any value but 0
     PolyRowsGeom g{};
     int nv = 0;                     // 16-byte reads per phase window
@@ -650,6 +661,7 @@ bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down,
             R.g = g2; R.nv = nv2; R.ch = ch; R.wide_rows = c.rows; R.wide_waves = c.waves; gtab.swap(gtab2); tt.swap(tt2);
             R.wide = true;
             R.wide_part = getenv("FA_RESAMPLE_WIDE_PART") ? atoi(getenv("FA_RESAMPLE_WIDE_PART")) : 0;
+            R.wide_no_rot = getenv("FA_RESAMPLE_WIDE_NO_ROT") != nullptr;
             R.lds = 0; R.up = up; R.down = down;     // (static LDS)
             return true;
         }
@@ -690,14 +702,17 @@ void poly_rows_wide_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, flo
     sets = std::max<int64_t>(1, std::min<int64_t>(sets, (tiles + 7) / 8));
     const unsigned grid = static_cast<unsigned>(sets * set);
     const int dbg = R.wide_part;
+    int rot = 0;                                                     // (sld / 4)^-1 mod 16 (sld / 4 is odd); FA_RESAMPLE_WIDE_NO_ROT (tables' build time): rows unrotated
+    for (int c = 1; c < 16; c += 2) if ((c * (R.g.sld / 4)) % 16 == 1) rot = c;
+    if (R.wide_no_rot) rot = 0;
     const int n_tiles = static_cast<int>(tiles);
     const int64_t k_lim = frames - 4;
 #define FA_WIDE_GO(R_, W_, V, S, C)                                                                                                                 \
     if (R.wide_rows == R_ && R.wide_waves == W_ && R.nv == V && R.g.share == S && R.ch == C) {                                                     \
-        if constexpr (R_ == 32 && W_ == 8) hipLaunchKernelGGL((poly_rows_wide32_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg);   \
-        else if constexpr (R_ == 32) hipLaunchKernelGGL((poly_rows_wide32w10_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg); \
-        else if constexpr (W_ == 8) hipLaunchKernelGGL((poly_rows_wide16_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg); \
-        else hipLaunchKernelGGL((poly_rows_wide16w10_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg); \
+        if constexpr (R_ == 32 && W_ == 8) hipLaunchKernelGGL((poly_rows_wide32_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg, rot);   \
+        else if constexpr (R_ == 32) hipLaunchKernelGGL((poly_rows_wide32w10_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg, rot); \
+        else if constexpr (W_ == 8) hipLaunchKernelGGL((poly_rows_wide16_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg, rot); \
+        else hipLaunchKernelGGL((poly_rows_wide16w10_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg, rot); \
         return;                                                                                                                                    \
     }
     FA_WIDE_INSTANCES(FA_WIDE_GO)

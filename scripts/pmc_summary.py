@@ -37,7 +37,7 @@ def main():
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
             if k in out:
                 res[k + "_frac_of_wave_cycles"] = out[k]["per_dispatch"] / wc
-    if "SQ_LDS_IDX_ACTIVE" in out and "SQ_LDS_BANK_CONFLICT" in out:
+    if "SQ_LDS_IDX_ACTIVE" in out and "SQ_LDS_BANK_CONFLICT" in out and out["SQ_LDS_IDX_ACTIVE"]["per_dispatch"] > 0:
         res["lds_bank_conflict_frac"] = out["SQ_LDS_BANK_CONFLICT"]["per_dispatch"] / out["SQ_LDS_IDX_ACTIVE"]["per_dispatch"]
     print(json.dumps(res, indent=1))
 
