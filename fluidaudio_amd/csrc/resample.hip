@@ -413,12 +413,13 @@ __global__ __launch_bounds__(kRowsThreads) FA_ROWS_ATTR void poly_rows_kernel(co
 // Same tables, same order of additions: the bits of poly_rows_kernel.
 // ROWS = rows of a tile: 32 (one workgroup per CU, two buffers of 64 KB, lanes = 2 phase quads x 32 rows) or 16 (two workgroups per CU, buffers of 32 KB,
 // lanes = 4 phase quads x 16 rows — one quad per DPP row); a UNIT is the 4 x 64 / ROWS phases one wavefront-instruction covers.
-// floats per LDS row, at most: two buffers of 32 x 512 floats = 128 KB (one workgroup per CU), of 16 x 512 = 64 KB or of 32 x 288 = 72 KB (two per CU)
-constexpr int wide_row_floats(int rows, int waves) { return rows == 32 && waves == 10 ? 288 : 512; }
+// floats per LDS row, at most: two buffers of 32 x 512 floats = 128 KB (one workgroup per CU), of 16 x 512 = 64 KB or of 32 x 288 = 72 KB (two per CU);
+// 16 x 576 for windows of 32 reads: 88.2 -> 16 kHz stages 564 floats per row
+constexpr int wide_row_floats(int rows, int waves, int nv) { return rows == 32 ? (waves == 10 ? 288 : 512) : (nv == 32 ? 576 : 512); }
 template <int ROWS, int WAVES, int NV, int SHARE, int CH>
 __device__ __forceinline__ void poly_rows_wide_body(const float *__restrict__ x, const float *__restrict__ tt, float *__restrict__ y, const PolyRowsGeom g_,
                                                     const int2 *__restrict__ gtab, const int tiles_, const int64_t m_end_, const int64_t k_lim_, const int vec_ok_, const int dbg_, const int rot) {
-    constexpr int kWideBuf = ROWS * wide_row_floats(ROWS, WAVES), PU = 4 * 64 / ROWS;     // floats per LDS buffer; phases per unit
+    constexpr int kWideBuf = ROWS * wide_row_floats(ROWS, WAVES, NV), PU = 4 * 64 / ROWS;     // floats per LDS buffer; phases per unit
     __shared__ float buf_a[kWideBuf];
     __shared__ float buf_b[kWideBuf];
     constexpr int NTW = 4 * NV, NQ = (NTW + 15) / 16, NW = 4 / SHARE;
@@ -653,7 +654,7 @@ bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down,
             std::vector<int> gtab2;
             std::vector<float> tt2;
             if (!fa::rows_geometry(g2, nv2, h, up, down, pre_remove, gtab2, tt2, c.budget, share_max)) continue;
-            if (g2.sld > wide_row_floats(c.rows, c.waves) || g2.groups > 8) continue;
+            if (g2.sld > wide_row_floats(c.rows, c.waves, nv2) || g2.groups > 8) continue;
             if (!(c.rows == 32 && c.waves == 10) && g2.groups != 1) continue;
             const int pu = 4 * 64 / c.rows, units = (g2.ppg + pu - 1) / pu, ch = (units + c.waves - 1) / c.waves;
             if (c.waves == 10 && units % 10 != 0) continue;              // (ten wavefronts only where they divide the units)
@@ -683,8 +684,8 @@ void poly_rows_launch_it(fa_ctx *ctx, const PolyRows &R, const float *d_x, float
 }
 // the instantiated combinations of the wide kernels: {rows per tile, wavefronts, 16-byte reads per window, phases per window, units per wavefront}
 //   44.1 -> 16 kHz: windows {16, 2}, 10 units of 16 phases or 20 of 8; 22.05 -> 16 kHz {10, 4}, 20 or 40 units; 11.025 -> 16 kHz {8, 4}, 40 units; 37.8 -> 16 kHz {16, 4}, 5 units;
-//   other pairs: poly_rows_kernel
-#define FA_WIDE_INSTANCES(X) X(32, 8, 16, 2, 3) X(32, 8, 10, 4, 5) X(16, 8, 16, 2, 2) X(16, 8, 10, 4, 3) X(16, 8, 8, 4, 5) X(16, 8, 16, 4, 1) X(16, 10, 16, 2, 1) X(16, 10, 10, 4, 2) X(16, 10, 8, 4, 4) \
+//   88.2 -> 16 kHz {32, 1} (two windows' worth of reads per phase), 5 units; other pairs: poly_rows_kernel
+#define FA_WIDE_INSTANCES(X) X(32, 8, 16, 2, 3) X(32, 8, 10, 4, 5) X(16, 8, 16, 2, 2) X(16, 8, 10, 4, 3) X(16, 8, 8, 4, 5) X(16, 8, 16, 4, 1) X(16, 8, 32, 1, 1) X(16, 10, 16, 2, 1) X(16, 10, 10, 4, 2) X(16, 10, 8, 4, 4) \
     X(32, 10, 16, 2, 1) X(32, 10, 10, 4, 2) X(32, 10, 8, 4, 4) X(32, 10, 16, 4, 1)
 bool wide_instance(int rows, int waves, int nv, int share, int ch) {
 #define FA_WIDE_IS(R_, W_, V, S, C) if (rows == R_ && waves == W_ && nv == V && share == S && ch == C) return true;
