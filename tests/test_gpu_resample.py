@@ -120,6 +120,35 @@ def test_every_row_kernel_form_equals_simple_kernel(fa, monkeypatch, form, up, d
     np.testing.assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("up,down,rate", [(160, 441, 44100), (320, 441, 22050), (80, 441, 88200)])
+def test_row_kernels_with_unaligned_device_buffers(fa, gpu_ctx, up, down, rate):
+    """fa_resample_poly_dev takes any 4-byte aligned device pointers: an output that is not 16-byte aligned sends the persistent row kernels through their
+    piecewise stores, an input that is not through another phase of their unaligned 16-byte global -> LDS requests; both equal the aligned call bit for bit."""
+    import ctypes as C
+    import torch
+    n = rate * 7 + 13
+    base = torch.randn(n + 8, device="cuda", dtype=torch.float32) * 0.1
+    n_out = fa.lib().fa_resample_poly_frames(n, up, down)
+    got = C.c_int64()
+
+    def run(x, y):
+        gpu_ctx.check(fa.lib().fa_resample_poly_dev(gpu_ctx.handle, C.c_void_p(x.data_ptr()), n, up, down, C.c_void_p(y.data_ptr()), n_out, C.byref(got)), "resample")
+        gpu_ctx.synchronize()
+        assert got.value == n_out
+
+    x0 = base[4:4 + n].clone()                               # 16-byte aligned copy of the signal
+    y0 = torch.empty(n_out + 8, device="cuda", dtype=torch.float32)
+    run(x0, y0[:n_out])
+    ref = y0[:n_out].clone()
+    for xoff, yoff in ((0, 1), (1, 0), (3, 2), (2, 3)):
+        xb = torch.empty(n + 8, device="cuda", dtype=torch.float32)
+        xb[xoff:xoff + n] = x0
+        yb = torch.full((n_out + 8,), float("nan"), device="cuda", dtype=torch.float32)
+        run(xb[xoff:xoff + n], yb[yoff:yoff + n_out])
+        assert torch.equal(yb[yoff:yoff + n_out], ref), (xoff, yoff)
+        assert torch.isnan(yb[:yoff]).all() and torch.isnan(yb[yoff + n_out:]).all()      # nothing written outside the output
+
+
 @pytest.mark.parametrize("up,down", [(160, 441), (320, 441)])
 def test_rows_kernel_on_non_finite_input(fa, gpu_ctx, monkeypatch, up, down):
     """The row-tiled kernel multiplies a register window by a table row whose unused positions hold ZERO taps (the shift of a phase inside its —
