@@ -121,6 +121,8 @@ template <int K>
 __device__ __forceinline__ void fmac_bcast(float &acc, const float taps16, const float x) {   // acc += taps16[lane K of this lane's row] * x
     asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(taps16), "v"(x), "n"(K));
 }
+// a wave-uniform tap as the SCALAR operand of the multiply-add (written out: left to the compiler, the SLP vectoriser pairs outputs into v_pk_fma_f32 + register moves)
+__device__ __forceinline__ void fmac_scalar(float &acc, const float tap, const float x) { asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(tap), "v"(x)); }
 // compile-time loop (the DPP lane is an immediate of the instruction: the index must be a constant expression, not a value the unroller may or may not
 // fold — the 169 x 8 body of down = 6 is beyond what it unrolls)
 template <int I, int N, class F>
@@ -609,6 +611,119 @@ FA_WIDE_KERNEL(poly_rows_wide16w10_kernel, 16, 10, 5)    // two of ten wavefront
 FA_WIDE_KERNEL(poly_rows_wide32w10_kernel, 32, 10, 5)    // the same with 32-row tiles of one phase GROUP (rows of <= 288 floats): groups of 80 k phases = 10 k units (44.1 / 22.05 / 11.025 kHz)
 #undef FA_WIDE_KERNEL
 
+// ------------------------------------------------------------------------------ integer decimation through LDS tiles (32 / 48 / 64 / 80 / 96 kHz -> 16 kHz)
+// poly_decim_tile_kernel<DOWN> (round 5).  poly_decim_kernel keeps a thread's whole window in registers and fetches it with 16-byte loads that lie R DOWN
+// floats apart from lane to lane: a wavefront's load touches 48 cache lines (DOWN = 3) where a contiguous one touches 8, and the address unit's line rate,
+// not HBM, bounds the kernel (22 loads x 48 lines per wavefront: 193 us of the 270 us per audio hour at 48 kHz; VALU busy 6 %).  Here a persistent workgroup
+// copies the CONTIGUOUS input span of a tile of 256 R outputs global -> LDS (global_load_lds_dwordx4: 16 bytes per lane, 8 lines per request) into one of two
+// buffers while the previous tile is computed from the other one — the scheme of poly_rows_wide_body: two static arrays, one wait + bare barrier per tile,
+// stores at the start of the next period.  Thread i computes the tile's outputs R i .. R i + R - 1 from the LDS floats [R DOWN i, + NIN): R DOWN = 4 x odd, so a
+// wavefront's 16-byte LDS reads are conflict-free; the window streams through two register quarters of 16 positions; a tap is the SCALAR operand of its
+// v_fmac_f32 (plain multiply-adds issue 1.6 x faster than the DPP form, profiles/r05_dpp_rate_ubench.jsonl), fetched through the scalar cache block by block
+// (a block of 16 positions meets 16 + (R - 1) DOWN taps: the pointer passes through an empty statement per block, or the compiler hoists all 127 loads).
+// The same fused multiply-adds in the same order as poly_decim_kernel: ascending input index per output.
+using fa::DecimTile;   // (resample_geom.h: shared with the CPU replay of the tests)
+static_assert(fa::kDecimThreads == kThreads, "one thread per R outputs of a tile");
+template <int DOWN>
+__global__ __launch_bounds__(kThreads) void poly_decim_tile_kernel(const float *__restrict__ x, const float *__restrict__ h, float *__restrict__ y, const int64_t m_begin_,
+                                                                   const int tiles_, const int64_t k_lim_) {
+    typedef DecimTile<DOWN> D;
+    constexpr int R = D::R, NT = D::NT, RS = D::RS, NIN = D::NIN, NB = D::NB, TO = D::TO;
+    __shared__ __attribute__((aligned(16))) float buf_a[D::BUF];
+    __shared__ __attribute__((aligned(16))) float buf_b[D::BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int64_t m_begin = m_begin_, k_lim = k_lim_;
+    int tiles = tiles_, grid = static_cast<int>(gridDim.x);
+    asm volatile("" : "+s"(m_begin), "+s"(k_lim), "+s"(tiles), "+s"(grid));      // (no kernel argument re-loaded inside the loop: see poly_rows_wide_body)
+    typedef const float __attribute__((address_space(4))) *c_f32;
+    auto stage = [&](const int tile, float *buf) {
+        const int64_t k0 = (m_begin + static_cast<int64_t>(tile) * TO - 10) * DOWN;      // first input of the tile (a multiple of 4: m_begin = 10 mod 4)
+        const float *src = x + k0;
+        const int64_t lim64 = k_lim - k0;
+        const int lim = lim64 < 0x3fffffff ? static_cast<int>(lim64) : 0x3fffffff;
+        constexpr int NREQ = (D::PIECES + 63) / 64;                          // requests of 64 pieces, dealt round-robin to the four wavefronts
+#pragma unroll
+        for (int it = 0; it < (NREQ + 3) / 4; ++it) {
+            const int req = it * 4 + wave;
+            const int off = 4 * (req * 64 + lane);
+            if (req < NREQ) __builtin_amdgcn_global_load_lds(src + (off < lim ? off : lim), buf + 256 * req, 16, 0, 2);
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile >= tiles) return;
+    stage(tile, buf_a);
+    float st_acc[R];
+    int st_tile = -1;
+    auto flush = [&]() {
+        if (st_tile < 0) return;
+        float *dst = y + m_begin + static_cast<int64_t>(st_tile) * TO + R * tid;      // 8-byte aligned (m_begin = 2 mod 4, R even) or 4-byte (R = 3)
+        if constexpr (R == 4) { f4u o; o.x = st_acc[0]; o.y = st_acc[1]; o.z = st_acc[2]; o.w = st_acc[3]; *reinterpret_cast<f4u *>(dst) = o; }
+        else if constexpr (R % 2 == 0) {
+#pragma unroll
+            for (int j = 0; j < R; j += 2) *reinterpret_cast<float2 *>(dst + j) = make_float2(st_acc[j], st_acc[j + 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) dst[j] = st_acc[j];
+        }
+        st_tile = -1;
+    };
+    auto step = [&](const float *mine, float *other) {
+        const int tile_n = tile + grid;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's pieces of the present tile have landed ...
+        __builtin_amdgcn_s_barrier();                       // ... everybody's have, and nobody reads the other buffer any more
+        asm volatile("" ::: "memory");
+        flush();
+        if (tile_n < tiles) stage(tile_n, other);
+        // the LDS reads and their waits are written out (see poly_rows_wide_body: the compiler would wait for the next tile's requests in front of the first
+        // read — it cannot know that the wait above already covered this buffer's); a scalar tap load the compiler adds in between only lengthens a wait
+        const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) float *) mine)) + 4u * static_cast<unsigned>(tid * RS);
+        float acc[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) acc[j] = 0.0f;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v q[2][4] = {};
+        auto load = [&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            f4v *d = q[b & 1];
+            const unsigned a = addr;                                         // (a local of this lambda: hipcc rejects captured variables as asm operands of a generic lambda)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d[0]) : "v"(a), "n"(64 * b));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d[1]) : "v"(a), "n"(64 * b + 16));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d[2]) : "v"(a), "n"(64 * b + 32));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d[3]) : "v"(a), "n"(64 * b + 48));
+        };
+        load(std::integral_constant<int, 0>{});
+        static_for<0, NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            if constexpr (b + 1 < NB) load(std::integral_constant<int, b + 1>{});
+            f4v *d = q[b & 1];
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "n"(b + 1 < NB ? 4 : 0));
+            c_f32 taps = (c_f32) h;
+            asm volatile("" : "+s"(taps));                                   // (this block's taps are fetched here, not with everybody else's at the top)
+            static_for<0, 16>([&](auto pc) {
+                constexpr int p = 16 * b + decltype(pc)::value;              // ascending input index; output j meets it with tap NT - 1 + j DOWN - p
+                if constexpr (p < NIN) {
+                    const float xv = d[(p % 16) / 4][p % 4];
+                    static_for<0, R>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value, ti = NT - 1 + j * DOWN - p;
+                        if constexpr (ti >= 0 && ti < NT) fmac_scalar(acc[j], taps[ti], xv);
+                    });
+                }
+            });
+        });
+#pragma unroll
+        for (int j = 0; j < R; ++j) st_acc[j] = acc[j];
+        st_tile = tile;
+        tile = tile_n;
+    };
+    for (;;) {
+        step(buf_a, buf_b);
+        if (tile >= tiles) break;
+        step(buf_b, buf_a);
+        if (tile >= tiles) break;
+    }
+    flush();
+}
+
 // host side of poly_rows_kernel: the tables of one rate pair, resident on the device with the context
 struct PolyRows {
     bool wide = false;              // served by poly_rows_wide_kernel (32-row tiles, every phase in one item, two LDS buffers)
@@ -886,21 +1001,46 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
             (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_y) & 7) == 0 && n_taps == 21 * dn + 1 && pre_remove == 11) {
             const int64_t m_begin = 10;                                                  // inputs start at (m - 10) dn >= 0; 10 = 10 (mod 4)
             const int64_t m_last = (frames - 1) / dn - 11;                               // (m + 11) dn <= frames - 1
-            const int64_t groups = m_last >= m_begin ? (std::min(m_last + 1, n_out) - m_begin) / kDecimR : 0;
+            const int64_t avail = m_last >= m_begin ? std::min(m_last + 1, n_out) - m_begin : 0;   // outputs whose inputs all exist
+            int64_t m_done = m_begin;                                                    // outputs [m_begin, m_done) are served by the tiled kernel
+            if (getenv("FA_RESAMPLE_NO_DECIM_TILES") == nullptr) {
+                // whole tiles of 256 R outputs through LDS (poly_decim_tile_kernel); what is left goes to the register-tiled kernel and the edges
+                auto go = [&](auto dc) {
+                    constexpr int DN = decltype(dc)::value;
+                    typedef DecimTile<DN> D;
+                    const int64_t tiles = std::min<int64_t>(avail / D::TO, (int64_t{1} << 30) / D::TO);
+                    if (tiles <= 0) return;
+                    const int per_cu = std::max(1, std::min(4, static_cast<int>(160 * 1024 / (2 * sizeof(float) * D::BUF))));
+                    const unsigned grid = static_cast<unsigned>(std::min<int64_t>(tiles, 256 * per_cu));
+                    hipLaunchKernelGGL(poly_decim_tile_kernel<DN>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, static_cast<int>(tiles), frames - 4);
+                    m_done = m_begin + tiles * D::TO;
+                };
+                switch (dn) {
+                    case 2: go(std::integral_constant<int, 2>{}); break;
+                    case 3: go(std::integral_constant<int, 3>{}); break;
+                    case 4: go(std::integral_constant<int, 4>{}); break;
+                    case 5: go(std::integral_constant<int, 5>{}); break;
+                    default: go(std::integral_constant<int, 6>{}); break;
+                }
+            }
+            const int64_t m_rest = m_done;                                               // m_done - 10 is a multiple of 4 (tiles of 256 R outputs)
+            const int64_t groups = (avail - (m_rest - m_begin)) / kDecimR;
             // the 16-byte loads of the last group may run up to 3 samples past its last input: keep them inside the signal
             int64_t gr = groups;
-            while (gr > 0 && ((m_begin + gr * kDecimR - 1) + 11) * dn + 3 > frames - 1) --gr;
+            while (gr > 0 && ((m_rest + gr * kDecimR - 1) + 11) * dn + 3 > frames - 1) --gr;
             if (gr > 0) {
                 const unsigned grid = static_cast<unsigned>((gr + kThreads - 1) / kThreads);
                 switch (dn) {
-                    case 2: hipLaunchKernelGGL(poly_decim_kernel<2>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;
-                    case 3: hipLaunchKernelGGL(poly_decim_kernel<3>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;
-                    case 4: hipLaunchKernelGGL(poly_decim_kernel<4>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;
-                    case 5: hipLaunchKernelGGL(poly_decim_kernel<5>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;
-                    default: hipLaunchKernelGGL(poly_decim_kernel<6>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_begin, gr); break;   // 96 kHz: 127 taps in eight registers, 169 inputs
+                    case 2: hipLaunchKernelGGL(poly_decim_kernel<2>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_rest, gr); break;
+                    case 3: hipLaunchKernelGGL(poly_decim_kernel<3>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_rest, gr); break;
+                    case 4: hipLaunchKernelGGL(poly_decim_kernel<4>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_rest, gr); break;
+                    case 5: hipLaunchKernelGGL(poly_decim_kernel<5>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_rest, gr); break;
+                    default: hipLaunchKernelGGL(poly_decim_kernel<6>, dim3(grid), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, m_rest, gr); break;   // 96 kHz: 127 taps in eight registers, 169 inputs
                 }
+            }
+            if (gr > 0 || m_done > m_begin) {
                 edges(0, m_begin);
-                edges(m_begin + gr * kDecimR, n_out);
+                edges(m_rest + gr * kDecimR, n_out);
                 decim = true;
             }
         }

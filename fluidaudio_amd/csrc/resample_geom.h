@@ -141,4 +141,16 @@ inline void interp_geometry(int up, int down, int nt, int r, int64_t frames, int
     if (m_begin < n_out) groups = std::min(groups, (n_out - m_begin) / no); else groups = 0;
 }
 
+// poly_decim_tile_kernel<DOWN>: the constants of a tile (resample.hip explains the kernel)
+constexpr int kDecimThreads = 256;
+template <int DOWN>
+struct DecimTile {
+    static constexpr int R = DOWN == 2 ? 6 : DOWN == 3 ? 4 : DOWN == 4 ? 3 : DOWN == 5 ? 4 : 2;     // R DOWN = 12, 12, 12, 20, 12 floats between two threads' windows
+    static constexpr int NT = 21 * DOWN + 1, RS = R * DOWN, NIN = NT + (R - 1) * DOWN, NB = (NIN + 15) / 16;
+    static constexpr int TO = kDecimThreads * R;                                  // outputs of a tile
+    static constexpr int SPAN = TO * DOWN + NT - 1, PIECES = (SPAN + 3) / 4;   // its inputs, in floats and in 16-byte pieces
+    static constexpr int BUF_A = (PIECES + 63) / 64 * 64 * 4, BUF_B = (kDecimThreads - 1) * RS + 16 * NB;
+    static constexpr int BUF = BUF_A > BUF_B ? BUF_A : BUF_B;                // floats per buffer: whole requests, and the last thread's last (partly unused) quarter
+};
+
 }  // namespace fa

@@ -10,6 +10,65 @@
 
 #include "../../fluidaudio_amd/csrc/resample_geom.h"
 
+
+// poly_decim_tile_kernel<DOWN> on whole tiles of the outputs [10, ...) whose inputs all exist (the host's split in fa_resample_poly_dev): every staged index
+// inside the signal or clamped (-2 if a READ position was clamped or lies outside), every window read inside the buffer (-3); every output of the tiles written
+// once (-4 / -5); a tile's first input 16-byte aligned (-6).  Values = the ascending-input fused multiply-adds of the kernel.
+template <int DOWN>
+static int decim_tiles_emulate_t(const float *x, int64_t n_in, const float *h, int64_t n_out, float *y, int64_t *m_lo, int64_t *m_hi) {
+    typedef fa::DecimTile<DOWN> D;
+    const int64_t m_begin = 10, m_last = (n_in - 1) / DOWN - 11;
+    const int64_t avail = m_last >= m_begin ? std::min(m_last + 1, n_out) - m_begin : 0;
+    const int64_t tiles = avail / D::TO;
+    *m_lo = *m_hi = m_begin;
+    if (tiles <= 0) return 0;
+    static_assert(D::RS % 4 == 0 && (D::RS / 4) % 2 == 1, "a thread's window starts 4 x odd floats behind its neighbour's: conflict-free 16-byte LDS reads");
+    static_assert(D::BUF % 4 == 0 && D::BUF >= D::SPAN, "whole pieces");
+    const int64_t k_lim = n_in - 4;
+    std::vector<float> buf(D::BUF);
+    std::vector<char> valid(D::BUF), written(static_cast<size_t>(tiles * D::TO), 0);
+    for (int64_t t = 0; t < tiles; ++t) {
+        const int64_t k0 = (m_begin + t * D::TO - 10) * DOWN;
+        if (k0 % 4 != 0 || k0 < 0) return -6;
+        std::fill(valid.begin(), valid.end(), 0);
+        const int nreq = (D::PIECES + 63) / 64;
+        for (int req = 0; req < nreq; ++req)
+            for (int lane = 0; lane < 64; ++lane) {
+                int64_t off = 4 * (req * 64 + lane);
+                const bool clamped = off > k_lim - k0;
+                if (clamped) off = k_lim - k0;
+                if (k0 + off < 0 || k0 + off + 3 >= n_in) return -2;
+                for (int e = 0; e < 4; ++e) {
+                    const size_t at = static_cast<size_t>(256 * req + 4 * lane + e);
+                    if (at >= buf.size()) return -3;
+                    buf[at] = x[k0 + off + e];
+                    valid[at] = clamped ? 0 : 1;
+                }
+            }
+        for (int i = 0; i < fa::kDecimThreads; ++i) {
+            if (i * D::RS + 16 * D::NB > D::BUF) return -3;
+            float acc[D::R];
+            for (int j = 0; j < D::R; ++j) acc[j] = 0.0f;
+            for (int p = 0; p < D::NIN; ++p) {
+                if (!valid[static_cast<size_t>(i * D::RS + p)]) return -2;
+                for (int j = 0; j < D::R; ++j) {
+                    const int ti = D::NT - 1 + j * DOWN - p;
+                    if (ti >= 0 && ti < D::NT) acc[j] = fmaf(h[ti], buf[static_cast<size_t>(i * D::RS + p)], acc[j]);
+                }
+            }
+            for (int j = 0; j < D::R; ++j) {
+                const int64_t m = m_begin + t * D::TO + D::R * i + j;
+                if (m >= n_out || written[static_cast<size_t>(m - m_begin)]) return -4;
+                written[static_cast<size_t>(m - m_begin)] = 1;
+                y[m] = acc[j];
+            }
+        }
+    }
+    for (char c : written) if (!c) return -5;
+    *m_hi = m_begin + tiles * D::TO;
+    return 0;
+}
+
 extern "C" {
 
 // poly_kernel: y[m] for m in [m_lo, m_hi)
@@ -119,6 +178,17 @@ int interp_emulate(const float *x, int64_t n_in, const float *h, int nt, int up,
     }
     *m_lo = m_begin; *m_hi = m_begin + groups * NO;
     return 0;
+}
+
+int decim_tiles_emulate(const float *x, int64_t n_in, const float *h, int down, int64_t n_out, float *y, int64_t *m_lo, int64_t *m_hi) {
+    switch (down) {
+        case 2: return decim_tiles_emulate_t<2>(x, n_in, h, n_out, y, m_lo, m_hi);
+        case 3: return decim_tiles_emulate_t<3>(x, n_in, h, n_out, y, m_lo, m_hi);
+        case 4: return decim_tiles_emulate_t<4>(x, n_in, h, n_out, y, m_lo, m_hi);
+        case 5: return decim_tiles_emulate_t<5>(x, n_in, h, n_out, y, m_lo, m_hi);
+        case 6: return decim_tiles_emulate_t<6>(x, n_in, h, n_out, y, m_lo, m_hi);
+        default: return -1;
+    }
 }
 
 }  // extern "C"

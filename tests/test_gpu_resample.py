@@ -93,6 +93,22 @@ def test_rows_kernel_actually_serves_the_common_non_integer_pairs(fa, gpu_ctx, m
         assert t_rows < 0.85 * t_lds, (up, down, t_rows, t_lds)
 
 
+@pytest.mark.parametrize("tiles", [True, False])
+@pytest.mark.parametrize("down,n", [(2, 1000003), (2, 20000), (3, 3000017), (3, 9000), (3, 3300), (4, 640000), (5, 800007), (5, 26000), (6, 3000007), (6, 6200), (6, 700)])
+def test_both_decimation_kernels_equal_simple_kernel(fa, gpu_ctx, monkeypatch, tiles, down, n):
+    """Round 5: integer decimation through LDS tiles (whole tiles of 256 R outputs; the remainder by the register-tiled kernel and the edges) and, with
+    FA_RESAMPLE_NO_DECIM_TILES, by the register-tiled kernel alone: the bits of the one-thread-per-output kernel, from several tiles per workgroup down to
+    signals shorter than one tile."""
+    if not tiles:
+        monkeypatch.setenv("FA_RESAMPLE_NO_DECIM_TILES", "1")
+    rng = np.random.default_rng(n + down)
+    x = (0.4 * np.sin(2 * np.pi * 440 * np.arange(n) / 16000.0) + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    got = fa.resample_poly(x, 1, down, ctx=gpu_ctx)
+    monkeypatch.setenv("FA_RESAMPLE_SIMPLE", "1")
+    ref = fa.resample_poly(x, 1, down, ctx=gpu_ctx)
+    np.testing.assert_array_equal(got, ref)
+
+
 @pytest.mark.parametrize("form", ["16:8", "32:8", "32:10", "one-tile-per-workgroup"])
 @pytest.mark.parametrize("up,down,n", [(160, 441, 1000003), (160, 441, 40000), (160, 441, 15000), (320, 441, 300007), (640, 441, 150000), (80, 189, 200000)])
 def test_every_row_kernel_form_equals_simple_kernel(fa, monkeypatch, form, up, down, n):

@@ -22,6 +22,7 @@ def emul():
     L.poly_simple.restype = None
     L.rows_emulate.argtypes = [f32p, i64, f32p, i64, C.c_int, C.c_int, i64, i64, f32p, C.POINTER(i64), C.POINTER(i64), np.ctypeslib.ndpointer(np.int32, flags="C"), C.c_int, i64, C.c_int]
     L.interp_emulate.argtypes = [f32p, i64, f32p, C.c_int, C.c_int, C.c_int, i64, i64, f32p, C.POINTER(i64), C.POINTER(i64)]
+    L.decim_tiles_emulate.argtypes = [f32p, i64, f32p, C.c_int, i64, f32p, C.POINTER(i64), C.POINTER(i64)]
     return L
 
 
@@ -82,3 +83,24 @@ def test_interp_kernel_indexing_on_the_library_geometry(fa, emul, up, down, nt, 
     assert np.isnan(y[:lo.value]).all() and np.isnan(y[hi.value:]).all()
     if n >= 1000:
         assert hi.value - lo.value > 0.9 * n_out
+
+
+@pytest.mark.parametrize("down,n", [(2, 40000), (2, 12000), (3, 100003), (3, 9000), (3, 3300), (4, 64000), (5, 80007), (5, 25000), (6, 300007), (6, 6200), (6, 700)])
+def test_decim_tile_kernel_indexing(fa, emul, down, n):
+    """Round 5: integer decimation through LDS tiles (poly_decim_tile_kernel): the tiles the host launches, every staged piece inside the signal or clamped and
+    never read where clamped, every window inside the buffer, every output of the tiles written once; values = the one-output-at-a-time evaluation bit for bit."""
+    taps, pre = fa.poly_taps(1, down)
+    assert taps.size == 21 * down + 1 and pre == 11
+    x = signal_of(n, n + down)
+    n_out = fa.lib().fa_resample_poly_frames(n, 1, down)
+    y = np.full(n_out, np.nan, np.float32)
+    lo, hi = C.c_int64(), C.c_int64()
+    rc = emul.decim_tiles_emulate(x, n, taps, down, n_out, y, C.byref(lo), C.byref(hi))
+    assert rc == 0, rc
+    ref = np.zeros(n_out, np.float32)
+    emul.poly_simple(x, n, taps, taps.size, 1, down, pre, ref, 0, n_out)
+    assert (hi.value - lo.value) % 256 == 0
+    if n // down > 3000:
+        assert hi.value > lo.value                                          # at least one tile
+    np.testing.assert_array_equal(y[lo.value:hi.value], ref[lo.value:hi.value])
+    assert np.isnan(y[:lo.value]).all() and np.isnan(y[hi.value:]).all()   # the rest belongs to the register-tiled kernel and the edges
