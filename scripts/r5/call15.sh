@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call 15: resampler PMC passes (bench.py's traffic, SHA-gated) on the final resample.hip, then the default bench with kernel trace
+# round 5, call 15 (re-run after every change of resample.hip): resampler PMC passes (bench.py's traffic, SHA-gated) on the final resample.hip, then the default bench with kernel trace
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r5 gpurun_out/summary
@@ -33,7 +33,7 @@ PY
 summ resample_44100 poly_rows_wide16_kernelILi16 "resample.hip resample_geom.h"
 summ resample_22050 poly_rows_wide16_kernelILi10 "resample.hip resample_geom.h"
 summ resample_8000 poly_interp_kernel "resample.hip resample_geom.h"
-summ resample_48000 poly_decim_kernel "resample.hip resample_geom.h"
+summ resample_48000 poly_decim_tile_kernel "resample.hip resample_geom.h"
 find gpurun_out/pmc_$name -name "*.db" -delete
 ( time timeout 1200 python bench.py ) > gpurun_out/r5/bench15.log 2> gpurun_out/r5/bench15.err; echo "bench rc=$?"
 tail -1 gpurun_out/r5/bench15.log > gpurun_out/r5/bench15.json; tail -4 gpurun_out/r5/bench15.err
