@@ -997,7 +997,7 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
         };
         // integer decimation: register-tiled kernel on the outputs whose inputs all exist, poly_kernel on the two edges
         bool decim = false;
-        if (!simple && u == 1 && dn >= 2 && dn <= 6 && getenv("FA_RESAMPLE_NO_DECIM") == nullptr &&
+        if (!simple && u == 1 && ((dn >= 2 && dn <= 6) || dn == 12) && getenv("FA_RESAMPLE_NO_DECIM") == nullptr &&
             (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_y) & 7) == 0 && n_taps == 21 * dn + 1 && pre_remove == 11) {
             const int64_t m_begin = 10;                                                  // inputs start at (m - 10) dn >= 0; 10 = 10 (mod 4)
             const int64_t m_last = (frames - 1) / dn - 11;                               // (m + 11) dn <= frames - 1
@@ -1020,11 +1020,12 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
                     case 3: go(std::integral_constant<int, 3>{}); break;
                     case 4: go(std::integral_constant<int, 4>{}); break;
                     case 5: go(std::integral_constant<int, 5>{}); break;
-                    default: go(std::integral_constant<int, 6>{}); break;
+                    case 6: go(std::integral_constant<int, 6>{}); break;
+                    default: go(std::integral_constant<int, 12>{}); break;          // 192 kHz: tiles only (no register-tiled instance: what is left goes to the edges' kernel)
                 }
             }
             const int64_t m_rest = m_done;                                               // m_done - 10 is a multiple of 4 (tiles of 256 R outputs)
-            const int64_t groups = (avail - (m_rest - m_begin)) / kDecimR;
+            const int64_t groups = dn <= 6 ? (avail - (m_rest - m_begin)) / kDecimR : 0;
             // the 16-byte loads of the last group may run up to 3 samples past its last input: keep them inside the signal
             int64_t gr = groups;
             while (gr > 0 && ((m_rest + gr * kDecimR - 1) + 11) * dn + 3 > frames - 1) --gr;

@@ -145,7 +145,7 @@ inline void interp_geometry(int up, int down, int nt, int r, int64_t frames, int
 constexpr int kDecimThreads = 256;
 template <int DOWN>
 struct DecimTile {
-    static constexpr int R = DOWN == 2 ? 6 : DOWN == 3 ? 4 : DOWN == 4 ? 3 : DOWN == 5 ? 4 : 2;     // R DOWN = 12, 12, 12, 20, 12 floats between two threads' windows
+    static constexpr int R = DOWN == 2 ? 6 : DOWN == 3 ? 4 : DOWN == 4 ? 3 : DOWN == 5 ? 4 : DOWN == 6 ? 2 : 1;     // R DOWN = 12, 12, 12, 20, 12 floats between two threads' windows; DOWN = 12 (192 kHz): R = 1
     static constexpr int NT = 21 * DOWN + 1, RS = R * DOWN, NIN = NT + (R - 1) * DOWN, NB = (NIN + 15) / 16;
     static constexpr int TO = kDecimThreads * R;                                  // outputs of a tile
     static constexpr int SPAN = TO * DOWN + NT - 1, PIECES = (SPAN + 3) / 4;   // its inputs, in floats and in 16-byte pieces

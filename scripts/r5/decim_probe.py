@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round 5: integer decimation (32 / 48 / 64 / 80 / 96 kHz -> 16 kHz) through LDS tiles (poly_decim_tile_kernel) against the register-tiled kernel
+"""Round 5: integer decimation (32 / 48 / 64 / 80 / 96 / 192 kHz -> 16 kHz; 192 kHz has no register-tiled instance: its second line is the LDS-staged kernel) through LDS tiles (poly_decim_tile_kernel) against the register-tiled kernel
 (FA_RESAMPLE_NO_DECIM_TILES=1), one hour of device-resident audio per pair; bits against the one-thread-per-output kernel on the first 10 s."""
 import ctypes as C, json, os, sys
 import torch
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import fluidaudio_amd as fa  # noqa: E402
 out = []
-for rate, down in ((32000, 2), (48000, 3), (64000, 4), (80000, 5), (96000, 6)):
+for rate, down in ((32000, 2), (48000, 3), (64000, 4), (80000, 5), (96000, 6), (192000, 12)):
     for form in ("tiles", "registers"):
         os.environ.pop("FA_RESAMPLE_NO_DECIM_TILES", None)
         if form == "registers":

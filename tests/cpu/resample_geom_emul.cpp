@@ -187,6 +187,7 @@ int decim_tiles_emulate(const float *x, int64_t n_in, const float *h, int down, 
         case 4: return decim_tiles_emulate_t<4>(x, n_in, h, n_out, y, m_lo, m_hi);
         case 5: return decim_tiles_emulate_t<5>(x, n_in, h, n_out, y, m_lo, m_hi);
         case 6: return decim_tiles_emulate_t<6>(x, n_in, h, n_out, y, m_lo, m_hi);
+        case 12: return decim_tiles_emulate_t<12>(x, n_in, h, n_out, y, m_lo, m_hi);
         default: return -1;
     }
 }
