@@ -776,7 +776,7 @@ bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down,
             if (!wide_instance(c.rows, c.waves, nv2, g2.share, ch)) continue;
             R.g = g2; R.nv = nv2; R.ch = ch; R.wide_rows = c.rows; R.wide_waves = c.waves; gtab.swap(gtab2); tt.swap(tt2);
             R.wide = true;
-            R.wide_part = getenv("FA_RESAMPLE_WIDE_PART") ? atoi(getenv("FA_RESAMPLE_WIDE_PART")) : 0;
+            if (const char *e = getenv("FA_RESAMPLE_WIDE_PART")) R.wide_part = atoi(e);
             R.wide_no_rot = getenv("FA_RESAMPLE_WIDE_NO_ROT") != nullptr;
             R.lds = 0; R.up = up; R.down = down;     // (static LDS)
             return true;
@@ -989,7 +989,12 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
             }
         }
         float *d_h = static_cast<float *>(ctx->poly_taps);
-        const bool simple = getenv("FA_RESAMPLE_SIMPLE") != nullptr;
+        // the kernel-choice switches of the tests and probes, read ONCE per call, here (the forms fixed with a context's tables — FA_RESAMPLE_WIDE*, _ROWS_* —
+        // are read when the tables are built)
+        struct { bool simple, no_decim, no_decim_tiles, no_interp, no_rows; } const sw = {
+            getenv("FA_RESAMPLE_SIMPLE") != nullptr, getenv("FA_RESAMPLE_NO_DECIM") != nullptr, getenv("FA_RESAMPLE_NO_DECIM_TILES") != nullptr,
+            getenv("FA_RESAMPLE_NO_INTERP") != nullptr, getenv("FA_RESAMPLE_NO_ROWS") != nullptr};
+        const bool simple = sw.simple;
         auto edges = [&](const int64_t m_lo, const int64_t m_hi) {   // outputs [m_lo, m_hi) by the one-thread-per-output kernel (clamps at the signal's ends)
             if (m_hi <= m_lo) return;
             hipLaunchKernelGGL(poly_kernel, dim3(static_cast<unsigned>((m_hi - m_lo + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, d_x, d_h, d_y, frames, n_out,
@@ -997,13 +1002,13 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
         };
         // integer decimation: register-tiled kernel on the outputs whose inputs all exist, poly_kernel on the two edges
         bool decim = false;
-        if (!simple && u == 1 && ((dn >= 2 && dn <= 6) || dn == 12) && getenv("FA_RESAMPLE_NO_DECIM") == nullptr &&
+        if (!simple && u == 1 && ((dn >= 2 && dn <= 6) || dn == 12) && !sw.no_decim &&
             (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_y) & 7) == 0 && n_taps == 21 * dn + 1 && pre_remove == 11) {
             const int64_t m_begin = 10;                                                  // inputs start at (m - 10) dn >= 0; 10 = 10 (mod 4)
             const int64_t m_last = (frames - 1) / dn - 11;                               // (m + 11) dn <= frames - 1
             const int64_t avail = m_last >= m_begin ? std::min(m_last + 1, n_out) - m_begin : 0;   // outputs whose inputs all exist
             int64_t m_done = m_begin;                                                    // outputs [m_begin, m_done) are served by the tiled kernel
-            if (getenv("FA_RESAMPLE_NO_DECIM_TILES") == nullptr) {
+            if (!sw.no_decim_tiles) {
                 // whole tiles of 256 R outputs through LDS (poly_decim_tile_kernel); what is left goes to the register-tiled kernel and the edges
                 auto go = [&](auto dc) {
                     constexpr int DN = decltype(dc)::value;
@@ -1046,7 +1051,7 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
             }
         }
         // small interpolation factors: register-tiled kernel on the outputs whose inputs all exist, poly_kernel on the two ends
-        if (!decim && !simple && u >= 2 && u <= 4 && getenv("FA_RESAMPLE_NO_INTERP") == nullptr) {
+        if (!decim && !simple && u >= 2 && u <= 4 && !sw.no_interp) {
             int64_t lo = 0, hi = 0;
             if (u == 2 && dn == 1 && n_taps == 42) poly_interp_launch<2, 1, 42>(ctx, d_x, d_h, d_y, frames, n_out, pre_remove, lo, hi);
             else if (u == 2 && dn == 3 && n_taps == 64) poly_interp_launch<2, 3, 64>(ctx, d_x, d_h, d_y, frames, n_out, pre_remove, lo, hi);
@@ -1062,7 +1067,7 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
         }
         // non-integer ratios: row-tiled kernel on the tiles whose staged inputs all exist, poly_kernel on the two ends
         bool rows = false;
-        if (!decim && !simple && ctx->poly_rows && getenv("FA_RESAMPLE_NO_ROWS") == nullptr) {
+        if (!decim && !simple && ctx->poly_rows && !sw.no_rows) {
             const PolyRows &R = *static_cast<const PolyRows *>(ctx->poly_rows);
             const PolyRowsGeom &G = R.g;
             const int tile_rows = R.wide ? R.wide_rows : 64;
