@@ -76,6 +76,7 @@ struct Heap {
         for (int32_t i = size >> 1; i > 0;) { --i; sift_down(i); }
     }
     FA_HD int32_t argmin() const { return at[0]; }        // :872-875
+    FA_HD double top_key() const { return key[at[0]]; }
     FA_HD void remove(const int32_t node) {               // :884-895: the last entry takes the place of `node`
         --size;
         pos[at[size]] = pos[node];
@@ -94,6 +95,102 @@ struct Heap {
     FA_HD void raise(const int32_t node, const double val) {   // update_geq (:931-935): the new key is not less than the old one
         key[node] = val;
         sift_down(pos[node]);
+    }
+};
+
+// ---- The same heap, laid out for a wavefront (round 5).
+// Heap above costs the selecting thread two dependent accesses per comparison (at[place] -> key[node]) and one memory round trip per level of a
+// sift: ~100 dependent accesses per dendrogram row, which was what a row of the reference-order run waited for (profiles/r05_ties_probe.txt).
+// Here an entry CARRIES its key (16 bytes: key, node), and a sift works on a block of entries fetched at once: a sift-up on the whole ancestor
+// chain of its place (<= 31 entries), a sift-down on the six levels below its place (126 entries), repeated from where it left off when the
+// entry is still moving at the bottom of the block.  The walk on the block makes the comparisons of sift_up / sift_down above in the same
+// order with the same strictness, so the array order — the tie order — is the same after every operation (tests/test_ahc_reforder_emul.py
+// runs both forms side by side on tie-heavy key streams and through whole dendrograms).  HOW a block reaches the walker is the policy `Mem`:
+// SerialMem (host, CPU tests) copies entry by entry; the device policy (ahc.hip: WaveMem) has the 64 lanes of the selecting wavefront load
+// the block into LDS in one round trip.  On the device every lane executes every store of the walk (same address, same value): a lane's later
+// loads — also the block loads, where lane l reads entries the walk wrote earlier — then see the latest values by its own program order.
+struct Ent { double key; int32_t node, pad; };
+
+constexpr int32_t kTreeLevels = 6;                          // levels below the root of a sift-down block
+constexpr int32_t kTreeEnts = (1 << (kTreeLevels + 1)) - 1; // relative indices 0 (the root: not fetched) .. 126
+FA_HD int32_t heap_depth(int32_t place) { int32_t L = 0; for (uint32_t v = static_cast<uint32_t>(place) + 1u; v > 1u; v >>= 1) ++L; return L; }   // ancestors of a place
+FA_HD int32_t heap_ancestor(const int32_t place, const int32_t j) { return static_cast<int32_t>((static_cast<uint32_t>(place) + 1u) >> (j + 1)) - 1; }   // j = 0: the parent
+// place of relative index t (children of t: 2 t + 1, 2 t + 2) in the subtree rooted at place r; 64-bit: beyond the heap for deep, wide blocks
+FA_HD int64_t heap_tree_place(const int32_t r, const int32_t t) {
+    int32_t lev = 0;
+    for (uint32_t v = static_cast<uint32_t>(t) + 1u; v > 1u; v >>= 1) ++lev;
+    return ((static_cast<int64_t>(r) + 1) << lev) - 1 + (static_cast<int64_t>(t) + 1 - (static_cast<int64_t>(1) << lev));
+}
+
+struct SerialMem {
+    Ent buf[kTreeEnts + 1];
+    FA_HD void fetch_chain(const Ent *ent, const int32_t place, const int32_t depth) { for (int32_t j = 0; j < depth; ++j) buf[j] = ent[heap_ancestor(place, j)]; }
+    FA_HD void fetch_tree(const Ent *ent, const int32_t root, const int32_t size) {
+        for (int32_t t = 1; t < kTreeEnts; ++t) { const int64_t p = heap_tree_place(root, t); if (p < size) buf[t] = ent[p]; }
+    }
+    FA_HD double key_at(const int32_t j) const { return buf[j].key; }
+    FA_HD Ent ent_at(const int32_t j) const { return buf[j]; }
+};
+
+template <class Mem>
+struct HeapK {
+    Ent *ent;         // [N]    place -> (key, node)
+    int32_t *pos;     // [2N]   node -> place
+    int32_t size;
+    Mem mem;
+
+    FA_HD void put(const int64_t place, const Ent e) { ent[place] = e; pos[e.node] = static_cast<int32_t>(place); }
+    FA_HD void sift_up(const int32_t i, const Ent e) {        // Heap::sift_up with the entry `e` arriving at place i
+        const int32_t depth = heap_depth(i);
+        mem.fetch_chain(ent, i, depth);
+        int32_t c = 0;
+        while (c < depth && e.key < mem.key_at(c)) ++c;       // strictly smaller than the ancestor: it comes down, the entry goes on
+        int32_t child = i;
+        for (int32_t j = 0; j < c; ++j) { put(child, mem.ent_at(j)); child = heap_ancestor(i, j); }
+        put(child, e);
+    }
+    FA_HD void sift_down(int32_t i, const Ent e) {             // Heap::sift_down with the entry `e` arriving at place i
+        for (;;) {
+            mem.fetch_tree(ent, i, size);
+            int32_t t = 0;
+            bool rest = false;
+            while (t < (1 << kTreeLevels) - 1) {                // t on levels 0 .. 5: both children are in the block
+                int32_t j = 2 * t + 1;
+                if (heap_tree_place(i, j) >= size) { rest = true; break; }
+                const double kl = mem.key_at(j);
+                if (kl >= e.key) {                              // left child not smaller: only a strictly smaller right child moves up
+                    ++j;
+                    if (heap_tree_place(i, j) >= size || mem.key_at(j) >= e.key) { rest = true; break; }
+                } else if (heap_tree_place(i, j + 1) < size && mem.key_at(j + 1) < kl) {
+                    ++j;                                        // both smaller: the right one only if strictly smaller than the left
+                }
+                put(heap_tree_place(i, t), mem.ent_at(j));
+                t = j;
+            }
+            const int64_t here = heap_tree_place(i, t);
+            if (rest) { put(here, e); return; }
+            i = static_cast<int32_t>(here);                    // still moving at the bottom of the block: the next six levels
+        }
+    }
+    FA_HD int32_t argmin() const { return ent[0].node; }
+    FA_HD double top_key() const { return ent[0].key; }
+    FA_HD void remove(const int32_t node) {                    // Heap::remove
+        --size;
+        const int32_t p = pos[node];
+        if (p == size) return;                                  // the last entry itself: above, a sift-up that never moves (its parent is not larger)
+        const Ent last = ent[size];
+        if (last.key <= ent[p].key) sift_up(p, last);
+        else sift_down(p, last);
+    }
+    FA_HD void replace(const int32_t old_node, const int32_t new_node, const double val) {   // Heap::replace
+        const int32_t p = pos[old_node];
+        Ent e; e.key = val; e.node = new_node; e.pad = 0;
+        if (val <= ent[p].key) sift_up(p, e);
+        else sift_down(p, e);
+    }
+    FA_HD void raise(const int32_t node, const double val) {   // Heap::raise
+        Ent e; e.key = val; e.node = node; e.pad = 0;
+        sift_down(pos[node], e);
     }
 };
 
@@ -121,8 +218,9 @@ struct ActiveList {
 // neighbour has been merged away (RESCAN).
 enum : int32_t { RO_NEW_ROW = 0, RO_RESCAN = 1, RO_DONE = 2 };
 
-struct Sel {
-    Heap heap;
+template <class H>
+struct SelT {
+    H heap;
     ActiveList list;
     int32_t *nghbr;      // [2N]  recorded nearest lower-indexed neighbour by node
     int32_t n;           // points
@@ -143,7 +241,7 @@ struct Sel {
             list.remove(other);
             pair_a[merges] = static_cast<double>(top);
             pair_b[merges] = static_cast<double>(other);
-            height_sq[merges] = heap.key[top];
+            height_sq[merges] = heap.top_key();
             ++merges;
             a = top; b = other;
             if (merges == n - 1) { op = RO_DONE; return; }                        // the last merge creates no row (:1745)
@@ -166,5 +264,7 @@ struct Sel {
         advance();
     }
 };
+
+using Sel = SelT<Heap>;
 
 }  // namespace fa_ro

@@ -14,9 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.fixture(scope="module")
 def emul():
-    so = os.path.join(HERE, "cpu", "libahc_reforder_emul.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, os.path.join(HERE, "cpu", "ahc_reforder_emul.cpp")], check=True)
-    lib = C.CDLL(so)
+    lib = _build("ahc_reforder_emul")
     lib.fa_reforder_emul.argtypes = [np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_int, C.c_int, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
 
     def run(x):
@@ -76,3 +74,77 @@ def test_selection_logic_on_random_tie_heavy_inputs(oracle_mod, emul, seed):
     z = emul(x)
     bad = np.nonzero((z != zr).any(axis=1))[0]
     assert bad.size == 0, f"seed {seed} (n {len(x)}, d {d}, step {step}): first differing row {bad[0]}: emulation {z[bad[0]]} reference {zr[bad[0]]}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# Round 5: the matrix-filtered reference-order run (ahc.hip: rom_scan / rom_select) — entries that carry their key, block-wise sifts
+# (ahc_reforder.h: HeapK), a Lance-Williams matrix supplying the candidates of every scan.  tests/cpu/ahc_rom_emul.cpp replays both on the CPU.
+
+def _build(name):
+    so = os.path.join(HERE, "cpu", f"lib{name}.so")
+    tmp = f"{so}.{os.getpid()}.tmp"                           # built aside and renamed: parallel test workers never load a half-written library
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", tmp, os.path.join(HERE, "cpu", f"{name}.cpp")], check=True)
+    os.replace(tmp, so)
+    return C.CDLL(so)
+
+
+@pytest.fixture(scope="module")
+def rom():
+    lib = _build("ahc_rom_emul")
+    lib.fa_heapk_equiv.argtypes = [C.c_int, C.c_int, C.c_ulonglong, C.c_int]
+    lib.fa_rom_emul.argtypes = [np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_int, C.c_int, C.c_double, C.c_ulonglong,
+                                np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
+
+    def run(x, noise=0.0, seed=0):
+        x = np.ascontiguousarray(x, np.float64)
+        z, stats = np.zeros((len(x) - 1, 4)), np.zeros(4)
+        assert lib.fa_rom_emul(x, x.shape[0], x.shape[1], noise, seed, z, stats) == 0
+        return z, stats
+    run.lib = lib
+    return run
+
+
+@pytest.mark.parametrize("n,levels", [(2, 1), (3, 2), (7, 1), (64, 3), (127, 2), (128, 50), (129, 4), (1000, 5), (5000, 3), (20000, 1000), (70000, 7)])
+def test_block_heap_equals_the_restated_heap_after_every_operation(rom, n, levels):
+    """remove / replace / raise in random order on heavily tied keys: place by place the same arrays (the tie order IS the array order).  Sizes on
+    both sides of the block boundaries: 127 places = one sift-down block, 70 000 = three blocks deep."""
+    for seed in range(6):
+        assert rom.lib.fa_heapk_equiv(n, min(4 * n, 6000), seed, levels) == 0, (n, levels, seed)
+
+
+@pytest.mark.parametrize("noise", [0.0, 0.45])
+@pytest.mark.parametrize("name,x", list(tie_inputs()), ids=[n for n, _ in tie_inputs()])
+def test_matrix_filtered_run_reproduces_the_reference_row_for_row(oracle_mod, rom, name, x, noise):
+    if not oracle_mod.ref_available():
+        pytest.skip("oracle/_ref not built")
+    x = np.ascontiguousarray(x, np.float64)
+    st, zr = oracle_mod.linkage_ref(x)
+    assert st == 0
+    z, stats = rom(x, noise, 7)
+    bad = np.nonzero((z != zr).any(axis=1))[0]
+    assert bad.size == 0, f"{name}: first differing row {bad[0]} of {len(z)}: emulation {z[bad[0]]} reference {zr[bad[0]]} (stats {stats})"
+    assert stats[1] >= stats[0] >= len(x) - 2
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_matrix_filtered_run_on_random_inputs(oracle_mod, rom, seed):
+    """Tie-heavy and tie-free inputs by turns, the start-up matrix perturbed by up to 0.45 eps per entry: the candidates of a scan then really are
+    several, and the exact evaluation has to pick the reference's."""
+    if not oracle_mod.ref_available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(2000 + seed)
+    n, d = int(rng.integers(3, 300)), int(rng.integers(1, 40))
+    x = rng.standard_normal((n, d))
+    if seed % 2 == 0:
+        step = float(rng.choice([1.0, 0.5, 0.25, 1 / 64]))
+        x = np.round(x * 2 / step) * step
+        k = max(1, n // 3)
+        x[rng.integers(0, n, k)] = x[rng.integers(0, n, k)]
+    else:
+        x /= np.linalg.norm(x, axis=1, keepdims=True)       # the pipeline's input: unit rows
+    x = np.ascontiguousarray(x, np.float64)
+    st, zr = oracle_mod.linkage_ref(x)
+    assert st == 0
+    z, stats = rom(x, 0.45, seed)
+    bad = np.nonzero((z != zr).any(axis=1))[0]
+    assert bad.size == 0, f"seed {seed} (n {n}, d {d}): first differing row {bad[0]}: emulation {z[bad[0]]} reference {zr[bad[0]]} (stats {stats})"
