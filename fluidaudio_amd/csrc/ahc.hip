@@ -1847,10 +1847,251 @@ __global__ void ro_finish(RoWs w) {
     z[3] = __dadd_rn(w.sizes[static_cast<int>(a)], w.sizes[static_cast<int>(b)]);
 }
 
+// ------------------------------------------------------------------------------ reference order, the matrix as the filter of its scans (round 5)
+// The run above evaluates O(A d) exact sums per dendrogram row and lets ONE thread replay the reference's heap: 28-30 us per row at 43 200 x 256
+// (profiles/r05_ties_probe.txt), what an input with exact ties paid for the reference's row order.  Here, whenever the N x N workspace is to be had:
+//   * the scans ask the Lance-Williams matrix of the filter-based rounds (Gram-form start-up on the fp64 matrix cores, pair_entry's validity rule,
+//     one row rewritten per merge): rom_scan writes the new row / reads the row of a re-scanned node — O(A) — and reduces it to block minima;
+//   * rom_select, one wavefront: every entry within 2 eps of the smallest one is a candidate (eps bounds |entry - the reference's sum| as in
+//     ahc_set_eps, plus the term of the sequentially summed d(a, b) used here); the candidates — one, on tie-free rows — are evaluated with the
+//     reference's sequential sums (lane i sums candidate i; the squares are formed by the whole wavefront), the winner by (value, node id) is what the
+//     reference's strict `<` scan in index order finds.  More than kRomCap candidates (massively duplicated inputs): the row is scanned again with
+//     exact sums by every workgroup (kind ROM_EXACT — the scan of the run above);
+//   * the heap replay is ahc_reforder.h's HeapK: entries carry their key, a sift works on a block fetched by the 64 lanes at once; every lane
+//     executes every store of the selection (same address, same value), so whatever a lane reads later it has written itself.
+// tests/cpu/ahc_rom_emul.cpp replays exactly this on the CPU against the reference build.
+enum : int32_t { ROM_NEW = 0, ROM_RESCAN = 1, ROM_EXACT = 2 };
+constexpr int kRomCap = 128;     // candidates one selection evaluates
+constexpr int kRomBatch = 16;    // candidates summed side by side (one lane each)
+constexpr int kRomChunk = 256;   // coordinates per staging pass
+struct __attribute__((aligned(16))) RomPart { double v1; int32_t x1, n1; };   // smallest entry of the block by (value, node id): value, slot, node
+struct RomDev {
+    int32_t heap_size, list_first, merges, op, a, b, n, done;              // fa_ro::SelT between launches
+    int32_t nan_seen, kind, scanned, sa, sb, created, pad0, pad1;          // what the next scan launch computes: the row of node `scanned` (slot sa)
+    double ma, mb, dab, eps;                                               // ROM_NEW: sizes of a and b, their exact squared distance
+    long long scans, exact_scans, cands, pad2;
+};
+static_assert(sizeof(RomDev) % 16 == 0, "copied in 16-byte pieces");
+struct RomWs {
+    double *M, *C, *XT, *sizes, *pair_a, *pair_b, *height_sq, *part2;
+    fa_ro::Ent *ent;
+    int32_t *node, *slot_of, *pos, *nghbr, *next, *prev, *flags;
+    RomPart *part;
+    RomDev *dev;
+    int32_t N, Np, d, nblk;
+};
+
+// what the scan after `sel` has to compute (host: the first one; device: every later one)
+template <class S>
+__host__ __device__ inline void rom_prepare(RomDev &st, const S &sel, const int32_t *slot_of, const double *sizes) {
+    st.heap_size = sel.heap.size; st.list_first = sel.list.first; st.merges = sel.merges; st.op = sel.op; st.a = sel.a; st.b = sel.b; st.n = sel.n;
+    if (sel.op == fa_ro::RO_NEW_ROW) {
+        st.kind = ROM_NEW; st.created = sel.n + sel.merges - 1; st.scanned = st.created;
+        st.sa = slot_of[sel.a]; st.sb = slot_of[sel.b]; st.ma = sizes[sel.a]; st.mb = sizes[sel.b]; st.dab = sel.height_sq[sel.merges - 1];
+    } else if (sel.op == fa_ro::RO_RESCAN) {
+        st.kind = ROM_RESCAN; st.scanned = sel.a; st.sa = slot_of[sel.a]; st.sb = -1; st.created = -1;
+    } else st.done = 1;
+}
+
+__global__ __launch_bounds__(kBlk) void rom_scan(const RomWs w) {
+    extern __shared__ double s_c[];            // [d] coordinates of the scanned node (ROM_EXACT)
+    __shared__ double s_v1[kWaves], s_v2[kWaves];
+    __shared__ int s_x1[kWaves], s_n1[kWaves];
+    const RomDev st = *w.dev;
+    if (st.done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x, x = blk * kBlk + tid, Np = w.Np, d = w.d;
+    const int nx = w.node[x];
+    double v = dinf();
+    if (st.kind == ROM_EXACT) {                // the reference's sums of node `scanned` against every active node below it (ro_scan's)
+        const double *cs = w.C + static_cast<size_t>(st.scanned) * d;
+        for (int k = tid; k < d; k += kBlk) s_c[k] = cs[k];
+        __syncthreads();
+        if (nx != kDead && x != st.sa && nx < st.scanned) {
+            const double *col = w.XT + x;
+            double sum = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < d; ++k) {
+                const double diff = __dsub_rn(col[static_cast<size_t>(k) * Np], s_c[k]);
+                sum = __dadd_rn(sum, __dmul_rn(diff, diff));
+            }
+            if (sum != sum) w.flags[0] = 1;
+            v = sum;
+        }
+    } else if (st.kind == ROM_NEW) {           // Lance-Williams row of the node created from (a, b) into the row of slot sa
+        if (nx != kDead && x != st.sa && x != st.sb) {
+            const double da = pair_entry(w.M, Np, st.sa, st.a, x, nx, w.N), db = pair_entry(w.M, Np, st.sb, st.b, x, nx, w.N);
+            const double den = st.ma + st.mb, inv = 1.0 / den, wa = st.ma * inv, wb = st.mb * inv, wab = wa * wb;
+            v = wa * da + wb * db - wab * st.dab;
+            if (!(v > 0.0)) v = 0.0;
+            w.M[static_cast<size_t>(st.sa) * Np + x] = v;
+        }
+        if (x == st.sa) { w.node[x] = st.created; w.slot_of[st.created] = x; w.sizes[st.created] = st.ma + st.mb; }
+        if (x == st.sb) w.node[x] = kDead;
+        if (st.sa / kBlk == blk) {             // merged centroid (FastClusterWrapper.cpp:89-100): by node id, and into the slot-major transpose
+            const double *ca = w.C + static_cast<size_t>(st.a) * d, *cb = w.C + static_cast<size_t>(st.b) * d, den = st.ma + st.mb;
+            for (int k = tid; k < d; k += kBlk) {
+                const double cc = __ddiv_rn(__dadd_rn(__dmul_rn(ca[k], st.ma), __dmul_rn(cb[k], st.mb)), den);
+                w.C[static_cast<size_t>(st.created) * d + k] = cc;
+                w.XT[static_cast<size_t>(k) * Np + st.sa] = cc;
+            }
+        }
+    } else if (nx != kDead && x != st.sa && nx < st.scanned) {   // ROM_RESCAN: the row of a is valid against every older node
+        v = w.M[static_cast<size_t>(st.sa) * Np + x];
+    }
+    // block minimum by (value, node id) + the block's second smallest value
+    const double m = wave_min(v);
+    const bool fin = m < dinf();
+    const unsigned id = wave_umin((fin && v == m) ? static_cast<unsigned>(nx) : static_cast<unsigned>(INT_MAX));
+    const unsigned long long msk = __builtin_amdgcn_ballot_w64(fin && v == m && static_cast<unsigned>(nx) == id);
+    const int L = __builtin_amdgcn_readfirstlane(msk ? __ffsll(static_cast<long long>(msk)) - 1 : 0);
+    const int x1 = lane_value(x, L);
+    const double second = wave_min(lane == L ? dinf() : v);
+    if (lane == 0) { s_v1[wave] = m; s_v2[wave] = second; s_x1[wave] = x1; s_n1[wave] = static_cast<int>(id); }
+    __syncthreads();
+    if (tid != 0) return;
+    double bv = s_v1[0], b2 = s_v2[0];
+    int bn = s_n1[0], bx = s_x1[0];
+#pragma unroll
+    for (int wv = 1; wv < kWaves; ++wv) {
+        if (lt2(s_v1[wv], s_n1[wv], bv, bn)) { if (bv < b2) b2 = bv; bv = s_v1[wv]; bn = s_n1[wv]; bx = s_x1[wv]; if (s_v2[wv] < b2) b2 = s_v2[wv]; }
+        else if (s_v1[wv] < b2) b2 = s_v1[wv];
+    }
+    RomPart pt; pt.v1 = bv; pt.x1 = bx; pt.n1 = bn;
+    w.part[blk] = pt;
+    w.part2[blk] = b2;
+}
+
+struct WaveMem {   // ahc_reforder.h's block fetches by the 64 lanes of the selecting wavefront
+    fa_ro::Ent *buf;   // LDS [fa_ro::kTreeEnts + 1]
+    __device__ __forceinline__ static void wave_sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ void fetch_chain(const fa_ro::Ent *ent, const int32_t place, const int32_t depth) {
+        const int lane = threadIdx.x & 63;
+        wave_sync();
+        if (lane < depth) buf[lane] = ent[fa_ro::heap_ancestor(place, lane)];
+        wave_sync();
+    }
+    __device__ __forceinline__ void fetch_tree(const fa_ro::Ent *ent, const int32_t root, const int32_t size) {
+        const int lane = threadIdx.x & 63;
+        wave_sync();
+        for (int32_t t = 1 + lane; t < fa_ro::kTreeEnts; t += 64) { const int64_t p = fa_ro::heap_tree_place(root, t); if (p < size) buf[t] = ent[p]; }
+        wave_sync();
+    }
+    __device__ __forceinline__ double key_at(const int32_t j) const { return buf[j].key; }
+    __device__ __forceinline__ fa_ro::Ent ent_at(const int32_t j) const { return buf[j]; }
+};
+
+__global__ __launch_bounds__(64) void rom_select(const RomWs w) {
+    __shared__ fa_ro::Ent s_buf[fa_ro::kTreeEnts + 1];
+    __shared__ double s_t[kRomBatch][kRomChunk + 2];
+    __shared__ int s_cand[kRomCap];
+    RomDev st = *w.dev;
+    if (st.done) return;
+    const int lane = threadIdx.x, Np = w.Np, d = w.d, nblk = w.nblk;
+    double best = dinf();
+    int best_id = INT_MAX;
+    if (st.kind == ROM_EXACT) {                // the block minima are the reference's sums: lowest (value, node id)
+        double v = dinf();
+        int id = INT_MAX;
+        for (int b = lane; b < nblk; b += 64) { const RomPart pt = w.part[b]; if (lt2(pt.v1, pt.n1, v, id)) { v = pt.v1; id = pt.n1; } }
+        best = wave_min(v);
+        best_id = static_cast<int>(wave_umin((v == best && best < dinf()) ? static_cast<unsigned>(id) : static_cast<unsigned>(INT_MAX)));
+    } else {
+        double mv = dinf();
+        for (int b = lane; b < nblk; b += 64) { const double v1 = w.part[b].v1; if (v1 < mv) mv = v1; }
+        const double m = wave_min(mv);
+        int ncand = 0;
+        if (m < dinf()) {
+            const double lim = m + 2.0 * st.eps;
+            const double *row = w.M + static_cast<size_t>(st.sa) * Np;
+            for (int base = 0; base < nblk && ncand <= kRomCap; base += 64) {
+                const int b = base + lane;
+                RomPart pt; pt.v1 = dinf(); pt.x1 = -1; pt.n1 = INT_MAX;
+                double v2 = dinf();
+                if (b < nblk) { pt = w.part[b]; v2 = w.part2[b]; }
+                const bool hit = pt.v1 <= lim, dense = hit && v2 <= lim, single = hit && !dense;
+                const unsigned long long ms = __builtin_amdgcn_ballot_w64(single);
+                const int at = ncand + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(ms >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(ms), 0));
+                if (single && at < kRomCap) s_cand[at] = pt.n1;
+                ncand += __popcll(ms);
+                unsigned long long md = __builtin_amdgcn_ballot_w64(dense);
+                while (md && ncand <= kRomCap) {   // a block with several entries inside the window: its 256 entries again
+                    const int bb = base + __ffsll(static_cast<long long>(md)) - 1;
+                    md &= md - 1;
+                    for (int j = 0; j < kBlk / 64; ++j) {
+                        const int x = bb * kBlk + 64 * j + lane, nx = w.node[x];
+                        const bool c = nx != kDead && x != st.sa && nx < st.scanned && row[x] <= lim;
+                        const unsigned long long mc = __builtin_amdgcn_ballot_w64(c);
+                        const int ac = ncand + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mc >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mc), 0));
+                        if (c && ac < kRomCap) s_cand[ac] = nx;
+                        ncand += __popcll(mc);
+                    }
+                }
+            }
+        }
+        if (ncand > kRomCap) {                 // too many for one wavefront: the same row by exact sums of every workgroup, then back here
+            if (lane == 0) { st.kind = ROM_EXACT; st.exact_scans = st.exact_scans + 1; *w.dev = st; }
+            return;
+        }
+        st.cands = st.cands + ncand;
+        WaveMem::wave_sync();
+        const double *cs = w.C + static_cast<size_t>(st.scanned) * d;
+        for (int b0 = 0; b0 < ncand; b0 += kRomBatch) {
+            const int nb = ncand - b0 < kRomBatch ? ncand - b0 : kRomBatch;
+            double sum = 0.0;
+            for (int k0 = 0; k0 < d; k0 += kRomChunk) {
+                double xs[kRomChunk / 64];
+#pragma unroll
+                for (int j = 0; j < kRomChunk / 64; ++j) { const int k = k0 + lane + 64 * j; xs[j] = k < d ? cs[k] : 0.0; }
+                for (int r = 0; r < nb; ++r) {
+                    const double *cc = w.C + static_cast<size_t>(s_cand[b0 + r]) * d;
+#pragma unroll
+                    for (int j = 0; j < kRomChunk / 64; ++j) {
+                        const int k = k0 + lane + 64 * j;
+                        const double diff = __dsub_rn(k < d ? cc[k] : 0.0, xs[j]);
+                        s_t[r][lane + 64 * j] = __dmul_rn(diff, diff);
+                    }
+                }
+                WaveMem::wave_sync();
+                if (lane < nb) {
+                    const int kn = d - k0 < kRomChunk ? d - k0 : kRomChunk;
+                    for (int kk = 0; kk < kn; ++kk) sum = __dadd_rn(sum, s_t[lane][kk]);   // sqeuclidean_extended (FastClusterWrapper.cpp:68-75): sequential in k
+                }
+                WaveMem::wave_sync();
+            }
+            const bool mine = lane < nb;
+            if (mine && sum != sum) w.flags[0] = 1;
+            const double sv = mine ? sum : dinf();
+            const double bm = wave_min(sv == sv ? sv : dinf());
+            const int bi = static_cast<int>(wave_umin((mine && sv == bm && bm < dinf()) ? static_cast<unsigned>(s_cand[b0 + lane]) : static_cast<unsigned>(INT_MAX)));
+            if (lt2(bm, bi, best, best_id)) { best = bm; best_id = bi; }
+        }
+    }
+    const int nan_flag = w.flags[0];
+    if (nan_flag || best_id == INT_MAX) {       // NaN distance (nan_error) / nothing to scan
+        if (lane == 0) { st.done = 1; st.nan_seen = nan_flag ? 1 : 2; *w.dev = st; }
+        return;
+    }
+    fa_ro::SelT<fa_ro::HeapK<WaveMem>> sel;
+    sel.heap.ent = w.ent; sel.heap.pos = w.pos; sel.heap.size = st.heap_size; sel.heap.mem.buf = s_buf;
+    sel.list.next = w.next; sel.list.prev = w.prev; sel.list.first = st.list_first;
+    sel.nghbr = w.nghbr; sel.n = st.n; sel.merges = st.merges; sel.op = st.op; sel.a = st.a; sel.b = st.b;
+    sel.pair_a = w.pair_a; sel.pair_b = w.pair_b; sel.height_sq = w.height_sq;
+    sel.scan_result(best, best_id);
+    rom_prepare(st, sel, w.slot_of, w.sizes);
+    st.scans = st.scans + 1;
+    if (lane == 0) *w.dev = st;
+}
+
 // ------------------------------------------------------------------------------ host driver
 struct Layout {
     size_t state, cnt, flags, prof, c, xt, row, e2, node, sizes, z, reca, reci, recs, recp, cand, pairs, norms, m, total;
 };
+
+size_t rom_total_bytes(size_t N, size_t Np, size_t d);   // workspace of the matrix-filtered reference-order run (below)
 
 Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
     Layout L{};
@@ -1875,7 +2116,7 @@ Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
     L.c = take(sizeof(double) * d * 2 * N);
     L.xt = take(sizeof(double) * d * Np);
     L.m = take(sizeof(double) * Np * Np);
-    L.total = o;
+    L.total = std::max(o, rom_total_bytes(N, Np, d));   // a run that meets an exact tie continues in reference order in the SAME workspace (no second hipMalloc of N^2 * 8 B)
     return L;
 }
 
@@ -2034,7 +2275,7 @@ struct RoundGraph {   // `rounds` rounds captured once, replayed until every pro
 namespace {
 
 // The whole problem in the reference's selection order (see the kernels above).  d_data / d_Z: device pointers.
-fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host = false) {
+fa_status ro_run_device_mf(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host = false) {
     // O(N d) memory: points / centroids, their slot-major transpose, the reference's heap and list arrays — no distance matrix, so neither the
     // block-record limit of the filter-based rounds nor HBM bounds N here (the start-up computes the nearest lower neighbours tile-wise)
     if (d * sizeof(double) > 60 * 1024) return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: dimension too large for the LDS centroid buffer");
@@ -2132,6 +2373,162 @@ fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, d
     return FA_SUCCESS;
 }
 
+
+// Workspace of the matrix-filtered run: the selection's arrays, then what the start-up kernels of the filter-based rounds expect (points / centroids,
+// transpose, norms, the two state records their maxima go to), the matrix last.
+struct RomLayout { size_t dev, flags, part, part2, node, slot, sizes, key, ent, pos, ngh, next, prev, pa, pb, hs, z, state, norms, c, xt, m, total; };
+RomLayout rom_layout(size_t N, size_t Np, size_t d) {
+    RomLayout L{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~static_cast<size_t>(255); return at; };
+    const size_t nblk = Np / kBlk;
+    L.dev = take(sizeof(RomDev)); L.flags = take(16); L.state = take(sizeof(AhcState) * 2);
+    L.part = take(sizeof(RomPart) * nblk); L.part2 = take(8 * nblk);
+    L.node = take(4 * Np); L.slot = take(4 * 2 * N); L.sizes = take(8 * 2 * N); L.key = take(8 * N); L.ent = take(sizeof(fa_ro::Ent) * N); L.pos = take(4 * 2 * N);
+    L.ngh = take(4 * 2 * N); L.next = take(4 * (2 * N + 1)); L.prev = take(4 * (2 * N + 1));
+    L.pa = take(8 * N); L.pb = take(8 * N); L.hs = take(8 * N); L.z = take(8 * 4 * N);
+    L.norms = take(8 * Np); L.c = take(8 * d * 2 * N); L.xt = take(8 * d * Np); L.m = take(8 * Np * Np);
+    L.total = o;
+    return L;
+}
+
+size_t rom_total_bytes(size_t N, size_t Np, size_t d) { return rom_layout(N, Np, d).total; }
+
+// The whole problem in the reference's selection order with the matrix as the filter of its scans.  `declined` (no error recorded): the matrix cannot be
+// had, or the Gram-form start-up met a non-finite entry (infinite coordinates: the sums of the matrix-free run decide what they mean) — the caller runs
+// the matrix-free form instead.
+fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host, bool &declined) {
+    declined = true;
+    if (N < 2 || d * sizeof(double) > 60 * 1024) return FA_SUCCESS;
+    const size_t Np = (N + kBlk - 1) / kBlk * kBlk, nblk = Np / kBlk;
+    if (nblk > static_cast<size_t>(kMaxBlocks)) return FA_SUCCESS;
+    const RomLayout L = rom_layout(N, Np, d);
+    if (fa::ws_acquire(ctx, L.total) != FA_SUCCESS) { ctx->last_error.clear(); return FA_SUCCESS; }
+    char *base = static_cast<char *>(ctx->ahc_ws);
+    RomWs w{};
+    w.dev = reinterpret_cast<RomDev *>(base + L.dev); w.flags = reinterpret_cast<int32_t *>(base + L.flags);
+    w.part = reinterpret_cast<RomPart *>(base + L.part); w.part2 = reinterpret_cast<double *>(base + L.part2);
+    w.node = reinterpret_cast<int32_t *>(base + L.node); w.slot_of = reinterpret_cast<int32_t *>(base + L.slot); w.sizes = reinterpret_cast<double *>(base + L.sizes);
+    w.ent = reinterpret_cast<fa_ro::Ent *>(base + L.ent); w.pos = reinterpret_cast<int32_t *>(base + L.pos);
+    w.nghbr = reinterpret_cast<int32_t *>(base + L.ngh); w.next = reinterpret_cast<int32_t *>(base + L.next); w.prev = reinterpret_cast<int32_t *>(base + L.prev);
+    w.pair_a = reinterpret_cast<double *>(base + L.pa); w.pair_b = reinterpret_cast<double *>(base + L.pb); w.height_sq = reinterpret_cast<double *>(base + L.hs);
+    w.C = reinterpret_cast<double *>(base + L.c); w.XT = reinterpret_cast<double *>(base + L.xt); w.M = reinterpret_cast<double *>(base + L.m);
+    w.N = static_cast<int32_t>(N); w.Np = static_cast<int32_t>(Np); w.d = static_cast<int32_t>(d); w.nblk = static_cast<int32_t>(nblk);
+    RoWs rw{};   // the kernels shared with the matrix-free run (ro_init, ro_lower_minima_direct, ro_finish) see their own view of the same arrays
+    rw.C = w.C; rw.XT = w.XT; rw.sizes = w.sizes; rw.key = reinterpret_cast<double *>(base + L.key); rw.pair_a = w.pair_a; rw.pair_b = w.pair_b; rw.height_sq = w.height_sq;
+    rw.Z = reinterpret_cast<double *>(base + L.z); rw.node = w.node; rw.slot_of = w.slot_of; rw.nghbr = w.nghbr; rw.flags = w.flags;
+    rw.N = w.N; rw.Np = w.Np; rw.d = w.d; rw.nblk = w.nblk;
+    Ws gw{};     // ... and the Gram-form start-up of the filter-based rounds its own (its non-finite flag lands in flags[2])
+    gw.state = reinterpret_cast<AhcState *>(base + L.state); gw.flags = w.flags + 2; gw.node = w.node; gw.XT = w.XT; gw.M = w.M; gw.C = w.C;
+    gw.N = w.N; gw.Np = w.Np; gw.d = w.d; gw.nblk = w.nblk;
+    double *d_norms = reinterpret_cast<double *>(base + L.norms);
+    hipStream_t st = ctx->stream;
+    hipEvent_t ev[3];
+    for (auto &e : ev) FA_HIP_TRY(ctx, hipEventCreate(&e));
+    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
+    FA_HIP_TRY(ctx, hipEventRecord(ev[0], st));
+    // ---- start-up: the reference's nearest lower-indexed neighbours (exact sums), and the Gram-form matrix of all pairs
+    FA_HIP_TRY(ctx, hipMemsetAsync(base + L.dev, 0, L.part - L.dev, st));              // RomDev, flags, the two state records (their maxima start at 0)
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(ro_init, dim3(static_cast<unsigned>((std::max(Np, 2 * N) + 255) / 256)), dim3(256), 0, st, rw);
+    hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, st, d_data, w.XT, w.N, w.Np, w.d);
+    hipLaunchKernelGGL(ro_lower_minima_direct, dim3(static_cast<unsigned>((N + kRoT - 1) / kRoT)), dim3(256), 0, st, rw);
+    hipLaunchKernelGGL(ahc_sqnorms, dim3((w.Np + 255) / 256), dim3(256), 0, st, gw, d_norms);
+    if (w.d % G2K == 0) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_gram_mfma2), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGram2LdsBytes));
+        FA_HIP_TRY(ctx, attr);
+        hipLaunchKernelGGL(ahc_gram_mfma2, dim3(w.Np / GT, w.Np / GT), dim3(256), kGram2LdsBytes, st, gw, d_norms);
+    } else
+        hipLaunchKernelGGL(ahc_gram_mfma, dim3(w.Np / GT, w.Np / GT), dim3(256), 0, st, gw, d_norms);
+    FA_HIP_TRY(ctx, hipGetLastError());
+    // ---- the heap over points 1 .. N-1, the list, the first pair: host (the selection logic is the same header on both sides)
+    std::vector<double> key(2 * N, 0.0), pa(N, 0.0), pb(N, 0.0), hs(N, 0.0);
+    std::vector<int32_t> at(N, 0), pos(2 * N, 0), ngh(2 * N, 0), next(2 * N + 1, 0), prev(2 * N + 1, 0);
+    int32_t hflags[4] = {0, 0, 0, 0};
+    AhcState hstate{};
+    FA_HIP_TRY(ctx, hipMemcpyAsync(key.data(), rw.key, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(ngh.data(), w.nghbr, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(hflags, w.flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(&hstate, gw.state, sizeof(hstate), hipMemcpyDeviceToHost, st));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (hflags[0]) { declined = false; return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance"); }
+    if (hflags[2]) return FA_SUCCESS;                                                  // declined: a non-finite Gram entry
+    declined = false;
+    fa_ro::Sel sel{};
+    sel.heap.key = key.data(); sel.heap.at = at.data(); sel.heap.pos = pos.data();
+    sel.heap.init_identity(static_cast<int32_t>(N) - 1, 1);
+    sel.heap.heapify();
+    sel.list.next = next.data(); sel.list.prev = prev.data();
+    sel.list.init(2 * static_cast<int32_t>(N) - 1);
+    sel.nghbr = ngh.data(); sel.n = static_cast<int32_t>(N); sel.merges = 0; sel.pair_a = pa.data(); sel.pair_b = pb.data(); sel.height_sq = hs.data();
+    sel.advance();
+    std::vector<fa_ro::Ent> ent(N);
+    for (int32_t p = 0; p < sel.heap.size; ++p) { ent[p].key = key[at[p]]; ent[p].node = at[p]; ent[p].pad = 0; }
+    std::vector<int32_t> slot0(2 * N, -1);
+    for (size_t i = 0; i < N; ++i) slot0[i] = static_cast<int32_t>(i);
+    const std::vector<double> ones(2 * N, 1.0);
+    RomDev hd{};
+    rom_prepare(hd, sel, slot0.data(), ones.data());
+    {   // eps of ahc_set_eps + the term of d(a, b): here the pair's exact squared distance is the reference's SEQUENTIAL sum (<= (d + 2) u of it, weight
+        // wa wb <= 1/4 per merge level) where the filter-based rounds sum it as a tree
+        const double dmax = __builtin_bit_cast(double, hstate.dmax_bits), nmax = __builtin_bit_cast(double, hstate.nmax_bits), u = 1.1102230246251565e-16;
+        hd.eps = (16.0 + 0.25 * (static_cast<double>(d) + 2.0)) * static_cast<double>(N) * u * dmax + 8.0 * (static_cast<double>(d) + 2.0) * u * nmax;
+    }
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.ent, ent.data(), sizeof(fa_ro::Ent) * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.pos, pos.data(), sizeof(int32_t) * 2 * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.nghbr, ngh.data(), sizeof(int32_t) * 2 * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.next, next.data(), sizeof(int32_t) * (2 * N + 1), hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.prev, prev.data(), sizeof(int32_t) * (2 * N + 1), hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.pair_a, pa.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.pair_b, pb.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.height_sq, hs.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipMemcpyAsync(w.dev, &hd, sizeof(hd), hipMemcpyHostToDevice, st));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(st));   // the vectors above are host temporaries
+    FA_HIP_TRY(ctx, hipEventRecord(ev[1], st));
+    // ---- one (scan, select) pair per dendrogram row, re-scan or exact re-evaluation, replayed from a graph until the device reports the end
+    const size_t lds = sizeof(double) * d;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rom_scan), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    auto launch = [&](const int) {
+        hipLaunchKernelGGL(rom_scan, dim3(w.nblk), dim3(kBlk), lds, st, w);
+        hipLaunchKernelGGL(rom_select, dim3(1), dim3(64), 0, st, w);
+    };
+    RoundGraph rg;
+    rg.capture(ctx, launch, static_cast<int>(std::min<size_t>(256, (N + 3) & ~static_cast<size_t>(3))));
+    const long long max_replays = 16 + 16 * static_cast<long long>(N) / rg.rounds;   // rows + re-scans + exact re-evaluations
+    for (long long it = 0; it < max_replays && !hd.done; ++it) {
+        FA_TRY(rg.replay(ctx, launch));
+        FA_HIP_TRY(ctx, hipMemcpyAsync(&hd, w.dev, sizeof(hd), hipMemcpyDeviceToHost, st));
+        FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    if (hd.nan_seen == 1) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
+    if (!hd.done || hd.nan_seen || hd.merges != static_cast<int32_t>(N) - 1) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: reference-order run stopped at row %d", hd.merges);
+    hipLaunchKernelGGL(ro_finish, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, st, rw);
+    FA_HIP_TRY(ctx, hipMemcpyAsync(d_Z, rw.Z, sizeof(double) * 4 * (N - 1), z_on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+    FA_HIP_TRY(ctx, hipEventRecord(ev[2], st));
+    FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (getenv("FA_AHC_DEBUG"))
+        fprintf(stderr, "ahc (reference order, matrix filter): N %zu scans %lld exact re-evaluations %lld candidates %lld eps %.3e\n", N, hd.scans, hd.exact_scans, hd.cands, hd.eps);
+    if (stats) {
+        float t01 = 0, t12 = 0;
+        (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+        stats->merges = hd.merges; stats->rounds += hd.scans + hd.exact_scans; if (!stats->reference_order) stats->reference_order = 1;
+        stats->rescans += hd.exact_scans;   // rows whose candidates were too many for one wavefront: scanned again with exact sums
+        stats->init_ms += t01; stats->merge_ms += t12; stats->total_ms += t01 + t12;
+    }
+    return FA_SUCCESS;
+}
+
+// The reference-order run: through the matrix filter when the workspace is to be had, matrix-free (O(N d) memory, O(A d) sums per row) when not.
+fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host = false) {
+    if (getenv("FA_AHC_RO_NO_MATRIX") == nullptr) {
+        bool declined = false;
+        const fa_status st = rom_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host, declined);
+        if (!declined) return st;
+    }
+    return ro_run_device_mf(ctx, d_data, N, d, d_Z, stats, z_on_host);
+}
+
 }  // namespace
 
 namespace {
@@ -2161,7 +2558,7 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     fa::WsUse ws_use(ctx);                      // released (and trimmed to the context's limit) when the call returns
     auto without_matrix = [&]() {
         if (stats) { *stats = fa_ahc_stats{}; stats->reference_order = 2; }
-        const fa_status st = ro_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host);
+        const fa_status st = ro_run_device_mf(ctx, d_data, N, d, d_Z, stats, z_on_host);
         if (st == FA_SUCCESS) ctx->last_error.clear();
         return st;
     };

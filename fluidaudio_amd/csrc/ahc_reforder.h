@@ -109,7 +109,7 @@ struct Heap {
 // SerialMem (host, CPU tests) copies entry by entry; the device policy (ahc.hip: WaveMem) has the 64 lanes of the selecting wavefront load
 // the block into LDS in one round trip.  On the device every lane executes every store of the walk (same address, same value): a lane's later
 // loads — also the block loads, where lane l reads entries the walk wrote earlier — then see the latest values by its own program order.
-struct Ent { double key; int32_t node, pad; };
+struct alignas(16) Ent { double key; int32_t node, pad; };   // one 16-byte load / store
 
 constexpr int32_t kTreeLevels = 6;                          // levels below the root of a sift-down block
 constexpr int32_t kTreeEnts = (1 << (kTreeLevels + 1)) - 1; // relative indices 0 (the root: not fetched) .. 126

@@ -355,3 +355,42 @@ def test_batch_with_tied_and_tie_free_problems(fa, gpu_ctx, oracle_mod):
     for x, z in zip(probs, zs):
         np.testing.assert_array_equal(z, oracle_mod.linkage_ref(x)[1])
     assert stats[1]["reference_order"] == 1 and stats[3]["reference_order"] == 1 and stats[0]["reference_order"] == 0
+
+
+@pytest.mark.parametrize("form", ["matrix-filter", "matrix-free"])
+@pytest.mark.parametrize("n,d,kind", [(2, 3, "iid"), (3, 2, "iid"), (40, 4, "equal"), (300, 5, "grid"), (600, 16, "equal"), (900, 300, "unit"), (1500, 8, "grid"),
+                                      (2000, 64, "dup90"), (2500, 256, "dup30"), (3000, 256, "unit"), (3000, 48, "lattice")])
+def test_both_reference_order_forms_equal_the_reference(fa, gpu_ctx, oracle_mod, monkeypatch, n, d, kind, form):
+    """FA_AHC_MODE_REFERENCE_ORDER through the matrix filter (round 5: rom_scan / rom_select — Lance-Williams candidates, exact sums of the few, the
+    key-carrying block heap) and matrix-free (FA_AHC_RO_NO_MATRIX: O(A d) sums per row, the restated heap): the reference build's dendrogram row for
+    row.  "equal" / "dup90" overflow the candidate list of one wavefront (ROM_EXACT rows), d = 300 takes two staging passes per candidate, d = 5 / 8
+    the Gram kernel without the LDS-direct loads."""
+    rng = np.random.default_rng(7 * n + d)
+    x = rng.standard_normal((n, d))
+    if kind == "grid":
+        x = np.round(x * 3) / 3
+    elif kind == "equal":
+        x = np.ones((n, d)) * 0.37
+    elif kind == "unit":
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+    elif kind in ("dup30", "dup90"):
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        k = int(n * (0.3 if kind == "dup30" else 0.9))
+        x[rng.integers(0, n, k)] = x[rng.integers(0, n, k)]
+    elif kind == "lattice":
+        x = np.zeros((n, d))
+        x[:, :3] = np.stack(np.meshgrid(np.arange(15.0), np.arange(20.0), np.arange(10.0)), -1).reshape(-1, 3)[rng.permutation(3000)[:n]]
+    x = np.ascontiguousarray(x)
+    if form == "matrix-free":
+        monkeypatch.setenv("FA_AHC_RO_NO_MATRIX", "1")
+    sr, zr = oracle_mod.linkage_ref(x)
+    st, z, stats = fa.linkage(x, mode=fa.AHC_MODE_REFERENCE_ORDER, ctx=gpu_ctx, return_stats=True)
+    assert st == sr == 0, gpu_ctx.last_error()
+    bad = np.nonzero((z != zr).any(axis=1))[0]
+    assert bad.size == 0, f"first differing row {bad[0]} of {n - 1}: device {z[bad[0]]} reference {zr[bad[0]]} ({stats})"
+    assert stats["reference_order"] == 1 and stats["merges"] == n - 1
+    if kind in ("equal", "dup90") and form == "matrix-filter" and n > 200:
+        assert stats["rescans"] > 0, stats                  # rows whose candidates overflowed one wavefront were scanned again with exact sums
+    st2, z2, stats2 = fa.linkage(x, mode=fa.AHC_MODE_AUTO, ctx=gpu_ctx, return_stats=True)   # and through AUTO -> tie -> reference order
+    assert st2 == 0
+    np.testing.assert_array_equal(z2, zr)
