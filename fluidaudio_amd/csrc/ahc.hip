@@ -1900,9 +1900,40 @@ __global__ __launch_bounds__(kBlk) void rom_scan(const RomWs w) {
     const RomDev st = *w.dev;
     if (st.done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x, x = blk * kBlk + tid, Np = w.Np, d = w.d;
-    const int nx = w.node[x];
     double v = dinf();
-    if (st.kind == ROM_EXACT) {                // the reference's sums of node `scanned` against every active node below it (ro_scan's)
+    int nx;
+    if (st.kind == ROM_NEW) {                  // Lance-Williams row of the node created from (a, b) into the row of slot sa
+        // the row copies of both entries are requested NEXT TO node[x], not behind it: they are the valid copies for every column older than a / b
+        // (most of them); only a column that holds a younger node asks for its column copy afterwards
+        double *const ra = w.M + static_cast<size_t>(st.sa) * Np + x;
+        const double *const rb = w.M + static_cast<size_t>(st.sb) * Np + x;
+        double da = *ra, db = *rb;
+        nx = w.node[x];
+        if (nx != kDead && x != st.sa && x != st.sb) {
+            const bool pts = nx < w.N;
+            if (!(st.a > nx || (st.a < w.N && pts))) da = w.M[static_cast<size_t>(x) * Np + st.sa];
+            if (!(st.b > nx || (st.b < w.N && pts))) db = w.M[static_cast<size_t>(x) * Np + st.sb];
+            const double den = st.ma + st.mb, inv = 1.0 / den, wa = st.ma * inv, wb = st.mb * inv, wab = wa * wb;
+            v = wa * da + wb * db - wab * st.dab;
+            if (!(v > 0.0)) v = 0.0;
+            *ra = v;
+        }
+        if (x == st.sa) { w.node[x] = st.created; w.slot_of[st.created] = x; w.sizes[st.created] = st.ma + st.mb; }
+        if (x == st.sb) w.node[x] = kDead;
+        if (st.sa / kBlk == blk) {             // merged centroid (FastClusterWrapper.cpp:89-100): by node id, and into the slot-major transpose
+            const double *ca = w.C + static_cast<size_t>(st.a) * d, *cb = w.C + static_cast<size_t>(st.b) * d, den = st.ma + st.mb;
+            for (int k = tid; k < d; k += kBlk) {
+                const double cc = __ddiv_rn(__dadd_rn(__dmul_rn(ca[k], st.ma), __dmul_rn(cb[k], st.mb)), den);
+                w.C[static_cast<size_t>(st.created) * d + k] = cc;
+                w.XT[static_cast<size_t>(k) * Np + st.sa] = cc;
+            }
+        }
+    } else if (st.kind == ROM_RESCAN) {        // the row of a is valid against every older node
+        const double e = w.M[static_cast<size_t>(st.sa) * Np + x];
+        nx = w.node[x];
+        if (nx != kDead && x != st.sa && nx < st.scanned) v = e;
+    } else {                                   // ROM_EXACT: the reference's sums of node `scanned` against every active node below it (ro_scan's)
+        nx = w.node[x];
         const double *cs = w.C + static_cast<size_t>(st.scanned) * d;
         for (int k = tid; k < d; k += kBlk) s_c[k] = cs[k];
         __syncthreads();
@@ -1917,37 +1948,17 @@ __global__ __launch_bounds__(kBlk) void rom_scan(const RomWs w) {
             if (sum != sum) w.flags[0] = 1;
             v = sum;
         }
-    } else if (st.kind == ROM_NEW) {           // Lance-Williams row of the node created from (a, b) into the row of slot sa
-        if (nx != kDead && x != st.sa && x != st.sb) {
-            const double da = pair_entry(w.M, Np, st.sa, st.a, x, nx, w.N), db = pair_entry(w.M, Np, st.sb, st.b, x, nx, w.N);
-            const double den = st.ma + st.mb, inv = 1.0 / den, wa = st.ma * inv, wb = st.mb * inv, wab = wa * wb;
-            v = wa * da + wb * db - wab * st.dab;
-            if (!(v > 0.0)) v = 0.0;
-            w.M[static_cast<size_t>(st.sa) * Np + x] = v;
-        }
-        if (x == st.sa) { w.node[x] = st.created; w.slot_of[st.created] = x; w.sizes[st.created] = st.ma + st.mb; }
-        if (x == st.sb) w.node[x] = kDead;
-        if (st.sa / kBlk == blk) {             // merged centroid (FastClusterWrapper.cpp:89-100): by node id, and into the slot-major transpose
-            const double *ca = w.C + static_cast<size_t>(st.a) * d, *cb = w.C + static_cast<size_t>(st.b) * d, den = st.ma + st.mb;
-            for (int k = tid; k < d; k += kBlk) {
-                const double cc = __ddiv_rn(__dadd_rn(__dmul_rn(ca[k], st.ma), __dmul_rn(cb[k], st.mb)), den);
-                w.C[static_cast<size_t>(st.created) * d + k] = cc;
-                w.XT[static_cast<size_t>(k) * Np + st.sa] = cc;
-            }
-        }
-    } else if (nx != kDead && x != st.sa && nx < st.scanned) {   // ROM_RESCAN: the row of a is valid against every older node
-        v = w.M[static_cast<size_t>(st.sa) * Np + x];
     }
     // block minimum by (value, node id) + the block's second smallest value
-    const double m = wave_min(v);
+    const double m = wave_min(v == v ? v : dinf());
     const bool fin = m < dinf();
     const unsigned id = wave_umin((fin && v == m) ? static_cast<unsigned>(nx) : static_cast<unsigned>(INT_MAX));
     const unsigned long long msk = __builtin_amdgcn_ballot_w64(fin && v == m && static_cast<unsigned>(nx) == id);
     const int L = __builtin_amdgcn_readfirstlane(msk ? __ffsll(static_cast<long long>(msk)) - 1 : 0);
     const int x1 = lane_value(x, L);
-    const double second = wave_min(lane == L ? dinf() : v);
+    const double second = wave_min((lane == L || v != v) ? dinf() : v);
     if (lane == 0) { s_v1[wave] = m; s_v2[wave] = second; s_x1[wave] = x1; s_n1[wave] = static_cast<int>(id); }
-    __syncthreads();
+    lds_barrier();
     if (tid != 0) return;
     double bv = s_v1[0], b2 = s_v2[0];
     int bn = s_n1[0], bx = s_x1[0];
@@ -1959,6 +1970,52 @@ __global__ __launch_bounds__(kBlk) void rom_scan(const RomWs w) {
     RomPart pt; pt.v1 = bv; pt.x1 = bx; pt.n1 = bn;
     w.part[blk] = pt;
     w.part2[blk] = b2;
+}
+
+// Start-up of the matrix-filtered run: the reference's nearest LOWER-indexed neighbour of every point (fastcluster_internal.hpp:1653-1678) with the
+// Gram-form matrix as the filter — row i: the smallest entry left of the diagonal, every entry within 2 eps of it is a candidate, the candidates (one, on
+// tie-free rows) get the reference's sequential sum, lowest (value, index) wins.  Reads the lower triangle twice (2 x 7.5 GB at 43 200 points) where
+// ro_lower_minima_direct evaluates all N^2 / 2 sums (57 ms there).  One workgroup per row.
+__global__ __launch_bounds__(kBlk) void rom_lower_minima(const RomWs w, const AhcState *__restrict__ state, double *__restrict__ key) {
+    __shared__ double s_v[kWaves];
+    __shared__ int s_i[kWaves];
+    const int i = blockIdx.x + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = w.d;
+    const double *row = w.M + static_cast<size_t>(i) * w.Np;
+    double mv = dinf();
+    for (int j = tid; j < i; j += kBlk) { const double e = row[j]; if (e < mv) mv = e; }
+    mv = wave_min(mv);
+    if (lane == 0) s_v[wave] = mv;
+    __syncthreads();
+    double m = s_v[0];
+#pragma unroll
+    for (int wv = 1; wv < kWaves; ++wv) if (s_v[wv] < m) m = s_v[wv];
+    __syncthreads();
+    const double dmax = __longlong_as_double(static_cast<long long>(state[0].dmax_bits)), nmax = __longlong_as_double(static_cast<long long>(state[0].nmax_bits));
+    const double u = 1.1102230246251565e-16;
+    const double lim = m + 2.0 * (16.0 * static_cast<double>(w.N) * u * dmax + 8.0 * (static_cast<double>(d) + 2.0) * u * nmax);   // ahc_set_eps (a superset of the Gram term alone)
+    const double *xi = w.C + static_cast<size_t>(i) * d;
+    double best = dinf();
+    int arg = INT_MAX;
+    for (int j = tid; j < i; j += kBlk) {
+        if (!(row[j] <= lim)) continue;
+        const double *xj = w.C + static_cast<size_t>(j) * d;
+        double sum = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < d; ++k) { const double diff = __dsub_rn(xi[k], xj[k]); sum = __dadd_rn(sum, __dmul_rn(diff, diff)); }   // FastClusterWrapper.cpp:45-52
+        if (sum != sum) w.flags[0] = 1;
+        else if (lt2(sum, j, best, arg)) { best = sum; arg = j; }   // j ascending per thread
+    }
+    const double bm = wave_min(best);
+    const unsigned bi = wave_umin((best == bm && bm < dinf()) ? static_cast<unsigned>(arg) : static_cast<unsigned>(INT_MAX));
+    if (lane == 0) { s_v[wave] = bm; s_i[wave] = static_cast<int>(bi); }
+    __syncthreads();
+    if (tid != 0) return;
+    double bv = s_v[0];
+    int ba = s_i[0];
+#pragma unroll
+    for (int wv = 1; wv < kWaves; ++wv) if (lt2(s_v[wv], s_i[wv], bv, ba)) { bv = s_v[wv]; ba = s_i[wv]; }
+    key[i] = bv;
+    w.nghbr[i] = ba == INT_MAX ? 0 : ba;
 }
 
 struct WaveMem {   // ahc_reforder.h's block fetches by the 64 lanes of the selecting wavefront
@@ -1984,24 +2041,53 @@ struct WaveMem {   // ahc_reforder.h's block fetches by the 64 lanes of the sele
     __device__ __forceinline__ fa_ro::Ent ent_at(const int32_t j) const { return buf[j]; }
 };
 
+// keeps a value requested early alive up to here without using it (the request warmed the caches for the loads of the selection)
+template <class T> __device__ __forceinline__ void rom_sink(const T v) { asm volatile("" ::"v"(v)); }
+
 __global__ __launch_bounds__(64) void rom_select(const RomWs w) {
     __shared__ fa_ro::Ent s_buf[fa_ro::kTreeEnts + 1];
-    __shared__ double s_t[kRomBatch][kRomChunk + 2];
+    __shared__ __attribute__((aligned(16))) double s_t[kRomBatch][kRomChunk + 2];
     __shared__ int s_cand[kRomCap];
     RomDev st = *w.dev;
     if (st.done) return;
     const int lane = threadIdx.x, Np = w.Np, d = w.d, nblk = w.nblk;
+    // ---- requests whose addresses the state already holds, all in flight together: the block minima, the coordinates of the scanned node, and — values
+    // not used here, the lines are what counts — the words the heap replay will ask for first: pos[] of the node it removes and of a, the last entry, the
+    // top block of the heap
+    constexpr int kFast = 4;                   // block records per lane held in registers (N <= 65 536)
+    const bool fast = nblk <= 64 * kFast;
+    RomPart pr[kFast];
+    double p2[kFast];
+#pragma unroll
+    for (int j = 0; j < kFast; ++j) {
+        const int b = lane + 64 * j, bc = b < nblk ? b : nblk - 1;
+        pr[j] = w.part[bc]; p2[j] = w.part2[bc];
+        if (b >= nblk) { pr[j].v1 = dinf(); pr[j].n1 = INT_MAX; p2[j] = dinf(); }
+    }
+    const double *cs = w.C + static_cast<size_t>(st.scanned) * d;
+    double xs0[kRomChunk / 64];
+#pragma unroll
+    for (int j = 0; j < kRomChunk / 64; ++j) { const int k = lane + 64 * j; xs0[j] = cs[k < d ? k : d - 1]; }
+    const int warm_node = lane == 0 ? (st.op == fa_ro::RO_NEW_ROW ? (st.b < st.list_first ? st.list_first : st.b) : st.a) : st.a;
+    const int warm_pos = w.pos[warm_node];
+    const int hs1 = st.heap_size > 1 ? st.heap_size - 1 : 0;
+    const fa_ro::Ent warm_a = w.ent[lane < hs1 ? lane : hs1], warm_b = w.ent[64 + lane < hs1 ? 64 + lane : hs1];
+
     double best = dinf();
     int best_id = INT_MAX;
     if (st.kind == ROM_EXACT) {                // the block minima are the reference's sums: lowest (value, node id)
         double v = dinf();
         int id = INT_MAX;
         for (int b = lane; b < nblk; b += 64) { const RomPart pt = w.part[b]; if (lt2(pt.v1, pt.n1, v, id)) { v = pt.v1; id = pt.n1; } }
-        best = wave_min(v);
+        best = wave_min(v == v ? v : dinf());
         best_id = static_cast<int>(wave_umin((v == best && best < dinf()) ? static_cast<unsigned>(id) : static_cast<unsigned>(INT_MAX)));
     } else {
         double mv = dinf();
-        for (int b = lane; b < nblk; b += 64) { const double v1 = w.part[b].v1; if (v1 < mv) mv = v1; }
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < kFast; ++j) if (pr[j].v1 < mv) mv = pr[j].v1;
+        } else
+            for (int b = lane; b < nblk; b += 64) { const double v1 = w.part[b].v1; if (v1 < mv) mv = v1; }
         const double m = wave_min(mv);
         int ncand = 0;
         if (m < dinf()) {
@@ -2011,7 +2097,10 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w) {
                 const int b = base + lane;
                 RomPart pt; pt.v1 = dinf(); pt.x1 = -1; pt.n1 = INT_MAX;
                 double v2 = dinf();
-                if (b < nblk) { pt = w.part[b]; v2 = w.part2[b]; }
+                if (fast) {
+#pragma unroll
+                    for (int j = 0; j < kFast; ++j) if (base == 64 * j) { pt = pr[j]; v2 = p2[j]; }
+                } else if (b < nblk) { pt = w.part[b]; v2 = w.part2[b]; }
                 const bool hit = pt.v1 <= lim, dense = hit && v2 <= lim, single = hit && !dense;
                 const unsigned long long ms = __builtin_amdgcn_ballot_w64(single);
                 const int at = ncand + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(ms >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(ms), 0));
@@ -2021,9 +2110,14 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w) {
                 while (md && ncand <= kRomCap) {   // a block with several entries inside the window: its 256 entries again
                     const int bb = base + __ffsll(static_cast<long long>(md)) - 1;
                     md &= md - 1;
+                    int nxs[kBlk / 64];
+                    double es[kBlk / 64];
+#pragma unroll
+                    for (int j = 0; j < kBlk / 64; ++j) { const int x = bb * kBlk + 64 * j + lane; nxs[j] = w.node[x]; es[j] = row[x]; }
+#pragma unroll
                     for (int j = 0; j < kBlk / 64; ++j) {
-                        const int x = bb * kBlk + 64 * j + lane, nx = w.node[x];
-                        const bool c = nx != kDead && x != st.sa && nx < st.scanned && row[x] <= lim;
+                        const int x = bb * kBlk + 64 * j + lane, nx = nxs[j];
+                        const bool c = nx != kDead && x != st.sa && nx < st.scanned && es[j] <= lim;
                         const unsigned long long mc = __builtin_amdgcn_ballot_w64(c);
                         const int ac = ncand + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mc >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mc), 0));
                         if (c && ac < kRomCap) s_cand[ac] = nx;
@@ -2033,43 +2127,58 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w) {
             }
         }
         if (ncand > kRomCap) {                 // too many for one wavefront: the same row by exact sums of every workgroup, then back here
+            rom_sink(warm_pos); rom_sink(warm_a.node); rom_sink(warm_b.node); rom_sink(xs0[0]);
             if (lane == 0) { st.kind = ROM_EXACT; st.exact_scans = st.exact_scans + 1; *w.dev = st; }
             return;
         }
         st.cands = st.cands + ncand;
         WaveMem::wave_sync();
-        const double *cs = w.C + static_cast<size_t>(st.scanned) * d;
         for (int b0 = 0; b0 < ncand; b0 += kRomBatch) {
             const int nb = ncand - b0 < kRomBatch ? ncand - b0 : kRomBatch;
             double sum = 0.0;
             for (int k0 = 0; k0 < d; k0 += kRomChunk) {
+                // squares of the coordinate differences by the whole wavefront (one rounding each, as the reference's loop body) ...
                 double xs[kRomChunk / 64];
+                int kc[kRomChunk / 64];
 #pragma unroll
-                for (int j = 0; j < kRomChunk / 64; ++j) { const int k = k0 + lane + 64 * j; xs[j] = k < d ? cs[k] : 0.0; }
+                for (int j = 0; j < kRomChunk / 64; ++j) { const int k = k0 + lane + 64 * j; kc[j] = k < d ? k : d - 1; }   // clamped: every request unconditional, all in flight
+                if (k0 == 0) {
+#pragma unroll
+                    for (int j = 0; j < kRomChunk / 64; ++j) xs[j] = xs0[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kRomChunk / 64; ++j) xs[j] = cs[kc[j]];
+                }
                 for (int r = 0; r < nb; ++r) {
                     const double *cc = w.C + static_cast<size_t>(s_cand[b0 + r]) * d;
+                    double cv[kRomChunk / 64];
 #pragma unroll
-                    for (int j = 0; j < kRomChunk / 64; ++j) {
-                        const int k = k0 + lane + 64 * j;
-                        const double diff = __dsub_rn(k < d ? cc[k] : 0.0, xs[j]);
-                        s_t[r][lane + 64 * j] = __dmul_rn(diff, diff);
-                    }
+                    for (int j = 0; j < kRomChunk / 64; ++j) cv[j] = cc[kc[j]];
+#pragma unroll
+                    for (int j = 0; j < kRomChunk / 64; ++j) { const double diff = __dsub_rn(cv[j], xs[j]); s_t[r][lane + 64 * j] = __dmul_rn(diff, diff); }
                 }
                 WaveMem::wave_sync();
+                // ... summed by ONE lane per candidate in the reference's order (sqeuclidean_extended, FastClusterWrapper.cpp:68-75: sequential in k)
                 if (lane < nb) {
                     const int kn = d - k0 < kRomChunk ? d - k0 : kRomChunk;
-                    for (int kk = 0; kk < kn; ++kk) sum = __dadd_rn(sum, s_t[lane][kk]);   // sqeuclidean_extended (FastClusterWrapper.cpp:68-75): sequential in k
+                    if (kn == kRomChunk) {
+                        const double2 *tp = reinterpret_cast<const double2 *>(&s_t[lane][0]);
+#pragma unroll 16
+                        for (int q = 0; q < kRomChunk / 2; ++q) { const double2 t = tp[q]; sum = __dadd_rn(sum, t.x); sum = __dadd_rn(sum, t.y); }
+                    } else
+                        for (int kk = 0; kk < kn; ++kk) sum = __dadd_rn(sum, s_t[lane][kk]);
                 }
                 WaveMem::wave_sync();
             }
             const bool mine = lane < nb;
             if (mine && sum != sum) w.flags[0] = 1;
-            const double sv = mine ? sum : dinf();
-            const double bm = wave_min(sv == sv ? sv : dinf());
+            const double sv = (mine && sum == sum) ? sum : dinf();
+            const double bm = wave_min(sv);
             const int bi = static_cast<int>(wave_umin((mine && sv == bm && bm < dinf()) ? static_cast<unsigned>(s_cand[b0 + lane]) : static_cast<unsigned>(INT_MAX)));
             if (lt2(bm, bi, best, best_id)) { best = bm; best_id = bi; }
         }
     }
+    rom_sink(warm_pos); rom_sink(warm_a.node); rom_sink(warm_b.node); rom_sink(xs0[0]);
     const int nan_flag = w.flags[0];
     if (nan_flag || best_id == INT_MAX) {       // NaN distance (nan_error) / nothing to scan
         if (lane == 0) { st.done = 1; st.nan_seen = nan_flag ? 1 : 2; *w.dev = st; }
@@ -2432,7 +2541,8 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(ro_init, dim3(static_cast<unsigned>((std::max(Np, 2 * N) + 255) / 256)), dim3(256), 0, st, rw);
     hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, st, d_data, w.XT, w.N, w.Np, w.d);
-    hipLaunchKernelGGL(ro_lower_minima_direct, dim3(static_cast<unsigned>((N + kRoT - 1) / kRoT)), dim3(256), 0, st, rw);
+    const bool direct_start = getenv("FA_AHC_ROM_DIRECT_START") != nullptr;   // the start-up of the matrix-free run (all N^2 / 2 exact sums) for A/B
+    if (direct_start) hipLaunchKernelGGL(ro_lower_minima_direct, dim3(static_cast<unsigned>((N + kRoT - 1) / kRoT)), dim3(256), 0, st, rw);
     hipLaunchKernelGGL(ahc_sqnorms, dim3((w.Np + 255) / 256), dim3(256), 0, st, gw, d_norms);
     if (w.d % G2K == 0) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_gram_mfma2), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGram2LdsBytes));
@@ -2440,6 +2550,7 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
         hipLaunchKernelGGL(ahc_gram_mfma2, dim3(w.Np / GT, w.Np / GT), dim3(256), kGram2LdsBytes, st, gw, d_norms);
     } else
         hipLaunchKernelGGL(ahc_gram_mfma, dim3(w.Np / GT, w.Np / GT), dim3(256), 0, st, gw, d_norms);
+    if (!direct_start) hipLaunchKernelGGL(rom_lower_minima, dim3(static_cast<unsigned>(N - 1)), dim3(kBlk), 0, st, w, gw.state, rw.key);
     FA_HIP_TRY(ctx, hipGetLastError());
     // ---- the heap over points 1 .. N-1, the list, the first pair: host (the selection logic is the same header on both sides)
     std::vector<double> key(2 * N, 0.0), pa(N, 0.0), pb(N, 0.0), hs(N, 0.0);
@@ -2451,8 +2562,8 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     FA_HIP_TRY(ctx, hipMemcpyAsync(hflags, w.flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(ctx, hipMemcpyAsync(&hstate, gw.state, sizeof(hstate), hipMemcpyDeviceToHost, st));
     FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (hflags[2]) return FA_SUCCESS;                                                  // declined: a non-finite Gram entry (the matrix-free run decides what the input means)
     if (hflags[0]) { declined = false; return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance"); }
-    if (hflags[2]) return FA_SUCCESS;                                                  // declined: a non-finite Gram entry
     declined = false;
     fa_ro::Sel sel{};
     sel.heap.key = key.data(); sel.heap.at = at.data(); sel.heap.pos = pos.data();

@@ -152,33 +152,34 @@ struct HeapK {
     FA_HD void sift_down(int32_t i, const Ent e) {             // Heap::sift_down with the entry `e` arriving at place i
         for (;;) {
             mem.fetch_tree(ent, i, size);
-            int32_t t = 0;
+            int32_t t = 0;                                      // relative index in the block and place in the heap of where the entry stands
+            int64_t P = i;
             bool rest = false;
             while (t < (1 << kTreeLevels) - 1) {                // t on levels 0 .. 5: both children are in the block
-                int32_t j = 2 * t + 1;
-                if (heap_tree_place(i, j) >= size) { rest = true; break; }
-                const double kl = mem.key_at(j);
-                if (kl >= e.key) {                              // left child not smaller: only a strictly smaller right child moves up
-                    ++j;
-                    if (heap_tree_place(i, j) >= size || mem.key_at(j) >= e.key) { rest = true; break; }
-                } else if (heap_tree_place(i, j + 1) < size && mem.key_at(j + 1) < kl) {
-                    ++j;                                        // both smaller: the right one only if strictly smaller than the left
-                }
-                put(heap_tree_place(i, t), mem.ent_at(j));
-                t = j;
+                const int32_t j = 2 * t + 1;
+                const int64_t Pj = 2 * P + 1;
+                if (Pj >= size) { rest = true; break; }
+                const Ent l = mem.ent_at(j), r = mem.ent_at(j + 1);   // both children requested together; r means something only when Pj + 1 < size
+                int32_t right;
+                if (l.key >= e.key) {                           // left child not smaller: only a strictly smaller right child moves up
+                    if (Pj + 1 >= size || r.key >= e.key) { rest = true; break; }
+                    right = 1;
+                } else right = (Pj + 1 < size && r.key < l.key) ? 1 : 0;   // both smaller: the right one only if strictly smaller than the left
+                put(P, right ? r : l);
+                t = j + right;
+                P = Pj + right;
             }
-            const int64_t here = heap_tree_place(i, t);
-            if (rest) { put(here, e); return; }
-            i = static_cast<int32_t>(here);                    // still moving at the bottom of the block: the next six levels
+            if (rest) { put(P, e); return; }
+            i = static_cast<int32_t>(P);                        // still moving at the bottom of the block: the next six levels
         }
     }
     FA_HD int32_t argmin() const { return ent[0].node; }
     FA_HD double top_key() const { return ent[0].key; }
     FA_HD void remove(const int32_t node) {                    // Heap::remove
         --size;
+        const Ent last = ent[size];                             // requested next to pos[node], not behind it
         const int32_t p = pos[node];
         if (p == size) return;                                  // the last entry itself: above, a sift-up that never moves (its parent is not larger)
-        const Ent last = ent[size];
         if (last.key <= ent[p].key) sift_up(p, last);
         else sift_down(p, last);
     }
@@ -211,6 +212,17 @@ struct ActiveList {
         next[i] = 0;
     }
     FA_HD bool gone(const int32_t i) const { return next[i] == 0; }
+    // remove(i) then remove(j) with the four list words (ni = next[i], pi = prev[i], nj = next[j], pj = prev[j]) READ BEFORE either removal — one
+    // memory round trip instead of two dependent ones: what the first removal would have changed for the second (i and j adjacent) is patched in
+    FA_HD void remove2(const int32_t i, const int32_t ni, const int32_t pi, const int32_t j, int32_t nj, int32_t pj) {
+        const bool i_first = i == first;
+        if (i_first) first = ni;
+        else { next[pi] = ni; prev[ni] = pi; if (pi == j) nj = ni; if (ni == j) pj = pi; }
+        next[i] = 0;
+        if (j == first) first = nj;
+        else { next[pj] = nj; prev[nj] = pj; }
+        next[j] = 0;
+    }
 };
 
 // What the single selecting thread does between two device-wide scans.  `Sel` carries the run; a scan is either the search of the
@@ -231,23 +243,22 @@ struct SelT {
     double *pair_a, *pair_b;   // [(n - 1)] dendrogram rows as the reference appends them: (idx1, idx2); heights are mindist[idx1]
     double *height_sq;         // [(n - 1)]
 
-    // take the next pair(s) off the heap until a scan is needed (or the run is complete)
+    // take the next pair off the heap unless a scan is needed first (or the run is complete).  Every word the step needs beyond the heap top is
+    // requested as soon as its address is known (the neighbour's list words next to the top's), not where the reference's statements use it.
     FA_HD void advance() {
-        for (;;) {
-            const int32_t top = heap.argmin();
-            if (list.gone(nghbr[top])) { op = RO_RESCAN; a = top; return; }      // :1705-1734
-            const int32_t other = nghbr[top];
-            list.remove(top);
-            list.remove(other);
-            pair_a[merges] = static_cast<double>(top);
-            pair_b[merges] = static_cast<double>(other);
-            height_sq[merges] = heap.top_key();
-            ++merges;
-            a = top; b = other;
-            if (merges == n - 1) { op = RO_DONE; return; }                        // the last merge creates no row (:1745)
-            op = RO_NEW_ROW;
-            return;
-        }
+        const int32_t top = heap.argmin();
+        const double top_key = heap.top_key();
+        const int32_t other = nghbr[top];
+        const int32_t nt = list.next[top], pt = list.prev[top];
+        const int32_t no = list.next[other], po = list.prev[other];
+        if (no == 0) { op = RO_RESCAN; a = top; return; }                         // the recorded neighbour is gone (:1705-1734)
+        list.remove2(top, nt, pt, other, no, po);
+        pair_a[merges] = static_cast<double>(top);
+        pair_b[merges] = static_cast<double>(other);
+        height_sq[merges] = top_key;
+        ++merges;
+        a = top; b = other;
+        op = merges == n - 1 ? RO_DONE : RO_NEW_ROW;                              // the last merge creates no row (:1745)
     }
     // the scan requested by `op` found (value, node): lowest node id among the minima over the active nodes below the scanned one
     FA_HD void scan_result(const double value, const int32_t node) {

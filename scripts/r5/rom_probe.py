@@ -34,10 +34,14 @@ def run(name, data, mode, env=None, reps=1):
     print(json.dumps({"case": name, "status": st, "wall_s": round(dt, 4), "reference_order": stats["reference_order"], "rounds": stats["rounds"], "exact_rows": stats["rescans"],
                       "init_ms": round(stats["init_ms"], 2), "merge_ms": round(stats["merge_ms"], 2), "us_per_row": round(1e3 * stats["merge_ms"] / (n - 1), 3)}), flush=True)
     return z
+if os.environ.get("ROM_PROBE_ONLY"):          # one run of one form (kernel traces)
+    run("tie-free, REFERENCE_ORDER (matrix filter)", x, fa.AHC_MODE_REFERENCE_ORDER)
+    sys.exit(0)
 z_auto = run("tie-free, AUTO", x, fa.AHC_MODE_AUTO, reps=2)
 z_rom = run("tie-free, REFERENCE_ORDER (matrix filter)", x, fa.AHC_MODE_REFERENCE_ORDER, reps=2)
 z_mf = run("tie-free, REFERENCE_ORDER (matrix-free)", x, fa.AHC_MODE_REFERENCE_ORDER, env="FA_AHC_RO_NO_MATRIX")
 print(json.dumps({"tie-free: matrix filter == matrix-free": bool(np.array_equal(z_rom, z_mf)), "== AUTO": bool(np.array_equal(z_rom, z_auto))}), flush=True)
+run("tie-free, REFERENCE_ORDER (matrix filter, start-up by all N^2 / 2 exact sums)", x, fa.AHC_MODE_REFERENCE_ORDER, env="FA_AHC_ROM_DIRECT_START")
 d_rom = run("30 % duplicates, REFERENCE_ORDER (matrix filter)", dup, fa.AHC_MODE_REFERENCE_ORDER, reps=2)
 d_mf = run("30 % duplicates, REFERENCE_ORDER (matrix-free)", dup, fa.AHC_MODE_REFERENCE_ORDER, env="FA_AHC_RO_NO_MATRIX")
 d_auto = run("30 % duplicates, AUTO (-> tie -> matrix filter)", dup, fa.AHC_MODE_AUTO, reps=2)

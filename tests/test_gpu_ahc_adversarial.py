@@ -363,7 +363,7 @@ def test_batch_with_tied_and_tie_free_problems(fa, gpu_ctx, oracle_mod):
 def test_both_reference_order_forms_equal_the_reference(fa, gpu_ctx, oracle_mod, monkeypatch, n, d, kind, form):
     """FA_AHC_MODE_REFERENCE_ORDER through the matrix filter (round 5: rom_scan / rom_select — Lance-Williams candidates, exact sums of the few, the
     key-carrying block heap) and matrix-free (FA_AHC_RO_NO_MATRIX: O(A d) sums per row, the restated heap): the reference build's dendrogram row for
-    row.  "equal" / "dup90" overflow the candidate list of one wavefront (ROM_EXACT rows), d = 300 takes two staging passes per candidate, d = 5 / 8
+    row.  "equal" overflows the candidate list of one wavefront (ROM_EXACT rows), d = 300 takes two staging passes per candidate, d = 5 / 8
     the Gram kernel without the LDS-direct loads."""
     rng = np.random.default_rng(7 * n + d)
     x = rng.standard_normal((n, d))
@@ -389,7 +389,7 @@ def test_both_reference_order_forms_equal_the_reference(fa, gpu_ctx, oracle_mod,
     bad = np.nonzero((z != zr).any(axis=1))[0]
     assert bad.size == 0, f"first differing row {bad[0]} of {n - 1}: device {z[bad[0]]} reference {zr[bad[0]]} ({stats})"
     assert stats["reference_order"] == 1 and stats["merges"] == n - 1
-    if kind in ("equal", "dup90") and form == "matrix-filter" and n > 200:
+    if kind == "equal" and form == "matrix-filter" and n > 200:
         assert stats["rescans"] > 0, stats                  # rows whose candidates overflowed one wavefront were scanned again with exact sums
     st2, z2, stats2 = fa.linkage(x, mode=fa.AHC_MODE_AUTO, ctx=gpu_ctx, return_stats=True)   # and through AUTO -> tie -> reference order
     assert st2 == 0
