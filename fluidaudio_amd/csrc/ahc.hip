@@ -1893,26 +1893,23 @@ __host__ __device__ inline void rom_prepare(RomDev &st, const S &sel, const int3
     } else st.done = 1;
 }
 
-__global__ __launch_bounds__(kBlk) void rom_scan(const RomWs w) {
+__global__ __launch_bounds__(kBlk) void rom_scan(const RomWs w, const int ph) {
     extern __shared__ double s_c[];            // [d] coordinates of the scanned node (ROM_EXACT)
     __shared__ double s_v1[kWaves], s_v2[kWaves];
     __shared__ int s_x1[kWaves], s_n1[kWaves];
-    const RomDev st = *w.dev;
+    const RomDev st = w.dev[ph];
     if (st.done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x, x = blk * kBlk + tid, Np = w.Np, d = w.d;
     double v = dinf();
     int nx;
     if (st.kind == ROM_NEW) {                  // Lance-Williams row of the node created from (a, b) into the row of slot sa
-        // the row copies of both entries are requested NEXT TO node[x], not behind it: they are the valid copies for every column older than a / b
-        // (most of them); only a column that holds a younger node asks for its column copy afterwards
+        // This run keeps the matrix SYMMETRIC over the live slots (the mirror workgroups of rom_select write the column of every new row while the
+        // selection runs), so both entries are row copies: two coalesced requests next to node[x], nothing behind it.  (The filter-based rounds
+        // read a column copy for every column younger than a — one 8-byte request per lane, each in another 345 KB row.)
         double *const ra = w.M + static_cast<size_t>(st.sa) * Np + x;
-        const double *const rb = w.M + static_cast<size_t>(st.sb) * Np + x;
-        double da = *ra, db = *rb;
+        const double da = *ra, db = w.M[static_cast<size_t>(st.sb) * Np + x];
         nx = w.node[x];
         if (nx != kDead && x != st.sa && x != st.sb) {
-            const bool pts = nx < w.N;
-            if (!(st.a > nx || (st.a < w.N && pts))) da = w.M[static_cast<size_t>(x) * Np + st.sa];
-            if (!(st.b > nx || (st.b < w.N && pts))) db = w.M[static_cast<size_t>(x) * Np + st.sb];
             const double den = st.ma + st.mb, inv = 1.0 / den, wa = st.ma * inv, wb = st.mb * inv, wab = wa * wb;
             v = wa * da + wb * db - wab * st.dab;
             if (!(v > 0.0)) v = 0.0;
@@ -1928,7 +1925,7 @@ __global__ __launch_bounds__(kBlk) void rom_scan(const RomWs w) {
                 w.XT[static_cast<size_t>(k) * Np + st.sa] = cc;
             }
         }
-    } else if (st.kind == ROM_RESCAN) {        // the row of a is valid against every older node
+    } else if (st.kind == ROM_RESCAN) {        // the row of a against every older node
         const double e = w.M[static_cast<size_t>(st.sa) * Np + x];
         nx = w.node[x];
         if (nx != kDead && x != st.sa && nx < st.scanned) v = e;
@@ -2033,8 +2030,19 @@ struct WaveMem {   // ahc_reforder.h's block fetches by the 64 lanes of the sele
     }
     __device__ __forceinline__ void fetch_tree(const fa_ro::Ent *ent, const int32_t root, const int32_t size) {
         const int lane = threadIdx.x & 63;
+        constexpr int kPer = (fa_ro::kTreeEnts - 1 + 63) / 64;   // entries per lane: all requested before the first one is stored (places beyond the heap ask for entry 0)
+        typedef int v4i32 __attribute__((ext_vector_type(4)));    // an entry as one 16-byte register value (an array of the struct went through scratch memory)
+        static_assert(sizeof(fa_ro::Ent) == sizeof(v4i32), "an entry is one 16-byte word");
+        v4i32 v[kPer];
         wave_sync();
-        for (int32_t t = 1 + lane; t < fa_ro::kTreeEnts; t += 64) { const int64_t p = fa_ro::heap_tree_place(root, t); if (p < size) buf[t] = ent[p]; }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int32_t t = 1 + lane + 64 * q, lev = 31 - __clz(t + 1);
+            const int64_t p = ((static_cast<int64_t>(root) + 1) << lev) - 1 + (t + 1 - (1 << lev));   // fa_ro::heap_tree_place(root, t)
+            v[q] = *reinterpret_cast<const v4i32 *>(ent + ((t < fa_ro::kTreeEnts && p < size) ? p : 0));
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) { const int32_t t = 1 + lane + 64 * q; if (t < fa_ro::kTreeEnts) *reinterpret_cast<v4i32 *>(buf + t) = v[q]; }
         wave_sync();
     }
     __device__ __forceinline__ double key_at(const int32_t j) const { return buf[j].key; }
@@ -2044,13 +2052,30 @@ struct WaveMem {   // ahc_reforder.h's block fetches by the 64 lanes of the sele
 // keeps a value requested early alive up to here without using it (the request warmed the caches for the loads of the selection)
 template <class T> __device__ __forceinline__ void rom_sink(const T v) { asm volatile("" ::"v"(v)); }
 
-__global__ __launch_bounds__(64) void rom_select(const RomWs w) {
+// Workgroup 0 (one wavefront) is the selection.  Workgroups 1 .. nblk mirror the row rom_scan has just written into its column, M[x][sa] = M[sa][x]:
+// 8-byte stores into 43 200 different rows that nobody waits for — they drain while the selection walks its heap, and the next rom_scan finds every
+// pair in BOTH orientations.  The state is double buffered by launch parity: the mirror workgroups read the record the selection does not write.
+__global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
     __shared__ fa_ro::Ent s_buf[fa_ro::kTreeEnts + 1];
     __shared__ __attribute__((aligned(16))) double s_t[kRomBatch][kRomChunk + 2];
     __shared__ int s_cand[kRomCap];
-    RomDev st = *w.dev;
+    RomDev st = w.dev[ph];
     if (st.done) return;
     const int lane = threadIdx.x, Np = w.Np, d = w.d, nblk = w.nblk;
+    if (blockIdx.x > 0) {
+        if (st.kind != ROM_NEW) return;
+        const int x0 = (static_cast<int>(blockIdx.x) - 1) * kBlk + lane;
+        const double *row = w.M + static_cast<size_t>(st.sa) * Np;
+        double e[kBlk / 64];
+        int nxs[kBlk / 64];
+#pragma unroll
+        for (int j = 0; j < kBlk / 64; ++j) { e[j] = row[x0 + 64 * j]; nxs[j] = w.node[x0 + 64 * j]; }
+#pragma unroll
+        for (int j = 0; j < kBlk / 64; ++j) { const int x = x0 + 64 * j; if (nxs[j] != kDead && x != st.sa) w.M[static_cast<size_t>(x) * Np + st.sa] = e[j]; }
+        return;
+    }
+    const int flag0 = w.flags[0];              // requested with everything else; a NaN met by THIS launch is carried in `nan_here`
+    bool nan_here = false;
     // ---- requests whose addresses the state already holds, all in flight together: the block minima, the coordinates of the scanned node, and — values
     // not used here, the lines are what counts — the words the heap replay will ask for first: pos[] of the node it removes and of a, the last entry, the
     // top block of the heap
@@ -2128,7 +2153,7 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w) {
         }
         if (ncand > kRomCap) {                 // too many for one wavefront: the same row by exact sums of every workgroup, then back here
             rom_sink(warm_pos); rom_sink(warm_a.node); rom_sink(warm_b.node); rom_sink(xs0[0]);
-            if (lane == 0) { st.kind = ROM_EXACT; st.exact_scans = st.exact_scans + 1; *w.dev = st; }
+            if (lane == 0) { st.kind = ROM_EXACT; st.exact_scans = st.exact_scans + 1; w.dev[ph ^ 1] = st; }
             return;
         }
         st.cands = st.cands + ncand;
@@ -2171,7 +2196,7 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w) {
                 WaveMem::wave_sync();
             }
             const bool mine = lane < nb;
-            if (mine && sum != sum) w.flags[0] = 1;
+            if (__builtin_amdgcn_ballot_w64(mine && sum != sum)) nan_here = true;
             const double sv = (mine && sum == sum) ? sum : dinf();
             const double bm = wave_min(sv);
             const int bi = static_cast<int>(wave_umin((mine && sv == bm && bm < dinf()) ? static_cast<unsigned>(s_cand[b0 + lane]) : static_cast<unsigned>(INT_MAX)));
@@ -2179,9 +2204,9 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w) {
         }
     }
     rom_sink(warm_pos); rom_sink(warm_a.node); rom_sink(warm_b.node); rom_sink(xs0[0]);
-    const int nan_flag = w.flags[0];
+    const bool nan_flag = flag0 != 0 || nan_here;
     if (nan_flag || best_id == INT_MAX) {       // NaN distance (nan_error) / nothing to scan
-        if (lane == 0) { st.done = 1; st.nan_seen = nan_flag ? 1 : 2; *w.dev = st; }
+        if (lane == 0) { st.done = 1; st.nan_seen = nan_flag ? 1 : 2; w.dev[0] = st; w.dev[1] = st; }
         return;
     }
     fa_ro::SelT<fa_ro::HeapK<WaveMem>> sel;
@@ -2192,7 +2217,7 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w) {
     sel.scan_result(best, best_id);
     rom_prepare(st, sel, w.slot_of, w.sizes);
     st.scans = st.scans + 1;
-    if (lane == 0) *w.dev = st;
+    if (lane == 0) { w.dev[ph ^ 1] = st; if (st.done) w.dev[ph] = st; }   // the end is written to both records: every later launch of the replay returns at once
 }
 
 // ------------------------------------------------------------------------------ host driver
@@ -2491,7 +2516,7 @@ RomLayout rom_layout(size_t N, size_t Np, size_t d) {
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~static_cast<size_t>(255); return at; };
     const size_t nblk = Np / kBlk;
-    L.dev = take(sizeof(RomDev)); L.flags = take(16); L.state = take(sizeof(AhcState) * 2);
+    L.dev = take(sizeof(RomDev) * 2); L.flags = take(16); L.state = take(sizeof(AhcState) * 2);
     L.part = take(sizeof(RomPart) * nblk); L.part2 = take(8 * nblk);
     L.node = take(4 * Np); L.slot = take(4 * 2 * N); L.sizes = take(8 * 2 * N); L.key = take(8 * N); L.ent = take(sizeof(fa_ro::Ent) * N); L.pos = take(4 * 2 * N);
     L.ngh = take(4 * 2 * N); L.next = take(4 * (2 * N + 1)); L.prev = take(4 * (2 * N + 1));
@@ -2599,9 +2624,9 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     // ---- one (scan, select) pair per dendrogram row, re-scan or exact re-evaluation, replayed from a graph until the device reports the end
     const size_t lds = sizeof(double) * d;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rom_scan), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    auto launch = [&](const int) {
-        hipLaunchKernelGGL(rom_scan, dim3(w.nblk), dim3(kBlk), lds, st, w);
-        hipLaunchKernelGGL(rom_select, dim3(1), dim3(64), 0, st, w);
+    auto launch = [&](const int ph4) {
+        hipLaunchKernelGGL(rom_scan, dim3(w.nblk), dim3(kBlk), lds, st, w, ph4 & 1);
+        hipLaunchKernelGGL(rom_select, dim3(1 + w.nblk), dim3(64), 0, st, w, ph4 & 1);
     };
     RoundGraph rg;
     rg.capture(ctx, launch, static_cast<int>(std::min<size_t>(256, (N + 3) & ~static_cast<size_t>(3))));

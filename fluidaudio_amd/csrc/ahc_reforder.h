@@ -102,7 +102,7 @@ struct Heap {
 // Heap above costs the selecting thread two dependent accesses per comparison (at[place] -> key[node]) and one memory round trip per level of a
 // sift: ~100 dependent accesses per dendrogram row, which was what a row of the reference-order run waited for (profiles/r05_ties_probe.txt).
 // Here an entry CARRIES its key (16 bytes: key, node), and a sift works on a block of entries fetched at once: a sift-up on the whole ancestor
-// chain of its place (<= 31 entries), a sift-down on the six levels below its place (126 entries), repeated from where it left off when the
+// chain of its place (<= 31 entries), a sift-down on the eight levels below its place (510 entries), repeated from where it left off when the
 // entry is still moving at the bottom of the block.  The walk on the block makes the comparisons of sift_up / sift_down above in the same
 // order with the same strictness, so the array order — the tie order — is the same after every operation (tests/test_ahc_reforder_emul.py
 // runs both forms side by side on tie-heavy key streams and through whole dendrograms).  HOW a block reaches the walker is the policy `Mem`:
@@ -111,8 +111,8 @@ struct Heap {
 // loads — also the block loads, where lane l reads entries the walk wrote earlier — then see the latest values by its own program order.
 struct alignas(16) Ent { double key; int32_t node, pad; };   // one 16-byte load / store
 
-constexpr int32_t kTreeLevels = 6;                          // levels below the root of a sift-down block
-constexpr int32_t kTreeEnts = (1 << (kTreeLevels + 1)) - 1; // relative indices 0 (the root: not fetched) .. 126
+constexpr int32_t kTreeLevels = 8;                          // levels below the root of a sift-down block (16 levels = 43 200 entries: two blocks)
+constexpr int32_t kTreeEnts = (1 << (kTreeLevels + 1)) - 1; // relative indices 0 (the root: not fetched) .. 510
 FA_HD int32_t heap_depth(int32_t place) { int32_t L = 0; for (uint32_t v = static_cast<uint32_t>(place) + 1u; v > 1u; v >>= 1) ++L; return L; }   // ancestors of a place
 FA_HD int32_t heap_ancestor(const int32_t place, const int32_t j) { return static_cast<int32_t>((static_cast<uint32_t>(place) + 1u) >> (j + 1)) - 1; }   // j = 0: the parent
 // place of relative index t (children of t: 2 t + 1, 2 t + 2) in the subtree rooted at place r; 64-bit: beyond the heap for deep, wide blocks
@@ -155,7 +155,7 @@ struct HeapK {
             int32_t t = 0;                                      // relative index in the block and place in the heap of where the entry stands
             int64_t P = i;
             bool rest = false;
-            while (t < (1 << kTreeLevels) - 1) {                // t on levels 0 .. 5: both children are in the block
+            while (t < (1 << kTreeLevels) - 1) {                // t above the lowest level of the block: both children are in the block
                 const int32_t j = 2 * t + 1;
                 const int64_t Pj = 2 * P + 1;
                 if (Pj >= size) { rest = true; break; }
@@ -170,7 +170,7 @@ struct HeapK {
                 P = Pj + right;
             }
             if (rest) { put(P, e); return; }
-            i = static_cast<int32_t>(P);                        // still moving at the bottom of the block: the next six levels
+            i = static_cast<int32_t>(P);                        // still moving at the bottom of the block: the next levels
         }
     }
     FA_HD int32_t argmin() const { return ent[0].node; }

@@ -104,10 +104,10 @@ def rom():
     return run
 
 
-@pytest.mark.parametrize("n,levels", [(2, 1), (3, 2), (7, 1), (64, 3), (127, 2), (128, 50), (129, 4), (1000, 5), (5000, 3), (20000, 1000), (70000, 7)])
+@pytest.mark.parametrize("n,levels", [(2, 1), (3, 2), (7, 1), (64, 3), (127, 2), (128, 50), (510, 3), (511, 2), (512, 4), (1000, 5), (5000, 3), (20000, 1000), (70000, 7), (140000, 3)])
 def test_block_heap_equals_the_restated_heap_after_every_operation(rom, n, levels):
     """remove / replace / raise in random order on heavily tied keys: place by place the same arrays (the tie order IS the array order).  Sizes on
-    both sides of the block boundaries: 127 places = one sift-down block, 70 000 = three blocks deep."""
+    both sides of the block boundaries: 511 places = one sift-down block (eight levels), 140 000 = three blocks deep."""
     for seed in range(6):
         assert rom.lib.fa_heapk_equiv(n, min(4 * n, 6000), seed, levels) == 0, (n, levels, seed)
 
