@@ -1878,6 +1878,7 @@ struct RomWs {
     int32_t *node, *slot_of, *pos, *nghbr, *next, *prev, *flags;
     RomPart *part;
     RomDev *dev;
+    unsigned long long *prof;   // [16] clock sums of the selection's phases (FA_ROM_PROFILE builds only)
     int32_t N, Np, d, nblk;
 };
 
@@ -2049,6 +2050,12 @@ struct WaveMem {   // ahc_reforder.h's block fetches by the 64 lanes of the sele
     __device__ __forceinline__ fa_ro::Ent ent_at(const int32_t j) const { return buf[j]; }
 };
 
+#ifdef FA_ROM_PROFILE   // where a selection spends its time: every stamp drains the memory counters first (phase costs in isolation)
+#define ROM_STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_now = clock64(); t_seg[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define ROM_STAMP(i) do {} while (0)
+#endif
+
 // keeps a value requested early alive up to here without using it (the request warmed the caches for the loads of the selection)
 template <class T> __device__ __forceinline__ void rom_sink(const T v) { asm volatile("" ::"v"(v)); }
 
@@ -2076,9 +2083,19 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
     }
     const int flag0 = w.flags[0];              // requested with everything else; a NaN met by THIS launch is carried in `nan_here`
     bool nan_here = false;
+#ifdef FA_ROM_PROFILE
+    unsigned long long t_seg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = clock64();
+    const unsigned long long w_begin = wall_clock64();
+#endif
     // ---- requests whose addresses the state already holds, all in flight together: the block minima, the coordinates of the scanned node, and — values
     // not used here, the lines are what counts — the words the heap replay will ask for first: pos[] of the node it removes and of a, the last entry, the
     // top block of the heap
+    typedef int v4i32 __attribute__((ext_vector_type(4)));
+    const int n2 = 2 * st.n - 1;               // node ids 0 .. 2 n - 2
+    const int hs1 = st.heap_size > 1 ? st.heap_size - 1 : 0;   // last place of the heap
+    const int rm_node = st.op == fa_ro::RO_NEW_ROW ? (st.b < st.list_first ? st.list_first : st.b) : st.a;   // the node heap.remove will be asked for (:1792-1797)
+    const int warm_pos = w.pos[lane == 0 ? rm_node : st.a];    // lane 0: its place; issued FIRST, so it is here when the block minima are
     constexpr int kFast = 4;                   // block records per lane held in registers (N <= 65 536)
     const bool fast = nblk <= 64 * kFast;
     RomPart pr[kFast];
@@ -2093,11 +2110,31 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
     double xs0[kRomChunk / 64];
 #pragma unroll
     for (int j = 0; j < kRomChunk / 64; ++j) { const int k = lane + 64 * j; xs0[j] = cs[k < d ? k : d - 1]; }
-    const int warm_node = lane == 0 ? (st.op == fa_ro::RO_NEW_ROW ? (st.b < st.list_first ? st.list_first : st.b) : st.a) : st.a;
-    const int warm_pos = w.pos[warm_node];
-    const int hs1 = st.heap_size > 1 ? st.heap_size - 1 : 0;
-    const fa_ro::Ent warm_a = w.ent[lane < hs1 ? lane : hs1], warm_b = w.ent[64 + lane < hs1 ? 64 + lane : hs1];
+    constexpr int kWarmPer = (fa_ro::kTreeEnts - 1 + 63) / 64;
+    v4i32 warm_top[kWarmPer];                  // places 1 .. 510: the block heap.replace walks first (entry 0 is replaced)
+#pragma unroll
+    for (int q = 0; q < kWarmPer; ++q) { const int pl = 1 + lane + 64 * q; warm_top[q] = *reinterpret_cast<const v4i32 *>(w.ent + (pl < hs1 ? pl : hs1)); }
+    const v4i32 warm_last = *reinterpret_cast<const v4i32 *>(w.ent + hs1);
 
+    ROM_STAMP(0);                              // the first round trip: block minima, coordinates, the warmed words
+    // ---- second layer, in flight while the candidates are collected and their rows travel: around the place heap.remove starts from (the entry, its
+    // ancestor chain, the block below it), and the list / slot words of the two nodes under the heap top — one of them, or the node created now, is the
+    // next top (advance)
+    const int rm_place = __builtin_amdgcn_readfirstlane(warm_pos);
+    const int rp = rm_place >= 0 && rm_place <= hs1 ? rm_place : 0;
+    const int rdepth = 31 - __clz(rp + 1);
+    const v4i32 warm_chain = *reinterpret_cast<const v4i32 *>(w.ent + (lane < rdepth ? static_cast<int>((static_cast<unsigned>(rp) + 1u) >> (lane + 1)) - 1 : rp));
+    v4i32 warm_tree[kWarmPer];
+#pragma unroll
+    for (int q = 0; q < kWarmPer; ++q) {
+        const int32_t t = 1 + lane + 64 * q, lev = 31 - __clz(t + 1);
+        const int64_t pl = ((static_cast<int64_t>(rp) + 1) << lev) - 1 + (t + 1 - (1 << lev));
+        warm_tree[q] = *reinterpret_cast<const v4i32 *>(w.ent + ((t < fa_ro::kTreeEnts && pl < hs1) ? pl : 0));
+    }
+    int wn = warm_top[0].z;                    // lanes 0 / 1: the nodes at places 1 / 2 (the third word of an entry is its node)
+    wn = (lane < 2 && lane + 1 < hs1 && wn >= 0 && wn < n2) ? wn : st.a;
+    const int warm_ng = w.nghbr[wn], warm_nx = w.next[wn], warm_pv = w.prev[wn], warm_so = w.slot_of[wn];
+    const double warm_sz = w.sizes[wn];
     double best = dinf();
     int best_id = INT_MAX;
     if (st.kind == ROM_EXACT) {                // the block minima are the reference's sums: lowest (value, node id)
@@ -2115,7 +2152,21 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
             for (int b = lane; b < nblk; b += 64) { const double v1 = w.part[b].v1; if (v1 < mv) mv = v1; }
         const double m = wave_min(mv);
         int ncand = 0;
-        if (m < dinf()) {
+        bool collected = false;
+        if (fast && m < dinf()) {              // the common row: ONE block minimum inside the window and that block's second entry outside it
+            const double lim = m + 2.0 * st.eps;
+            bool hit = false, dense = false;
+            int n1 = INT_MAX;
+#pragma unroll
+            for (int j = 0; j < kFast; ++j) { const bool h = pr[j].v1 <= lim; if (h) { n1 = pr[j].n1; dense = dense || hit || p2[j] <= lim; hit = true; } }
+            const unsigned long long mh = __builtin_amdgcn_ballot_w64(hit), mdn = __builtin_amdgcn_ballot_w64(dense);
+            if (mdn == 0 && __popcll(mh) == 1) {
+                if (hit) s_cand[0] = n1;
+                ncand = 1;
+                collected = true;
+            }
+        }
+        if (!collected && m < dinf()) {
             const double lim = m + 2.0 * st.eps;
             const double *row = w.M + static_cast<size_t>(st.sa) * Np;
             for (int base = 0; base < nblk && ncand <= kRomCap; base += 64) {
@@ -2152,12 +2203,19 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
             }
         }
         if (ncand > kRomCap) {                 // too many for one wavefront: the same row by exact sums of every workgroup, then back here
-            rom_sink(warm_pos); rom_sink(warm_a.node); rom_sink(warm_b.node); rom_sink(xs0[0]);
+            rom_sink(warm_pos); rom_sink(xs0[0]); rom_sink(warm_last.x); rom_sink(warm_chain.x); rom_sink(warm_top[0].x); rom_sink(warm_tree[0].x); rom_sink(warm_ng); rom_sink(warm_sz);
             if (lane == 0) { st.kind = ROM_EXACT; st.exact_scans = st.exact_scans + 1; w.dev[ph ^ 1] = st; }
             return;
         }
         st.cands = st.cands + ncand;
         WaveMem::wave_sync();
+        ROM_STAMP(1);                          // candidates collected
+        // third layer: the list / slot words of the recorded neighbours of those two nodes, of the first candidate (the neighbour the created node will
+        // record, most rows) and of the created node itself
+        int wo = lane < 2 ? warm_ng : (lane == 2 ? s_cand[0] : (st.created >= 0 ? st.created : st.a));
+        wo = (wo >= 0 && wo < n2) ? wo : st.a;
+        const int warm_onx = w.next[wo], warm_opv = w.prev[wo], warm_oso = w.slot_of[wo];
+        const double warm_osz = w.sizes[wo];
         for (int b0 = 0; b0 < ncand; b0 += kRomBatch) {
             const int nb = ncand - b0 < kRomBatch ? ncand - b0 : kRomBatch;
             double sum = 0.0;
@@ -2186,10 +2244,24 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
                 // ... summed by ONE lane per candidate in the reference's order (sqeuclidean_extended, FastClusterWrapper.cpp:68-75: sequential in k)
                 if (lane < nb) {
                     const int kn = d - k0 < kRomChunk ? d - k0 : kRomChunk;
-                    if (kn == kRomChunk) {
+                    if (kn == kRomChunk) {      // 32 values travel LDS -> registers while the previous 32 are added (the chain of additions is the floor)
                         const double2 *tp = reinterpret_cast<const double2 *>(&s_t[lane][0]);
-#pragma unroll 16
-                        for (int q = 0; q < kRomChunk / 2; ++q) { const double2 t = tp[q]; sum = __dadd_rn(sum, t.x); sum = __dadd_rn(sum, t.y); }
+                        double2 ta[16], tb[16];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) ta[q] = tp[q];
+#pragma unroll
+                        for (int h = 0; h < kRomChunk / 64; ++h) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) tb[q] = tp[32 * h + 16 + q];
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) { sum = __dadd_rn(sum, ta[q].x); sum = __dadd_rn(sum, ta[q].y); }
+                            if (h + 1 < kRomChunk / 64) {
+#pragma unroll
+                                for (int q = 0; q < 16; ++q) ta[q] = tp[32 * (h + 1) + q];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) { sum = __dadd_rn(sum, tb[q].x); sum = __dadd_rn(sum, tb[q].y); }
+                        }
                     } else
                         for (int kk = 0; kk < kn; ++kk) sum = __dadd_rn(sum, s_t[lane][kk]);
                 }
@@ -2197,13 +2269,24 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
             }
             const bool mine = lane < nb;
             if (__builtin_amdgcn_ballot_w64(mine && sum != sum)) nan_here = true;
-            const double sv = (mine && sum == sum) ? sum : dinf();
-            const double bm = wave_min(sv);
-            const int bi = static_cast<int>(wave_umin((mine && sv == bm && bm < dinf()) ? static_cast<unsigned>(s_cand[b0 + lane]) : static_cast<unsigned>(INT_MAX)));
-            if (lt2(bm, bi, best, best_id)) { best = bm; best_id = bi; }
+            if (ncand == 1) {                  // one candidate: lane 0 holds the answer
+                best = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sum)), __builtin_amdgcn_readfirstlane(__double2loint(sum)));
+                best_id = s_cand[0];
+                if (best != best) { best = dinf(); best_id = INT_MAX; }
+            } else {
+                const double sv = (mine && sum == sum) ? sum : dinf();
+                const double bm = wave_min(sv);
+                const int bi = static_cast<int>(wave_umin((mine && sv == bm && bm < dinf()) ? static_cast<unsigned>(s_cand[b0 + lane]) : static_cast<unsigned>(INT_MAX)));
+                if (lt2(bm, bi, best, best_id)) { best = bm; best_id = bi; }
+            }
         }
+        rom_sink(warm_onx); rom_sink(warm_opv); rom_sink(warm_oso); rom_sink(warm_osz);
     }
-    rom_sink(warm_pos); rom_sink(warm_a.node); rom_sink(warm_b.node); rom_sink(xs0[0]);
+    ROM_STAMP(2);                              // candidates evaluated
+    rom_sink(warm_pos); rom_sink(xs0[0]); rom_sink(warm_last.x); rom_sink(warm_chain.x);
+#pragma unroll
+    for (int q = 0; q < kWarmPer; ++q) { rom_sink(warm_top[q].x); rom_sink(warm_tree[q].x); }
+    rom_sink(warm_ng); rom_sink(warm_nx); rom_sink(warm_pv); rom_sink(warm_so); rom_sink(warm_sz);
     const bool nan_flag = flag0 != 0 || nan_here;
     if (nan_flag || best_id == INT_MAX) {       // NaN distance (nan_error) / nothing to scan
         if (lane == 0) { st.done = 1; st.nan_seen = nan_flag ? 1 : 2; w.dev[0] = st; w.dev[1] = st; }
@@ -2214,10 +2297,36 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
     sel.list.next = w.next; sel.list.prev = w.prev; sel.list.first = st.list_first;
     sel.nghbr = w.nghbr; sel.n = st.n; sel.merges = st.merges; sel.op = st.op; sel.a = st.a; sel.b = st.b;
     sel.pair_a = w.pair_a; sel.pair_b = w.pair_b; sel.height_sq = w.height_sq;
+#ifdef FA_ROM_PROFILE   // scan_result's statements one by one
+    if (sel.op == fa_ro::RO_NEW_ROW) {
+        const int32_t created = sel.n + sel.merges - 1;
+        sel.nghbr[created] = best_id;
+        if (sel.b < sel.list.first) sel.heap.remove(sel.list.first);
+        else sel.heap.remove(sel.b);
+        ROM_STAMP(3);                          // heap.remove
+        sel.heap.replace(sel.a, created, best);
+        ROM_STAMP(4);                          // heap.replace
+    } else {
+        sel.nghbr[sel.a] = best_id;
+        sel.heap.raise(sel.a, best);
+        ROM_STAMP(5);
+    }
+    sel.advance();
+    ROM_STAMP(6);                              // advance
+#else
     sel.scan_result(best, best_id);
+#endif
     rom_prepare(st, sel, w.slot_of, w.sizes);
     st.scans = st.scans + 1;
     if (lane == 0) { w.dev[ph ^ 1] = st; if (st.done) w.dev[ph] = st; }   // the end is written to both records: every later launch of the replay returns at once
+#ifdef FA_ROM_PROFILE
+    ROM_STAMP(7);                              // next state
+    if (lane == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&w.prof[i], t_seg[i]);
+        atomicAdd(&w.prof[14], wall_clock64() - w_begin);
+        atomicAdd(&w.prof[15], 1ULL);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------ host driver
@@ -2510,13 +2619,13 @@ fa_status ro_run_device_mf(fa_ctx *ctx, const double *d_data, size_t N, size_t d
 
 // Workspace of the matrix-filtered run: the selection's arrays, then what the start-up kernels of the filter-based rounds expect (points / centroids,
 // transpose, norms, the two state records their maxima go to), the matrix last.
-struct RomLayout { size_t dev, flags, part, part2, node, slot, sizes, key, ent, pos, ngh, next, prev, pa, pb, hs, z, state, norms, c, xt, m, total; };
+struct RomLayout { size_t prof, dev, flags, part, part2, node, slot, sizes, key, ent, pos, ngh, next, prev, pa, pb, hs, z, state, norms, c, xt, m, total; };
 RomLayout rom_layout(size_t N, size_t Np, size_t d) {
     RomLayout L{};
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~static_cast<size_t>(255); return at; };
     const size_t nblk = Np / kBlk;
-    L.dev = take(sizeof(RomDev) * 2); L.flags = take(16); L.state = take(sizeof(AhcState) * 2);
+    L.dev = take(sizeof(RomDev) * 2); L.flags = take(16); L.state = take(sizeof(AhcState) * 2); L.prof = take(8 * 16);
     L.part = take(sizeof(RomPart) * nblk); L.part2 = take(8 * nblk);
     L.node = take(4 * Np); L.slot = take(4 * 2 * N); L.sizes = take(8 * 2 * N); L.key = take(8 * N); L.ent = take(sizeof(fa_ro::Ent) * N); L.pos = take(4 * 2 * N);
     L.ngh = take(4 * 2 * N); L.next = take(4 * (2 * N + 1)); L.prev = take(4 * (2 * N + 1));
@@ -2542,6 +2651,7 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     RomWs w{};
     w.dev = reinterpret_cast<RomDev *>(base + L.dev); w.flags = reinterpret_cast<int32_t *>(base + L.flags);
     w.part = reinterpret_cast<RomPart *>(base + L.part); w.part2 = reinterpret_cast<double *>(base + L.part2);
+    w.prof = reinterpret_cast<unsigned long long *>(base + L.prof);
     w.node = reinterpret_cast<int32_t *>(base + L.node); w.slot_of = reinterpret_cast<int32_t *>(base + L.slot); w.sizes = reinterpret_cast<double *>(base + L.sizes);
     w.ent = reinterpret_cast<fa_ro::Ent *>(base + L.ent); w.pos = reinterpret_cast<int32_t *>(base + L.pos);
     w.nghbr = reinterpret_cast<int32_t *>(base + L.ngh); w.next = reinterpret_cast<int32_t *>(base + L.next); w.prev = reinterpret_cast<int32_t *>(base + L.prev);
@@ -2642,6 +2752,15 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     FA_HIP_TRY(ctx, hipMemcpyAsync(d_Z, rw.Z, sizeof(double) * 4 * (N - 1), z_on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
     FA_HIP_TRY(ctx, hipEventRecord(ev[2], st));
     FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+#ifdef FA_ROM_PROFILE
+    {
+        unsigned long long hp[16];
+        (void)hipMemcpy(hp, w.prof, sizeof(hp), hipMemcpyDeviceToHost);
+        const double n = hp[15] ? static_cast<double>(hp[15]) : 1.0;
+        fprintf(stderr, "rom_select profile (clocks per selection, %llu selections; wall 100 MHz ticks %.1f): first trip %.0f | candidates %.0f | evaluation %.0f | heap.remove %.0f | heap.replace %.0f | raise %.0f | advance %.0f | next state %.0f\n",
+                hp[15], hp[14] / n, hp[0] / n, hp[1] / n, hp[2] / n, hp[3] / n, hp[4] / n, hp[5] / n, hp[6] / n, hp[7] / n);
+    }
+#endif
     if (getenv("FA_AHC_DEBUG"))
         fprintf(stderr, "ahc (reference order, matrix filter): N %zu scans %lld exact re-evaluations %lld candidates %lld eps %.3e\n", N, hd.scans, hd.exact_scans, hd.cands, hd.eps);
     if (stats) {
