@@ -179,6 +179,47 @@ def ahc_leg(fa, ctx, torch, n=50000, d=256, ref_n=3000):
     return out
 
 
+def ahc_ties_leg(fa, ctx, hours=8.0, dup=0.3):
+    """What an input with exact ties costs: the 8 h session with `dup` of its rows duplicated.  AUTO halts at the first tied minimum
+    and the problem runs in the reference's selection order — through the matrix filter (rom_scan / rom_select, round 5) where the N x N workspace
+    is to be had.  Checked row for row against the matrix-free form of the same order (O(A d) exact sums per row, the restated heap: the run that is
+    pinned to the reference build by the tests), timed next to it and next to the tie-free session."""
+    sess = e2e_session_for(0, hours)[0]
+    x = sess["emb"].astype(np.float64)
+    x /= np.sqrt((x * x).sum(axis=1, keepdims=True))
+    n = len(x)
+    rng = np.random.default_rng(1)
+    xd = x.copy()
+    k = int(dup * n)
+    xd[rng.integers(0, n, k)] = xd[rng.integers(0, n, k)]
+
+    def timed(data, mode, env=None, reps=2):
+        if env:
+            os.environ[env] = "1"
+        try:
+            best = None
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                st, z, stats = fa.linkage(data, mode=mode, ctx=ctx, return_stats=True)
+                dt = time.perf_counter() - t0
+                if st != 0:
+                    raise RuntimeError(f"linkage status {st}: {ctx.last_error()}")
+                if best is None or dt < best[0]:
+                    best = (dt, z, stats)
+        finally:
+            if env:
+                os.environ.pop(env, None)
+        return best
+    t_free, z_free, s_free = timed(x, fa.AHC_MODE_AUTO)
+    t_tie, z_tie, s_tie = timed(xd, fa.AHC_MODE_AUTO)
+    t_mf, z_mf, s_mf = timed(xd, fa.AHC_MODE_REFERENCE_ORDER, env="FA_AHC_RO_NO_MATRIX", reps=1)
+    return {"n": n, "d": x.shape[1], "duplicated_rows": k, "tie_free_seconds": t_free, "tied_seconds": t_tie, "tied_over_tie_free": t_tie / t_free,
+            "tied_reference_order": s_tie["reference_order"], "tied_us_per_row": 1e3 * s_tie["merge_ms"] / (n - 1), "tied_startup_ms": s_tie["init_ms"],
+            "matrix_free_seconds": t_mf, "matrix_free_us_per_row": 1e3 * s_mf["merge_ms"] / (n - 1),
+            "equals_matrix_free_form_row_for_row": bool(np.array_equal(z_tie, z_mf)),
+            "note": "host-pointer entries: the uploads / downloads of 88 MB are inside the wall times of all three"}
+
+
 def ahc_batch_leg(fa, ctx, recordings=16, n=5400, d=256, speakers=8):
     """Many medium-sized recordings: fa_ahc_linkage_batch (one launch = one round of every recording) vs sequential calls."""
     import oracle
@@ -1209,6 +1250,10 @@ def main():
             line["ahc_batch"] = ahc_batch_leg(fa, ctx)
         except Exception as e:  # noqa: BLE001
             line["ahc_batch"] = {"error": repr(e)}
+        try:
+            line["ahc_ties"] = ahc_ties_leg(fa, ctx)
+        except Exception as e:  # noqa: BLE001
+            line["ahc_ties"] = {"error": repr(e)}
     if solo and not args.skip_e2e:
         torch.cuda.empty_cache()
         try:
@@ -1253,6 +1298,8 @@ def main():
             v = v.get(k) if isinstance(v, dict) else None
         return v
     line["config"].update({
+        "ahc_8h_tied_over_tie_free": pick("ahc_ties", "tied_over_tie_free"), "ahc_8h_tied_seconds": pick("ahc_ties", "tied_seconds"),
+        "ahc_8h_tied_equals_matrix_free_form": pick("ahc_ties", "equals_matrix_free_form_row_for_row"),
         "ahc_50k_seconds": pick("ahc_50k", "seconds"), "ahc_50k_bit_exact_vs_reference_digest": pick("ahc_50k", "bit_exact_vs_reference_digest"),
         "mel_roofline_frac": pick("mel", "roofline", "frac"), "mel_realtime_factor": pick("mel", "realtime_factor"),
         "ctc_roofline_frac": pick("ctc", "roofline", "frac"), "ctc_ids_exact": pick("ctc", "ids_exact"),
