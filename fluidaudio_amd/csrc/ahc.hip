@@ -1901,6 +1901,16 @@ __global__ __launch_bounds__(kBlk) void rom_scan(const RomWs w, const int ph) {
     const RomDev st = w.dev[ph];
     if (st.done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x, x = blk * kBlk + tid, Np = w.Np, d = w.d;
+    if (blk == w.nblk) {                       // one workgroup beyond the columns: the merged centroid (FastClusterWrapper.cpp:89-100), by node id and into
+        if (st.kind != ROM_NEW) return;        // the slot-major transpose — its own two round trips, beside the row's instead of behind them in the block of slot sa
+        const double *ca = w.C + static_cast<size_t>(st.a) * d, *cb = w.C + static_cast<size_t>(st.b) * d, den = st.ma + st.mb;
+        for (int k = tid; k < d; k += kBlk) {
+            const double cc = __ddiv_rn(__dadd_rn(__dmul_rn(ca[k], st.ma), __dmul_rn(cb[k], st.mb)), den);
+            w.C[static_cast<size_t>(st.created) * d + k] = cc;
+            w.XT[static_cast<size_t>(k) * Np + st.sa] = cc;
+        }
+        return;
+    }
     double v = dinf();
     int nx;
     if (st.kind == ROM_NEW) {                  // Lance-Williams row of the node created from (a, b) into the row of slot sa
@@ -1918,14 +1928,6 @@ __global__ __launch_bounds__(kBlk) void rom_scan(const RomWs w, const int ph) {
         }
         if (x == st.sa) { w.node[x] = st.created; w.slot_of[st.created] = x; w.sizes[st.created] = st.ma + st.mb; }
         if (x == st.sb) w.node[x] = kDead;
-        if (st.sa / kBlk == blk) {             // merged centroid (FastClusterWrapper.cpp:89-100): by node id, and into the slot-major transpose
-            const double *ca = w.C + static_cast<size_t>(st.a) * d, *cb = w.C + static_cast<size_t>(st.b) * d, den = st.ma + st.mb;
-            for (int k = tid; k < d; k += kBlk) {
-                const double cc = __ddiv_rn(__dadd_rn(__dmul_rn(ca[k], st.ma), __dmul_rn(cb[k], st.mb)), den);
-                w.C[static_cast<size_t>(st.created) * d + k] = cc;
-                w.XT[static_cast<size_t>(k) * Np + st.sa] = cc;
-            }
-        }
     } else if (st.kind == ROM_RESCAN) {        // the row of a against every older node
         const double e = w.M[static_cast<size_t>(st.sa) * Np + x];
         nx = w.node[x];
@@ -2135,9 +2137,15 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
     wn = (lane < 2 && lane + 1 < hs1 && wn >= 0 && wn < n2) ? wn : st.a;
     const int warm_ng = w.nghbr[wn], warm_nx = w.next[wn], warm_pv = w.prev[wn], warm_so = w.slot_of[wn];
     const double warm_sz = w.sizes[wn];
+    fa_ro::SelT<fa_ro::HeapK<WaveMem>> sel;
+    sel.heap.ent = w.ent; sel.heap.pos = w.pos; sel.heap.size = st.heap_size; sel.heap.mem.buf = s_buf;
+    sel.list.next = w.next; sel.list.prev = w.prev; sel.list.first = st.list_first;
+    sel.nghbr = w.nghbr; sel.n = st.n; sel.merges = st.merges; sel.op = st.op; sel.a = st.a; sel.b = st.b;
+    sel.pair_a = w.pair_a; sel.pair_b = w.pair_b; sel.height_sq = w.height_sq;
     double best = dinf();
     int best_id = INT_MAX;
     if (st.kind == ROM_EXACT) {                // the block minima are the reference's sums: lowest (value, node id)
+        sel.scan_begin();
         double v = dinf();
         int id = INT_MAX;
         for (int b = lane; b < nblk; b += 64) { const RomPart pt = w.part[b]; if (lt2(pt.v1, pt.n1, v, id)) { v = pt.v1; id = pt.n1; } }
@@ -2216,6 +2224,17 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
         wo = (wo >= 0 && wo < n2) ? wo : st.a;
         const int warm_onx = w.next[wo], warm_opv = w.prev[wo], warm_oso = w.slot_of[wo];
         const double warm_osz = w.sizes[wo];
+        // the coordinates of the first candidate are requested now, and the half of the heap replay that does not depend on the scan's result (the
+        // entry that goes after the merge, :1792-1797) runs under that round trip
+        double cv0[kRomChunk / 64];
+        {
+            const int c0 = ncand > 0 ? s_cand[0] : st.scanned;
+            const double *cc0 = w.C + static_cast<size_t>(c0 >= 0 && c0 < n2 ? c0 : st.scanned) * d;
+#pragma unroll
+            for (int j = 0; j < kRomChunk / 64; ++j) { const int k = lane + 64 * j; cv0[j] = cc0[k < d ? k : d - 1]; }
+        }
+        sel.scan_begin();
+        ROM_STAMP(3);                          // heap.remove
         for (int b0 = 0; b0 < ncand; b0 += kRomBatch) {
             const int nb = ncand - b0 < kRomBatch ? ncand - b0 : kRomBatch;
             double sum = 0.0;
@@ -2235,8 +2254,13 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
                 for (int r = 0; r < nb; ++r) {
                     const double *cc = w.C + static_cast<size_t>(s_cand[b0 + r]) * d;
                     double cv[kRomChunk / 64];
+                    if (b0 == 0 && k0 == 0 && r == 0) {
 #pragma unroll
-                    for (int j = 0; j < kRomChunk / 64; ++j) cv[j] = cc[kc[j]];
+                        for (int j = 0; j < kRomChunk / 64; ++j) cv[j] = cv0[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < kRomChunk / 64; ++j) cv[j] = cc[kc[j]];
+                    }
 #pragma unroll
                     for (int j = 0; j < kRomChunk / 64; ++j) { const double diff = __dsub_rn(cv[j], xs[j]); s_t[r][lane + 64 * j] = __dmul_rn(diff, diff); }
                 }
@@ -2292,18 +2316,10 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
         if (lane == 0) { st.done = 1; st.nan_seen = nan_flag ? 1 : 2; w.dev[0] = st; w.dev[1] = st; }
         return;
     }
-    fa_ro::SelT<fa_ro::HeapK<WaveMem>> sel;
-    sel.heap.ent = w.ent; sel.heap.pos = w.pos; sel.heap.size = st.heap_size; sel.heap.mem.buf = s_buf;
-    sel.list.next = w.next; sel.list.prev = w.prev; sel.list.first = st.list_first;
-    sel.nghbr = w.nghbr; sel.n = st.n; sel.merges = st.merges; sel.op = st.op; sel.a = st.a; sel.b = st.b;
-    sel.pair_a = w.pair_a; sel.pair_b = w.pair_b; sel.height_sq = w.height_sq;
-#ifdef FA_ROM_PROFILE   // scan_result's statements one by one
+#ifdef FA_ROM_PROFILE   // scan_finish's statements one by one
     if (sel.op == fa_ro::RO_NEW_ROW) {
         const int32_t created = sel.n + sel.merges - 1;
         sel.nghbr[created] = best_id;
-        if (sel.b < sel.list.first) sel.heap.remove(sel.list.first);
-        else sel.heap.remove(sel.b);
-        ROM_STAMP(3);                          // heap.remove
         sel.heap.replace(sel.a, created, best);
         ROM_STAMP(4);                          // heap.replace
     } else {
@@ -2314,7 +2330,7 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
     sel.advance();
     ROM_STAMP(6);                              // advance
 #else
-    sel.scan_result(best, best_id);
+    sel.scan_finish(best, best_id);
 #endif
     rom_prepare(st, sel, w.slot_of, w.sizes);
     st.scans = st.scans + 1;
@@ -2735,7 +2751,7 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     const size_t lds = sizeof(double) * d;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(rom_scan), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     auto launch = [&](const int ph4) {
-        hipLaunchKernelGGL(rom_scan, dim3(w.nblk), dim3(kBlk), lds, st, w, ph4 & 1);
+        hipLaunchKernelGGL(rom_scan, dim3(w.nblk + 1), dim3(kBlk), lds, st, w, ph4 & 1);
         hipLaunchKernelGGL(rom_select, dim3(1 + w.nblk), dim3(64), 0, st, w, ph4 & 1);
     };
     RoundGraph rg;

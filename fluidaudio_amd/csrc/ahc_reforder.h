@@ -260,13 +260,17 @@ struct SelT {
         a = top; b = other;
         op = merges == n - 1 ? RO_DONE : RO_NEW_ROW;                              // the last merge creates no row (:1745)
     }
-    // the scan requested by `op` found (value, node): lowest node id among the minima over the active nodes below the scanned one
-    FA_HD void scan_result(const double value, const int32_t node) {
+    // the scan requested by `op` found (value, node): lowest node id among the minima over the active nodes below the scanned one.  In two halves: what
+    // does not depend on the scan's result (which heap entry goes after a merge, :1792-1797) may run while the result is still being computed.
+    FA_HD void scan_begin() {
+        if (op != RO_NEW_ROW) return;
+        if (b < list.first) heap.remove(list.first);
+        else heap.remove(b);
+    }
+    FA_HD void scan_finish(const double value, const int32_t node) {
         if (op == RO_NEW_ROW) {
             const int32_t created = n + merges - 1;
             nghbr[created] = node;
-            if (b < list.first) heap.remove(list.first);                          // :1792-1797
-            else heap.remove(b);
             heap.replace(a, created, value);
         } else {
             nghbr[a] = node;
@@ -274,6 +278,7 @@ struct SelT {
         }
         advance();
     }
+    FA_HD void scan_result(const double value, const int32_t node) { scan_begin(); scan_finish(value, node); }
 };
 
 using Sel = SelT<Heap>;
