@@ -748,7 +748,10 @@ __device__ __forceinline__ void block_record(const Ws &w, const int par, const i
 }
 
 template <int CPT>
-__global__ __launch_bounds__(kBlk) void ahc_records(Ws w) {  // records of parity 0 from the row arrays; one workgroup per block of kBlk * CPT slots
+__global__ __launch_bounds__(kBlk) void ahc_records(Ws w) {  // records of BOTH parities (blockIdx.y) from the row arrays; one workgroup per block of kBlk * CPT slots.
+    // Parity 1 too: a round requests the operands of its presumptive merge from the records BEFORE it looks at the halt flag, and a run that halts in
+    // round 0 (a NaN met by the start-up) has never written parity 1 — round 1 then formed addresses from whatever the workspace held there (harmless
+    // while that was zeros or an older run's records; after a reference-order run had used the same bytes: a memory fault, found by the tests of round 5).
     __shared__ WaveOut s_out[1];
     const int tid = threadIdx.x, blk = blockIdx.x, x0 = (blk * kBlk + tid) * CPT;
     int nx[CPT];
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(kBlk) void ahc_records(Ws w) {  // records of parit
         if (j == 0 || keys_all[j] < key) { key = keys_all[j]; bx = x0 + j; bnx = nx[j]; bnn = r.nn; bnnnode = r.nnnode; }
         if (live && r.nn < 0 && r.d1 < skey) skey = r.d1;
     }
-    block_record<CPT>(w, 0, blk, w.state[0].eps, key, keys_all, skey, pkey, pslot, pnode, bx, bnx, bnn, bnnnode, s_out);
+    block_record<CPT>(w, static_cast<int>(blockIdx.y), blk, w.state[0].eps, key, keys_all, skey, pkey, pslot, pnode, bx, bnx, bnn, bnnnode, s_out);
 }
 
 // ------------------------------------------------------------------------------ the round kernel
@@ -2457,9 +2460,9 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
     }
     hipLaunchKernelGGL(ahc_row_minima, dim3(w.Np), dim3(kBlk), 0, ctx->stream, w);
     hipLaunchKernelGGL(ahc_set_eps, dim3(1), dim3(64), 0, ctx->stream, w);
-    if (p.cpt == 4) hipLaunchKernelGGL(ahc_records<4>, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);  // window counts need eps
-    else if (p.cpt == 2) hipLaunchKernelGGL(ahc_records<2>, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);
-    else hipLaunchKernelGGL(ahc_records<1>, dim3(w.nblk), dim3(kBlk), 0, ctx->stream, w);
+    if (p.cpt == 4) hipLaunchKernelGGL(ahc_records<4>, dim3(w.nblk, 2), dim3(kBlk), 0, ctx->stream, w);  // window counts need eps
+    else if (p.cpt == 2) hipLaunchKernelGGL(ahc_records<2>, dim3(w.nblk, 2), dim3(kBlk), 0, ctx->stream, w);
+    else hipLaunchKernelGGL(ahc_records<1>, dim3(w.nblk, 2), dim3(kBlk), 0, ctx->stream, w);
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }
