@@ -2,8 +2,8 @@
 // compile (ahc_reforder.h: HeapK — entries that carry their key, block-wise sifts — and SelT).  Two entry points:
 //   fa_heapk_equiv : Heap (the statement-for-statement restatement of the reference's binary_min_heap) and HeapK side by side on a random
 //                    stream of remove / replace / raise with heavily tied keys; every array compared after every operation.
-//   fa_rom_emul    : the whole dendrogram the way the device computes it — a Lance-Williams matrix (Gram-form start, the pair_entry validity
-//                    rule, the device's eps) supplies the candidates of every scan (entries within 2 eps of the approximate minimum), the few
+//   fa_rom_emul    : the whole dendrogram the way the device computes it — a Lance-Williams matrix (Gram-form start, kept symmetric
+//                    over the live slots, the device's eps) supplies the candidates of every scan — the start-up scans included — (entries within 2 eps of the approximate minimum), the few
 //                    candidates are evaluated with the reference's sequential sums, the heap replay picks the pair.  `noise` perturbs the
 //                    start-up matrix by up to noise * eps per entry (a stand-in for the worst rounding the bound allows).
 // tests/test_ahc_reforder_emul.py compares the result with the reference build (oracle/_ref) row for row.  Test infrastructure only.
@@ -70,25 +70,6 @@ extern "C" int fa_rom_emul(const double *x, int n, int d, double noise, unsigned
     std::vector<int32_t> at(n), pos(2 * n, 0), nghbr(2 * n, 0), next(2 * n + 1, 0), prev(2 * n + 1, 0);
     for (size_t i = 0; i < static_cast<size_t>(n) * d; ++i) cent[i] = x[i];
     auto P = [&](int node) { return cent.data() + static_cast<size_t>(node) * d; };
-    for (int i = 1; i < n; ++i) {   // start-up (:1653-1678)
-        double best = inf;
-        int arg = 0;
-        for (int j = 0; j < i; ++j) { const double v = sqdist(P(i), P(j), d); if (v < best) { best = v; arg = j; } }
-        if (best != best) return 5;
-        key0[i] = best; nghbr[i] = arg;
-    }
-    // the initial heap through the restated heap, then entry form (what the device's host side does)
-    fa_ro::Heap h0{};
-    h0.key = key0.data(); h0.at = at.data(); h0.pos = pos.data();
-    h0.init_identity(n - 1, 1);
-    h0.heapify();
-    std::vector<fa_ro::Ent> ent(n);
-    for (int p = 0; p < h0.size; ++p) { ent[p].key = key0[at[p]]; ent[p].node = at[p]; ent[p].pad = 0; }
-    fa_ro::SelT<HeapS> s{};
-    s.heap.ent = ent.data(); s.heap.pos = pos.data(); s.heap.size = h0.size;
-    s.list.next = next.data(); s.list.prev = prev.data();
-    s.list.init(2 * n - 1);
-    s.nghbr = nghbr.data(); s.n = n; s.merges = 0; s.pair_a = pa.data(); s.pair_b = pb.data(); s.height_sq = hs.data();
     // the filter: Gram-form matrix over slots (slot i = point i), eps as ahc_set_eps + the term of the sequentially summed d(a, b)
     std::vector<double> M(static_cast<size_t>(n) * n, inf), norm(n, 0.0);
     std::vector<int32_t> node_of(n), slot_of(total, -1);
@@ -115,10 +96,38 @@ extern "C" int fa_rom_emul(const double *x, int n, int d, double noise, unsigned
                 M[static_cast<size_t>(i) * n + j] = M[static_cast<size_t>(j) * n + i] = v;
             }
     }
-    auto entry = [&](int r, int nr, int c, int nc) {   // pair_entry of ahc.hip with sym_limit = n
-        const bool row_copy = nr > nc || (nr < n && nc < n);
-        return row_copy ? M[static_cast<size_t>(r) * n + c] : M[static_cast<size_t>(c) * n + r];
-    };
+    // start-up (:1653-1678) the way rom_lower_minima computes it: the nearest LOWER-indexed neighbour of every point from the (perturbed) matrix row —
+    // smallest entry left of the diagonal, every entry within 2 eps of it a candidate, the reference's sum for those, lowest (value, index)
+    double start_cands = 0;
+    for (int i = 1; i < n; ++i) {
+        double m = inf;
+        for (int j = 0; j < i; ++j) if (M[static_cast<size_t>(i) * n + j] < m) m = M[static_cast<size_t>(i) * n + j];
+        const double lim = m + 2.0 * eps;
+        double best = inf;
+        int arg = 0;
+        for (int j = 0; j < i; ++j) {
+            if (!(M[static_cast<size_t>(i) * n + j] <= lim)) continue;
+            const double v = sqdist(P(i), P(j), d);
+            if (v != v) return 5;
+            ++start_cands;
+            if (v < best) { best = v; arg = j; }
+        }
+        key0[i] = best; nghbr[i] = arg;
+    }
+    // the initial heap through the restated heap, then entry form (what the device's host side does)
+    fa_ro::Heap h0{};
+    h0.key = key0.data(); h0.at = at.data(); h0.pos = pos.data();
+    h0.init_identity(n - 1, 1);
+    h0.heapify();
+    std::vector<fa_ro::Ent> ent(n);
+    for (int p = 0; p < h0.size; ++p) { ent[p].key = key0[at[p]]; ent[p].node = at[p]; ent[p].pad = 0; }
+    fa_ro::SelT<HeapS> s{};
+    s.heap.ent = ent.data(); s.heap.pos = pos.data(); s.heap.size = h0.size;
+    s.list.next = next.data(); s.list.prev = prev.data();
+    s.list.init(2 * n - 1);
+    s.nghbr = nghbr.data(); s.n = n; s.merges = 0; s.pair_a = pa.data(); s.pair_b = pb.data(); s.height_sq = hs.data();
+    // the device keeps the matrix symmetric over the live slots (the column of every new row is written too), so an entry is always read as a row copy
+    auto entry = [&](int r, int, int c, int) { return M[static_cast<size_t>(r) * n + c]; };
     double n_scans = 0, n_cand = 0, max_cand = 0;
     s.advance();
     std::vector<double> vals(n);
@@ -138,7 +147,7 @@ extern "C" int fa_rom_emul(const double *x, int n, int d, double noise, unsigned
                 if (!(v > 0.0)) v = 0.0;
                 vals[c] = v;
             }
-            for (int c = 0; c < n; ++c) if (vals[c] < inf) M[static_cast<size_t>(sa) * n + c] = vals[c];
+            for (int c = 0; c < n; ++c) if (vals[c] < inf) M[static_cast<size_t>(sa) * n + c] = M[static_cast<size_t>(c) * n + sa] = vals[c];   // row (rom_scan) and column (the mirror workgroups of rom_select)
             node_of[sa] = created; slot_of[created] = sa; node_of[sb] = -1;
             scanned = created; limit = created; ss = sa;
         } else {
@@ -167,6 +176,6 @@ extern "C" int fa_rom_emul(const double *x, int n, int d, double noise, unsigned
         sz[n + r] = sz[a] + sz[b];
         z[4 * r] = a < b ? a : b; z[4 * r + 1] = a < b ? b : a; z[4 * r + 2] = std::sqrt(hs[r]); z[4 * r + 3] = sz[n + r];
     }
-    if (stats) { stats[0] = n_scans; stats[1] = n_cand; stats[2] = max_cand; stats[3] = eps; }
+    if (stats) { stats[0] = n_scans; stats[1] = n_cand + start_cands; stats[2] = max_cand; stats[3] = eps; }
     return 0;
 }
