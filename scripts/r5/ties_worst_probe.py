@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Round 5: what tied inputs other than "30 % duplicated rows" cost through AUTO (-> tie -> the reference's order through the matrix filter) on the 8 h session
+(43 200 x 256): 5 % of the rows one identical "digital silence" embedding, the embeddings rounded to fp16 (quantised: near-ties and exact ties), 90 % duplicated rows
+(the candidate lists of many rows overflow one wavefront: ROM_EXACT re-evaluations).  Wall time, rows re-evaluated with exact sums, ratio to the tie-free run."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import fluidaudio_amd as fa
+from e2e_inputs import e2e_session
+ctx = fa.default_context()
+x = e2e_session(8.0, 12, seed=5)["emb"].astype(np.float64)
+x /= np.sqrt((x * x).sum(axis=1, keepdims=True))
+n = len(x)
+rng = np.random.default_rng(2)
+def dup(frac):
+    y = x.copy(); k = int(frac * n); y[rng.integers(0, n, k)] = y[rng.integers(0, n, k)]; return y
+silence = x.copy(); silence[rng.choice(n, n // 20, replace=False)] = x[7]
+fp16 = x.astype(np.float16).astype(np.float64)
+cases = [("tie-free", x), ("5 % identical rows (silence)", silence), ("rows rounded to fp16", fp16), ("30 % duplicated rows", dup(0.3)), ("90 % duplicated rows", dup(0.9))]
+base = None
+for name, data in cases:
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        st, z, stats = fa.linkage(data, ctx=ctx, return_stats=True)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]: best = (dt, st, stats)
+    dt, st, stats = best
+    if base is None: base = dt
+    print(json.dumps({"case": name, "status": st, "wall_s": round(dt, 4), "over_tie_free": round(dt / base, 2), "reference_order": stats["reference_order"], "scans": stats["rounds"],
+                      "rows_re_evaluated_with_exact_sums": stats["rescans"], "init_ms": round(stats["init_ms"], 1), "merge_ms": round(stats["merge_ms"], 1)}), flush=True)
