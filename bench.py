@@ -11,20 +11,26 @@ features, resident in HBM): AHC (threshold 0.6) -> VBx -> gamma-weighted centroi
 library call (fa_offline_cluster).  `value` = audio hours featurized + clustered per second over all ranks (weak scaling: every
 rank owns its own recording; the merge chain of one recording does not shard — DESIGN.md §4).  The session of rank 0 is the one
 whose CPU-side results are committed (tests/golden/e2e_8h.json: AHC on the REFERENCE's own linkage build, the rest from the C
-restatements); `e2e_equals_reference_digest` says the timed calls reproduced them.  Rank 0 prints ONE JSON line which also carries
+restatements); `e2e_equals_reference_digest` says the timed calls reproduced them.
+
+Output (rank 0): one `{"leg": name, "result": {...}}` line per leg as soon as the leg is done, everything again in bench_legs.json,
+one `{"summary": {...}}` line, and LAST the result line the driver parses — the contract's keys, scalars only, < 4 KB — with
   roofline      — the dominant kernel of the step (ahc_round_t, one launch per merge): algorithmic bytes per launch / average
                   launch period measured with HIP events around the merge phase, against 8 TB/s; traffic from the committed PMC pass
   cpu_baseline  — the same path on this box's host cores: the reference's linkage build (oracle/_ref) + the C restatements, 1 thread
+Legs:
+  e2e_8h        — the timed region itself (stages, digest checks, start-up TFLOP/s)
   mel           — BASELINE configs[1]: 1024 x 15 s chunks per GPU, its own HBM roofline (HIP events per launch)
   mel_single_10s— configs[0] shape: one 10 s utterance through the host-pointer entry, p50 / p99 latency
   ctc           — configs[3]: greedy CTC on 10 000 x [1500, 1024] matrices (sharded over the ranks at N > 1), ids verified in-bench
   ahc_50k       — configs[2]: the metric's second half, dendrogram SHA-256 against the reference build's committed digest
-  ahc_batch, e2e_16x1h, e2e_8h_batch, e2e_8h_hard, beam_search — serving-shaped legs (rank 0, N = 1)
+  ahc_batch, ahc_ties, e2e_16x1h, e2e_8h_batch, e2e_8h_hard, beam_search — serving-shaped legs (rank 0, N = 1)
   resample, tdt, ctc_fp16 — the other north-star kernels, each with its own roofline and an in-bench check
 """
 import argparse
 import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -954,10 +960,11 @@ def cpu_e2e_baseline(hours=1.0):
     t0 = time.perf_counter()
     oracle.cluster_embeddings(s["emb"], s["rho"], s["chunks"], s["phi"])
     t_cl = time.perf_counter() - t0
-    return {"value": hours / (t_mel + t_cl), "unit": "audio_hours/s", "cores": 1, "kind": "reference-linkage+ports",
+    return {"value": hours / (t_mel + t_cl), "unit": "audio_hours/s", "cores": 1, "kind": "port",
+            "sample": f"{hours:g} h recording ({len(s['emb'])} embeds), 1 of {os.cpu_count()} cores: mel port {t_mel:.1f} s + linkage (reference build) and VBx/assignment ports {t_cl:.1f} s",
             "kind_note": "only the linkage is the reference's own code (its FastClusterWrapper C++ compiled by oracle/Makefile); mel, VBx, centroids and Hungarian are "
                          "CPU restatements (ports) of the Swift sources — the Swift/Accelerate path itself cannot run here",
-            "sample": f"{hours:g} h recording ({len(s['emb'])} embeddings): clustering {t_cl:.1f} s = the reference's FastClusterWrapper build (oracle/_ref) + C "
+            "sample_long": f"{hours:g} h recording ({len(s['emb'])} embeddings): clustering {t_cl:.1f} s = the reference's FastClusterWrapper build (oracle/_ref) + C "
                       f"restatements of VBx / centroids / Hungarian; mel {t_mel:.1f} s = oracle computeFlat restatement on {n_chunks} chunks ({timed} timed, scaled); "
                       f"1 of {os.cpu_count()} host cores; Swift/Accelerate itself cannot run on this box",
             "mel_s": t_mel, "cluster_s": t_cl,
@@ -1047,6 +1054,162 @@ def mel_leg(fa, ctx, torch, dist, rank, world, B, steps, warmup, clock_warm_s, m
                          "algorithmic_bytes_per_launch": B * MEL_BYTES_PER_CHUNK,
                          "note": "VALU / LDS-issue bound rather than HBM bound (DESIGN.md §3.1)"}}
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# What is printed.  The driver parses the LAST stdout line and keeps the last 8 KB of stdout; a line that grew to 25 KB (round 5) was not
+# parsed at all.  So: every leg is printed as its own line the moment it is done ({"leg": name, "result": {...}}), all of them are
+# written to bench_legs.json, then one {"summary": ...} line of the scalars worth a glance, then the RESULT line — the contract's keys,
+# scalars only, strings <= 120 characters, < 4 KB (tests/test_bench_line.py holds it to that on a stored full record).
+RESULT_LINE_MAX_BYTES = 4096
+_STR_MAX = 120
+
+
+def _pick(d, *path):
+    for k in path:
+        d = d.get(k) if isinstance(d, dict) else None
+    return d
+
+
+def _num(v, digits=6):
+    """Scalars of the printed lines: 6 significant digits are what a reader compares; NaN / inf have no strict-JSON form."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v[:_STR_MAX] if isinstance(v, str) else v
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}") if math.isfinite(v) else None
+    if isinstance(v, (list, tuple)):
+        return [_num(x, digits) for x in v]
+    try:
+        return _num(float(v), digits)
+    except (TypeError, ValueError):
+        return str(v)[:_STR_MAX]
+
+
+class LegRecord(dict):
+    """The full record of a run.  Assigning a leg (a dict) prints it at once; the contract's own keys are set through update()."""
+
+    def __init__(self, rank):
+        super().__init__()
+        self.rank = rank
+
+    def __setitem__(self, name, result):
+        super().__setitem__(name, result)
+        if isinstance(result, dict):
+            emit_leg(name, result, self.rank)
+
+
+def _strict_tree(v):
+    """A leg as strict JSON: non-finite floats (a 0 / 0 of a leg that measured nothing) become null instead of the bare NaN json.dumps would print."""
+    if isinstance(v, dict):
+        return {str(k): _strict_tree(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_strict_tree(x) for x in v]
+    if isinstance(v, (np.floating, float)):
+        return float(v) if math.isfinite(v) else None
+    if isinstance(v, np.integer):
+        return int(v)
+    if isinstance(v, np.bool_):
+        return bool(v)
+    return v
+
+
+def emit_leg(name, result, rank=0):
+    """One line per leg, as soon as it exists (a later crash keeps the earlier legs; the driver's 8 KB tail shows the last ones)."""
+    if rank == 0:
+        print(json.dumps({"leg": name, "result": _strict_tree(result)}, allow_nan=False, default=str), flush=True)
+
+
+def summary_of(full):
+    """The scalars of the legs a reader wants beside the headline (each from the leg of the same name in bench_legs.json)."""
+    batch = full.get("e2e_8h_batch") if isinstance(full.get("e2e_8h_batch"), dict) else {}
+    s = {
+        "e2e_equals_reference_digest": full.get("e2e_equals_reference_digest"),
+        "e2e_digest_means": "reference-build linkage + restated VBx/centroids/Hungarian (their parity is unpinned, DESIGN.md section 2)",
+        "e2e_per_rank_audio_hours_per_s": _pick(full, "e2e_8h", "per_rank_audio_hours_per_s"), "e2e_all_ranks_ok": _pick(full, "e2e_8h", "all_ranks_ok"),
+        "ahc_50k_seconds": _pick(full, "ahc_50k", "seconds"), "ahc_50k_bit_exact_vs_reference_digest": _pick(full, "ahc_50k", "bit_exact_vs_reference_digest"),
+        "ahc_50k_us_per_round": _pick(full, "ahc_50k", "us_per_round"), "ahc_50k_init_ms": _pick(full, "ahc_50k", "device_init_ms"),
+        "e2e_us_per_round": _pick(full, "e2e_8h", "ahc", "us_per_round"), "e2e_ahc_init_ms": _pick(full, "e2e_8h", "ahc", "init_ms"),
+        "startup_tflops_fp64": _pick(full, "e2e_8h", "ahc", "gram", "achieved"),
+        "ahc_tied_over_tie_free": _pick(full, "ahc_ties", "tied_over_tie_free"), "ahc_tied_seconds": _pick(full, "ahc_ties", "tied_seconds"),
+        "ahc_tied_equals_reference_digest": _pick(full, "ahc_ties", "equals_reference_digest"),
+        "mel_frac": _pick(full, "mel", "roofline", "frac"), "mel_realtime_factor": _pick(full, "mel", "realtime_factor"),
+        "mel_audio_hours_per_s": _pick(full, "mel", "audio_hours_per_s"),
+        "ctc_frac": _pick(full, "ctc", "roofline", "frac"), "ctc_ids_exact": _pick(full, "ctc", "ids_exact"), "ctc_scaling": _pick(full, "ctc", "scaling"),
+        "ctc_matrices_per_s": _pick(full, "ctc", "matrices_per_s"), "ctc_audio_hours_per_s": _pick(full, "ctc", "audio_hours_per_s"),
+        "ctc_matrices_per_rank": _pick(full, "ctc", "matrices_per_rank"),
+        "ctc_fp16_frac": _pick(full, "ctc_fp16", "roofline", "frac"), "ctc_v1025_frac": _pick(full, "ctc_v1025", "roofline", "frac"),
+        "ctc_v1025_fp16_frac": _pick(full, "ctc_v1025_fp16", "roofline", "frac"),
+        "tdt_frac": _pick(full, "tdt", "roofline", "frac"), "tdt_4096_frac": _pick(full, "tdt_4096", "roofline", "frac"),
+        "tdt_4096_fp16_frac": _pick(full, "tdt_4096_fp16", "roofline", "frac"), "tdt_ids_equal_cpu": _pick(full, "tdt", "ids_equal_cpu_restatement_all_chunks"),
+        "resample_frac": {k.split("->")[0]: _pick(v, "roofline", "frac") for k, v in (full.get("resample") or {}).items() if isinstance(v, dict) and "->" in k},
+        "beam_us_per_frame_step": _pick(full, "beam_search", "us_per_frame_step"), "beam_sclk_mhz": _pick(full, "beam_search", "sclk_mhz_before_after"),
+        "e2e_batch_audio_hours_per_s": {k: _pick(v, "audio_hours_per_s") for k, v in batch.items() if k.startswith("x") and isinstance(v, dict)},
+        "e2e_batch_us_per_round": {k: _pick(v, "us_per_round") for k, v in batch.items() if k.startswith("x") and isinstance(v, dict)},
+        "e2e_batch_equal_single_calls": {k: _pick(v, "equal_single_calls") for k, v in batch.items() if k.startswith("x") and isinstance(v, dict)},
+        "e2e_16x1h_audio_hours_per_s": _pick(full, "e2e_16x1h", "audio_hours_per_s"),
+        "e2e_hard_audio_hours_per_s": _pick(full, "e2e_8h_hard", "audio_hours_per_s"),
+        "vbx_sharded_all_ranks_same_elbos": _pick(full, "vbx_sharded", "all_ranks_same_elbos"),
+        "errors": sorted(k for k, v in full.items() if isinstance(v, dict) and "error" in v),
+    }
+    return {k: (_num(v) if not isinstance(v, dict) else {kk: _num(vv) for kk, vv in v.items()}) for k, v in s.items()}
+
+
+def result_line_of(full):
+    """The one line the driver parses: the contract's keys + `roofline` + `cpu_baseline`, scalars only."""
+    batch = full.get("e2e_8h_batch") if isinstance(full.get("e2e_8h_batch"), dict) else {}
+    cfg = full.get("config") or {}
+    roof = full.get("roofline") or {}
+    cpu = full.get("cpu_baseline")
+    out = {k: _num(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                           "dtype", "data")}
+    out["config"] = {
+        "workload": _num(cfg.get("workload")),
+        "hours_per_step_per_gpu": _num(cfg.get("hours_per_step_per_gpu")), "embeddings_per_recording": _num(cfg.get("embeddings_per_recording")),
+        "realtime_factor": _num(cfg.get("realtime_factor")), "parallelism": _num(cfg.get("parallelism")),
+        "e2e_equals_reference_digest": full.get("e2e_equals_reference_digest"),
+        "ahc_50k_seconds": _num(_pick(full, "ahc_50k", "seconds")), "ahc_50k_bit_exact_vs_reference_digest": _pick(full, "ahc_50k", "bit_exact_vs_reference_digest"),
+        "mel_realtime_factor": _num(_pick(full, "mel", "realtime_factor")), "mel_roofline_frac": _num(_pick(full, "mel", "roofline", "frac")),
+        "ctc_roofline_frac": _num(_pick(full, "ctc", "roofline", "frac")), "ctc_ids_exact": _pick(full, "ctc", "ids_exact"),
+        "batch_x8_audio_hours_per_s": _num(_pick(batch, "x8", "audio_hours_per_s")),
+    }
+    if (full.get("n_gpus") or 1) > 1:
+        # N > 1: the single-GPU legs did not run; their places carry what a scaling record needs from the legs the driver drops — the strong-scaled
+        # configs[3] rate, the slowest rank's own end-to-end rate, and that the one leg with a collective agreed across ranks
+        for k in ("ahc_50k_seconds", "ahc_50k_bit_exact_vs_reference_digest", "batch_x8_audio_hours_per_s"):
+            out["config"].pop(k)
+        per_rank = _pick(full, "e2e_8h", "per_rank_audio_hours_per_s") or [None]
+        out["config"].update({
+            "e2e_all_ranks_ok": _pick(full, "e2e_8h", "all_ranks_ok"),
+            "e2e_slowest_rank_audio_hours_per_s": _num(min((v for v in per_rank if v is not None), default=None)),
+            "ctc_matrices_per_s_strong_scaled": _num(_pick(full, "ctc", "matrices_per_s")),
+            "vbx_sharded_all_ranks_same_elbos": _pick(full, "vbx_sharded", "all_ranks_same_elbos"),
+        })
+    out["roofline"] = {k: _num(roof.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_period_us", "launches_per_step",
+                                                        "algorithmic_bytes_per_launch")}
+    if isinstance(cpu, dict):
+        out["cpu_baseline"] = {k: _num(cpu.get(k)) for k in ("value", "unit", "cores", "kind", "sample", "mel_s", "cluster_s") if k in cpu} if "error" not in cpu \
+            else {"error": _num(cpu["error"])}
+    else:
+        out["cpu_baseline"] = None            # N > 1 (rank 0 of a multi-rank run does not time the CPU side) or --skip-cpu
+    out["legs_file"] = "bench_legs.json"
+    return out
+
+
+def finish(full, rank):
+    """Rank 0: bench_legs.json (everything), the summary line, the result line (last)."""
+    if rank != 0:
+        return
+    for dest in (os.path.join(ROOT, "bench_legs.json"), os.path.join(ROOT, "gpurun_out", "bench_legs.json")):
+        if os.path.isdir(os.path.dirname(dest)):
+            try:
+                with open(dest, "w") as f:
+                    json.dump(_strict_tree(full), f, allow_nan=False, default=str)
+            except OSError as e:
+                print(f"bench.py: could not write {dest}: {e}", file=sys.stderr)
+    print(json.dumps({"summary": summary_of(full)}, allow_nan=False), flush=True)
+    text = json.dumps(result_line_of(full), allow_nan=False)
+    assert len(text) < RESULT_LINE_MAX_BYTES, len(text)
+    print(text, flush=True)
 
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: start N ranks of this script, one per GPU, under torch.distributed.run
@@ -1164,25 +1327,26 @@ def main():
     elapsed = h.pop("elapsed")
     value = world * args.hours * args.steps / elapsed
     roof = h.pop("roofline")
-    line = {
+    line = LegRecord(rank)
+    line.update({
         "metric": "audio hours/sec featurized+clustered per node; AHC wall-clock @ 50k x 256 embeds (ahc_50k.seconds)",
         "value": value, "unit": "audio_hours/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 (clustering; the mel stage computes in f32)", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[4] on {world} GPU(s): per GPU one {args.hours:g} h synthetic 16 kHz recording -> mel ({int(args.hours * 240)} x 15 s chunks) -> "
-                               f"{int(args.hours * 5400)} precomputed 256-d embeddings + 128-d PLDA features -> AHC (thr 0.6) + VBx + centroids + constrained assignment; "
-                               "PCM, embeddings and PLDA features resident in HBM, labels + centroids returned to the host",
+        "dtype": "f64", "data": "synthetic",
+        # strings of the result line stay <= 120 characters (the driver cuts at 128); the long form of the workload is DESIGN.md section 5
+        "config": {"workload": f"configs[4]: per GPU one {args.hours:g} h 16 kHz recording -> mel -> {int(args.hours * 5400)} embeds -> AHC+VBx+assignment, HBM-resident",
                    "hours_per_step_per_gpu": args.hours, "embeddings_per_recording": h["embeddings"], "realtime_factor": value * 3600.0,
-                   "parallelism": f"dp{world} (one recording per GPU, no data-path collective: the merge chain of a recording does not shard)"},
+                   "parallelism": f"dp{world}"},
         "e2e_equals_reference_digest": h["e2e_equals_reference_digest"],
         "roofline": roof,
-        "e2e_8h": h,
-    }
+    })
+    line["e2e_8h"] = h
     torch.cuda.empty_cache()
     if solo and not args.skip_cpu and rank == 0:
         try:
-            line["cpu_baseline"] = cpu_e2e_baseline(args.hours if args.cpu_full else 1.0)
-            line["cpu_baseline"]["stages"] = cpu_baselines()
+            cpu = cpu_e2e_baseline(args.hours if args.cpu_full else 1.0)
+            cpu["stages"] = cpu_baselines()
+            line["cpu_baseline"] = cpu
         except Exception as e:  # noqa: BLE001
             line["cpu_baseline"] = {"error": repr(e)}
     if not args.skip_mel:
@@ -1262,10 +1426,6 @@ def main():
             line["e2e_16x1h"] = {"error": repr(e)}
         try:
             line["e2e_8h_batch"] = e2e_batch_leg(fa, ctx)
-            best = max((v for k, v in line["e2e_8h_batch"].items() if k.startswith("x")), key=lambda v: v["audio_hours_per_s"])
-            line["config"]["recordings_per_call"] = (f"value = ONE 8 h recording per step (its latency); {best['recordings']} such recordings through one fa_offline_cluster_batch call "
-                                                     f"on the same GPU: {best['audio_hours_per_s']:.1f} audio-hours/s ({best['us_per_round']:.2f} us per round of all of them, "
-                                                     f"equal to the single calls: {best['equal_single_calls']}; leg e2e_8h_batch)")
         except Exception as e:  # noqa: BLE001
             line["e2e_8h_batch"] = {"error": repr(e)}
         torch.cuda.empty_cache()
@@ -1290,44 +1450,7 @@ def main():
             line["beam_search"] = beam_leg(fa, ctx, torch)
         except Exception as e:  # noqa: BLE001
             line["beam_search"] = {"error": repr(e)}
-    # The driver keeps `config` whole and drops / truncates the extra keys: the second half of the metric and the fractions of the other
-    # north-star kernels ride in it (each from the leg of the same name, where the inputs of the number are).
-    def pick(leg, *path):
-        v = line.get(leg)
-        for k in path:
-            v = v.get(k) if isinstance(v, dict) else None
-        return v
-    line["config"].update({
-        "ahc_8h_tied_over_tie_free": pick("ahc_ties", "tied_over_tie_free"), "ahc_8h_tied_seconds": pick("ahc_ties", "tied_seconds"),
-        "ahc_8h_tied_equals_matrix_free_form": pick("ahc_ties", "equals_matrix_free_form_row_for_row"),
-        "ahc_50k_seconds": pick("ahc_50k", "seconds"), "ahc_50k_bit_exact_vs_reference_digest": pick("ahc_50k", "bit_exact_vs_reference_digest"),
-        "mel_roofline_frac": pick("mel", "roofline", "frac"), "mel_realtime_factor": pick("mel", "realtime_factor"),
-        "ctc_roofline_frac": pick("ctc", "roofline", "frac"), "ctc_ids_exact": pick("ctc", "ids_exact"),
-        "ctc_fp16_roofline_frac": pick("ctc_fp16", "roofline", "frac"),
-        "ctc_v1025_roofline_frac": pick("ctc_v1025", "roofline", "frac"),
-        "ctc_v1025_fp16_roofline_frac": pick("ctc_v1025_fp16", "roofline", "frac"),
-        "resample_44k1_roofline_frac": pick("resample", "44100->16000", "roofline", "frac"),
-        "resample_96k_roofline_frac": pick("resample", "96000->16000", "roofline", "frac"), "resample_88k2_roofline_frac": pick("resample", "88200->16000", "roofline", "frac"),
-        "tdt_roofline_frac": pick("tdt", "roofline", "frac"), "tdt_4096_fp16_roofline_frac": pick("tdt_4096_fp16", "roofline", "frac"),
-        "tdt_4096_roofline_frac": pick("tdt_4096", "roofline", "frac"),
-        "vbx_sharded_all_ranks_same_elbos": pick("vbx_sharded", "all_ranks_same_elbos"),
-        # N > 1: what the driver's scaling record needs from the legs it drops — the strong-scaled configs[3] rate and every rank's own e2e rate
-        "e2e_per_rank_audio_hours_per_s": pick("e2e_8h", "per_rank_audio_hours_per_s"),
-        "e2e_all_ranks_ok": pick("e2e_8h", "all_ranks_ok"),
-        "ctc_scaling": pick("ctc", "scaling"), "ctc_matrices_per_s": pick("ctc", "matrices_per_s"), "ctc_audio_hours_per_s": pick("ctc", "audio_hours_per_s"),
-        "ctc_matrices_per_rank": pick("ctc", "matrices_per_rank"),
-        "mel_audio_hours_per_s": pick("mel", "audio_hours_per_s"),
-        # latency-bound legs with the clock they ran at (a fresh box idles between legs)
-        "beam_us_per_frame_step": pick("beam_search", "us_per_frame_step"), "beam_device_us_per_frame_step": pick("beam_search", "device_us_per_frame_step"),
-        "beam_seconds_min_median_max": pick("beam_search", "seconds_min_median_max"), "beam_sclk_mhz_before_after": pick("beam_search", "sclk_mhz_before_after"),
-        "beam_kernel": pick("beam_search", "kernel"),
-        "e2e_8h_batch_best_audio_hours_per_s": max((v.get("audio_hours_per_s", 0.0) for k, v in (line.get("e2e_8h_batch") or {}).items()
-                                                   if k.startswith("x") and isinstance(v, dict)), default=None),
-        "e2e_16x1h_audio_hours_per_s": pick("e2e_16x1h", "audio_hours_per_s"),
-        "e2e_equals_reference_digest_means": "labels / centroids equal the digests of the CPU side run once at full size: the REFERENCE's linkage build (oracle/_ref) + the "
-                                             "restated VBx / centroids / Hungarian (parity of those restatements is unpinned, DESIGN.md section 2)",
-    })
-    print(json.dumps(line))
+    finish(line, rank)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -11,12 +11,27 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _strict(text):
+    def refuse(name):
+        raise ValueError(f"{name} is not JSON")
+    return json.loads(text, parse_constant=refuse)
+
+
 def _run(args, env_extra=None, timeout=600):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    return r, (json.loads(lines[-1]) if lines else None)
+    return r, (_strict(lines[-1]) if lines else None)
+
+
+def _legs(r):
+    out = {}
+    for l in r.stdout.splitlines():
+        if l.startswith('{"leg"'):
+            rec = _strict(l)
+            out[rec["leg"]] = rec["result"]
+    return out
 
 
 def test_bare_command_with_gpus_2_starts_two_ranks():
@@ -41,12 +56,37 @@ def test_two_ranks_on_the_one_gpu_print_a_whole_line():
     r, line = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--hours", "1", "--mel-steps", "5", "--mel-warmup", "2", "--clock-warm-s", "0",
                     "--chunks", "64", "--ctc-matrices", "64"], {"FA_BENCH_BACKEND": "gloo"}, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    last = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert len(last) < 4096                                             # the driver parses this line: small, strict JSON (round 5's 25 KB line was not parsed)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2
-    assert line["e2e_8h"]["all_ranks_ok"] is True
-    assert line["vbx_sharded"]["all_ranks_same_elbos"] is True and line["vbx_sharded"]["elbos_equal_single_device"] is True
-    assert line["config"]["vbx_sharded_all_ranks_same_elbos"] is True
-    assert line["ctc"]["ids_exact"] is True and line["ctc"]["matrices_per_rank"] == 32
-    assert abs(line["value"] - 2 * 1.0 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]
+    assert line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None and len(line["config"]) <= 13
+    assert line["config"]["e2e_all_ranks_ok"] is True and line["config"]["vbx_sharded_all_ranks_same_elbos"] is True
+    assert line["config"]["ctc_matrices_per_s_strong_scaled"] > 0 and line["config"]["e2e_slowest_rank_audio_hours_per_s"] > 0
+    assert abs(line["value"] - 2 * 1.0 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-4 * line["value"]
+    legs = _legs(r)                                                     # every N > 1 leg ran and was printed as its own line
+    assert legs["e2e_8h"]["all_ranks_ok"] is True
+    assert legs["vbx_sharded"]["all_ranks_same_elbos"] is True and legs["vbx_sharded"]["elbos_equal_single_device"] is True
+    assert legs["ctc"]["ids_exact"] is True and legs["ctc"]["matrices_per_rank"] == 32
+    full = json.load(open(os.path.join(ROOT, "bench_legs.json")))
+    assert full["vbx_sharded"] == legs["vbx_sharded"] and full["n_gpus"] == 2
+
+
+@pytest.mark.gpu
+def test_single_gpu_run_prints_a_line_the_driver_can_parse():
+    """The driver's own command form, shortened: last line strict JSON < 4 KB with roofline + cpu_baseline, legs on their own lines."""
+    r, line = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--hours", "1", "--mel-steps", "5", "--mel-warmup", "2", "--clock-warm-s", "0",
+                    "--chunks", "64", "--ctc-matrices", "64", "--skip-ahc", "--skip-e2e", "--skip-beam", "--skip-resample"], timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    last = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert len(last) < 4096
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["unit"] == "audio_hours/s"
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    assert line["cpu_baseline"]["kind"] in ("port", "reference") and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == 1
+    assert abs(line["value"] - 1.0 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-4 * line["value"]
+    legs = _legs(r)
+    assert {"e2e_8h", "cpu_baseline", "mel", "ctc"} <= set(legs)
+    summary = [l for l in r.stdout.splitlines() if l.startswith('{"summary"')]
+    assert len(summary) == 1 and _strict(summary[0])["summary"]["errors"] == []
 
 
 @pytest.mark.gpu
