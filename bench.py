@@ -1175,7 +1175,7 @@ def result_line_of(full):
     if (full.get("n_gpus") or 1) > 1:
         # N > 1: the single-GPU legs did not run; their places carry what a scaling record needs from the legs the driver drops — the strong-scaled
         # configs[3] rate, the slowest rank's own end-to-end rate, and that the one leg with a collective agreed across ranks
-        for k in ("ahc_50k_seconds", "ahc_50k_bit_exact_vs_reference_digest", "batch_x8_audio_hours_per_s"):
+        for k in ("ahc_50k_seconds", "ahc_50k_bit_exact_vs_reference_digest", "batch_x8_audio_hours_per_s", "mel_realtime_factor"):
             out["config"].pop(k)
         per_rank = _pick(full, "e2e_8h", "per_rank_audio_hours_per_s") or [None]
         out["config"].update({
