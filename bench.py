@@ -185,45 +185,44 @@ def ahc_leg(fa, ctx, torch, n=50000, d=256, ref_n=3000):
     return out
 
 
-def ahc_ties_leg(fa, ctx, hours=8.0, dup=0.3):
-    """What an input with exact ties costs: the 8 h session with `dup` of its rows duplicated.  AUTO halts at the first tied minimum
-    and the problem runs in the reference's selection order — through the matrix filter (rom_scan / rom_select, round 5) where the N x N workspace
-    is to be had.  Checked row for row against the matrix-free form of the same order (O(A d) exact sums per row, the restated heap: the run that is
-    pinned to the reference build by the tests), timed next to it and next to the tie-free session."""
-    sess = e2e_session_for(0, hours)[0]
-    x = sess["emb"].astype(np.float64)
-    x /= np.sqrt((x * x).sum(axis=1, keepdims=True))
-    n = len(x)
-    rng = np.random.default_rng(1)
-    xd = x.copy()
-    k = int(dup * n)
-    xd[rng.integers(0, n, k)] = xd[rng.integers(0, n, k)]
+def ahc_ties_leg(fa, ctx, kinds=("dup30", "silence5", "grid64")):
+    """What an input with exact ties costs, and that the tie route returns what the REFERENCE BUILD returns: the 8 h session's rows with 30 % duplicated /
+    5 % one identical row / on a 1/64 grid (tests/golden/ahc_full_inputs.ahc_tied_input).  AUTO halts at the first tied minimum and the problem runs in
+    the reference's selection order (fastcluster_internal.hpp:1685-1799) through the matrix filter; every dendrogram is compared with the SHA-256 of what
+    oracle/_ref produced on the same bytes (tests/golden/ahc_tied_<kind>_43200.json, make_ahc_full_digest.py --tied) and timed next to the tie-free rows."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from ahc_full_inputs import ahc_tied_input, dendrogram_digest, sha256
 
-    def timed(data, mode, env=None, reps=2):
-        if env:
-            os.environ[env] = "1"
-        try:
-            best = None
-            for _ in range(reps):
-                t0 = time.perf_counter()
-                st, z, stats = fa.linkage(data, mode=mode, ctx=ctx, return_stats=True)
-                dt = time.perf_counter() - t0
-                if st != 0:
-                    raise RuntimeError(f"linkage status {st}: {ctx.last_error()}")
-                if best is None or dt < best[0]:
-                    best = (dt, z, stats)
-        finally:
-            if env:
-                os.environ.pop(env, None)
+    def timed(data, reps=2):
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            st, z, stats = fa.linkage(data, mode=fa.AHC_MODE_AUTO, ctx=ctx, return_stats=True)
+            dt = time.perf_counter() - t0
+            if st != 0:
+                raise RuntimeError(f"linkage status {st}: {ctx.last_error()}")
+            if best is None or dt < best[0]:
+                best = (dt, z, stats)
         return best
-    t_free, z_free, s_free = timed(x, fa.AHC_MODE_AUTO)
-    t_tie, z_tie, s_tie = timed(xd, fa.AHC_MODE_AUTO)
-    t_mf, z_mf, s_mf = timed(xd, fa.AHC_MODE_REFERENCE_ORDER, env="FA_AHC_RO_NO_MATRIX", reps=1)
-    return {"n": n, "d": x.shape[1], "duplicated_rows": k, "tie_free_seconds": t_free, "tied_seconds": t_tie, "tied_over_tie_free": t_tie / t_free,
-            "tied_reference_order": s_tie["reference_order"], "tied_us_per_row": 1e3 * s_tie["merge_ms"] / (n - 1), "tied_startup_ms": s_tie["init_ms"],
-            "matrix_free_seconds": t_mf, "matrix_free_us_per_row": 1e3 * s_mf["merge_ms"] / (n - 1),
-            "equals_matrix_free_form_row_for_row": bool(np.array_equal(z_tie, z_mf)),
-            "note": "host-pointer entries: the uploads / downloads of 88 MB are inside the wall times of all three"}
+    x = ahc_tied_input("tie_free")
+    n = len(x)
+    t_free, _, s_free = timed(x)
+    out = {"n": n, "d": x.shape[1], "tie_free_seconds": t_free, "tie_free_reference_order": s_free["reference_order"],
+           "note": "host-pointer entries: the upload / download of 88 MB is inside every wall time"}
+    for kind in kinds:
+        with open(os.path.join(ROOT, "tests", "golden", f"ahc_tied_{kind}_{n}.json")) as f:
+            want = json.load(f)
+        xd = ahc_tied_input(kind)
+        same_input = sha256(xd) == want["input_sha256"]
+        t_tie, z_tie, s_tie = timed(xd)
+        out[kind] = {"seconds": t_tie, "over_tie_free": t_tie / t_free, "reference_order": s_tie["reference_order"], "us_per_row": 1e3 * s_tie["merge_ms"] / (n - 1),
+                     "startup_ms": s_tie["init_ms"], "rescans": s_tie.get("rescans"), "input_regenerated_bit_for_bit": same_input,
+                     "equals_reference_digest": bool(same_input and dendrogram_digest(z_tie)["dendrogram_sha256"] == want["dendrogram_sha256"]),
+                     "reference_seconds_1_core_when_generated": want["reference_seconds_1_core"]}
+    out["tied_seconds"] = out[kinds[0]]["seconds"]                                  # the 30 % duplicates: the figure rounds 4 and 5 quoted
+    out["tied_over_tie_free"] = out[kinds[0]]["over_tie_free"]
+    out["equals_reference_digest"] = all(out[k]["equals_reference_digest"] for k in kinds)
+    return out
 
 
 def ahc_batch_leg(fa, ctx, recordings=16, n=5400, d=256, speakers=8):

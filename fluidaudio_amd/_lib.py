@@ -30,7 +30,7 @@ FAULT_VBX, FAULT_THREAD_START, FAULT_DEVBUF_MALLOC, FAULT_WS_MALLOC, FAULT_AHC =
 
 # Every symbol include/fluidaudio_hip.h + include/FastClusterWrapper.h declare (checked by tests/test_abi.py).
 EXPORTED_SYMBOLS = [
-    "fa_version", "fa_debug_inject_fault", "fa_ctx_set_timing", "fa_ctx_last_device_ms", "fa_debug_sclk_mhz", "fa_ctc_beam_plan", "fa_host_alloc", "fa_host_free", "fa_ctx_create", "fa_ctx_destroy", "fa_ctx_synchronize", "fa_ctx_stream", "fa_ctx_last_error",
+    "fa_version", "fa_debug_inject_fault", "fa_debug_set_switch", "fa_debug_hooks_enabled", "fa_ctx_set_timing", "fa_ctx_last_device_ms", "fa_debug_sclk_mhz", "fa_ctc_beam_plan", "fa_host_alloc", "fa_host_free", "fa_ctx_create", "fa_ctx_destroy", "fa_ctx_synchronize", "fa_ctx_stream", "fa_ctx_last_error",
     "fa_ctx_set_workspace_limit", "fa_ctx_set_workspace_cap", "fa_ctx_trim", "fa_ctx_workspace_bytes", "fa_ctx_reserve",
     "fa_mel_default_config", "fa_mel_num_frames", "fa_mel_padded_frames", "fa_mel_plan_create", "fa_mel_plan_destroy",
     "fa_mel_plan_utt_stride", "fa_mel_plan_frame_stride", "fa_mel_plan_total_frames", "fa_mel_execute_dev",
@@ -125,6 +125,8 @@ def lib() -> C.CDLL:
     L.fa_version.restype = C.c_char_p
     L.fa_debug_inject_fault.argtypes = [i32, i32]
     L.fa_debug_inject_fault.restype = None
+    L.fa_debug_set_switch.argtypes = [C.c_char_p, C.c_char_p]
+    L.fa_debug_hooks_enabled.restype = i32
     L.fa_ctx_set_timing.argtypes = [vp, i32]
     L.fa_ctx_last_device_ms.argtypes = [vp]
     L.fa_ctx_last_device_ms.restype = f64

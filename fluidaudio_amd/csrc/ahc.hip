@@ -2448,7 +2448,7 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
     if (dev_mode == FA_AHC_MODE_AUTO) {  // Gram form on the fp64 matrix cores (approximate entries, see ahc_gram_mfma)
         double *d_norms = reinterpret_cast<double *>(base + L.norms);
         hipLaunchKernelGGL(ahc_sqnorms, dim3((w.Np + 255) / 256), dim3(256), 0, ctx->stream, w, d_norms);
-        if (w.d % G2K == 0 && getenv("FA_AHC_GRAM_V1") == nullptr) {
+        if (w.d % G2K == 0 && !fa::sw_on(fa::Sw::AHC_GRAM_V1)) {
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_gram_mfma2), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGram2LdsBytes));
             FA_HIP_TRY(ctx, attr);
             hipLaunchKernelGGL(ahc_gram_mfma2, dim3(w.Np / GT, w.Np / GT), dim3(256), kGram2LdsBytes, ctx->stream, w, d_norms);
@@ -2638,6 +2638,7 @@ fa_status ro_run_device_mf(fa_ctx *ctx, const double *d_data, size_t N, size_t d
 
 // Workspace of the matrix-filtered run: the selection's arrays, then what the start-up kernels of the filter-based rounds expect (points / centroids,
 // transpose, norms, the two state records their maxima go to), the matrix last.
+fa_status ctx_events(fa_ctx *ctx, hipEvent_t (&ev)[3]);   // below: the three timing events a context keeps
 struct RomLayout { size_t prof, dev, flags, part, part2, node, slot, sizes, key, ent, pos, ngh, next, prev, pa, pb, hs, z, state, norms, c, xt, m, total; };
 RomLayout rom_layout(size_t N, size_t Np, size_t d) {
     RomLayout L{};
@@ -2687,15 +2688,14 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     double *d_norms = reinterpret_cast<double *>(base + L.norms);
     hipStream_t st = ctx->stream;
     hipEvent_t ev[3];
-    for (auto &e : ev) FA_HIP_TRY(ctx, hipEventCreate(&e));
-    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
+    FA_TRY(ctx_events(ctx, ev));                // the context's own three events (created once, destroyed with the context)
     FA_HIP_TRY(ctx, hipEventRecord(ev[0], st));
     // ---- start-up: the reference's nearest lower-indexed neighbours (exact sums), and the Gram-form matrix of all pairs
     FA_HIP_TRY(ctx, hipMemsetAsync(base + L.dev, 0, L.part - L.dev, st));              // RomDev, flags, the two state records (their maxima start at 0)
     FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(ro_init, dim3(static_cast<unsigned>((std::max(Np, 2 * N) + 255) / 256)), dim3(256), 0, st, rw);
     hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, st, d_data, w.XT, w.N, w.Np, w.d);
-    const bool direct_start = getenv("FA_AHC_ROM_DIRECT_START") != nullptr;   // the start-up of the matrix-free run (all N^2 / 2 exact sums) for A/B
+    const bool direct_start = fa::sw_on(fa::Sw::AHC_ROM_DIRECT_START);   // the start-up of the matrix-free run (all N^2 / 2 exact sums) for A/B
     if (direct_start) hipLaunchKernelGGL(ro_lower_minima_direct, dim3(static_cast<unsigned>((N + kRoT - 1) / kRoT)), dim3(256), 0, st, rw);
     hipLaunchKernelGGL(ahc_sqnorms, dim3((w.Np + 255) / 256), dim3(256), 0, st, gw, d_norms);
     if (w.d % G2K == 0) {
@@ -2780,7 +2780,7 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
                 hp[15], hp[14] / n, hp[0] / n, hp[1] / n, hp[2] / n, hp[3] / n, hp[4] / n, hp[5] / n, hp[6] / n, hp[7] / n);
     }
 #endif
-    if (getenv("FA_AHC_DEBUG"))
+    if (fa::sw(fa::Sw::AHC_DEBUG))
         fprintf(stderr, "ahc (reference order, matrix filter): N %zu scans %lld exact re-evaluations %lld candidates %lld eps %.3e\n", N, hd.scans, hd.exact_scans, hd.cands, hd.eps);
     if (stats) {
         float t01 = 0, t12 = 0;
@@ -2795,7 +2795,7 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
 
 // The reference-order run: through the matrix filter when the workspace is to be had, matrix-free (O(N d) memory, O(A d) sums per row) when not.
 fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host = false) {
-    if (getenv("FA_AHC_RO_NO_MATRIX") == nullptr) {
+    if (!fa::sw_on(fa::Sw::AHC_RO_NO_MATRIX)) {
         bool declined = false;
         const fa_status st = rom_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host, declined);
         if (!declined) return st;
@@ -2840,7 +2840,7 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
         if (stats) *stats = fa_ahc_stats{};
         return ro_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host);
     }
-    const bool may_fall_back = getenv("FA_AHC_NO_MATRIX_FREE") == nullptr;
+    const bool may_fall_back = !fa::sw_on(fa::Sw::AHC_NO_MATRIX_FREE);
     if (prob_check_shape(ctx, N, d) != FA_SUCCESS) {   // too many points for the block records (a too large d fails in ro_run_device as well)
         if (may_fall_back) return without_matrix();
         return FA_ALLOCATION_FAILURE;
@@ -2851,8 +2851,8 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     // 2 / 4); 2 where that makes the problem ONE block (257 .. 512 points: all rounds of a replay inside one launch, no kernel boundary between them:
     // 400 points 2.35 -> 2.08 ms per call; four slots per thread for <= 1 024 points lose to the multi-block chain, 5.0 against 4.9 ms at 900).
     // FA_AHC_CPT forces a value (measurements: profiles/r05_cpt_probe_v2.json).
-    const int env_cpt = [] { const char *e = getenv("FA_AHC_CPT"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? v : 0; }();   // per call, like the other switches (the tests flip them)
-    const bool no_single_block = getenv("FA_AHC_NO_SINGLE_BLOCK") != nullptr;
+    const int env_cpt = [] { const char *e = fa::sw(fa::Sw::AHC_CPT); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? v : 0; }();   // per call, like the other switches (the tests flip them)
+    const bool no_single_block = fa::sw_on(fa::Sw::AHC_NO_SINGLE_BLOCK);
     p.cpt = env_cpt ? env_cpt : (no_single_block || N <= kBlk || N > 2 * kBlk ? 1 : 2);
     const size_t cols = static_cast<size_t>(kBlk) * p.cpt;
     p.N = N; p.d = d; p.Np = (N + cols - 1) / cols * cols; p.d_data = d_data; p.d_Z = d_Z; p.mode = mode;
@@ -2871,7 +2871,7 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
     FA_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
 
     const Ws w = p.w;
-    const bool env_big = getenv("FA_AHC_ROUND_BIG") != nullptr;
+    const bool env_big = fa::sw_on(fa::Sw::AHC_ROUND_BIG);
     const bool big = w.nblk > (4 / p.cpt) * 64 || env_big;   // more than 65 536 points (four block records per lane at one slot per thread): the kernel with the many-record reduction
     if (lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -2954,7 +2954,7 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
         fprintf(stderr, "  decide = wave reduction %.0f | barrier + result read %.0f | finished rows + global minimum %.0f | state machine + piggy choice %.0f\n", hp[6] / n, hp[7] / n, hp[8] / n, hp[1] / n);
     }
 #endif
-    if (getenv("FA_AHC_DEBUG"))
+    if (fa::sw(fa::Sw::AHC_DEBUG))
         fprintf(stderr, "ahc: N %zu rounds %lld merges %d forced re-scans %lld piggy-backed re-scans %lld windows %lld fallback %lld (kPiggy %d)\n", N, p.h.rounds,
                 p.h.step, p.h.rescans, p.h.piggy, p.h.windows, p.fallback, kPiggy);
     if (stats) {
@@ -3028,7 +3028,7 @@ fa_status ahc_batch_once(fa_ctx *ctx, int count, const double *const *d_data, co
     int2 *d_map = reinterpret_cast<int2 *>(base + o_map);
     FA_HIP_TRY(ctx, hipMemcpyAsync(const_cast<Ws *>(d_table), table.data(), sizeof(Ws) * count, hipMemcpyHostToDevice, ctx->stream));
     const size_t lds = sizeof(double) * d;
-    bool big = getenv("FA_AHC_ROUND_BIG") != nullptr;
+    bool big = fa::sw_on(fa::Sw::AHC_ROUND_BIG);
     for (const Prob &p : probs) if (p.active && p.Np / kBlk > 4 * 64) big = true;
     if (lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -3132,7 +3132,7 @@ int uniform_kernel_choice(size_t blocks_total) {
     // 5 waves per SIMD = 1 280 resident workgroups (7 recordings of 8 h).  Capped at 80 / 64 VGPRs (52 / 120 bytes of scratch): 1 536 / 2 048.
     // FA_AHC_UNI_WAVES = 5 | 6 | 8 picks one (measurements: profiles/r04_uni_probe.json).
     (void)blocks_total;
-    if (const char *e = getenv("FA_AHC_UNI_WAVES")) { const int v = atoi(e); if (v == 6) return 3; if (v == 8) return 4; }
+    if (const char *e = fa::sw(fa::Sw::AHC_UNI_WAVES)) { const int v = atoi(e); if (v == 6) return 3; if (v == 8) return 4; }
     return 2;
 }
 
@@ -3157,7 +3157,7 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
     // Slots per thread of the round (ahc_round_body's CPT): a launch over several problems is bound by instruction issue, and a thread that owns four
     // slots leaves a quarter of the workgroups, wavefronts and block records per problem; small problems keep enough blocks to spread over.
     // FA_AHC_UNI_CPT forces 1 / 2 / 4 (measurements).
-    const int env_cpt = [] { const char *e = getenv("FA_AHC_UNI_CPT"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? v : 0; }();
+    const int env_cpt = [] { const char *e = fa::sw(fa::Sw::AHC_UNI_CPT); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? v : 0; }();
     const size_t Nmax = n[ord[0]];
     // Measured (profiles/r05_cpt_probe_v2.json, us per round of 43 200-point problems, one batch): K = 2: 5.80 / 5.93 / 6.83 with 1 / 2 / 4 slots per thread,
     // K = 4: 6.89 / 6.66 / 7.15, K = 8: 10.83 / 7.93 / 8.49, K = 12: 13.41 / 10.00 / 9.80; two batches side by side, K = 8: 8.82 / 7.59 / 8.12, K = 12: 11.17 /
@@ -3287,7 +3287,7 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
 }
 
 bool uniform_eligible(int count, const size_t *n, int mode) {
-    if (count < 2 || mode == FA_AHC_MODE_REFERENCE_ORDER || getenv("FA_AHC_NO_UNIFORM")) return false;
+    if (count < 2 || mode == FA_AHC_MODE_REFERENCE_ORDER || fa::sw(fa::Sw::AHC_NO_UNIFORM)) return false;
     size_t lo = SIZE_MAX, hi = 0;
     for (int k = 0; k < count; ++k) {
         if (n[k] < 2) return false;
@@ -3366,7 +3366,7 @@ fa_status run_device_batch_impl(fa_ctx *ctx, int count, const double *const *d_d
 
 constexpr size_t kUniGroupsMinN = 4096;
 int uniform_groups(int count, const size_t *n) {
-    if (const char *e = getenv("FA_AHC_UNI_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= 4) return std::min(v, count / 2 > 0 ? count / 2 : 1); }
+    if (const char *e = fa::sw(fa::Sw::AHC_UNI_GROUPS)) { const int v = atoi(e); if (v >= 1 && v <= 4) return std::min(v, count / 2 > 0 ? count / 2 : 1); }
     size_t lo = SIZE_MAX;
     for (int k = 0; k < count; ++k) lo = std::min(lo, n[k]);
     // six long recordings, or eight medium ones (chains of >= 4 096 rounds: the second stream's thread + graph capture, ~2 ms, must be worth it)
@@ -3461,7 +3461,7 @@ fa_status run_device_batch_impl(fa_ctx *ctx, int count, const double *const *d_d
     {
         // chains in flight on helper contexts (round 3) only on request since round 4: the uniform-layout batch advances the same problems by
         // ONE launch per round, on one stream — its rate does not depend on which hardware queues the process's streams landed on
-        bool large = count >= 2 && count <= kInFlightMax && getenv("FA_AHC_IN_FLIGHT") != nullptr;
+        bool large = count >= 2 && count <= kInFlightMax && fa::sw_on(fa::Sw::AHC_IN_FLIGHT);
         for (int k = 0; k < count && large; ++k) large = n[k] >= kInFlightMinN;
         if (large) return ahc_batch_in_flight(ctx, count, d_data, n, d, d_Z, mode, stats, sts);
     }

@@ -15,6 +15,19 @@
 // tie-heavy inputs without a GPU.  The heap below RESTATES the reference's binary_min_heap (fastcluster_internal.hpp:845-922: remove / replace /
 // update_geq_ / update_leq_, statement for statement with other array names): the order a heap breaks ties in IS its sequence of swaps — which
 // comparison is strict, which child wins, what moves where — so reproducing that order admits no other sequence.
+//
+// struct Heap follows fastcluster's binary_min_heap:
+//   Copyright (c) 2011 Daniel Müllner <https://danifold.net>; changes from version 1.1.24 on (c) Google Inc.  All rights reserved.
+//   Redistribution and use in source and binary forms, with or without modification, are permitted provided that the following conditions
+//   are met: redistributions of source code must retain the above copyright notice, this list of conditions and the following disclaimer;
+//   redistributions in binary form must reproduce them in the documentation and/or other materials provided with the distribution.
+//   THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS" AND ANY EXPRESS OR IMPLIED WARRANTIES, INCLUDING, BUT NOT
+//   LIMITED TO, THE IMPLIED WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A PARTICULAR PURPOSE ARE DISCLAIMED.  IN NO EVENT SHALL THE
+//   COPYRIGHT HOLDER OR CONTRIBUTORS BE LIABLE FOR ANY DIRECT, INDIRECT, INCIDENTAL, SPECIAL, EXEMPLARY, OR CONSEQUENTIAL DAMAGES (INCLUDING,
+//   BUT NOT LIMITED TO, PROCUREMENT OF SUBSTITUTE GOODS OR SERVICES; LOSS OF USE, DATA, OR PROFITS; OR BUSINESS INTERRUPTION) HOWEVER CAUSED
+//   AND ON ANY THEORY OF LIABILITY, WHETHER IN CONTRACT, STRICT LIABILITY, OR TORT (INCLUDING NEGLIGENCE OR OTHERWISE) ARISING IN ANY WAY OUT
+//   OF THE USE OF THIS SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
+// (full text: ThirdPartyLicenses/fastcluster-LICENSE.md at the repository root)
 #pragma once
 #include <cstdint>
 

@@ -841,7 +841,7 @@ fa_status fa_ctc_beam_search_batch_dev(fa_ctx *ctx, const float *d_log_probs, in
     FA_HIP_TRY(ctx, d_arena.alloc(ctx, static_cast<size_t>(per) * chunk));   // the context's buffer cache: a second call pays no hipMalloc
     a.arena = d_arena.as<unsigned long long>();
     fa::DevBuf d_prof;
-    if (getenv("FA_BEAM_PROF")) { FA_HIP_TRY(ctx, d_prof.alloc(128)); FA_HIP_TRY(ctx, hipMemsetAsync(d_prof.p, 0, 128, ctx->stream)); a.prof = d_prof.as<unsigned long long>(); }
+    if (fa::sw(fa::Sw::BEAM_PROF)) { FA_HIP_TRY(ctx, d_prof.alloc(128)); FA_HIP_TRY(ctx, hipMemsetAsync(d_prof.p, 0, 128, ctx->stream)); a.prof = d_prof.as<unsigned long long>(); }
     // the pre-pass' table of one launch: K (token, log-prob) pairs + the blank's log-prob per frame
     fa::DevBuf d_top;
     const size_t rows_max = static_cast<size_t>(chunk) * std::max(frames, 1);

@@ -47,9 +47,48 @@ size_t release_idle_device_memory(const fa_ctx *self, const int device) {
 }
 
 std::atomic<int32_t> g_fault[FA_FAULT_SITES];
+
+// The switch table: values are heap copies that are never freed (a reader may hold the pointer it loaded; fa_debug_set_switch is a test hook).
+constexpr int kSwCount = static_cast<int>(fa::Sw::kCount);
+const char *const kSwName[kSwCount] = {
+#define FA_SW_NAME(id, name) name,
+    FA_SWITCHES(FA_SW_NAME, FA_SW_NAME)
+#undef FA_SW_NAME
+};
+std::atomic<const char *> g_sw[kSwCount];
+std::once_flag g_sw_once;
+bool g_debug_hooks = false;   // FLUIDAUDIO_HIP_DEBUG_HOOKS=1 in the environment of the process: fa_debug_inject_fault / fa_debug_set_switch act
+const char *sw_copy(const char *v) {
+    if (!v) return nullptr;
+    const size_t n = strlen(v) + 1;
+    char *c = static_cast<char *>(malloc(n));
+    if (c) memcpy(c, v, n);
+    return c;
+}
+void sw_read_environment() {   // the library's only look at the environment
+    for (int i = 0; i < kSwCount; ++i) g_sw[i].store(sw_copy(getenv(kSwName[i])), std::memory_order_release);
+    const char *h = getenv("FLUIDAUDIO_HIP_DEBUG_HOOKS");
+    g_debug_hooks = h && h[0] == '1';
+}
+bool debug_hooks() {
+    std::call_once(g_sw_once, sw_read_environment);
+    return g_debug_hooks;
+}
 }  // namespace
 
 namespace fa {
+// -DFA_POISON_WORKSPACE (make POISON=1 -> libfluidaudio_hip_poison.so): everything a call is handed — the linkage workspace, cached device buffers,
+// the scratch — is filled with 0xFF first (NaN as a double, -1 as an index, a wild address as a pointer), so that code which reads bytes it
+// never wrote fails in the tests instead of working on whatever an earlier call left there (round 5 found such a read of four rounds' standing
+// only because a new path reused the bytes).  The GPU suite is run once over that build.
+static inline void poison(fa_ctx *ctx, void *p, size_t bytes) {
+#ifdef FA_POISON_WORKSPACE
+    if (p && bytes) { (void)hipMemsetAsync(p, 0xFF, bytes, ctx->stream); (void)hipStreamSynchronize(ctx->stream); }
+#else
+    (void)ctx; (void)p; (void)bytes;
+#endif
+}
+
 fa_status ws_acquire(fa_ctx *ctx, size_t bytes) {
     // The registry mutex guards the bookkeeping (who is busy, whose idle cache may be taken) — not the allocation itself: a hipMalloc of tens
     // of gigabytes takes 0.3 - 6 s, and since round 4 several host threads of one call allocate at the same time (the groups of
@@ -59,7 +98,7 @@ fa_status ws_acquire(fa_ctx *ctx, size_t bytes) {
         std::lock_guard<std::mutex> lock(g_registry_mutex);
         ctx->ws_busy = true;
         if (bytes > ctx->ws_cap) return set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: %zu bytes of workspace needed, the context's cap is %zu", bytes, ctx->ws_cap);
-        if (ctx->ahc_ws_bytes >= bytes) return FA_SUCCESS;
+        if (ctx->ahc_ws_bytes >= bytes) { poison(ctx, ctx->ahc_ws, ctx->ahc_ws_bytes); return FA_SUCCESS; }
     }
     if (ctx->ahc_ws) { FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ahc_ws); ctx->ahc_ws = nullptr; ctx->ahc_ws_bytes = 0; }
     hipError_t e = fault_hit(FA_FAULT_WS_MALLOC) ? hipErrorOutOfMemory : hipMalloc(&ctx->ahc_ws, bytes);
@@ -75,6 +114,7 @@ fa_status ws_acquire(fa_ctx *ctx, size_t bytes) {
         return set_error(ctx, FA_ALLOCATION_FAILURE, "ahc: cannot allocate %zu bytes of HBM", bytes);
     }
     ctx->ahc_ws_bytes = bytes;
+    poison(ctx, ctx->ahc_ws, bytes);
     return FA_SUCCESS;
 }
 
@@ -87,8 +127,16 @@ void ws_release(fa_ctx *ctx) {
 // ---- fault injection for the tests (fa_debug_inject_fault): the next `count` passes through a site fail
 bool fault_hit(const int site) {
     if (site < 0 || site >= FA_FAULT_SITES) return false;
-    if (g_fault[site].load(std::memory_order_relaxed) <= 0) return false;
-    return g_fault[site].fetch_sub(1, std::memory_order_relaxed) > 0;
+    int32_t have = g_fault[site].load(std::memory_order_relaxed);
+    while (have > 0)   // compare-exchange: two threads racing for the last armed pass cannot drive the counter negative
+        if (g_fault[site].compare_exchange_weak(have, have - 1, std::memory_order_relaxed)) return true;
+    return false;
+}
+
+// ---- switches (fa_common.h): the process environment, read once
+const char *sw_lookup(const Sw s) {
+    std::call_once(g_sw_once, sw_read_environment);
+    return g_sw[static_cast<int>(s)].load(std::memory_order_acquire);
 }
 
 // ---- buffer cache of a context (see fa_ctx::buf_free)
@@ -99,6 +147,7 @@ void buf_cache_flush(fa_ctx *ctx) {                               // caller hold
     ctx->buf_cached_bytes = 0;
 }
 hipError_t devbuf_take(fa_ctx *ctx, size_t bytes, void **p, size_t *cap) {
+    bool cached = false;
     {
         std::lock_guard<std::mutex> lock(ctx->buf_mutex);
         int best = -1;
@@ -110,9 +159,10 @@ hipError_t devbuf_take(fa_ctx *ctx, size_t bytes, void **p, size_t *cap) {
             *p = ctx->buf_free[best].first; *cap = ctx->buf_free[best].second;
             ctx->buf_cached_bytes -= *cap;
             ctx->buf_free.erase(ctx->buf_free.begin() + best);
-            return hipSuccess;
+            cached = true;
         }
     }
+    if (cached) { poison(ctx, *p, *cap); return hipSuccess; }
     const size_t want = (bytes + 255) & ~static_cast<size_t>(255);
     hipError_t e = fault_hit(FA_FAULT_DEVBUF_MALLOC) ? hipErrorOutOfMemory : hipMalloc(p, want);
     if (e != hipSuccess) {   // HBM pressure: every idle byte the library holds on this device goes (the caches of ALL its contexts, idle linkage workspaces)
@@ -121,6 +171,7 @@ hipError_t devbuf_take(fa_ctx *ctx, size_t bytes, void **p, size_t *cap) {
         e = hipMalloc(p, want);
     }
     *cap = want;
+    if (e == hipSuccess) poison(ctx, *p, want);
     return e;
 }
 void devbuf_give(fa_ctx *ctx, void *p, size_t cap) {
@@ -137,7 +188,7 @@ void devbuf_give(fa_ctx *ctx, void *p, size_t cap) {
 }
 
 fa_status ensure_scratch(fa_ctx *ctx, size_t bytes) {
-    if (ctx->scratch_bytes >= bytes) return FA_SUCCESS;
+    if (ctx->scratch_bytes >= bytes) { poison(ctx, ctx->scratch, ctx->scratch_bytes); return FA_SUCCESS; }
     if (ctx->scratch) {
         FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->scratch);
@@ -146,6 +197,7 @@ fa_status ensure_scratch(fa_ctx *ctx, size_t bytes) {
     }
     FA_HIP_TRY(ctx, hipMalloc(&ctx->scratch, bytes));
     ctx->scratch_bytes = bytes;
+    poison(ctx, ctx->scratch, bytes);
     return FA_SUCCESS;
 }
 }  // namespace fa
@@ -155,8 +207,27 @@ extern "C" {
 const char *fa_version(void) { return "fluidaudio_hip 0.1 gfx950"; }
 
 void fa_debug_inject_fault(int32_t site, int32_t count) {
+    if (!debug_hooks()) return;   // a process that did not ask for the hooks cannot be made to degrade by a stray call
     if (site >= 0 && site < FA_FAULT_SITES) g_fault[site].store(count < 0 ? 0 : count, std::memory_order_relaxed);
 }
+
+fa_status fa_debug_set_switch(const char *name, const char *value) {
+    if (!name) return FA_INVALID_ARGUMENT;
+    if (!debug_hooks()) return FA_RUNTIME_ERROR;
+    for (int i = 0; i < kSwCount; ++i)
+        if (strcmp(name, kSwName[i]) == 0) {
+#ifndef FA_AB_SWITCHES
+            if (fa::sw_is_ab(static_cast<fa::Sw>(i))) return FA_INVALID_ARGUMENT;   // compiled out of this build
+#endif
+            const char *c = sw_copy(value);
+            if (value && !c) return FA_ALLOCATION_FAILURE;
+            g_sw[i].store(c, std::memory_order_release);
+            return FA_SUCCESS;
+        }
+    return FA_INVALID_ARGUMENT;
+}
+
+int32_t fa_debug_hooks_enabled(void) { return debug_hooks() ? 1 : 0; }
 
 fa_status fa_ctx_create(int device, void *stream, fa_ctx **out) {
     if (!out) return FA_INVALID_ARGUMENT;
@@ -174,7 +245,7 @@ fa_status fa_ctx_create(int device, void *stream, fa_ctx **out) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return FA_RUNTIME_ERROR; }
         ctx->owns_stream = true;
     }
-    if (const char *lim = getenv("FLUIDAUDIO_HIP_WORKSPACE_LIMIT")) {
+    if (const char *lim = fa::sw(fa::Sw::HIP_WORKSPACE_LIMIT)) {
         char *end = nullptr;
         const unsigned long long v = strtoull(lim, &end, 10);
         if (end != lim) ctx->ws_limit = static_cast<size_t>(v);

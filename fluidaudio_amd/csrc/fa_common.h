@@ -112,6 +112,50 @@ inline fa_status no_throw(fa_ctx *ctx, const char *what, F &&f) noexcept {
 // Test hook (fa_debug_inject_fault, ctx.hip): true for the next `count` passes through `site`.  One relaxed atomic load when nothing is armed.
 bool fault_hit(int site);
 
+// ---- switches: every environment variable the library looks at, in ONE table (ctx.hip).  The environment is read ONCE per process (the first
+// lookup; getenv is not safe against a concurrent setenv, and several host threads of one call dispatch at the same time); afterwards a value
+// changes only through fa_debug_set_switch (tests; include/fluidaudio_hip.h documents the ROUTE switches and the hook).  A lookup is one
+// atomic pointer load.  The AB switches select kernels / parameters for A/B measurements only: without -DFA_AB_SWITCHES (the release
+// build) fa::sw() of one of them is the constant nullptr, so the code behind it is dead and dropped by the compiler.
+#define FA_SWITCHES(ROUTE, AB)                                                                                                       \
+    ROUTE(HIP_WORKSPACE_LIMIT, "FLUIDAUDIO_HIP_WORKSPACE_LIMIT") ROUTE(HIP_DEVICES, "FLUIDAUDIO_HIP_DEVICES") ROUTE(HIP_DEVICE, "FLUIDAUDIO_HIP_DEVICE") \
+    ROUTE(AHC_CPT, "FA_AHC_CPT") ROUTE(AHC_NO_SINGLE_BLOCK, "FA_AHC_NO_SINGLE_BLOCK") ROUTE(AHC_NO_UNIFORM, "FA_AHC_NO_UNIFORM")      \
+    ROUTE(AHC_RO_NO_MATRIX, "FA_AHC_RO_NO_MATRIX") ROUTE(AHC_UNI_CPT, "FA_AHC_UNI_CPT") ROUTE(AHC_UNI_GROUPS, "FA_AHC_UNI_GROUPS")    \
+    ROUTE(AHC_UNI_WAVES, "FA_AHC_UNI_WAVES") ROUTE(AHC_IN_FLIGHT, "FA_AHC_IN_FLIGHT") ROUTE(AHC_DEBUG, "FA_AHC_DEBUG")                \
+    ROUTE(MEL_GENERIC, "FA_MEL_GENERIC") ROUTE(MEL_SLICE_MB, "FA_MEL_SLICE_MB") ROUTE(VBX_NO_TILED, "FA_VBX_NO_TILED")                \
+    ROUTE(RESAMPLE_SIMPLE, "FA_RESAMPLE_SIMPLE") ROUTE(RESAMPLE_NO_DECIM, "FA_RESAMPLE_NO_DECIM")                                     \
+    ROUTE(RESAMPLE_NO_DECIM_TILES, "FA_RESAMPLE_NO_DECIM_TILES") ROUTE(RESAMPLE_NO_ROWS, "FA_RESAMPLE_NO_ROWS")                       \
+    ROUTE(RESAMPLE_NO_WIDE, "FA_RESAMPLE_NO_WIDE") ROUTE(RESAMPLE_WIDE, "FA_RESAMPLE_WIDE")                                           \
+    AB(AHC_GRAM_V1, "FA_AHC_GRAM_V1") AB(AHC_NO_MATRIX_FREE, "FA_AHC_NO_MATRIX_FREE") AB(AHC_ROM_DIRECT_START, "FA_AHC_ROM_DIRECT_START") \
+    AB(AHC_ROUND_BIG, "FA_AHC_ROUND_BIG") AB(BEAM_PROF, "FA_BEAM_PROF") AB(CENTROID_SIMPLE, "FA_CENTROID_SIMPLE")                     \
+    AB(MEL_NO_EZ, "FA_MEL_NO_EZ") AB(MEL_PRIO, "FA_MEL_PRIO") AB(MEL_PROF, "FA_MEL_PROF") AB(MEL_ROUNDS, "FA_MEL_ROUNDS")             \
+    AB(MEL_SCALAR, "FA_MEL_SCALAR") AB(MEL_V4, "FA_MEL_V4") AB(MEL_V4_DEEP, "FA_MEL_V4_DEEP") AB(MEL_V4_LDS_PAD, "FA_MEL_V4_LDS_PAD") \
+    AB(RESAMPLE_NO_INTERP, "FA_RESAMPLE_NO_INTERP") AB(RESAMPLE_ROWS_LDS_KB, "FA_RESAMPLE_ROWS_LDS_KB")                               \
+    AB(RESAMPLE_ROWS_SHARE, "FA_RESAMPLE_ROWS_SHARE") AB(RESAMPLE_WIDE_NO_ROT, "FA_RESAMPLE_WIDE_NO_ROT")                             \
+    AB(RESAMPLE_WIDE_PART, "FA_RESAMPLE_WIDE_PART")
+enum class Sw : int {
+#define FA_SW_ENUM(id, name) id,
+    FA_SWITCHES(FA_SW_ENUM, FA_SW_ENUM)
+#undef FA_SW_ENUM
+    kCount
+};
+constexpr bool sw_is_ab(const Sw s) {
+#define FA_SW_NO(id, name) if (s == Sw::id) return false;
+#define FA_SW_YES(id, name) if (s == Sw::id) return true;
+    FA_SWITCHES(FA_SW_NO, FA_SW_YES)
+#undef FA_SW_NO
+#undef FA_SW_YES
+    return false;
+}
+const char *sw_lookup(Sw s);   // ctx.hip: the value (a string that lives for the whole process) or nullptr
+__attribute__((always_inline)) inline const char *sw(const Sw s) {
+#ifndef FA_AB_SWITCHES
+    if (sw_is_ab(s)) return nullptr;
+#endif
+    return sw_lookup(s);
+}
+inline bool sw_on(const Sw s) { return sw(s) != nullptr; }
+
 // A host thread for `f`, appended to `pool`; false when none is to be had (std::system_error from the constructor, std::bad_alloc from the
 // vector, or an armed FA_FAULT_THREAD_START) — the caller then runs that share itself.  An exception escaping while `pool` holds joinable threads
 // would std::terminate the process across the C ABI.

@@ -667,7 +667,7 @@ fa_status validate(const fa_mel_config *c) {
 // configurations the tuned n_fft = 512 kernels do not cover take mel_generic_kernel
 bool needs_generic(const fa_mel_config *c) {
     return c->n_fft != kNfft || c->power == 1.0f || (c->center_pad == FA_MEL_CENTER_REFLECT && c->padding_mode == FA_MEL_PAD_CENTER) ||
-           c->tail_mode == FA_MEL_TAIL_REPLICATE || getenv("FA_MEL_GENERIC") != nullptr;
+           c->tail_mode == FA_MEL_TAIL_REPLICATE || fa::sw_on(fa::Sw::MEL_GENERIC);
 }
 
 }  // namespace
@@ -839,7 +839,7 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         }
         std::vector<float> windowz(kNfft, 0.0f);
         for (int i = 0; i < cfg->win; ++i) windowz[off + i] = hann[i];
-        p->edge_zero = getenv("FA_MEL_NO_EZ") == nullptr;
+        p->edge_zero = !fa::sw_on(fa::Sw::MEL_NO_EZ);
         for (int i = 0; i < 32; ++i) if (windowz[i] != 0.0f || windowz[kNfft - 32 + i] != 0.0f) p->edge_zero = false;
         std::vector<float2> tw256(256), tw512(129);
         for (int k = 0; k < 256; ++k) { const double a = -2.0 * M_PI * k / 256.0; tw256[k] = make_float2((float)cos(a), (float)sin(a)); }
@@ -923,24 +923,24 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         a.log_floor = cfg->log_floor;
         a.floor_clamped = cfg->floor_mode == FA_MEL_FLOOR_CLAMPED;
         a.prio_lo = 0; a.prio_hi = 3; a.prio_pw = 1; a.prio_rd = 2;   // measured best of the sweep in DESIGN.md §3.1
-        if (const char *pe = getenv("FA_MEL_PRIO")) {   // diagnostics
+        if (const char *pe = fa::sw(fa::Sw::MEL_PRIO)) {   // diagnostics
             int v4[4] = {0, 3, 1, 2};
             const int got = sscanf(pe, "%d,%d,%d,%d", &v4[0], &v4[1], &v4[2], &v4[3]);
             if (got == 2) { v4[2] = v4[0]; v4[3] = v4[1]; }
             if (got >= 2) { a.prio_lo = v4[0] & 3; a.prio_hi = v4[1] & 3; a.prio_pw = v4[2] & 3; a.prio_rd = v4[3] & 3; }
         }
-        p->pk = fast && cfg->hop == kPkHop && getenv("FA_MEL_SCALAR") == nullptr;   // FA_MEL_SCALAR: diagnostics, one frame per lane
+        p->pk = fast && cfg->hop == kPkHop && !fa::sw_on(fa::Sw::MEL_SCALAR);   // FA_MEL_SCALAR: diagnostics, one frame per lane
         if (p->pk && cfg->n_mels == kFastGroups * kGroup) {   // FA_MEL_V4=0: the v3 kernel (diagnostics); FA_MEL_V4=4: four workgroups per CU
-            const char *ve = getenv("FA_MEL_V4");
+            const char *ve = fa::sw(fa::Sw::MEL_V4);
             p->v4_wps = ve ? atoi(ve) : 3;
             if (p->v4_wps != 3) p->v4_wps = 0;
-            if (const char *de = getenv("FA_MEL_V4_DEEP")) p->v4_deep = atoi(de) != 0;
+            if (const char *de = fa::sw(fa::Sw::MEL_V4_DEEP)) p->v4_deep = atoi(de) != 0;
         }
         p->lds_bytes = sizeof(float) * (a.stage_alloc + kRegions * (p->pk ? kRegionFloatsPk : kRegionFloats) + a.out_alloc) + sizeof(int32_t) * kMaxMels +
                        sizeof(float) * (static_cast<size_t>(a.n_weights) + 24 + 4 + (p->pk ? fa::melpk::kWindowTableFloats : 0));   // the paired weight reads of the packed kernel touch one slot row past the table
         if (p->v4_wps) {
             p->lds_bytes = kV4LdsBytes;
-            if (const char *pe = getenv("FA_MEL_V4_LDS_PAD")) p->lds_bytes += static_cast<size_t>(atoi(pe));   // diagnostics: fewer resident workgroups per CU
+            if (const char *pe = fa::sw(fa::Sw::MEL_V4_LDS_PAD)) p->lds_bytes += static_cast<size_t>(atoi(pe));   // diagnostics: fewer resident workgroups per CU
         }
         if (p->lds_bytes > 160 * 1024) { (void)hipFree(p->dev); delete p; return fa::set_error(ctx, FA_INVALID_ARGUMENT, "mel: hop too large for LDS staging"); }
         if (p->lds_bytes > 64 * 1024) {
@@ -963,7 +963,7 @@ fa_status fa_mel_plan_create(fa_ctx *ctx, const fa_mel_config *cfg, const int64_
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, ctx->device);
         const int cus = e == hipSuccess ? prop.multiProcessorCount : 256;
-        const char *rounds_env = getenv("FA_MEL_ROUNDS");  // diagnostics
+        const char *rounds_env = fa::sw(fa::Sw::MEL_ROUNDS);  // diagnostics
         // Equal-length batches: one persistent round (the per-workgroup prologue — tables, lane constants — is paid once:
         // 0.663 vs 0.685 ms with four rounds on the bench workload).  Ragged batches keep four rounds, so that the hardware
         // scheduler evens out ranges that hold many empty tiles of short utterances.
@@ -1010,7 +1010,7 @@ fa_status fa_mel_execute_dev(fa_mel_plan *p, const float *d_pcm, const float *d_
     static unsigned long long s_last_span[4] = {0, 0, 0, 0};
     static std::mutex s_prof_mutex;   // the diagnostics state is process-wide; entries of different contexts may run concurrently
     std::unique_lock<std::mutex> prof_lock(s_prof_mutex, std::defer_lock);
-    if (getenv("FA_MEL_PROF")) {  // diagnostics only: per-phase cycles of one workgroup, printed every 10 launches
+    if (fa::sw(fa::Sw::MEL_PROF)) {  // diagnostics only: per-phase cycles of one workgroup, printed every 10 launches
         prof_lock.lock();
         if (!s_prof) { (void)hipMalloc(&s_prof, 128 + 4 * 8192); (void)hipMemset(s_prof, 0, 128 + 4 * 8192); }
         a.prof = s_prof;
@@ -1181,7 +1181,7 @@ fa_status fa_mel_batch(fa_ctx *ctx, const fa_mel_config *cfg, const float *pcm, 
         return at.type == hipMemoryTypeHost;
     };
     int64_t slice_bytes = pinned(pcm) && pinned(mel) ? (64ll << 20) : (1ll << 62);
-    if (const char *se = getenv("FA_MEL_SLICE_MB")) { const long v = atol(se); slice_bytes = v > 0 ? v * (1ll << 20) : (1ll << 62); }   // diagnostics / tests; 0 = one slice
+    if (const char *se = fa::sw(fa::Sw::MEL_SLICE_MB)) { const long v = atol(se); slice_bytes = v > 0 ? v * (1ll << 20) : (1ll << 62); }   // diagnostics / tests; 0 = one slice
     // slices: consecutive utterances up to slice_bytes of samples or of output, whichever is reached first
     std::vector<int32_t> first{0};
     for (int32_t b = 0; b < batch; ++b) {

@@ -174,10 +174,13 @@ struct ClusterJob {
             std::vector<double> elbos(static_cast<size_t>(std::max(config->max_vbx_iterations, 1)));
             const fa_status vbx_st = fa::vbx_run_dev(ctx, d_trho, nt, rho_dim, b_lab.as<int32_t>(), S, phi, config->warm_start_fa, config->warm_start_fb,
                                                      config->max_vbx_iterations, config->convergence_tolerance, elbos.data(), &vbx_iters, vbx);
+            if (vbx_st == FA_ALLOCATION_FAILURE || vbx_st == FA_INVALID_ARGUMENT) return vbx_st;   // not what the reference's catch covers (see fa_vbx_refine)
             if (vbx_st != FA_SUCCESS) {   // VBxClustering.refine's catch block (VBxClustering.swift:136-141): gamma = one-hot AHC labels, pi = 1/S, no ELBOs — and on
+                const std::string why = ctx->last_error;
                 vbx_iters = 0;
                 vbx_degraded = true;
                 FA_TRY(fa::vbx_degrade_dev(ctx, nt, S, b_lab.as<int32_t>(), vbx));
+                fa::set_error(ctx, FA_SUCCESS, "offline cluster: VBx degraded to the AHC clusters (%s)", why.c_str());   // a SUCCESS return does not leave a failure text behind
             }
             pi.resize(S);
             FA_HIP_TRY(ctx, hipMemcpyAsync(pi.data(), vbx.pi.p, sizeof(double) * S, hipMemcpyDeviceToHost, st));

@@ -112,9 +112,9 @@ fa_status default_pool(fa_pool **out) {
     std::lock_guard<std::mutex> lock(g_default_pool_mutex);
     if (!g_default_pool) {
         std::vector<int> devs;
-        if (!parse_device_list(getenv("FLUIDAUDIO_HIP_DEVICES"), devs)) {
+        if (!parse_device_list(fa::sw(fa::Sw::HIP_DEVICES), devs)) {
             devs.clear();
-            if (const char *one = getenv("FLUIDAUDIO_HIP_DEVICE")) devs.push_back(atoi(one));   // the round-1 variable: one device
+            if (const char *one = fa::sw(fa::Sw::HIP_DEVICE)) devs.push_back(atoi(one));   // the round-1 variable: one device
         }
         const fa_status st = fa_pool_create(devs.empty() ? nullptr : devs.data(), static_cast<int32_t>(devs.size()), &g_default_pool);
         if (st != FA_SUCCESS) return st;

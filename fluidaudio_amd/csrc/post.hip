@@ -403,7 +403,7 @@ fa_status fa_constrained_assign(fa_ctx *ctx, const double *scores, int64_t n, in
 fa_status fa::centroids_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_gamma, int32_t S, const int32_t *d_spk, int32_t K,
                             double *d_cent) {
     if (K <= 0) return FA_SUCCESS;
-    if (n >= 4 * kCenTile && getenv("FA_CENTROID_SIMPLE") == nullptr) {
+    if (n >= 4 * kCenTile && !fa::sw_on(fa::Sw::CENTROID_SIMPLE)) {
         const size_t lds = sizeof(double) * (2 * kCenTile * 64 + 2 * kCenTile);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(centroid_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         hipLaunchKernelGGL(centroid_tiled_kernel, dim3((d + 63) / 64, K), dim3(256), lds, ctx->stream, d_emb, d_gamma, d_spk, d_cent, n, d, S, K);

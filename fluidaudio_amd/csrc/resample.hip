@@ -744,13 +744,13 @@ bool wide_instance(int rows, int waves, int nv, int share, int ch);
 // Geometry + tables (resample_geom.h); false when the pair does not suit the kernel (then poly_lds_kernel serves it).
 bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down, int64_t pre_remove, std::vector<int> &gtab, std::vector<float> &tt) {
     size_t budget = 0;                                                  // automatic (resample_geom.h); FA_RESAMPLE_ROWS_LDS_KB: measurements (r04_rows_lds_probe.json)
-    if (const char *e = getenv("FA_RESAMPLE_ROWS_LDS_KB")) { const int v = atoi(e); if (v >= 16 && v <= 150) budget = static_cast<size_t>(v) * 1024; }
+    if (const char *e = fa::sw(fa::Sw::RESAMPLE_ROWS_LDS_KB)) { const int v = atoi(e); if (v >= 16 && v <= 150) budget = static_cast<size_t>(v) * 1024; }
     int share_max = 4;                                                  // FA_RESAMPLE_ROWS_SHARE = 1 | 2 | 4: measurements (1 = every phase its own window, round 4's reads)
-    if (const char *e = getenv("FA_RESAMPLE_ROWS_SHARE")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) share_max = v; }
+    if (const char *e = fa::sw(fa::Sw::RESAMPLE_ROWS_SHARE)) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) share_max = v; }
     // the persistent kernel with two buffers (FA_RESAMPLE_NO_WIDE=1: the one-tile-per-workgroup kernel): one phase group — an unbounded LDS budget keeps
     // rows_geometry from splitting —, rows of at most 512 floats, and one of the instantiated (window, sharing, units per wavefront) combinations
     R.wide = false;
-    if (budget == 0 && getenv("FA_RESAMPLE_NO_WIDE") == nullptr) {
+    if (budget == 0 && !fa::sw_on(fa::Sw::RESAMPLE_NO_WIDE)) {
         // candidates, in order: {rows, wavefronts, LDS budget of rows_geometry (per 64 rows: it decides the phase groups)}.  FA_RESAMPLE_WIDE = "rows:waves" picks
         // one.  Measured per audio hour (profiles/r05_resample_wide_steps.json): 16-row tiles, 8 wavefronts, two workgroups per CU — 44.1 kHz 233 - 250 us,
         // 22.05 kHz 128, 11.025 kHz 116; 32-row tiles with one workgroup per CU 243 - 262 / 152 / (no instance); 32-row tiles of one phase GROUP (80 k phases:
@@ -759,9 +759,11 @@ bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down,
         struct Cand { int rows, waves; size_t budget; };
         const size_t group_budget = size_t{64} * 288 * 4;      // (rows_geometry budgets 64 rows)
         std::vector<Cand> cands = {{16, 8, size_t{1} << 30}, {32, 10, group_budget}, {32, 8, size_t{1} << 30}};
-        if (const char *e = getenv("FA_RESAMPLE_WIDE")) {
+        if (const char *e = fa::sw(fa::Sw::RESAMPLE_WIDE)) {
             int r_ = 0, w_ = 0;
-            if (sscanf(e, "%d:%d", &r_, &w_) == 2) cands = {{r_, w_, r_ == 32 && w_ == 10 ? group_budget : size_t{1} << 30}};
+            // only the instantiated forms: any other pair would reach the geometry arithmetic below (rows 0: a division by zero)
+            if (sscanf(e, "%d:%d", &r_, &w_) == 2 && (r_ == 16 || r_ == 32) && (w_ == 8 || w_ == 10))
+                cands = {{r_, w_, r_ == 32 && w_ == 10 ? group_budget : size_t{1} << 30}};
         }
         for (const Cand &c : cands) {
             PolyRowsGeom g2{};
@@ -776,8 +778,8 @@ bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down,
             if (!wide_instance(c.rows, c.waves, nv2, g2.share, ch)) continue;
             R.g = g2; R.nv = nv2; R.ch = ch; R.wide_rows = c.rows; R.wide_waves = c.waves; gtab.swap(gtab2); tt.swap(tt2);
             R.wide = true;
-            if (const char *e = getenv("FA_RESAMPLE_WIDE_PART")) R.wide_part = atoi(e);
-            R.wide_no_rot = getenv("FA_RESAMPLE_WIDE_NO_ROT") != nullptr;
+            if (const char *e = fa::sw(fa::Sw::RESAMPLE_WIDE_PART)) R.wide_part = atoi(e);
+            R.wide_no_rot = fa::sw_on(fa::Sw::RESAMPLE_WIDE_NO_ROT);
             R.lds = 0; R.up = up; R.down = down;     // (static LDS)
             return true;
         }
@@ -992,8 +994,8 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
         // the kernel-choice switches of the tests and probes, read ONCE per call, here (the forms fixed with a context's tables — FA_RESAMPLE_WIDE*, _ROWS_* —
         // are read when the tables are built)
         struct { bool simple, no_decim, no_decim_tiles, no_interp, no_rows; } const sw = {
-            getenv("FA_RESAMPLE_SIMPLE") != nullptr, getenv("FA_RESAMPLE_NO_DECIM") != nullptr, getenv("FA_RESAMPLE_NO_DECIM_TILES") != nullptr,
-            getenv("FA_RESAMPLE_NO_INTERP") != nullptr, getenv("FA_RESAMPLE_NO_ROWS") != nullptr};
+            fa::sw_on(fa::Sw::RESAMPLE_SIMPLE), fa::sw_on(fa::Sw::RESAMPLE_NO_DECIM), fa::sw_on(fa::Sw::RESAMPLE_NO_DECIM_TILES),
+            fa::sw_on(fa::Sw::RESAMPLE_NO_INTERP), fa::sw_on(fa::Sw::RESAMPLE_NO_ROWS)};
         const bool simple = sw.simple;
         auto edges = [&](const int64_t m_lo, const int64_t m_hi) {   // outputs [m_lo, m_hi) by the one-thread-per-output kernel (clamps at the signal's ends)
             if (m_hi <= m_lo) return;

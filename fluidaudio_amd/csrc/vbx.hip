@@ -405,7 +405,11 @@ fa_status fa_vbx_refine(fa_ctx *ctx, const double *rho, int64_t T, int32_t D, co
         FA_HIP_TRY(ctx, hipMemcpyAsync(blab.p, initial, 4 * T, hipMemcpyHostToDevice, st));
         fa::VbxDevice dev;
         const fa_status run = fa::vbx_run_dev(ctx, bX.as<double>(), T, D, blab.as<int32_t>(), S, phi, Fa, Fb, max_iter, epsilon, elbos, n_iters, dev);
-        if (run != FA_SUCCESS) {   // VBxClustering.refine's catch block (:136-141): the refinement degrades to its start, it does not fail
+        // VBxClustering.refine's catch block (:136-141) covers what runVBx THROWS — an argument its BLAS calls refuse: the refinement degrades to
+        // its start, it does not fail.  That is the RUNTIME_ERROR class here (a failing launch, the injected fault).  An allocation failure (a
+        // retry may succeed; Swift would not have caught it either) and a refused argument are the caller's to see.
+        if (run == FA_ALLOCATION_FAILURE || run == FA_INVALID_ARGUMENT) return run;
+        if (run != FA_SUCCESS) {
             const std::string why = ctx->last_error;
             *n_iters = 0;          // elboHistory = []
             FA_TRY(fa::vbx_degrade_dev(ctx, T, S, blab.as<int32_t>(), dev));
@@ -452,7 +456,7 @@ fa_status vbx_setup(fa_ctx *ctx, const double *d_X, int64_t T, int64_t Tg, int64
     w.rec_in = o.part.as<double>(); w.rec_out = o.part.as<double>() + static_cast<int64_t>(z_lo) * stride;
     w.alpha = o.alpha.as<double>(); w.invL = o.invL.as<double>(); w.phiT = o.phiT.as<double>(); w.llrow = o.ll.as<double>();
     w.scal = o.scal.as<double>(); w.T = T; w.Tg = Tg; w.t0g = t0g; w.stride = stride; w.D = D; w.S = S; w.z_lo = z_lo; w.z_n = z_n; w.Fa = Fa; w.Fb = Fb;
-    w.tiled = getenv("FA_VBX_NO_TILED") == nullptr ? 1 : 0;   // once per refinement: not inside the iteration (several host threads run refinements at once)
+    w.tiled = !fa::sw_on(fa::Sw::VBX_NO_TILED) ? 1 : 0;   // once per refinement: not inside the iteration (several host threads run refinements at once)
     if (static_cast<size_t>(8) * 4 * D > 64 * 1024) return fa::set_error(ctx, FA_INVALID_ARGUMENT, "vbx: feature dimension too large");
     if (T > 0) {
         const int wave_blocks = static_cast<int>((T + 3) / 4);

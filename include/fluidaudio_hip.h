@@ -75,8 +75,29 @@ const char *fa_ctx_last_error(const fa_ctx *ctx);
 /* Library build identification, e.g. "fluidaudio_hip 0.1 gfx950". */
 const char *fa_version(void);
 
+/* Environment.  The library reads the process environment ONCE (at the first context or switch lookup) and never again:
+ *   FLUIDAUDIO_HIP_DEVICES / FLUIDAUDIO_HIP_DEVICE   device set behind the context-free drop-in symbol (fa_pool, below)
+ *   FLUIDAUDIO_HIP_WORKSPACE_LIMIT                   default of fa_ctx_set_workspace_limit, bytes
+ *   FLUIDAUDIO_HIP_DEBUG_HOOKS=1                     lets fa_debug_inject_fault / fa_debug_set_switch act (tests); without it both are inert
+ * ROUTE switches — each forces one of the routes the dispatch chooses between by problem shape, so that every route can be tested on any
+ * input; results are identical on every route (that is what the tests check), only the speed differs:
+ *   FA_AHC_CPT=1|2|4, FA_AHC_UNI_CPT=1|2|4   slots per thread of the round kernel (single problem / uniform batch)
+ *   FA_AHC_NO_SINGLE_BLOCK                   problems of <= 512 points through the multi-block chain
+ *   FA_AHC_NO_UNIFORM, FA_AHC_IN_FLIGHT, FA_AHC_UNI_GROUPS=1..4, FA_AHC_UNI_WAVES=6|8   how a batch of problems is laid over launches / streams
+ *   FA_AHC_RO_NO_MATRIX                      the reference-order run without the N x N filter matrix (O(N d) memory, like the reference)
+ *   FA_AHC_DEBUG                             one line of statistics per linkage call on stderr
+ *   FA_MEL_GENERIC, FA_MEL_SLICE_MB=n        the generic mel kernel; slice size of host-pointer batches
+ *   FA_VBX_NO_TILED                          the untiled VBx iteration
+ *   FA_RESAMPLE_SIMPLE, _NO_DECIM, _NO_DECIM_TILES, _NO_ROWS, _NO_WIDE, FA_RESAMPLE_WIDE=rows:waves (16:8, 16:10, 32:8, 32:10)   polyphase kernel family
+ * Switches that only select kernels / parameters for A/B measurements (fa_common.h, FA_SWITCHES' AB list) exist in builds made with
+ * -DFA_AB_SWITCHES only.
+ * fa_debug_set_switch(name, value): value NULL = unset.  Changes what the NEXT calls see (process-wide; not for use while calls are in flight
+ * on other threads).  RUNTIME_ERROR without FLUIDAUDIO_HIP_DEBUG_HOOKS=1, INVALID_ARGUMENT for an unknown name. */
+fa_status fa_debug_set_switch(const char *name, const char *value);
+int32_t fa_debug_hooks_enabled(void);
 /* Test hook: the next `count` passes through `site` fail the way the real failure would (count 0 disarms).  Process-wide; one relaxed
- * atomic load on the paths that carry a site.  Used by the fault-injection tests of the degrade contracts:
+ * atomic load on the paths that carry a site.  Inert unless the process was started with FLUIDAUDIO_HIP_DEBUG_HOOKS=1.  Used by the
+ * fault-injection tests of the degrade contracts:
  *   FA_FAULT_VBX            fa::vbx_run_dev returns RUNTIME_ERROR  -> VBxClustering.refine's catch block (VBxClustering.swift:136-141)
  *   FA_FAULT_THREAD_START   no host thread to be had (std::system_error) -> the share runs on the calling thread
  *   FA_FAULT_DEVBUF_MALLOC  the first hipMalloc of a cached-buffer request fails -> idle caches of the device released, retried

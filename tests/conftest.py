@@ -9,6 +9,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 REFERENCE = "/root/reference"
+# The library reads its environment ONCE, when it is first used; this asks it to let the test hooks act (fa_debug_inject_fault,
+# fa_debug_set_switch: include/fluidaudio_hip.h).  Child processes the tests start (the C hosts) inherit it.
+os.environ["FLUIDAUDIO_HIP_DEBUG_HOOKS"] = "1"
 
 
 def pytest_configure(config):
@@ -29,6 +32,21 @@ def fa():
     if not os.path.exists(fluidaudio_amd._lib.LIB_PATH):
         fluidaudio_amd.build()
     return fluidaudio_amd
+
+
+@pytest.fixture
+def switch(fa):
+    """switch(name, value): force one route of the dispatch for the rest of the test (fa_debug_set_switch — the library does not look at the
+    environment after start-up); what a test set is unset again afterwards."""
+    touched = []
+
+    def set_switch(name, value="1"):
+        st = fa.lib().fa_debug_set_switch(name.encode(), None if value is None else str(value).encode())
+        assert st == 0, f"fa_debug_set_switch({name}) -> {st}"
+        touched.append(name)
+    yield set_switch
+    for name in touched:
+        fa.lib().fa_debug_set_switch(name.encode(), None)
 
 
 @pytest.fixture(scope="session")

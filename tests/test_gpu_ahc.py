@@ -311,7 +311,7 @@ def test_more_than_65536_points_takes_the_many_record_path(fa, gpu_ctx):
     torch.cuda.empty_cache()
 
 
-def test_batch_of_large_problems_three_ways(fa, gpu_ctx, monkeypatch):
+def test_batch_of_large_problems_three_ways(fa, gpu_ctx, switch):
     """fa_ahc_linkage_batch with 2 .. 4 problems of >= 16 384 points: by default ONE launch per round advances all of them (uniform layout,
     ahc_round_uni; round 4); FA_AHC_IN_FLIGHT=1 runs each merge chain on its own helper context concurrently (round 3), FA_AHC_NO_UNIFORM=1 the
     round-2 batched chain.  Every dendrogram of every form equals the single-problem call bit for bit; helper workspaces count towards
@@ -329,14 +329,14 @@ def test_batch_of_large_problems_three_ways(fa, gpu_ctx, monkeypatch):
     one = 18176 * 18176 * 8
     assert gpu_ctx.workspace_bytes() > 3 * one             # three workspaces of the largest problem's layout, one allocation
     gpu_ctx.trim()
-    monkeypatch.setenv("FA_AHC_IN_FLIGHT", "1")
+    switch("FA_AHC_IN_FLIGHT", "1")
     st1, zs1 = fa.linkage_batch(probs, ctx=gpu_ctx)
     assert list(st1) == [0, 0, 0]
     for z, zr in zip(zs1, singles):
         np.testing.assert_array_equal(z, zr)
     assert gpu_ctx.workspace_bytes() > 2.5 * 17000 * 17000 * 8   # the context's and two helpers'
-    monkeypatch.delenv("FA_AHC_IN_FLIGHT")
-    monkeypatch.setenv("FA_AHC_NO_UNIFORM", "1")
+    switch("FA_AHC_IN_FLIGHT", None)
+    switch("FA_AHC_NO_UNIFORM", "1")
     st2, zs2 = fa.linkage_batch(probs, ctx=gpu_ctx)
     for z, zr in zip(zs2, singles):
         np.testing.assert_array_equal(z, zr)
@@ -347,12 +347,12 @@ def test_batch_of_large_problems_three_ways(fa, gpu_ctx, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("waves", ["", "6", "8"])
-def test_uniform_batch_equals_reference_build(fa, gpu_ctx, oracle_mod, monkeypatch, waves):
+def test_uniform_batch_equals_reference_build(fa, gpu_ctx, oracle_mod, switch, waves):
     """The uniform-layout batch (every problem in the layout of the largest, one launch per round, problem = workgroup id y): ragged sizes
     within a factor of two, both distributions, a NaN problem that fails alone, a problem with exact ties at the minimum that is recomputed in
     reference order — per problem the reference build's dendrogram bit for bit, at each of the kernel's three register budgets."""
     if waves:
-        monkeypatch.setenv("FA_AHC_UNI_WAVES", waves)
+        switch("FA_AHC_UNI_WAVES", waves)
     rng = np.random.default_rng(11)
     tied = speaker_mixture(1400, 64, 6, 0.05, 21).copy()
     tied[700:1400] = tied[0:700]                            # every row twice: exact ties at every minimum
@@ -382,7 +382,7 @@ def test_uniform_batch_equals_reference_build(fa, gpu_ctx, oracle_mod, monkeypat
     np.testing.assert_array_equal(zs[1], z1)
 
 
-def test_uniform_batches_side_by_side_equal_single_calls(fa, gpu_ctx, monkeypatch):
+def test_uniform_batches_side_by_side_equal_single_calls(fa, gpu_ctx, switch):
     """Six or more large recordings: two uniform batches on two streams (the caller's context and a helper context) fill each other's latency
     (ahc_batch_uniform_groups; FA_AHC_UNI_GROUPS picks 1 .. 4 groups).  Every dendrogram equals the single call at every group count, the statistics
     are those of the problem's own group, and a cap that leaves no room for the groups' workspaces still ends in the right dendrograms."""
@@ -393,9 +393,9 @@ def test_uniform_batches_side_by_side_equal_single_calls(fa, gpu_ctx, monkeypatc
     gpu_ctx.trim()
     for groups in (None, "1", "2", "3"):
         if groups is None:
-            monkeypatch.delenv("FA_AHC_UNI_GROUPS", raising=False)
+            switch("FA_AHC_UNI_GROUPS", None)
         else:
-            monkeypatch.setenv("FA_AHC_UNI_GROUPS", groups)
+            switch("FA_AHC_UNI_GROUPS", groups)
         st, zs, stats = fa.linkage_batch(probs, ctx=gpu_ctx, return_stats=True)
         assert list(st) == [0] * 6, (groups, st)
         for z, zr, s in zip(zs, singles, stats):
@@ -404,7 +404,7 @@ def test_uniform_batches_side_by_side_equal_single_calls(fa, gpu_ctx, monkeypatc
     # a recording with exact ties inside the SECOND group (it runs on the helper context): recomputed there in reference order, the others untouched
     tied = probs[4].copy()
     tied[8000:16000] = tied[0:8000]
-    monkeypatch.setenv("FA_AHC_UNI_GROUPS", "2")
+    switch("FA_AHC_UNI_GROUPS", "2")
     st, zs, stats = fa.linkage_batch(probs[:4] + [tied] + probs[5:], ctx=gpu_ctx, return_stats=True)
     assert list(st) == [0] * 6 and stats[4]["reference_order"] == 1 and stats[3]["reference_order"] == 0
     st1, z1 = fa.linkage(tied, ctx=gpu_ctx)
@@ -454,7 +454,7 @@ def test_random_batches_through_whichever_path_serves_them(fa, gpu_ctx, oracle_m
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cpt", ["1", "2", "4"])
-def test_slots_per_thread_forms_equal_reference_build(fa, gpu_ctx, oracle_mod, monkeypatch, cpt):
+def test_slots_per_thread_forms_equal_reference_build(fa, gpu_ctx, oracle_mod, switch, cpt):
     """Round 5: a thread of the round kernel may own 1, 2 or 4 consecutive slots (ahc_round_body's CPT; a block record then covers 256 x CPT slots).
     Which form serves a call is a matter of speed (one slot per thread for a chain of its own, two where a launch holds many workgroups or where
     that makes a short recording one block); every form must give the reference build's dendrogram bit for bit — single problems through the
@@ -465,11 +465,11 @@ def test_slots_per_thread_forms_equal_reference_build(fa, gpu_ctx, oracle_mod, m
     dup = oracle_mod.ahc_normalize(rng.standard_normal((400, 8)))
     dup = np.concatenate([dup, dup[:150]])                     # exact ties at the minimum
     for single_block in (True, False):
-        monkeypatch.setenv("FA_AHC_CPT", cpt)
+        switch("FA_AHC_CPT", cpt)
         if single_block:
-            monkeypatch.delenv("FA_AHC_NO_SINGLE_BLOCK", raising=False)
+            switch("FA_AHC_NO_SINGLE_BLOCK", None)
         else:
-            monkeypatch.setenv("FA_AHC_NO_SINGLE_BLOCK", "1")
+            switch("FA_AHC_NO_SINGLE_BLOCK", "1")
         for mode in (fa.AHC_MODE_AUTO, fa.AHC_MODE_EXACT):
             for x in cases:
                 st, z = fa.linkage(x, ctx=gpu_ctx, mode=mode)
@@ -482,9 +482,9 @@ def test_slots_per_thread_forms_equal_reference_build(fa, gpu_ctx, oracle_mod, m
         bad = cases[4].copy()
         bad[300, 5] = np.nan
         assert fa.linkage(bad, ctx=gpu_ctx)[0] == 5
-    monkeypatch.delenv("FA_AHC_CPT")
-    monkeypatch.delenv("FA_AHC_NO_SINGLE_BLOCK", raising=False)
-    monkeypatch.setenv("FA_AHC_UNI_CPT", cpt)
+    switch("FA_AHC_CPT", None)
+    switch("FA_AHC_NO_SINGLE_BLOCK", None)
+    switch("FA_AHC_UNI_CPT", cpt)
     base = cases[-1]
     tied = base[:2000].copy()
     tied[1000:2000] = tied[0:1000]

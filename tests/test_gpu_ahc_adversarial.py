@@ -360,7 +360,7 @@ def test_batch_with_tied_and_tie_free_problems(fa, gpu_ctx, oracle_mod):
 @pytest.mark.parametrize("form", ["matrix-filter", "matrix-free"])
 @pytest.mark.parametrize("n,d,kind", [(2, 3, "iid"), (3, 2, "iid"), (40, 4, "equal"), (300, 5, "grid"), (600, 16, "equal"), (900, 300, "unit"), (1500, 8, "grid"),
                                       (2000, 64, "dup90"), (2500, 256, "dup30"), (3000, 256, "unit"), (3000, 48, "lattice")])
-def test_both_reference_order_forms_equal_the_reference(fa, gpu_ctx, oracle_mod, monkeypatch, n, d, kind, form):
+def test_both_reference_order_forms_equal_the_reference(fa, gpu_ctx, oracle_mod, switch, n, d, kind, form):
     """FA_AHC_MODE_REFERENCE_ORDER through the matrix filter (round 5: rom_scan / rom_select — Lance-Williams candidates, exact sums of the few, the
     key-carrying block heap) and matrix-free (FA_AHC_RO_NO_MATRIX: O(A d) sums per row, the restated heap): the reference build's dendrogram row for
     row.  "equal" overflows the candidate list of one wavefront (ROM_EXACT rows), d = 300 takes two staging passes per candidate, d = 5 / 8
@@ -382,7 +382,7 @@ def test_both_reference_order_forms_equal_the_reference(fa, gpu_ctx, oracle_mod,
         x[:, :3] = np.stack(np.meshgrid(np.arange(15.0), np.arange(20.0), np.arange(10.0)), -1).reshape(-1, 3)[rng.permutation(3000)[:n]]
     x = np.ascontiguousarray(x)
     if form == "matrix-free":
-        monkeypatch.setenv("FA_AHC_RO_NO_MATRIX", "1")
+        switch("FA_AHC_RO_NO_MATRIX", "1")
     sr, zr = oracle_mod.linkage_ref(x)
     st, z, stats = fa.linkage(x, mode=fa.AHC_MODE_REFERENCE_ORDER, ctx=gpu_ctx, return_stats=True)
     assert st == sr == 0, gpu_ctx.last_error()

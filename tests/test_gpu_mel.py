@@ -365,7 +365,7 @@ def test_other_fft_sizes_vs_oracle_and_float64(fa, gpu_ctx, oracle_mod, n_fft, w
         close(got.reshape(nf, n_mels)[:ml], ref[:ml], f"n_fft {n_fft} prepadded")
 
 
-def test_generic_kernel_equals_tuned_kernels(fa, gpu_ctx, oracle_mod, monkeypatch):
+def test_generic_kernel_equals_tuned_kernels(fa, gpu_ctx, oracle_mod, switch):
     """FA_MEL_GENERIC=1 routes the NeMo configuration (n_fft 512) through mel_generic_kernel: the two independent device
     implementations (radix-2 Stockham vs radix-16 packed) agree within the fp32 tolerance and both pass the float64 gate."""
     lens = [16000, 12370, 1, 0, 52000, 4801]
@@ -373,10 +373,10 @@ def test_generic_kernel_equals_tuned_kernels(fa, gpu_ctx, oracle_mod, monkeypatc
     outs = []
     for generic in (False, True):
         if generic:
-            monkeypatch.setenv("FA_MEL_GENERIC", "1")
+            switch("FA_MEL_GENERIC", "1")
         mel = fa.AudioMelSpectrogram(ctx=gpu_ctx)
         outs.append([mel.compute_flat(a, last_audio_sample=0.2) for a in audios])
-    monkeypatch.delenv("FA_MEL_GENERIC")
+    switch("FA_MEL_GENERIC", None)
     for a, (m0, l0, n0), (m1, l1, n1) in zip(audios, outs[0], outs[1]):
         assert (l0, n0) == (l1, n1)
         if l0:
@@ -384,7 +384,7 @@ def test_generic_kernel_equals_tuned_kernels(fa, gpu_ctx, oracle_mod, monkeypatc
             close64(oracle_mod, m1.reshape(128, n1)[:, :l1].T, a, "generic kernel", last=0.2)
 
 
-def test_host_pointer_entry_pipelined_slices_equal_one_slice(fa, gpu_ctx, monkeypatch):
+def test_host_pointer_entry_pipelined_slices_equal_one_slice(fa, gpu_ctx, switch):
     """fa_mel_batch cuts large batches into slices (upload of slice k+1 overlaps the download of slice k on a helper thread):
     forced 1 MB slices over a ragged batch give byte-identical output and lengths to the single-slice path."""
     import ctypes as C
@@ -398,13 +398,13 @@ def test_host_pointer_entry_pipelined_slices_equal_one_slice(fa, gpu_ctx, monkey
     stride = 1501
     outs = []
     for mb in ("0", "1"):
-        monkeypatch.setenv("FA_MEL_SLICE_MB", mb)
+        switch("FA_MEL_SLICE_MB", mb)
         mel = np.full((len(lens), 128, stride), 9.0, np.float32)
         ln = np.zeros(len(lens), np.int32)
         gpu_ctx.check(fa.lib().fa_mel_batch(gpu_ctx.handle, C.byref(cfg), pcm.ctypes.data, offs.ctypes.data, len(lens), lasts.ctypes.data, None, stride,
                                             mel.ctypes.data, ln.ctypes.data), "fa_mel_batch")
         outs.append((mel, ln))
-    monkeypatch.delenv("FA_MEL_SLICE_MB")
+    switch("FA_MEL_SLICE_MB", None)
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     assert outs[0][1].tolist() == [fa.lib().fa_mel_num_frames(C.byref(cfg), n) for n in lens]

@@ -44,7 +44,7 @@ def test_polyphase_extension_vs_scipy(fa, gpu_ctx, up, down, n):
                                        # the register-tiled kernel of small interpolation factors (8 / 12 / 24 / 4 / 5.33 / 10.67 kHz -> 16 kHz)
                                        (2, 1, 1000003), (2, 1, 100), (2, 1, 57), (2, 3, 240000), (2, 3, 130), (4, 3, 120001), (4, 1, 40000), (3, 1, 53333), (3, 2, 106667),
                                        (4, 3, 64), (3, 2, 40)])
-def test_lds_kernel_equals_simple_kernel(fa, gpu_ctx, monkeypatch, up, down, n):
+def test_lds_kernel_equals_simple_kernel(fa, gpu_ctx, switch, up, down, n):
     """The LDS-staged persistent polyphase kernel and the register-tiled decimation kernel (up = 1, down 2 .. 5: interior outputs, the
     edges by the simple kernel) keep the summation order of the one-thread-per-output kernel: identical bits on several rate pairs
     (48k / 44.1k / 8k / 11.025k / 32k / 64k / 80k / 96k -> 16k, 44.1k -> 48k), multi-tile signals, tiny ones, and lengths around the
@@ -52,13 +52,13 @@ def test_lds_kernel_equals_simple_kernel(fa, gpu_ctx, monkeypatch, up, down, n):
     rng = np.random.default_rng(n)
     x = (0.4 * np.sin(2 * np.pi * 440 * np.arange(n) / 16000.0) + 0.1 * rng.standard_normal(n)).astype(np.float32)
     got = fa.resample_poly(x, up, down, ctx=gpu_ctx)
-    monkeypatch.setenv("FA_RESAMPLE_SIMPLE", "1")
+    switch("FA_RESAMPLE_SIMPLE", "1")
     ref = fa.resample_poly(x, up, down, ctx=gpu_ctx)
-    monkeypatch.delenv("FA_RESAMPLE_SIMPLE")
+    switch("FA_RESAMPLE_SIMPLE", None)
     np.testing.assert_array_equal(got, ref)
 
 
-def test_rows_kernel_actually_serves_the_common_non_integer_pairs(fa, gpu_ctx, monkeypatch):
+def test_rows_kernel_actually_serves_the_common_non_integer_pairs(fa, gpu_ctx, switch):
     """44.1 / 22.05 kHz -> 16 kHz go through poly_rows_kernel (not silently through the fallback): with FA_RESAMPLE_NO_ROWS the LDS-staged kernel
     produces the same bits, and on a device-resident hour of audio the row-tiled kernel is the faster of the two by a wide margin."""
     import ctypes as C
@@ -86,40 +86,40 @@ def test_rows_kernel_actually_serves_the_common_non_integer_pairs(fa, gpu_ctx, m
             gpu_ctx.synchronize()
             return e0.elapsed_time(e1) / 3
         t_rows = timed(y)
-        monkeypatch.setenv("FA_RESAMPLE_NO_ROWS", "1")
+        switch("FA_RESAMPLE_NO_ROWS", "1")
         t_lds = timed(y2)
-        monkeypatch.delenv("FA_RESAMPLE_NO_ROWS")
+        switch("FA_RESAMPLE_NO_ROWS", None)
         assert torch.equal(y, y2)
         assert t_rows < 0.85 * t_lds, (up, down, t_rows, t_lds)
 
 
 @pytest.mark.parametrize("tiles", [True, False])
 @pytest.mark.parametrize("down,n", [(2, 1000003), (2, 20000), (3, 3000017), (3, 9000), (3, 3300), (4, 640000), (5, 800007), (5, 26000), (6, 3000007), (6, 6200), (6, 700), (12, 4000003), (12, 40000), (12, 3500)])
-def test_both_decimation_kernels_equal_simple_kernel(fa, gpu_ctx, monkeypatch, tiles, down, n):
+def test_both_decimation_kernels_equal_simple_kernel(fa, gpu_ctx, switch, tiles, down, n):
     """Round 5: integer decimation through LDS tiles (whole tiles of 256 R outputs; the remainder by the register-tiled kernel and the edges) and, with
     FA_RESAMPLE_NO_DECIM_TILES, by the register-tiled kernel alone: the bits of the one-thread-per-output kernel, from several tiles per workgroup down to
     signals shorter than one tile."""
     if not tiles:
-        monkeypatch.setenv("FA_RESAMPLE_NO_DECIM_TILES", "1")
+        switch("FA_RESAMPLE_NO_DECIM_TILES", "1")
     rng = np.random.default_rng(n + down)
     x = (0.4 * np.sin(2 * np.pi * 440 * np.arange(n) / 16000.0) + 0.1 * rng.standard_normal(n)).astype(np.float32)
     got = fa.resample_poly(x, 1, down, ctx=gpu_ctx)
-    monkeypatch.setenv("FA_RESAMPLE_SIMPLE", "1")
+    switch("FA_RESAMPLE_SIMPLE", "1")
     ref = fa.resample_poly(x, 1, down, ctx=gpu_ctx)
     np.testing.assert_array_equal(got, ref)
 
 
 @pytest.mark.parametrize("form", ["16:8", "32:8", "32:10", "one-tile-per-workgroup"])
 @pytest.mark.parametrize("up,down,n", [(160, 441, 1000003), (160, 441, 40000), (160, 441, 15000), (320, 441, 300007), (640, 441, 150000), (80, 189, 200000)])
-def test_every_row_kernel_form_equals_simple_kernel(fa, monkeypatch, form, up, down, n):
+def test_every_row_kernel_form_equals_simple_kernel(fa, switch, form, up, down, n):
     """Round 5: the persistent double-buffered row kernels (poly_rows_wide_body: 16-row tiles with two workgroups per CU — the default —, 32-row tiles with one,
     32-row tiles of one phase group with ten wavefronts; FA_RESAMPLE_WIDE picks the form when a context builds its tables) and the one-tile-per-workgroup
     kernel they replaced for 44.1 / 22.05 / 11.025 / 37.8 kHz produce the bits of the one-thread-per-output kernel: several tiles per workgroup, a ragged
     last tile, signals shorter than one tile."""
     if form == "one-tile-per-workgroup":
-        monkeypatch.setenv("FA_RESAMPLE_NO_WIDE", "1")
+        switch("FA_RESAMPLE_NO_WIDE", "1")
     else:
-        monkeypatch.setenv("FA_RESAMPLE_WIDE", form)
+        switch("FA_RESAMPLE_WIDE", form)
     rng = np.random.default_rng(n + up)
     x = (0.4 * np.sin(2 * np.pi * 440 * np.arange(n) / 16000.0) + 0.1 * rng.standard_normal(n)).astype(np.float32)
     ctx = fa.Context(0)                     # the tables (and the kernel form) of a pair are fixed when a context first resamples it
@@ -127,7 +127,7 @@ def test_every_row_kernel_form_equals_simple_kernel(fa, monkeypatch, form, up, d
         got = fa.resample_poly(x, up, down, ctx=ctx)
     finally:
         ctx.close()
-    monkeypatch.setenv("FA_RESAMPLE_SIMPLE", "1")
+    switch("FA_RESAMPLE_SIMPLE", "1")
     ref_ctx = fa.Context(0)
     try:
         ref = fa.resample_poly(x, up, down, ctx=ref_ctx)
@@ -166,7 +166,7 @@ def test_row_kernels_with_unaligned_device_buffers(fa, gpu_ctx, up, down, rate):
 
 
 @pytest.mark.parametrize("up,down", [(160, 441), (320, 441)])
-def test_rows_kernel_on_non_finite_input(fa, gpu_ctx, monkeypatch, up, down):
+def test_rows_kernel_on_non_finite_input(fa, gpu_ctx, switch, up, down):
     """The row-tiled kernel multiplies a register window by a table row whose unused positions hold ZERO taps (the shift of a phase inside its —
     since round 5 shared — window is absorbed by the table).  On finite input that adds +-0 and changes no bit.  An Inf / NaN sample times a zero
     tap is NaN: it reaches every output whose padded window covers it, a few samples more on either side than the true FIR support (where the
@@ -178,9 +178,9 @@ def test_rows_kernel_on_non_finite_input(fa, gpu_ctx, monkeypatch, up, down):
     x[n // 2] = np.inf
     x[n // 2 + 50000] = np.nan
     got = fa.resample_poly(x, up, down, ctx=gpu_ctx)
-    monkeypatch.setenv("FA_RESAMPLE_SIMPLE", "1")
+    switch("FA_RESAMPLE_SIMPLE", "1")
     ref = fa.resample_poly(x, up, down, ctx=gpu_ctx)
-    monkeypatch.delenv("FA_RESAMPLE_SIMPLE")
+    switch("FA_RESAMPLE_SIMPLE", None)
     bad_ref, bad_got = ~np.isfinite(ref), ~np.isfinite(got)
     assert bad_ref.sum() > 0 and (bad_got | ~bad_ref).all()                 # wherever the simple kernel is non-finite, so is the row-tiled one
     both_ok = ~bad_got

@@ -135,16 +135,16 @@ def test_vbx_sharded_two_processes_one_gpu(fa, gpu_ctx):
 
 
 @pytest.mark.parametrize("T,D,K,seed", [(3000, 128, 70, 3), (5000, 128, 300, 4), (700, 40, 49, 5), (4097, 96, 129, 6)])
-def test_tiled_kernels_of_many_speakers_keep_the_bits(fa, gpu_ctx, oracle_mod, monkeypatch, T, D, K, seed):
+def test_tiled_kernels_of_many_speakers_keep_the_bits(fa, gpu_ctx, oracle_mod, switch, T, D, K, seed):
     """S >= 48 speakers (hard sessions: hundreds of AHC clusters): the two contractions of an iteration run as 64 x 64 tiled products
     (vbx_gt_rho_tiled, vbx_logits_tiled + vbx_softmax_rows).  Every output is one accumulator fed in ascending k by the same fused
     multiply-adds as the one-speaker-per-wavefront kernels: gamma, pi, ELBOs and labels are identical bit for bit (FA_VBX_NO_TILED=1 runs
     the old kernels), and equal to the CPU restatement at its tolerance."""
     x, init, phi = make_problem(T, D, K, seed)
     tiled = fa.VBxClustering(phi, ctx=gpu_ctx).refine(x, init)
-    monkeypatch.setenv("FA_VBX_NO_TILED", "1")
+    switch("FA_VBX_NO_TILED", "1")
     plain = fa.VBxClustering(phi, ctx=gpu_ctx).refine(x, init)
-    monkeypatch.delenv("FA_VBX_NO_TILED")
+    switch("FA_VBX_NO_TILED", None)
     assert tiled.num_clusters == plain.num_clusters == K
     assert tiled.elbos == plain.elbos
     np.testing.assert_array_equal(tiled.gamma, plain.gamma)
