@@ -382,12 +382,21 @@ __global__ __launch_bounds__(256) void ahc_pairwise(Ws w) {
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int GT = 128, GK = 16, GS = 144;
 
-__global__ void ahc_sqnorms(Ws w, double *__restrict__ norms) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= w.Np) return;
+// Squared norms of the slots (Gram form only: the entries are a filter, their rounding error is inside eps).  Workgroup = 64 slots x 4 quarters of the
+// coordinates; the quarters are added in a fixed order (deterministic).  One thread per slot walking all d coordinates was 73 us of dependent loads at
+// 43 200 x 256 — 0.7 % of the start-up for 44 MB of reads.
+__global__ __launch_bounds__(256) void ahc_sqnorms(Ws w, double *__restrict__ norms) {
+    __shared__ double s_q[3][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, x = blockIdx.x * 64 + lane;
+    const int per = (w.d + 3) / 4, k0 = q * per, k1 = k0 + per < w.d ? k0 + per : w.d;
     double s = 0.0;
-    for (int k = 0; k < w.d; ++k) { const double v = w.XT[static_cast<size_t>(k) * w.Np + x]; s += v * v; }
-    norms[x] = s;
+    if (x < w.Np)
+        for (int k = k0; k < k1; ++k) { const double v = w.XT[static_cast<size_t>(k) * w.Np + x]; s += v * v; }
+    if (q) s_q[q - 1][lane] = s;
+    __syncthreads();
+    if (q || x >= w.Np) return;
+    s = ((s + s_q[0][lane]) + s_q[1][lane]) + s_q[2][lane];
+    norms[x] = w.node[x] != kDead ? s : -1.0;   // an empty slot carries a negative "norm": the Gram tiles test liveness on the value they load anyway (no second load per row)
     if (s > 0.0) atomicMax(&w.state[0].nmax_bits, static_cast<unsigned long long>(__double_as_longlong(s)));
 }
 
@@ -489,7 +498,34 @@ typedef double d2f64 __attribute__((ext_vector_type(2)));
 constexpr int G2K = 16, G2S = 144;
 constexpr size_t kGram2LdsBytes = sizeof(double) * 2 * 2 * G2K * G2S;   // [stage][operand][k][144]: 73 728 B, two workgroups per CU
 
-__global__ __launch_bounds__(256, 2) void ahc_gram_mfma2(Ws w, const double *__restrict__ norms) {
+// MINIMA (round 6): the tile also leaves, for each of its 128 rows, the minimum / lowest-index argmin / second minimum over its 128 columns —
+// and, mirrored, for each of its columns over its rows — in part_vs / part_ix[tile column][row]: ahc_row_minima_parts merges the Np / 128 partials
+// of a row.  ahc_row_minima re-read the whole matrix for the same three numbers (15 GB at 43 200 points: 2.8 of the start-up's 13.2 ms).
+// Partials are (v, s, i): smallest entry, the smallest entry OTHER than the one at i, lowest index of v; merged by (value, index), the loser's v
+// competing for s — associative and commutative, so any tile order gives what one ascending scan gives.
+struct MinAcc { double v, s; int i; };
+// (entries are non-negative or +inf here — a NaN entry sets the flag that declines the run.  v_min_f64 / v_max_f64 directly: fmin / fmax
+// come with a canonicalising v_max_f64 x, x per operand under IEEE mode, a third of the epilogue's instructions when it was written with them)
+__device__ __forceinline__ double vmin64(const double a, const double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double vmax64(const double a, const double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ void min_ins(MinAcc &a, const double m, const int x) {   // x ascending within one accumulator: the lowest index of equal values is kept
+    a.i = m < a.v ? x : a.i;
+    a.s = vmin64(a.s, vmax64(a.v, m));
+    a.v = vmin64(a.v, m);
+}
+__device__ __forceinline__ void min_merge(MinAcc &a, const MinAcc o) {
+    const bool take = o.v < a.v || (o.v == a.v && o.i < a.i);
+    a.s = vmin64(vmin64(a.s, o.s), vmax64(a.v, o.v));   // the loser's minimum competes for the second place
+    a.v = vmin64(a.v, o.v);
+    a.i = take ? o.i : a.i;
+}
+__device__ __forceinline__ MinAcc min_xor(const MinAcc a, const int mask) {
+    MinAcc o; o.v = __shfl_xor(a.v, mask); o.s = __shfl_xor(a.s, mask); o.i = __shfl_xor(a.i, mask);
+    return o;
+}
+
+template <bool MINIMA>
+__global__ __launch_bounds__(256, 2) void ahc_gram_mfma2_t(Ws w, const double *__restrict__ norms, double2 *__restrict__ part_vs, int *__restrict__ part_ix) {
     extern __shared__ __attribute__((aligned(16))) double sg[];
     if (blockIdx.x > blockIdx.y) return;   // symmetric: tiles on and below the diagonal, off-diagonal tiles are written twice
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;   // wave: in an SGPR, so the row addresses below are scalar
@@ -541,19 +577,40 @@ __global__ __launch_bounds__(256, 2) void ahc_gram_mfma2(Ws w, const double *__r
         if (ok && v > lmax) lmax = v;
         return ok ? v : dinf();
     };
+    // MINIMA: the wave's entries of a strip (64 rows x 32 columns) also go through a private 17 KB piece of the idle operand LDS, row-major with a
+    // 34-double stride, and come back transposed: lane l reads ROW l (16 ds_read_b128, bank-conflict free at that stride) and folds its 32 entries
+    // in ascending column order into the lane's row accumulator, which simply carries on through the second strip; lanes (c, h) read COLUMN c over
+    // the rows 32 h .. 32 h + 31 in ascending order and the two halves meet through one exchange.  No cross-lane reduction per row: a DPP butterfly per row
+    // pair and strip cost 5 000 VALU instructions per tile (12.6 instead of 10.3 ms for the kernel: nothing of it hid under the other workgroup's
+    // matrix-core loop); this form costs ~1 000.  The norms of the tile's rows and columns are staged in LDS as well.
+    MinAcc mine, cmine;
+    mine.v = cmine.v = dinf(); mine.s = cmine.s = dinf(); mine.i = cmine.i = INT_MAX;
+    constexpr int TS = 34;                                 // doubles per LDS row: 272 B, a multiple of 16 that walks the banks
+    double *const tile = sg + wave * 64 * TS;              // [64][TS] of this wave
+    double *const sn = sg + 4 * 64 * TS;                   // [0, 128): norms of the rows i0 .., [128, 256): of the columns j0 ..
+    static_assert((4 * 64 * TS + 2 * GT) * sizeof(double) <= kGram2LdsBytes, "the epilogue's LDS lives inside the operand stages");
+    if constexpr (MINIMA) {
+        __syncthreads();     // everybody is done with the operands of the last chunk
+        sn[tid] = norms[(tid < GT ? i0 : j0 - GT) + tid];
+        __syncthreads();
+    }
 #pragma unroll
     for (int cp = 0; cp < 2; ++cp) {   // column pair group: columns jb, jb + 1
         __builtin_amdgcn_sched_barrier(0);   // one strip at a time (register pressure)
         const int jb = j0 + wc + 32 * cp + 2 * l15;
-        const bool lj0 = w.node[jb] != kDead, lj1 = w.node[jb + 1] != kDead;
-        const double nj0 = norms[jb], nj1 = norms[jb + 1];
+        double nj0, nj1;
+        if constexpr (MINIMA) { const d2f64 q = *reinterpret_cast<const d2f64 *>(sn + GT + wc + 32 * cp + 2 * l15); nj0 = q.x; nj1 = q.y; }
+        else { nj0 = norms[jb]; nj1 = norms[jb + 1]; }
+        const bool lj0 = !(nj0 < 0.0), lj1 = !(nj1 < 0.0);   // (NaN norms are live rows)
 #pragma unroll
         for (int rp = 0; rp < 2; ++rp)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int ib = i0 + wr + 32 * rp + 2 * (lq + 4 * e);   // rows ib (tiles 2 rp) and ib + 1 (tiles 2 rp + 1)
-                const bool li0 = w.node[ib] != kDead, li1 = w.node[ib + 1] != kDead;
-                const double ni0 = norms[ib], ni1 = norms[ib + 1];
+                const int il = 32 * rp + 2 * (lq + 4 * e), ib = i0 + wr + il;   // rows ib (tiles 2 rp) and ib + 1 (tiles 2 rp + 1); il: within the wave
+                double ni0, ni1;
+                if constexpr (MINIMA) { const d2f64 q = *reinterpret_cast<const d2f64 *>(sn + wr + il); ni0 = q.x; ni1 = q.y; }
+                else { ni0 = norms[ib]; ni1 = norms[ib + 1]; }
+                const bool li0 = !(ni0 < 0.0), li1 = !(ni1 < 0.0);
                 const double v00 = entry(acc[2 * rp][2 * cp][e], ni0, nj0, li0 && lj0 && ib != jb);
                 const double v01 = entry(acc[2 * rp][2 * cp + 1][e], ni0, nj1, li0 && lj1 && ib != jb + 1);
                 const double v10 = entry(acc[2 * rp + 1][2 * cp][e], ni1, nj0, li1 && lj0 && ib + 1 != jb);
@@ -564,7 +621,53 @@ __global__ __launch_bounds__(256, 2) void ahc_gram_mfma2(Ws w, const double *__r
                     *reinterpret_cast<d2f64 *>(w.M + static_cast<size_t>(jb) * Np + ib) = d2f64{v00, v10};
                     *reinterpret_cast<d2f64 *>(w.M + static_cast<size_t>(jb + 1) * Np + ib) = d2f64{v01, v11};
                 }
+                if constexpr (MINIMA) {
+                    *reinterpret_cast<d2f64 *>(tile + il * TS + 2 * l15) = d2f64{v00, v01};
+                    *reinterpret_cast<d2f64 *>(tile + (il + 1) * TS + 2 * l15) = d2f64{v10, v11};
+                }
             }
+        if constexpr (MINIMA) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int jc = j0 + wc + 32 * cp;
+#pragma unroll 4
+            for (int k = 0; k < 16; ++k) {   // row `lane` of the wave, columns jc .. jc + 31 ascending (a real loop: unrolled whole, its 48 loads are hoisted and spill)
+                const d2f64 q = *reinterpret_cast<const d2f64 *>(tile + lane * TS + 2 * k);
+                min_ins(mine, q.x, jc + 2 * k);
+                min_ins(mine, q.y, jc + 2 * k + 1);
+            }
+            const int c = lane & 31, h = lane >> 5;
+            MinAcc ca;
+            ca.v = ca.s = dinf(); ca.i = INT_MAX;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) min_ins(ca, tile[(32 * h + r) * TS + c], i0 + wr + 32 * h + r);   // column c of the strip, rows ascending
+            min_merge(ca, min_xor(ca, 32));
+            if (h == cp) cmine = ca;         // lane l keeps column l of the wave's 64
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the next strip overwrites the piece
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    if constexpr (MINIMA) {
+        // the two waves that share rows (wc 0 / 64) and the two that share columns (wr 0 / 64) meet through the sender's own piece
+        MinAcc *const xw = reinterpret_cast<MinAcc *>(tile);           // [0, 64): rows, [64, 128): columns
+        if (wc) xw[lane] = mine;
+        if (wr) xw[64 + lane] = cmine;
+        __syncthreads();
+        const size_t npz = static_cast<size_t>(Np);
+        if (!wc) {
+            min_merge(mine, reinterpret_cast<const MinAcc *>(sg + (wave + 1) * 64 * TS)[lane]);          // wave (wr, 64) = this wave + 1
+            const size_t at = blockIdx.x * npz + i0 + wr + lane;
+            part_vs[at] = make_double2(mine.v, mine.s);
+            part_ix[at] = mine.i;
+        }
+        if (!wr && mirror) {
+            min_merge(cmine, reinterpret_cast<const MinAcc *>(sg + (wave + 2) * 64 * TS)[64 + lane]);    // wave (64, wc) = this wave + 2
+            const size_t at = blockIdx.y * npz + j0 + wc + lane;
+            part_vs[at] = make_double2(cmine.v, cmine.s);
+            part_ix[at] = cmine.i;
+        }
     }
     if (bad) w.flags[0] = 1;
 #pragma unroll
@@ -617,6 +720,31 @@ __global__ __launch_bounds__(kBlk) void ahc_row_minima(Ws w) {
         for (int wv = 1; wv < kWaves; ++wv) if (s_second[wv] < c2) c2 = s_second[wv];
         w.e2[i] = c2;
     }
+}
+
+// The same three numbers per row from the partials the Gram tiles left (ahc_gram_mfma2_t<true>): Np / 128 partials per row, merged by (value, index).
+// Workgroup = 64 rows x 4 shares of the tile columns; the shares meet in LDS.
+__global__ __launch_bounds__(256) void ahc_row_minima_parts(Ws w, const double2 *__restrict__ part_vs, const int *__restrict__ part_ix) {
+    __shared__ MinAcc s_acc[3][64];
+    const int lane = threadIdx.x & 63, share = threadIdx.x >> 6, i = blockIdx.x * 64 + lane, nT = w.Np / GT;
+    MinAcc a;
+    a.v = dinf(); a.s = dinf(); a.i = INT_MAX;
+    const size_t npz = static_cast<size_t>(w.Np);
+#pragma unroll 8
+    for (int t = share; t < nT; t += 4) {
+        const double2 vs = part_vs[t * npz + i];
+        MinAcc o; o.v = vs.x; o.s = vs.y; o.i = part_ix[t * npz + i];
+        min_merge(a, o);
+    }
+    if (share) s_acc[share - 1][lane] = a;
+    __syncthreads();
+    if (share) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) min_merge(a, s_acc[q][lane]);
+    const bool any = a.i != INT_MAX && w.node[i] != kDead;
+    RowSt r; r.d1 = any ? a.v : dinf(); r.nn = any ? a.i : -1; r.nnnode = any ? w.node[a.i] : -1;
+    w.row[i] = r;
+    w.e2[i] = any ? a.s : dinf();
 }
 
 // ------------------------------------------------------------------------------ block record
@@ -2350,7 +2478,7 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
 
 // ------------------------------------------------------------------------------ host driver
 struct Layout {
-    size_t state, cnt, flags, prof, c, xt, row, e2, node, sizes, z, reca, reci, recs, recp, cand, pairs, norms, m, total;
+    size_t state, cnt, flags, prof, c, xt, row, e2, node, sizes, z, reca, reci, recs, recp, cand, pairs, norms, m, part_vs, part_ix, total;
 };
 
 size_t rom_total_bytes(size_t N, size_t Np, size_t d);   // workspace of the matrix-filtered reference-order run (below)
@@ -2378,6 +2506,8 @@ Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
     L.c = take(sizeof(double) * d * 2 * N);
     L.xt = take(sizeof(double) * d * Np);
     L.m = take(sizeof(double) * Np * Np);
+    L.part_vs = take(sizeof(double2) * (Np / GT) * Np);   // per-tile row minima of the Gram start-up (0.13 % of the matrix each)
+    L.part_ix = take(sizeof(int32_t) * (Np / GT) * Np);
     L.total = std::max(o, rom_total_bytes(N, Np, d));   // a run that meets an exact tie continues in reference order in the SAME workspace (no second hipMalloc of N^2 * 8 B)
     return L;
 }
@@ -2441,24 +2571,29 @@ fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base) {
     w.N = static_cast<int32_t>(N); w.Np = static_cast<int32_t>(Np); w.d = static_cast<int32_t>(d); w.nblk = static_cast<int32_t>(Np / (static_cast<size_t>(kBlk) * p.cpt));
 
     const int dev_mode = p.mode == FA_AHC_MODE_EXACT ? FA_AHC_MODE_EXACT : FA_AHC_MODE_AUTO;
+    bool minima_done = false;   // the Gram tiles left per-tile row minima (ahc_gram_mfma2_t<true>): no second pass over the matrix
     hipLaunchKernelGGL(ahc_init_state, dim3(1), dim3(64), 0, ctx->stream, w, dev_mode);
     FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, p.d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(ahc_init_rows, dim3((std::max(Np, 2 * N) + 255) / 256), dim3(256), 0, ctx->stream, w);
     hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, ctx->stream, p.d_data, w.XT, w.N, w.Np, w.d);
     if (dev_mode == FA_AHC_MODE_AUTO) {  // Gram form on the fp64 matrix cores (approximate entries, see ahc_gram_mfma)
         double *d_norms = reinterpret_cast<double *>(base + L.norms);
-        hipLaunchKernelGGL(ahc_sqnorms, dim3((w.Np + 255) / 256), dim3(256), 0, ctx->stream, w, d_norms);
+        hipLaunchKernelGGL(ahc_sqnorms, dim3((w.Np + 63) / 64), dim3(256), 0, ctx->stream, w, d_norms);
         if (w.d % G2K == 0 && !fa::sw_on(fa::Sw::AHC_GRAM_V1)) {
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_gram_mfma2), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGram2LdsBytes));
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_gram_mfma2_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGram2LdsBytes));
             FA_HIP_TRY(ctx, attr);
-            hipLaunchKernelGGL(ahc_gram_mfma2, dim3(w.Np / GT, w.Np / GT), dim3(256), kGram2LdsBytes, ctx->stream, w, d_norms);
+            double2 *part_vs = reinterpret_cast<double2 *>(base + L.part_vs);
+            int *part_ix = reinterpret_cast<int *>(base + L.part_ix);
+            hipLaunchKernelGGL(ahc_gram_mfma2_t<true>, dim3(w.Np / GT, w.Np / GT), dim3(256), kGram2LdsBytes, ctx->stream, w, d_norms, part_vs, part_ix);
+            hipLaunchKernelGGL(ahc_row_minima_parts, dim3(w.Np / 64), dim3(256), 0, ctx->stream, w, part_vs, part_ix);
+            minima_done = true;
         } else
             hipLaunchKernelGGL(ahc_gram_mfma, dim3(w.Np / GT, w.Np / GT), dim3(256), 0, ctx->stream, w, d_norms);
     } else {
         const int tiles = w.Np / PT;
         hipLaunchKernelGGL(ahc_pairwise, dim3(tiles, tiles), dim3(256), 0, ctx->stream, w);
     }
-    hipLaunchKernelGGL(ahc_row_minima, dim3(w.Np), dim3(kBlk), 0, ctx->stream, w);
+    if (!minima_done) hipLaunchKernelGGL(ahc_row_minima, dim3(w.Np), dim3(kBlk), 0, ctx->stream, w);
     hipLaunchKernelGGL(ahc_set_eps, dim3(1), dim3(64), 0, ctx->stream, w);
     if (p.cpt == 4) hipLaunchKernelGGL(ahc_records<4>, dim3(w.nblk, 2), dim3(kBlk), 0, ctx->stream, w);  // window counts need eps
     else if (p.cpt == 2) hipLaunchKernelGGL(ahc_records<2>, dim3(w.nblk, 2), dim3(kBlk), 0, ctx->stream, w);
@@ -2697,11 +2832,11 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     hipLaunchKernelGGL(ahc_transpose, dim3((Np + 31) / 32, (d + 31) / 32), dim3(256), 0, st, d_data, w.XT, w.N, w.Np, w.d);
     const bool direct_start = fa::sw_on(fa::Sw::AHC_ROM_DIRECT_START);   // the start-up of the matrix-free run (all N^2 / 2 exact sums) for A/B
     if (direct_start) hipLaunchKernelGGL(ro_lower_minima_direct, dim3(static_cast<unsigned>((N + kRoT - 1) / kRoT)), dim3(256), 0, st, rw);
-    hipLaunchKernelGGL(ahc_sqnorms, dim3((w.Np + 255) / 256), dim3(256), 0, st, gw, d_norms);
+    hipLaunchKernelGGL(ahc_sqnorms, dim3((w.Np + 63) / 64), dim3(256), 0, st, gw, d_norms);
     if (w.d % G2K == 0) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_gram_mfma2), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGram2LdsBytes));
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_gram_mfma2_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGram2LdsBytes));
         FA_HIP_TRY(ctx, attr);
-        hipLaunchKernelGGL(ahc_gram_mfma2, dim3(w.Np / GT, w.Np / GT), dim3(256), kGram2LdsBytes, st, gw, d_norms);
+        hipLaunchKernelGGL(ahc_gram_mfma2_t<false>, dim3(w.Np / GT, w.Np / GT), dim3(256), kGram2LdsBytes, st, gw, d_norms, static_cast<double2 *>(nullptr), static_cast<int *>(nullptr));
     } else
         hipLaunchKernelGGL(ahc_gram_mfma, dim3(w.Np / GT, w.Np / GT), dim3(256), 0, st, gw, d_norms);
     if (!direct_start) hipLaunchKernelGGL(rom_lower_minima, dim3(static_cast<unsigned>(N - 1)), dim3(kBlk), 0, st, w, gw.state, rw.key);
