@@ -656,7 +656,7 @@ def tdt_leg(fa, ctx, torch, B=1024, U=64, T=188, V1=1025, nd=5, dtype="float32")
                                  "the batch of chunks is the parallel axis"}}
 
 
-AHC_SOURCES = ("ahc.hip",)
+AHC_SOURCES = ("ahc_round_body.h", "ahc_ws.h", "ahc_rounds.hip")   # the round kernel of the headline: body, shared definitions, entry kernels
 CTC_SOURCES = ("ctc.hip",)
 RESAMPLE_SOURCES = ("resample.hip", "resample_geom.h")
 TDT_SOURCES = ("tdt.hip",)

@@ -1,7 +1,7 @@
 /*
  * ahc_model.c — CPU MODEL of the GPU merge-round algorithm (test infrastructure only).
  *
- * Mirrors, step for step, the round structure of fluidaudio_amd/csrc/ahc.hip
+ * Mirrors, step for step, the round structure of fluidaudio_amd/csrc/ahc_round_body.h
  * (asymmetric slot matrix M, per-row minima with lazy rescans, Lance-Williams filter with
  * mutual-nearest certification and exact window re-evaluation, exact heights after the loop) so that the algorithm itself can be checked against the
  * reference build (oracle/_ref) on the CPU, and so that round counts can be measured

@@ -1,4 +1,4 @@
-// CPU replay of the matrix-filtered reference-order run (fluidaudio_amd/csrc/ahc.hip: rom_scan / rom_select) on the SAME header the HIP kernels
+// CPU replay of the matrix-filtered reference-order run (fluidaudio_amd/csrc/ahc_rom.hip: rom_scan / rom_select) on the SAME header the HIP kernels
 // compile (ahc_reforder.h: HeapK — entries that carry their key, block-wise sifts — and SelT).  Two entry points:
 //   fa_heapk_equiv : Heap (the statement-for-statement restatement of the reference's binary_min_heap) and HeapK side by side on a random
 //                    stream of remove / replace / raise with heavily tied keys; every array compared after every operation.

@@ -77,7 +77,7 @@ def test_selection_logic_on_random_tie_heavy_inputs(oracle_mod, emul, seed):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------------
-# Round 5: the matrix-filtered reference-order run (ahc.hip: rom_scan / rom_select) — entries that carry their key, block-wise sifts
+# Round 5: the matrix-filtered reference-order run (ahc_rom.hip: rom_scan / rom_select) — entries that carry their key, block-wise sifts
 # (ahc_reforder.h: HeapK), a Lance-Williams matrix supplying the candidates of every scan.  tests/cpu/ahc_rom_emul.cpp replays both on the CPU.
 
 def _build(name):

@@ -64,7 +64,7 @@ def test_naive_restatement_equals_reference_build(oracle_mod):
 
 
 def test_gpu_algorithm_model_equals_reference_build(oracle_mod):
-    """oracle/ahc_model.c replays the round structure of csrc/ahc.hip on the CPU: both the exact-row mode and the
+    """oracle/ahc_model.c replays the round structure of csrc/ahc_round_body.h on the CPU: both the exact-row mode and the
     Lance-Williams + exact-verify mode must reproduce the reference dendrogram bit for bit."""
     import subprocess
     here = os.path.join(os.path.dirname(__file__), "..", "oracle")
