@@ -1015,7 +1015,11 @@ fa_status fa_resample_poly_dev(fa_ctx *ctx, const float *d_x, int64_t frames, in
                 auto go = [&](auto dc) {
                     constexpr int DN = decltype(dc)::value;
                     typedef DecimTile<DN> D;
-                    const int64_t tiles = std::min<int64_t>(avail / D::TO, (int64_t{1} << 30) / D::TO);
+                    int64_t tiles = std::min<int64_t>(avail / D::TO, (int64_t{1} << 30) / D::TO);
+                    // the 16-byte piece that holds a tile's last input may run up to 3 samples past it: a last tile whose piece would leave the signal is not a
+                    // tile (its piece would be clamped and land shifted in LDS) — its outputs go to the register-tiled kernel and the edges (the same
+                    // guard as the register-tiled kernel's below, mirrored in tests/cpu/resample_geom_emul.cpp)
+                    while (tiles > 0 && ((m_begin + tiles * D::TO - 1) + 11) * DN + 3 > frames - 1) --tiles;
                     if (tiles <= 0) return;
                     const int per_cu = std::max(1, std::min(4, static_cast<int>(160 * 1024 / (2 * sizeof(float) * D::BUF))));
                     const unsigned grid = static_cast<unsigned>(std::min<int64_t>(tiles, 256 * per_cu));

@@ -19,7 +19,8 @@ static int decim_tiles_emulate_t(const float *x, int64_t n_in, const float *h, i
     typedef fa::DecimTile<DOWN> D;
     const int64_t m_begin = 10, m_last = (n_in - 1) / DOWN - 11;
     const int64_t avail = m_last >= m_begin ? std::min(m_last + 1, n_out) - m_begin : 0;
-    const int64_t tiles = avail / D::TO;
+    int64_t tiles = avail / D::TO;
+    while (tiles > 0 && ((m_begin + tiles * D::TO - 1) + 11) * DOWN + 3 > n_in - 1) --tiles;   // the host's guard: the last tile's last 16-byte piece stays inside the signal
     *m_lo = *m_hi = m_begin;
     if (tiles <= 0) return 0;
     static_assert(D::RS % 4 == 0 && (D::RS / 4) % 2 == 1, "a thread's window starts 4 x odd floats behind its neighbour's: conflict-free 16-byte LDS reads");
