@@ -115,4 +115,4 @@ class AHCClustering:
                                     labels.ctypes.data, C.byref(stats))
         self.last_status, self.last_stats = st, stats.as_dict()
         # on failure the library has already filled labels with 0..<count (:52-55)
-        return [int(v) for v in labels]
+        return np.asarray(labels).tolist()   # (one C loop: a Python-level comprehension over 43 200 labels costs 2-3 ms)

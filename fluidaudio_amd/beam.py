@@ -93,7 +93,7 @@ def ctc_beam_search_ids_batch(log_probs, vocabulary: dict | None = None, lm: ARP
                                                voc.handle if voc else None, lm.handle if lm is not None else None, beam_width, lm_weight,
                                                word_bonus, blank_id, token_candidates, tokens.ctypes.data, lens.ctypes.data,
                                                scores.ctypes.data), "fa_ctc_beam_search_batch")
-    return [[int(v) for v in tokens[b, :lens[b]]] for b in range(B)], scores
+    return [tokens[b, :lens[b]].tolist() for b in range(B)], scores
 
 
 def ctc_beam_search(log_probs, vocabulary: dict, lm: ARPALanguageModel | None = None, beam_width: int = 100, lm_weight: float = 0.3,

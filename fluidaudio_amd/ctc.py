@@ -72,7 +72,7 @@ class LogitsArgmax:
         if frames <= 0:
             return []
         _, fids = ctc_greedy_ids_batch(x[:frames], blank_id=-1, vocab=vocab, ctx=ctx, return_frame_ids=True)
-        return [int(v) for v in fids[0]]
+        return np.asarray(fids[0]).tolist()
 
 
 def decode_ctc_token_ids(ids, vocabulary: dict[int, str]) -> str:

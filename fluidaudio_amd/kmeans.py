@@ -47,7 +47,7 @@ class KMeansClustering:
         k, it = C.c_int32(), C.c_int32()
         ctx.check(L.lib().fa_kmeans_cluster(ctx.handle, x.ctypes.data, n, d, num_clusters, max_iterations, (seed or 0) & (2 ** 64 - 1),
                                             labels.ctypes.data, cen.ctypes.data, C.byref(k), C.byref(it)), "fa_kmeans_cluster")
-        return [int(v) for v in labels], cen[:k.value, :d].copy()
+        return np.asarray(labels).tolist(), cen[:k.value, :d].copy()
 
     @staticmethod
     def cluster(embeddings, num_clusters: int, max_iterations: int = 300, seed: int | None = None, ctx: L.Context | None = None) -> list:
@@ -70,7 +70,7 @@ class KMeansClustering:
                                                   inert.ctypes.data), "fa_kmeans_cluster_ninit")
         if details is not None:
             details.update(best_run=best.value, inertias=inert)
-        return [int(v) for v in labels], cen[:k.value, :d].copy()
+        return np.asarray(labels).tolist(), cen[:k.value, :d].copy()
 
 
 @dataclass(frozen=True)

@@ -126,7 +126,7 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, config: Offline
                                              ph.ctypes.data if rd else None, C.byref(c), int(on_device), labels.ctypes.data, cen.ctypes.data, cap, C.byref(k),
                                              C.byref(info)), "fa_offline_cluster")
     t = {"inputs_s": info.inputs_s, "ahc_s": info.ahc_s, "vbx_s": info.vbx_s, "assign_s": info.assign_s, "total_s": info.total_s}
-    res = ClusteringResult(labels if intermediates else [int(v) for v in labels], cen[:k.value].copy(), [], None, [], t)
+    res = ClusteringResult(labels if intermediates else np.asarray(labels).tolist(), cen[:k.value].copy(), [], None, [], t)
     res.info = {f: getattr(info, f) for f, _ in info._fields_ if f != "ahc"}
     res.info["ahc"] = info.ahc.as_dict()
     if intermediates:
@@ -190,7 +190,7 @@ def cluster_embeddings_batch(recordings, phi, config: OfflineClusteringConfig | 
             continue
         info = infos[i]
         t = {"inputs_s": info.inputs_s, "ahc_s": info.ahc_s, "vbx_s": info.vbx_s, "assign_s": info.assign_s, "total_s": info.total_s}
-        res = ClusteringResult([int(v) for v in labels[i][:recs[i][0].shape[0]]], cens[i][:kc[i]].copy(), [], None, [], t)
+        res = ClusteringResult(labels[i][:recs[i][0].shape[0]].tolist(), cens[i][:kc[i]].copy(), [], None, [], t)
         res.info = {f: getattr(info, f) for f, _ in info._fields_ if f != "ahc"}
         res.info["ahc"] = info.ahc.as_dict()
         out.append(res)

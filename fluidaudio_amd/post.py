@@ -40,7 +40,7 @@ def assign_embeddings(embedding_features, centroids, ctx: L.Context | None = Non
     ctx = ctx or L.default_context()
     out = np.zeros(n, np.int32)
     ctx.check(L.lib().fa_assign_cosine(ctx.handle, emb.ctypes.data, n, d, cen.ctypes.data, K, out.ctypes.data), "fa_assign_cosine")
-    return [int(v) for v in out]
+    return np.asarray(out).tolist()
 
 
 def centroid_scores(embedding_features, centroids, ctx: L.Context | None = None) -> np.ndarray:
@@ -75,7 +75,7 @@ class ConstrainedClusterAssignment:
         ctx = ctx or L.default_context()
         ctx.check(L.lib().fa_constrained_assign(ctx.handle, sc.ctypes.data if K else None, n, K, ch.ctypes.data, out.ctypes.data),
                   "fa_constrained_assign")
-        return [int(v) for v in out]
+        return np.asarray(out).tolist()
 
 
 class HungarianAssignment:

@@ -63,7 +63,7 @@ class VBxClustering:
         ctx.check(L.lib().fa_vbx_refine(ctx.handle, rho.ctypes.data, T, D, init.ctypes.data, phi.ctypes.data, self.fa,
                                         self.fb, self.max_iterations, self.tol, gamma.ctypes.data, pi.ctypes.data,
                                         hard.ctypes.data, elbos.ctypes.data, C.byref(it), C.byref(ns)), "fa_vbx_refine")
-        return VBxOutput(gamma, pi, [[int(v) for v in hard]], [], S, [float(v) for v in elbos[:it.value]])
+        return VBxOutput(gamma, pi, [np.asarray(hard).tolist()], [], S, [float(v) for v in elbos[:it.value]])
 
     def refine_with_constraints(self, rho_features, training_embeddings, initial_clusters, constraints) -> VBxOutput:
         """refineWithConstraints (:685-733): when the clusters the posteriors actually use fall outside [min, max] speakers,
