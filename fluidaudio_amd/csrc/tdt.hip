@@ -322,6 +322,13 @@ __device__ __forceinline__ float tdt_wave_max(float v) {
 #undef FA_TDT_STEP
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+__device__ __forceinline__ unsigned tdt_wave_umin(unsigned v) {   // minimum over the 64 lanes, in every lane (uniform)
+#define FA_TDT_STEP(CTRL, MASK) { const unsigned o = static_cast<unsigned>(__builtin_amdgcn_update_dpp(-1, static_cast<int>(v), CTRL, MASK, 0xf, false)); v = o < v ? o : v; }
+    FA_TDT_STEP(0x111, 0xf) FA_TDT_STEP(0x112, 0xf) FA_TDT_STEP(0x114, 0xf) FA_TDT_STEP(0x118, 0xf)
+    FA_TDT_STEP(0x142, 0xa) FA_TDT_STEP(0x143, 0xc)
+#undef FA_TDT_STEP
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
 __device__ __forceinline__ float tdt_low8_max(float v) {   // over lanes 0 .. 7
 #define FA_TDT_STEP(CTRL, MASK) v = __builtin_fmaxf(v, tdt_dpp<CTRL, MASK>(-INFINITY, v));
     FA_TDT_STEP(0x111, 0xf) FA_TDT_STEP(0x112, 0xf) FA_TDT_STEP(0x114, 0xf)
@@ -361,15 +368,14 @@ __global__ __launch_bounds__(64) void tdt_logits_fits_kernel(const TdtArgs a, co
 #pragma unroll
         for (int j = 1; j < kP; ++j) me = __builtin_fmaxf(me, v[j]);            // a NaN operand is dropped
         const float M = tdt_wave_max(me);                                         // all NaN: NaN; nothing above -inf: -inf
-        int found = 0, idx = 0;
+        // the FIRST index holding M: per lane the lowest piece whose value equals M (index 64 j + lane; 17 compares + selects, walked downwards so the
+        // lowest j is written last), then the minimum of those indices over the wavefront — six v_min_u32 with a DPP operand.  Round 5 searched the 17 lane
+        // masks on the scalar unit (ballot, compare, find-first, select per piece: 11 scalar instructions each, 318 per decision in r05_tdt_pmc.json).
+        unsigned key = 0xffffffffu;
 #pragma unroll
-        for (int j = 0; j < kP; ++j) {
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(v[j] == M);
-            const int here = mask != 0 && !found;
-            idx = here ? 64 * j + __ffsll(static_cast<long long>(mask)) - 1 : idx;
-            found |= here;
-        }
-        tok = (M > -INFINITY && found) ? idx : 0;                                // all NaN / -inf: index 0 (LogitsArgmax semantics: nothing beats the -inf seed)
+        for (int j = kP - 1; j >= 0; --j) key = v[j] == M ? static_cast<unsigned>(64 * j + lane) : key;
+        key = tdt_wave_umin(key);
+        tok = (M > -INFINITY && key != 0xffffffffu) ? static_cast<int>(key) : 0;   // all NaN / -inf: index 0 (LogitsArgmax semantics: nothing beats the -inf seed)
         const float DM = tdt_low8_max(dv);
         const unsigned long long dmask = __builtin_amdgcn_ballot_w64(lane < g.nd && dv == DM);
         bin = (DM > -INFINITY && dmask != 0) ? __ffsll(static_cast<long long>(dmask)) - 1 : 0;   // first maximum; nothing above -inf: bin 0 (the scan's initial value)
