@@ -417,7 +417,7 @@ __global__ __launch_bounds__(kRowsThreads) FA_ROWS_ATTR void poly_rows_kernel(co
 // lanes = 4 phase quads x 16 rows — one quad per DPP row); a UNIT is the 4 x 64 / ROWS phases one wavefront-instruction covers.
 // floats per LDS row, at most: two buffers of 32 x 512 floats = 128 KB (one workgroup per CU), of 16 x 512 = 64 KB or of 32 x 288 = 72 KB (two per CU);
 // 16 x 576 for windows of 32 reads: 88.2 -> 16 kHz stages 564 floats per row
-constexpr int wide_row_floats(int rows, int waves, int nv) { return rows == 32 ? (waves == 10 ? 288 : 512) : (nv == 32 ? 576 : 512); }
+constexpr int wide_row_floats(int rows, int waves, int nv) { return rows == 32 ? (waves == 10 ? (nv == 32 ? 576 : 288) : 512) : (nv == 32 ? 576 : 512); }
 template <int ROWS, int WAVES, int NV, int SHARE, int CH>
 __device__ __forceinline__ void poly_rows_wide_body(const float *__restrict__ x, const float *__restrict__ tt, float *__restrict__ y, const PolyRowsGeom g_,
                                                     const int2 *__restrict__ gtab, const int tiles_, const int64_t m_end_, const int64_t k_lim_, const int vec_ok_, const int dbg_, const int rot) {
@@ -608,6 +608,7 @@ __device__ __forceinline__ void poly_rows_wide_body(const float *__restrict__ x,
 FA_WIDE_KERNEL(poly_rows_wide32_kernel, 32, 8, 2)        // one workgroup per CU: 2 wavefronts per SIMD, 256 registers
 FA_WIDE_KERNEL(poly_rows_wide16_kernel, 16, 8, 4)        // two per CU: 4 per SIMD, 128 registers
 FA_WIDE_KERNEL(poly_rows_wide16w10_kernel, 16, 10, 5)    // two of ten wavefronts: 5 per SIMD, 96 registers
+FA_WIDE_KERNEL(poly_rows_wide32w10l_kernel, 32, 10, 3)   // windows of 32 reads (88.2 kHz: rows of 564 floats, two buffers of 72 KB): ONE workgroup of ten wavefronts per CU, 170 registers
 FA_WIDE_KERNEL(poly_rows_wide32w10_kernel, 32, 10, 5)    // the same with 32-row tiles of one phase GROUP (rows of <= 288 floats): groups of 80 k phases = 10 k units (44.1 / 22.05 / 11.025 kHz)
 #undef FA_WIDE_KERNEL
 
@@ -758,12 +759,14 @@ bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down,
         // The 16-row form wins or ties in spite of its 2-way LDS bank conflicts (two phase quads with different window offsets share a ds_read_b128 lane group)
         struct Cand { int rows, waves; size_t budget; };
         const size_t group_budget = size_t{64} * 288 * 4;      // (rows_geometry budgets 64 rows)
-        std::vector<Cand> cands = {{16, 8, size_t{1} << 30}, {32, 10, group_budget}, {32, 8, size_t{1} << 30}};
+        // (round 6: windows of 32 reads — 88.2 kHz, 80 phases — first try 32-row tiles with ten wavefronts: 10 units of 8 phases, one per wavefront; with 16-row
+        // tiles the 5 units of 16 phases leave three of eight wavefronts without work, and those still issue their share of the LDS reads)
+        std::vector<Cand> cands = {{32, 10, size_t{1} << 30}, {16, 8, size_t{1} << 30}, {32, 10, group_budget}, {32, 8, size_t{1} << 30}};
         if (const char *e = fa::sw(fa::Sw::RESAMPLE_WIDE)) {
             int r_ = 0, w_ = 0;
             // only the instantiated forms: any other pair would reach the geometry arithmetic below (rows 0: a division by zero)
             if (sscanf(e, "%d:%d", &r_, &w_) == 2 && (r_ == 16 || r_ == 32) && (w_ == 8 || w_ == 10))
-                cands = {{r_, w_, r_ == 32 && w_ == 10 ? group_budget : size_t{1} << 30}};
+                cands = r_ == 32 && w_ == 10 ? std::vector<Cand>{{32, 10, size_t{1} << 30}, {32, 10, group_budget}} : std::vector<Cand>{{r_, w_, size_t{1} << 30}};
         }
         for (const Cand &c : cands) {
             PolyRowsGeom g2{};
@@ -771,6 +774,7 @@ bool poly_rows_build(PolyRows &R, const std::vector<float> &h, int up, int down,
             std::vector<int> gtab2;
             std::vector<float> tt2;
             if (!fa::rows_geometry(g2, nv2, h, up, down, pre_remove, gtab2, tt2, c.budget, share_max)) continue;
+            if (c.rows == 32 && c.waves == 10 && c.budget > group_budget && nv2 != 32) continue;   // the ungrouped ten-wavefront form exists for the long windows only
             if (g2.sld > wide_row_floats(c.rows, c.waves, nv2) || g2.groups > 8) continue;
             if (!(c.rows == 32 && c.waves == 10) && g2.groups != 1) continue;
             const int pu = 4 * 64 / c.rows, units = (g2.ppg + pu - 1) / pu, ch = (units + c.waves - 1) / c.waves;
@@ -803,7 +807,7 @@ void poly_rows_launch_it(fa_ctx *ctx, const PolyRows &R, const float *d_x, float
 //   44.1 -> 16 kHz: windows {16, 2}, 10 units of 16 phases or 20 of 8; 22.05 -> 16 kHz {10, 4}, 20 or 40 units; 11.025 -> 16 kHz {8, 4}, 40 units; 37.8 -> 16 kHz {16, 4}, 5 units;
 //   88.2 -> 16 kHz {32, 1} (two windows' worth of reads per phase), 5 units; other pairs: poly_rows_kernel
 #define FA_WIDE_INSTANCES(X) X(32, 8, 16, 2, 3) X(32, 8, 10, 4, 5) X(16, 8, 16, 2, 2) X(16, 8, 10, 4, 3) X(16, 8, 8, 4, 5) X(16, 8, 16, 4, 1) X(16, 8, 32, 1, 1) X(16, 10, 16, 2, 1) X(16, 10, 10, 4, 2) X(16, 10, 8, 4, 4) \
-    X(32, 10, 16, 2, 1) X(32, 10, 10, 4, 2) X(32, 10, 8, 4, 4) X(32, 10, 16, 4, 1)
+    X(32, 10, 16, 2, 1) X(32, 10, 10, 4, 2) X(32, 10, 8, 4, 4) X(32, 10, 16, 4, 1) X(32, 10, 32, 1, 1)
 bool wide_instance(int rows, int waves, int nv, int share, int ch) {
 #define FA_WIDE_IS(R_, W_, V, S, C) if (rows == R_ && waves == W_ && nv == V && share == S && ch == C) return true;
     FA_WIDE_INSTANCES(FA_WIDE_IS)
@@ -815,7 +819,7 @@ void poly_rows_wide_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, flo
     const float *tt = reinterpret_cast<const float *>(static_cast<const char *>(R.d_tables) + R.tt_offset);
     const int vec_ok = R.up % 4 == 0 && (reinterpret_cast<uintptr_t>(d_y) & 15) == 0 ? 1 : 0;
     // the resident workgroups: one (128 KB of LDS) or two (64 / 72 KB) per CU, in whole sets of 8 x groups (kernel: workgroup -> XCD, group, tile chain)
-    const int per_cu = R.wide_rows == 32 && R.wide_waves == 8 ? 1 : 2, set = 8 * R.g.groups;
+    const int per_cu = R.wide_rows == 32 && (R.wide_waves == 8 || R.nv == 32) ? 1 : 2, set = 8 * R.g.groups;
     int64_t sets = 256 * per_cu / set;
     sets = std::max<int64_t>(1, std::min<int64_t>(sets, (tiles + 7) / 8));
     const unsigned grid = static_cast<unsigned>(sets * set);
@@ -828,6 +832,7 @@ void poly_rows_wide_launch(fa_ctx *ctx, const PolyRows &R, const float *d_x, flo
 #define FA_WIDE_GO(R_, W_, V, S, C)                                                                                                                 \
     if (R.wide_rows == R_ && R.wide_waves == W_ && R.nv == V && R.g.share == S && R.ch == C) {                                                     \
         if constexpr (R_ == 32 && W_ == 8) hipLaunchKernelGGL((poly_rows_wide32_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg, rot);   \
+        else if constexpr (R_ == 32 && V == 32) hipLaunchKernelGGL((poly_rows_wide32w10l_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg, rot); \
         else if constexpr (R_ == 32) hipLaunchKernelGGL((poly_rows_wide32w10_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg, rot); \
         else if constexpr (W_ == 8) hipLaunchKernelGGL((poly_rows_wide16_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg, rot); \
         else hipLaunchKernelGGL((poly_rows_wide16w10_kernel<V, S, C>), dim3(grid), dim3(64 * W_), 0, ctx->stream, d_x, tt, d_y, R.g, gtab, n_tiles, m_end, k_lim, vec_ok, dbg, rot); \

@@ -110,7 +110,8 @@ def test_both_decimation_kernels_equal_simple_kernel(fa, gpu_ctx, switch, tiles,
 
 
 @pytest.mark.parametrize("form", ["16:8", "32:8", "32:10", "one-tile-per-workgroup"])
-@pytest.mark.parametrize("up,down,n", [(160, 441, 1000003), (160, 441, 40000), (160, 441, 15000), (320, 441, 300007), (640, 441, 150000), (80, 189, 200000)])
+@pytest.mark.parametrize("up,down,n", [(160, 441, 1000003), (160, 441, 40000), (160, 441, 15000), (320, 441, 300007), (640, 441, 150000), (80, 189, 200000),
+                                       (80, 441, 2000003), (80, 441, 30000)])   # 88.2 kHz: windows of 32 reads — 32-row tiles with ten wavefronts (round 6) / 16-row tiles
 def test_every_row_kernel_form_equals_simple_kernel(fa, switch, form, up, down, n):
     """Round 5: the persistent double-buffered row kernels (poly_rows_wide_body: 16-row tiles with two workgroups per CU — the default —, 32-row tiles with one,
     32-row tiles of one phase group with ten wavefronts; FA_RESAMPLE_WIDE picks the form when a context builds its tables) and the one-tile-per-workgroup
