@@ -75,7 +75,7 @@ class TdtConfig(C.Structure):
 
 class AhcStats(C.Structure):
     _fields_ = [("merges", C.c_int64), ("rounds", C.c_int64), ("rescans", C.c_int64), ("exact_fallback", C.c_int64),
-                ("init_ms", C.c_double), ("merge_ms", C.c_double), ("total_ms", C.c_double), ("windows", C.c_int64), ("reference_order", C.c_int64)]
+                ("init_ms", C.c_double), ("merge_ms", C.c_double), ("total_ms", C.c_double), ("windows", C.c_int64), ("reference_order", C.c_int64), ("handed_over_at", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

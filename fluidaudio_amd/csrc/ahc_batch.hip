@@ -204,7 +204,7 @@ fa_status ahc_batch_once(fa_ctx *ctx, int count, const double *const *d_data, co
     for (int k = 0; k < count; ++k) {
         Prob &p = probs[k];
         if (!p.needs_ro || p.st != FA_SUCCESS) continue;
-        p.st = ro_run_device(ctx, p.d_data, p.N, p.d, p.d_Z, stats ? &stats[k] : nullptr);
+        p.st = ro_run_device(ctx, p.d_data, p.N, p.d, p.d_Z, stats ? &stats[k] : nullptr, false, p.mode == FA_AHC_MODE_AUTO);
         if (statuses) statuses[k] = p.st;
         if (p.st != FA_SUCCESS && worst == FA_SUCCESS) worst = p.st;
     }
@@ -374,7 +374,7 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
     for (int j = 0; j < count; ++j) {   // exact ties at the minimum: those problems again, one after the other, in reference order
         Prob &p = probs[j];
         if (!p.needs_ro || p.st != FA_SUCCESS) continue;
-        p.st = ro_run_device(ctx, p.d_data, p.N, p.d, p.d_Z, stats ? &stats[ord[j]] : nullptr);
+        p.st = ro_run_device(ctx, p.d_data, p.N, p.d, p.d_Z, stats ? &stats[ord[j]] : nullptr, false, p.mode == FA_AHC_MODE_AUTO);
         if (statuses) statuses[ord[j]] = p.st;
         if (p.st != FA_SUCCESS && worst == FA_SUCCESS) worst = p.st;
     }

@@ -24,7 +24,9 @@ constexpr int kRomChunk = 256;   // coordinates per staging pass
 struct __attribute__((aligned(16))) RomPart { double v1; int32_t x1, n1; };   // smallest entry of the block by (value, node id): value, slot, node
 struct RomDev {
     int32_t heap_size, list_first, merges, op, a, b, n, done;              // fa_ro::SelT between launches
-    int32_t nan_seen, kind, scanned, sa, sb, created, pad0, pad1;          // what the next scan launch computes: the row of node `scanned` (slot sa)
+    int32_t nan_seen, kind, scanned, sa, sb, created, last_tie, tie_nonzero; // what the next scan launch computes: the row of node `scanned` (slot sa); last_tie: the
+                                                                           // row count when an exact tie was last seen (equal sums among a scan's candidates, a height equal to the
+                                                                           // previous row's, a row that went to exact sums), tie_nonzero: one of them while the merges were above height 0
     double ma, mb, dab, eps;                                               // ROM_NEW: sizes of a and b, their exact squared distance
     long long scans, exact_scans, cands, pad2;
 };
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
     sel.pair_a = w.pair_a; sel.pair_b = w.pair_b; sel.height_sq = w.height_sq;
     double best = dinf();
     int best_id = INT_MAX;
+    bool row_tie = st.kind == ROM_EXACT;       // (a row that needed exact sums of every workgroup: more than kRomCap near-ties)
     if (st.kind == ROM_EXACT) {                // the block minima are the reference's sums: lowest (value, node id)
         sel.scan_begin();
         double v = dinf();
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
         }
         if (ncand > kRomCap) {                 // too many for one wavefront: the same row by exact sums of every workgroup, then back here
             rom_sink(warm_pos); rom_sink(xs0[0]); rom_sink(warm_last.x); rom_sink(warm_chain.x); rom_sink(warm_top[0].x); rom_sink(warm_tree[0].x); rom_sink(warm_ng); rom_sink(warm_sz);
-            if (lane == 0) { st.kind = ROM_EXACT; st.exact_scans = st.exact_scans + 1; w.dev[ph ^ 1] = st; }
+            if (lane == 0) { st.kind = ROM_EXACT; st.exact_scans = st.exact_scans + 1; st.last_tie = st.merges; if (st.dab != 0.0) st.tie_nonzero = 1; w.dev[ph ^ 1] = st; }
             return;
         }
         st.cands = st.cands + ncand;
@@ -458,6 +461,7 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
                 const double sv = (mine && sum == sum) ? sum : dinf();
                 const double bm = wave_min(sv);
                 const int bi = static_cast<int>(wave_umin((mine && sv == bm && bm < dinf()) ? static_cast<unsigned>(s_cand[b0 + lane]) : static_cast<unsigned>(INT_MAX)));
+                if (bm < dinf() && (__popcll(__builtin_amdgcn_ballot_w64(mine && sv == bm)) >= 2 || (bm == best && bi != best_id))) row_tie = true;
                 if (lt2(bm, bi, best, best_id)) { best = bm; best_id = bi; }
             }
         }
@@ -489,7 +493,14 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
 #else
     sel.scan_finish(best, best_id);
 #endif
+    const double prev_height = st.dab;
+    const int prev_merges = st.merges;
     rom_prepare(st, sel, w.slot_of, w.sizes);
+    // tie bookkeeping for the host's hand-over decision (rom_run_device): this scan's candidates, and a merge at exactly the previous merge's height
+    // (tie_nonzero: a tie while the merges are at a height > 0.  Duplicated points tie — among a scan's candidates at ANY distance, two copies being equally far
+    // from everything — only until the copies have merged, and all of those merges are at height 0; a tie seen while the dendrogram is above 0 is of the other kind)
+    if (st.kind == ROM_NEW && st.merges > prev_merges && prev_merges >= 1 && st.dab == prev_height) row_tie = true;
+    if (row_tie) { st.last_tie = st.merges; if (st.dab != 0.0) st.tie_nonzero = 1; }
     st.scans = st.scans + 1;
     if (lane == 0) { w.dev[ph ^ 1] = st; if (st.done) w.dev[ph] = st; }   // the end is written to both records: every later launch of the replay returns at once
 #ifdef FA_ROM_PROFILE
@@ -507,18 +518,22 @@ __global__ __launch_bounds__(64) void rom_select(const RomWs w, const int ph) {
 namespace fa_ahc {
 // Workspace of the matrix-filtered run: the selection's arrays, then what the start-up kernels of the filter-based rounds expect (points / centroids,
 // transpose, norms, the two state records their maxima go to), the matrix last.
-struct RomLayout { size_t prof, dev, flags, part, part2, node, slot, sizes, key, ent, pos, ngh, next, prev, pa, pb, hs, z, state, norms, c, xt, m, total; };
+struct RomLayout { size_t prof, dev, flags, part, part2, node, slot, sizes, key, ent, pos, ngh, next, prev, pa, pb, hs, z, state, norms, c, xt, m, total; Layout core; };
+// What this run shares with the filter-based rounds sits WHERE THEY KEEP IT (make_layout_core with one slot per thread: state, flags, node, sizes, dendrogram,
+// norms, centroids, transpose, matrix), its own arrays behind their last byte: the rounds can take the problem over in place (prob_adopt).
 RomLayout rom_layout(size_t N, size_t Np, size_t d) {
     RomLayout L{};
-    size_t o = 0;
+    L.core = make_layout_core(N, Np, d, Np / kBlk);
+    L.state = L.core.state; L.flags = L.core.flags; L.node = L.core.node; L.sizes = L.core.sizes; L.z = L.core.z; L.norms = L.core.norms;
+    L.c = L.core.c; L.xt = L.core.xt; L.m = L.core.m;
+    size_t o = L.core.total;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~static_cast<size_t>(255); return at; };
     const size_t nblk = Np / kBlk;
-    L.dev = take(sizeof(RomDev) * 2); L.flags = take(16); L.state = take(sizeof(AhcState) * 2); L.prof = take(8 * 16);
+    L.dev = take(sizeof(RomDev) * 2); L.prof = take(8 * 16);
     L.part = take(sizeof(RomPart) * nblk); L.part2 = take(8 * nblk);
-    L.node = take(4 * Np); L.slot = take(4 * 2 * N); L.sizes = take(8 * 2 * N); L.key = take(8 * N); L.ent = take(sizeof(fa_ro::Ent) * N); L.pos = take(4 * 2 * N);
+    L.slot = take(4 * 2 * N); L.key = take(8 * N); L.ent = take(sizeof(fa_ro::Ent) * N); L.pos = take(4 * 2 * N);
     L.ngh = take(4 * 2 * N); L.next = take(4 * (2 * N + 1)); L.prev = take(4 * (2 * N + 1));
-    L.pa = take(8 * N); L.pb = take(8 * N); L.hs = take(8 * N); L.z = take(8 * 4 * N);
-    L.norms = take(8 * Np); L.c = take(8 * d * 2 * N); L.xt = take(8 * d * Np); L.m = take(8 * Np * Np);
+    L.pa = take(8 * N); L.pb = take(8 * N); L.hs = take(8 * N);
     L.total = o;
     return L;
 }
@@ -528,7 +543,18 @@ size_t rom_total_bytes(size_t N, size_t Np, size_t d) { return rom_layout(N, Np,
 // The whole problem in the reference's selection order with the matrix as the filter of its scans.  `declined` (no error recorded): the matrix cannot be
 // had, or the Gram-form start-up met a non-finite entry (infinite coordinates: the sums of the matrix-free run decide what they mean) — the caller runs
 // the matrix-free form instead.
-fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host, bool &declined) {
+// Handing the problem back (round 6).  An input whose exact ties are DUPLICATES (repeated embeddings, digital silence) ties at distance 0 only: once the copies
+// have merged, the rest of the problem has a unique closest pair at every step, and every algorithm that merges the closest pair — the reference's and the
+// filter-based rounds alike — produces the same rows.  So AUTO's tie route (may_hand_over) watches the ties go by (RomDev::last_tie / tie_nonzero) and, after
+// kRomQuiet rows without one, none of them at a distance > 0 so far, and enough rows left to pay for it, lets the rounds adopt the state in place
+// (prob_adopt: both runs keep node ids, sizes, centroids, matrix and dendrogram in the same arrays) at 5 us per row instead of 12.8.  The rounds detect an
+// exact tie at the minimum themselves (need_exact): should one still come, the whole problem is run again in reference order WITHOUT handing over —
+// slower than never having tried, never different from the reference.  Inputs that tie at distances > 0 (quantised embeddings) stay in reference order.
+constexpr int kRomQuiet = 1024, kRomMinRest = 4096;
+
+fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host, bool &declined, bool may_hand_over,
+                         bool &tie_after_hand_over) {
+    tie_after_hand_over = false;
     declined = true;
     if (N < 2 || d * sizeof(double) > 60 * 1024) return FA_SUCCESS;
     const size_t Np = (N + kBlk - 1) / kBlk * kBlk, nblk = Np / kBlk;
@@ -559,7 +585,9 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     FA_TRY(ctx_events(ctx, ev));                // the context's own three events (created once, destroyed with the context)
     FA_HIP_TRY(ctx, hipEventRecord(ev[0], st));
     // ---- start-up: the reference's nearest lower-indexed neighbours (exact sums), and the Gram-form matrix of all pairs
-    FA_HIP_TRY(ctx, hipMemsetAsync(base + L.dev, 0, L.part - L.dev, st));              // RomDev, flags, the two state records (their maxima start at 0)
+    FA_HIP_TRY(ctx, hipMemsetAsync(base + L.dev, 0, L.part - L.dev, st));              // RomDev, the profile counters
+    FA_HIP_TRY(ctx, hipMemsetAsync(base + L.flags, 0, 16, st));
+    FA_HIP_TRY(ctx, hipMemsetAsync(base + L.state, 0, sizeof(AhcState) * 2, st));      // the two state records (the start-up's maxima start at 0)
     FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, st));
     ro_launch_init(st, rw, std::max(Np, 2 * N));
     startup_transpose(st, d_data, w.XT, w.N, w.Np, w.d);
@@ -626,6 +654,36 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
         FA_TRY(rg.replay(ctx, launch));
         FA_HIP_TRY(ctx, hipMemcpyAsync(&hd, w.dev, sizeof(hd), hipMemcpyDeviceToHost, st));
         FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (fa::sw(fa::Sw::AHC_DEBUG) && (it % 8 == 0 || hd.done))
+            fprintf(stderr, "ahc (reference order): replay %lld rows %d last tie at %d nonzero %d scans %lld exact %lld\n", it, hd.merges, hd.last_tie, hd.tie_nonzero, hd.scans, hd.exact_scans);
+        if (may_hand_over && !hd.done && !hd.nan_seen && !hd.tie_nonzero && hd.merges >= 1 && hd.merges - hd.last_tie >= kRomQuiet &&
+            static_cast<long long>(N) - 1 - hd.merges >= kRomMinRest && hd.kind != ROM_EXACT) {
+            // the state of a replay boundary sits in dev[0] (a replay is an even number of launch pairs).  A merge that is decided but not applied yet (ROM_NEW
+            // pending: its row, node id, size and centroid are the next scan's work) is applied by that scan; its column copies stay unwritten, which is
+            // what prob_adopt's sym_limit says.
+            if (hd.kind == ROM_NEW) hipLaunchKernelGGL(rom_scan, dim3(w.nblk + 1), dim3(kBlk), lds, st, w, 0);
+            Prob p;
+            p.N = N; p.d = d; p.Np = Np; p.cpt = 1; p.d_data = d_data; p.d_Z = d_Z; p.mode = FA_AHC_MODE_AUTO; p.z_on_host = z_on_host;
+            p.L = L.core;
+            prob_bind(p, base);
+            FA_TRY(prob_adopt(ctx, p, hd.merges, hd.eps, w.pair_a, w.pair_b));
+            FA_TRY(prob_run_rounds(ctx, p));
+            if (p.needs_ro) { tie_after_hand_over = true; return FA_SUCCESS; }   // an exact tie after all: the caller runs the problem again, in reference order to the end
+            FA_HIP_TRY(ctx, hipEventRecord(ev[2], st));
+            FA_HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (fa::sw(fa::Sw::AHC_DEBUG))
+                fprintf(stderr, "ahc (reference order, matrix filter): N %zu handed over to the rounds after %d rows (%lld scans), last tie at row %d; %lld rounds\n", N, hd.merges,
+                        hd.scans, hd.last_tie, static_cast<long long>(p.h.rounds));
+            if (stats) {
+                float t01 = 0, t12 = 0;
+                (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+                (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+                stats->merges = p.h.step; stats->rounds += hd.scans + hd.exact_scans + p.h.rounds; if (!stats->reference_order) stats->reference_order = 1;
+                stats->rescans += hd.exact_scans + p.h.rescans; stats->windows += p.h.windows; stats->handed_over_at = hd.merges;
+                stats->init_ms += t01; stats->merge_ms += t12; stats->total_ms += t01 + t12;
+            }
+            return FA_SUCCESS;
+        }
     }
     if (hd.nan_seen == 1) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: NaN distance");
     if (!hd.done || hd.nan_seen || hd.merges != static_cast<int32_t>(N) - 1) return fa::set_error(ctx, FA_RUNTIME_ERROR, "ahc: reference-order run stopped at row %d", hd.merges);
@@ -656,10 +714,16 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
 }
 
 // The reference-order run: through the matrix filter when the workspace is to be had, matrix-free (O(N d) memory, O(A d) sums per row) when not.
-fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host) {
+fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host, bool may_hand_over) {
     if (!fa::sw_on(fa::Sw::AHC_RO_NO_MATRIX)) {
-        bool declined = false;
-        const fa_status st = rom_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host, declined);
+        bool declined = false, tie_again = false;
+        const fa_ahc_stats before = stats ? *stats : fa_ahc_stats{};
+        fa_status st = rom_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host, declined, may_hand_over && !fa::sw_on(fa::Sw::AHC_RO_NO_HANDOVER), tie_again);
+        if (!declined && st == FA_SUCCESS && tie_again) {   // the rounds met an exact tie after the hand-over: once more, in reference order to the last row
+            if (stats) *stats = before;
+            st = rom_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host, declined, false, tie_again);
+            if (stats && !declined) stats->handed_over_at = -1;
+        }
         if (!declined) return st;
     }
     return ro_run_device_mf(ctx, d_data, N, d, d_Z, stats, z_on_host);

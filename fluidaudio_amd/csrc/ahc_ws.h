@@ -223,9 +223,12 @@ struct Layout {
     size_t state, cnt, flags, prof, c, xt, row, e2, node, sizes, z, reca, reci, recs, recp, cand, pairs, norms, m, part_vs, part_ix, total;
 };
 
-size_t rom_total_bytes(size_t N, size_t Np, size_t d);   // workspace of the matrix-filtered reference-order run (below)
+size_t rom_total_bytes(size_t N, size_t Np, size_t d);   // workspace of the matrix-filtered reference-order run (ahc_rom.hip)
 
-inline Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
+// The arrays of the filter-based rounds.  `total` here is their end; make_layout() below adds what the reference-order run keeps BEHIND them (it shares
+// these arrays — state, flags, node, sizes, centroids, transpose, norms, matrix, dendrogram — so that a run in reference order can hand its problem back to
+// the rounds in place: ahc_rom.hip, prob_adopt).
+inline Layout make_layout_core(size_t N, size_t Np, size_t d, size_t nblk) {
     Layout L{};
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~static_cast<size_t>(255); return at; };
@@ -250,7 +253,12 @@ inline Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
     L.m = take(sizeof(double) * Np * Np);
     L.part_vs = take(sizeof(double2) * (Np / GT) * Np);   // per-tile row minima of the Gram start-up (0.13 % of the matrix each)
     L.part_ix = take(sizeof(int32_t) * (Np / GT) * Np);
-    L.total = std::max(o, rom_total_bytes(N, Np, d));   // a run that meets an exact tie continues in reference order in the SAME workspace (no second hipMalloc of N^2 * 8 B)
+    L.total = o;
+    return L;
+}
+inline Layout make_layout(size_t N, size_t Np, size_t d, size_t nblk) {
+    Layout L = make_layout_core(N, Np, d, nblk);
+    L.total = std::max(L.total, rom_total_bytes(N, Np, d));   // a run that meets an exact tie continues in reference order in the SAME workspace (no second hipMalloc of N^2 * 8 B)
     return L;
 }
 
@@ -327,7 +335,15 @@ fa_status startup_gram(fa_ctx *ctx, hipStream_t st, const Ws &gw, double *d_norm
 // ahc_rounds.hip
 void window_counter_init(WinCounters (&c)[4]);
 fa_status prob_check_shape(fa_ctx *ctx, size_t N, size_t d);
-fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base);
+void prob_bind(Prob &p, char *base);                      // p.w = the arrays of p.L at `base` (no device work)
+fa_status prob_setup(fa_ctx *ctx, Prob &p, char *base);   // prob_bind + the start-up kernels
+// The rounds of a problem whose workspace is bound and whose device state is ready (prob_setup, or prob_adopt): replays of the round graph until the device
+// reports the end or halts, then the exact heights and the dendrogram to p.d_Z — unless p.needs_ro (an exact tie: the caller recomputes in reference order).
+fa_status prob_run_rounds(fa_ctx *ctx, Prob &p);
+// Adopt a clustering in progress (the reference-order run hands its problem back, ahc_rom.hip): `merges` merges are done — node[], sizes[], centroids and
+// a matrix that holds BOTH copies of every live pair among nodes below N + merges - 1 (the newest node's row is valid, its column may not be) are in
+// place, the merged pairs (node ids) in pair_a / pair_b.  Builds the row states, the state record, the block records and the first `merges` dendrogram rows.
+fa_status prob_adopt(fa_ctx *ctx, Prob &p, int merges, double eps, const double *pair_a, const double *pair_b);
 fa_status prob_after_replay(fa_ctx *ctx, Prob &p);
 fa_status prob_finish(fa_ctx *ctx, Prob &p);
 struct CachedGraph {   // the round launches of one problem shape, kept in the context between calls
@@ -341,7 +357,8 @@ void cached_graph_free(void *p);
 fa_status ctx_events(fa_ctx *ctx, hipEvent_t (&ev)[3]);   // the three timing events a context keeps
 // ahc_ro.hip / ahc_rom.hip
 fa_status ro_run_device_mf(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host = false);
-fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host = false);
+// may_hand_over: the caller is AUTO's tie route — once the ties have stopped the rest of the problem may go back to the filter-based rounds (ahc_rom.hip)
+fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host = false, bool may_hand_over = false);
 size_t rom_total_bytes(size_t N, size_t Np, size_t d);   // workspace of the matrix-filtered reference-order run
 void ro_launch_init(hipStream_t st, const RoWs &w, size_t threads);
 void ro_launch_lower_minima_direct(hipStream_t st, const RoWs &w);

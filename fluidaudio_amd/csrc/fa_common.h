@@ -120,7 +120,7 @@ bool fault_hit(int site);
 #define FA_SWITCHES(ROUTE, AB)                                                                                                       \
     ROUTE(HIP_WORKSPACE_LIMIT, "FLUIDAUDIO_HIP_WORKSPACE_LIMIT") ROUTE(HIP_DEVICES, "FLUIDAUDIO_HIP_DEVICES") ROUTE(HIP_DEVICE, "FLUIDAUDIO_HIP_DEVICE") \
     ROUTE(AHC_CPT, "FA_AHC_CPT") ROUTE(AHC_NO_SINGLE_BLOCK, "FA_AHC_NO_SINGLE_BLOCK") ROUTE(AHC_NO_UNIFORM, "FA_AHC_NO_UNIFORM")      \
-    ROUTE(AHC_RO_NO_MATRIX, "FA_AHC_RO_NO_MATRIX") ROUTE(AHC_UNI_CPT, "FA_AHC_UNI_CPT") ROUTE(AHC_UNI_GROUPS, "FA_AHC_UNI_GROUPS")    \
+    ROUTE(AHC_RO_NO_MATRIX, "FA_AHC_RO_NO_MATRIX") ROUTE(AHC_RO_NO_HANDOVER, "FA_AHC_RO_NO_HANDOVER") ROUTE(AHC_UNI_CPT, "FA_AHC_UNI_CPT") ROUTE(AHC_UNI_GROUPS, "FA_AHC_UNI_GROUPS")    \
     ROUTE(AHC_UNI_WAVES, "FA_AHC_UNI_WAVES") ROUTE(AHC_IN_FLIGHT, "FA_AHC_IN_FLIGHT") ROUTE(AHC_DEBUG, "FA_AHC_DEBUG")                \
     ROUTE(MEL_GENERIC, "FA_MEL_GENERIC") ROUTE(MEL_SLICE_MB, "FA_MEL_SLICE_MB") ROUTE(VBX_NO_TILED, "FA_VBX_NO_TILED")                \
     ROUTE(RESAMPLE_SIMPLE, "FA_RESAMPLE_SIMPLE") ROUTE(RESAMPLE_NO_DECIM, "FA_RESAMPLE_NO_DECIM")                                     \

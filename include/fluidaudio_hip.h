@@ -85,6 +85,7 @@ const char *fa_version(void);
  *   FA_AHC_NO_SINGLE_BLOCK                   problems of <= 512 points through the multi-block chain
  *   FA_AHC_NO_UNIFORM, FA_AHC_IN_FLIGHT, FA_AHC_UNI_GROUPS=1..4, FA_AHC_UNI_WAVES=6|8   how a batch of problems is laid over launches / streams
  *   FA_AHC_RO_NO_MATRIX                      the reference-order run without the N x N filter matrix (O(N d) memory, like the reference)
+ *   FA_AHC_RO_NO_HANDOVER                    AUTO's tie route stays in reference order to the last row (no hand-over to the rounds once the ties have stopped)
  *   FA_AHC_DEBUG                             one line of statistics per linkage call on stderr
  *   FA_MEL_GENERIC, FA_MEL_SLICE_MB=n        the generic mel kernel; slice size of host-pointer batches
  *   FA_VBX_NO_TILED                          the untiled VBx iteration
@@ -317,6 +318,8 @@ typedef struct {
     int64_t reference_order; /* 1 if the run met an EXACT tie at the minimum (or was asked to) and was computed in the reference's own
                               * selection order (binary heap + index-ordered scans, fastcluster_internal.hpp:778-935,1625-1800):
                               * row for row the reference's output on tied input; `rounds` then counts its scans */
+    int64_t handed_over_at;  /* AUTO's tie route: rows computed in reference order before the rest of the problem went back to the filter-based rounds
+                              * (ties at distance 0 only — duplicates — that had stopped); 0: not handed over, -1: handed over, met a tie, recomputed */
 } fa_ahc_stats;
 
 enum { FA_AHC_MODE_AUTO = 0,   /* Lance-Williams filter + exact re-verification; an exact tie at the minimum (or a window overflowing
