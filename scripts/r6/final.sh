@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 6, final pass on the committed tree: the GPU suite (release + poisoned workspace), smoke(), PMC passes for the present sources of the round kernel,
+# the resampler's six rates and the TDT walk, the bench in the driver's command form, the kernel trace of the headline step
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/r6 gpurun_out/summary
+export TMPDIR=/tmp
+( time python -m pytest tests -q -m gpu -p no:cacheprovider ) > gpurun_out/r6/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 4 gpurun_out/r6/pytest.log | cut -c1-300
+( time FLUIDAUDIO_HIP_LIBRARY=$PWD/fluidaudio_amd/csrc/libfluidaudio_hip_poison.so python -m pytest tests -q -m gpu -p no:cacheprovider ) > gpurun_out/r6/pytest_poison.log 2>&1; echo "pytest poison rc=$?"; tail -n 4 gpurun_out/r6/pytest_poison.log | cut -c1-300
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -n 2
+bash scripts/gpu_pmc_kernel.sh ahc_round ahc_round_t "ahc_round_body.h ahc_ws.h ahc_rounds.hip" python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --skip-mel --skip-ctc --skip-cpu --skip-ahc --skip-e2e --skip-beam --skip-resample 2>&1 | tail -n 2 | cut -c1-600
+bash scripts/r6/resample_pmc.sh 2>&1 | grep -v "rc=0" | cut -c1-400
+FA_PROBE=tdt bash scripts/gpu_pmc_kernel.sh tdt tdt_logits_fits_kernel "tdt.hip" python $GRAFT_REPO_ROOT/scripts/r4_kernels_probe.py 2>&1 | tail -n 1 | cut -c1-400
+( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/r6/bench.out 2> gpurun_out/r6/bench.err; echo "bench rc=$?"; tail -n 3 gpurun_out/r6/bench.err
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_e2e" -o e2e -- python "$GRAFT_REPO_ROOT/bench.py" --steps 2 --warmup 1 --skip-mel --skip-ahc --skip-ctc --skip-cpu --skip-e2e --skip-beam --skip-resample ) > gpurun_out/r6/rocprof_e2e.log 2>&1; echo "rocprof rc=$?"
+python scripts/rocprof_summary.py $(find gpurun_out/prof_e2e -name "*.db" | head -n 1) --top 14 | tee gpurun_out/summary/r06_e2e_kernel_stats.txt | cut -c1-200
+rm -rf gpurun_out/prof_e2e
+tail -n 1 gpurun_out/r6/bench.out | cut -c1-2500
