@@ -507,7 +507,7 @@ __device__ __forceinline__ void poly_rows_wide_body(const float *__restrict__ x,
     float st_acc[CH][4];
     int st_tile = -1;
     typedef float f4v __attribute__((ext_vector_type(4)));
-    constexpr int AHEAD = WAVES == 10 ? 1 : (ROWS == 32 ? 3 : 2), RING = AHEAD + 1;    // pieces read ahead (two workgroups per CU: 4 - 5 wavefronts per SIMD cover each other, and 128 / 96 registers are all there is)
+    constexpr int AHEAD = (WAVES == 10 && NV != 32) ? 1 : (ROWS == 32 ? 3 : 2), RING = AHEAD + 1;    // pieces read ahead (two workgroups per CU: 4 - 5 wavefronts per SIMD cover each other, and 128 / 96 registers are all there is; the long-window ten-wavefront instance is ONE workgroup per CU with 170 registers: three ahead, 0.530 -> 0.512 ms at 88.2 kHz)
     f4v xq[RING][4] = {};                                   // the ring of window quarters (see the arithmetic below)
     auto flush = [&]() {
         if (st_tile < 0) return;
