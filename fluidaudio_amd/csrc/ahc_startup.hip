@@ -527,7 +527,6 @@ __global__ __launch_bounds__(256) void ahc_row_minima_parts(Ws w, const double2 
     MinAcc a;
     a.v = dinf(); a.s = dinf(); a.i = INT_MAX;
     const size_t npz = static_cast<size_t>(w.Np);
-#pragma unroll 8
     for (int t = share; t < nT; t += 4) {
         const double2 vs = part_vs[t * npz + i];
         MinAcc o; o.v = vs.x; o.s = vs.y; o.i = part_ix[t * npz + i];
