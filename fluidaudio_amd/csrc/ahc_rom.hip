@@ -553,7 +553,7 @@ size_t rom_total_bytes(size_t N, size_t Np, size_t d) { return rom_layout(N, Np,
 constexpr int kRomQuiet = 1024, kRomMinRest = 4096;
 
 fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host, bool &declined, bool may_hand_over,
-                         bool &tie_after_hand_over) {
+                         bool &tie_after_hand_over, bool matrix_ready = false) {
     tie_after_hand_over = false;
     declined = true;
     if (N < 2 || d * sizeof(double) > 60 * 1024) return FA_SUCCESS;
@@ -587,13 +587,17 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
     // ---- start-up: the reference's nearest lower-indexed neighbours (exact sums), and the Gram-form matrix of all pairs
     FA_HIP_TRY(ctx, hipMemsetAsync(base + L.dev, 0, L.part - L.dev, st));              // RomDev, the profile counters
     FA_HIP_TRY(ctx, hipMemsetAsync(base + L.flags, 0, 16, st));
-    FA_HIP_TRY(ctx, hipMemsetAsync(base + L.state, 0, sizeof(AhcState) * 2, st));      // the two state records (the start-up's maxima start at 0)
-    FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, st));
+    // matrix_ready (AUTO's attempt halted before its first merge, in these very arrays): points, transpose, norms, Gram-form matrix and the start-up's maxima
+    // (the cold part of state[0], which the rounds never write) are what this start-up would compute again — 10.6 of its 14 ms at 43 200 x 256
+    if (!matrix_ready) {
+        FA_HIP_TRY(ctx, hipMemsetAsync(base + L.state, 0, sizeof(AhcState) * 2, st));  // the two state records (the start-up's maxima start at 0)
+        FA_HIP_TRY(ctx, hipMemcpyAsync(w.C, d_data, sizeof(double) * N * d, hipMemcpyDeviceToDevice, st));
+    }
     ro_launch_init(st, rw, std::max(Np, 2 * N));
-    startup_transpose(st, d_data, w.XT, w.N, w.Np, w.d);
+    if (!matrix_ready) startup_transpose(st, d_data, w.XT, w.N, w.Np, w.d);
     const bool direct_start = fa::sw_on(fa::Sw::AHC_ROM_DIRECT_START);   // the start-up of the matrix-free run (all N^2 / 2 exact sums) for A/B
     if (direct_start) ro_launch_lower_minima_direct(st, rw);
-    FA_TRY(startup_gram(ctx, st, gw, d_norms));
+    if (!matrix_ready) FA_TRY(startup_gram(ctx, st, gw, d_norms));
     if (!direct_start) hipLaunchKernelGGL(rom_lower_minima, dim3(static_cast<unsigned>(N - 1)), dim3(kBlk), 0, st, w, gw.state, rw.key);
     FA_HIP_TRY(ctx, hipGetLastError());
     // ---- the heap over points 1 .. N-1, the list, the first pair: host (the selection logic is the same header on both sides)
@@ -714,11 +718,11 @@ fa_status rom_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, 
 }
 
 // The reference-order run: through the matrix filter when the workspace is to be had, matrix-free (O(N d) memory, O(A d) sums per row) when not.
-fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host, bool may_hand_over) {
+fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host, bool may_hand_over, bool matrix_ready) {
     if (!fa::sw_on(fa::Sw::AHC_RO_NO_MATRIX)) {
         bool declined = false, tie_again = false;
         const fa_ahc_stats before = stats ? *stats : fa_ahc_stats{};
-        fa_status st = rom_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host, declined, may_hand_over && !fa::sw_on(fa::Sw::AHC_RO_NO_HANDOVER), tie_again);
+        fa_status st = rom_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host, declined, may_hand_over && !fa::sw_on(fa::Sw::AHC_RO_NO_HANDOVER), tie_again, matrix_ready);
         if (!declined && st == FA_SUCCESS && tie_again) {   // the rounds met an exact tie after the hand-over: once more, in reference order to the last row
             if (stats) *stats = before;
             st = rom_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host, declined, false, tie_again);

@@ -358,7 +358,10 @@ fa_status ctx_events(fa_ctx *ctx, hipEvent_t (&ev)[3]);   // the three timing ev
 // ahc_ro.hip / ahc_rom.hip
 fa_status ro_run_device_mf(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host = false);
 // may_hand_over: the caller is AUTO's tie route — once the ties have stopped the rest of the problem may go back to the filter-based rounds (ahc_rom.hip)
-fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host = false, bool may_hand_over = false);
+// matrix_ready: the caller's filter-based attempt halted before its first merge in this very workspace (one slot per thread, Gram-form start-up): transpose, norms,
+// matrix and the start-up's maxima are in place — the reference-order start-up does not build them again
+fa_status ro_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t d, double *d_Z, fa_ahc_stats *stats, bool z_on_host = false, bool may_hand_over = false,
+                        bool matrix_ready = false);
 size_t rom_total_bytes(size_t N, size_t Np, size_t d);   // workspace of the matrix-filtered reference-order run
 void ro_launch_init(hipStream_t st, const RoWs &w, size_t threads);
 void ro_launch_lower_minima_direct(hipStream_t st, const RoWs &w);
