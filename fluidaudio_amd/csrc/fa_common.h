@@ -126,7 +126,7 @@ bool fault_hit(int site);
     ROUTE(RESAMPLE_SIMPLE, "FA_RESAMPLE_SIMPLE") ROUTE(RESAMPLE_NO_DECIM, "FA_RESAMPLE_NO_DECIM")                                     \
     ROUTE(RESAMPLE_NO_DECIM_TILES, "FA_RESAMPLE_NO_DECIM_TILES") ROUTE(RESAMPLE_NO_ROWS, "FA_RESAMPLE_NO_ROWS")                       \
     ROUTE(RESAMPLE_NO_WIDE, "FA_RESAMPLE_NO_WIDE") ROUTE(RESAMPLE_WIDE, "FA_RESAMPLE_WIDE")                                           \
-    AB(AHC_GRAM_V1, "FA_AHC_GRAM_V1") AB(AHC_GRAM_STAGGER, "FA_AHC_GRAM_STAGGER") AB(AHC_NO_MATRIX_FREE, "FA_AHC_NO_MATRIX_FREE") AB(AHC_ROM_DIRECT_START, "FA_AHC_ROM_DIRECT_START") \
+    AB(AHC_GRAM_V1, "FA_AHC_GRAM_V1") AB(AHC_NO_MATRIX_FREE, "FA_AHC_NO_MATRIX_FREE") AB(AHC_ROM_DIRECT_START, "FA_AHC_ROM_DIRECT_START") \
     AB(AHC_ROUND_BIG, "FA_AHC_ROUND_BIG") AB(BEAM_PROF, "FA_BEAM_PROF") AB(CENTROID_SIMPLE, "FA_CENTROID_SIMPLE")                     \
     AB(MEL_NO_EZ, "FA_MEL_NO_EZ") AB(MEL_PRIO, "FA_MEL_PRIO") AB(MEL_PROF, "FA_MEL_PROF") AB(MEL_ROUNDS, "FA_MEL_ROUNDS")             \
     AB(MEL_SCALAR, "FA_MEL_SCALAR") AB(MEL_V4, "FA_MEL_V4") AB(MEL_V4_DEEP, "FA_MEL_V4_DEEP") AB(MEL_V4_LDS_PAD, "FA_MEL_V4_LDS_PAD") \
