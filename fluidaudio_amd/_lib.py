@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = [
     "fa_vbx_shard_slices", "fa_vbx_shard_range", "fa_vbx_shard_chunk_doubles", "fa_vbx_shard_create", "fa_vbx_shard_destroy",
     "fa_vbx_shard_frames", "fa_vbx_shard_begin", "fa_vbx_shard_iterate", "fa_vbx_shard_finish_iteration", "fa_vbx_shard_result",
     "fa_vbx_weighted_centroids", "fa_assign_cosine", "fa_centroid_scores", "fa_constrained_assign",
-    "fa_offline_cluster_default_config", "fa_offline_cluster", "fa_offline_cluster_ex", "fa_offline_cluster_batch",
+    "fa_offline_cluster_default_config", "fa_offline_cluster", "fa_offline_cluster_ex", "fa_offline_cluster_batch", "fa_offline_cluster_batch_dev",
     "fa_arpa_parse", "fa_arpa_destroy", "fa_arpa_unigram_count", "fa_arpa_bigram_context_count", "fa_arpa_score",
     "fa_ctc_vocab_create", "fa_ctc_vocab_destroy", "fa_ctc_beam_search_batch_dev", "fa_ctc_beam_search_batch",
     "fa_wav_pcm16_size", "fa_wav_encode_pcm16", "fa_wav_decode", "fa_rttm_parse", "fa_rttm_format", "fa_export_embeddings_json",
@@ -263,6 +263,7 @@ def lib() -> C.CDLL:
     L.fa_resample_poly.argtypes = [vp, vp, i64, i32, i32, vp, i64, C.POINTER(i64)]
     L.fa_resample_poly_dev.argtypes = [vp, vp, i64, i32, i32, vp, i64, C.POINTER(i64)]
     L.fa_offline_cluster_batch.argtypes = [vp, i32, vp, vp, i32, vp, i32, vp, vp, C.POINTER(OfflineClusterConfig), vp, vp, i32, vp, vp, vp]
+    L.fa_offline_cluster_batch_dev.argtypes = L.fa_offline_cluster_batch.argtypes
     L.fa_device_count.argtypes = [C.POINTER(i32)]
     L.fa_pool_create.argtypes = [vp, i32, C.POINTER(vp)]
     L.fa_pool_destroy.argtypes = [vp]

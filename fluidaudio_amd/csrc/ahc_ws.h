@@ -31,7 +31,10 @@ namespace fa_ahc {
 constexpr int kBlk = FA_AHC_BLK;   // rows per block record == threads per round workgroup (512 measured: see profiles/r03_ahc_variants.txt)
 constexpr int kWaves = kBlk / 64;
 constexpr int kMaxBlocks = 768;    // N <= 196 608 (N^2 * 8 B = 288 GB is reached at N ~ 190 000)
-constexpr int kRoundsPerGraph = 512;  // multiple of 4 (counter rotation) and of 2 (parity)
+#ifndef FA_AHC_ROUNDS_PER_GRAPH
+#define FA_AHC_ROUNDS_PER_GRAPH 512
+#endif
+constexpr int kRoundsPerGraph = FA_AHC_ROUNDS_PER_GRAPH;  // multiple of 4 (counter rotation) and of 2 (parity)
 constexpr int kMaxCand = 64;       // candidate rows inside an ambiguity window
 constexpr int kMaxPairs = 1024;    // matrix entries inside an ambiguity window
 constexpr int kDead = INT_MAX;     // node id of an empty slot

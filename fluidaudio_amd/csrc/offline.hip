@@ -345,19 +345,24 @@ fa_status fa_offline_cluster_ex(fa_ctx *ctx, const float *embeddings, int64_t n,
     });
 }
 
-fa_status fa_offline_cluster_batch(fa_ctx *ctx, int32_t count, const float *const *embeddings, const int64_t *n, int32_t d, const double *const *rho,
-                                   int32_t rho_dim, const int32_t *const *chunk_indices, const double *phi, const fa_offline_cluster_config *config,
-                                   int32_t *const *labels, double *const *centroids, int32_t max_centroids, int32_t *n_centroids,
-                                   fa_offline_cluster_info *infos, int32_t *statuses) {
+}  // extern "C"
+
+namespace {
+fa_status cluster_batch(fa_ctx *ctx, int32_t count, const float *const *embeddings, const int64_t *n, int32_t d, const double *const *rho,
+                        int32_t rho_dim, const int32_t *const *chunk_indices, const double *phi, const fa_offline_cluster_config *config,
+                        const int32_t device_pointers, int32_t *const *labels, double *const *centroids, int32_t max_centroids, int32_t *n_centroids,
+                        fa_offline_cluster_info *infos, int32_t *statuses) {
     if (!ctx || count < 0 || (count > 0 && (!embeddings || !n || !labels || !n_centroids || !config))) return FA_INVALID_ARGUMENT;
     if (count == 0) return FA_SUCCESS;
     fa::DeviceGuard guard(ctx->device);
     return guarded(ctx, [&]() -> fa_status {
+        // device-resident inputs were produced on the caller's stream; the recordings are prepared on the workers' streams
+        if (device_pointers) FA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         std::vector<ClusterJob> jobs;
         jobs.reserve(static_cast<size_t>(count));   // the jobs own device buffers: they must never be copied after prepare()
         std::vector<fa_status> st(static_cast<size_t>(count), FA_SUCCESS);
         for (int32_t r = 0; r < count; ++r) {
-            jobs.push_back(ClusterJob{ctx, embeddings[r], n[r], d, rho ? rho[r] : nullptr, rho_dim, chunk_indices ? chunk_indices[r] : nullptr, phi, config, 0,
+            jobs.push_back(ClusterJob{ctx, embeddings[r], n[r], d, rho ? rho[r] : nullptr, rho_dim, chunk_indices ? chunk_indices[r] : nullptr, phi, config, device_pointers,
                                       labels[r], centroids ? centroids[r] : nullptr, max_centroids, &n_centroids[r], infos ? &infos[r] : nullptr});
             st[r] = jobs.back().check_args();
         }
@@ -423,6 +428,23 @@ fa_status fa_offline_cluster_batch(fa_ctx *ctx, int32_t count, const float *cons
         }
         return first;
     });
+}
+}  // namespace
+
+extern "C" {
+
+fa_status fa_offline_cluster_batch(fa_ctx *ctx, int32_t count, const float *const *embeddings, const int64_t *n, int32_t d, const double *const *rho,
+                                   int32_t rho_dim, const int32_t *const *chunk_indices, const double *phi, const fa_offline_cluster_config *config,
+                                   int32_t *const *labels, double *const *centroids, int32_t max_centroids, int32_t *n_centroids,
+                                   fa_offline_cluster_info *infos, int32_t *statuses) {
+    return cluster_batch(ctx, count, embeddings, n, d, rho, rho_dim, chunk_indices, phi, config, 0, labels, centroids, max_centroids, n_centroids, infos, statuses);
+}
+
+fa_status fa_offline_cluster_batch_dev(fa_ctx *ctx, int32_t count, const float *const *d_embeddings, const int64_t *n, int32_t d, const double *const *d_rho,
+                                       int32_t rho_dim, const int32_t *const *chunk_indices, const double *phi, const fa_offline_cluster_config *config,
+                                       int32_t *const *labels, double *const *centroids, int32_t max_centroids, int32_t *n_centroids,
+                                       fa_offline_cluster_info *infos, int32_t *statuses) {
+    return cluster_batch(ctx, count, d_embeddings, n, d, d_rho, rho_dim, chunk_indices, phi, config, 1, labels, centroids, max_centroids, n_centroids, infos, statuses);
 }
 
 }  // extern "C"

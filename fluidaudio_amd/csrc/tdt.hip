@@ -336,16 +336,26 @@ __device__ __forceinline__ float tdt_low8_max(float v) {   // over lanes 0 .. 7
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 7));
 }
 
-template <bool F16>
+// PAIRS (fp16 rows whose every row starts on a 4-byte boundary): a lane's request is a PAIR of neighbouring logits (one dword), nine requests of 256 bytes
+// per row instead of seventeen of 128 — round 6: with one request per half the fp16 walk was SLOWER than the fp32 walk of the same chunks (0.179 against
+// 0.155 ms for 1 024 chunks) although it moves half the bytes.  Element e of piece j of lane l is logit 2 (l + 64 j) + e.
+template <bool F16, bool PAIRS = false>
 __global__ __launch_bounds__(64) void tdt_logits_fits_kernel(const TdtArgs a, const TdtLogitArgs g) {
+    static_assert(F16 || !PAIRS, "pairs are two halves in a dword");
     using E = std::conditional_t<F16, __half, float>;
-    constexpr int kP = 17;
+    constexpr int kP = PAIRS ? 18 : 17;          // logits per lane
+    constexpr int kReq = PAIRS ? 9 : 17;         // requests per lane
     const int b = blockIdx.x, lane = threadIdx.x;
     const int64_t tb = static_cast<int64_t>(b) * a.U * a.T;
     const int last_k = g.V1 - 1;
-    unsigned off[kP];
+    auto index_of = [lane](const int j) { return PAIRS ? 2 * (lane + 64 * (j >> 1)) + (j & 1) : lane + 64 * j; };
+    unsigned off[kReq];
 #pragma unroll
-    for (int j = 0; j < kP; ++j) { const int k = lane + 64 * j; off[j] = static_cast<unsigned>(k < last_k ? k : last_k) * static_cast<unsigned>(sizeof(E)); }
+    for (int j = 0; j < kReq; ++j) {
+        const int k = PAIRS ? 2 * (lane + 64 * j) : lane + 64 * j;
+        const int kc = PAIRS ? (k < (last_k & ~1) ? k : (last_k & ~1)) : (k < last_k ? k : last_k);   // beyond the row: its last request again (see above)
+        off[j] = static_cast<unsigned>(kc) * static_cast<unsigned>(sizeof(E));
+    }
     const unsigned doff = static_cast<unsigned>(g.V1 + (lane < g.nd ? lane : g.nd - 1)) * static_cast<unsigned>(sizeof(E));
     const int row_bytes = (g.V1 + g.nd) * static_cast<int>(sizeof(E));
     float v[kP];   // fp16 rows are widened as they arrive (LogitsArgmax.swift:31-55 widens fp16 logits before the scan): one conversion per element —
@@ -360,8 +370,20 @@ __global__ __launch_bounds__(64) void tdt_logits_fits_kernel(const TdtArgs a, co
             else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, static_cast<int>(byte_off), 0, 0));
         };
         const float dve = fetch(doff);                                         // the duration logits travel with the row
+        if constexpr (PAIRS) {
+            unsigned w2[kReq];
 #pragma unroll
-        for (int j = 0; j < kP; ++j) v[j] = fetch(off[j]);
+            for (int j = 0; j < kReq; ++j) w2[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, static_cast<int>(off[j]), 0, 0);
+#pragma unroll
+            for (int j = 0; j < kReq; ++j) {
+                v[2 * j] = __half2float(__ushort_as_half(static_cast<unsigned short>(w2[j] & 0xffffu)));
+                const float hi = __half2float(__ushort_as_half(static_cast<unsigned short>(w2[j] >> 16)));
+                v[2 * j + 1] = index_of(2 * j + 1) <= last_k ? hi : -INFINITY;   // the half behind the last token logit is a duration logit (or the next row's first)
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kReq; ++j) v[j] = fetch(off[j]);
+        }
         float dv = lane < g.nd ? dve : -INFINITY;
         dv = dv != dv ? -INFINITY : dv;                                          // NaN never wins the first-maximum scan
         float me = v[0];
@@ -373,7 +395,7 @@ __global__ __launch_bounds__(64) void tdt_logits_fits_kernel(const TdtArgs a, co
         // masks on the scalar unit (ballot, compare, find-first, select per piece: 11 scalar instructions each, 318 per decision in r05_tdt_pmc.json).
         unsigned key = 0xffffffffu;
 #pragma unroll
-        for (int j = kP - 1; j >= 0; --j) key = v[j] == M ? static_cast<unsigned>(64 * j + lane) : key;
+        for (int j = kP - 1; j >= 0; --j) key = v[j] == M ? static_cast<unsigned>(index_of(j)) : key;
         key = tdt_wave_umin(key);
         tok = (M > -INFINITY && key != 0xffffffffu) ? static_cast<int>(key) : 0;   // all NaN / -inf: index 0 (LogitsArgmax semantics: nothing beats the -inf seed)
         const float DM = tdt_low8_max(dv);
@@ -387,7 +409,7 @@ __global__ __launch_bounds__(64) void tdt_logits_fits_kernel(const TdtArgs a, co
         for (int j = 0; j < kP; ++j) { const float x = v[j]; m = x > m ? x : m; nan_seen = nan_seen | (x != x); }
         const bool finite_max = m > -INFINITY;
 #pragma unroll
-        for (int j = 0; j < kP; ++j) { const float e = __expf(v[j] - m); ssum += (finite_max & (lane + 64 * j <= last_k)) ? e : 0.0f; }
+        for (int j = 0; j < kP; ++j) { const float e = __expf(v[j] - m); ssum += (finite_max & (index_of(j) <= last_k)) ? e : 0.0f; }
         tdt_wave_softmax(m, ssum);
         return __builtin_amdgcn_ballot_w64(nan_seen) ? NAN : 1.0f / ssum;
     });
@@ -548,8 +570,13 @@ fa_status fa_tdt_greedy_logits_dev(fa_ctx *ctx, const fa_tdt_config *cfg, const 
     a.B = batch; a.U = U; a.T = T; a.max_out = max_out; a.cfg = *cfg;
     TdtLogitArgs g{d_logits, dtype == FA_DTYPE_F16 ? 1 : 0, vocab_with_blank, cfg->n_duration_bins, row_stride};
     const bool fits = vocab_with_blank <= 64 * 17;   // the row stays in registers between its argmax and the (rare) request for its probability
-    if (g.f16) { if (fits) hipLaunchKernelGGL(tdt_logits_fits_kernel<true>, dim3(batch), dim3(64), 0, ctx->stream, a, g); else hipLaunchKernelGGL(tdt_logits_kernel<true>, dim3(batch), dim3(64), 0, ctx->stream, a, g); }
-    else { if (fits) hipLaunchKernelGGL(tdt_logits_fits_kernel<false>, dim3(batch), dim3(64), 0, ctx->stream, a, g); else hipLaunchKernelGGL(tdt_logits_kernel<false>, dim3(batch), dim3(64), 0, ctx->stream, a, g); }
+    const bool pairs = g.f16 && fits && row_stride % 2 == 0 && reinterpret_cast<uintptr_t>(d_logits) % 4 == 0 && vocab_with_blank >= 2;   // every row starts on a 4-byte boundary
+    if (g.f16) {
+        if (fits && pairs) hipLaunchKernelGGL((tdt_logits_fits_kernel<true, true>), dim3(batch), dim3(64), 0, ctx->stream, a, g);
+        else if (fits) hipLaunchKernelGGL((tdt_logits_fits_kernel<true, false>), dim3(batch), dim3(64), 0, ctx->stream, a, g);
+        else hipLaunchKernelGGL(tdt_logits_kernel<true>, dim3(batch), dim3(64), 0, ctx->stream, a, g);
+    }
+    else { if (fits) hipLaunchKernelGGL((tdt_logits_fits_kernel<false, false>), dim3(batch), dim3(64), 0, ctx->stream, a, g); else hipLaunchKernelGGL(tdt_logits_kernel<false>, dim3(batch), dim3(64), 0, ctx->stream, a, g); }
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }

@@ -137,6 +137,21 @@ def cluster_embeddings(embedding256, rho128, chunk_indices, phi, config: Offline
     return res
 
 
+class _DevArray:
+    """A torch CUDA tensor behind the few ndarray attributes cluster_embeddings_batch reads (shape / ndim / size / ctypes.data = the device address)."""
+
+    class _Ptr:
+        def __init__(self, p):
+            self.data = p
+
+    def __init__(self, t):
+        self.t = t
+        self.shape = tuple(t.shape) if t is not None else (0,)
+        self.ndim = len(self.shape)
+        self.size = int(t.numel()) if t is not None else 0
+        self.ctypes = _DevArray._Ptr(int(t.data_ptr()) if t is not None and t.numel() else 0)
+
+
 def _c_config(cfg: OfflineClusteringConfig):
     import ctypes as C
     c = L.OfflineClusterConfig()
@@ -153,12 +168,21 @@ def _c_config(cfg: OfflineClusteringConfig):
 def cluster_embeddings_batch(recordings, phi, config: OfflineClusteringConfig | None = None, ctx: L.Context | None = None):
     """Several recordings through the clustering stage in one call (fa_offline_cluster_batch: their merge chains advance together).
     recordings: iterable of (embedding256 [n, d] float32, rho128 [n, rho_dim] float64, chunk_indices [n]) with common d / rho_dim.
+    Embeddings / rho given as torch CUDA tensors (all recordings, or none) go through fa_offline_cluster_batch_dev: nothing is uploaded.
     Returns (statuses, [ClusteringResult | None]) — per recording identical to cluster_embeddings()."""
     import ctypes as C
     cfg = config or OfflineClusteringConfig()
     cfg.validate()
     ctx = ctx or L.default_context()
-    recs = [(np.ascontiguousarray(e, np.float32), np.ascontiguousarray(r, np.float64), np.ascontiguousarray(c, np.int32)) for e, r, c in recordings]
+    recordings = list(recordings)
+    on_device = bool(recordings) and all(hasattr(e, "data_ptr") for e, _, _ in recordings)
+    if on_device:
+        for e, r, _ in recordings:
+            assert e.is_cuda and e.is_contiguous() and e.dtype.itemsize == 4 and e.dim() == 2
+            assert r is None or (r.is_cuda and r.is_contiguous() and r.dtype.itemsize == 8)
+        recs = [(_DevArray(e), _DevArray(r), np.ascontiguousarray(c, np.int32)) for e, r, c in recordings]
+    else:
+        recs = [(np.ascontiguousarray(e, np.float32), np.ascontiguousarray(r, np.float64), np.ascontiguousarray(c, np.int32)) for e, r, c in recordings]
     k = len(recs)
     if k == 0:
         return [], []
@@ -182,7 +206,8 @@ def cluster_embeddings_batch(recordings, phi, config: OfflineClusteringConfig | 
     infos = (L.OfflineClusterInfo * k)()
     st = (C.c_int32 * k)()
     c = _c_config(cfg)
-    L.lib().fa_offline_cluster_batch(ctx.handle, k, ep, ns, d, rp if rd else None, rd, cp, ph.ctypes.data if rd else None, C.byref(c), lp, zp, cap, kc, infos, st)
+    entry = L.lib().fa_offline_cluster_batch_dev if on_device else L.lib().fa_offline_cluster_batch
+    entry(ctx.handle, k, ep, ns, d, rp if rd else None, rd, cp, ph.ctypes.data if rd else None, C.byref(c), lp, zp, cap, kc, infos, st)
     out = []
     for i in range(k):
         if st[i] != L.SUCCESS:

@@ -477,6 +477,13 @@ fa_status fa_offline_cluster_batch(fa_ctx *ctx, int32_t count, const float *cons
                                    const double *const *rho, int32_t rho_dim, const int32_t *const *chunk_indices, const double *phi,
                                    const fa_offline_cluster_config *config, int32_t *const *labels, double *const *centroids,
                                    int32_t max_centroids, int32_t *n_centroids, fa_offline_cluster_info *infos, int32_t *statuses);
+/* The same with the recordings' inputs RESIDENT on the context's device (what device_pointers = 1 is to fa_offline_cluster): d_embeddings[r] /
+ * d_rho[r] are DEVICE pointers (the arrays of pointers themselves, n, chunk_indices[r], phi, labels[r], centroids[r] stay on the host).  The call
+ * waits for the context's stream first (the inputs' producer), nothing is uploaded.  Results equal fa_offline_cluster_batch's bit for bit. */
+fa_status fa_offline_cluster_batch_dev(fa_ctx *ctx, int32_t count, const float *const *d_embeddings, const int64_t *n, int32_t d,
+                                       const double *const *d_rho, int32_t rho_dim, const int32_t *const *chunk_indices, const double *phi,
+                                       const fa_offline_cluster_config *config, int32_t *const *labels, double *const *centroids,
+                                       int32_t max_centroids, int32_t *n_centroids, fa_offline_cluster_info *infos, int32_t *statuses);
 
 
 /* ------------------------------------------------ speaker-count constraints + K-Means fallback ------ */

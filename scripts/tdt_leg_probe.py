@@ -14,7 +14,10 @@ import fluidaudio_amd as fa  # noqa: E402
 
 ctx = fa.default_context(0)
 torch.cuda.set_device(0)
-for B, dt in ((1024, "float32"), (1024, "float16"), (4096, "float16"), (4096, "float32"), (8192, "float16")):
+CASES = ((1024, "float32"), (1024, "float16"), (4096, "float16"), (4096, "float32"), (8192, "float16"))
+if len(sys.argv) > 1:   # e.g. 1024:float32,4096:float32
+    CASES = tuple((int(c.split(":")[0]), c.split(":")[1]) for c in sys.argv[1].split(","))
+for B, dt in CASES:
     try:
         r = bench.tdt_leg(fa, ctx, torch, B=B, dtype=dt)
         print(json.dumps({"B": B, "dtype": dt, "ms_per_pass": r["ms_per_pass"], "frac": r["roofline"]["frac"], "GBps": r["roofline"]["achieved"],

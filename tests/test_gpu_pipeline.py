@@ -86,6 +86,16 @@ def test_batched_recordings_equal_single_calls(fa, gpu_ctx):
         for key in ("training_rows", "initial_clusters", "vbx_iterations", "was_adjusted", "constrained"):
             assert got.info[key] == one.info[key], key
     assert out[2].info["training_rows"] == len(recs[2][0]) - 1
+    # the same recordings RESIDENT on the device (fa_offline_cluster_batch_dev: nothing uploaded): bit for bit the host-pointer call
+    import torch
+    dev = [(torch.from_numpy(np.ascontiguousarray(e)).cuda(), torch.from_numpy(np.ascontiguousarray(r)).cuda(), c) for e, r, c in recs[:-1]]
+    st_d, out_d = fa.cluster_embeddings_batch(dev, phi, ctx=gpu_ctx)
+    assert st_d == st[:-1]
+    for got, want in zip(out_d, out[:-1]):
+        assert got.assignments == want.assignments
+        np.testing.assert_array_equal(got.centroids, want.centroids)
+        for key in ("training_rows", "initial_clusters", "vbx_iterations", "was_adjusted", "constrained"):
+            assert got.info[key] == want.info[key], key
     # forced speaker count goes through the K-Means fallback per recording
     cfg = fa.OfflineClusteringConfig(num_speakers=2)
     st2, out2 = fa.cluster_embeddings_batch(recs[:2], phi, cfg, ctx=gpu_ctx)

@@ -78,7 +78,7 @@ def test_walk_on_joint_logits_equals_walk_on_tables(fa, gpu_ctx, oracle_mod, dty
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float16"])
-@pytest.mark.parametrize("V1", [5, 64, 130, 1025, 1088, 1089, 2500])
+@pytest.mark.parametrize("V1", [5, 64, 130, 1025, 1087, 1088, 1089, 2500])   # fp16 rows of even stride (5, 1025, 1087 + 5 durations) take the pair requests
 def test_logits_walk_every_row_form_and_every_option(fa, gpu_ctx, oracle_mod, dtype, V1):
     """Round 5: the walk on joint logits is a state machine with one joint evaluation per iteration (tdt_walk_wave); rows of up to 17 x 64 logits
     are decided from registers (row maximum + first index holding it, soft-max only when the token is emitted: tdt_logits_fits_kernel), longer
