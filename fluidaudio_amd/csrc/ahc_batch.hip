@@ -13,7 +13,7 @@ namespace {
 // indexed by the problem — in front of its first request: 11 us per round of 16 problems against 5.3 us for one.)  Only N differs per
 // problem: it comes from the hot part of the problem's state, with the first batch of loads.
 // arg 0 = (blocks << 2) | (round & 3), stride in 4 KB pages: 14 preloaded dwords like ahc_round_t.
-template <int CPT>
+template <int CPT, int KC = 4 / CPT>
 __device__ __forceinline__ void ahc_round_uni_body(const unsigned nblk_ph, const unsigned stride_pages, AhcState *const state_, RecA *const recA_, int4 *const recI_,
                                                    RecP *const recP_, const unsigned off_row, const unsigned off_node, const unsigned off_e2, const unsigned off_flags,
                                                    const Ws &w_one) {
@@ -25,21 +25,27 @@ __device__ __forceinline__ void ahc_round_uni_body(const unsigned nblk_ph, const
     char *base = reinterpret_cast<char *>(w_.state);
     w_.row = reinterpret_cast<RowSt *>(base + off_row); w_.node = reinterpret_cast<int *>(base + off_node);
     w_.e2 = reinterpret_cast<double *>(base + off_e2); w_.flags = reinterpret_cast<int *>(base + off_flags);
-    ahc_round_body<true, false, CPT>(w_, blockIdx.x, static_cast<int>(nblk_ph & 3u), sh);   // the host sends problems of more than 65 536 points elsewhere
+    ahc_round_body<true, false, CPT, KC>(w_, blockIdx.x, static_cast<int>(nblk_ph & 3u), sh);   // the host sends problems of more than 65 536 points elsewhere
 }
-#define FA_AHC_UNI_KERNEL(NAME, ATTR, CPT)                                                                                                              \
+#define FA_AHC_UNI_KERNEL(NAME, ATTR, CPT, KC)                                                                                                              \
     __global__ __launch_bounds__(kBlk) ATTR void NAME(const unsigned nblk_ph, const unsigned stride_pages, AhcState *const state_, RecA *const recA_,  \
                                                       int4 *const recI_, RecP *const recP_, const unsigned off_row, const unsigned off_node,           \
                                                       const unsigned off_e2, const unsigned off_flags, const Ws w_one) {                              \
-        ahc_round_uni_body<CPT>(nblk_ph, stride_pages, state_, recA_, recI_, recP_, off_row, off_node, off_e2, off_flags, w_one);                      \
+        ahc_round_uni_body<CPT, KC>(nblk_ph, stride_pages, state_, recA_, recI_, recP_, off_row, off_node, off_e2, off_flags, w_one);                      \
     }
 // one slot per thread at three register budgets (more co-resident workgroups per CU against spills; round 4) and the round-5 forms with 2 / 4 slots per
 // thread (which one serves a batch: ahc_batch_uniform)
-FA_AHC_UNI_KERNEL(ahc_round_uni, , 1)
-FA_AHC_UNI_KERNEL(ahc_round_uni_w3, __attribute__((amdgpu_waves_per_eu(6, 6))), 1)   // "w3" / "w4": the second and third budget
-FA_AHC_UNI_KERNEL(ahc_round_uni_w4, __attribute__((amdgpu_waves_per_eu(8, 8))), 1)
-FA_AHC_UNI_KERNEL(ahc_round_uni_c2, , 2)
-FA_AHC_UNI_KERNEL(ahc_round_uni_c4, , 4)
+FA_AHC_UNI_KERNEL(ahc_round_uni, , 1, 4)
+FA_AHC_UNI_KERNEL(ahc_round_uni_w3, __attribute__((amdgpu_waves_per_eu(6, 6))), 1, 4)   // "w3" / "w4": the second and third budget
+FA_AHC_UNI_KERNEL(ahc_round_uni_w4, __attribute__((amdgpu_waves_per_eu(8, 8))), 1, 4)
+FA_AHC_UNI_KERNEL(ahc_round_uni_c2, , 2, 2)
+FA_AHC_UNI_KERNEL(ahc_round_uni_c4, , 4, 1)
+// the same with the block records a lane of the first reduction actually owns held in registers (round 6: a request for a record the lane does not own is
+// not free, ahc_round_body): problems of up to 16 384 / 32 768 / 49 152 slots at one slot per thread, up to 32 768 slots at two
+FA_AHC_UNI_KERNEL(ahc_round_uni_k1, , 1, 1)
+FA_AHC_UNI_KERNEL(ahc_round_uni_k2, , 1, 2)
+FA_AHC_UNI_KERNEL(ahc_round_uni_k3, , 1, 3)
+FA_AHC_UNI_KERNEL(ahc_round_uni_c2k1, , 2, 1)
 
 constexpr int kArgProblems = 16;
 struct BatchArgs {
@@ -293,8 +299,13 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
     auto launch = [&](const int ph) {
         const unsigned a0 = (static_cast<unsigned>(w0.nblk) << 2) | static_cast<unsigned>(ph & 3);
         const dim3 grid(static_cast<unsigned>(w0.nblk), static_cast<unsigned>(grid_y));
+        const int lane_recs = (w0.nblk + 63) / 64;   // block records a lane of the first reduction owns
         if (cpt == 4) hipLaunchKernelGGL(ahc_round_uni_c4, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
+        else if (cpt == 2 && lane_recs == 1) hipLaunchKernelGGL(ahc_round_uni_c2k1, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
         else if (cpt == 2) hipLaunchKernelGGL(ahc_round_uni_c2, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
+        else if (kernel == 2 && lane_recs == 1) hipLaunchKernelGGL(ahc_round_uni_k1, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
+        else if (kernel == 2 && lane_recs == 2) hipLaunchKernelGGL(ahc_round_uni_k2, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
+        else if (kernel == 2 && lane_recs == 3) hipLaunchKernelGGL(ahc_round_uni_k3, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
         else if (kernel == 4) hipLaunchKernelGGL(ahc_round_uni_w4, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
         else if (kernel == 3) hipLaunchKernelGGL(ahc_round_uni_w3, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
         else hipLaunchKernelGGL(ahc_round_uni, grid, dim3(kBlk), lds, ctx->stream, a0, stride_pages, w0.state, w0.recA, w0.recI, w0.recP, o_row, o_node, o_e2, o_flags, w0);
@@ -305,6 +316,10 @@ fa_status ahc_batch_uniform(fa_ctx *ctx, int count, const double *const *d_data,
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_w4), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_c2), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_c4), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_k1), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_k2), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_k3), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_uni_c2k1), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     }
     const long long max_batches = 64 + 8 * static_cast<long long>(Nmax) / rounds_for(Nmax);
     // The captured launches hold the workspace address, the layout (N of the largest problem, d, slots per thread), the grid and the kernel build:

@@ -119,6 +119,7 @@ __device__ __forceinline__ void block_record(const Ws &w, const int par, const i
         const bool any = best.v < dinf();
         w.recA[o1] = ra;
         w.recI[o1] = any ? make_int4(best.a, best.b, best.c, best.d) : make_int4(-1, -1, -1, -1);
+        w.recI[2 * static_cast<size_t>(w.nblk) + o1] = rec_pack(ra.v1, ra.cnt, any ? best.a - blk * kBlk * CPT : 0, any ? best.b : -1, any ? best.c : 0, any ? best.d : 0);
     } else if (kStaleQ && tid == 1) {
         RecS rsv; rsv.sv = best.v;
         const bool any = best.v < dinf();
@@ -280,7 +281,7 @@ struct Dec {
 // wavefront its DPP reductions, the centroid sum, the decision arithmetic: ~830 instructions per wavefront and round whatever it owns — so
 // there a thread owns 4 slots: a quarter of the workgroups, wavefronts and block records per problem, and only the per-slot part of a round
 // (the two matrix entries, the Lance-Williams value, the row bookkeeping) is repeated per slot.
-template <bool N_IN_STATE = false, bool BIG = true, int CPT = 1>
+template <bool N_IN_STATE = false, bool BIG = true, int CPT = 1, int KC = 4 / CPT>
 __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, const int ph /* round index & 3 */, const size_t late_shift = 0) {
     static_assert(CPT == 1 || kPiggy == 0, "piggy-backed re-scans were only ever built for one slot per thread");
     constexpr int kCols = kBlk * CPT;
@@ -308,11 +309,17 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     const int pk0 = wave == 2 ? 1 : 0, pk1r = wave == 2 ? 2 : 3;
     const bool phas1 = pk1r < kPend;
     const int pk1 = phas1 ? pk1r : pk0;
-    constexpr int kC4 = 4 / CPT;                                        // block records per lane held in registers (N <= 65 536 = 64 lanes x kC4 x kBlk x CPT); beyond: the generic path
+    // kC4 = KC: block records per lane held in registers (N <= 64 lanes x KC x kBlk x CPT; at most 65 536 slots); beyond: the generic path.  A request for a
+    // record the lane does not own is not free (round 6: the four wavefronts of a workgroup share the CU's one address unit — at 43 200 points, three
+    // records per lane, the fourth pair of requests cost 0.12 us of a 5.1 us round), so the host picks the instance with KC = the records a lane owns.
+    constexpr int kC4 = KC;
+    static_assert(KC >= 1 && KC * CPT <= 4, "at most 65 536 slots through the register path");
     int4 q0[kC4], q1[kC4];
     bool qok[kC4];
     {
-        const void *b0 = wave == 0 ? static_cast<const void *>(w.recA + ro) : static_cast<const void *>(w.recP + (static_cast<size_t>(par) * kPend + pk0) * nblk);
+        // wave 0 reads the PACKED records (rec_pack, ahc_ws.h: one request per record instead of two — 5.07 -> 4.96 us per round at 43 200 points); a second
+        // request per record only where a row wave finishes two rows
+        const void *b0 = wave == 0 ? static_cast<const void *>(w.recI + 2 * static_cast<size_t>(nblk) + ro) : static_cast<const void *>(w.recP + (static_cast<size_t>(par) * kPend + pk0) * nblk);
         const void *b1 = wave == 0 ? static_cast<const void *>(w.recI + ro) : static_cast<const void *>(w.recP + (static_cast<size_t>(par) * kPend + pk1) * nblk);
 #pragma unroll
         for (int j = 0; j < kC4; ++j) {
@@ -320,7 +327,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
             qok[j] = c <= kC4 && j < c && i < nblk && (wave == 0 || row_wave);
             const size_t ii = qok[j] ? i : 0;
             q0[j] = rec16(b0, ii);
-            q1[j] = rec16(b1, ii);
+            if constexpr (kPend > 1) q1[j] = rec16(b1, ii); else q1[j] = q0[j];
         }
     }
     int vz = 0;
@@ -390,6 +397,35 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
         const int r1 = lane_value(ids.x, L[0]), q1_ = lane_value(ids.y, L[0]), nr1 = lane_value(ids.z, L[0]), nq1 = lane_value(ids.w, L[0]);
         if (lane == 0) { s_dec.v1 = m[0]; s_dec.cnt = cnt; s_dec.r1 = r1; s_dec.q1 = q1_; s_dec.nr1 = nr1; s_dec.nq1 = nq1; }
     };
+    auto reduce_minimum_packed = [&](auto cc, const int4 *rx, const bool *ok) {
+        constexpr int C = decltype(cc)::value;
+        double va[C], key = dinf();
+        int ca[C], bz = 0, bw = 0, bi = 0;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            va[j] = ok[j] ? rec_f64(rx[j]) : dinf();
+            ca[j] = ok[j] ? (rx[j].z >> 10) & 3 : 0;
+            const bool better = va[j] < key;
+            key = better ? va[j] : key;
+            bz = better ? rx[j].z : bz; bw = better ? rx[j].w : bw; bi = better ? lane * c + j : bi;
+        }
+        AHC_STAMP(0);
+        const double keys[1] = {key};
+        double m[1];
+        int L[1];
+        wave_min_multi<1>(keys, m, L);
+        int cl = 0;
+        const double wl = m[0] + 2.0 * st.eps;
+#pragma unroll
+        for (int j = 0; j < C; ++j) cl += (va[j] <= wl && va[j] < dinf()) ? ca[j] : 0;
+        const int cnt = wave_count(cl >= 1) + wave_count(cl >= 2) + wave_count(cl >= 3);
+        const unsigned uz = static_cast<unsigned>(lane_value(bz, L[0])), uw = static_cast<unsigned>(lane_value(bw, L[0]));
+        const int ui = lane_value(bi, L[0]);
+        int local, q1_, nr1, nq1;
+        rec_unpack(uz, uw, local, q1_, nr1, nq1);
+        const bool any = m[0] < dinf();
+        if (lane == 0) { s_dec.v1 = m[0]; s_dec.cnt = cnt; s_dec.r1 = any ? ui * kCols + local : -1; s_dec.q1 = any ? q1_ : -1; s_dec.nr1 = any ? nr1 : -1; s_dec.nq1 = any ? nq1 : -1; }
+    };
     // waves 2 / 3: block-partial minima of the rows the previous round produced -> their minimum and nearest neighbour
     auto reduce_rows = [&](auto cc, const int4 *r0, const int4 *r1, const bool *ok) {
         constexpr int C = decltype(cc)::value;
@@ -410,7 +446,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
         if (lane == 0) { s_dec.pd[pk0] = m[0]; s_dec.ps[pk0] = a0; s_dec.pn[pk0] = b0; if (phas1) { s_dec.pd[pk1] = m[1]; s_dec.ps[pk1] = a1; s_dec.pn[pk1] = b1; } }
     };
     if (c <= kC4) {
-        if (wave == 0) reduce_minimum(std::integral_constant<int, kC4>{}, q0, q1, qok);
+        if (wave == 0) reduce_minimum_packed(std::integral_constant<int, kC4>{}, q0, qok);
         else if (row_wave) reduce_rows(std::integral_constant<int, kC4>{}, q0, q1, qok);
     } else if (BIG && (wave == 0 || row_wave)) {   // more than 65 536 points: 5 .. 12 records per lane, requested together, then the same reductions
         int4 g0[kMaxC], g1[kMaxC];
@@ -488,6 +524,20 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     // window count, the state tests and the dispatch below (~900 cycles of branches on uniform values) only decide whether the values are
     // used.  The second memory round trip of the round starts that much earlier; a round that does something else drops them.
     constexpr int kCk = 4;                                   // centroid elements per lane handled without a loop (d <= 256)
+    // A lane's four centroid elements are two PAIRS of neighbours, 2 lane + 128 r + {0, 1} (round 6): two 16-byte requests per centroid instead of four of
+    // 8 bytes (4.99 -> 4.93 us per round at 43 200 points; the squared difference below is a tree sum in any case).  Rows of odd d start on 8-byte boundaries
+    // (the unaligned access mode serves the 16-byte read) and their last element, which has no partner, is handled on its own in the merge phase.
+    // STRAIGHT-LINE code on purpose: the same reads behind `if (d even) .. else ..`, or through a packed 8-byte-aligned pair type with a one-element
+    // branch, compiled into rounds of 5.6 / 5.9 us (profiles/r06_round_requests_probe.txt).
+    auto celem = [lane](const int j) { return 2 * lane + 128 * (j >> 1) + (j & 1); };
+    auto cload = [&](const double *c, double (&x)[kCk]) {
+#pragma unroll
+        for (int r = 0; r < kCk / 2; ++r) {
+            const int k = 2 * lane + 128 * r;
+            const double2 q = k + 1 < d ? *reinterpret_cast<const double2 *>(c + k) : make_double2(0.0, 0.0);
+            x[2 * r] = q.x; x[2 * r + 1] = q.y;
+        }
+    };
     const bool spec = FA_AHC_SPECULATE && R1 >= 0 && Q1 >= 0;
     const bool spec_lo = R1 < Q1;
     const int sp_a = spec_lo ? R1 : Q1, sp_b = spec_lo ? Q1 : R1, sp_na = spec_lo ? NR1 : NQ1, sp_nb = spec_lo ? NQ1 : NR1;
@@ -500,13 +550,12 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     // nothing in the decision below has to wait on the counter — a wait there would also wait for the requests that follow)
     asm volatile("" :: "v"(nanflag), "v"(e2x[CPT - 1]), "v"(rs[CPT - 1].d1), "v"(nx[CPT - 1]));
     if (spec) {
-        // sizes and centroids first, the two matrix entries (a cold row each) last: loads complete in order.  (Requesting the entries from
-        // every thread, so that the wait for the centroids need not cover them, was measured: dead columns then read cold column copies
-        // nobody needs — 5.8 instead of 5.3 us per round at 43 200 points.)
+        // sizes and centroids first, the two matrix entries (a cold row each) last: loads complete in order, the centroid arithmetic runs under the entries'
+        // latency.  (Entries first measured in round 6: 5.12 against 5.07 us.  Requesting the entries from every thread, round 4: dead columns then read cold
+        // column copies nobody needs — 5.8 instead of 5.3 us per round at 43 200 points.)
         sp_ma = w.sizes[sp_na]; sp_mb = w.sizes[sp_nb];
         const double *ca = w.C + static_cast<size_t>(sp_na) * d, *cb = w.C + static_cast<size_t>(sp_nb) * d;
-#pragma unroll
-        for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; sp_xa[j] = k < d ? ca[k] : 0.0; sp_xb[j] = k < d ? cb[k] : 0.0; }
+        cload(ca, sp_xa); cload(cb, sp_xb);
         __builtin_amdgcn_sched_barrier(0);
         if (st.mode == FA_AHC_MODE_AUTO) {
             pair_entries<CPT>(w.M, Np, sp_a, sp_na, x0, nx, st.sym_limit, sp_a, sp_b, sp_da);
@@ -666,15 +715,14 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
 #pragma unroll
         for (int j = 0; j < kCk; ++j) { xa[j] = sp_xa[j]; xb[j] = sp_xb[j]; }
         if (!sp_hit) {
-#pragma unroll
-            for (int j = 0; j < kCk; ++j) { const int k = lane + 64 * j; xa[j] = k < d ? ca[k] : 0.0; xb[j] = k < d ? cb[k] : 0.0; }
+            cload(ca, xa); cload(cb, xb);
         }
         AHC_STAMP(9);
         const bool keeps_centroid = wave == 0 && (st.mode == FA_AHC_MODE_EXACT || blk == 0);
         double part = 0.0;
 #pragma unroll
         for (int j = 0; j < kCk; ++j) {
-            const int k = lane + 64 * j;
+            const int k = celem(j);
             if (keeps_centroid && k < d) {
                 const double cc = __ddiv_rn(__dadd_rn(__dmul_rn(xa[j], ma), __dmul_rn(xb[j], mb)), den);
                 if (st.mode == FA_AHC_MODE_EXACT) s_cvec[k] = cc;
@@ -683,7 +731,9 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
             const double diff = xa[j] - xb[j];
             part += diff * diff;
         }
-        for (int k = lane + 64 * kCk; k < d; k += 64) {      // d > 256
+        // d > 256: the elements from 256 on, 64 at a time; odd d <= 256: the last element (it has no partner in the pair reads) through the same loop — no
+        // conditional region of its own: a join behind one with memory operations costs a wait on the in-order counter in EVERY round (measured: 0.15 us)
+        for (int k = ((d & 1) != 0 && d <= 64 * kCk ? d - 1 : 64 * kCk) + lane; k < d; k += 64) {
             const double ya = ca[k], yb = cb[k];
             if (keeps_centroid) {
                 const double cc = __ddiv_rn(__dadd_rn(__dmul_rn(ya, ma), __dmul_rn(yb, mb)), den);
@@ -919,7 +969,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
 //                       (constant address space = scalar loads): two dependent memory round trips before the round can start.
 //   ahc_round_args    : up to kArgProblems problems with their workspaces and block ranges IN the kernel arguments: no extra round trip
 //                       (fa_ahc_linkage_batch / fa_offline_cluster_batch with <= 16 recordings).
-template <bool BATCH, bool BIG, int CPT = 1>
+template <bool BATCH, bool BIG, int CPT = 1, int KC = 4 / CPT>
 __global__ __launch_bounds__(kBlk) void ahc_round_t(const int ph, const int nblk_, AhcState *const state_, RecA *const recA_, int4 *const recI_, RecP *const recP_,
                                                     const unsigned off_row, const unsigned off_node, const unsigned off_e2, const unsigned off_flags,
                                                     const Ws w_one, const Ws *__restrict__ table, const int2 *__restrict__ blkmap) {
@@ -947,7 +997,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const int ph, const int nblk
         for (unsigned i = 0; i < sizeof(Ws) / 8; ++i) words[i] = src[i];
         __builtin_memcpy(&w_, words, sizeof(Ws));
     }
-    ahc_round_body<false, BIG, CPT>(w_, blk_, ph);
+    ahc_round_body<false, BIG, CPT, KC>(w_, blk_, ph);
 }
 
 // A problem of at most 256 points is ONE block: its rounds need no device-wide barrier at all, a workgroup barrier between them (with
@@ -957,7 +1007,7 @@ __global__ __launch_bounds__(kBlk) void ahc_round_t(const int ph, const int nblk
 template <int CPT>   // up to kBlk * CPT points
 __global__ __launch_bounds__(kBlk) void ahc_rounds_single_block(const Ws w, const int rounds) {
     for (int r = 0; r < rounds; ++r) {
-        ahc_round_body<false, false, CPT>(w, 0, r & 3);
+        ahc_round_body<false, false, CPT, 1>(w, 0, r & 3);   // one block: one record
         __syncthreads();   // workgroup-scope release / acquire: the waves of one workgroup share the CU's caches
     }
 }

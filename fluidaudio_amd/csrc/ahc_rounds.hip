@@ -213,24 +213,28 @@ fa_status prob_run_rounds(fa_ctx *ctx, Prob &p) {
     const Ws w = p.w;
     const bool env_big = fa::sw_on(fa::Sw::AHC_ROUND_BIG);
     const bool big = w.nblk > (4 / p.cpt) * 64 || env_big;   // more than 65 536 points (four block records per lane at one slot per thread): the kernel with the many-record reduction
-    if (lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ahc_round_t<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    }
+    // records a lane of the first reduction owns: the one-slot-per-thread kernel exists per count (ahc_round_body: a request for a record the lane does not own
+    // is not free); the forms with 2 / 4 slots per thread hold all 2 / 1 of theirs
+    const int kc = p.cpt == 1 && !big ? std::max(1, (w.nblk + 63) / 64) : 4 / p.cpt;
     auto off_of = [&](const void *p) { return static_cast<unsigned>(static_cast<const char *>(p) - reinterpret_cast<const char *>(w.state)); };   // small arrays: within 4 GB of the state (make_layout puts the matrix last)
     const unsigned o_row = off_of(w.row), o_node = off_of(w.node), o_e2 = off_of(w.e2), o_flags = off_of(w.flags);
-#define FA_AHC_ROUND_LAUNCH(BIG_, CPT_) hipLaunchKernelGGL((ahc_round_t<false, BIG_, CPT_>), dim3(w.nblk), dim3(kBlk), lds, ctx->stream, ph, w.nblk, w.state, w.recA, w.recI, w.recP, \
-                                                          o_row, o_node, o_e2, o_flags, w, static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr))
-    auto launch = [&](const int ph) {
-        if (p.cpt == 4) { if (big) FA_AHC_ROUND_LAUNCH(true, 4); else FA_AHC_ROUND_LAUNCH(false, 4); }
-        else if (p.cpt == 2) { if (big) FA_AHC_ROUND_LAUNCH(true, 2); else FA_AHC_ROUND_LAUNCH(false, 2); }
-        else { if (big) FA_AHC_ROUND_LAUNCH(true, 1); else FA_AHC_ROUND_LAUNCH(false, 1); }
+    bool lds_ok = true;
+    auto launch_as = [&](auto kernel, const int ph, const bool set_lds_only) {
+        if (set_lds_only) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) lds_ok = false; return; }
+        hipLaunchKernelGGL(kernel, dim3(w.nblk), dim3(kBlk), lds, ctx->stream, ph, w.nblk, w.state, w.recA, w.recI, w.recP, o_row, o_node, o_e2, o_flags, w,
+                           static_cast<const Ws *>(nullptr), static_cast<const int2 *>(nullptr));
     };
-#undef FA_AHC_ROUND_LAUNCH
+    auto dispatch = [&](const int ph, const bool set_lds_only) {
+        if (p.cpt == 4) { if (big) launch_as(ahc_round_t<false, true, 4>, ph, set_lds_only); else launch_as(ahc_round_t<false, false, 4>, ph, set_lds_only); }
+        else if (p.cpt == 2) { if (big) launch_as(ahc_round_t<false, true, 2>, ph, set_lds_only); else launch_as(ahc_round_t<false, false, 2>, ph, set_lds_only); }
+        else if (big) launch_as(ahc_round_t<false, true, 1>, ph, set_lds_only);
+        else if (kc == 1) launch_as(ahc_round_t<false, false, 1, 1>, ph, set_lds_only);
+        else if (kc == 2) launch_as(ahc_round_t<false, false, 1, 2>, ph, set_lds_only);
+        else if (kc == 3) launch_as(ahc_round_t<false, false, 1, 3>, ph, set_lds_only);
+        else launch_as(ahc_round_t<false, false, 1, 4>, ph, set_lds_only);
+    };
+    if (lds > 48 * 1024) { dispatch(0, true); (void)lds_ok; (void)hipGetLastError(); }
+    auto launch = [&](const int ph) { dispatch(ph, false); };
     // The captured graph only holds launch parameters (workspace pointers, block count): it is reused as long as the workspace sits at
     // the same address and the shape is the same — repeated calls on recordings of one length skip capture + instantiation.
     RoundGraph single_rg;

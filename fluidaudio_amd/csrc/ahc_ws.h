@@ -87,6 +87,21 @@ struct __attribute__((aligned(16))) RecA { double v1; int cnt, pad; };        //
 struct __attribute__((aligned(16))) RecS { double sv; int srow, snode; };     // smallest bound among the block's stale rows
 struct __attribute__((aligned(16))) RecP { double pv; int slot, node; };      // block-partial minimum of a row being produced
 // recI: int4 {r1, q1, node(r1), node(q1)}: the row holding v1, its neighbour slot (-1: stale), their node ids
+// The PACKED record (round 6), behind recI in the same array: everything the first reduction wants of a block in ONE 16-byte element — v1 and, in the other
+// 64 bits, the row's slot within its block (10 bits), the window count saturated at 3 (2), the neighbour slot + 1 (17), the two node ids (17 each).  Holds
+// while slots <= 65 536 and node ids < 131 072, i.e. for every problem the register path of the first reduction serves; larger ones read recA / recI.
+__device__ __forceinline__ int4 rec_pack(const double v1, const int cnt, const int local, const int q1, const int nr1, const int nq1) {
+    const unsigned c3 = cnt > 3 ? 3u : static_cast<unsigned>(cnt), q = static_cast<unsigned>(q1 + 1) & 0x1ffffu, nq = q1 >= 0 ? static_cast<unsigned>(nq1) & 0x1ffffu : 0u;
+    const unsigned z = (static_cast<unsigned>(local) & 1023u) | (c3 << 10) | (q << 12) | ((nq >> 15) << 29);
+    const unsigned wv = (static_cast<unsigned>(nr1) & 0x1ffffu) | ((nq & 0x7fffu) << 17);
+    return make_int4(__double2loint(v1), __double2hiint(v1), static_cast<int>(z), static_cast<int>(wv));
+}
+__device__ __forceinline__ void rec_unpack(const unsigned z, const unsigned wv, int &local, int &q1, int &nr1, int &nq1) {
+    local = static_cast<int>(z & 1023u);
+    q1 = static_cast<int>((z >> 12) & 0x1ffffu) - 1;
+    nr1 = static_cast<int>(wv & 0x1ffffu);
+    nq1 = q1 >= 0 ? static_cast<int>((wv >> 17) | (((z >> 29) & 3u) << 15)) : -1;
+}
 
 struct __attribute__((aligned(16))) RowSt {  // per slot, owned by thread (slot & 255) of workgroup (slot >> 8)
     double d1;               // minimum over all other live slots (lower bound while nn < 0)
@@ -240,7 +255,7 @@ inline Layout make_layout_core(size_t N, size_t Np, size_t d, size_t nblk) {
     L.flags = take(sizeof(int32_t) * 4);
     L.prof = take(sizeof(unsigned long long) * 16);
     L.reca = take(sizeof(RecA) * 2 * nblk);
-    L.reci = take(sizeof(int4) * 2 * nblk);
+    L.reci = take(sizeof(int4) * 4 * nblk);   // [2][nblk] recI, then [2][nblk] the packed records (rec_pack)
     L.recs = take(sizeof(RecS) * 2 * nblk);
     L.recp = take(sizeof(RecP) * 2 * kPend * nblk);
     L.row = take(sizeof(RowSt) * Np);

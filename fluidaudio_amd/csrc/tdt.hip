@@ -336,25 +336,31 @@ __device__ __forceinline__ float tdt_low8_max(float v) {   // over lanes 0 .. 7
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 7));
 }
 
-// PAIRS (fp16 rows whose every row starts on a 4-byte boundary): a lane's request is a PAIR of neighbouring logits (one dword), nine requests of 256 bytes
-// per row instead of seventeen of 128 — round 6: with one request per half the fp16 walk was SLOWER than the fp32 walk of the same chunks (0.179 against
-// 0.155 ms for 1 024 chunks) although it moves half the bytes.  Element e of piece j of lane l is logit 2 (l + 64 j) + e.
-template <bool F16, bool PAIRS = false>
+// W = logits per request and lane (round 6).  A request of one HALF per lane moves 128 bytes per wavefront, and with those the fp16 walk was SLOWER than
+// the fp32 walk of the same chunks (0.179 against 0.155 ms for 1 024 chunks) although it reads half the bytes.  fp16 rows whose every start is 4-byte
+// aligned are therefore read as PAIRS (W = 2: nine requests of 256 bytes instead of seventeen of 128; 0.142 ms, 4 096 chunks 33 -> 40 % of HBM): logit e
+// of piece j of lane l is W (l + 64 j) + e.  The first logit of a piece is a token logit or a clamped duplicate of one (as above); the others are masked
+// to -inf by their index when they lie behind the last token logit (a duration logit or the next row's first; the masks are loop invariants).  Pieces of
+// 512 bytes and more per wavefront (fp32 pairs / quads, fp16 quads / octets) measured SLOWER than 256: profiles/r06_tdt_piece_probe.txt.
+typedef unsigned tdt_v2u __attribute__((ext_vector_type(2)));
+typedef unsigned tdt_v4u __attribute__((ext_vector_type(4)));
+template <bool F16, int W = 1>
 __global__ __launch_bounds__(64) void tdt_logits_fits_kernel(const TdtArgs a, const TdtLogitArgs g) {
-    static_assert(F16 || !PAIRS, "pairs are two halves in a dword");
     using E = std::conditional_t<F16, __half, float>;
-    constexpr int kP = PAIRS ? 18 : 17;          // logits per lane
-    constexpr int kReq = PAIRS ? 9 : 17;         // requests per lane
+    constexpr int kBytes = W * static_cast<int>(sizeof(E));   // per request and lane
+    static_assert(W == 1 || kBytes == 4 || kBytes == 8 || kBytes == 16, "a request is one element or 1 / 2 / 4 dwords");
+    constexpr int kReq = (17 + W - 1) / W;       // requests per lane: 64 W kReq >= 1 088 logits
+    constexpr int kP = kReq * W;                 // logits per lane
     const int b = blockIdx.x, lane = threadIdx.x;
     const int64_t tb = static_cast<int64_t>(b) * a.U * a.T;
     const int last_k = g.V1 - 1;
-    auto index_of = [lane](const int j) { return PAIRS ? 2 * (lane + 64 * (j >> 1)) + (j & 1) : lane + 64 * j; };
+    auto index_of = [lane](const int j) { return W * (lane + 64 * (j / W)) + (j % W); };
     unsigned off[kReq];
 #pragma unroll
     for (int j = 0; j < kReq; ++j) {
-        const int k = PAIRS ? 2 * (lane + 64 * j) : lane + 64 * j;
-        const int kc = PAIRS ? (k < (last_k & ~1) ? k : (last_k & ~1)) : (k < last_k ? k : last_k);   // beyond the row: its last request again (see above)
-        off[j] = static_cast<unsigned>(kc) * static_cast<unsigned>(sizeof(E));
+        const int k = W * (lane + 64 * j);
+        const int lim = W == 1 ? last_k : last_k / W * W;                      // beyond the row: its last request again
+        off[j] = static_cast<unsigned>(k < lim ? k : lim) * static_cast<unsigned>(sizeof(E));
     }
     const unsigned doff = static_cast<unsigned>(g.V1 + (lane < g.nd ? lane : g.nd - 1)) * static_cast<unsigned>(sizeof(E));
     const int row_bytes = (g.V1 + g.nd) * static_cast<int>(sizeof(E));
@@ -370,19 +376,27 @@ __global__ __launch_bounds__(64) void tdt_logits_fits_kernel(const TdtArgs a, co
             else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, static_cast<int>(byte_off), 0, 0));
         };
         const float dve = fetch(doff);                                         // the duration logits travel with the row
-        if constexpr (PAIRS) {
-            unsigned w2[kReq];
-#pragma unroll
-            for (int j = 0; j < kReq; ++j) w2[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, static_cast<int>(off[j]), 0, 0);
-#pragma unroll
-            for (int j = 0; j < kReq; ++j) {
-                v[2 * j] = __half2float(__ushort_as_half(static_cast<unsigned short>(w2[j] & 0xffffu)));
-                const float hi = __half2float(__ushort_as_half(static_cast<unsigned short>(w2[j] >> 16)));
-                v[2 * j + 1] = index_of(2 * j + 1) <= last_k ? hi : -INFINITY;   // the half behind the last token logit is a duration logit (or the next row's first)
-            }
-        } else {
+        if constexpr (W == 1) {
 #pragma unroll
             for (int j = 0; j < kReq; ++j) v[j] = fetch(off[j]);
+        } else {
+            constexpr int kDw = kBytes / 4;
+            unsigned raw[kReq][kDw];
+#pragma unroll
+            for (int j = 0; j < kReq; ++j) {
+                if constexpr (kDw == 1) raw[j][0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, static_cast<int>(off[j]), 0, 0);
+                else if constexpr (kDw == 2) { const tdt_v2u q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, static_cast<int>(off[j]), 0, 0); raw[j][0] = q.x; raw[j][1] = q.y; }
+                else { const tdt_v4u q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(off[j]), 0, 0); raw[j][0] = q.x; raw[j][1] = q.y; raw[j][2] = q.z; raw[j][3] = q.w; }
+            }
+#pragma unroll
+            for (int j = 0; j < kP; ++j) {
+                float x;
+                if constexpr (F16) {
+                    const unsigned dw = raw[j / W][(j % W) / 2];
+                    x = __half2float(__ushort_as_half(static_cast<unsigned short>((j & 1) ? dw >> 16 : dw & 0xffffu)));
+                } else x = __uint_as_float(raw[j / W][j % W]);
+                v[j] = (j % W == 0 || index_of(j) <= last_k) ? x : -INFINITY;
+            }
         }
         float dv = lane < g.nd ? dve : -INFINITY;
         dv = dv != dv ? -INFINITY : dv;                                          // NaN never wins the first-maximum scan
@@ -390,8 +404,8 @@ __global__ __launch_bounds__(64) void tdt_logits_fits_kernel(const TdtArgs a, co
 #pragma unroll
         for (int j = 1; j < kP; ++j) me = __builtin_fmaxf(me, v[j]);            // a NaN operand is dropped
         const float M = tdt_wave_max(me);                                         // all NaN: NaN; nothing above -inf: -inf
-        // the FIRST index holding M: per lane the lowest piece whose value equals M (index 64 j + lane; 17 compares + selects, walked downwards so the
-        // lowest j is written last), then the minimum of those indices over the wavefront — six v_min_u32 with a DPP operand.  Round 5 searched the 17 lane
+        // the FIRST index holding M: per lane the lowest of its logits that equals M (compares + selects, walked downwards so the lowest index is written
+        // last), then the minimum of those indices over the wavefront — six v_min_u32 with a DPP operand.  Round 5 searched the 17 lane
         // masks on the scalar unit (ballot, compare, find-first, select per piece: 11 scalar instructions each, 318 per decision in r05_tdt_pmc.json).
         unsigned key = 0xffffffffu;
 #pragma unroll
@@ -570,13 +584,17 @@ fa_status fa_tdt_greedy_logits_dev(fa_ctx *ctx, const fa_tdt_config *cfg, const 
     a.B = batch; a.U = U; a.T = T; a.max_out = max_out; a.cfg = *cfg;
     TdtLogitArgs g{d_logits, dtype == FA_DTYPE_F16 ? 1 : 0, vocab_with_blank, cfg->n_duration_bins, row_stride};
     const bool fits = vocab_with_blank <= 64 * 17;   // the row stays in registers between its argmax and the (rare) request for its probability
-    const bool pairs = g.f16 && fits && row_stride % 2 == 0 && reinterpret_cast<uintptr_t>(d_logits) % 4 == 0 && vocab_with_blank >= 2;   // every row starts on a 4-byte boundary
+    // fp16 rows that all start on a 4-byte boundary are read as pairs (tdt_logits_fits_kernel)
+    const bool pairs = g.f16 && fits && (row_stride * 2) % 4 == 0 && reinterpret_cast<uintptr_t>(d_logits) % 4 == 0;
+    const dim3 grid(batch), block(64);
     if (g.f16) {
-        if (fits && pairs) hipLaunchKernelGGL((tdt_logits_fits_kernel<true, true>), dim3(batch), dim3(64), 0, ctx->stream, a, g);
-        else if (fits) hipLaunchKernelGGL((tdt_logits_fits_kernel<true, false>), dim3(batch), dim3(64), 0, ctx->stream, a, g);
-        else hipLaunchKernelGGL(tdt_logits_kernel<true>, dim3(batch), dim3(64), 0, ctx->stream, a, g);
+        if (!fits) hipLaunchKernelGGL(tdt_logits_kernel<true>, grid, block, 0, ctx->stream, a, g);
+        else if (pairs) hipLaunchKernelGGL((tdt_logits_fits_kernel<true, 2>), grid, block, 0, ctx->stream, a, g);
+        else hipLaunchKernelGGL((tdt_logits_fits_kernel<true, 1>), grid, block, 0, ctx->stream, a, g);
+    } else {
+        if (!fits) hipLaunchKernelGGL(tdt_logits_kernel<false>, grid, block, 0, ctx->stream, a, g);
+        else hipLaunchKernelGGL((tdt_logits_fits_kernel<false, 1>), grid, block, 0, ctx->stream, a, g);
     }
-    else { if (fits) hipLaunchKernelGGL((tdt_logits_fits_kernel<false, false>), dim3(batch), dim3(64), 0, ctx->stream, a, g); else hipLaunchKernelGGL(tdt_logits_kernel<false>, dim3(batch), dim3(64), 0, ctx->stream, a, g); }
     FA_HIP_TRY(ctx, hipGetLastError());
     return FA_SUCCESS;
 }

@@ -39,7 +39,8 @@ def test_drop_in_symbol_status_contract(fa, gpu_ctx):
 
 
 @pytest.mark.parametrize("n,d,kind", [(2, 4, "iid"), (3, 1, "iid"), (257, 7, "iid"), (1000, 256, "iid"), (1500, 64, "mix"),
-                                      (2000, 256, "mix"), (777, 300, "iid"), (600, 16, "iid"), (900, 48, "mix")])   # d % 16 == 0: the direct-to-LDS Gram kernel (one and three k-chunks)
+                                      (2000, 256, "mix"), (777, 300, "iid"), (600, 16, "iid"), (900, 48, "mix"),
+                                      (400, 257, "iid"), (300, 255, "iid"), (520, 129, "mix")])   # odd d: centroid rows on 8-byte boundaries, a last element without a partner (round 6)   # d % 16 == 0: the direct-to-LDS Gram kernel (one and three k-chunks)
 def test_bit_exact_vs_reference_build(fa, gpu_ctx, oracle_mod, n, d, kind):
     if kind == "iid":
         x = oracle_mod.ahc_normalize(np.random.default_rng(n).standard_normal((n, d)))
