@@ -41,10 +41,13 @@ template <int CPT> __device__ __forceinline__ void store_f64(double *p, const do
 // pair_entry for the thread's CPT columns against row slot r (node nr); columns that are dead or equal skip0 / skip1 get 0.  The ROW copies of the
 // CPT columns are one contiguous piece of row r and are requested together whenever any column wants an entry (the bytes share cache lines with
 // the wanted ones); a column whose valid copy is the column copy M[x][r] is requested on top — the rare case (see pair_entry).
-template <int CPT>
+// BRANCH (one slot per thread, single chain): the request sits behind its condition — a column that wants nothing requests nothing.  Measured both ways in
+// round 6 (profiles/r06_round_uncond.txt): the single chain of 43 200 points 4.95 us per round this way against 5.05 without the branch, the launches
+// over several problems the other way round (K = 8 x 8 h: 159 against 162 - 164 audio-hours/s).
+template <int CPT, bool BRANCH = false>
 __device__ __forceinline__ void pair_entries(const double *M, const int Np, const int r, const int nr, const int x0, const int (&nx)[CPT], const int sym_limit,
                                              const int skip0, const int skip1, double (&out)[CPT]) {
-    if constexpr (CPT == 1) {
+    if constexpr (CPT == 1 && BRANCH) {
         out[0] = (nx[0] != kDead && x0 != skip0 && x0 != skip1) ? pair_entry(M, Np, r, nr, x0, nx[0], sym_limit) : 0.0;
     } else {
         // No branch per column: every column requests ONE entry from an address that is always valid — its column copy where that is the valid one,
@@ -285,6 +288,12 @@ template <bool N_IN_STATE = false, bool BIG = true, int CPT = 1, int KC = 4 / CP
 __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, const int ph /* round index & 3 */, const size_t late_shift = 0) {
     static_assert(CPT == 1 || kPiggy == 0, "piggy-backed re-scans were only ever built for one slot per thread");
     constexpr int kCols = kBlk * CPT;
+    // Requests of the round's second memory round trip: behind their conditions (single chain) or unconditional with dropped values (launches over several
+    // problems).  A conditional request costs the compiler its count of the in-order memory counter — behind the join it no longer knows how many requests are
+    // younger than an older one and waits for all of them — so the unconditional form lets the centroid arithmetic run under the latency of the two cold matrix
+    // entries; it also requests for dead columns and for rounds that merge nothing.  Measured (profiles/r06_round_uncond.txt): K = 8 x 8 h 159 -> 162 - 164
+    // audio-hours/s unconditional, the single chain of 43 200 points 4.95 -> 5.05 us per round: each form where it wins.
+    constexpr bool kUncond = N_IN_STATE, kEntryBranch = !N_IN_STATE;
     Ws w = w_in;
     extern __shared__ double s_cvec[];  // [d] merged centroid (EXACT rows)
     __shared__ WaveOut s_out[1];
@@ -534,13 +543,17 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
 #pragma unroll
         for (int r = 0; r < kCk / 2; ++r) {
             const int k = 2 * lane + 128 * r;
-            const double2 q = k + 1 < d ? *reinterpret_cast<const double2 *>(c + k) : make_double2(0.0, 0.0);
-            x[2 * r] = q.x; x[2 * r + 1] = q.y;
+            const bool in = k + 1 < d;
+            double2 q;
+            if constexpr (kUncond) q = *reinterpret_cast<const double2 *>(c + (in ? k : 0));
+            else q = in ? *reinterpret_cast<const double2 *>(c + k) : make_double2(0.0, 0.0);
+            x[2 * r] = in ? q.x : 0.0; x[2 * r + 1] = in ? q.y : 0.0;
         }
     };
     const bool spec = FA_AHC_SPECULATE && R1 >= 0 && Q1 >= 0;
     const bool spec_lo = R1 < Q1;
-    const int sp_a = spec_lo ? R1 : Q1, sp_b = spec_lo ? Q1 : R1, sp_na = spec_lo ? NR1 : NQ1, sp_nb = spec_lo ? NQ1 : NR1;
+    // without a pair to speculate on (a re-scan round) the unconditional form requests slot / node 0 and drops the values
+    const int sp_a = !spec ? 0 : (spec_lo ? R1 : Q1), sp_b = !spec ? 0 : (spec_lo ? Q1 : R1), sp_na = !spec ? 0 : (spec_lo ? NR1 : NQ1), sp_nb = !spec ? 0 : (spec_lo ? NQ1 : NR1);
     double sp_ma = 0.0, sp_mb = 0.0, sp_da[CPT], sp_db[CPT], sp_xa[kCk], sp_xb[kCk];
 #pragma unroll
     for (int j = 0; j < kCk; ++j) { sp_xa[j] = 0.0; sp_xb[j] = 0.0; }
@@ -549,17 +562,19 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
     // (the youngest load of the round's first batch is consumed here: the load counter completes in order, so everything older has arrived and
     // nothing in the decision below has to wait on the counter — a wait there would also wait for the requests that follow)
     asm volatile("" :: "v"(nanflag), "v"(e2x[CPT - 1]), "v"(rs[CPT - 1].d1), "v"(nx[CPT - 1]));
-    if (spec) {
+    if (kUncond || spec)
+    {
         // sizes and centroids first, the two matrix entries (a cold row each) last: loads complete in order, the centroid arithmetic runs under the entries'
         // latency.  (Entries first measured in round 6: 5.12 against 5.07 us.  Requesting the entries from every thread, round 4: dead columns then read cold
-        // column copies nobody needs — 5.8 instead of 5.3 us per round at 43 200 points.)
+        // column copies nobody needs — 5.8 instead of 5.3 us per round at 43 200 points; here a column that wants nothing reads its ROW copy, next to its
+        // neighbours' entries.)
         sp_ma = w.sizes[sp_na]; sp_mb = w.sizes[sp_nb];
         const double *ca = w.C + static_cast<size_t>(sp_na) * d, *cb = w.C + static_cast<size_t>(sp_nb) * d;
         cload(ca, sp_xa); cload(cb, sp_xb);
         __builtin_amdgcn_sched_barrier(0);
-        if (st.mode == FA_AHC_MODE_AUTO) {
-            pair_entries<CPT>(w.M, Np, sp_a, sp_na, x0, nx, st.sym_limit, sp_a, sp_b, sp_da);
-            pair_entries<CPT>(w.M, Np, sp_b, sp_nb, x0, nx, st.sym_limit, sp_a, sp_b, sp_db);
+        if (kUncond || st.mode == FA_AHC_MODE_AUTO) {
+            pair_entries<CPT, kEntryBranch>(w.M, Np, sp_a, sp_na, x0, nx, st.sym_limit, sp_a, sp_b, sp_da);
+            pair_entries<CPT, kEntryBranch>(w.M, Np, sp_b, sp_nb, x0, nx, st.sym_limit, sp_a, sp_b, sp_db);
         }
     }
     const double glim = g1 + 2.0 * st.eps;
@@ -679,6 +694,15 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
 #pragma unroll
     for (int k = 0; k < kPend; ++k) { pkey[k] = dinf(); pslot[k] = x0; pnd[k] = nx[0]; }
 
+    if (D.op != OP_MERGE) {
+        // a round that does something else drops the speculative operands: consumed here, or their requests stay "pending" for the compiler on this path and
+        // the join in front of the block record waits for the whole in-order counter — on the MERGE path that is a wait for the round's STORES (round 6)
+        asm volatile("" :: "v"(sp_ma), "v"(sp_mb));
+#pragma unroll
+        for (int j = 0; j < kCk; ++j) asm volatile("" :: "v"(sp_xa[j]), "v"(sp_xb[j]));
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) asm volatile("" :: "v"(sp_da[j]), "v"(sp_db[j]));
+    }
     if (D.op == OP_MERGE) {
         const int a = D.a, b = D.b, na = D.na, nb = D.nb, nnew = N + st.step;
         const bool sp_hit = spec && a == sp_a && b == sp_b && na == sp_na && nb == sp_nb;   // uniform; false only for the pair an exact window picked
@@ -694,9 +718,14 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
 #pragma unroll
             for (int j = 0; j < CPT; ++j) { da[j] = 0.0; db[j] = 0.0; }
             if (st.mode == FA_AHC_MODE_AUTO) {  // valid copy of a pair lives in the row of the younger node
-                pair_entries<CPT>(w.M, Np, a, na, x0, nx, st.sym_limit, a, b, da);
-                pair_entries<CPT>(w.M, Np, b, nb, x0, nx, st.sym_limit, a, b, db);
+                pair_entries<CPT, kEntryBranch>(w.M, Np, a, na, x0, nx, st.sym_limit, a, b, da);
+                pair_entries<CPT, kEntryBranch>(w.M, Np, b, nb, x0, nx, st.sym_limit, a, b, db);
             }
+            // consumed INSIDE the (rare) branch: loads still pending at the join make the compiler wait for the whole in-order counter at the first use
+            // behind it — on the common path that was a wait for the two cold matrix entries in front of the centroid arithmetic (round 6, from the listing)
+            asm volatile("" :: "v"(ma), "v"(mb));
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) asm volatile("" :: "v"(da[j]), "v"(db[j]));
         }
         const double den = ma + mb;
         if constexpr (kPend > 1) {
@@ -716,6 +745,8 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
         for (int j = 0; j < kCk; ++j) { xa[j] = sp_xa[j]; xb[j] = sp_xb[j]; }
         if (!sp_hit) {
             cload(ca, xa); cload(cb, xb);
+#pragma unroll
+            for (int j = 0; j < kCk; ++j) asm volatile("" :: "v"(xa[j]), "v"(xb[j]));   // (as above)
         }
         AHC_STAMP(9);
         const bool keeps_centroid = wave == 0 && (st.mode == FA_AHC_MODE_EXACT || blk == 0);
@@ -870,7 +901,7 @@ __device__ __forceinline__ void ahc_round_body(const Ws w_in, const int blk, con
             const int S = prow[k];
             if (S < 0) continue;
             double ent[CPT];
-            pair_entries<CPT>(w.M, Np, S, pnode_[k], x0, nx, st.sym_limit, S, -1, ent);
+            pair_entries<CPT, kEntryBranch>(w.M, Np, S, pnode_[k], x0, nx, st.sym_limit, S, -1, ent);
 #pragma unroll
             for (int j = 0; j < CPT; ++j) {
                 if (nx[j] != kDead && x0 + j != S && (CPT == 1 || ent[j] < pkey[k])) { pkey[k] = ent[j]; pslot[k] = x0 + j; pnd[k] = nx[j]; }
