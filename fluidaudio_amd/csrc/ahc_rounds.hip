@@ -336,7 +336,11 @@ fa_status fa::ahc_run_device(fa_ctx *ctx, const double *d_data, size_t N, size_t
         }
         // halted before the first merge (duplicates: the very first window ties), one slot per thread, Gram-form start-up: the matrix in the workspace is the one the
         // reference-order run would build first (ahc_rom.hip shares the arrays)
+#ifdef FA_POISON_WORKSPACE
+        const bool matrix_ready = false;   // the poisoned build fills the workspace again when the reference-order run acquires it: nothing of the attempt survives
+#else
         const bool matrix_ready = mode == FA_AHC_MODE_AUTO && p.h.step == 0 && p.cpt == 1 && d % 16 == 0;
+#endif
         return ro_run_device(ctx, d_data, N, d, d_Z, stats, z_on_host, /* may_hand_over = */ mode == FA_AHC_MODE_AUTO, matrix_ready);
     }
 #ifdef FA_AHC_PROFILE
