@@ -228,7 +228,7 @@ fa_status vbx_run_dev(fa_ctx *ctx, const double *d_X, int64_t T, int32_t D, cons
 fa_status vbx_degrade_dev(fa_ctx *ctx, int64_t T, int32_t S, const int32_t *d_labels, VbxDevice &out);                             // vbx.hip
 
 fa_status centroids_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_gamma, int32_t S, const int32_t *d_spk, int32_t K,
-                        double *d_cent);                                                                                             // post.hip
+                        double *d_cent, bool rows_finite = false);                                                                                             // post.hip
 fa_status scores_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_cent, int32_t K, double *d_cn, double *d_scores);
 fa_status assign_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_cent, int32_t K, double *d_cn, int32_t *d_out);
 fa_status constrained_assign_dev(fa_ctx *ctx, const double *d_scores, int64_t n, int32_t K, const int32_t *chunk_indices_host, int32_t *d_out);

@@ -68,6 +68,7 @@ struct ClusterJob {
     const float *d_emb32 = nullptr;
     const double *d_rho_all = nullptr, *d_temb = nullptr, *d_trho = nullptr;
     int64_t nt = 0;
+    bool rows_finite = false;   // every training row is free of NaN / Inf (the centroid sums may then add a zero-weight row instead of skipping it: same bits)
     double t_begin = 0, t_inputs = 0, t_ahc = 0;
     fa_ahc_stats ahc_stats{};
 
@@ -106,6 +107,7 @@ struct ClusterJob {
         FA_HIP_TRY(ctx, hipStreamSynchronize(st));
         std::vector<int32_t> train;
         for (int64_t i = 0; i < n; ++i) if (ok[i]) train.push_back(static_cast<int32_t>(i));
+        rows_finite = !train.empty();   // the training rows are the finite ones — unless none is, and all rows train (:606-609)
         const bool all_rows = train.empty() || static_cast<int64_t>(train.size()) == n;
         if (train.empty()) { train.resize(n); for (int64_t i = 0; i < n; ++i) train[i] = static_cast<int32_t>(i); }
         nt = static_cast<int64_t>(train.size());
@@ -229,7 +231,7 @@ struct ClusterJob {
             if (K > 0) {
                 if (b_cent.alloc(ctx, sizeof(double) * K * d) != hipSuccess || b_spk.alloc(ctx, sizeof(int32_t) * K) != hipSuccess) { (void)hipGetLastError(); return fa::set_error(ctx, FA_ALLOCATION_FAILURE, "offline cluster: allocation failed"); }
                 FA_HIP_TRY(ctx, hipMemcpyAsync(b_spk.p, spk.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice, st));
-                FA_TRY(fa::centroids_dev(ctx, d_temb, nt, d, vbx.gamma.as<double>(), S, b_spk.as<int32_t>(), K, b_cent.as<double>()));
+                FA_TRY(fa::centroids_dev(ctx, d_temb, nt, d, vbx.gamma.as<double>(), S, b_spk.as<int32_t>(), K, b_cent.as<double>(), rows_finite));
                 FA_HIP_TRY(ctx, hipStreamSynchronize(st));   // spk is a host temporary
             }
         }

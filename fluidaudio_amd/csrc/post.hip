@@ -56,10 +56,20 @@ __global__ void centroid_kernel(const double *__restrict__ emb, const double *__
 // 128 rows (32 requests in flight per thread, coalesced 512-byte rows) into a double-buffered LDS tile while wavefront 0 walks
 // the previous tile in row order.  Same operations in the same order: identical bits.
 constexpr int kCenTile = 128;
+// Round 6 (second half): the kernel was 1.44 ms at the 8 h session and, with one workgroup per CU (133 KB of LDS), 11 of the 17 ms that eight recordings spend
+// behind their merge chains in one fa_offline_cluster_batch call.  The chain of one (speaker, dimension) was 9 vector instructions per row: two additions, a
+// multiplication, a compare and four selects for the reference's `weight <= 0 -> skip` (:655).  Now:
+//   * a row of weight +0 needs no select when its embedding is finite: num + 0 * e == num and den + 0 == den bit for bit (the sums start at +0; -0 + +0 = +0).
+//     `rows_finite` (the caller knows: the training rows of the clustering stage are the finite ones) turns the selects off; the fetching wavefronts vote on
+//     their weights, and a tile that holds a negative or NaN weight walks the select form — the same bits either way on valid input;
+//   * the denominator is the same sum for all 64 dimensions: wavefront 1 walks it while wavefront 0 walks the numerators (one multiplication + one addition per
+//     row on the chain).
 __global__ __launch_bounds__(256) void centroid_tiled_kernel(const double *__restrict__ emb, const double *__restrict__ gamma, const int32_t *__restrict__ spk,
-                                                             double *__restrict__ cent, int64_t n, int d, int S, int K) {
-    extern __shared__ double cen_lds[];                      // [2][kCenTile][64] values, then [2][kCenTile] weights
+                                                             double *__restrict__ cent, int64_t n, int d, int S, int K, const int rows_finite) {
+    extern __shared__ double cen_lds[];                      // [2][kCenTile][64] values, then [2][kCenTile] weights, then the denominator and [2] tile flags
     double *wbuf = cen_lds + 2 * kCenTile * 64;
+    double *s_den = wbuf + 2 * kCenTile;
+    int *s_flag = reinterpret_cast<int *>(s_den + 1);        // [2]: the tile in this buffer holds a weight that is negative or NaN
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + lane, c = blockIdx.y;
     const int s = spk[c];
@@ -79,33 +89,56 @@ __global__ __launch_bounds__(256) void centroid_tiled_kernel(const double *__res
 #pragma unroll
         for (int j = 0; j < kPer; ++j) cen_lds[(static_cast<size_t>(buf) * kCenTile + wave * kPer + j) * 64 + lane] = ev[j];
         if (lane < kPer) wbuf[buf * kCenTile + wave * kPer + lane] = wv;
+        if (__builtin_amdgcn_ballot_w64(!(wv >= 0.0)) != 0 && lane == 0) atomicOr(&s_flag[buf], 1);
     };
+    if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
+    __syncthreads();
     double num = 0.0, den = 0.0;
     fetch(0);
     put(0);
     __syncthreads();
     int buf = 0;
     for (int64_t t0 = 0; t0 < n; t0 += kCenTile, buf ^= 1) {
-        if (t0 + kCenTile < n) fetch(t0 + kCenTile);         // in flight while wavefront 0 adds
+        if (t0 + kCenTile < n) fetch(t0 + kCenTile);         // in flight while wavefronts 0 / 1 add
+        const bool plain = rows_finite != 0 && s_flag[buf] == 0;
         if (wave == 0) {
             const double *tile = cen_lds + static_cast<size_t>(buf) * kCenTile * 64 + lane;
             const double *wt = wbuf + buf * kCenTile;
-            for (int r0 = 0; r0 < kCenTile; r0 += 16) {   // 32 LDS reads requested together, then 16 branch-free steps of the chain: a skipped
-                double ww[16], ee[16];                    // row (weight <= 0, :655) keeps the old sums through a select — no 0 * e is ever added
+            for (int r0 = 0; r0 < kCenTile; r0 += 16) {   // 32 LDS reads requested together, then 16 branch-free steps of the chain
+                double ww[16], ee[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { ww[j] = wt[r0 + j]; ee[j] = tile[(r0 + j) * 64]; }
+                if (plain) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const bool on = ww[j] > 0;
-                    const double d2 = __dadd_rn(den, ww[j]), n2 = __dadd_rn(num, __dmul_rn(ww[j], ee[j]));
-                    den = on ? d2 : den;
-                    num = on ? n2 : num;
+                    for (int j = 0; j < 16; ++j) num = __dadd_rn(num, __dmul_rn(ww[j], ee[j]));
+                } else {                                   // a skipped row (weight <= 0, :655) keeps the old sum through a select — no 0 * e is ever added
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { const double n2 = __dadd_rn(num, __dmul_rn(ww[j], ee[j])); num = ww[j] > 0 ? n2 : num; }
+                }
+            }
+        } else if (wave == 1) {
+            const double *wt = wbuf + buf * kCenTile;
+            for (int r0 = 0; r0 < kCenTile; r0 += 16) {
+                double ww[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ww[j] = wt[r0 + j];
+                if (plain) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) den = __dadd_rn(den, ww[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { const double d2 = __dadd_rn(den, ww[j]); den = ww[j] > 0 ? d2 : den; }
                 }
             }
         }
-        if (t0 + kCenTile < n) put(buf ^ 1);                 // the other buffer: its last readers finished before the previous barrier
+        __syncthreads();                                     // the tile and its flag have been read
+        if (threadIdx.x == 0) s_flag[buf] = 0;               // (the buffer is filled again two tiles on: behind the next barrier)
+        if (t0 + kCenTile < n) put(buf ^ 1);                 // the other buffer: its last readers finished before the barrier above
         __syncthreads();
     }
+    if (threadIdx.x == 64) s_den[0] = den;
+    __syncthreads();
+    den = s_den[0];
     if (wave == 0 && kin) cent[static_cast<int64_t>(c) * d + k] = den > 0 ? __ddiv_rn(num, den) : 0.0;
 }
 
@@ -401,12 +434,12 @@ fa_status fa_constrained_assign(fa_ctx *ctx, const double *scores, int64_t n, in
 
 // ---- device-level cores (fa_common.h): inputs and outputs are device pointers, work is enqueued on ctx->stream
 fa_status fa::centroids_dev(fa_ctx *ctx, const double *d_emb, int64_t n, int32_t d, const double *d_gamma, int32_t S, const int32_t *d_spk, int32_t K,
-                            double *d_cent) {
+                            double *d_cent, const bool rows_finite) {
     if (K <= 0) return FA_SUCCESS;
     if (n >= 4 * kCenTile && !fa::sw_on(fa::Sw::CENTROID_SIMPLE)) {
-        const size_t lds = sizeof(double) * (2 * kCenTile * 64 + 2 * kCenTile);
+        const size_t lds = sizeof(double) * (2 * kCenTile * 64 + 2 * kCenTile + 2);   // + the denominator and the two tile flags
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(centroid_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        hipLaunchKernelGGL(centroid_tiled_kernel, dim3((d + 63) / 64, K), dim3(256), lds, ctx->stream, d_emb, d_gamma, d_spk, d_cent, n, d, S, K);
+        hipLaunchKernelGGL(centroid_tiled_kernel, dim3((d + 63) / 64, K), dim3(256), lds, ctx->stream, d_emb, d_gamma, d_spk, d_cent, n, d, S, K, rows_finite ? 1 : 0);
     } else
         hipLaunchKernelGGL(centroid_kernel, dim3((d + 63) / 64, K), dim3(64), 0, ctx->stream, d_emb, d_gamma, d_spk, d_cent, n, d, S, K);
     FA_HIP_TRY(ctx, hipGetLastError());

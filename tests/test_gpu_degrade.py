@@ -29,6 +29,15 @@ def test_vbx_failure_degrades_to_the_initial_clusters(fa, gpu_ctx, oracle_mod):
     assert np.array_equal(one.info["vbx_hard"], ref["hard"]) and np.array_equal(one.initial_clusters, ref["initial"])
     assert np.asarray(one.assignments).tolist() == ref["assignments"].tolist()
     np.testing.assert_allclose(one.centroids, ref["centroids"], rtol=0, atol=1e-12)
+    # a longer recording: the one-hot posteriors (exact zeros in every row) through the tiled centroid sums, whose zero-weight rows are ADDED as +-0 instead of
+    # skipped when every training row is finite (round 6) — the reference's bits (it skips them)
+    emb2, rho2, chunks2, phi2, _ = synth_session(260, 4, 0)
+    fa.lib().fa_debug_inject_fault(fa._lib.FAULT_VBX, 1)
+    two = fa.cluster_embeddings(emb2, rho2, chunks2, phi2, ctx=gpu_ctx, intermediates=True)
+    ref2 = oracle_mod.cluster_embeddings(emb2, rho2, chunks2, phi2, vbx_fails=True)
+    assert two.info["vbx_degraded"] == 1 and len(emb2) >= 512
+    np.testing.assert_array_equal(two.centroids, ref2["centroids"])
+    assert np.asarray(two.assignments).tolist() == ref2["assignments"].tolist()
     # the next call is undisturbed
     again = fa.cluster_embeddings(emb, rho, chunks, phi, ctx=gpu_ctx)
     assert again.info["vbx_degraded"] == 0 and again.info["vbx_iterations"] > 0
