@@ -503,3 +503,18 @@ def test_slots_per_thread_forms_equal_reference_build(fa, gpu_ctx, oracle_mod, s
             np.testing.assert_array_equal(z, zr)
         if mode == fa.AHC_MODE_AUTO:
             assert stats[3]["reference_order"] == 1 and stats[0]["reference_order"] == 0
+
+
+@pytest.mark.parametrize("n", [65536, 65600])
+def test_register_path_boundary_equals_the_reference_build(fa, gpu_ctx, oracle_mod, n):
+    """65 536 points is the largest problem whose first reduction holds its block records in registers (four per lane) and reads them PACKED — slot, neighbour
+    slot + 1 and both node ids at the full width of their bit fields (round 6, rec_pack); 65 600 is the first size of the many-record kernel, which keeps
+    the unpacked arrays.  d = 2 keeps the reference build at ~12 s on one core; the dendrogram must be its, row for row."""
+    x = np.random.default_rng(n).standard_normal((n, 2))
+    sr, zr = oracle_mod.linkage_ref(x)
+    st, z, stats = fa.linkage(x, ctx=gpu_ctx, return_stats=True)
+    gpu_ctx.trim()                                            # 34 GB of matrix
+    assert st == sr == 0, gpu_ctx.last_error()
+    bad = np.nonzero((z != zr).any(axis=1))[0]
+    assert bad.size == 0, f"first differing row {bad[0]} of {n - 1}: device {z[bad[0]]} reference {zr[bad[0]]} ({stats})"
+    assert stats["merges"] == n - 1 and stats["reference_order"] == 0
