@@ -321,12 +321,18 @@ __device__ __forceinline__ MinAcc min_xor(const MinAcc a, const int mask) {
     return o;
 }
 
+#define FA_GRAM_GRID(T) dim3(static_cast<unsigned>((T) * ((T) + 1) / 2))   // tiles on and below the diagonal
 template <bool MINIMA>
 __global__ __launch_bounds__(256, 2) void ahc_gram_mfma2_t(Ws w, const double *__restrict__ norms, double2 *__restrict__ part_vs, int *__restrict__ part_ix) {
     extern __shared__ __attribute__((aligned(16))) double sg[];
-    if (blockIdx.x > blockIdx.y) return;   // symmetric: tiles on and below the diagonal, off-diagonal tiles are written twice
+    // symmetric: one workgroup per tile on or below the diagonal, off-diagonal tiles are written twice.  (Until round 6 a square grid whose upper half returned
+    // at once: 57 000 workgroups of 73 KB LDS that each take a slot for a moment — 10.70 -> 10.56 ms at 43 200 points.)  Tile (by, bx), bx <= by, of the linear id:
+    int by = static_cast<int>((sqrtf(8.0f * static_cast<float>(blockIdx.x) + 1.0f) - 1.0f) * 0.5f);
+    while ((by + 1) * (by + 2) / 2 <= static_cast<int>(blockIdx.x)) ++by;      // (the float root is off by at most one)
+    while (by * (by + 1) / 2 > static_cast<int>(blockIdx.x)) --by;
+    const int bx = static_cast<int>(blockIdx.x) - by * (by + 1) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, lq = lane >> 4;   // wave: in an SGPR, so the row addresses below are scalar
-    const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+    const int i0 = by * GT, j0 = bx * GT;
     const bool mirror = i0 != j0;
     const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
     const int Np = w.Np, nchunk = w.d / G2K;
@@ -455,13 +461,13 @@ __global__ __launch_bounds__(256, 2) void ahc_gram_mfma2_t(Ws w, const double *_
         const size_t npz = static_cast<size_t>(Np);
         if (!wc) {
             min_merge(mine, reinterpret_cast<const MinAcc *>(sg + (wave + 1) * 64 * TS)[lane]);          // wave (wr, 64) = this wave + 1
-            const size_t at = blockIdx.x * npz + i0 + wr + lane;
+            const size_t at = bx * npz + i0 + wr + lane;
             part_vs[at] = make_double2(mine.v, mine.s);
             part_ix[at] = mine.i;
         }
         if (!wr && mirror) {
             min_merge(cmine, reinterpret_cast<const MinAcc *>(sg + (wave + 2) * 64 * TS)[64 + lane]);    // wave (64, wc) = this wave + 2
-            const size_t at = blockIdx.y * npz + j0 + wc + lane;
+            const size_t at = by * npz + j0 + wc + lane;
             part_vs[at] = make_double2(cmine.v, cmine.s);
             part_ix[at] = cmine.i;
         }
@@ -572,7 +578,7 @@ void startup_filter(hipStream_t st, const Ws &w, const Layout &L, char *base, in
         if (w.d % G2K == 0 && !fa::sw_on(fa::Sw::AHC_GRAM_V1) && gram2_attr<true>() == hipSuccess) {
             double2 *part_vs = reinterpret_cast<double2 *>(base + L.part_vs);
             int *part_ix = reinterpret_cast<int *>(base + L.part_ix);
-            hipLaunchKernelGGL(ahc_gram_mfma2_t<true>, dim3(w.Np / GT, w.Np / GT), dim3(256), kGram2LdsBytes, st, w, d_norms, part_vs, part_ix);
+            hipLaunchKernelGGL(ahc_gram_mfma2_t<true>, FA_GRAM_GRID(w.Np / GT), dim3(256), kGram2LdsBytes, st, w, d_norms, part_vs, part_ix);
             hipLaunchKernelGGL(ahc_row_minima_parts, dim3(w.Np / 64), dim3(256), 0, st, w, part_vs, part_ix);
             minima_done = true;
         } else
@@ -590,7 +596,7 @@ fa_status startup_gram(fa_ctx *ctx, hipStream_t st, const Ws &gw, double *d_norm
     hipLaunchKernelGGL(ahc_sqnorms, dim3((gw.Np + 63) / 64), dim3(256), 0, st, gw, d_norms);
     if (gw.d % G2K == 0) {
         FA_HIP_TRY(ctx, gram2_attr<false>());
-        hipLaunchKernelGGL(ahc_gram_mfma2_t<false>, dim3(gw.Np / GT, gw.Np / GT), dim3(256), kGram2LdsBytes, st, gw, d_norms, static_cast<double2 *>(nullptr), static_cast<int *>(nullptr));
+        hipLaunchKernelGGL(ahc_gram_mfma2_t<false>, FA_GRAM_GRID(gw.Np / GT), dim3(256), kGram2LdsBytes, st, gw, d_norms, static_cast<double2 *>(nullptr), static_cast<int *>(nullptr));
     } else
         hipLaunchKernelGGL(ahc_gram_mfma, dim3(gw.Np / GT, gw.Np / GT), dim3(256), 0, st, gw, d_norms);
     return FA_SUCCESS;
